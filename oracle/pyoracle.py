@@ -1,0 +1,432 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package (xmipp3_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+class CtfParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "Tm", "kV", "DeltafU", "DeltafV", "azimuthal_angle", "Cs", "Ca", "espr", "ispr", "alpha",
+        "DeltaF", "DeltaR", "Q0", "K", "envR0", "envR1", "envR2", "phase_shift", "VPP_radius")]
+
+
+class RfParams(C.Structure):
+    _fields_ = [("imgSize", C.c_int), ("padding_proj", C.c_double), ("padding_vol", C.c_double),
+                ("maxResolution", C.c_double), ("blob_radius", C.c_double), ("blob_order", C.c_int),
+                ("blob_alpha", C.c_double), ("useFast", C.c_int), ("useCTF", C.c_int),
+                ("isPhaseFlipped", C.c_int), ("minCTF", C.c_double), ("iTs", C.c_double),
+                ("paddedImgSize", C.c_int), ("maxVolumeIndexX", C.c_int),
+                ("maxVolumeIndexYZ", C.c_int), ("iDeltaSqrt", C.c_float),
+                ("iDeltaFourier", C.c_float)]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    vp = C.c_void_p
+    i, d = C.c_int, C.c_double
+    sig = {
+        "xo_fft1d_r2c": (None, [c_double_p, i, c_double_p]),
+        "xo_fft1d_c2r": (None, [c_double_p, i, c_double_p]),
+        "xo_fft2d_r2c": (None, [c_double_p, i, i, c_double_p]),
+        "xo_fft2d_c2r": (None, [c_double_p, i, i, c_double_p]),
+        "xo_fft3d_c2r": (None, [c_double_p, i, i, i, c_double_p]),
+        "xo_fft1d_c2c": (None, [c_double_p, i, i, c_double_p]),
+        "xo_fft_idx2digfreq": (d, [i, i]),
+        "xo_bspline3_prefilter2d": (None, [c_double_p, i, i, c_double_p]),
+        "xo_bspline3_interp2d": (d, [c_double_p, i, i, i, i, d, d]),
+        "xo_polar_nsam": (i, [i]),
+        "xo_polar_layout": (None, [i, i, c_int32_p, c_int32_p, c_int32_p]),
+        "xo_polar_from_cartesian_bspline": (None, [c_double_p, i, i, i, i, i, i, d, d, c_double_p]),
+        "xo_polar_avg_std": (None, [c_double_p, i, i, c_double_p, c_double_p]),
+        "xo_polar_fft_rings": (None, [c_double_p, i, i, i, c_double_p]),
+        "xo_rotational_correlation": (None, [c_double_p, c_double_p, i, i, c_double_p]),
+        "xo_euler_matrix": (None, [d, d, d, c_double_p]),
+        "xo_apply_geometry2d": (None, [i, c_double_p, i, i, c_double_p, i, i, c_double_p]),
+        "xo_rotate2d": (None, [i, c_double_p, i, i, d, i, c_double_p]),
+        "xo_translate2d": (None, [i, c_double_p, i, i, d, d, i, c_double_p]),
+        "xo_correlation_matrix": (None, [c_double_p, c_double_p, i, i, c_double_p]),
+        "xo_best_shift_mcorr": (d, [c_double_p, i, i, i, c_double_p, c_double_p]),
+        "xo_best_shift": (d, [c_double_p, c_double_p, i, i, i, c_double_p, c_double_p]),
+        "xo_correlation_index": (d, [c_double_p, c_double_p, C.c_size_t]),
+        "xo_pm_create": (vp, [i, i, i, i, c_double_p, c_double_p, i]),
+        "xo_pm_destroy": (None, [vp]),
+        "xo_pm_nsam_outer": (i, [vp]),
+        "xo_pm_ncoef": (i, [vp]),
+        "xo_pm_ref_coefs": (c_double_p, [vp, i]),
+        "xo_pm_ref_sigma": (d, [vp, i]),
+        "xo_pm_prepare_particle": (None, [vp, c_double_p, d, d, c_double_p, c_double_p, c_double_p]),
+        "xo_pm_match": (None, [vp, c_double_p, i, c_int32_p, c_int32_p, i, i, c_int32_p, c_int32_p,
+                               i, i, c_int32_p, c_int32_p, c_uint8_p, c_double_p]),
+        "xo_pm_corr_rows": (None, [vp, c_double_p, i, c_double_p]),
+        "xo_pm_translate": (None, [vp, c_double_p, i, c_int32_p, c_int32_p, c_uint8_p, d, i,
+                                   c_double_p, c_double_p, c_double_p]),
+        "xo_kaiser_value": (d, [d, d, d, i]),
+        "xo_kaiser_fourier_value": (d, [d, d, d, i]),
+        "xo_bessi0": (d, [d]),
+        "xo_bessi1": (d, [d]),
+        "xo_ctf_defaults": (None, [C.POINTER(CtfParams)]),
+        "xo_ctf_value_pure_nok": (d, [C.POINTER(CtfParams), d, d]),
+        "xo_ctf_lambda": (d, [C.POINTER(CtfParams)]),
+        "xo_rf_create": (vp, [C.POINTER(RfParams)]),
+        "xo_rf_destroy": (None, [vp]),
+        "xo_rf_blob_table_sqrt": (c_float_p, [vp]),
+        "xo_rf_fourier_blob_table": (c_double_p, [vp]),
+        "xo_rf_prepare_image": (None, [vp, c_double_p, c_float_p]),
+        "xo_rf_ctf_arrays": (None, [vp, C.POINTER(CtfParams), c_float_p, c_float_p]),
+        "xo_rf_insert": (None, [vp, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, C.c_float]),
+        "xo_rf_temp_volume": (c_float_p, [vp]),
+        "xo_rf_temp_weights": (c_float_p, [vp]),
+        "xo_rf_reset": (None, [vp]),
+        "xo_rf_mirror_and_crop": (None, [vp]),
+        "xo_rf_finish": (None, [vp, c_double_p]),
+        "xo_rf_hermitian_and_weights": (None, [vp]),
+        "xo_num_threads": (i, []),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(c_float_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int32_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---------------------------------------------------------------- FFT
+def fft2d_r2c(img):
+    img = f64(img)
+    y, x = img.shape
+    out = np.empty((y, x // 2 + 1, 2))
+    lib().xo_fft2d_r2c(_dp(img), y, x, _dp(out))
+    return out[..., 0] + 1j * out[..., 1]
+
+
+def fft2d_c2r(F, xdim):
+    y = F.shape[0]
+    buf = np.ascontiguousarray(np.stack([F.real, F.imag], -1), dtype=np.float64)
+    out = np.empty((y, xdim))
+    lib().xo_fft2d_c2r(_dp(buf), y, xdim, _dp(out))
+    return out
+
+
+def fft1d_r2c(v):
+    v = f64(v)
+    out = np.empty((len(v) // 2 + 1, 2))
+    lib().xo_fft1d_r2c(_dp(v), len(v), _dp(out))
+    return out[:, 0] + 1j * out[:, 1]
+
+
+def fft1d_c2r(F, n):
+    buf = np.ascontiguousarray(np.stack([F.real, F.imag], -1), dtype=np.float64)
+    out = np.empty(n)
+    lib().xo_fft1d_c2r(_dp(buf), n, _dp(out))
+    return out
+
+
+def fft1d_c2c(v, sign):
+    buf = np.ascontiguousarray(np.stack([np.real(v), np.imag(v)], -1), dtype=np.float64)
+    out = np.empty_like(buf)
+    lib().xo_fft1d_c2c(_dp(buf), len(v), sign, _dp(out))
+    return out[:, 0] + 1j * out[:, 1]
+
+
+# ---------------------------------------------------------------- B-spline / geometry
+def prefilter2d(img):
+    img = f64(img)
+    out = np.empty_like(img)
+    lib().xo_bspline3_prefilter2d(_dp(img), img.shape[0], img.shape[1], _dp(out))
+    return out
+
+
+def rotate2d(img, ang, degree=3, wrap=False):
+    img = f64(img)
+    out = np.empty_like(img)
+    lib().xo_rotate2d(degree, _dp(img), img.shape[0], img.shape[1], float(ang), int(wrap), _dp(out))
+    return out
+
+
+def translate2d(img, sx, sy, degree=1, wrap=True):
+    img = f64(img)
+    out = np.empty_like(img)
+    lib().xo_translate2d(degree, _dp(img), img.shape[0], img.shape[1], float(sx), float(sy),
+                         int(wrap), _dp(out))
+    return out
+
+
+def apply_geometry2d(img, A, degree, is_inv, wrap):
+    img = f64(img)
+    A = f64(A)
+    out = np.empty_like(img)
+    lib().xo_apply_geometry2d(degree, _dp(img), img.shape[0], img.shape[1], _dp(A), int(is_inv),
+                              int(wrap), _dp(out))
+    return out
+
+
+def correlation_matrix(a, b):
+    a, b = f64(a), f64(b)
+    out = np.empty_like(a)
+    lib().xo_correlation_matrix(_dp(a), _dp(b), a.shape[0], a.shape[1], _dp(out))
+    return out
+
+
+def best_shift(a, b, max_shift=-1):
+    a, b = f64(a), f64(b)
+    sx, sy = C.c_double(0), C.c_double(0)
+    m = lib().xo_best_shift(_dp(a), _dp(b), a.shape[0], a.shape[1], max_shift, C.byref(sx), C.byref(sy))
+    return sx.value, sy.value, m
+
+
+def correlation_index(a, b):
+    a, b = f64(a), f64(b)
+    return lib().xo_correlation_index(_dp(a), _dp(b), a.size)
+
+
+def euler_matrix(rot, tilt, psi):
+    A = np.empty((3, 3))
+    lib().xo_euler_matrix(rot, tilt, psi, _dp(A))
+    return A
+
+
+# ---------------------------------------------------------------- polar
+def polar_layout(Ri, Ro):
+    n = Ro - Ri + 1
+    nsam = np.zeros(n, np.int32)
+    ts, tc = C.c_int32(0), C.c_int32(0)
+    lib().xo_polar_layout(Ri, Ro, _ip(nsam), C.byref(ts), C.byref(tc))
+    return nsam, ts.value, tc.value
+
+
+def polar_from_cartesian(coef, Ri, Ro, starty, startx, xoff=0.0, yoff=0.0):
+    coef = f64(coef)
+    _, ts, _ = polar_layout(Ri, Ro)
+    out = np.empty(ts)
+    lib().xo_polar_from_cartesian_bspline(_dp(coef), coef.shape[0], coef.shape[1], starty, startx,
+                                          Ri, Ro, xoff, yoff, _dp(out))
+    return out
+
+
+def polar_avg_std(rings, Ri, Ro):
+    rings = f64(rings)
+    a, s = C.c_double(0), C.c_double(0)
+    lib().xo_polar_avg_std(_dp(rings), Ri, Ro, C.byref(a), C.byref(s))
+    return a.value, s.value
+
+
+def polar_fft_rings(rings, Ri, Ro, conj):
+    rings = f64(rings)
+    _, _, tc = polar_layout(Ri, Ro)
+    out = np.empty((tc, 2))
+    lib().xo_polar_fft_rings(_dp(rings), Ri, Ro, int(conj), _dp(out))
+    return out[:, 0] + 1j * out[:, 1]
+
+
+def rotational_correlation(F1, F2, Ri, Ro):
+    b1 = np.ascontiguousarray(np.stack([F1.real, F1.imag], -1), dtype=np.float64)
+    b2 = np.ascontiguousarray(np.stack([F2.real, F2.imag], -1), dtype=np.float64)
+    N = lib().xo_polar_nsam(Ro)
+    out = np.empty(N)
+    lib().xo_rotational_correlation(_dp(b1), _dp(b2), Ri, Ro, _dp(out))
+    return out
+
+
+# ---------------------------------------------------------------- projection matching
+class PM:
+    def __init__(self, refs, Ri=1, Ro=-1, Mctf=None, paddim=0):
+        refs = f64(refs)
+        self.nrefs, self.D, _ = refs.shape
+        self.Ri = max(1, Ri)
+        self.Ro = Ro if Ro >= 0 else self.D // 2 - 1
+        m = None if Mctf is None else _dp(f64(Mctf))
+        self._keep = (refs, Mctf)
+        self.h = lib().xo_pm_create(self.D, Ri, Ro, self.nrefs, _dp(refs), m, paddim)
+        self.N = lib().xo_pm_nsam_outer(self.h)
+        self.ncoef = lib().xo_pm_ncoef(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().xo_pm_destroy(self.h)
+            self.h = None
+
+    def ref_coefs(self, r):
+        p = lib().xo_pm_ref_coefs(self.h, r)
+        a = np.ctypeslib.as_array(p, shape=(self.ncoef, 2)).copy()
+        return a[:, 0] + 1j * a[:, 1]
+
+    def ref_sigma(self, r):
+        return lib().xo_pm_ref_sigma(self.h, r)
+
+    def prepare_particle(self, img, xoff=0.0, yoff=0.0):
+        img = f64(img)
+        fP = np.empty((self.ncoef, 2))
+        fPm = np.empty((self.ncoef, 2))
+        s = C.c_double(0)
+        lib().xo_pm_prepare_particle(self.h, _dp(img), xoff, yoff, _dp(fP), _dp(fPm), C.byref(s))
+        return fP[:, 0] + 1j * fP[:, 1], fPm[:, 0] + 1j * fPm[:, 1], s.value
+
+    def corr_rows(self, img, ref):
+        img = f64(img)
+        out = np.empty(2 * self.N)
+        lib().xo_pm_corr_rows(self.h, _dp(img), ref, _dp(out))
+        return out
+
+    def match(self, particles, nbr_off=None, nbr_ids=None, parity=0, n_orient=1, xoff5d=None,
+              yoff5d=None, nthreads=0):
+        particles = f64(particles)
+        n = particles.shape[0]
+        refno = np.empty((n, n_orient), np.int32)
+        psi = np.empty((n, n_orient), np.int32)
+        flip = np.empty((n, n_orient), np.uint8)
+        cc = np.empty((n, n_orient))
+        if nbr_off is not None:
+            nbr_off = np.ascontiguousarray(nbr_off, np.int32)
+            nbr_ids = np.ascontiguousarray(nbr_ids, np.int32)
+        nt = 0
+        if xoff5d is not None:
+            xoff5d = np.ascontiguousarray(xoff5d, np.int32)
+            yoff5d = np.ascontiguousarray(yoff5d, np.int32)
+            nt = len(xoff5d)
+        lib().xo_pm_match(self.h, _dp(particles), n, _ip(nbr_off), _ip(nbr_ids), parity, n_orient,
+                          _ip(xoff5d), _ip(yoff5d), nt, nthreads, _ip(refno), _ip(psi),
+                          flip.ctypes.data_as(c_uint8_p), _dp(cc))
+        return refno, psi, flip, cc
+
+    def translate(self, particles, refno, psi_idx, flip, max_shift=-1.0, nthreads=0):
+        particles = f64(particles)
+        n = particles.shape[0]
+        refno = np.ascontiguousarray(refno, np.int32).reshape(-1)
+        psi_idx = np.ascontiguousarray(psi_idx, np.int32).reshape(-1)
+        flip = np.ascontiguousarray(flip, np.uint8).reshape(-1)
+        sx, sy, cc = np.empty(n), np.empty(n), np.empty(n)
+        lib().xo_pm_translate(self.h, _dp(particles), n, _ip(refno), _ip(psi_idx),
+                              flip.ctypes.data_as(c_uint8_p), float(max_shift), nthreads, _dp(sx),
+                              _dp(sy), _dp(cc))
+        return sx, sy, cc
+
+
+# ---------------------------------------------------------------- reconstruction
+def ctf_params(**kw):
+    p = CtfParams()
+    lib().xo_ctf_defaults(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class RF:
+    def __init__(self, D, padding_proj=2.0, padding_vol=2.0, max_resolution=0.5, blob_radius=1.9,
+                 blob_order=0, blob_alpha=15.0, fast=False, use_ctf=False, phase_flipped=False,
+                 min_ctf=0.01, sampling=1.0):
+        p = RfParams()
+        p.imgSize = D
+        p.padding_proj, p.padding_vol = padding_proj, padding_vol
+        p.maxResolution = max_resolution
+        p.blob_radius, p.blob_order, p.blob_alpha = blob_radius, blob_order, blob_alpha
+        p.useFast, p.useCTF, p.isPhaseFlipped = int(fast), int(use_ctf), int(phase_flipped)
+        p.minCTF, p.iTs = min_ctf, 1.0 / sampling
+        self.p = p
+        self.h = lib().xo_rf_create(C.byref(p))
+        self.D = D
+        self.P = p.paddedImgSize
+        self.mv = p.maxVolumeIndexYZ
+        self.cropped = False
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().xo_rf_destroy(self.h)
+            self.h = None
+
+    @property
+    def blob_table(self):
+        return np.ctypeslib.as_array(lib().xo_rf_blob_table_sqrt(self.h), shape=(10000,)).copy()
+
+    @property
+    def fourier_blob_table(self):
+        return np.ctypeslib.as_array(lib().xo_rf_fourier_blob_table(self.h), shape=(10000,)).copy()
+
+    def prepare_image(self, img):
+        img = f64(img)
+        out = np.empty((self.mv, self.mv // 2, 2), np.float32)
+        lib().xo_rf_prepare_image(self.h, _dp(img), _fp(out))
+        return out
+
+    def ctf_arrays(self, ctf):
+        c = np.empty((self.mv, self.mv // 2), np.float32)
+        m = np.empty((self.mv, self.mv // 2), np.float32)
+        lib().xo_rf_ctf_arrays(self.h, C.byref(ctf), _fp(c), _fp(m))
+        return c, m
+
+    def insert(self, fft, euler_T, R=None, weight=1.0, ctf=None, modulator=None):
+        fft = np.ascontiguousarray(fft, np.float32)
+        A = f64(euler_T)
+        R = f64(np.eye(3) if R is None else R)
+        if ctf is not None:
+            ctf = np.ascontiguousarray(ctf, np.float32)
+            modulator = np.ascontiguousarray(modulator, np.float32)
+        lib().xo_rf_insert(self.h, _fp(fft), _fp(ctf), _fp(modulator), _dp(A), _dp(R), weight)
+
+    def temp(self):
+        mv = self.mv
+        nx = (mv // 2 + 1) if self.cropped else (mv + 1)
+        v = np.ctypeslib.as_array(lib().xo_rf_temp_volume(self.h), shape=(mv + 1, mv + 1, nx, 2)).copy()
+        w = np.ctypeslib.as_array(lib().xo_rf_temp_weights(self.h), shape=(mv + 1, mv + 1, nx)).copy()
+        return v, w
+
+    def set_temp(self, v, w):
+        mv = self.mv
+        nx = (mv // 2 + 1) if self.cropped else (mv + 1)
+        dv = np.ctypeslib.as_array(lib().xo_rf_temp_volume(self.h), shape=(mv + 1, mv + 1, nx, 2))
+        dw = np.ctypeslib.as_array(lib().xo_rf_temp_weights(self.h), shape=(mv + 1, mv + 1, nx))
+        dv[...] = v
+        dw[...] = w
+
+    def reset(self):
+        lib().xo_rf_reset(self.h)
+        self.cropped = False
+
+    def mirror_and_crop(self):
+        lib().xo_rf_mirror_and_crop(self.h)
+        self.cropped = True
+
+    def finish(self):
+        out = np.empty((self.D, self.D, self.D))
+        lib().xo_rf_finish(self.h, _dp(out))
+        return out

@@ -1,0 +1,120 @@
+"""Pin the CPU oracle against the reference's own known-answer unit tests.
+
+Every expected value below is re-typed from the reference's gtest sources
+(/root/reference/src/xmipp/applications/tests/function_tests/...), cited per test.
+"""
+import numpy as np
+import pytest
+
+M3 = np.array([[1., 2., 3.], [3., 2., 1.], [4., 4., 5.]])  # fixture used by all four suites
+
+
+def test_fft_forward_values_and_normalisation(oracle):
+    # test_fftw_main.cpp:35-51  (FourierTransformer: forward divided by N)
+    F = oracle.fft2d_r2c(M3)
+    exp = np.array([[2.77778 + 0j, -0.0555556 + 0.096225j],
+                    [-0.388889 + 0.673575j, -0.388889 - 0.096225j],
+                    [-0.388889 - 0.673575j, -0.0555556 + 0.288675j]])
+    assert np.allclose(F, exp, atol=1e-5)
+    assert np.allclose(F, np.fft.rfft2(M3) / 9, atol=1e-14)
+    # inverse is un-normalised: round trip restores the input
+    assert np.allclose(oracle.fft2d_c2r(F, 3), M3, atol=1e-13)
+
+
+def test_fft_idx2digfreq(oracle):
+    # test_fftw_main.cpp:80-109
+    f = oracle.lib().xo_fft_idx2digfreq
+    assert f(0, 128) == 0 and f(1, 128) == 1 / 128 and f(64, 128) == 0.5
+    assert f(65, 128) == -63 / 128 and f(127, 128) == -1 / 128
+    assert f(64, 129) == 64 / 129 and f(65, 129) == -64 / 129 and f(128, 129) == -1 / 129
+    assert f(255, 256) == -1 / 256
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 6, 12, 50, 97, 194, 197, 394, 398, 796, 1024, 1000])
+def test_fft_any_length_matches_numpy(oracle, n):
+    rng = np.random.default_rng(n)
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert np.allclose(oracle.fft1d_c2c(v, -1), np.fft.fft(v), atol=1e-10)
+    assert np.allclose(oracle.fft1d_c2c(v, +1), np.fft.ifft(v) * n, atol=1e-10)
+    r = rng.standard_normal(n)
+    assert np.allclose(oracle.fft1d_r2c(r), np.fft.rfft(r) / n, atol=1e-12)
+    if n > 1:
+        assert np.allclose(oracle.fft1d_c2r(np.fft.rfft(r), n), r * n, atol=1e-9)
+
+
+def test_polar_average_and_stddev_pin(oracle):
+    # test_polar_main.cpp:32-40: raw 3x3 (STARTING = 0), rings 0..1, tolerance 1e-6
+    rings = oracle.polar_from_cartesian(M3, 0, 1, 0, 0)
+    mean, std = oracle.polar_avg_std(rings, 0, 1)
+    assert abs(mean - 1.886528450043468) < 1e-6
+    assert abs(std - 0.49643800057938808) < 1e-6
+
+
+def test_rotate_bspline3_pin(oracle):
+    # test_transformation_main.cpp:76-95 (MultidimArray == compares within 1e-6)
+    out = oracle.rotate2d(M3, 10.0, degree=3, wrap=False)
+    exp = np.array([[0, 2.1950049, 0], [2.6541736, 2, 1.3803737], [0, 3.9039731, 0]])
+    assert np.allclose(out, exp, atol=1e-6)
+
+
+def test_translate_wrap_is_row_roll(oracle):
+    # test_transformation_main.cpp:97-113: translate by (0,1) with wrap moves row i to i+1
+    out = oracle.translate2d(M3, 0.0, 1.0, degree=3, wrap=True)
+    assert np.allclose(out, np.roll(M3, 1, axis=0), atol=1e-6)
+
+
+def test_correlation_matrix_pin(oracle):
+    # test_filters_main.cpp:71-92
+    R = oracle.correlation_matrix(M3, M3)
+    exp = np.array([[64., 62, 66], [78, 85, 78], [66, 62, 64]])
+    assert np.allclose(R, exp, atol=1e-6)
+
+
+def test_best_shift_self_is_zero(oracle):
+    # test_filters_main.cpp:59-69
+    sx, sy, _ = oracle.best_shift(M3, M3)
+    assert sx == 0.0 and sy == 0.0
+
+
+def test_correlation_index_self_is_one(oracle):
+    # test_filters_main.cpp:94-103 (EXPECT_DOUBLE_EQ => 4 ulp)
+    assert abs(oracle.correlation_index(M3, M3) - 1.0) < 1e-15
+
+
+def test_euler_matrix_closed_form(oracle):
+    # test_geometry_main.cpp:26-67
+    for rot in (0., 30., 150., 270.):
+        for tilt in (0., 60., 120.):
+            for psi in (0., 90., 210.):
+                A = oracle.euler_matrix(rot, tilt, psi)
+                a, b, g = np.radians([rot, tilt, psi])
+                assert abs(A[0, 0] - (np.cos(g) * np.cos(b) * np.cos(a) - np.sin(g) * np.sin(a))) < 1e-12
+                assert abs(A[0, 1] - (np.cos(g) * np.cos(b) * np.sin(a) + np.sin(g) * np.cos(a))) < 1e-12
+                assert abs(A[0, 2] - (-np.cos(g) * np.sin(b))) < 1e-12
+                assert abs(A[1, 1] - (-np.sin(g) * np.cos(b) * np.sin(a) + np.cos(g) * np.cos(a))) < 1e-12
+                assert abs(A[1, 2] - (np.sin(g) * np.sin(b))) < 1e-12
+                assert abs(A[2, 2] - np.cos(b)) < 1e-12
+                assert np.allclose(A @ A.T, np.eye(3), atol=1e-12)
+
+
+def test_ctf_wavelength_and_first_zero_pin(oracle):
+    # test_ctf_main.cpp:77-96: errorMaxFreqCTFs = 7.6852355 at 300 kV, defoci 6000/7500;
+    # ctf.cpp:187-211: 1/sqrt((pi/2)/(K1*|dU-dV|)), K1 = pi*lambda
+    p = oracle.ctf_params(kV=300.0)
+    lam = oracle.lib().xo_ctf_lambda(p)
+    assert abs(lam - 0.0196876) < 1e-6
+    val = 1.0 / np.sqrt((np.pi / 2) / (np.pi * lam * abs(6000.0 - 7500.0)))
+    assert abs(val - 7.6852355) < 2e-6
+
+
+def test_prefilter_inverts_bspline_sampling(oracle):
+    # coefficients c reproduce the samples: s[k] = (c[k-1] + 4 c[k] + c[k+1]) / 6 with
+    # half-sample mirror (c[-1] = c[0], c[n] = c[n-1])  
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((17, 23))
+    c = oracle.prefilter2d(img)
+    cp = np.pad(c, 1, mode="symmetric")
+    k = np.array([1, 4, 1]) / 6.0
+    rows = cp[:, :-2] * k[0] + cp[:, 1:-1] * k[1] + cp[:, 2:] * k[2]
+    rec = rows[:-2] * k[0] + rows[1:-1] * k[1] + rows[2:] * k[2]
+    assert np.allclose(rec, img, atol=1e-12)
