@@ -1,0 +1,202 @@
+/*
+ * xmipp_hip.h -- C ABI of libxmipp_hip.so: the MI355X (gfx950) device side of
+ * Xmipp's projection-matching + Fourier-gridding hot path.
+ *
+ * This is the drop-in boundary.  Host programs (our C++ mirrors of
+ * ProgAngularProjectionMatching / ProgRecFourierAccel in xmipp3_amd/host, the
+ * Python harness in xmipp3_amd/, or upstream Xmipp itself -- see
+ * INTEGRATION.md) call only these entry points.  Plain pointers and sizes, no
+ * C++/torch types.  Reference paths below are relative to
+ * /root/reference/src/xmipp/libraries.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative xh_status otherwise;
+ *    xh_last_error() gives the message (thread-local).  There is NO CPU
+ *    fallback: without a usable HIP device xh_ctx_create fails.
+ *  - pointers named d_* are device pointers (HBM) valid on the context's
+ *    device, h_* are host pointers.  Device buffers may be owned by the caller
+ *    (e.g. a torch tensor) -- the library never frees caller memory.
+ *  - all work is enqueued on the context's HIP stream; calls return when the
+ *    work is enqueued unless stated otherwise ("synchronous").
+ *  - one host thread per context; handles are not thread-safe (same contract
+ *    as reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:46-157, one
+ *    stream per host thread).
+ *  - images are row-major float32, D x D, logical (Xmipp) origin at pixel
+ *    (D/2, D/2) as after MultidimArray::setXmippOrigin().
+ */
+#ifndef XMIPP_HIP_H
+#define XMIPP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    XH_OK = 0,
+    XH_ERR_ARG = -1,     /* invalid argument / unsupported size */
+    XH_ERR_HIP = -2,     /* HIP runtime error */
+    XH_ERR_NOMEM = -3,
+    XH_ERR_STATE = -4,   /* call made in the wrong state */
+    XH_ERR_UNSUPPORTED = -5
+} xh_status;
+
+const char *xh_last_error(void);
+const char *xh_version(void);
+
+/* ------------------------------------------------------------------ context
+ * Replaces createStreams/deleteStreams/waitForGPU
+ * (reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:46-60, :128) and the
+ * GPU HW object (reconstruction_cuda/gpu.h:36-). */
+typedef struct xh_ctx xh_ctx;
+/* stream: an existing hipStream_t to enqueue on (e.g. torch's current stream), or NULL to
+ * let the context create its own. */
+int xh_ctx_create(int device, void *stream, xh_ctx **out);
+int xh_ctx_destroy(xh_ctx *ctx);
+int xh_ctx_sync(xh_ctx *ctx);                 /* synchronous: waits for the stream */
+void *xh_ctx_stream(xh_ctx *ctx);
+int xh_device_count(int *count);
+/* device memory helpers for hosts that do not bring their own allocator
+ * (allocateTempVolumeGPU/releaseTempVolumeGPU, cuda_gpu_reconstruct_fourier.h:83-91) */
+int xh_malloc(xh_ctx *ctx, size_t bytes, void **d_ptr);
+int xh_free(xh_ctx *ctx, void *d_ptr);
+int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* synchronous */
+int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
+/* elapsed-time probes on the context stream (HIP events), for bench.py's roofline object */
+int xh_timer_create(xh_ctx *ctx, void **timer);
+int xh_timer_start(xh_ctx *ctx, void *timer);
+int xh_timer_stop(xh_ctx *ctx, void *timer);
+int xh_timer_elapsed_ms(xh_ctx *ctx, void *timer, float *ms); /* synchronous */
+int xh_timer_destroy(xh_ctx *ctx, void *timer);
+
+/* ------------------------------------------------------- Fourier gridding
+ * Replaces ProgRecFourierAccel's inner loops (reconstruction/
+ * reconstruct_fourier_accel.cpp: preloadBuffer :300-388, cropAndShift :271-298,
+ * preloadCTF :548-592, processProjection :710-763, processVoxelBlob :627-700,
+ * processVoxel :595-625, mirrorAndCrop :853-887, finishComputations :1002-1055)
+ * and the CUDA seam processBufferGPU/copyTempVolumes/copyBlobTable/copyConstants
+ * (reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:93-157). */
+typedef struct {
+    int32_t imgSize;            /* D; only square images (RFA:192-193) */
+    double padding_proj;        /* --padding <proj> (RFA:65,91) */
+    double padding_vol;         /* --padding <vol> */
+    double max_resolution;      /* --max_resolution, digital frequency (RFA:66) */
+    double blob_radius;         /* --blob radius order alpha (RFA:68) */
+    int32_t blob_order;
+    double blob_alpha;
+    int32_t use_fast;           /* --fast */
+    int32_t phase_flipped;      /* --phaseFlipped */
+    double min_ctf;             /* --minCTF */
+    double sampling;            /* --sampling Ts (A/px); iTs = 1/Ts */
+} xh_rf_params;
+
+/* CTFDescription fields used by getValuePureNoKAt (data/ctf.h:452-502,
+ * data/ctf.cpp:645-679,1392-1402); defaults via xh_ctf_defaults
+ * (data/ctf.cpp:365-388). */
+typedef struct {
+    double Tm, kV, DeltafU, DeltafV, azimuthal_angle, Cs, Ca, espr, ispr, alpha, DeltaF, DeltaR,
+        Q0, K, envR0, envR1, envR2, phase_shift, VPP_radius;
+} xh_ctf_params;
+void xh_ctf_defaults(xh_ctf_params *p);
+
+/* One projection x symmetry placement ("traverse space",
+ * reconstruction/reconstruct_fourier_projection_traverse_space.h:37-59). The
+ * library fills these itself from Euler angles; exposed for hosts that
+ * already hold matrices. */
+typedef struct xh_rf xh_rf;
+
+int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out);
+int xh_rf_destroy(xh_rf *rf);
+/* derived sizes (RFA:196-199): paddedImgSize P, maxVolumeIndexYZ mv, fft crop sizeX=mv/2, sizeY=mv */
+int xh_rf_sizes(const xh_rf *rf, int32_t *paddedImgSize, int32_t *maxVolumeIndex,
+                int32_t *fftSizeX, int32_t *fftSizeY);
+/* host copies of the lookup tables (RFA:201-239): blobTableSqrt[10000] float,
+ * Fourier_blob_table[10000] double, iDeltaSqrt, iDeltaFourier */
+int xh_rf_tables(const xh_rf *rf, float *h_blobTableSqrt, double *h_fourierBlobTable,
+                 float *iDeltaSqrt, float *iDeltaFourier);
+/* Temp spaces: one contiguous float buffer [ volume (mv+1)^3 complex | weights (mv+1)^3 ],
+ * i.e. 3*(mv+1)^3 floats, layout [z][y][x]. By default owned by the handle; a caller-owned
+ * buffer (e.g. a torch tensor, so torch.distributed can all-reduce it) can be attached
+ * instead. xh_rf_reset zeroes it. */
+size_t xh_rf_temp_floats(const xh_rf *rf);
+int xh_rf_attach_temp(xh_rf *rf, float *d_temp /* xh_rf_temp_floats() floats */);
+int xh_rf_temp_ptr(xh_rf *rf, float **d_temp);
+int xh_rf_reset(xh_rf *rf);
+/* preloadBuffer + cropAndShift for n images already shifted (shifts applied):
+ * d_imgs [n][D][D] float  ->  d_fft [n][mv][mv/2] complex<float> (interleaved) */
+int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft);
+/* preloadCTF for n images: h_ctf [n] params -> d_ctf, d_mod [n][mv][mv/2] float */
+int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod);
+/* processBuffer: insert n prepared projections. h_angles [n][3] = (rot,tilt,psi) degrees;
+ * h_weights [n] or NULL (=1); h_sym [nsym][9] row-major symmetry matrices R (NULL => identity,
+ * nsym=1; RFA:241-256); d_ctf/d_mod NULL => no CTF. */
+int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                 const double *h_angles, const float *h_weights, int32_t n, const double *h_sym,
+                 int32_t nsym);
+/* same but taking the 3x3 "localAInv" (= Euler^T) matrices directly, h_ainv [n][9] */
+int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                          const double *h_ainv, const float *h_weights, int32_t n,
+                          const double *h_sym, int32_t nsym);
+/* mirrorAndCropTempSpaces (RFA:853-887): temp -> cropped [ (mv+1)^2*(mv/2+1) complex | weights ]
+ * stored at the start of the same buffer; 3*(mv+1)^2*(mv/2+1) floats are what a multi-GPU
+ * host all-reduces (SUM) before xh_rf_finish. */
+int xh_rf_mirror_and_crop(xh_rf *rf);
+size_t xh_rf_cropped_floats(const xh_rf *rf);
+/* finishComputations (RFA:1002-1055): synchronous; writes D^3 doubles, [z][y][x] */
+int xh_rf_finish(xh_rf *rf, double *h_volume);
+
+/* ---------------------------------------------------- projection matching
+ * Replaces ProgAngularProjectionMatching's inner loops (reconstruction/
+ * angular_projection_matching.cpp: getCurrentReference :408-528,
+ * threadRotationallyAlignOneImage :530-773, translationallyAlignOneImage :776-868)
+ * and the primitives under them (data/polar.h:488-534,625-738, data/polar.cpp:34-148,
+ * data/filters.cpp:1593-1752). */
+typedef struct xh_pm xh_pm;
+/* Builds the reference library on the device: d_refs [nrefs][D][D] float. Ri<1 -> 1,
+ * Ro<0 -> D/2-1 (APM:266-274). h_Mctf: optional real filter [paddim][paddim] in FFT order
+ * applied to every reference (APM:457-481), NULL for none. */
+int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs,
+                 const float *d_refs, const double *h_Mctf, int32_t paddim, xh_pm **out);
+int xh_pm_destroy(xh_pm *pm);
+int xh_pm_info(const xh_pm *pm, int32_t *nsam_outer /*N*/, int32_t *ncoef, int32_t *nsamples);
+/* Rotational search for n particles (d_particles [n][D][D] float), --thr 1 semantics.
+ * Neighbour lists in CSR form on the HOST: h_nbr_off [n+1], h_nbr_ids; both NULL => every
+ * particle is compared with references 0..nrefs-1 (dense mode).
+ * first_image_parity: 0 if the first particle of this call is an even-numbered image of the
+ * run (the visiting order of references flips per image, APM:615-626,1112).
+ * Outputs (device, one per particle): refno (-1 if the list is empty), psi_idx in [0,N)
+ * (psi = psi_idx*360/N, polar.cpp:145-147), flip.
+ * The orientation indices are exact w.r.t. a double-precision evaluation: an fp32 coarse
+ * pass ranks all (ref, angle, mirror) candidates and every particle whose runner-up lies
+ * within the fp32 error margin of the winner is re-scored in fp64. */
+int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off,
+                const int32_t *h_nbr_ids, int32_t first_image_parity, int32_t *d_refno,
+                int32_t *d_psi_idx, uint8_t *d_flip);
+/* Translational step for the winners (APM:776-868): bestShift on correlation_matrix(rotated
+ * reference, (mirrored) particle), rejection beyond max_shift (<0 => D/2), translate+
+ * correlationIndex => maxCC. fp64 on the device. Outputs device double [n]. */
+int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *d_refno,
+                    const int32_t *d_psi_idx, const uint8_t *d_flip, double max_shift,
+                    double *d_shiftX, double *d_shiftY, double *d_maxCC);
+/* statistics of the last xh_pm_match call: rows evaluated, particles re-scored in fp64 */
+int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rescored_particles,
+                     int64_t *rescored_rows);
+/* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
+int xh_pm_set_option(xh_pm *pm, const char *name, double value);
+
+/* ---- test hooks (used only by tests/ to localise a parity failure per stage) ---- */
+/* polar Fourier transform of one stage: precision 32 or 64; outputs on host */
+int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision,
+                        double *h_coefs /* [n][ncoef][2] */, double *h_sigma /* [n] */);
+int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs /* [ncoef][2] conj'd */,
+                    double *h_sigma);
+/* full normalised correlation rows (straight || mirror, 2N) of particle p vs reference r as
+ * computed by the fp32 coarse pass (precision 32) or the fp64 re-scorer (64) */
+int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32_t precision,
+                          double *h_corr2N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMIPP_HIP_H */

@@ -1,0 +1,77 @@
+"""Seeded synthetic cryo-EM-like data shared by the tests, smoke() and bench.py.
+(phantom = sum of 3-D Gaussians; projections by real-space rotation + sum.)"""
+import numpy as np
+
+
+def euler_matrix(rot, tilt, psi):
+    """xmippCore Euler_angles2matrix (closed form: function_tests/test_geometry_main.cpp:46-65)."""
+    a, b, g = np.radians([rot, tilt, psi])
+    ca, cb, cg, sa, sb, sg = np.cos(a), np.cos(b), np.cos(g), np.sin(a), np.sin(b), np.sin(g)
+    cc, cs, sc, ss = cb * ca, cb * sa, sb * ca, sb * sa
+    return np.array([[cg * cc - sg * sa, cg * cs + sg * ca, -cg * sb],
+                     [-sg * cc - cg * sa, -sg * cs + cg * ca, sg * sb],
+                     [sc, ss, cb]])
+
+
+def phantom(D, seed=1, nblobs=20):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.mgrid[-(D // 2):D - D // 2, -(D // 2):D - D // 2, -(D // 2):D - D // 2].astype(np.float64)
+    vol = np.zeros((D, D, D))
+    for _ in range(nblobs):
+        c = rng.uniform(-0.3 * D / 2 * 1.0, 0.3 * D / 2 * 1.0, 3) * 1.0
+        s = rng.uniform(2.0, 5.0) * D / 64.0
+        a = rng.uniform(0.5, 1.0)
+        vol += a * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s))
+    return vol
+
+
+def project(vol, rot, tilt, psi):
+    from scipy import ndimage
+    D = vol.shape[0]
+    A = euler_matrix(rot, tilt, psi)
+    c = np.array([D // 2] * 3, float)
+    M = A.T[::-1, ::-1]
+    r = ndimage.affine_transform(vol, M, offset=c - M @ c, order=3, mode="constant")
+    return r.sum(0)
+
+
+def fibonacci_directions(n):
+    """(rot, tilt) in degrees, roughly uniform on the sphere."""
+    i = np.arange(n) + 0.5
+    tilt = np.degrees(np.arccos(1 - 2 * i / n))
+    rot = np.degrees((np.pi * (1 + 5 ** 0.5) * i) % (2 * np.pi))
+    return np.stack([rot, tilt], 1)
+
+
+def random_angles(n, rng):
+    rot = rng.uniform(0, 360, n)
+    tilt = np.degrees(np.arccos(rng.uniform(-1, 1, n)))
+    psi = rng.uniform(0, 360, n)
+    return np.stack([rot, tilt, psi], 1)
+
+
+def make_refs(vol, nrefs):
+    dirs = fibonacci_directions(nrefs)
+    return np.stack([project(vol, r, t, 0.0) for r, t in dirs]).astype(np.float32), dirs
+
+
+def make_particles(refs, n, rng, snr=0.1, max_shift=3):
+    """Random reference, in-plane rotation, mirror, integer shift, white noise."""
+    from scipy import ndimage
+    nrefs, D, _ = refs.shape
+    out = np.empty((n, D, D), np.float32)
+    truth = []
+    for i in range(n):
+        k = int(rng.integers(nrefs))
+        ang = float(rng.uniform(0, 360))
+        fl = int(rng.integers(2))
+        img = ndimage.rotate(refs[k].astype(np.float64), ang, reshape=False, order=3, mode="constant")
+        if fl:
+            img = img[:, ::-1]
+        sh = rng.integers(-max_shift, max_shift + 1, 2)
+        img = np.roll(img, sh, (0, 1))
+        sig = img.std()
+        img = img + rng.standard_normal(img.shape) * sig / np.sqrt(snr)
+        out[i] = img
+        truth.append((k, ang, fl, int(sh[1]), int(sh[0])))
+    return out, truth

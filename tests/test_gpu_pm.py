@@ -1,0 +1,168 @@
+"""GPU parity tests of the projection-matching path (C ABI -> HIP) against the CPU oracle.
+
+The bar (BASELINE.json north_star): best-orientation indices (reference id, in-plane angle
+index, mirror flag) bit-identical to the CPU path; shifts within 1e-3 px, maxCC within 1e-5.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import xmipp3_amd as xa
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return xa, xa.Context(0), torch
+
+
+def _library(D, nrefs, seed=1):
+    vol = synth.phantom(D, seed=seed, nblobs=14)
+    refs, dirs = synth.make_refs(vol, nrefs)
+    return refs
+
+
+@pytest.fixture(scope="module")
+def lib64():
+    D, nrefs = 64, 48
+    refs = _library(D, nrefs)
+    rng = np.random.default_rng(3)
+    parts, truth = synth.make_particles(refs, 37, rng, snr=0.1, max_shift=2)
+    return D, refs, parts, truth
+
+
+def test_reference_library_fp64(gpu, oracle, lib64):
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    assert (pm.N, pm.ncoef) == (o.N, o.ncoef)
+    for r in (0, 5, len(refs) - 1):
+        c, s = pm.debug_ref(r)
+        ce, se = o.ref_coefs(r), o.ref_sigma(r)
+        assert abs(s - se) <= 1e-12 * se
+        assert np.abs(c - ce).max() <= 1e-12 * np.abs(ce).max()
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-12), (32, 5e-6)])
+def test_particle_polar_fourier_transform(gpu, oracle, lib64, precision, tol):
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    c, s = pm.debug_prepare(torch.from_numpy(parts[:6]).cuda(), precision)
+    for i in range(6):
+        fP, fPm, sig = o.prepare_particle(parts[i])
+        assert abs(s[i] - sig) <= tol * sig
+        assert np.abs(c[i] - fP).max() <= tol * np.abs(fP).max()
+        assert np.allclose(fPm, np.conj(fP))
+
+
+def test_correlation_rows_and_fp32_margin(gpu, oracle, lib64):
+    """fp64 re-scorer == oracle to rounding; fp32 coarse pass within the ambiguity margin."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    scale = sum(2 * np.pi * r for r in range(o.Ri, o.Ro + 1))
+    worst32 = 0.0
+    for i, r in ((0, 0), (1, 7), (2, 47), (3, 20)):
+        exp = o.corr_rows(parts[i], r)
+        p = torch.from_numpy(parts[i:i + 1]).cuda()
+        got64 = pm.debug_corr_rows(p, r, 64)
+        got32 = pm.debug_corr_rows(p, r, 32)
+        assert np.abs(got64 - exp).max() <= 1e-10 * scale
+        worst32 = max(worst32, np.abs(got32 - exp).max() / scale)
+        assert np.argmax(got64) == np.argmax(exp)
+    print("fp32 coarse-pass error / scale:", worst32)
+    assert worst32 < 2e-5 / 4   # default tau_rel = 2e-5 leaves 4x headroom
+
+
+@pytest.mark.parametrize("parity", [0, 1])
+def test_match_dense_indices_bit_identical(gpu, oracle, lib64, parity):
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    refno, psi, flip = pm.match(torch.from_numpy(parts).cuda(), parity=parity)
+    er, ep, ef, ecc = o.match(parts, parity=parity)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    st = pm.last_stats()
+    assert st["rows"] == len(parts) * len(refs)
+    print("rescored particles:", st["rescored_particles"], "of", len(parts))
+
+
+def test_match_with_neighbour_lists_and_chunking(gpu, oracle, lib64):
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    rng = np.random.default_rng(11)
+    n, nrefs = len(parts), len(refs)
+    lists = []
+    for i in range(n):
+        k = int(rng.integers(0, 12)) if i != 4 else 0     # particle 4 has no neighbours
+        lists.append(rng.choice(nrefs, size=k, replace=False))
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists).astype(np.int32)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    pm.set_option("chunk_rows", 50)   # forces several chunks
+    o = oracle.PM(refs)
+    refno, psi, flip = pm.match(torch.from_numpy(parts).cuda(), off, ids, parity=1)
+    er, ep, ef, ecc = o.match(parts, off, ids, parity=1)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert refno[4].item() == -1
+    valid = er[:, 0] >= 0
+    assert np.array_equal(psi.cpu().numpy()[valid], ep[valid, 0])
+    assert np.array_equal(flip.cpu().numpy()[valid], ef[valid, 0])
+
+
+def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
+    """Duplicated references give bit-equal correlations in the reference: the first visited
+    wins, and the visiting order flips every image (APM:615-626,1112)."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    refs2 = np.concatenate([refs[:10], refs[3:4], refs[10:20], refs[3:4]])  # ref 3 also at 10 and 21
+    rng = np.random.default_rng(21)
+    pp = np.stack([refs2[3] + 0.3 * refs2[3].std() * rng.standard_normal((D, D)).astype(np.float32) for _ in range(6)])
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs2).cuda())
+    o = oracle.PM(refs2)
+    for parity in (0, 1):
+        refno, psi, flip = pm.match(torch.from_numpy(pp).cuda(), parity=parity)
+        er, ep, ef, _ = o.match(pp, parity=parity)
+        assert set(er[:, 0]) <= {3, 10, 21}
+        assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+        assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+        assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    assert pm.last_stats()["rescored_particles"] == 6
+
+
+def test_translational_alignment(gpu, oracle, lib64):
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    er, ep, ef, _ = o.match(parts)
+    er, ep, ef = er[:, 0].copy(), ep[:, 0].copy(), ef[:, 0].copy()
+    er[5] = -1
+    for max_shift in (-1.0, 1.5):
+        sx, sy, cc = pm.translate(torch.from_numpy(parts).cuda(), torch.from_numpy(er).cuda(),
+                                  torch.from_numpy(ep).cuda(), torch.from_numpy(ef).cuda(), max_shift)
+        ex, ey, ec = o.translate(parts, er, ep, ef, max_shift)
+        assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3
+        assert np.abs(sy.cpu().numpy() - ey).max() <= 1e-3
+        assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+
+
+def test_errors_are_loud(gpu):
+    xa, ctx, torch = gpu
+    refs = torch.zeros((2, 64, 64), device="cuda")
+    with pytest.raises(xa.XhError):
+        xa.ProjectionMatcher(ctx, refs, Ri=10, Ro=5)
+    pm = xa.ProjectionMatcher(ctx, torch.rand((2, 64, 64), device="cuda"))
+    with pytest.raises(xa.XhError):
+        pm.match(torch.rand((1, 64, 64), device="cuda"), np.array([0, 1], np.int32), np.array([7], np.int32))

@@ -1,0 +1,217 @@
+"""GPU parity tests of the Fourier-gridding path (C ABI -> HIP) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import xmipp3_amd as xa
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    ctx = xa.Context(0)
+    return xa, ctx, torch
+
+
+@pytest.fixture(scope="module")
+def data32():
+    D = 32
+    vol = synth.phantom(D, seed=1, nblobs=12)
+    rng = np.random.default_rng(2)
+    ang = synth.random_angles(40, rng)
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    return D, vol, ang, imgs
+
+
+def test_tables_match_oracle(gpu, oracle):
+    xa, ctx, torch = gpu
+    for D, order in ((32, 0), (64, 0), (64, 2)):
+        rf = xa.RecFourier(ctx, D, blob_order=order)
+        o = oracle.RF(D, blob_order=order)
+        bt, fbt, ids, idf = rf.tables()
+        assert np.allclose(bt, o.blob_table, rtol=1e-6, atol=1e-9)
+        assert np.allclose(fbt, o.fourier_blob_table, rtol=1e-12)
+        assert ids == o.p.iDeltaSqrt and idf == o.p.iDeltaFourier
+        assert (rf.P, rf.mv) == (o.P, o.mv)
+
+
+@pytest.mark.parametrize("D,maxres", [(32, 0.5), (64, 0.5), (64, 0.3)])
+def test_prepare_images(gpu, oracle, D, maxres):
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(D)
+    imgs = rng.standard_normal((5, D, D)).astype(np.float32)
+    rf = xa.RecFourier(ctx, D, max_resolution=maxres)
+    o = oracle.RF(D, max_resolution=maxres)
+    got = rf.prepare_images(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    for i in range(5):
+        exp = o.prepare_image(imgs[i])
+        assert got[i].shape == exp.shape
+        # fp32 device FFT vs double FFT narrowed to float (RFA:293): tolerance 3e-6 of the spectrum peak
+        assert np.abs(got[i] - exp).max() <= 3e-6 * np.abs(exp).max()
+        assert ((exp == 0) == (got[i] == 0)).all() or np.abs(got[i][exp == 0]).max() == 0
+
+
+def test_ctf_arrays(gpu, oracle):
+    xa, ctx, torch = gpu
+    D = 64
+    rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.5)
+    o = oracle.RF(D, min_ctf=0.01, sampling=1.5, use_ctf=True)
+    from xmipp3_amd.api import ctf_params
+    kw = dict(kV=300.0, Cs=2.7, Q0=0.07, DeltafU=15000.0, DeltafV=17000.0, azimuthal_angle=30.0, K=1.0)
+    c, m = rf.ctf_arrays([ctf_params(**kw)])
+    ce, me = o.ctf_arrays(oracle.ctf_params(**kw))
+    c, m = c.cpu().numpy()[0], m.cpu().numpy()[0]
+    # same double-precision formula; libm vs device sin/cos differ in the last ulps, amplified by 1/CTF
+    rel = np.abs(c - ce) / np.maximum(1.0, np.abs(ce))
+    assert rel.max() < 1e-4
+    assert np.abs(m - me).max() < 1e-6
+
+
+def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, **kw):
+    rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
+    o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
+    ffts = np.stack([o.prepare_image(im) for im in imgs])
+    return rf, o, ffts
+
+
+def test_insert_single_projection_bit_exact(gpu, oracle, data32):
+    """One projection into an empty volume: the same voxels and, summing taps in the same
+    order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    for i in (0, 3, 7):
+        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[i:i + 1], ang[i:i + 1])
+        o.insert(ffts[0], synth.euler_matrix(*ang[i]).T)
+        rf.insert(torch.from_numpy(ffts).cuda(), ang[i:i + 1])
+        ev, ew = o.temp()
+        gv, gw = rf.temp_spaces()
+        gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+        assert (ew > 0).sum() > 1000
+        assert np.array_equal(gw, ew)
+        assert np.array_equal(gv, ev)
+
+
+def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
+    """rot=tilt=psi=0 makes getX (RFA:479-490) divide 0/0: the reference visits no voxel."""
+    xa, ctx, torch = gpu
+    D = 32
+    rf = xa.RecFourier(ctx, D)
+    o = oracle.RF(D)
+    f = o.prepare_image(np.random.default_rng(0).standard_normal((D, D)))
+    o.insert(f, np.eye(3))
+    rf.insert(torch.from_numpy(f[None]).cuda(), np.zeros((1, 3)))
+    ev, ew = o.temp()
+    gv, gw = rf.temp_spaces()
+    assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
+
+
+@pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
+def test_insert_many(gpu, oracle, data32, mode):
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    fast = mode.startswith("fast")
+    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, fast=fast)
+    n = len(imgs)
+    rng = np.random.default_rng(5)
+    weights = None
+    sym = None
+    ctf = mod = None
+    if mode == "sym_weights":
+        weights = rng.uniform(0.0, 2.0, n).astype(np.float32)
+        weights[3] = 0.0  # skipped, RFA:327-329
+        c2 = np.diag([-1.0, -1.0, 1.0])
+        sym = np.stack([np.eye(3), c2])
+    if mode in ("ctf", "fast_ctf"):
+        ctf = rng.uniform(0.5, 2.0, ffts.shape[:3]).astype(np.float32) * rng.choice([-1, 1], ffts.shape[:3])
+        mod = rng.uniform(0.0, 1.0, ffts.shape[:3]).astype(np.float32)
+    for i in range(n):
+        w = 1.0 if weights is None else float(weights[i])
+        if weights is not None and w == 0.0:
+            continue
+        for R in ([np.eye(3)] if sym is None else sym):
+            o.insert(ffts[i], synth.euler_matrix(*ang[i]).T, R=R, weight=w,
+                     ctf=None if ctf is None else ctf[i], modulator=None if mod is None else mod[i])
+    rf.insert(torch.from_numpy(ffts).cuda(), ang, weights=weights, sym=sym,
+              ctf=None if ctf is None else torch.from_numpy(ctf).cuda(),
+              modulator=None if mod is None else torch.from_numpy(mod).cuda())
+    ev, ew = o.temp()
+    gv, gw = rf.temp_spaces()
+    gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+    # identical voxel sets; sums differ only by float summation order (atomics)
+    assert ((ew != 0) == (gw != 0)).all()
+    assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
+    assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+
+
+def test_mirror_crop_and_finish_given_same_temp(gpu, oracle, data32):
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    for fast in (False, True):
+        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, fast=fast)
+        for i in range(len(imgs)):
+            o.insert(ffts[i], synth.euler_matrix(*ang[i]).T)
+        ev, ew = o.temp()
+        gv, gw = rf.temp_spaces()
+        gv.copy_(torch.from_numpy(ev))
+        gw.copy_(torch.from_numpy(ew))
+        rf.mirror_and_crop()
+        o.mirror_and_crop()
+        ev2, ew2 = o.temp()
+        gv2, gw2 = rf.temp_spaces()
+        assert np.array_equal(gv2.cpu().numpy(), ev2)
+        assert np.array_equal(gw2.cpu().numpy(), ew2)
+        got = rf.finish()
+        exp = o.finish()
+        assert np.abs(got - exp).max() <= 1e-9 * np.abs(exp).max()
+
+
+def test_end_to_end_reconstruction(gpu, oracle, data32):
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    rf = xa.RecFourier(ctx, D)
+    o = oracle.RF(D)
+    rf.insert(rf.prepare_images(torch.from_numpy(imgs).cuda()), ang)
+    rf.mirror_and_crop()
+    got = rf.finish()
+    for i in range(len(imgs)):
+        o.insert(o.prepare_image(imgs[i]), synth.euler_matrix(*ang[i]).T)
+    o.mirror_and_crop()
+    exp = o.finish()
+    # stated float tolerance of the volume: 1e-4 of the peak
+    assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()
+    assert np.corrcoef(got.ravel(), exp.ravel())[0, 1] > 0.999999
+    # reset + idempotence: a second identical run gives the same volume within atomics noise
+    rf.reset()
+    rf.insert(rf.prepare_images(torch.from_numpy(imgs).cuda()), ang)
+    rf.mirror_and_crop()
+    again = rf.finish()
+    assert np.abs(again - got).max() <= 1e-5 * np.abs(got).max()
+
+
+def test_linearity_of_insertion(gpu, data32):
+    """Size-independent property: inserting A then B equals inserting A and B in one call."""
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    rf = xa.RecFourier(ctx, D)
+    f = rf.prepare_images(torch.from_numpy(imgs).cuda())
+    rf.insert(f, ang)
+    v1 = rf.temp.clone()
+    rf.reset()
+    rf.insert(f[:17].contiguous(), ang[:17])
+    rf.insert(f[17:].contiguous(), ang[17:])
+    assert (rf.temp - v1).abs().max().item() <= 2e-6 * v1.abs().max().item()
+
+
+def test_errors_are_loud(gpu):
+    xa, ctx, torch = gpu
+    with pytest.raises(xa.XhError):
+        xa.RecFourier(ctx, 50)          # padded size 100 is not a power of two
+    with pytest.raises(xa.XhError):
+        xa.RecFourier(ctx, 32, blob_order=1)
+    rf = xa.RecFourier(ctx, 32)
+    rf.mirror_and_crop()
+    with pytest.raises(xa.XhError):
+        rf.insert(torch.zeros((1, 64, 32, 2), device="cuda"), np.zeros((1, 3)))

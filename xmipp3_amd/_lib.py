@@ -1,0 +1,106 @@
+"""ctypes loader for libxmipp_hip.so (C ABI: include/xmipp_hip.h). Fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class XhError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libxmipp_hip.so")
+
+
+class RfParams(C.Structure):
+    _fields_ = [("imgSize", C.c_int32), ("padding_proj", C.c_double), ("padding_vol", C.c_double),
+                ("max_resolution", C.c_double), ("blob_radius", C.c_double),
+                ("blob_order", C.c_int32), ("blob_alpha", C.c_double), ("use_fast", C.c_int32),
+                ("phase_flipped", C.c_int32), ("min_ctf", C.c_double), ("sampling", C.c_double)]
+
+
+class CtfParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "Tm", "kV", "DeltafU", "DeltafV", "azimuthal_angle", "Cs", "Ca", "espr", "ispr", "alpha",
+        "DeltaF", "DeltaR", "Q0", "K", "envR0", "envR1", "envR2", "phase_shift", "VPP_radius")]
+
+
+# every symbol include/xmipp_hip.h declares: name -> (restype, argtypes)
+vp, i32, i64, d, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+pvp = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "xh_last_error": (C.c_char_p, []),
+    "xh_version": (C.c_char_p, []),
+    "xh_ctx_create": (C.c_int, [C.c_int, vp, pvp]),
+    "xh_ctx_destroy": (C.c_int, [vp]),
+    "xh_ctx_sync": (C.c_int, [vp]),
+    "xh_ctx_stream": (vp, [vp]),
+    "xh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "xh_malloc": (C.c_int, [vp, sz, pvp]),
+    "xh_free": (C.c_int, [vp, vp]),
+    "xh_memset": (C.c_int, [vp, vp, C.c_int, sz]),
+    "xh_memcpy_h2d": (C.c_int, [vp, vp, vp, sz]),
+    "xh_memcpy_d2h": (C.c_int, [vp, vp, vp, sz]),
+    "xh_timer_create": (C.c_int, [vp, pvp]),
+    "xh_timer_start": (C.c_int, [vp, vp]),
+    "xh_timer_stop": (C.c_int, [vp, vp]),
+    "xh_timer_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "xh_timer_destroy": (C.c_int, [vp, vp]),
+    "xh_ctf_defaults": (None, [C.POINTER(CtfParams)]),
+    "xh_rf_create": (C.c_int, [vp, C.POINTER(RfParams), pvp]),
+    "xh_rf_destroy": (C.c_int, [vp]),
+    "xh_rf_sizes": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "xh_rf_tables": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "xh_rf_temp_floats": (sz, [vp]),
+    "xh_rf_attach_temp": (C.c_int, [vp, vp]),
+    "xh_rf_temp_ptr": (C.c_int, [vp, pvp]),
+    "xh_rf_reset": (C.c_int, [vp]),
+    "xh_rf_prepare_images": (C.c_int, [vp, vp, i32, vp]),
+    "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
+    "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
+    "xh_rf_insert_matrices": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
+    "xh_rf_mirror_and_crop": (C.c_int, [vp]),
+    "xh_rf_cropped_floats": (sz, [vp]),
+    "xh_rf_finish": (C.c_int, [vp, vp]),
+    "xh_pm_create": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, i32, pvp]),
+    "xh_pm_destroy": (C.c_int, [vp]),
+    "xh_pm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "xh_pm_match": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp]),
+    "xh_pm_translate": (C.c_int, [vp, vp, i32, vp, vp, vp, d, vp, vp, vp]),
+    "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "xh_pm_set_option": (C.c_int, [vp, C.c_char_p, d]),
+    "xh_pm_debug_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+    "xh_pm_debug_ref": (C.c_int, [vp, i32, vp, vp]),
+    "xh_pm_debug_corr_rows": (C.c_int, [vp, vp, i32, i32, vp]),
+}
+
+
+def lib():
+    """Load the HIP library; raise XhError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise XhError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(xmipp3_amd/csrc/build.sh). There is no CPU fallback.")
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise XhError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            f = getattr(L, name)
+        except AttributeError as e:
+            raise XhError(f"{path} does not export {name}") from e
+        f.restype = res
+        f.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise XhError(f"xmipp_hip error {rc}: {lib().xh_last_error().decode()}")

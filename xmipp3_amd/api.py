@@ -1,0 +1,288 @@
+"""Host-side Python mirror of the two Xmipp programs' inner interfaces.
+
+Names follow the reference (ProgRecFourierAccel / ProgAngularProjectionMatching members);
+every method is a thin call into libxmipp_hip.so.  torch provides device memory (tensors),
+the stream and torch.distributed -- plumbing only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CtfParams, RfParams, XhError, check, lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def shard_range(n, rank, world):
+    """Contiguous particle range of `rank` ([g*N/G, (g+1)*N/G))."""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+class Context:
+    """xh_ctx bound to torch's current stream on `device`."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        L = lib()
+        if not torch.cuda.is_available():
+            raise XhError("no HIP device visible to torch; xmipp3_amd has no CPU fallback")
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        check(L.xh_ctx_create(self.device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.torch_device = torch.device("cuda", self.device)
+
+    def sync(self):
+        check(lib().xh_ctx_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # HIP-event timer on the library stream (bench.py roofline)
+    def timer(self):
+        return _Timer(self)
+
+
+class _Timer:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.t = C.c_void_p()
+        check(lib().xh_timer_create(ctx.h, C.byref(self.t)))
+
+    def start(self):
+        check(lib().xh_timer_start(self.ctx.h, self.t))
+
+    def stop(self):
+        check(lib().xh_timer_stop(self.ctx.h, self.t))
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(lib().xh_timer_elapsed_ms(self.ctx.h, self.t, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().xh_timer_destroy(self.ctx.h, self.t)
+        except Exception:
+            pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def ctf_params(**kw):
+    p = CtfParams()
+    lib().xh_ctf_defaults(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, float(v))
+    return p
+
+
+class RecFourier:
+    """Device side of ProgRecFourierAccel (reconstruction/reconstruct_fourier_accel.cpp)."""
+
+    def __init__(self, ctx, imgSize, padding_proj=2.0, padding_vol=2.0, max_resolution=0.5,
+                 blob_radius=1.9, blob_order=0, blob_alpha=15.0, fast=False, phase_flipped=False,
+                 min_ctf=0.01, sampling=1.0):
+        torch = _torch()
+        self.ctx = ctx
+        p = RfParams(int(imgSize), padding_proj, padding_vol, max_resolution, blob_radius,
+                     int(blob_order), blob_alpha, int(fast), int(phase_flipped), min_ctf, sampling)
+        h = C.c_void_p()
+        check(lib().xh_rf_create(ctx.h, C.byref(p), C.byref(h)))
+        self.h = h
+        P, mv, sx, sy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().xh_rf_sizes(h, C.byref(P), C.byref(mv), C.byref(sx), C.byref(sy)))
+        self.D, self.P, self.mv, self.sizeX, self.sizeY = int(imgSize), P.value, mv.value, sx.value, sy.value
+        # temp spaces are a torch tensor so that torch.distributed can all-reduce them in place
+        self.temp = torch.zeros(lib().xh_rf_temp_floats(h), dtype=torch.float32, device=ctx.torch_device)
+        check(lib().xh_rf_attach_temp(h, _ptr(self.temp)))
+        self.cropped = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xh_rf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tables(self):
+        bt = np.empty(10000, np.float32)
+        fbt = np.empty(10000, np.float64)
+        a, b = C.c_float(), C.c_float()
+        check(lib().xh_rf_tables(self.h, _np_ptr(bt), _np_ptr(fbt), C.byref(a), C.byref(b)))
+        return bt, fbt, a.value, b.value
+
+    def reset(self):
+        check(lib().xh_rf_reset(self.h))
+        self.cropped = False
+
+    def prepare_images(self, imgs, out=None):
+        """imgs: cuda float32 [n,D,D] -> [n, mv, mv/2, 2] float32 (centred half spectra)."""
+        torch = _torch()
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
+        n = imgs.shape[0]
+        if out is None:
+            out = torch.empty((n, self.sizeY, self.sizeX, 2), dtype=torch.float32, device=imgs.device)
+        check(lib().xh_rf_prepare_images(self.h, _ptr(imgs), n, _ptr(out)))
+        return out
+
+    def ctf_arrays(self, ctfs):
+        torch = _torch()
+        n = len(ctfs)
+        arr = (CtfParams * n)(*ctfs)
+        c = torch.empty((n, self.sizeY, self.sizeX), dtype=torch.float32, device=self.ctx.torch_device)
+        m = torch.empty_like(c)
+        check(lib().xh_rf_ctf_arrays(self.h, arr, n, _ptr(c), _ptr(m)))
+        return c, m
+
+    def insert(self, fft, angles, weights=None, ctf=None, modulator=None, sym=None):
+        """angles: [n,3] (rot,tilt,psi) degrees on the host."""
+        n = fft.shape[0]
+        ang = np.ascontiguousarray(angles, np.float64).reshape(n, 3)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
+        check(lib().xh_rf_insert(self.h, _ptr(fft), _ptr(ctf), _ptr(modulator), _np_ptr(ang), _np_ptr(w), n,
+                                 _np_ptr(s), 0 if s is None else s.shape[0]))
+
+    def insert_matrices(self, fft, ainv, weights=None, ctf=None, modulator=None, sym=None):
+        n = fft.shape[0]
+        a = np.ascontiguousarray(ainv, np.float64).reshape(n, 9)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
+        check(lib().xh_rf_insert_matrices(self.h, _ptr(fft), _ptr(ctf), _ptr(modulator), _np_ptr(a), _np_ptr(w),
+                                          n, _np_ptr(s), 0 if s is None else s.shape[0]))
+
+    def temp_spaces(self):
+        """(volume [mv+1,mv+1,nx,2], weights [mv+1,mv+1,nx]) views of the temp tensor."""
+        d = self.mv + 1
+        nx = (self.mv // 2 + 1) if self.cropped else d
+        tot = d * d * nx
+        return self.temp[:2 * tot].view(d, d, nx, 2), self.temp[2 * tot:3 * tot].view(d, d, nx)
+
+    def mirror_and_crop(self):
+        check(lib().xh_rf_mirror_and_crop(self.h))
+        self.cropped = True
+
+    def cropped_view(self):
+        """Flat view [volume | weights] of the cropped spaces: the all-reduce payload."""
+        assert self.cropped
+        return self.temp[:lib().xh_rf_cropped_floats(self.h)]
+
+    def finish(self):
+        out = np.empty((self.D, self.D, self.D), np.float64)
+        check(lib().xh_rf_finish(self.h, _np_ptr(out)))
+        return out
+
+
+def allreduce_reconstruction(rf):
+    """The one exchange step of the sharded path: SUM of [volume | weights] over ranks
+    (replaces the per-row MPI_Reduce of parallel/mpi_reconstruct_fourier_accel.cpp:249-267)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(rf.cropped_view(), op=dist.ReduceOp.SUM)
+
+
+class ProjectionMatcher:
+    """Device side of ProgAngularProjectionMatching
+    (reconstruction/angular_projection_matching.cpp)."""
+
+    def __init__(self, ctx, refs, Ri=1, Ro=-1, Mctf=None, paddim=0):
+        torch = _torch()
+        assert refs.is_cuda and refs.dtype == torch.float32 and refs.is_contiguous()
+        self.ctx = ctx
+        self.nrefs, self.D, _ = refs.shape
+        h = C.c_void_p()
+        m = None if Mctf is None else np.ascontiguousarray(Mctf, np.float64)
+        check(lib().xh_pm_create(ctx.h, self.D, Ri, Ro, self.nrefs, _ptr(refs), _np_ptr(m), paddim, C.byref(h)))
+        self.h = h
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().xh_pm_info(h, C.byref(a), C.byref(b), C.byref(c)))
+        self.N, self.ncoef, self.nsamples = a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xh_pm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        check(lib().xh_pm_set_option(self.h, name.encode(), float(value)))
+
+    def match(self, particles, nbr_off=None, nbr_ids=None, parity=0):
+        torch = _torch()
+        assert particles.is_cuda and particles.dtype == torch.float32 and particles.is_contiguous()
+        n = particles.shape[0]
+        dev = particles.device
+        refno = torch.empty(n, dtype=torch.int32, device=dev)
+        psi = torch.empty(n, dtype=torch.int32, device=dev)
+        flip = torch.empty(n, dtype=torch.uint8, device=dev)
+        off = ids = None
+        if nbr_off is not None:
+            off = np.ascontiguousarray(nbr_off, np.int32)
+            ids = np.ascontiguousarray(nbr_ids, np.int32)
+        check(lib().xh_pm_match(self.h, _ptr(particles), n, _np_ptr(off), _np_ptr(ids), int(parity), _ptr(refno),
+                                _ptr(psi), _ptr(flip)))
+        return refno, psi, flip
+
+    def translate(self, particles, refno, psi, flip, max_shift=-1.0):
+        torch = _torch()
+        n = particles.shape[0]
+        dev = particles.device
+        sx = torch.empty(n, dtype=torch.float64, device=dev)
+        sy = torch.empty_like(sx)
+        cc = torch.empty_like(sx)
+        check(lib().xh_pm_translate(self.h, _ptr(particles), n, _ptr(refno), _ptr(psi), _ptr(flip), float(max_shift),
+                                    _ptr(sx), _ptr(sy), _ptr(cc)))
+        return sx, sy, cc
+
+    def last_stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().xh_pm_last_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rows": a.value, "rescored_particles": b.value, "rescored_rows": c.value}
+
+    # ---- test hooks
+    def debug_prepare(self, particles, precision=32):
+        n = particles.shape[0]
+        coefs = np.empty((n, self.ncoef, 2), np.float64)
+        sigma = np.empty(n, np.float64)
+        check(lib().xh_pm_debug_prepare(self.h, _ptr(particles), n, precision, _np_ptr(coefs), _np_ptr(sigma)))
+        return coefs[..., 0] + 1j * coefs[..., 1], sigma
+
+    def debug_ref(self, r):
+        coefs = np.empty((self.ncoef, 2), np.float64)
+        s = C.c_double()
+        check(lib().xh_pm_debug_ref(self.h, r, _np_ptr(coefs), C.byref(s)))
+        return coefs[:, 0] + 1j * coefs[:, 1], s.value
+
+    def debug_corr_rows(self, particle, ref, precision=32):
+        out = np.empty(2 * self.N, np.float64)
+        check(lib().xh_pm_debug_corr_rows(self.h, _ptr(particle), ref, precision, _np_ptr(out)))
+        return out

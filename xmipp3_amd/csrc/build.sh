@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds libxmipp_hip.so for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result"
+mkdir -p build
+pids=()
+# geometry of the gridding must round like the reference's scalar code: no FMA contraction
+$HIPCC $COMMON -ffp-contract=off -c xh_rf.hip -o build/xh_rf.o & pids+=($!)
+$HIPCC $COMMON -c xh_ctx.hip -o build/xh_ctx.o & pids+=($!)
+if [ -f xh_pm.hip ]; then $HIPCC $COMMON -c xh_pm.hip -o build/xh_pm.o & pids+=($!); fi
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libxmipp_hip.so build/*.o
+echo "built $(cd .. && pwd)/libxmipp_hip.so"

@@ -1,0 +1,65 @@
+// xh_common.h -- shared internals of libxmipp_hip.so (gfx950 only).
+#ifndef XH_COMMON_H
+#define XH_COMMON_H
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/xmipp_hip.h"
+
+void xh_set_error(const char *fmt, ...);
+
+#define XH_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            xh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                       \
+            return XH_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define XH_CHECK(cond, code, ...)       \
+    do {                                \
+        if (!(cond)) {                  \
+            xh_set_error(__VA_ARGS__);  \
+            return code;                \
+        }                               \
+    } while (0)
+
+#define XH_TRY(call)              \
+    do {                          \
+        int r_ = (call);          \
+        if (r_ != XH_OK) return r_; \
+    } while (0)
+
+#define XH_LAUNCH_CHECK() XH_HIP(hipGetLastError())
+
+struct xh_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int num_cus;
+};
+
+// RAII-less tracked device allocation helper for handles
+struct XhBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+int xh_buf_alloc(xh_ctx *ctx, XhBuf &b, size_t bytes);
+void xh_buf_free(XhBuf &b);
+// grow-only scratch
+int xh_buf_reserve(xh_ctx *ctx, XhBuf &b, size_t bytes);
+
+static inline int xh_ilog2(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+static inline bool xh_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+#endif

@@ -1,0 +1,1492 @@
+// xh_pm.hip -- projection matching on MI355X (gfx950): polar resampling, ring DFTs,
+// rotational cross-correlation with mirror search, exact arg-max, translational alignment.
+//
+// Device side of ProgAngularProjectionMatching (reference: reconstruction/
+// angular_projection_matching.cpp "APM", data/polar.{h,cpp} "POL", data/filters.cpp "FIL").
+//
+// Pipeline per chunk of particles (stage boundaries are kernel boundaries):
+//   S1  prep<T>      B-spline prefilter (APM:569) -> polar sampling (POL polar.h:625-703, float
+//                    angle cache polar.cpp:57-83) -> ring-weighted mean/sigma (polar.h:488-534)
+//                    -> per-ring DFT / nsam (polar.cpp:34-54)                       T = float | double
+//   S2  contract     raw[row][k] = sum_r w_r (a*c, a*d, b*c, b*d)   (polar.cpp:122-135 for the
+//                    straight AND the mirrored particle at once: both are linear in these 4 sums)
+//   S3  idft_max     Fs,Fm -> one packed complex length-N inverse DFT (Bluestein, LDS, fp32)
+//                    -> corr_straight = Re, corr_mirror = Im (polar.cpp:138-142) -> row best/second
+//   S4  select       per particle: winner over its rows + ambiguity test against the fp32 margin
+//   S5  rescore      ambiguous particles only: S1<double> + fp64 rows + exact pick with the
+//                    reference's visiting order / first-strictly-greater rule (APM:609-735)
+//   S6  translate    rotate(BSPLINE3) ref, mirror particle, correlation_matrix, bestShift,
+//                    translate(LINEAR,wrap), correlationIndex (APM:776-868, FIL:1593-1752), fp64
+//
+// HBM layout
+//   refs64  [nrefs][ncoef] complex<double>   conj(polar FT), mean-subtracted (APM:484-488)
+//   refsB   [nrefs][ncoef] complex<float>    = refs64 * 2*pi*r   (ring weight folded, polar.cpp:123)
+//   refcoef [nrefs][D][D]  double            cubic B-spline coefficients of the references (for S6)
+//   A32     [chunk][ncoef] complex<float>    particle polar FT
+//   raw     [rows][nk] float4                the S2 -> S3 intermediate (nk = N/2+1)
+#include "xh_common.h"
+#include "xh_fft.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+const double kPI = 3.14159265358979323846;
+const double kTWOPI = 6.2831853071795864769;
+
+struct Layout {
+    int D, Ri, Ro, nrings, nsamples, ncoef, N, nk;
+    std::vector<int> nsam, soff, coff;
+};
+
+void make_layout(Layout &L, int D, int Ri, int Ro)
+{
+    L.D = D; L.Ri = Ri; L.Ro = Ro; L.nrings = Ro - Ri + 1;
+    L.nsam.resize(L.nrings); L.soff.resize(L.nrings); L.coff.resize(L.nrings);
+    L.nsamples = L.ncoef = 0;
+    for (int r = 0; r < L.nrings; ++r) {
+        const float radius = (float)r + Ri;
+        int n = 2 * (int)(0.5 * 1.0 * kTWOPI * radius);   // polar.h:723-726, oversample 1
+        n = n > 1 ? n : 1;
+        L.nsam[r] = n; L.soff[r] = L.nsamples; L.coff[r] = L.ncoef;
+        L.nsamples += n;
+        L.ncoef += n / 2 + 1;
+    }
+    L.N = L.nsam[L.nrings - 1];
+    L.nk = L.N / 2 + 1;
+}
+
+// host radix-2 FFT (double) used once to precompute the Bluestein kernel spectrum
+void h_fft(std::vector<xh_cd> &a, bool inv)
+{
+    const int n = (int)a.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < len / 2; ++j) {
+                const long double ang = (inv ? 2.0L : -2.0L) * 3.14159265358979323846264338327950288L * j / len;
+                const double wr = (double)cosl(ang), wi = (double)sinl(ang);
+                xh_cd u = a[i + j], v = a[i + j + len / 2];
+                xh_cd t{v.x * wr - v.y * wi, v.x * wi + v.y * wr};
+                a[i + j] = xh_cd{u.x + t.x, u.y + t.y};
+                a[i + j + len / 2] = xh_cd{u.x - t.x, u.y - t.y};
+            }
+    }
+}
+
+struct BlockDesc {   // one S2 workgroup: np particles x nq references
+    int p0, np;      // chunk-local particle index of the first particle
+    int qoff, nq;    // reference slots [qoff, qoff+nq) (dense: reference ids; CSR: index into nbr_ids)
+    int row0;        // row of (particle 0, slot 0)
+    int rowstride;   // rows between consecutive particles of the tile
+};
+}  // namespace
+
+struct xh_pm {
+    xh_ctx *ctx;
+    Layout L;
+    int nrefs, logM, M;
+    double tau_rel, scale, tie_rel;
+    size_t chunk_rows;
+    // static device data
+    XhBuf d_sin, d_cos, d_ringOfSample, d_nsam, d_soff, d_coff, d_rstart;
+    XhBuf d_tw32, d_tw64;        // ring DFT twiddles per ring, [nsamples] complex
+    XhBuf d_refs64, d_refsB, d_refSigma, d_refCoef;
+    XhBuf d_W32;                 // FFT twiddles for length M (float)
+    XhBuf d_chirp, d_vhat;       // Bluestein: chirp[N], vhat[M] (bit-reversed, /M)
+    XhBuf d_csN;                 // cos/sin(2 pi j / N) double, for the fp64 re-scorer
+    XhBuf d_WD64;                // FFT twiddles for length D (double) for S6
+    // per-call scratch
+    XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
+    XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
+    XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
+    XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters;
+    XhBuf d_t1, d_t2, d_t3;      // S6 scratch
+    int64_t stat_rows, stat_resc_p, stat_resc_r;
+};
+
+// =========================================================================== S1 kernels
+// cubic B-spline prefilter, pole sqrt(3)-2, half-sample mirror boundary (xmippCore
+// produceSplineCoefficients; in-tree GPU twin reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41)
+template <typename T>
+__device__ __forceinline__ void d_prefilter_line(T *c, int n, int stride)
+{
+    if (n == 1) return;
+    const T z = (T)(-0.26794919243112270647);   // sqrt(3) - 2
+    const T lambda = (T)6.0;
+    for (int i = 0; i < n; ++i) c[i * stride] *= lambda;
+    T sum = c[0];
+    T zk = z;
+    const int H = 64;                          // |z|^64 ~ 2e-37: below fp64 resolution
+    int k = 1;
+    for (; k <= n && k <= H; ++k) { sum += zk * c[(k - 1) * stride]; zk *= z; }
+    if (n < H) {
+        for (k = n + 1; k <= 2 * n - 1; ++k) { sum += zk * c[(2 * n - k) * stride]; zk *= z; }
+        sum /= ((T)1 - zk);
+    }
+    c[0] = sum;
+    for (int i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
+    c[(n - 1) * stride] = (z / (z - (T)1)) * c[(n - 1) * stride];
+    for (int i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+
+// rows pass through an LDS tile: block = 64 threads handles 32 rows of one image
+template <typename T, typename TIN>
+__global__ void __launch_bounds__(64)
+k_pm_prefilter_rows(const TIN *__restrict__ imgs, const int *__restrict__ gather, T *__restrict__ coefs, int D,
+                    int TR, const int *__restrict__ count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    const int tilesPerImg = (D + TR - 1) / TR;
+    const int slot = blockIdx.x / tilesPerImg;
+    if (count && slot >= *count) return;
+    const int row0 = (blockIdx.x - slot * tilesPerImg) * TR;
+    const int src = gather ? gather[slot] : slot;
+    const int nrow = min(TR, D - row0);
+    const int ld = D + 1;
+    const TIN *in = imgs + (size_t)src * D * D + (size_t)row0 * D;
+    for (int i = threadIdx.x; i < nrow * D; i += 64) {
+        const int r = i / D, c = i - r * D;
+        s[r * ld + c] = (T)in[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nrow) d_prefilter_line(s + threadIdx.x * ld, D, 1);
+    __syncthreads();
+    T *out = coefs + (size_t)slot * D * D + (size_t)row0 * D;
+    for (int i = threadIdx.x; i < nrow * D; i += 64) {
+        const int r = i / D, c = i - r * D;
+        out[i] = s[r * ld + c];
+    }
+}
+
+template <typename T>
+__global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, const int *__restrict__ count)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = gid / D, x = gid - slot * D;
+    if (slot >= nslots) return;
+    if (count && slot >= *count) return;
+    d_prefilter_line(coefs + (size_t)slot * D * D + x, D, D);
+}
+
+template <typename T> __device__ __forceinline__ T d_bspline03(T x)
+{
+    // reconstruction_cuda/cuda_gpu_bilib.cu:16-25
+    T a = fabs(x);
+    if (a < (T)1) return a * a * (a - (T)2) * (T)0.5 + (T)(2.0 / 3.0);
+    if (a < (T)2) { a -= (T)2; return a * a * a * (T)(-1.0 / 6.0); }
+    return (T)0;
+}
+
+// interpolatedElementBSpline2D degree 3 at logical (x,y); reconstruction_cuda/cuda_gpu_multidim_array.cu:78-157
+template <typename T>
+__device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T y)
+{
+    const int start = -(D / 2);
+    x -= (T)start;
+    y -= (T)start;
+    const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
+    int el[4];
+    T wx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int l = l1 + t;
+        wx[t] = d_bspline03<T>(x - (T)l);
+        el[t] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+    }
+    T columns = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int m = m1 + t;
+        const int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
+        const T *ref = coef + (size_t)em * D;
+        T rows = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rows += ref[el[u]] * wx[u];
+        columns += rows * d_bspline03<T>(y - (T)m);
+    }
+    return columns;
+}
+
+template <typename T> __device__ __forceinline__ T d_realwrap(T x, T x0, T xF)
+{
+    if (x >= x0 && x <= xF) return x;
+    if (x < x0) return x - (int)((x - x0) / (xF - x0) - 1) * (xF - x0);
+    return x - (int)((x - xF) / (xF - x0) + 1) * (xF - x0);
+}
+
+__device__ __forceinline__ double d_block_sum(double v, double *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// polar sampling + ring-weighted statistics; one block per particle slot.
+// stat[slot] = (mean, sigma)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restrict__ stat,
+           const float *__restrict__ sinr, const float *__restrict__ cosr, const short *__restrict__ ringOf,
+           const int *__restrict__ nsam, int D, int Ri, int nsamples, double xoff, double yoff,
+           const int *__restrict__ count)
+{
+    __shared__ double red[8];
+    const int slot = blockIdx.x;
+    if (count && slot >= *count) return;
+    const T *c = coefs + (size_t)slot * D * D;
+    const T minp = (T)(-(D / 2)), maxp = (T)(-(D / 2) + D - 1);
+    const T eps = (T)1e-6;
+    double sw = 0, swv = 0, swv2 = 0;
+    for (int i = threadIdx.x; i < nsamples; i += blockDim.x) {
+        T xp = (T)sinr[i] + (T)xoff;
+        T yp = (T)cosr[i] + (T)yoff;
+        if (xp < minp - eps || xp > maxp + eps) xp = d_realwrap<T>(xp, minp - (T)0.5, maxp + (T)0.5);
+        if (yp < minp - eps || yp > maxp + eps) yp = d_realwrap<T>(yp, minp - (T)0.5, maxp + (T)0.5);
+        const T v = d_interp<T>(c, D, xp, yp);
+        polar[(size_t)slot * nsamples + i] = v;
+        const int r = ringOf[i];
+        const double w = (6.2831853071795864769 * (double)(r + Ri)) / (double)nsam[r];
+        const double dv = (double)v;
+        sw += w; swv += w * dv; swv2 += w * dv * dv;
+    }
+    const double N = d_block_sum(sw, red);
+    const double S = d_block_sum(swv, red);
+    const double S2 = d_block_sum(swv2, red);
+    if (threadIdx.x == 0) {
+        double avg = 0, sd = 0;
+        if (N > 0) { avg = S / N; sd = sqrt(fabs(S2 / N - avg * avg)); }
+        stat[2 * slot] = avg;
+        stat[2 * slot + 1] = sd;
+    }
+}
+
+// per-ring direct DFT of (samples - mean), divided by nsam; optional conjugation.
+// grid (ring, slot); twiddle table tw[soff[r]+j] = exp(-2 pi i j / nsam_r)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2<T> *__restrict__ out,
+             const xh_c2<T> *__restrict__ tw, const int *__restrict__ nsam, const int *__restrict__ soff,
+             const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, const int *__restrict__ count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int r = blockIdx.x, slot = blockIdx.y;
+    if (count && slot >= *count) return;
+    const int n = nsam[r];
+    T *x = reinterpret_cast<T *>(smem);
+    xh_c2<T> *w = reinterpret_cast<xh_c2<T> *>(smem + sizeof(T) * ((n + 3) & ~3));
+    const T mean = (T)stat[2 * slot];
+    const T *src = polar + (size_t)slot * nsamples + soff[r];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        x[i] = src[i] - mean;
+        w[i] = tw[soff[r] + i];
+    }
+    __syncthreads();
+    const T inv = (T)1 / (T)n;
+    for (int k = threadIdx.x; k <= n / 2; k += blockDim.x) {
+        T re = 0, im = 0;
+        int j = 0;
+        for (int s = 0; s < n; ++s) {
+            const xh_c2<T> t = w[j];
+            re += x[s] * t.x;
+            im += x[s] * t.y;
+            j += k;
+            if (j >= n) j -= n;
+        }
+        re *= inv;
+        im *= inv;
+        if (conjugate) im = im * (T)(-1);
+        out[(size_t)slot * ncoef + coff[r] + k] = xh_c2<T>{re, im};
+    }
+}
+
+// refsB = float(refs64 * 2*pi*r)
+__global__ void k_pm_pack_refs(const xh_cd *__restrict__ refs64, xh_cf *__restrict__ refsB,
+                               const short *__restrict__ ringOfCoef, int Ri, int ncoef, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % ncoef;
+    const double w = 2. * 3.14159265358979323846 * (double)(ringOfCoef[c] + Ri);
+    const xh_cd v = refs64[i];
+    refsB[i] = xh_cf{(float)(w * v.x), (float)(w * v.y)};
+}
+
+template <typename TI, typename TO>
+__global__ void k_pm_convert(const TI *__restrict__ in, TO *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (TO)in[i];
+}
+
+// =========================================================================== S2
+// thread <-> angular frequency k; register tile PT particles x QT references.
+template <int PT, int QT>
+__global__ void __launch_bounds__(1024)
+k_pm_contract(const BlockDesc *__restrict__ desc, const xh_cf *__restrict__ A, const xh_cf *__restrict__ B,
+              const int *__restrict__ refIds, float4 *__restrict__ raw, const int *__restrict__ coff,
+              const int *__restrict__ rstart, int nrings, int ncoef, int nk)
+{
+    __shared__ int sCoff[512];
+    for (int i = threadIdx.x; i < nrings; i += blockDim.x) sCoff[i] = coff[i];
+    __syncthreads();
+    const BlockDesc d = desc[blockIdx.x];
+    const int k = threadIdx.x;
+    if (k >= nk) return;
+    float acc[PT][QT][4];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[p][q][e] = 0.f;
+    const xh_cf *ap[PT];
+    const xh_cf *bq[QT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) ap[p] = A + (size_t)(d.p0 + (p < d.np ? p : 0)) * ncoef + k;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int slot = d.qoff + (q < d.nq ? q : 0);
+        const int ref = refIds ? refIds[slot] : slot;
+        bq[q] = B + (size_t)ref * ncoef + k;
+    }
+    for (int r = rstart[k]; r < nrings; ++r) {
+        const int o = sCoff[r];
+        xh_cf a[PT], b[QT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) a[p] = ap[p][o];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) b[q] = bq[q][o];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                acc[p][q][0] = fmaf(a[p].x, b[q].x, acc[p][q][0]);   // a*c
+                acc[p][q][1] = fmaf(a[p].x, b[q].y, acc[p][q][1]);   // a*d
+                acc[p][q][2] = fmaf(a[p].y, b[q].x, acc[p][q][2]);   // b*c
+                acc[p][q][3] = fmaf(a[p].y, b[q].y, acc[p][q][3]);   // b*d
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            if (p < d.np && q < d.nq) {
+                const size_t row = (size_t)d.row0 + (size_t)p * d.rowstride + q;
+                raw[row * nk + k] = make_float4(acc[p][q][0], acc[p][q][1], acc[p][q][2], acc[p][q][3]);
+            }
+}
+
+// =========================================================================== S3
+struct RowRes { float best; int idx; float second; int pad; };
+
+__device__ __forceinline__ void d_top2_insert(float v, int i, float &b, int &bi, float &s)
+{
+    // keep (best value, lowest index among equals) and the runner-up value
+    if (v > b || (v == b && i < bi)) { s = b; b = v; bi = i; }
+    else if (v > s) s = v;
+}
+
+template <int LOGM>
+__global__ void __launch_bounds__(256)
+k_pm_idft_max(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ W,
+              const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vhat, int N, int nk, int nrows, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    constexpr int M = 1 << LOGM;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int row0 = blockIdx.x * lpb;
+    const int nl = min(lpb, nrows - row0);
+    // 1. build u[k] = Z[k] * chirp[k], zero padded to M
+    for (int i = tid; i < lpb * M; i += nth) s[i] = xh_cf{0.f, 0.f};
+    __syncthreads();
+    const int half = N / 2;
+    for (int i = tid; i < nl * nk; i += nth) {
+        const int l = i / nk, k = i - l * nk;
+        const float4 q = raw[(size_t)(row0 + l) * nk + k];
+        // Fs = (ac - bd) + i(ad + bc)   [polar.cpp:133-134 with M1 = particle]
+        // Fm = (ac + bd) + i(ad - bc)   [M1 = conj(particle): the mirrored particle, APM:584,710]
+        const float fsr = q.x - q.w, fsi = q.y + q.z;
+        const float fmr = q.x + q.w, fmi = q.y - q.z;
+        xh_cf *u = s + l * M;
+        if (k == 0 || k == half) {
+            // c2r ignores the imaginary part of the DC / Nyquist coefficients
+            u[k] = xh_cmul(xh_cf{fsr, fmr}, chirp[k]);
+        } else {
+            u[k] = xh_cmul(xh_cf{fsr - fmi, fsi + fmr}, chirp[k]);           // Z[k]   = Fs + i Fm
+            u[N - k] = xh_cmul(xh_cf{fsr + fmi, fmr - fsi}, chirp[N - k]);   // Z[N-k] = conj(Fs) + i conj(Fm)
+        }
+    }
+    __syncthreads();
+    // 2-4. circular convolution with the chirp: DIF forward, multiply, DIT inverse
+    xh_fft_dif<float, false>(s, LOGM, lpb, W, LOGM, tid, nth);
+    for (int i = tid; i < lpb * M; i += nth) s[i] = xh_cmul(s[i], vhat[i & (M - 1)]);
+    __syncthreads();
+    xh_fft_dit<float, true>(s, LOGM, lpb, W, LOGM, tid, nth);
+    // 5. z[i] = chirp[i] * y[i]; straight = Re, mirror = Im; per-row top-2
+    __shared__ float rb[4 * 64], rs[4 * 64];
+    __shared__ int ri[4 * 64];
+    const int lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
+    for (int l = 0; l < nl; ++l) {
+        float b = -3.0e38f, sec = -3.0e38f;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < N; i += nth) {
+            const xh_cf z = xh_cmul(s[l * M + i], chirp[i]);
+            d_top2_insert(z.x, i, b, bi, sec);
+            d_top2_insert(z.y, N + i, b, bi, sec);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_down(b, o, 64), os = __shfl_down(sec, o, 64);
+            const int oi = __shfl_down(bi, o, 64);
+            // merge two (best, idx, second) triples
+            if (ob > b || (ob == b && oi < bi)) { sec = fmaxf(b, os); b = ob; bi = oi; }
+            else sec = fmaxf(sec, ob);
+        }
+        if (lane == 0) { rb[wv] = b; ri[wv] = bi; rs[wv] = sec; }
+        __syncthreads();
+        if (tid == 0) {
+            float B = rb[0], S = rs[0];
+            int I = ri[0];
+            for (int w = 1; w < nw; ++w) {
+                const float ob = rb[w], os = rs[w];
+                const int oi = ri[w];
+                if (ob > B || (ob == B && oi < I)) { S = fmaxf(B, os); B = ob; I = oi; }
+                else S = fmaxf(S, ob);
+            }
+            RowRes rr; rr.best = B; rr.idx = I; rr.second = S; rr.pad = 0;
+            res[row0 + l] = rr;
+        }
+        __syncthreads();
+    }
+}
+
+// =========================================================================== S4
+// one block per particle: winner over its rows, ambiguity test, candidate rows for fp64.
+// poff[p], poff[p+1]: row range (chunk-local); refOfRow via refIds (CSR) or row - poff[p] (dense)
+__global__ void __launch_bounds__(256)
+k_pm_select(const RowRes *__restrict__ res, const int *__restrict__ poff, const int *__restrict__ refIds,
+            const double *__restrict__ refSigma, const double *__restrict__ stat32, int pBase,
+            int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip, int N,
+            float tauAbs, int *__restrict__ counters, int *__restrict__ ambList, int *__restrict__ ambSlotOfP,
+            int *__restrict__ candRow)
+{
+    __shared__ float sb[256], ss[256];
+    __shared__ int sr[256];
+    const int p = blockIdx.x;
+    const int r0 = poff[p], r1 = poff[p + 1];
+    const int gp = pBase + p;
+    if (r1 <= r0) {
+        if (threadIdx.x == 0) { refno[gp] = -1; psi[gp] = 0; flip[gp] = 0; ambSlotOfP[p] = -1; }
+        return;
+    }
+    const float sigImg = (float)stat32[2 * p + 1];
+    // per-thread: best normalised row value, its row, and the runner-up value seen
+    float b = -3.0e38f, sec = -3.0e38f;
+    int br = 0x7fffffff;
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const RowRes rr = res[r];
+        const int ref = refIds ? refIds[r] : (r - r0);
+        const float den = (float)refSigma[ref] * sigImg;
+        const float v1 = rr.best / den, v2 = rr.second / den;
+        if (v1 > b || (v1 == b && r < br)) { sec = fmaxf(fmaxf(b, sec), v2); b = v1; br = r; }
+        else sec = fmaxf(sec, v1);     // v2 <= v1 so v1 bounds this row
+    }
+    sb[threadIdx.x] = b; ss[threadIdx.x] = sec; sr[threadIdx.x] = br;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float ob = sb[threadIdx.x + o], os = ss[threadIdx.x + o];
+            const int orow = sr[threadIdx.x + o];
+            float mb = sb[threadIdx.x], ms = ss[threadIdx.x];
+            int mr = sr[threadIdx.x];
+            if (ob > mb || (ob == mb && orow < mr)) { ms = fmaxf(fmaxf(mb, ms), os); mb = ob; mr = orow; }
+            else ms = fmaxf(ms, ob);
+            sb[threadIdx.x] = mb; ss[threadIdx.x] = ms; sr[threadIdx.x] = mr;
+        }
+        __syncthreads();
+    }
+    const float G = sb[0], runner = ss[0];
+    const int wrow = sr[0];
+    __shared__ int sAmb;
+    if (threadIdx.x == 0) {
+        const RowRes rr = res[wrow];
+        refno[gp] = refIds ? refIds[wrow] : (wrow - r0);
+        psi[gp] = rr.idx % N;
+        flip[gp] = rr.idx >= N ? 1 : 0;
+        // NaN-safe: anything that is not clearly separated is re-scored
+        const bool amb = !(runner < G - tauAbs);
+        sAmb = amb ? 1 : 0;
+        if (amb) {
+            const int slot = atomicAdd(&counters[0], 1);
+            ambList[slot] = p;
+            ambSlotOfP[p] = slot;
+        } else ambSlotOfP[p] = -1;
+    }
+    __syncthreads();
+    if (sAmb) {
+        const float thr = G - tauAbs;
+        for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            const RowRes rr = res[r];
+            const int ref = refIds ? refIds[r] : (r - r0);
+            const float den = (float)refSigma[ref] * sigImg;
+            if (!(rr.best / den < thr)) candRow[atomicAdd(&counters[1], 1)] = r;
+        }
+    }
+}
+
+// =========================================================================== S5
+struct CandRes { double val; int idx; int row; };
+
+// fp64 correlation row (straight || mirror) of one candidate; block per candidate row
+__global__ void __launch_bounds__(256)
+k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candRow, const int *__restrict__ rowP,
+                 const int *__restrict__ poff, const int *__restrict__ refIds, const int *__restrict__ ambSlotOfP,
+                 const xh_cd *__restrict__ A64, const xh_cd *__restrict__ refs64, const double *__restrict__ refSigma,
+                 const double *__restrict__ stat64, const xh_cd *__restrict__ csN, const int *__restrict__ nsamv,
+                 const int *__restrict__ coff, int nrings, int Ri, int ncoef, int N, int nk,
+                 CandRes *__restrict__ out, double *__restrict__ dbgRow)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *Fs = reinterpret_cast<xh_cd *>(smem);
+    xh_cd *Fm = Fs + nk;
+    xh_cd *cs = Fm + nk;   // N entries
+    const int c = blockIdx.x;
+    if (c >= counters[1]) return;
+    const int row = candRow[c];
+    const int p = rowP[row];
+    const int ref = refIds ? refIds[row] : (row - poff[p]);
+    const int slot = ambSlotOfP[p];
+    const xh_cd *a = A64 + (size_t)slot * ncoef;
+    const xh_cd *b = refs64 + (size_t)ref * ncoef;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) cs[i] = csN[i];
+    // Fsum (polar.cpp:122-135), ring order ascending, straight and mirrored particle
+    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+        double sr = 0, si = 0, mr = 0, mi = 0;
+        for (int r = 0; r < nrings; ++r) {
+            if (k > nsamv[r] / 2) continue;
+            const double w = 2. * 3.14159265358979323846 * (double)(r + Ri);
+            const xh_cd x = a[coff[r] + k], y = b[coff[r] + k];
+            sr += w * (x.x * y.x - x.y * y.y);
+            si += w * (x.y * y.x + x.x * y.y);
+            // mirrored particle = conj(x): (a, -b)
+            mr += w * (x.x * y.x - (-x.y) * y.y);
+            mi += w * ((-x.y) * y.x + x.x * y.y);
+        }
+        Fs[k] = xh_cd{sr, si};
+        Fm[k] = xh_cd{mr, mi};
+    }
+    __syncthreads();
+    const double den = refSigma[ref] * stat64[2 * slot + 1];
+    double best = -1.0e300;
+    int bi = 0x7fffffff;
+    const int half = N / 2;
+    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) {
+        const xh_cd *F = i < N ? Fs : Fm;
+        const int ii = i < N ? i : i - N;
+        double acc = F[0].x + ((ii & 1) ? -F[half].x : F[half].x);
+        int j = 0;
+        double t = 0;
+        for (int k = 1; k < half; ++k) {
+            j += ii;
+            if (j >= N) j -= N;
+            t += F[k].x * cs[j].x - F[k].y * cs[j].y;
+        }
+        acc += 2.0 * t;
+        const double v = acc / den;
+        if (dbgRow) dbgRow[i] = v;
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    __shared__ double sbv[256];
+    __shared__ int sbi[256];
+    sbv[threadIdx.x] = best; sbi[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double ov = sbv[threadIdx.x + o];
+            const int oi = sbi[threadIdx.x + o];
+            if (ov > sbv[threadIdx.x] || (ov == sbv[threadIdx.x] && oi < sbi[threadIdx.x])) { sbv[threadIdx.x] = ov; sbi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { CandRes r; r.val = sbv[0]; r.idx = sbi[0]; r.row = row; out[c] = r; }
+}
+
+// exact pick for each ambiguous particle: the reference visits references forward for even images
+// and backward for odd ones and replaces the incumbent only on a strictly greater value
+// (APM:609-626,715-735,1112) => among (near-)equal maxima the earliest visited row wins.
+__global__ void k_pm_pick(const int *__restrict__ counters, const int *__restrict__ ambList,
+                          const CandRes *__restrict__ cand, const int *__restrict__ rowP, const int *__restrict__ poff,
+                          const int *__restrict__ refIds, int pBase, int parity, int N, double tieAbs,
+                          int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= counters[0]) return;
+    const int p = ambList[a];
+    const int nc = counters[1];
+    const bool forward = (((pBase + p + parity) & 1) == 0);
+    const int r0 = poff[p], r1 = poff[p + 1];
+    double best = -1.0e300;
+    for (int c = 0; c < nc; ++c)
+        if (rowP[cand[c].row] == p && cand[c].val > best) best = cand[c].val;
+    int bestRow = -1, bestIdx = 0, bestOrder = 0x7fffffff;
+    for (int c = 0; c < nc; ++c) {
+        const int row = cand[c].row;
+        if (rowP[row] != p) continue;
+        if (cand[c].val >= best - tieAbs) {
+            const int order = forward ? (row - r0) : (r1 - 1 - row);
+            if (order < bestOrder) { bestOrder = order; bestRow = row; bestIdx = cand[c].idx; }
+        }
+    }
+    if (bestRow >= 0) {
+        const int gp = pBase + p;
+        refno[gp] = refIds ? refIds[bestRow] : (bestRow - r0);
+        psi[gp] = bestIdx % N;
+        flip[gp] = bestIdx >= N ? 1 : 0;
+    }
+}
+
+// fp32 debug: full row from the S3 pipeline
+template <int LOGM>
+__global__ void __launch_bounds__(256)
+k_pm_idft_dump(const float4 *__restrict__ raw, float *__restrict__ out, const xh_cf *__restrict__ W,
+               const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vhat, int N, int nk)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    constexpr int M = 1 << LOGM;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < M; i += nth) s[i] = xh_cf{0.f, 0.f};
+    __syncthreads();
+    const int half = N / 2;
+    for (int k = tid; k < nk; k += nth) {
+        const float4 q = raw[k];
+        const float fsr = q.x - q.w, fsi = q.y + q.z, fmr = q.x + q.w, fmi = q.y - q.z;
+        if (k == 0 || k == half) s[k] = xh_cmul(xh_cf{fsr, fmr}, chirp[k]);
+        else {
+            s[k] = xh_cmul(xh_cf{fsr - fmi, fsi + fmr}, chirp[k]);
+            s[N - k] = xh_cmul(xh_cf{fsr + fmi, fmr - fsi}, chirp[N - k]);
+        }
+    }
+    __syncthreads();
+    xh_fft_dif<float, false>(s, LOGM, 1, W, LOGM, tid, nth);
+    for (int i = tid; i < M; i += nth) s[i] = xh_cmul(s[i], vhat[i]);
+    __syncthreads();
+    xh_fft_dit<float, true>(s, LOGM, 1, W, LOGM, tid, nth);
+    for (int i = tid; i < N; i += nth) {
+        const xh_cf z = xh_cmul(s[i], chirp[i]);
+        out[i] = z.x;
+        out[N + i] = z.y;
+    }
+}
+
+// =========================================================================== S6 (fp64)
+// Mref = rotate(BSPLINE3, ref, psi, DONT_WRAP) (APM:812); Mimg = mirrored particle (APM:820-828).
+// Packed as z = Mref + i*Mimg for one complex 2-D FFT.
+__global__ void k_pm_rot_mirror(const float *__restrict__ particles, const double *__restrict__ refCoef,
+                                const int *__restrict__ refno, const int *__restrict__ psi,
+                                const unsigned char *__restrict__ flip, xh_cd *__restrict__ z, int D, int N)
+{
+    const int p = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= D * D) return;
+    const int i = pix / D, j = pix - i * D;
+    const int ref = refno[p];
+    xh_cd out = xh_cd{0., 0.};
+    if (ref >= 0) {
+        const int cen = D / 2;
+        const double ang = (double)psi[p] * (360. / (double)N) * 3.14159265358979323846 / 180.0;
+        // rotation2DMatrix(ang) = [[c, s],[-s, c]]; IS_NOT_INV => sample at A^-1 (x,y)
+        const double c = cos(ang), s = sin(ang);
+        const double x = j - cen, y = i - cen;
+        const double xp = c * x - s * y, yp = s * x + c * y;    // A^-1 = [[c,-s],[s,c]]
+        const double minp = -cen, maxp = D - cen - 1;
+        if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6))
+            out.x = d_interp<double>(refCoef + (size_t)ref * D * D, D, xp, yp);
+        const float *img = particles + (size_t)p * D * D;
+        if (flip[p]) {
+            // applyGeometry(LINEAR, A = diag(-1,1,1), IS_INV, DONT_WRAP): xp = -x, integer => exact copy
+            const double mx = -(double)(j - cen);
+            if (!(mx < minp - 1e-6 || mx > maxp + 1e-6)) out.y = (double)img[(size_t)i * D + (2 * cen - j)];
+        } else out.y = (double)img[pix];
+    }
+    z[(size_t)p * D * D + pix] = out;
+}
+
+// product FFT1 * conj(FFT2) * N from the packed spectrum Z (FFT of Mref + i Mimg), in place.
+// F1[k] = (Z[k] + conj(Z[-k]))/2, F2[k] = (Z[k] - conj(Z[-k]))/(2i); forward FFTs are /N in the
+// reference and the product is multiplied by N (xmippCore correlation_matrix) => net 1/N.
+__global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__ Pout, int D)
+{
+    const int p = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= D * D) return;
+    const int i = pix / D, j = pix - i * D;
+    const int ni = (D - i) & (D - 1), nj = (D - j) & (D - 1);
+    const xh_cd a = Z[(size_t)p * D * D + pix];
+    const xh_cd b = Z[(size_t)p * D * D + (size_t)ni * D + nj];
+    const xh_cd f1 = xh_cd{0.5 * (a.x + b.x), 0.5 * (a.y - b.y)};
+    const xh_cd f2 = xh_cd{0.5 * (a.y + b.y), -0.5 * (a.x - b.x)};
+    const double inv = 1.0 / ((double)D * (double)D);
+    xh_cd r = xh_cmulc(f1, f2);
+    r.x *= inv;
+    r.y *= inv;
+    Pout[(size_t)p * D * D + pix] = r;
+}
+
+// bestShift on the centred correlation map (FIL:1593-1719, mask == nullptr, maxShift == -1),
+// max_shift rejection (APM:841-842), translate(LINEAR, wrap) + correlationIndex (APM:850-851).
+// One block per particle. R = real part of the inverse FFT, un-centred (zero lag at index 0).
+__global__ void __launch_bounds__(256)
+k_pm_bestshift(const xh_cd *__restrict__ Rraw, const xh_cd *__restrict__ zimg, const int *__restrict__ refno,
+               const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
+               double *__restrict__ shiftY, double *__restrict__ maxCC)
+{
+    __shared__ double red[8];
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    __shared__ double sh[2];
+    const int p = blockIdx.x;
+    if (refno[p] < 0) {
+        if (threadIdx.x == 0) { shiftX[p] = 0; shiftY[p] = 0; maxCC[p] = 0; }
+        return;
+    }
+    const int n = D * D, cen = D / 2;
+    const xh_cd *R = Rraw + (size_t)p * n;
+    // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
+#define RC(i, j) (R[(size_t)(((i) - cen) & (D - 1)) * D + (((j) - cen) & (D - 1))].x)
+    double s1 = 0, s2 = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[t].x; s1 += v; s2 += v * v; }
+    const double S1 = d_block_sum(s1, red), S2 = d_block_sum(s2, red);
+    const double avg = S1 / n;
+    double sd = sqrt(fabs(S2 / n - avg * avg));
+    const double a = sd != 0 ? 1.0 / sd : 0.0, b = sd != 0 ? -avg * a : 0.0;   // statisticsAdjust(0,1)
+    // first maximum in raster order of the centred map
+    double bv = -1.0e300;
+    int bi = 0x7fffffff;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int i = t / D, j = t - i * D;
+        const double v = a * RC(i, j) + b;
+        if (v > bv || (v == bv && t < bi)) { bv = v; bi = t; }
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double ov = sv[threadIdx.x + o];
+            const int oi = si[threadIdx.x + o];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int start = -cen, fin = start + D - 1;
+        const int imax = si[0] / D + start, jmax = si[0] % D + start;
+        const double mx = sv[0];
+#define MC(li, lj) (a * RC((li) - start, (lj) - start) + b)
+        bool neighbourhood = true;
+        int n_max = -1;
+        while (neighbourhood) {
+            n_max++;
+            for (int i = -n_max; i <= n_max && neighbourhood; i++) {
+                const int ia = i + imax;
+                if (ia < start || ia > fin) { neighbourhood = false; break; }
+                for (int j = -n_max; j <= n_max && neighbourhood; j++) {
+                    const int ja = j + jmax;
+                    if (ja < start || ja > fin) { neighbourhood = false; break; }
+                    else if (mx / 1.414 > MC(ia, ja)) { neighbourhood = false; break; }
+                }
+            }
+        }
+        if (imax - n_max < start) n_max = min(imax - start, n_max);
+        if (imax + n_max > fin) n_max = min(fin - imax, n_max);
+        if (jmax - n_max < start) n_max = min(jmax - start, n_max);
+        if (jmax + n_max > fin) n_max = min(fin - jmax, n_max);
+        double xmax = 0, ymax = 0, sumcorr = 0;
+        for (int i = -n_max; i <= n_max; i++)
+            for (int j = -n_max; j <= n_max; j++) {
+                const int ia = i + imax, ja = j + jmax;
+                const double val = MC(ia, ja);
+                ymax += ia * val;
+                xmax += ja * val;
+                sumcorr += val;
+            }
+        double ox = 0, oy = 0;
+        if (sumcorr != 0) { ox = xmax / sumcorr; oy = ymax / sumcorr; }
+        if (!(maxShift > 0)) ox = oy = 0.;
+        if (ox * ox + oy * oy > maxShift * maxShift) ox = oy = 0.;
+        sh[0] = ox; sh[1] = oy;
+#undef MC
+    }
+    __syncthreads();
+#undef RC
+    const double ox = sh[0], oy = sh[1];
+    // Mtrans = translate(LINEAR, Mimg, (ox,oy), WRAP): out(x,y) samples Mimg at (x-ox, y-oy)
+    // correlationIndex(Mref, Mtrans): population statistics
+    const xh_cd *Z = zimg + (size_t)p * n;    // .x = Mref, .y = Mimg
+    const double minp = -cen, maxp = D - cen - 1;
+    double sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int i = t / D, j = t - i * D;
+        double xp = (double)(j - cen) - ox, yp = (double)(i - cen) - oy;
+        double val;
+        if (ox == 0.0 && oy == 0.0) val = Z[t].y;      // identity matrix: applyGeometry copies
+        else {
+            if (xp < minp - 1e-6 || xp > maxp + 1e-6) xp = d_realwrap<double>(xp, minp - 0.5, maxp + 0.5);
+            if (yp < minp - 1e-6 || yp > maxp + 1e-6) yp = d_realwrap<double>(yp, minp - 0.5, maxp + 0.5);
+            double wx = xp + cen;
+            const int m1 = (int)wx;
+            wx = wx - m1;
+            int m2 = m1 + 1;
+            double wy = yp + cen;
+            const int n1 = (int)wy;
+            wy = wy - n1;
+            int n2 = n1 + 1;
+            if (m2 >= D) m2 = 0;
+            if (n2 >= D) n2 = 0;
+            const double wx_1 = 1 - wx, wy_1 = 1 - wy;
+            double aux2 = wy_1 * wx_1;
+            double tmp = aux2 * Z[(size_t)n1 * D + m1].y;
+            if (wx != 0 && m2 < D) tmp += (wy_1 - aux2) * Z[(size_t)n1 * D + m2].y;
+            if (wy != 0 && n2 < D) {
+                aux2 = wy * wx_1;
+                tmp += aux2 * Z[(size_t)n2 * D + m1].y;
+                if (wx != 0 && m2 < D) tmp += (wy - aux2) * Z[(size_t)n2 * D + m2].y;
+            }
+            val = tmp;
+        }
+        const double r = Z[t].x;
+        sx += r; sxx += r * r; sy += val; syy += val * val; sxy += r * val;
+    }
+    const double SX = d_block_sum(sx, red), SXX = d_block_sum(sxx, red), SY = d_block_sum(sy, red);
+    const double SYY = d_block_sum(syy, red), SXY = d_block_sum(sxy, red);
+    if (threadIdx.x == 0) {
+        const double mxr = SX / n, myr = SY / n;
+        const double sdx = sqrt(fabs(SXX / n - mxr * mxr)), sdy = sqrt(fabs(SYY / n - myr * myr));
+        double cc = 0;
+        if (!(fabs(sdx) < 1e-6 || fabs(sdy) < 1e-6)) cc = (SXY - n * mxr * myr) / ((sdx * sdy) * n);
+        maxCC[p] = cc;
+        shiftX[p] = flip[p] ? -ox : ox;     // APM:858-859
+        shiftY[p] = oy;
+    }
+}
+
+// generic strided complex line FFT (same as in xh_rf.hip; duplicated to keep TUs independent)
+template <typename T, bool INV>
+__global__ void __launch_bounds__(256)
+k_pm_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int logn, size_t nlinesTotal,
+               size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
+    const int n = 1 << logn;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const size_t line0 = (size_t)blockIdx.x * lpb;
+    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;
+        xh_c2<T> v = xh_c2<T>{0, 0};
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
+        }
+        s[l * n + xh_bitrev(e, logn)] = v;
+    }
+    __syncthreads();
+    xh_fft_dit<T, INV>(s, logn, lpb, W, logn, tid, nth);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * n + e];
+        }
+    }
+}
+
+// =========================================================================== host
+template <typename T>
+static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d_gather, int nslots,
+                    const int *d_count, XhBuf &coefBuf, XhBuf &polarBuf, XhBuf &outBuf, XhBuf &statBuf,
+                    const XhBuf &twBuf, bool conjugate, double xoff, double yoff)
+{
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    const int D = L.D;
+    XH_TRY(xh_buf_reserve(ctx, coefBuf, sizeof(T) * (size_t)nslots * D * D));
+    XH_TRY(xh_buf_reserve(ctx, polarBuf, sizeof(T) * (size_t)nslots * L.nsamples));
+    XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * (size_t)nslots * L.ncoef));
+    XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * (size_t)nslots));
+    const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(T)))));
+    const int tiles = (D + TR - 1) / TR;
+    const size_t smem = sizeof(T) * TR * (D + 1);
+    if (imgsAreFloat)
+        hipLaunchKernelGGL((k_pm_prefilter_rows<T, float>), dim3(nslots * tiles), dim3(64), smem, ctx->stream,
+                           (const float *)imgs, d_gather, (T *)coefBuf.p, D, TR, d_count);
+    else
+        hipLaunchKernelGGL((k_pm_prefilter_rows<T, double>), dim3(nslots * tiles), dim3(64), smem, ctx->stream,
+                           (const double *)imgs, d_gather, (T *)coefBuf.p, D, TR, d_count);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_pm_prefilter_cols<T>), dim3((nslots * D + 63) / 64), dim3(64), 0, ctx->stream,
+                       (T *)coefBuf.p, D, nslots, d_count);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_pm_polar<T>), dim3(nslots), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
+                       (double *)statBuf.p, (const float *)pm->d_sin.p, (const float *)pm->d_cos.p,
+                       (const short *)pm->d_ringOfSample.p, (const int *)pm->d_nsam.p, D, L.Ri, L.nsamples, xoff, yoff,
+                       d_count);
+    XH_LAUNCH_CHECK();
+    const size_t smem2 = sizeof(T) * ((L.N + 3) & ~3) + sizeof(xh_c2<T>) * L.N;
+    hipLaunchKernelGGL((k_pm_ringdft<T>), dim3(L.nrings, nslots), dim3(256), smem2, ctx->stream, (const T *)polarBuf.p,
+                       (const double *)statBuf.p, (xh_c2<T> *)outBuf.p, (const xh_c2<T> *)twBuf.p,
+                       (const int *)pm->d_nsam.p, (const int *)pm->d_soff.p, (const int *)pm->d_coff.p, L.nsamples,
+                       L.ncoef, conjugate ? 1 : 0, d_count);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+template <typename T> static int upload(xh_ctx *ctx, XhBuf &b, const std::vector<T> &v)
+{
+    XH_TRY(xh_buf_alloc(ctx, b, sizeof(T) * v.size()));
+    XH_HIP(hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+static void free_all(xh_pm *pm)
+{
+    XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart,
+                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32,
+                     &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
+                     &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
+                     &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
+                     &pm->d_counters, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+    for (XhBuf *b : bufs) xh_buf_free(*b);
+}
+
+template <int LOGM>
+static void launch_idft(xh_pm *pm, int nrows, int lpb, size_t smem)
+{
+    hipLaunchKernelGGL((k_pm_idft_max<LOGM>), dim3((nrows + lpb - 1) / lpb), dim3(256), smem, pm->ctx->stream,
+                       (const float4 *)pm->d_raw.p, (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_W32.p,
+                       (const xh_cf *)pm->d_chirp.p, (const xh_cf *)pm->d_vhat.p, pm->L.N, pm->L.nk, nrows, lpb);
+}
+template <int LOGM>
+static void launch_idft_dump(xh_pm *pm, float *d_out, size_t smem)
+{
+    hipLaunchKernelGGL((k_pm_idft_dump<LOGM>), dim3(1), dim3(256), smem, pm->ctx->stream, (const float4 *)pm->d_raw.p, d_out,
+                       (const xh_cf *)pm->d_W32.p, (const xh_cf *)pm->d_chirp.p, (const xh_cf *)pm->d_vhat.p, pm->L.N,
+                       pm->L.nk);
+}
+
+extern "C" {
+
+int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, const float *d_refs,
+                 const double *h_Mctf, int32_t paddim, xh_pm **out)
+{
+    XH_CHECK(ctx && d_refs && out && nrefs > 0, XH_ERR_ARG, "xh_pm_create: bad argument");
+    XH_CHECK(h_Mctf == nullptr, XH_ERR_UNSUPPORTED,
+             "xh_pm_create: --ctf filtering of the references (APM:457-481) is not available on the device yet; "
+             "apply it to the reference stack before upload");
+    if (Ri < 1) Ri = 1;               // APM:266-274
+    if (Ro < 0) Ro = (D / 2) - 1;
+    XH_CHECK(D >= 8 && Ro >= Ri && Ro < D, XH_ERR_ARG, "xh_pm_create: bad geometry D=%d Ri=%d Ro=%d", D, Ri, Ro);
+    XH_HIP(hipSetDevice(ctx->device));
+    xh_pm *pm = new xh_pm;
+    pm->ctx = ctx;
+    pm->nrefs = nrefs;
+    make_layout(pm->L, D, Ri, Ro);
+    Layout &L = pm->L;
+    if (L.nk > 1024 || L.nrings > 512) {
+        xh_set_error("xh_pm_create: Ro=%d gives %d angular frequencies / %d rings; limits are 1024 / 512", Ro, L.nk, L.nrings);
+        delete pm;
+        return XH_ERR_UNSUPPORTED;
+    }
+    pm->M = 1;
+    while (pm->M < 2 * L.N - 1) pm->M <<= 1;
+    pm->logM = xh_ilog2(pm->M);
+    if (pm->logM < 6 || pm->logM > 12) {
+        xh_set_error("xh_pm_create: convolution length %d outside the supported 64..4096", pm->M);
+        delete pm;
+        return XH_ERR_UNSUPPORTED;
+    }
+    pm->scale = 0;
+    for (int r = 0; r < L.nrings; ++r) pm->scale += 2. * kPI * (r + Ri);
+    pm->tau_rel = 2e-5;
+    pm->tie_rel = 1e-12;
+    pm->chunk_rows = 0;
+    pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    int rc = XH_OK;
+    {
+        // float angle cache, polar.cpp:57-83
+        std::vector<float> sn(L.nsamples), cs(L.nsamples);
+        std::vector<short> ringOf(L.nsamples), ringOfCoef(L.ncoef);
+        std::vector<xh_cf> tw32(L.nsamples);
+        std::vector<xh_cd> tw64(L.nsamples);
+        for (int r = 0; r < L.nrings; ++r) {
+            const float radius = r + Ri;
+            const int n = L.nsam[r];
+            const float dphi = kTWOPI / (float)n;
+            for (int i = 0; i < n; ++i) {
+                const float phi = i * dphi;
+                sn[L.soff[r] + i] = std::sin(phi) * radius;
+                cs[L.soff[r] + i] = std::cos(phi) * radius;
+                ringOf[L.soff[r] + i] = (short)r;
+                const long double a = -2.0L * 3.14159265358979323846264338327950288L * i / n;
+                tw64[L.soff[r] + i] = xh_cd{(double)cosl(a), (double)sinl(a)};
+                tw32[L.soff[r] + i] = xh_cf{(float)cosl(a), (float)sinl(a)};
+            }
+            for (int k = 0; k <= n / 2; ++k) ringOfCoef[L.coff[r] + k] = (short)r;
+        }
+        std::vector<int> rstart(L.nk);
+        for (int k = 0; k < L.nk; ++k) {
+            int r = 0;
+            while (r < L.nrings && L.nsam[r] / 2 < k) ++r;
+            rstart[k] = r;
+        }
+        // FFT twiddles, Bluestein chirp and kernel spectrum
+        const int M = pm->M, N = L.N;
+        std::vector<xh_cf> W32(M / 2), chirp(N), vbr(M);
+        for (int j = 0; j < M / 2; ++j) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / M;
+            W32[j] = xh_cf{(float)cosl(a), (float)sinl(a)};
+        }
+        std::vector<xh_cd> b(M, xh_cd{0., 0.});
+        for (int n2 = 0; n2 < N; ++n2) {
+            const long long q = ((long long)n2 * n2) % (2LL * N);
+            const long double a = 3.14159265358979323846264338327950288L * (long double)q / (long double)N;
+            chirp[n2] = xh_cf{(float)cosl(a), (float)sinl(a)};                // exp(+i pi n^2 / N)
+            const xh_cd v{(double)cosl(a), (double)-sinl(a)};                 // exp(-i pi n^2 / N)
+            b[n2] = v;
+            if (n2 > 0) b[M - n2] = v;
+        }
+        h_fft(b, false);
+        for (int j = 0; j < M; ++j) {
+            unsigned rev = 0;
+            for (int t = 0; t < pm->logM; ++t) if (j & (1 << t)) rev |= 1u << (pm->logM - 1 - t);
+            vbr[j] = xh_cf{(float)(b[rev].x / M), (float)(b[rev].y / M)};
+        }
+        std::vector<xh_cd> csN(N);
+        for (int j = 0; j < N; ++j) {
+            const long double a = 2.0L * 3.14159265358979323846264338327950288L * j / N;
+            csN[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
+        }
+        std::vector<xh_cd> WD(std::max(1, D / 2));
+        for (int j = 0; j < D / 2; ++j) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / D;
+            WD[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
+        }
+        XhBuf d_ringOfCoef;
+        if (rc == XH_OK) rc = upload(ctx, pm->d_sin, sn);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_cos, cs);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_ringOfSample, ringOf);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_nsam, L.nsam);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_soff, L.soff);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_coff, L.coff);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_rstart, rstart);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_tw32, tw32);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_tw64, tw64);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_W32, W32);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_chirp, chirp);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_vhat, vbr);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_csN, csN);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_WD64, WD);
+        if (rc == XH_OK) rc = upload(ctx, d_ringOfCoef, ringOfCoef);
+        // reference library in fp64: getCurrentReference (APM:484-488) for every reference
+        const int RB = 64;   // references per batch
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refs64, sizeof(xh_cd) * (size_t)nrefs * L.ncoef);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refsB, sizeof(xh_cf) * (size_t)nrefs * L.ncoef);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refSigma, sizeof(double) * nrefs);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refCoef, sizeof(double) * (size_t)nrefs * D * D);
+        std::vector<double> stat(2 * RB), sig(nrefs);
+        for (int r0 = 0; r0 < nrefs && rc == XH_OK; r0 += RB) {
+            const int m = std::min(RB, nrefs - r0);
+            rc = run_prep<double>(pm, d_refs + (size_t)r0 * D * D, true, nullptr, m, nullptr, pm->d_coef64, pm->d_polar64,
+                                  pm->d_A64, pm->d_stat64, pm->d_tw64, true, 0., 0.);
+            if (rc != XH_OK) break;
+            if (hipMemcpyAsync((xh_cd *)pm->d_refs64.p + (size_t)r0 * L.ncoef, pm->d_A64.p, sizeof(xh_cd) * (size_t)m * L.ncoef,
+                               hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync((double *)pm->d_refCoef.p + (size_t)r0 * D * D, pm->d_coef64.p, sizeof(double) * (size_t)m * D * D,
+                               hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(stat.data(), pm->d_stat64.p, sizeof(double) * 2 * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                xh_set_error("xh_pm_create: reference library copy failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = XH_ERR_HIP;
+                break;
+            }
+            for (int i = 0; i < m; ++i) sig[r0 + i] = stat[2 * i + 1];
+        }
+        if (rc == XH_OK && hipMemcpy(pm->d_refSigma.p, sig.data(), sizeof(double) * nrefs, hipMemcpyHostToDevice) != hipSuccess) {
+            xh_set_error("xh_pm_create: sigma upload failed");
+            rc = XH_ERR_HIP;
+        }
+        if (rc == XH_OK) {
+            const size_t total = (size_t)nrefs * L.ncoef;
+            hipLaunchKernelGGL(k_pm_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const xh_cd *)pm->d_refs64.p, (xh_cf *)pm->d_refsB.p, (const short *)d_ringOfCoef.p, Ri, L.ncoef, total);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                xh_set_error("xh_pm_create: pack kernel failed");
+                rc = XH_ERR_HIP;
+            }
+        }
+        xh_buf_free(d_ringOfCoef);
+    }
+    if (rc != XH_OK) { free_all(pm); delete pm; return rc; }
+    *out = pm;
+    return XH_OK;
+}
+
+int xh_pm_destroy(xh_pm *pm)
+{
+    if (!pm) return XH_OK;
+    (void)hipStreamSynchronize(pm->ctx->stream);
+    free_all(pm);
+    delete pm;
+    return XH_OK;
+}
+
+int xh_pm_info(const xh_pm *pm, int32_t *N, int32_t *ncoef, int32_t *nsamples)
+{
+    XH_CHECK(pm, XH_ERR_ARG, "null handle");
+    if (N) *N = pm->L.N;
+    if (ncoef) *ncoef = pm->L.ncoef;
+    if (nsamples) *nsamples = pm->L.nsamples;
+    return XH_OK;
+}
+
+int xh_pm_set_option(xh_pm *pm, const char *name, double value)
+{
+    XH_CHECK(pm && name, XH_ERR_ARG, "null argument");
+    if (!strcmp(name, "tau_rel")) pm->tau_rel = value;
+    else if (!strcmp(name, "tie_rel")) pm->tie_rel = value;
+    else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
+    else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
+    return XH_OK;
+}
+
+int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
+{
+    XH_CHECK(pm, XH_ERR_ARG, "null handle");
+    if (rows) *rows = pm->stat_rows;
+    if (rp) *rp = pm->stat_resc_p;
+    if (rr) *rr = pm->stat_resc_r;
+    return XH_OK;
+}
+
+// S2+S3 for a prepared chunk. h_poff: chunk-local row offsets [m+1]; d_ids device ref ids per row or null (dense)
+static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq)
+{
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    const int nrows = poff[m];
+    if (nrows == 0) return XH_OK;
+    XH_TRY(xh_buf_reserve(ctx, pm->d_raw, sizeof(float4) * (size_t)nrows * L.nk));
+    XH_TRY(xh_buf_reserve(ctx, pm->d_rowres, sizeof(RowRes) * (size_t)nrows));
+    std::vector<BlockDesc> desc;
+    const int PT = 4, QT = 4;
+    if (dense) {
+        for (int p0 = 0; p0 < m; p0 += PT)
+            for (int q0 = 0; q0 < nq; q0 += QT) {
+                BlockDesc d;
+                d.p0 = p0; d.np = std::min(PT, m - p0); d.qoff = q0; d.nq = std::min(QT, nq - q0);
+                d.row0 = p0 * nq + q0; d.rowstride = nq;
+                desc.push_back(d);
+            }
+    } else {
+        for (int p = 0; p < m; ++p)
+            for (int q0 = poff[p]; q0 < poff[p + 1]; q0 += 8) {
+                BlockDesc d;
+                d.p0 = p; d.np = 1; d.qoff = q0; d.nq = std::min(8, poff[p + 1] - q0);
+                d.row0 = q0; d.rowstride = 0;
+                desc.push_back(d);
+            }
+    }
+    XH_TRY(xh_buf_reserve(ctx, pm->d_desc, sizeof(BlockDesc) * desc.size()));
+    XH_HIP(hipMemcpyAsync(pm->d_desc.p, desc.data(), sizeof(BlockDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    const int nt = ((L.nk + 63) / 64) * 64;
+    if (dense)
+        hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
+                           (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,
+                           (const int *)nullptr, (float4 *)pm->d_raw.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p,
+                           L.nrings, L.ncoef, L.nk);
+    else
+        hipLaunchKernelGGL((k_pm_contract<1, 8>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
+                           (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p, d_ids,
+                           (float4 *)pm->d_raw.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p, L.nrings, L.ncoef, L.nk);
+    XH_LAUNCH_CHECK();
+    const int lpb = std::max(1, std::min(4, (60 * 1024) / (int)(pm->M * sizeof(xh_cf))));
+    const size_t smem = (size_t)lpb * pm->M * sizeof(xh_cf);
+    switch (pm->logM) {
+        case 6: launch_idft<6>(pm, nrows, lpb, smem); break;
+        case 7: launch_idft<7>(pm, nrows, lpb, smem); break;
+        case 8: launch_idft<8>(pm, nrows, lpb, smem); break;
+        case 9: launch_idft<9>(pm, nrows, lpb, smem); break;
+        case 10: launch_idft<10>(pm, nrows, lpb, smem); break;
+        case 11: launch_idft<11>(pm, nrows, lpb, smem); break;
+        default: launch_idft<12>(pm, nrows, lpb, smem); break;
+    }
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off, const int32_t *h_nbr_ids,
+                int32_t parity, int32_t *d_refno, int32_t *d_psi, uint8_t *d_flip)
+{
+    XH_CHECK(pm && d_particles && d_refno && d_psi && d_flip && n >= 0, XH_ERR_ARG, "xh_pm_match: bad argument");
+    XH_CHECK((h_nbr_off == nullptr) == (h_nbr_ids == nullptr), XH_ERR_ARG, "xh_pm_match: neighbour arrays go together");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    const int D = L.D;
+    const bool dense = h_nbr_off == nullptr;
+    if (!dense)
+        for (int i = 0; i < h_nbr_off[n]; ++i)
+            XH_CHECK(h_nbr_ids[i] >= 0 && h_nbr_ids[i] < pm->nrefs, XH_ERR_ARG, "xh_pm_match: reference id %d out of range", h_nbr_ids[i]);
+    pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
+    const size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, (size_t)(512u << 20) / (L.nk * sizeof(float4)));
+    const float tauAbs = (float)(pm->tau_rel * pm->scale);
+    const double tieAbs = pm->tie_rel * pm->scale;
+    int p0 = 0;
+    while (p0 < n) {
+        // particles of this chunk
+        int m = 0;
+        size_t rows = 0;
+        while (p0 + m < n && m < 4096) {
+            const size_t nn = dense ? (size_t)pm->nrefs : (size_t)(h_nbr_off[p0 + m + 1] - h_nbr_off[p0 + m]);
+            if (m > 0 && rows + nn > maxRows) break;
+            rows += nn;
+            ++m;
+        }
+        std::vector<int> poff(m + 1), rowP(rows);
+        poff[0] = 0;
+        for (int i = 0; i < m; ++i) {
+            const int nn = dense ? pm->nrefs : (h_nbr_off[p0 + i + 1] - h_nbr_off[p0 + i]);
+            poff[i + 1] = poff[i] + nn;
+            for (int r = poff[i]; r < poff[i + 1]; ++r) rowP[r] = i;
+        }
+        const int nrows = (int)rows;
+        XH_TRY(xh_buf_reserve(ctx, pm->d_poff, sizeof(int) * (m + 1 + rows)));
+        int *d_poff = (int *)pm->d_poff.p, *d_rowP = d_poff + (m + 1);
+        XH_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice, ctx->stream));
+        if (rows) XH_HIP(hipMemcpyAsync(d_rowP, rowP.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+        const int *d_ids = nullptr;
+        if (!dense && rows) {
+            XH_TRY(xh_buf_reserve(ctx, pm->d_nbr, sizeof(int) * rows));
+            XH_HIP(hipMemcpyAsync(pm->d_nbr.p, h_nbr_ids + h_nbr_off[p0], sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+            d_ids = (const int *)pm->d_nbr.p;
+        }
+        XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
+        // S1 fp32
+        XH_TRY(run_prep<float>(pm, d_particles + (size_t)p0 * D * D, true, nullptr, m, nullptr, pm->d_coef32, pm->d_polar32,
+                               pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0.));
+        // S2 + S3
+        XH_TRY(run_rows(pm, m, poff, d_ids, dense, pm->nrefs));
+        // S4
+        XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_ambList, sizeof(int) * m));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_ambSlot, sizeof(int) * m));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_candRow, sizeof(int) * std::max<size_t>(1, rows)));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_candRes, sizeof(CandRes) * std::max<size_t>(1, rows)));
+        XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_pm_select, dim3(m), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p, (const int *)d_poff,
+                           d_ids, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p, p0, d_refno, d_psi, d_flip,
+                           L.N, tauAbs, (int *)pm->d_counters.p, (int *)pm->d_ambList.p, (int *)pm->d_ambSlot.p,
+                           (int *)pm->d_candRow.p);
+        XH_LAUNCH_CHECK();
+        // S5: read the counters (tiny D2H) to size the fp64 work
+        int counters[4];
+        XH_HIP(hipMemcpyAsync(counters, pm->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+        pm->stat_rows += nrows;
+        pm->stat_resc_p += counters[0];
+        pm->stat_resc_r += counters[1];
+        if (counters[0] > 0) {
+            const int na = counters[0], nc = counters[1];
+            XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, (const int *)pm->d_ambList.p, na, nullptr,
+                                    pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64, pm->d_tw64, false, 0., 0.));
+            const size_t smem = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N);
+            hipLaunchKernelGGL(k_pm_rescore_row, dim3(nc), dim3(256), smem, ctx->stream, (const int *)pm->d_counters.p,
+                               (const int *)pm->d_candRow.p, (const int *)d_rowP, (const int *)d_poff, d_ids,
+                               (const int *)pm->d_ambSlot.p, (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p,
+                               (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p,
+                               (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, L.N, L.nk,
+                               (CandRes *)pm->d_candRes.p, (double *)nullptr);
+            XH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_pm_pick, dim3((na + 63) / 64), dim3(64), 0, ctx->stream, (const int *)pm->d_counters.p,
+                               (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, (const int *)d_rowP,
+                               (const int *)d_poff, d_ids, p0, parity, L.N, tieAbs, d_refno, d_psi, d_flip);
+            XH_LAUNCH_CHECK();
+        }
+        p0 += m;
+    }
+    return XH_OK;
+}
+
+int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *d_refno, const int32_t *d_psi,
+                    const uint8_t *d_flip, double max_shift, double *d_sx, double *d_sy, double *d_cc)
+{
+    XH_CHECK(pm && d_particles && d_refno && d_psi && d_flip && d_sx && d_sy && d_cc && n >= 0, XH_ERR_ARG,
+             "xh_pm_translate: bad argument");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    const int D = L.D;
+    XH_CHECK(xh_is_pow2(D) && D <= 2048, XH_ERR_UNSUPPORTED, "xh_pm_translate: image size %d must be a power of two", D);
+    if (max_shift < 0) max_shift = D / 2;    // APM:262-263
+    const int logD = xh_ilog2(D);
+    const size_t per = (size_t)D * D;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)(256u << 20) / (per * sizeof(xh_cd))));
+    XH_TRY(xh_buf_reserve(ctx, pm->d_t1, sizeof(xh_cd) * per * chunk));
+    XH_TRY(xh_buf_reserve(ctx, pm->d_t2, sizeof(xh_cd) * per * chunk));
+    const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(D * sizeof(xh_cd))));
+    const size_t smem = (size_t)lpb * D * sizeof(xh_cd);
+    for (int p0 = 0; p0 < n; p0 += chunk) {
+        const int m = std::min(chunk, n - p0);
+        xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
+        hipLaunchKernelGGL(k_pm_rot_mirror, dim3((unsigned)((per + 255) / 256), m), dim3(256), 0, ctx->stream,
+                           d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0, d_psi + p0,
+                           d_flip + p0, z, D, L.N);
+        XH_LAUNCH_CHECK();
+        XH_HIP(hipMemcpyAsync(w, z, sizeof(xh_cd) * per * m, hipMemcpyDeviceToDevice, ctx->stream));
+        const size_t nlines = (size_t)m * D;
+        // forward 2-D FFT of w: rows (contiguous), then columns
+        hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           w, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           w, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
+        XH_LAUNCH_CHECK();
+        XH_TRY(xh_buf_reserve(ctx, pm->d_t3, sizeof(xh_cd) * per * chunk));
+        xh_cd *pw = (xh_cd *)pm->d_t3.p;
+        hipLaunchKernelGGL(k_pm_crosspower, dim3((unsigned)((per + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)w, pw, D);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           pw, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           pw, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const xh_cd *)pw, (const xh_cd *)z, d_refno + p0,
+                           d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);
+        XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+}
+
+// ------------------------------------------------------------------------------ test hooks
+int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision, double *h_coefs, double *h_sigma)
+{
+    XH_CHECK(pm && d_particles && h_coefs && h_sigma && n > 0, XH_ERR_ARG, "bad argument");
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    std::vector<double> stat(2 * (size_t)n);
+    if (precision == 64) {
+        XH_TRY(run_prep<double>(pm, d_particles, true, nullptr, n, nullptr, pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64,
+                                pm->d_tw64, false, 0., 0.));
+        XH_HIP(hipMemcpyAsync(h_coefs, pm->d_A64.p, sizeof(xh_cd) * (size_t)n * L.ncoef, hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(hipMemcpyAsync(stat.data(), pm->d_stat64.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        XH_TRY(run_prep<float>(pm, d_particles, true, nullptr, n, nullptr, pm->d_coef32, pm->d_polar32, pm->d_A32, pm->d_stat32,
+                               pm->d_tw32, false, 0., 0.));
+        std::vector<float> tmp(2 * (size_t)n * L.ncoef);
+        XH_HIP(hipMemcpyAsync(tmp.data(), pm->d_A32.p, sizeof(xh_cf) * (size_t)n * L.ncoef, hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(hipMemcpyAsync(stat.data(), pm->d_stat32.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < tmp.size(); ++i) h_coefs[i] = tmp[i];
+    }
+    for (int i = 0; i < n; ++i) h_sigma[i] = stat[2 * i + 1];
+    return XH_OK;
+}
+
+int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs, double *h_sigma)
+{
+    XH_CHECK(pm && h_coefs && h_sigma && ref >= 0 && ref < pm->nrefs, XH_ERR_ARG, "bad argument");
+    xh_ctx *ctx = pm->ctx;
+    XH_HIP(hipMemcpyAsync(h_coefs, (const xh_cd *)pm->d_refs64.p + (size_t)ref * pm->L.ncoef, sizeof(xh_cd) * pm->L.ncoef,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(hipMemcpyAsync(h_sigma, (const double *)pm->d_refSigma.p + ref, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    return XH_OK;
+}
+
+int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32_t precision, double *h_corr2N)
+{
+    XH_CHECK(pm && d_particle && h_corr2N && ref >= 0 && ref < pm->nrefs, XH_ERR_ARG, "bad argument");
+    xh_ctx *ctx = pm->ctx;
+    const Layout &L = pm->L;
+    const int N = L.N;
+    int h_ids[1] = {ref};
+    XH_TRY(xh_buf_reserve(ctx, pm->d_nbr, sizeof(int)));
+    XH_HIP(hipMemcpyAsync(pm->d_nbr.p, h_ids, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> poff = {0, 1};
+    if (precision == 32) {
+        XH_TRY(run_prep<float>(pm, d_particle, true, nullptr, 1, nullptr, pm->d_coef32, pm->d_polar32, pm->d_A32, pm->d_stat32,
+                               pm->d_tw32, false, 0., 0.));
+        XH_TRY(run_rows(pm, 1, poff, (const int *)pm->d_nbr.p, false, 1));
+        XhBuf out;
+        XH_TRY(xh_buf_alloc(ctx, out, sizeof(float) * 2 * N));
+        const size_t smem = (size_t)pm->M * sizeof(xh_cf);
+        switch (pm->logM) {
+            case 6: launch_idft_dump<6>(pm, (float *)out.p, smem); break;
+            case 7: launch_idft_dump<7>(pm, (float *)out.p, smem); break;
+            case 8: launch_idft_dump<8>(pm, (float *)out.p, smem); break;
+            case 9: launch_idft_dump<9>(pm, (float *)out.p, smem); break;
+            case 10: launch_idft_dump<10>(pm, (float *)out.p, smem); break;
+            case 11: launch_idft_dump<11>(pm, (float *)out.p, smem); break;
+            default: launch_idft_dump<12>(pm, (float *)out.p, smem); break;
+        }
+        std::vector<float> tmp(2 * N);
+        double stat[2], sig;
+        hipError_t e = hipMemcpyAsync(tmp.data(), out.p, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(stat, pm->d_stat32.p, sizeof(stat), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&sig, (const double *)pm->d_refSigma.p + ref, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        xh_buf_free(out);
+        if (e != hipSuccess) { xh_set_error("debug_corr_rows: %s", hipGetErrorString(e)); return XH_ERR_HIP; }
+        const float den = (float)sig * (float)stat[1];
+        for (int i = 0; i < 2 * N; ++i) h_corr2N[i] = tmp[i] / den;
+        return XH_OK;
+    }
+    // fp64 path: one candidate row through the re-scorer
+    XH_TRY(run_prep<double>(pm, d_particle, true, nullptr, 1, nullptr, pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64,
+                            pm->d_tw64, false, 0., 0.));
+    XhBuf misc, dbg;
+    XH_TRY(xh_buf_alloc(ctx, misc, sizeof(int) * 16));
+    XH_TRY(xh_buf_alloc(ctx, dbg, sizeof(double) * 2 * N));
+    // layout in misc: counters[4] | candRow[1] | rowP[1] | poff[2] | ambSlotOfP[1]
+    int h[16] = {1, 1, 0, 0, /*candRow*/ 0, /*rowP*/ 0, /*poff*/ 0, 1, /*ambSlot*/ 0};
+    XH_TRY(xh_buf_reserve(ctx, pm->d_candRes, sizeof(CandRes)));
+    hipError_t e = hipMemcpyAsync(misc.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+        int *m = (int *)misc.p;
+        const size_t smem = sizeof(xh_cd) * (2 * (size_t)L.nk + N);
+        hipLaunchKernelGGL(k_pm_rescore_row, dim3(1), dim3(256), smem, ctx->stream, (const int *)m, (const int *)(m + 4),
+                           (const int *)(m + 5), (const int *)(m + 6), (const int *)pm->d_nbr.p, (const int *)(m + 8),
+                           (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p, (const double *)pm->d_refSigma.p,
+                           (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p,
+                           (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, N, L.nk, (CandRes *)pm->d_candRes.p, (double *)dbg.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_corr2N, dbg.p, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    xh_buf_free(misc);
+    xh_buf_free(dbg);
+    if (e != hipSuccess) { xh_set_error("debug_corr_rows(64): %s", hipGetErrorString(e)); return XH_ERR_HIP; }
+    return XH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1096 @@
+// xh_rf.hip -- Kaiser-Bessel Fourier gridding on MI355X (gfx950).
+//
+// Device side of ProgRecFourierAccel (reference: reconstruction/reconstruct_fourier_accel.cpp,
+// "RFA").  Built with -ffp-contract=off: the float geometry that decides which voxels a
+// projection touches (RFA:440-522,710-763) must round like the reference's scalar code.
+//
+// Data layout in HBM
+//   images      [n][D][D]            float   (caller)
+//   spectra     [n][mv][mv/2]        float2  centred half-plane, DC at row mv/2 (RFA:271-298)
+//   ctf, mod    [n][mv][mv/2]        float
+//   temp        [ V (mv+1)^3 float2 | W (mv+1)^3 float ]  [z][y][x]   (RFA:974-979)
+//   cropped     [ V (mv+1)^2 (mv/2+1) float2 | W ... ]    after mirrorAndCrop (RFA:853-887)
+//
+// Kernels and their bounds (DESIGN.md has the byte counts):
+//   k_rf_rows / k_rf_cols   batched 2-D r2c FFT via LDS (pad, CenterFFT and crop fused)   HBM
+//   k_rf_ctf                CTF / modulator planes                                         VALU (fp64 sincos)
+//   k_rf_insert             gridding: slab traversal + blob gather + 3 float atomics/voxel HBM atomics  <-- dominant
+//   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, k_fft_lines, k_rf_c2r_window   O(volume) once
+#include "xh_common.h"
+#include "xh_fft.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#define XH_BLOB_TABLE 10000
+
+namespace {
+const double kPI = 3.14159265358979323846;
+
+// ------------------------------------------------------------------ host: Kaiser-Bessel
+// data/blobs.cpp:37-92,144-172 with the Numerical-Recipes modified Bessel functions that
+// xmippCore provides (in-tree float copies: reconstruction_cuda/cuda_gpu_reconstruct_fourier.cpp:85-148).
+double h_bessi0(double x)
+{
+    double ax = std::fabs(x);
+    if (ax < 3.75) {
+        double y = (x / 3.75) * (x / 3.75);
+        return 1.0 + y * (3.5156229 + y * (3.0899424 + y * (1.2067492 + y * (0.2659732 + y * (0.360768e-1 + y * 0.45813e-2)))));
+    }
+    double y = 3.75 / ax;
+    return (std::exp(ax) / std::sqrt(ax)) *
+           (0.39894228 + y * (0.1328592e-1 + y * (0.225319e-2 + y * (-0.157565e-2 + y * (0.916281e-2 + y * (-0.2057706e-1 + y * (0.2635537e-1 + y * (-0.1647633e-1 + y * 0.392377e-2))))))));
+}
+double h_bessi1(double x)
+{
+    double ax = std::fabs(x), ans;
+    if (ax < 3.75) {
+        double y = (x / 3.75) * (x / 3.75);
+        ans = ax * (0.5 + y * (0.87890594 + y * (0.51498869 + y * (0.15084934 + y * (0.2658733e-1 + y * (0.301532e-2 + y * 0.32411e-3))))));
+    } else {
+        double y = 3.75 / ax;
+        ans = 0.2282967e-1 + y * (-0.2895312e-1 + y * (0.1787654e-1 - y * 0.420059e-2));
+        ans = 0.39894228 + y * (-0.3988024e-1 + y * (-0.362018e-2 + y * (0.163801e-2 + y * (-0.1031555e-1 + y * ans))));
+        ans *= (std::exp(ax) / std::sqrt(ax));
+    }
+    return x < 0.0 ? -ans : ans;
+}
+double h_bessin(int n, double x)
+{
+    if (n == 0) return h_bessi0(x);
+    if (n == 1) return h_bessi1(x);
+    if (x == 0) return 0;
+    return h_bessin(n - 2, x) - ((2 * (n - 1)) / x) * h_bessin(n - 1, x);
+}
+double h_kaiser_value(double r, double a, double alpha, int m)
+{
+    double rda = r / a;
+    if (rda > 1.0) return 0.0;
+    double rdas = rda * rda;
+    double arg = alpha * std::sqrt(1.0 - rdas);
+    if (m == 0) return h_bessi0(arg) / h_bessi0(alpha);
+    double w = std::sqrt(1.0 - rdas);
+    double wp = w;
+    for (int i = 1; i < m; ++i) wp *= w;
+    if (alpha != 0.0) wp *= h_bessin(m, arg) / h_bessin(m, alpha);
+    return wp;
+}
+double h_bessi_half(int twice_order, double x)  // I_{1/2}, I_{3/2}, I_{5/2}, I_{7/2}
+{
+    if (x == 0) return 0;
+    const double c = std::sqrt(2 / (kPI * x));
+    double i05 = c * std::sinh(x);
+    double i15 = c * (std::cosh(x) - std::sinh(x) / x);
+    if (twice_order == 1) return i05;
+    if (twice_order == 3) return i15;
+    double i25 = i05 - (3 / x) * i15;
+    if (twice_order == 5) return i25;
+    return i15 - (5 / x) * i25;
+}
+double h_bessj_half(int twice_order, double x)  // J_{3/2}, J_{7/2}
+{
+    if (x == 0) return 0;
+    const double c = std::sqrt(2 / (kPI * x));
+    if (twice_order == 3) return c * (std::sin(x) / x - std::cos(x));
+    return c * ((15 / (x * x * x) - 6 / x) * std::sin(x) - (15 / (x * x) - 1) * std::cos(x));
+}
+double h_kaiser_fourier(double w, double a, double alpha, int m)
+{
+    const double t = 2. * kPI * a * w;
+    const double sigma = std::sqrt(std::fabs(alpha * alpha - t * t));
+    if (m == 2) {
+        const double num = std::pow(2. * kPI, 1.5) * std::pow(a, 3.) * std::pow(alpha, 2.);
+        const double den = h_bessi0(alpha) * std::pow(sigma, 3.5);
+        return num * (t > alpha ? h_bessj_half(7, sigma) : h_bessi_half(7, sigma)) / den;
+    }
+    const double num = std::pow(2. * kPI, 1.5) * std::pow(a, 3);
+    const double den = h_bessi0(alpha) * std::pow(sigma, 1.5);
+    return num * (t > alpha ? h_bessj_half(3, sigma) : h_bessi_half(3, sigma)) / den;
+}
+
+// xmippCore Euler_angles2matrix (closed form in applications/tests/function_tests/test_geometry_main.cpp:46-65)
+void h_euler(double rot, double tilt, double psi, double *A)
+{
+    const double a = rot * kPI / 180., b = tilt * kPI / 180., g = psi * kPI / 180.;
+    const double ca = std::cos(a), cb = std::cos(b), cg = std::cos(g);
+    const double sa = std::sin(a), sb = std::sin(b), sg = std::sin(g);
+    const double cc = cb * ca, cs = cb * sa, sc = sb * ca, ss = sb * sa;
+    A[0] = cg * cc - sg * sa; A[1] = cg * cs + sg * ca; A[2] = -cg * sb;
+    A[3] = -sg * cc - cg * sa; A[4] = -sg * cs + cg * ca; A[5] = sg * sb;
+    A[6] = sc; A[7] = ss; A[8] = cb;
+}
+void h_inv3(const double *A, double *B)
+{
+    const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double id = 1.0 / det;
+    B[0] = (e * i - f * h) * id; B[1] = (c * h - b * i) * id; B[2] = (b * f - c * e) * id;
+    B[3] = (f * g - d * i) * id; B[4] = (a * i - c * g) * id; B[5] = (c * d - a * f) * id;
+    B[6] = (d * h - e * g) * id; B[7] = (b * g - a * h) * id; B[8] = (a * e - b * d) * id;
+}
+
+// One projection x symmetry placement; cf. RecFourierProjectionTraverseSpace
+// (reconstruction/reconstruct_fourier_projection_traverse_space.h:37-59)
+struct XhSpace {
+    float tInv[9];
+    float u[3], v[3];
+    float p0[3], p4[3];
+    int minY, maxY, minZ, maxZ;
+    float weight;
+    int img;
+};
+
+struct f3 { float x, y, z; };
+inline void h_mul(const float t[9], f3 &p)
+{
+    float a = t[0] * p.x + t[1] * p.y + t[2] * p.z;
+    float b = t[3] * p.x + t[4] * p.y + t[5] * p.z;
+    float c = t[6] * p.x + t[7] * p.y + t[8] * p.z;
+    p.x = a; p.y = b; p.z = c;
+}
+
+// RFA:430-442,492-522,258-269,724-741 in float, same operation order
+void h_make_space(XhSpace &S, const double *A_SL, const double *A_SLInv, int mv, double blobRadius,
+                  bool useFast, float weight, int img)
+{
+    float tr[9];
+    for (int i = 0; i < 9; ++i) { tr[i] = A_SL[i]; S.tInv[i] = A_SLInv[i]; }
+    const int imgSizeX = mv / 2, imgSizeY = mv;
+    f3 cub[8];
+    const float sizeX = imgSizeX, sizeY = imgSizeY, blobSize = useFast ? 0.f : blobRadius;
+    const float halfY = sizeY / 2.0f;
+    cub[0].x = cub[3].x = cub[4].x = cub[7].x = 0.f - blobSize;
+    cub[1].x = cub[2].x = cub[5].x = cub[6].x = sizeX + blobSize;
+    cub[0].y = cub[1].y = cub[4].y = cub[5].y = -(halfY + blobSize);
+    cub[2].y = cub[3].y = cub[6].y = cub[7].y = halfY + blobSize;
+    cub[0].z = cub[1].z = cub[2].z = cub[3].z = 0.f + blobSize;
+    cub[4].z = cub[5].z = cub[6].z = cub[7].z = 0.f - blobSize;
+    const f3 origin = {mv / 2.f, mv / 2.f, mv / 2.f};
+    for (int i = 0; i < 8; ++i) h_mul(tr, cub[i]);
+    for (int i = 0; i < 8; ++i) { cub[i].x += origin.x; cub[i].y += origin.y; cub[i].z += origin.z; }
+    f3 lo = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    // the reference seeds the upper corner with numeric_limits<float>::min() (RFA:503-504); kept
+    f3 hi = {std::numeric_limits<float>::min(), std::numeric_limits<float>::min(), std::numeric_limits<float>::min()};
+    for (int i = 0; i < 8; ++i) {
+        if (lo.x > cub[i].x) lo.x = cub[i].x;
+        if (lo.y > cub[i].y) lo.y = cub[i].y;
+        if (lo.z > cub[i].z) lo.z = cub[i].z;
+        if (hi.x < cub[i].x) hi.x = cub[i].x;
+        if (hi.y < cub[i].y) hi.y = cub[i].y;
+        if (hi.z < cub[i].z) hi.z = cub[i].z;
+    }
+    const float mx = mv;
+    if (lo.y < 0) lo.y = 0;
+    if (lo.z < 0) lo.z = 0;
+    if (hi.y > mx) hi.y = mx;
+    if (hi.z > mx) hi.z = mx;
+    S.u[0] = cub[1].x - cub[0].x; S.u[1] = cub[1].y - cub[0].y; S.u[2] = cub[1].z - cub[0].z;
+    S.v[0] = cub[3].x - cub[0].x; S.v[1] = cub[3].y - cub[0].y; S.v[2] = cub[3].z - cub[0].z;
+    S.p0[0] = cub[0].x; S.p0[1] = cub[0].y; S.p0[2] = cub[0].z;
+    S.p4[0] = cub[4].x; S.p4[1] = cub[4].y; S.p4[2] = cub[4].z;
+    S.minZ = (int)std::floor(lo.z);
+    S.minY = (int)std::floor(lo.y);
+    S.maxZ = (int)std::ceil(hi.z);
+    S.maxY = (int)std::ceil(hi.y);
+    S.weight = weight;
+    S.img = img;
+}
+}  // namespace
+
+struct xh_rf {
+    xh_ctx *ctx;
+    xh_rf_params p;
+    int D, P, mv, sizeX, sizeY;
+    float iDeltaSqrt, iDeltaFourier;
+    std::vector<float> blobTableSqrt;
+    std::vector<double> fourierBlobTable;
+    XhBuf d_blob;     // float[10000]
+    XhBuf d_twP32;    // float2 twiddles for length P
+    XhBuf d_twP64;    // double2 twiddles for length P
+    XhBuf own_temp;   // 3*(mv+1)^3 floats when library-owned
+    float *d_temp;    // active temp buffer
+    XhBuf d_rows;     // intermediate of the 2-D FFT
+    XhBuf d_spaces;
+    XhBuf d_ctfp;
+    XhBuf d_fin;      // finaliser scratch
+    bool cropped;
+};
+
+// =========================================================================== device code
+// ---- 2-D r2c FFT of the zero-padded, centred image (RFA:332-345) ------------------------
+// pass 1: FFT along x of the D image rows; keeps kx < sizeX. rows[img][y][kx]
+__global__ void __launch_bounds__(256)
+k_rf_rows(const float *__restrict__ imgs, xh_cf *__restrict__ rows, const xh_cf *__restrict__ W,
+          int D, int logP, int sizeX, int totalLines, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    const int P = 1 << logP;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int line0 = blockIdx.x * lpb;
+    const int nl = min(lpb, totalLines - line0);
+    for (int i = tid; i < lpb * P; i += nth) s[i] = xh_cf{0.f, 0.f};
+    __syncthreads();
+    const int half = D / 2;  // -FIRST_XMIPP_INDEX(D)
+    for (int i = tid; i < nl * D; i += nth) {
+        const int l = i / D, x = i - l * D;
+        const int xl = x - half;              // logical coordinate
+        const int px = xl & (P - 1);          // (xl mod P): pad centred + CenterFFT(.,true)
+        s[l * P + xh_bitrev(px, logP)].x = imgs[(size_t)(line0 + l) * D + x];
+    }
+    __syncthreads();
+    xh_fft_dit<float, false>(s, logP, lpb, W, logP, tid, nth);
+    for (int i = tid; i < nl * sizeX; i += nth) {
+        const int l = i / sizeX, k = i - l * sizeX;
+        rows[(size_t)(line0 + l) * sizeX + k] = s[l * P + k];
+    }
+}
+
+// pass 2: FFT along y for each kept kx, then cropAndShift (RFA:271-298):
+// out[img][myPadI][kx] for rows i < sizeX or i >= P-sizeX with freq^2 <= maxRes^2, scaled 1/P^2
+__global__ void __launch_bounds__(256)
+k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *__restrict__ W,
+          int D, int logP, int sizeX, double maxResSqr, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    const int P = 1 << logP;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int groupsPerImg = (sizeX + lpb - 1) / lpb;
+    const int img = blockIdx.x / groupsPerImg;
+    const int kx0 = (blockIdx.x - img * groupsPerImg) * lpb;
+    const int nl = min(lpb, sizeX - kx0);
+    for (int i = tid; i < lpb * P; i += nth) s[i] = xh_cf{0.f, 0.f};
+    __syncthreads();
+    const int half = D / 2;
+    const xh_cf *src = rows + (size_t)img * D * sizeX;
+    for (int i = tid; i < D * nl; i += nth) {
+        const int y = i / nl, l = i - y * nl;
+        const int py = (y - half) & (P - 1);
+        s[l * P + xh_bitrev(py, logP)] = src[(size_t)y * sizeX + kx0 + l];
+    }
+    __syncthreads();
+    xh_fft_dit<float, false>(s, logP, lpb, W, logP, tid, nth);
+    const float scale = 1.0f / ((float)P * (float)P);
+    const int sizeY = 2 * sizeX;
+    xh_cf *dst = out + (size_t)img * sizeY * sizeX;
+    for (int i = tid; i < sizeY * nl; i += nth) {
+        const int r = i / nl, l = i - r * nl;   // r = myPadI
+        const int ii = (r >= sizeX) ? r - sizeX : r + P - sizeX;  // FFT row index
+        const int j = kx0 + l;
+        const double fx = (double)j / (double)P;                  // j <= P/2
+        const double fy = (double)(ii <= P / 2 ? ii : ii - P) / (double)P;
+        xh_cf v = xh_cf{0.f, 0.f};
+        if (!(fx * fx + fy * fy > maxResSqr)) {
+            v = s[l * P + ii];
+            v.x *= scale;
+            v.y *= scale;
+        }
+        dst[(size_t)r * sizeX + j] = v;
+    }
+}
+
+// ---- CTF planes (RFA:548-592; data/ctf.h:452-502,1002-1029; data/ctf.cpp:645-679,1392-1402)
+struct XhCtfDev {
+    double K1, K2, K3, K5, K6, K7, Ksin, Kcos, rad_azimuth, defocus_average, defocus_deviation;
+    double DeltaR, K, envR0, envR1, envR2, phase_shift, VPP_radius;
+};
+__device__ double d_bessj0(double x)
+{
+    double ax = fabs(x);
+    if (ax < 8.0) {
+        double y = x * x;
+        double a1 = 57568490574.0 + y * (-13362590354.0 + y * (651619640.7 + y * (-11214424.18 + y * (77392.33017 + y * (-184.9052456)))));
+        double a2 = 57568490411.0 + y * (1029532985.0 + y * (9494680.718 + y * (59272.64853 + y * (267.8532712 + y * 1.0))));
+        return a1 / a2;
+    }
+    double z = 8.0 / ax, y = z * z, xx = ax - 0.785398164;
+    double a1 = 1.0 + y * (-0.1098628627e-2 + y * (0.2734510407e-4 + y * (-0.2073370639e-5 + y * 0.2093887211e-6)));
+    double a2 = -0.1562499995e-1 + y * (0.1430488765e-3 + y * (-0.6911147651e-5 + y * (0.7621095161e-6 - y * 0.934935152e-7)));
+    return sqrt(0.636619772 / ax) * (cos(xx) * a1 - z * sin(xx) * a2);
+}
+__global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ctf, float *__restrict__ mod,
+                         int n, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+{
+    const size_t per = (size_t)sizeX * sizeY;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * n) return;
+    const int img = idx / per;
+    const int rem = idx - (size_t)img * per;
+    const int y = rem / sizeX, x = rem - y * sizeX;
+    const XhCtfDev c = cp[img];
+    const float freqY = (y - (P / 2.f)) / (float)P;
+    float freqX = (float)((double)(x <= P / 2 ? x : x - P) / (double)P);
+    const double X = freqX * iTs, Y = freqY * iTs;
+    const double ang = atan2(Y, X);
+    const double u2 = X * X + Y * Y;
+    const double u = sqrt(u2);
+    const double u4 = u2 * u2;
+    double deltaf;
+    if (fabs(X) < 1e-6 && fabs(Y) < 1e-6) deltaf = 0;
+    else deltaf = c.defocus_average + c.defocus_deviation * cos(2 * (ang - c.rad_azimuth));
+    double VPP = 0.0;
+    if (round(c.VPP_radius * 1000) != 0) VPP = -c.phase_shift * (1 - exp(-u2 / (2 * c.VPP_radius * c.VPP_radius)));
+    const double argument = VPP + c.K1 * deltaf * u2 + c.K2 * u4;
+    const double sine_part = sin(argument), cosine_part = cos(argument);
+    const double Eespr = exp(-c.K3 * u4);
+    const double EdeltaF = d_bessj0(c.K5 * u2);
+    const double xs = u * c.DeltaR;
+    const double EdeltaR = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
+    const double aux = (c.K7 * u2 * u + deltaf * u);
+    const double Ealpha = exp(-c.K6 * aux * aux);
+    double E = Eespr * EdeltaF * EdeltaR * Ealpha + c.envR0 + c.envR1 * u + c.envR2 * u2;
+    if (E < 0) E = 0;
+    const double pure = -c.K * (c.Ksin * sine_part - c.Kcos * cosine_part) * E;
+    float CTFVal = (float)(c.K * pure);   // getValuePureNoKAt multiplies by K (ctf.h:499-502)
+    float modulatorVal = 1.f;
+    if (isnan(CTFVal)) {
+        if (x == 0 && y == 0) modulatorVal = CTFVal = 1.0f;
+        else modulatorVal = CTFVal = 0.0f;
+    }
+    if (fabs((double)CTFVal) < minCTF) {
+        modulatorVal = fabsf(CTFVal);
+        CTFVal = (CTFVal >= 0) ? 1.f : -1.f;
+    } else CTFVal = (float)(1.0 / (double)CTFVal);
+    if (phaseFlipped) CTFVal = fabsf(CTFVal);
+    ctf[idx] = CTFVal;
+    mod[idx] = modulatorVal;
+}
+
+// ---- gridding (RFA:627-700 processVoxelBlob, :595-625 processVoxel, :710-763 traversal) --
+__device__ __forceinline__ bool d_getX(float &x, float y, float z, const float *a, const float *b, const float *p0)
+{
+    // RFA:479-490
+    const float x0 = p0[0], y0 = p0[1], z0 = p0[2];
+    const float u = ((z - z0) * a[1] + (y0 - y) * a[2]) / (a[1] * b[2] - b[1] * a[2]);
+    const float t = (-y0 + y - u * b[1]) / (a[1]);
+    x = x0 + t * a[0] + u * b[0];
+    return (t > 0.f) && (t < 1.f) && (u > 0.f) && (u < 1.f);
+}
+
+#define XH_TILE 16
+// persistent blocks: block b serves spaces s == b%8 (mod 8) so that one projection's
+// spectrum stays in one XCD's L2 (block b runs on XCD b%8).
+template <bool HAS_CTF, bool FAST>
+__global__ void __launch_bounds__(256)
+k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__restrict__ ffts,
+            const float *__restrict__ ctfs, const float *__restrict__ mods,
+            const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
+            int mv, float iDeltaSqrt, double blobRadius)
+{
+    __shared__ float sBlob[XH_BLOB_TABLE];
+    if (!FAST) {
+        for (int i = threadIdx.x; i < XH_BLOB_TABLE; i += blockDim.x) sBlob[i] = blobTable[i];
+        __syncthreads();
+    }
+    const int tilesPerDim = (mv + 1 + XH_TILE - 1) / XH_TILE;
+    const int tilesPerSpace = tilesPerDim * tilesPerDim;
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    const int spacesHere = (nspaces - xcd + 7) >> 3;
+    const long long items = (long long)spacesHere * tilesPerSpace;
+    const int ty = threadIdx.x & (XH_TILE - 1), tz = threadIdx.x >> 4;
+    const int sizeX = mv / 2, sizeY = mv;
+    const float maxDistanceSqr = (sizeX + (FAST ? 0.f : blobRadius)) * (sizeX + (FAST ? 0.f : blobRadius));
+    const float radiusSqr = blobRadius * blobRadius;
+    const int dim = mv + 1;
+    for (long long it = rank; it < items; it += nb) {
+        const int sIdx = xcd + 8 * (int)(it / tilesPerSpace);
+        const int tile = (int)(it % tilesPerSpace);
+        const XhSpace &S = spaces[sIdx];
+        const int y = (tile % tilesPerDim) * XH_TILE + ty;
+        const int z = (tile / tilesPerDim) * XH_TILE + tz;
+        if (y < S.minY || y > S.maxY || z < S.minZ || z > S.maxZ) continue;
+        const xh_cf *img = ffts + (size_t)S.img * sizeX * sizeY;
+        const float *CTF = HAS_CTF ? ctfs + (size_t)S.img * sizeX * sizeY : nullptr;
+        const float *MOD = HAS_CTF ? mods + (size_t)S.img * sizeX * sizeY : nullptr;
+        const float dataWeight = S.weight;
+        if (FAST) {
+            float hitX;
+            if (!d_getX(hitX, (float)y, (float)z, S.u, S.v, S.p0)) continue;
+            const int x = (int)(hitX + 0.5f);
+            // processVoxel RFA:595-625
+            float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
+            if (px * px + py * py + pz * pz > maxDistanceSqr) continue;
+            const float ix = S.tInv[0] * px + S.tInv[1] * py + S.tInv[2] * pz;
+            const float iy = S.tInv[3] * px + S.tInv[4] * py + S.tInv[5] * pz;
+            int imgX = (int)(ix + 0.5f);
+            imgX = imgX > sizeX - 1 ? sizeX - 1 : imgX;
+            imgX = imgX < 0 ? 0 : imgX;
+            int imgY = (int)(iy + 0.5f + mv / 2);
+            imgY = imgY > sizeY - 1 ? sizeY - 1 : imgY;
+            imgY = imgY < 0 ? 0 : imgY;
+            float wCTF = 1.f, wMod = 1.f;
+            if (HAS_CTF) { wCTF = CTF[(size_t)imgY * sizeX + imgX]; wMod = MOD[(size_t)imgY * sizeX + imgX]; }
+            const float weight = 1.f * wMod * dataWeight;
+            const xh_cf pix = img[(size_t)imgY * sizeX + imgX];
+            const size_t vi = ((size_t)z * dim + y) * dim + x;
+            atomicAdd(&tempV[2 * vi], pix.x * weight * wCTF);
+            atomicAdd(&tempV[2 * vi + 1], pix.y * weight * wCTF);
+            atomicAdd(&tempW[vi], weight);
+            continue;
+        }
+        float x1, x2;
+        const bool hit1 = d_getX(x1, (float)y, (float)z, S.u, S.v, S.p0);
+        const bool hit2 = d_getX(x2, (float)y, (float)z, S.u, S.v, S.p4);
+        if (!(hit1 || hit2)) continue;
+        const float fmv = (float)mv;
+        x1 = x1 > fmv ? fmv : x1; x1 = x1 < 0.f ? 0.f : x1;
+        x2 = x2 > fmv ? fmv : x2; x2 = x2 < 0.f ? 0.f : x2;
+        // std::min / std::max semantics of the reference (RFA:752-753)
+        const float lower = (x2 < x1) ? x2 : x1, upper = (x1 < x2) ? x2 : x1;
+        if (!(lower >= 0.f) || !(upper <= fmv)) continue;  // non-finite bounds: undefined in the reference
+        const int xEnd = (int)ceilf(upper);
+        for (int x = (int)floorf(lower); x <= xEnd; x++) {
+            // processVoxelBlob RFA:627-700
+            float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
+            if ((px * px + py * py + pz * pz) > maxDistanceSqr) continue;
+            const float ix = S.tInv[0] * px + S.tInv[1] * py + S.tInv[2] * pz;
+            float iy = S.tInv[3] * px + S.tInv[4] * py + S.tInv[5] * pz;
+            const float iz = S.tInv[6] * px + S.tInv[7] * py + S.tInv[8] * pz;
+            iy += mv / 2;
+            const float zSqr = iz * iz;
+            if (zSqr > radiusSqr) continue;
+            int minX = (int)ceil((double)ix - blobRadius);
+            int maxX = (int)floor((double)ix + blobRadius);
+            int minY = (int)ceil((double)iy - blobRadius);
+            int maxY = (int)floor((double)iy + blobRadius);
+            minX = max(minX, 0);
+            minY = max(minY, 0);
+            maxX = min(maxX, sizeX - 1);
+            maxY = min(maxY, sizeY - 1);
+            float accW = 0.f, accR = 0.f, accI = 0.f;
+            for (int i = minY; i <= maxY; i++) {
+                const float ySqr = (iy - i) * (iy - i);
+                const float yzSqr = ySqr + zSqr;
+                if (yzSqr > radiusSqr) continue;
+                for (int j = minX; j <= maxX; j++) {
+                    const float xD = ix - j;
+                    const float distanceSqr = xD * xD + yzSqr;
+                    if (distanceSqr > radiusSqr) continue;
+                    const int aux = (int)(distanceSqr * iDeltaSqrt + 0.5f);
+                    const float wBlob = sBlob[aux];
+                    const xh_cf pix = img[(size_t)i * sizeX + j];
+                    if (HAS_CTF) {
+                        const float wCTF = CTF[(size_t)i * sizeX + j];
+                        const float wModulator = MOD[(size_t)i * sizeX + j];
+                        const float weight = wBlob * wModulator * dataWeight;
+                        accW += weight;
+                        accR += pix.x * weight * wCTF;
+                        accI += pix.y * weight * wCTF;
+                    } else {
+                        const float weight = wBlob * dataWeight;
+                        accW += weight;
+                        accR += pix.x * weight;
+                        accI += pix.y * weight;
+                    }
+                }
+            }
+            if (accW != 0.f || accR != 0.f || accI != 0.f) {
+                const size_t vi = ((size_t)z * dim + y) * dim + x;
+                atomicAdd(&tempV[2 * vi], accR);
+                atomicAdd(&tempV[2 * vi + 1], accI);
+                atomicAdd(&tempW[vi], accW);
+            }
+        }
+    }
+}
+
+// ---- finaliser ---------------------------------------------------------------------------
+// mirrorAndCrop RFA:861-887 in gather form. in: (mv+1)^3, out: (mv+1)^2 (half+1)
+__global__ void k_rf_mirror(const xh_cf *__restrict__ inV, const float *__restrict__ inW,
+                            xh_cf *__restrict__ outV, float *__restrict__ outW, int mv)
+{
+    const int half = mv / 2, dim = mv + 1, nx = half + 1;
+    const size_t total = (size_t)dim * dim * nx;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int xo = idx % nx;
+    const int y = (idx / nx) % dim;
+    const int z = idx / ((size_t)nx * dim);
+    const size_t d = ((size_t)z * dim + y) * dim + (xo + half);
+    xh_cf v = inV[d];
+    float w = inW[d];
+    if (xo >= 1) {
+        const size_t m = ((size_t)(mv - z) * dim + (mv - y)) * dim + (half - xo);
+        // reference order: the mirrored contribution (x < half) is added before or after the
+        // direct one depending on traversal; float addition of two terms commutes
+        xh_cf mvv = inV[m];
+        v.x += mvv.x;
+        v.y += -mvv.y;
+        w += inW[m];
+    }
+    outV[idx] = v;
+    outW[idx] = w;
+}
+
+// applyBlob (--fast) RFA:793-831 on the cropped spaces
+template <typename T>
+__global__ void k_rf_applyblob(const T *__restrict__ in, T *__restrict__ out, const float *__restrict__ blobTable,
+                               int mv, float blobSize, float iDeltaSqrt, int ncomp)
+{
+    const int half = mv / 2, dim = mv + 1, nx = half + 1;
+    const size_t total = (size_t)dim * dim * nx;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = idx % nx;
+    const int j = (idx / nx) % dim;
+    const int i = idx / ((size_t)nx * dim);
+    const float blobSizeSqr = blobSize * blobSize;
+    const int blob = (int)floorf(blobSize);
+    for (int c = 0; c < ncomp; ++c) {
+        float tmp = 0;
+        for (int z = max(0, i - blob); z <= min(mv, i + blob); z++) {
+            const float dZSqr = (i - z) * (i - z);
+            for (int y = max(0, j - blob); y <= min(mv, j + blob); y++) {
+                const float dYSqr = (j - y) * (j - y);
+                for (int x = max(0, k - blob); x <= min(half, k + blob); x++) {
+                    const float dXSqr = (k - x) * (k - x);
+                    const float distanceSqr = dZSqr + dYSqr + dXSqr;
+                    if (distanceSqr > blobSizeSqr) continue;
+                    const int aux = (int)(distanceSqr * iDeltaSqrt + 0.5f);
+                    tmp += blobTable[aux] * in[(((size_t)z * dim + y) * nx + x) * ncomp + c];
+                }
+            }
+        }
+        out[idx * ncomp + c] = tmp;
+    }
+}
+
+// forceHermitianSymmetry RFA:889-906 (x = 0 plane); each unordered pair handled once, by the
+// member the reference's loop meets first
+__global__ void k_rf_hermitian(xh_cf *__restrict__ V, float *__restrict__ W, int mv)
+{
+    const int half = mv / 2, dim = mv + 1, nx = half + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= dim * (half + 1)) return;
+    const int z = idx / (half + 1), y = idx - z * (half + 1);
+    if (y == half && z > half) return;
+    const size_t o = ((size_t)z * dim + y) * nx;
+    const size_t n = ((size_t)(mv - z) * dim + (mv - y)) * nx;
+    const xh_cf vn = V[n], vo = V[o];
+    xh_cf t;
+    t.x = 0.5f * (vn.x + vo.x);
+    t.y = 0.5f * (vn.y + (-vo.y));
+    const float tw = 0.5f * (W[n] + W[o]);
+    V[n] = t;
+    V[o] = xh_cf{t.x, -t.y};
+    W[n] = tw;
+    W[o] = tw;
+}
+
+// processWeights RFA:908-924
+__global__ void k_rf_weights(xh_cf *__restrict__ V, const float *__restrict__ W, size_t total, float corr2D_3D)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float weight = W[idx];
+    xh_cf v = V[idx];
+    if ((double)weight > 0.001) {   // "weight > ACCURACY": ACCURACY is a double constant
+        const float f = corr2D_3D / weight;
+        v.x *= f;
+        v.y *= f;
+    } else v = xh_cf{0.f, 0.f};
+    V[idx] = v;
+}
+
+// convertToExpectedSpace RFA:834-851 in gather form: out [P][P][P/2+1] complex<double>
+__global__ void k_rf_expand(const xh_cf *__restrict__ V, xh_cd *__restrict__ out, int mv, int P)
+{
+    const int half = mv / 2, dim = mv + 1, nx = half + 1, xh = P / 2 + 1;
+    const size_t total = (size_t)P * P * xh;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int n0 = idx % xh;
+    const int n1 = (idx / xh) % P;
+    const int n2 = idx / ((size_t)xh * P);
+    xh_cd acc = xh_cd{0., 0.};
+    if (n0 <= half) {
+        // pre-images of n1: y = n1 + half (y >= half) and y = n1 - (P - half) (y < half)
+        int ys[2], zs[2], ny = 0, nz = 0;
+        if (n1 + half <= mv) ys[ny++] = n1 + half;
+        if (n1 - (P - half) >= 0 && n1 - (P - half) < half) ys[ny++] = n1 - (P - half);
+        if (n2 + half <= mv) zs[nz++] = n2 + half;
+        if (n2 - (P - half) >= 0 && n2 - (P - half) < half) zs[nz++] = n2 - (P - half);
+        // reference accumulation order: z ascending, then y ascending
+        if (nz == 2 && zs[0] > zs[1]) { int t = zs[0]; zs[0] = zs[1]; zs[1] = t; }
+        if (ny == 2 && ys[0] > ys[1]) { int t = ys[0]; ys[0] = ys[1]; ys[1] = t; }
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < ny; ++b) {
+                const xh_cf v = V[((size_t)zs[a] * dim + ys[b]) * nx + n0];
+                acc.x += (double)v.x;
+                acc.y += (double)v.y;
+            }
+    }
+    out[idx] = acc;
+}
+
+// generic in-place strided complex line FFT (un-normalised), used for the z and y passes of the
+// 3-D inverse transform. line l -> base offset (l / inner) * outerStride + (l % inner) * innerStride
+template <typename T, bool INV>
+__global__ void __launch_bounds__(256)
+k_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int logn, size_t nlinesTotal,
+            size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
+    const int n = 1 << logn;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const size_t line0 = (size_t)blockIdx.x * lpb;
+    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;  // consecutive threads -> consecutive lines
+        xh_c2<T> v = xh_c2<T>{0, 0};
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
+        }
+        s[l * n + xh_bitrev(e, logn)] = v;
+    }
+    __syncthreads();
+    xh_fft_dit<T, INV>(s, logn, lpb, W, logn, tid, nth);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * n + e];
+        }
+    }
+}
+
+// last pass of the 3-D c2r inverse + CenterFFT(.,false) + window to D^3 + blob/sinc correction
+// (RFA:1028-1052). One line = (z,y) of the padded volume; only lines inside the window run.
+__global__ void __launch_bounds__(256)
+k_rf_c2r_window(const xh_cd *__restrict__ F, const xh_cd *__restrict__ W, double *__restrict__ vol,
+                const double *__restrict__ fourierBlob, int logP, int D, double iDeltaFourier,
+                double ipad_relation, double meanFactor2, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *s = reinterpret_cast<xh_cd *>(smem);
+    const int P = 1 << logP, xh = P / 2 + 1;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int line0 = blockIdx.x * lpb;
+    const int totalLines = D * D;
+    const int nl = min(lpb, totalLines - line0);
+    const int s0 = -(D / 2);
+    for (int i = tid; i < lpb * P; i += nth) {
+        const int l = i / P, e = i - l * P;
+        xh_cd v = xh_cd{0., 0.};
+        if (l < nl) {
+            const int ln = line0 + l;
+            const int k = ln / D, ii = ln - k * D;          // output (z,y) index in the window
+            const int rk = (k + s0) & (P - 1), ri = (ii + s0) & (P - 1);  // raw FFT indices
+            const xh_cd *row = F + ((size_t)rk * P + ri) * xh;
+            // Hermitian extension of the half row; c2r ignores Im of DC and Nyquist
+            if (e < xh) { v = row[e]; if (e == 0 || 2 * e == P) v.y = 0; }
+            else { v = row[P - e]; v.y = -v.y; }
+        }
+        s[l * P + xh_bitrev(e, logP)] = v;
+    }
+    __syncthreads();
+    xh_fft_dit<double, true>(s, logP, lpb, W, logP, tid, nth);
+    for (int i = tid; i < nl * D; i += nth) {
+        const int l = i / D, j = i - l * D;
+        const int ln = line0 + l;
+        const int k = ln / D, ii = ln - k * D;
+        const int lk = k + s0, li = ii + s0, lj = j + s0;
+        const int rj = lj & (P - 1);
+        double val = s[l * P + rj].x;
+        const double radius = sqrt((double)(lk * lk + li * li + lj * lj));
+        const double aux = radius * iDeltaFourier;
+        const double factor = fourierBlob[(int)floor(aux + 0.5)];
+        const double xs = radius / (2 * D);
+        const double sinc = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
+        const double factor2 = sinc * sinc;
+        val /= (ipad_relation * factor2 * factor);
+        vol[((size_t)k * D + ii) * D + j] = val * meanFactor2;
+    }
+}
+
+// =========================================================================== host API
+static int make_twiddles(xh_ctx *ctx, int n, XhBuf &b32, XhBuf &b64)
+{
+    std::vector<xh_cf> w32(n / 2);
+    std::vector<xh_cd> w64(n / 2);
+    for (int j = 0; j < n / 2; ++j) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / n;
+        w64[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
+        w32[j] = xh_cf{(float)w64[j].x, (float)w64[j].y};
+    }
+    XH_TRY(xh_buf_alloc(ctx, b32, sizeof(xh_cf) * (n / 2)));
+    XH_TRY(xh_buf_alloc(ctx, b64, sizeof(xh_cd) * (n / 2)));
+    XH_HIP(hipMemcpy(b32.p, w32.data(), b32.bytes, hipMemcpyHostToDevice));
+    XH_HIP(hipMemcpy(b64.p, w64.data(), b64.bytes, hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+extern "C" {
+
+int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
+{
+    XH_CHECK(ctx && p && out, XH_ERR_ARG, "xh_rf_create: null argument");
+    XH_CHECK(p->imgSize >= 4, XH_ERR_ARG, "xh_rf_create: imgSize %d too small", p->imgSize);
+    XH_CHECK(p->blob_order == 0 || p->blob_order == 2, XH_ERR_ARG,
+             "xh_rf_create: blob order %d unsupported (kaiser_Fourier_value handles 0 and 2 only, blobs.cpp:146-147)",
+             p->blob_order);
+    XH_HIP(hipSetDevice(ctx->device));
+    xh_rf *rf = new xh_rf;
+    rf->ctx = ctx;
+    rf->p = *p;
+    rf->D = p->imgSize;
+    // RFA:196-199
+    rf->P = (int)(rf->D * p->padding_vol);
+    size_t conserveRows = (size_t)std::ceil((double)rf->P * p->max_resolution * 2.0);
+    conserveRows = (size_t)std::ceil((double)conserveRows / 2.0);
+    rf->mv = 2 * (int)conserveRows;
+    rf->sizeX = rf->mv / 2;
+    rf->sizeY = rf->mv;
+    if (!xh_is_pow2(rf->P) || rf->P > 4096 || rf->mv > rf->P) {
+        xh_set_error("xh_rf_create: padded size %d (imgSize %d x padding %g) must be a power of two <= 4096 "
+                     "and max_resolution <= 0.5 for the device FFT", rf->P, rf->D, p->padding_vol);
+        delete rf;
+        return XH_ERR_UNSUPPORTED;
+    }
+    // tables, RFA:201-239
+    rf->blobTableSqrt.resize(XH_BLOB_TABLE);
+    rf->fourierBlobTable.resize(XH_BLOB_TABLE);
+    const int Xdim = rf->D;
+    const double rFourier = p->blob_radius / (p->padding_vol * Xdim);
+    const double rNorm = p->blob_radius / (p->padding_proj / p->padding_vol);
+    const double deltaSqrt = (p->blob_radius * p->blob_radius) / (XH_BLOB_TABLE - 1);
+    const double deltaFourier = (std::sqrt(3.) * Xdim / 2.) / (XH_BLOB_TABLE - 1);
+    const double iw0 = 1.0 / h_kaiser_fourier(0.0, rNorm, p->blob_alpha, p->blob_order);
+    double padXdim3 = p->padding_vol * Xdim;
+    padXdim3 = padXdim3 * padXdim3 * padXdim3;
+    const double blobTableSize = p->blob_radius * std::sqrt(1. / (XH_BLOB_TABLE - 1));
+    for (int i = 0; i < XH_BLOB_TABLE; i++) {
+        rf->blobTableSqrt[i] = h_kaiser_value(blobTableSize * std::sqrt((double)i), p->blob_radius, p->blob_alpha, p->blob_order) * iw0;
+        rf->fourierBlobTable[i] = h_kaiser_fourier(deltaFourier * i, rFourier, p->blob_alpha, p->blob_order) * padXdim3 * iw0;
+    }
+    rf->iDeltaSqrt = 1 / deltaSqrt;
+    rf->iDeltaFourier = 1 / deltaFourier;
+    rf->d_temp = nullptr;
+    rf->cropped = false;
+    int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
+    if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+    if (r == XH_OK) r = make_twiddles(ctx, rf->P, rf->d_twP32, rf->d_twP64);
+    if (r != XH_OK) { xh_rf_destroy(rf); return r; }
+    *out = rf;
+    return XH_OK;
+}
+
+int xh_rf_destroy(xh_rf *rf)
+{
+    if (!rf) return XH_OK;
+    (void)hipStreamSynchronize(rf->ctx->stream);
+    xh_buf_free(rf->d_blob); xh_buf_free(rf->d_twP32); xh_buf_free(rf->d_twP64);
+    xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
+    xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
+    delete rf;
+    return XH_OK;
+}
+
+int xh_rf_sizes(const xh_rf *rf, int32_t *P, int32_t *mv, int32_t *sx, int32_t *sy)
+{
+    XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    if (P) *P = rf->P;
+    if (mv) *mv = rf->mv;
+    if (sx) *sx = rf->sizeX;
+    if (sy) *sy = rf->sizeY;
+    return XH_OK;
+}
+
+int xh_rf_tables(const xh_rf *rf, float *bt, double *fbt, float *ids, float *idf)
+{
+    XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    if (bt) memcpy(bt, rf->blobTableSqrt.data(), sizeof(float) * XH_BLOB_TABLE);
+    if (fbt) memcpy(fbt, rf->fourierBlobTable.data(), sizeof(double) * XH_BLOB_TABLE);
+    if (ids) *ids = rf->iDeltaSqrt;
+    if (idf) *idf = rf->iDeltaFourier;
+    return XH_OK;
+}
+
+size_t xh_rf_temp_floats(const xh_rf *rf)
+{
+    const size_t d = rf->mv + 1;
+    return 3 * d * d * d;
+}
+size_t xh_rf_cropped_floats(const xh_rf *rf)
+{
+    const size_t d = rf->mv + 1;
+    return 3 * d * d * (size_t)(rf->mv / 2 + 1);
+}
+
+int xh_rf_attach_temp(xh_rf *rf, float *d_temp)
+{
+    XH_CHECK(rf && d_temp, XH_ERR_ARG, "null argument");
+    rf->d_temp = d_temp;
+    rf->cropped = false;
+    return XH_OK;
+}
+
+static int ensure_temp(xh_rf *rf)
+{
+    if (rf->d_temp) return XH_OK;
+    XH_TRY(xh_buf_alloc(rf->ctx, rf->own_temp, sizeof(float) * xh_rf_temp_floats(rf)));
+    rf->d_temp = (float *)rf->own_temp.p;
+    XH_HIP(hipMemsetAsync(rf->d_temp, 0, rf->own_temp.bytes, rf->ctx->stream));
+    return XH_OK;
+}
+
+int xh_rf_temp_ptr(xh_rf *rf, float **d_temp)
+{
+    XH_CHECK(rf && d_temp, XH_ERR_ARG, "null argument");
+    XH_TRY(ensure_temp(rf));
+    *d_temp = rf->d_temp;
+    return XH_OK;
+}
+
+int xh_rf_reset(xh_rf *rf)
+{
+    XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    XH_TRY(ensure_temp(rf));
+    XH_HIP(hipMemsetAsync(rf->d_temp, 0, sizeof(float) * xh_rf_temp_floats(rf), rf->ctx->stream));
+    rf->cropped = false;
+    return XH_OK;
+}
+
+int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft)
+{
+    XH_CHECK(rf && d_imgs && d_fft && n >= 0, XH_ERR_ARG, "xh_rf_prepare_images: bad argument");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    const int D = rf->D, P = rf->P, logP = xh_ilog2(P), sizeX = rf->sizeX;
+    // chunk so that the row-pass intermediate stays modest
+    const int chunk = std::max(1, std::min(n, (int)((256u << 20) / ((size_t)D * sizeX * sizeof(xh_cf)))));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_rows, (size_t)chunk * D * sizeX * sizeof(xh_cf)));
+    const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(P * sizeof(xh_cf))));
+    const size_t smem = (size_t)lpb * P * sizeof(xh_cf);
+    const double maxResSqr = rf->p.max_resolution * rf->p.max_resolution;
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        const int totalLines = m * D;
+        hipLaunchKernelGGL(k_rf_rows, dim3((totalLines + lpb - 1) / lpb), dim3(256), smem, ctx->stream,
+                           d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, (const xh_cf *)rf->d_twP32.p, D,
+                           logP, sizeX, totalLines, lpb);
+        XH_LAUNCH_CHECK();
+        const int groups = (sizeX + lpb - 1) / lpb;
+        hipLaunchKernelGGL(k_rf_cols, dim3(m * groups), dim3(256), smem, ctx->stream, (const xh_cf *)rf->d_rows.p,
+                           (xh_cf *)d_fft + (size_t)i0 * rf->sizeY * sizeX, (const xh_cf *)rf->d_twP32.p, D, logP,
+                           sizeX, maxResSqr, lpb);
+        XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+}
+
+int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod)
+{
+    XH_CHECK(rf && h_ctf && d_ctf && d_mod && n >= 0, XH_ERR_ARG, "xh_rf_ctf_arrays: bad argument");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    std::vector<XhCtfDev> hc(n);
+    for (int i = 0; i < n; ++i) {
+        const xh_ctf_params &c = h_ctf[i];
+        // produceSideInfo, data/ctf.cpp:645-679,1392-1402
+        const double local_Cs = c.Cs * 1e7, local_Ca = c.Ca * 1e7, local_kV = c.kV * 1e3, local_ispr = c.ispr * 1e6;
+        const double lambda = 12.2643247 / std::sqrt(local_kV * (1. + 0.978466e-6 * local_kV));
+        XhCtfDev &d = hc[i];
+        d.K1 = kPI * lambda;
+        d.K2 = kPI / 2 * local_Cs * lambda * lambda * lambda;
+        d.K3 = std::pow(0.25 * kPI * local_Ca * lambda * (c.espr / c.kV + 2 * local_ispr), 2) / std::log(2.0);
+        d.K5 = kPI * c.DeltaF * lambda;
+        d.K6 = kPI * kPI * c.alpha * c.alpha;
+        d.K7 = local_Cs * lambda * lambda;
+        d.Ksin = std::sqrt(1 - c.Q0 * c.Q0);
+        d.Kcos = c.Q0;
+        d.rad_azimuth = c.azimuthal_angle * kPI / 180.;
+        d.defocus_average = -(c.DeltafU + c.DeltafV) * 0.5;
+        d.defocus_deviation = -(c.DeltafU - c.DeltafV) * 0.5;
+        d.DeltaR = c.DeltaR; d.K = c.K; d.envR0 = c.envR0; d.envR1 = c.envR1; d.envR2 = c.envR2;
+        d.phase_shift = c.phase_shift; d.VPP_radius = c.VPP_radius;
+    }
+    XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
+    XH_HIP(hipMemcpyAsync(rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));  // hc is a stack-lifetime buffer
+    const size_t total = (size_t)n * rf->sizeX * rf->sizeY;
+    hipLaunchKernelGGL(k_rf_ctf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const XhCtfDev *)rf->d_ctfp.p, d_ctf, d_mod, n, rf->sizeX, rf->sizeY, rf->P,
+                       1.0 / rf->p.sampling, rf->p.min_ctf, rf->p.phase_flipped);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                         const double *h_ainv, const float *h_weights, int n, const double *h_sym, int nsym)
+{
+    XH_CHECK(rf && d_fft && h_ainv && n >= 0, XH_ERR_ARG, "xh_rf_insert: bad argument");
+    XH_CHECK((d_ctf == nullptr) == (d_mod == nullptr), XH_ERR_ARG, "xh_rf_insert: ctf and modulator go together");
+    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert: temp spaces already mirrored/cropped; call xh_rf_reset");
+    if (n == 0) return XH_OK;
+    XH_TRY(ensure_temp(rf));
+    xh_ctx *ctx = rf->ctx;
+    static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!h_sym) { h_sym = ident; nsym = 1; }
+    std::vector<XhSpace> spaces;
+    spaces.reserve((size_t)n * nsym);
+    for (int i = 0; i < n; ++i) {
+        const float w = h_weights ? h_weights[i] : 1.0f;
+        if (h_weights && w == 0.f) continue;  // RFA:327-329
+        for (int s = 0; s < nsym; ++s) {
+            double A_SL[9], A_SLInv[9];
+            const double *R = h_sym + 9 * s, *Ainv = h_ainv + 9 * (size_t)i;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < 3; ++k) acc += R[r * 3 + k] * Ainv[k * 3 + c];
+                    A_SL[r * 3 + c] = acc;
+                }
+            h_inv3(A_SL, A_SLInv);
+            XhSpace S;
+            h_make_space(S, A_SL, A_SLInv, rf->mv, rf->p.blob_radius, rf->p.use_fast != 0, w, i);
+            spaces.push_back(S);
+        }
+    }
+    const int ns = (int)spaces.size();
+    if (ns == 0) return XH_OK;
+    XH_TRY(xh_buf_reserve(ctx, rf->d_spaces, sizeof(XhSpace) * ns));
+    XH_HIP(hipMemcpyAsync(rf->d_spaces.p, spaces.data(), sizeof(XhSpace) * ns, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t d = rf->mv + 1;
+    float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
+    const int grid = 8 * std::max(1, (ctx->num_cus * 4) / 8);
+    const bool hasCtf = d_ctf != nullptr, fast = rf->p.use_fast != 0;
+#define XH_INSERT(CTF_, FAST_)                                                                              \
+    hipLaunchKernelGGL((k_rf_insert<CTF_, FAST_>), dim3(grid), dim3(256), 0, ctx->stream,                    \
+                       (const XhSpace *)rf->d_spaces.p, ns, (const xh_cf *)d_fft, d_ctf, d_mod,              \
+                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius)
+    if (hasCtf && fast) XH_INSERT(true, true);
+    else if (hasCtf) XH_INSERT(true, false);
+    else if (fast) XH_INSERT(false, true);
+    else XH_INSERT(false, false);
+#undef XH_INSERT
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                          const double *h_ainv, const float *h_weights, int32_t n, const double *h_sym, int32_t nsym)
+{
+    return insert_common(rf, d_fft, d_ctf, d_mod, h_ainv, h_weights, n, h_sym, nsym);
+}
+
+int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                 const double *h_angles, const float *h_weights, int32_t n, const double *h_sym, int32_t nsym)
+{
+    XH_CHECK(h_angles && n >= 0, XH_ERR_ARG, "xh_rf_insert: bad argument");
+    std::vector<double> ainv((size_t)n * 9);
+    for (int i = 0; i < n; ++i) {
+        double A[9];
+        h_euler(h_angles[3 * i], h_angles[3 * i + 1], h_angles[3 * i + 2], A);
+        double *T = &ainv[(size_t)i * 9];   // localAInv = A^T (RFA:348-350)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[c * 3 + r];
+    }
+    return insert_common(rf, d_fft, d_ctf, d_mod, ainv.data(), h_weights, n, h_sym, nsym);
+}
+
+int xh_rf_mirror_and_crop(xh_rf *rf)
+{
+    XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_mirror_and_crop: already cropped");
+    XH_TRY(ensure_temp(rf));
+    xh_ctx *ctx = rf->ctx;
+    const size_t d = rf->mv + 1, nx = rf->mv / 2 + 1;
+    const size_t total = d * d * nx;
+    XH_TRY(xh_buf_reserve(ctx, rf->d_fin, 3 * total * sizeof(float)));
+    float *outV = (float *)rf->d_fin.p, *outW = outV + 2 * total;
+    hipLaunchKernelGGL(k_rf_mirror, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const xh_cf *)rf->d_temp, (const float *)(rf->d_temp + 2 * d * d * d), (xh_cf *)outV, outW, rf->mv);
+    XH_LAUNCH_CHECK();
+    XH_HIP(hipMemcpyAsync(rf->d_temp, outV, 3 * total * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    rf->cropped = true;
+    return XH_OK;
+}
+
+int xh_rf_finish(xh_rf *rf, double *h_volume)
+{
+    XH_CHECK(rf && h_volume, XH_ERR_ARG, "null argument");
+    XH_CHECK(rf->cropped, XH_ERR_STATE, "xh_rf_finish: call xh_rf_mirror_and_crop first (RFA:149-152)");
+    xh_ctx *ctx = rf->ctx;
+    const int mv = rf->mv, P = rf->P, D = rf->D, logP = xh_ilog2(P), xh = P / 2 + 1;
+    const size_t d = mv + 1, nx = mv / 2 + 1, total = d * d * nx;
+    xh_cf *V = (xh_cf *)rf->d_temp;
+    float *W = rf->d_temp + 2 * total;
+    if (rf->p.use_fast) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_fin, 3 * total * sizeof(float)));
+        float *tv = (float *)rf->d_fin.p, *tw = tv + 2 * total;
+        hipLaunchKernelGGL((k_rf_applyblob<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)V, tv, (const float *)rf->d_blob.p, mv, (float)rf->p.blob_radius, rf->iDeltaSqrt, 2);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_rf_applyblob<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)W, tw, (const float *)rf->d_blob.p, mv, (float)rf->p.blob_radius, rf->iDeltaSqrt, 1);
+        XH_LAUNCH_CHECK();
+        XH_HIP(hipMemcpyAsync(rf->d_temp, tv, 3 * total * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_rf_hermitian, dim3((unsigned)((d * (mv / 2 + 1) + 255) / 256)), dim3(256), 0, ctx->stream, V, W, mv);
+    XH_LAUNCH_CHECK();
+    const float corr2D_3D = std::pow(rf->p.padding_proj, 2.) / (D * std::pow(rf->p.padding_vol, 3.));
+    hipLaunchKernelGGL(k_rf_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, V, (const float *)W, total, corr2D_3D);
+    XH_LAUNCH_CHECK();
+    // expanded spectrum + output volume live in scratch
+    const size_t specElems = (size_t)P * P * xh;
+    XhBuf spec, vol, fbt;
+    int r = xh_buf_alloc(ctx, spec, specElems * sizeof(xh_cd));
+    if (r == XH_OK) r = xh_buf_alloc(ctx, vol, sizeof(double) * (size_t)D * D * D);
+    if (r == XH_OK) r = xh_buf_alloc(ctx, fbt, sizeof(double) * XH_BLOB_TABLE);
+    if (r != XH_OK) { xh_buf_free(spec); xh_buf_free(vol); xh_buf_free(fbt); return r; }
+    auto cleanup = [&]() { xh_buf_free(spec); xh_buf_free(vol); xh_buf_free(fbt); };
+#define XH_HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { xh_set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return XH_ERR_HIP; } } while (0)
+    XH_HIP_C(hipMemcpyAsync(fbt.p, rf->fourierBlobTable.data(), fbt.bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rf_expand, dim3((unsigned)((specElems + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)V, (xh_cd *)spec.p, mv, P);
+    XH_HIP_C(hipGetLastError());
+    const int lpb = std::max(1, std::min(8, (64 * 1024) / (int)(P * sizeof(xh_cd))));
+    const size_t smem = (size_t)lpb * P * sizeof(xh_cd);
+    // inverse along z: lines (y,x), element stride P*xh
+    {
+        const size_t nlines = (size_t)P * xh;
+        hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           (xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, logP, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
+        XH_HIP_C(hipGetLastError());
+    }
+    // inverse along y: lines (z,x): offset z*P*xh + x, element stride xh
+    {
+        const size_t nlines = (size_t)P * xh;
+        hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           (xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, logP, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
+        XH_HIP_C(hipGetLastError());
+    }
+    // meanFactor2 = mean over the D^3 window of sinc^2(radius/(2D)) (RFA:1040-1050), same loop order
+    double meanFactor2 = 0;
+    {
+        const int s0 = -(D / 2);
+        for (int k = 0; k < D; ++k)
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    const int lk = k + s0, li = i + s0, lj = j + s0;
+                    const double radius = std::sqrt((double)(lk * lk + li * li + lj * lj));
+                    const double xs = radius / (2 * D);
+                    const double sinc = (xs == 0) ? 1.0 : std::sin(kPI * xs) / (kPI * xs);
+                    meanFactor2 += std::pow(sinc, 2);
+                }
+        meanFactor2 /= (double)D * D * D;
+    }
+    const double pr0 = rf->p.padding_proj / rf->p.padding_vol;
+    const double ipad_relation = 1.0 / (pr0 * pr0 * pr0);
+    hipLaunchKernelGGL(k_rf_c2r_window, dim3((unsigned)(((size_t)D * D + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                       (const xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, (double *)vol.p, (const double *)fbt.p, logP, D,
+                       (double)rf->iDeltaFourier, ipad_relation, meanFactor2, lpb);
+    XH_HIP_C(hipGetLastError());
+    XH_HIP_C(hipMemcpyAsync(h_volume, vol.p, vol.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP_C(hipStreamSynchronize(ctx->stream));
+#undef XH_HIP_C
+    cleanup();
+    return XH_OK;
+}
+
+}  // extern "C"
