@@ -49,9 +49,11 @@ const char *xh_version(void);
  * (reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:46-60, :128) and the
  * GPU HW object (reconstruction_cuda/gpu.h:36-). */
 typedef struct xh_ctx xh_ctx;
-/* stream: an existing hipStream_t to enqueue on (e.g. torch's current stream), or NULL to
- * let the context create its own. */
+/* stream: the hipStream_t all work of this context is enqueued on (e.g. torch's current
+ * stream); NULL means the device's default (null) stream. The stream stays owned by the caller. */
 int xh_ctx_create(int device, void *stream, xh_ctx **out);
+/* same, but the context creates (and destroys) a private non-blocking stream */
+int xh_ctx_create_private(int device, xh_ctx **out);
 int xh_ctx_destroy(xh_ctx *ctx);
 int xh_ctx_sync(xh_ctx *ctx);                 /* synchronous: waits for the stream */
 void *xh_ctx_stream(xh_ctx *ctx);
@@ -123,6 +125,10 @@ size_t xh_rf_temp_floats(const xh_rf *rf);
 int xh_rf_attach_temp(xh_rf *rf, float *d_temp /* xh_rf_temp_floats() floats */);
 int xh_rf_temp_ptr(xh_rf *rf, float **d_temp);
 int xh_rf_reset(xh_rf *rf);
+/* Image::readApplyGeo(..., only_apply_shifts) (RFA:304-323): out = in translated by
+ * h_shiftXY[i] = (shiftX, shiftY) pixels, cubic B-spline interpolation with wrapping. */
+int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY /* [n][2] */, int32_t n,
+                       float *d_out);
 /* preloadBuffer + cropAndShift for n images already shifted (shifts applied):
  * d_imgs [n][D][D] float  ->  d_fft [n][mv][mv/2] complex<float> (interleaved) */
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft);
@@ -182,6 +188,9 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
 /* statistics of the last xh_pm_match call: rows evaluated, particles re-scored in fp64 */
 int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rescored_particles,
                      int64_t *rescored_rows);
+/* accumulated device time (HIP events) per stage of xh_pm_match since the last reset:
+ * h_ms[8] = { prep32, contract, idft_max, select, rescore_fp64, 0, 0, 0 } milliseconds */
+int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 

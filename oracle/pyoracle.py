@@ -282,9 +282,12 @@ class PM:
         self.ncoef = lib().xo_pm_ncoef(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().xo_pm_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().xo_pm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def ref_coefs(self, r):
         p = lib().xo_pm_ref_coefs(self.h, r)
@@ -370,9 +373,12 @@ class RF:
         self.cropped = False
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().xo_rf_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().xo_rf_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     @property
     def blob_table(self):

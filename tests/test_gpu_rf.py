@@ -54,6 +54,21 @@ def test_prepare_images(gpu, oracle, D, maxres):
         assert ((exp == 0) == (got[i] == 0)).all() or np.abs(got[i][exp == 0]).max() == 0
 
 
+def test_shift_images(gpu, oracle):
+    """readApplyGeo(only_apply_shifts): BSPLINE3 translation with wrapping (RFA:304-323)."""
+    xa, ctx, torch = gpu
+    D = 64
+    rng = np.random.default_rng(4)
+    imgs = rng.standard_normal((4, D, D)).astype(np.float32)
+    shifts = np.array([[0.0, 0.0], [1.0, -2.0], [0.37, 2.6], [-3.25, -0.5]], np.float32)
+    rf = xa.RecFourier(ctx, D)
+    got = rf.shift_images(torch.from_numpy(imgs).cuda(), shifts).cpu().numpy()
+    for i in range(4):
+        exp = oracle.translate2d(imgs[i], shifts[i, 0], shifts[i, 1], degree=3, wrap=True)
+        assert np.abs(got[i] - exp).max() <= 2e-5 * np.abs(exp).max()
+    assert np.array_equal(got[0], imgs[0])
+
+
 def test_ctf_arrays(gpu, oracle):
     xa, ctx, torch = gpu
     D = 64

@@ -34,6 +34,7 @@ SIGNATURES = {
     "xh_last_error": (C.c_char_p, []),
     "xh_version": (C.c_char_p, []),
     "xh_ctx_create": (C.c_int, [C.c_int, vp, pvp]),
+    "xh_ctx_create_private": (C.c_int, [C.c_int, pvp]),
     "xh_ctx_destroy": (C.c_int, [vp]),
     "xh_ctx_sync": (C.c_int, [vp]),
     "xh_ctx_stream": (vp, [vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "xh_rf_attach_temp": (C.c_int, [vp, vp]),
     "xh_rf_temp_ptr": (C.c_int, [vp, pvp]),
     "xh_rf_reset": (C.c_int, [vp]),
+    "xh_rf_shift_images": (C.c_int, [vp, vp, vp, i32, vp]),
     "xh_rf_prepare_images": (C.c_int, [vp, vp, i32, vp]),
     "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
     "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     "xh_pm_match": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp]),
     "xh_pm_translate": (C.c_int, [vp, vp, i32, vp, vp, vp, d, vp, vp, vp]),
     "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "xh_pm_stage_ms": (C.c_int, [vp, vp, i32]),
     "xh_pm_set_option": (C.c_int, [vp, C.c_char_p, d]),
     "xh_pm_debug_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
     "xh_pm_debug_ref": (C.c_int, [vp, i32, vp, vp]),

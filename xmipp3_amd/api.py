@@ -139,6 +139,15 @@ class RecFourier:
         check(lib().xh_rf_reset(self.h))
         self.cropped = False
 
+    def shift_images(self, imgs, shifts):
+        """Image::readApplyGeo(only_apply_shifts): shifts [n,2] = (shiftX, shiftY) on the host."""
+        torch = _torch()
+        n = imgs.shape[0]
+        sh = np.ascontiguousarray(shifts, np.float32).reshape(n, 2)
+        out = torch.empty_like(imgs)
+        check(lib().xh_rf_shift_images(self.h, _ptr(imgs), _np_ptr(sh), n, _ptr(out)))
+        return out
+
     def prepare_images(self, imgs, out=None):
         """imgs: cuda float32 [n,D,D] -> [n, mv, mv/2, 2] float32 (centred half spectra)."""
         torch = _torch()
@@ -262,6 +271,11 @@ class ProjectionMatcher:
         check(lib().xh_pm_translate(self.h, _ptr(particles), n, _ptr(refno), _ptr(psi), _ptr(flip), float(max_shift),
                                     _ptr(sx), _ptr(sy), _ptr(cc)))
         return sx, sy, cc
+
+    def stage_ms(self, reset=True):
+        ms = np.zeros(8, np.float64)
+        check(lib().xh_pm_stage_ms(self.h, _np_ptr(ms), int(reset)))
+        return dict(zip(("prep32", "contract", "idft_max", "select", "rescore_fp64"), ms[:5].tolist()))
 
     def last_stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

@@ -1,0 +1,121 @@
+// xh_bspline.h -- cubic B-spline prefilter / interpolation device code shared by the
+// projection-matching and gridding translation units (gfx950).
+// xmippCore produceSplineCoefficients + interpolatedElementBSpline2D(.,.,3); in-tree evidence:
+// reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41, cuda_gpu_bilib.cu:16-25,
+// cuda_gpu_multidim_array.cu:78-157.
+#ifndef XH_BSPLINE_H
+#define XH_BSPLINE_H
+#include <hip/hip_runtime.h>
+
+// cubic B-spline prefilter, pole sqrt(3)-2, half-sample mirror boundary (xmippCore
+// produceSplineCoefficients; in-tree GPU twin reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41)
+template <typename T>
+__device__ __forceinline__ void d_prefilter_line(T *c, int n, int stride)
+{
+    if (n == 1) return;
+    const T z = (T)(-0.26794919243112270647);   // sqrt(3) - 2
+    const T lambda = (T)6.0;
+    for (int i = 0; i < n; ++i) c[i * stride] *= lambda;
+    T sum = c[0];
+    T zk = z;
+    const int H = 64;                          // |z|^64 ~ 2e-37: below fp64 resolution
+    int k = 1;
+    for (; k <= n && k <= H; ++k) { sum += zk * c[(k - 1) * stride]; zk *= z; }
+    if (n < H) {
+        for (k = n + 1; k <= 2 * n - 1; ++k) { sum += zk * c[(2 * n - k) * stride]; zk *= z; }
+        sum /= ((T)1 - zk);
+    }
+    c[0] = sum;
+    for (int i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
+    c[(n - 1) * stride] = (z / (z - (T)1)) * c[(n - 1) * stride];
+    for (int i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+
+// rows pass through an LDS tile: block = 64 threads handles 32 rows of one image
+template <typename T, typename TIN>
+__global__ void __launch_bounds__(64)
+k_pm_prefilter_rows(const TIN *__restrict__ imgs, const int *__restrict__ gather, T *__restrict__ coefs, int D,
+                    int TR, const int *__restrict__ count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    const int tilesPerImg = (D + TR - 1) / TR;
+    const int slot = blockIdx.x / tilesPerImg;
+    if (count && slot >= *count) return;
+    const int row0 = (blockIdx.x - slot * tilesPerImg) * TR;
+    const int src = gather ? gather[slot] : slot;
+    const int nrow = min(TR, D - row0);
+    const int ld = D + 1;
+    const TIN *in = imgs + (size_t)src * D * D + (size_t)row0 * D;
+    for (int i = threadIdx.x; i < nrow * D; i += 64) {
+        const int r = i / D, c = i - r * D;
+        s[r * ld + c] = (T)in[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nrow) d_prefilter_line(s + threadIdx.x * ld, D, 1);
+    __syncthreads();
+    T *out = coefs + (size_t)slot * D * D + (size_t)row0 * D;
+    for (int i = threadIdx.x; i < nrow * D; i += 64) {
+        const int r = i / D, c = i - r * D;
+        out[i] = s[r * ld + c];
+    }
+}
+
+template <typename T>
+__global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, const int *__restrict__ count)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = gid / D, x = gid - slot * D;
+    if (slot >= nslots) return;
+    if (count && slot >= *count) return;
+    d_prefilter_line(coefs + (size_t)slot * D * D + x, D, D);
+}
+
+template <typename T> __device__ __forceinline__ T d_bspline03(T x)
+{
+    // reconstruction_cuda/cuda_gpu_bilib.cu:16-25
+    T a = fabs(x);
+    if (a < (T)1) return a * a * (a - (T)2) * (T)0.5 + (T)(2.0 / 3.0);
+    if (a < (T)2) { a -= (T)2; return a * a * a * (T)(-1.0 / 6.0); }
+    return (T)0;
+}
+
+// interpolatedElementBSpline2D degree 3 at logical (x,y); reconstruction_cuda/cuda_gpu_multidim_array.cu:78-157
+template <typename T>
+__device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T y)
+{
+    const int start = -(D / 2);
+    x -= (T)start;
+    y -= (T)start;
+    const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
+    int el[4];
+    T wx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int l = l1 + t;
+        wx[t] = d_bspline03<T>(x - (T)l);
+        el[t] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+    }
+    T columns = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int m = m1 + t;
+        const int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
+        const T *ref = coef + (size_t)em * D;
+        T rows = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rows += ref[el[u]] * wx[u];
+        columns += rows * d_bspline03<T>(y - (T)m);
+    }
+    return columns;
+}
+
+template <typename T> __device__ __forceinline__ T d_realwrap(T x, T x0, T xF)
+{
+    if (x >= x0 && x <= xF) return x;
+    if (x < x0) return x - (int)((x - x0) / (xF - x0) - 1) * (xF - x0);
+    return x - (int)((x - xF) / (xF - x0) + 1) * (xF - x0);
+}
+
+
+#endif

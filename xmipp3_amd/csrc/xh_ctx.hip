@@ -54,7 +54,7 @@ int xh_device_count(int *count)
     return XH_OK;
 }
 
-int xh_ctx_create(int device, void *stream, xh_ctx **out)
+static int ctx_create(int device, void *stream, bool own, xh_ctx **out)
 {
     XH_CHECK(out, XH_ERR_ARG, "xh_ctx_create: null out pointer");
     int n = 0;
@@ -77,10 +77,9 @@ int xh_ctx_create(int device, void *stream, xh_ctx **out)
     xh_ctx *c = new xh_ctx;
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-        c->own_stream = false;
-    } else {
+    c->stream = (hipStream_t)stream;   // NULL = the device's default (null) stream
+    c->own_stream = false;
+    if (own) {
         hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (se != hipSuccess) {
             delete c;
@@ -92,6 +91,9 @@ int xh_ctx_create(int device, void *stream, xh_ctx **out)
     *out = c;
     return XH_OK;
 }
+
+int xh_ctx_create(int device, void *stream, xh_ctx **out) { return ctx_create(device, stream, false, out); }
+int xh_ctx_create_private(int device, xh_ctx **out) { return ctx_create(device, nullptr, true, out); }
 
 int xh_ctx_destroy(xh_ctx *ctx)
 {

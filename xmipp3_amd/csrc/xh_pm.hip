@@ -26,6 +26,7 @@
 //   raw     [rows][nk] float4                the S2 -> S3 intermediate (nk = N/2+1)
 #include "xh_common.h"
 #include "xh_fft.h"
+#include "xh_bspline.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -108,119 +109,11 @@ struct xh_pm {
     XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters;
     XhBuf d_t1, d_t2, d_t3;      // S6 scratch
     int64_t stat_rows, stat_resc_p, stat_resc_r;
+    hipEvent_t ev[6];
+    double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
 };
 
 // =========================================================================== S1 kernels
-// cubic B-spline prefilter, pole sqrt(3)-2, half-sample mirror boundary (xmippCore
-// produceSplineCoefficients; in-tree GPU twin reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41)
-template <typename T>
-__device__ __forceinline__ void d_prefilter_line(T *c, int n, int stride)
-{
-    if (n == 1) return;
-    const T z = (T)(-0.26794919243112270647);   // sqrt(3) - 2
-    const T lambda = (T)6.0;
-    for (int i = 0; i < n; ++i) c[i * stride] *= lambda;
-    T sum = c[0];
-    T zk = z;
-    const int H = 64;                          // |z|^64 ~ 2e-37: below fp64 resolution
-    int k = 1;
-    for (; k <= n && k <= H; ++k) { sum += zk * c[(k - 1) * stride]; zk *= z; }
-    if (n < H) {
-        for (k = n + 1; k <= 2 * n - 1; ++k) { sum += zk * c[(2 * n - k) * stride]; zk *= z; }
-        sum /= ((T)1 - zk);
-    }
-    c[0] = sum;
-    for (int i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
-    c[(n - 1) * stride] = (z / (z - (T)1)) * c[(n - 1) * stride];
-    for (int i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
-}
-
-// rows pass through an LDS tile: block = 64 threads handles 32 rows of one image
-template <typename T, typename TIN>
-__global__ void __launch_bounds__(64)
-k_pm_prefilter_rows(const TIN *__restrict__ imgs, const int *__restrict__ gather, T *__restrict__ coefs, int D,
-                    int TR, const int *__restrict__ count)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    T *s = reinterpret_cast<T *>(smem);
-    const int tilesPerImg = (D + TR - 1) / TR;
-    const int slot = blockIdx.x / tilesPerImg;
-    if (count && slot >= *count) return;
-    const int row0 = (blockIdx.x - slot * tilesPerImg) * TR;
-    const int src = gather ? gather[slot] : slot;
-    const int nrow = min(TR, D - row0);
-    const int ld = D + 1;
-    const TIN *in = imgs + (size_t)src * D * D + (size_t)row0 * D;
-    for (int i = threadIdx.x; i < nrow * D; i += 64) {
-        const int r = i / D, c = i - r * D;
-        s[r * ld + c] = (T)in[i];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nrow) d_prefilter_line(s + threadIdx.x * ld, D, 1);
-    __syncthreads();
-    T *out = coefs + (size_t)slot * D * D + (size_t)row0 * D;
-    for (int i = threadIdx.x; i < nrow * D; i += 64) {
-        const int r = i / D, c = i - r * D;
-        out[i] = s[r * ld + c];
-    }
-}
-
-template <typename T>
-__global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, const int *__restrict__ count)
-{
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = gid / D, x = gid - slot * D;
-    if (slot >= nslots) return;
-    if (count && slot >= *count) return;
-    d_prefilter_line(coefs + (size_t)slot * D * D + x, D, D);
-}
-
-template <typename T> __device__ __forceinline__ T d_bspline03(T x)
-{
-    // reconstruction_cuda/cuda_gpu_bilib.cu:16-25
-    T a = fabs(x);
-    if (a < (T)1) return a * a * (a - (T)2) * (T)0.5 + (T)(2.0 / 3.0);
-    if (a < (T)2) { a -= (T)2; return a * a * a * (T)(-1.0 / 6.0); }
-    return (T)0;
-}
-
-// interpolatedElementBSpline2D degree 3 at logical (x,y); reconstruction_cuda/cuda_gpu_multidim_array.cu:78-157
-template <typename T>
-__device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T y)
-{
-    const int start = -(D / 2);
-    x -= (T)start;
-    y -= (T)start;
-    const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
-    int el[4];
-    T wx[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int l = l1 + t;
-        wx[t] = d_bspline03<T>(x - (T)l);
-        el[t] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
-    }
-    T columns = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int m = m1 + t;
-        const int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
-        const T *ref = coef + (size_t)em * D;
-        T rows = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rows += ref[el[u]] * wx[u];
-        columns += rows * d_bspline03<T>(y - (T)m);
-    }
-    return columns;
-}
-
-template <typename T> __device__ __forceinline__ T d_realwrap(T x, T x0, T xF)
-{
-    if (x >= x0 && x <= xF) return x;
-    if (x < x0) return x - (int)((x - x0) / (xF - x0) - 1) * (xF - x0);
-    return x - (int)((x - xF) / (xF - x0) + 1) * (xF - x0);
-}
-
 __device__ __forceinline__ double d_block_sum(double v, double *red)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1025,6 +918,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    for (int i = 0; i < 8; ++i) pm->stage_ms[i] = 0;
+    for (int i = 0; i < 6; ++i) (void)hipEventCreate(&pm->ev[i]);
     int rc = XH_OK;
     {
         // float angle cache, polar.cpp:57-83
@@ -1149,6 +1044,7 @@ int xh_pm_destroy(xh_pm *pm)
 {
     if (!pm) return XH_OK;
     (void)hipStreamSynchronize(pm->ctx->stream);
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(pm->ev[i]);
     free_all(pm);
     delete pm;
     return XH_OK;
@@ -1173,6 +1069,13 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     return XH_OK;
 }
 
+int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset)
+{
+    XH_CHECK(pm && h_ms, XH_ERR_ARG, "null argument");
+    for (int i = 0; i < 8; ++i) { h_ms[i] = pm->stage_ms[i]; if (reset) pm->stage_ms[i] = 0; }
+    return XH_OK;
+}
+
 int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 {
     XH_CHECK(pm, XH_ERR_ARG, "null handle");
@@ -1183,7 +1086,7 @@ int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 }
 
 // S2+S3 for a prepared chunk. h_poff: chunk-local row offsets [m+1]; d_ids device ref ids per row or null (dense)
-static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq)
+static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq, hipEvent_t evMid = nullptr)
 {
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
@@ -1224,6 +1127,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p, d_ids,
                            (float4 *)pm->d_raw.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p, L.nrings, L.ncoef, L.nk);
     XH_LAUNCH_CHECK();
+    if (evMid) XH_HIP(hipEventRecord(evMid, ctx->stream));
     const int lpb = std::max(1, std::min(4, (60 * 1024) / (int)(pm->M * sizeof(xh_cf))));
     const size_t smem = (size_t)lpb * pm->M * sizeof(xh_cf);
     switch (pm->logM) {
@@ -1288,10 +1192,13 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
         }
         XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
         // S1 fp32
+        XH_HIP(hipEventRecord(pm->ev[0], ctx->stream));
         XH_TRY(run_prep<float>(pm, d_particles + (size_t)p0 * D * D, true, nullptr, m, nullptr, pm->d_coef32, pm->d_polar32,
                                pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0.));
+        XH_HIP(hipEventRecord(pm->ev[1], ctx->stream));
         // S2 + S3
-        XH_TRY(run_rows(pm, m, poff, d_ids, dense, pm->nrefs));
+        XH_TRY(run_rows(pm, m, poff, d_ids, dense, pm->nrefs, pm->ev[2]));
+        XH_HIP(hipEventRecord(pm->ev[3], ctx->stream));
         // S4
         XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
         XH_TRY(xh_buf_reserve(ctx, pm->d_ambList, sizeof(int) * m));
@@ -1304,10 +1211,16 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
                            L.N, tauAbs, (int *)pm->d_counters.p, (int *)pm->d_ambList.p, (int *)pm->d_ambSlot.p,
                            (int *)pm->d_candRow.p);
         XH_LAUNCH_CHECK();
+        XH_HIP(hipEventRecord(pm->ev[4], ctx->stream));
         // S5: read the counters (tiny D2H) to size the fp64 work
         int counters[4];
         XH_HIP(hipMemcpyAsync(counters, pm->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
         XH_HIP(hipStreamSynchronize(ctx->stream));
+        {
+            float ms;
+            for (int e = 0; e < 4; ++e)
+                if (hipEventElapsedTime(&ms, pm->ev[e], pm->ev[e + 1]) == hipSuccess) pm->stage_ms[e] += ms;
+        }
         pm->stat_rows += nrows;
         pm->stat_resc_p += counters[0];
         pm->stat_resc_r += counters[1];
@@ -1327,6 +1240,10 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
                                (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, (const int *)d_rowP,
                                (const int *)d_poff, d_ids, p0, parity, L.N, tieAbs, d_refno, d_psi, d_flip);
             XH_LAUNCH_CHECK();
+            XH_HIP(hipEventRecord(pm->ev[5], ctx->stream));
+            XH_HIP(hipEventSynchronize(pm->ev[5]));
+            float ms;
+            if (hipEventElapsedTime(&ms, pm->ev[4], pm->ev[5]) == hipSuccess) pm->stage_ms[4] += ms;
         }
         p0 += m;
     }

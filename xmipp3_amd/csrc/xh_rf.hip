@@ -18,6 +18,7 @@
 //   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, k_fft_lines, k_rf_c2r_window   O(volume) once
 #include "xh_common.h"
 #include "xh_fft.h"
+#include "xh_bspline.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -214,6 +215,7 @@ struct xh_rf {
     XhBuf d_spaces;
     XhBuf d_ctfp;
     XhBuf d_fin;      // finaliser scratch
+    XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     bool cropped;
 };
 
@@ -289,6 +291,26 @@ k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *
         }
         dst[(size_t)r * sizeX + j] = v;
     }
+}
+
+
+// ---- Image::readApplyGeo with only_apply_shifts (RFA:304-323): translation by (shiftX, shiftY)
+// with cubic B-spline interpolation and wrapping (xmippCore applyGeometry(BSPLINE3, ..., WRAP)).
+// out(x,y) samples the prefiltered input at (x - shiftX, y - shiftY).
+__global__ void k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
+                           const float2 *__restrict__ shifts, float *__restrict__ out, int D)
+{
+    const int p = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= D * D) return;
+    const float2 sh = shifts[p];
+    if (sh.x == 0.f && sh.y == 0.f) { out[(size_t)p * D * D + pix] = imgs[(size_t)p * D * D + pix]; return; }
+    const int i = pix / D, j = pix - i * D, cen = D / 2;
+    const float minp = -cen, maxp = D - cen - 1;
+    float xp = (float)(j - cen) - sh.x, yp = (float)(i - cen) - sh.y;
+    if (xp < minp - 1e-6f || xp > maxp + 1e-6f) xp = d_realwrap<float>(xp, minp - 0.5f, maxp + 0.5f);
+    if (yp < minp - 1e-6f || yp > maxp + 1e-6f) yp = d_realwrap<float>(yp, minp - 0.5f, maxp + 0.5f);
+    out[(size_t)p * D * D + pix] = d_interp<float>(coefs + (size_t)p * D * D, D, xp, yp);
 }
 
 // ---- CTF planes (RFA:548-592; data/ctf.h:452-502,1002-1029; data/ctf.cpp:645-679,1392-1402)
@@ -786,6 +808,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_blob); xh_buf_free(rf->d_twP32); xh_buf_free(rf->d_twP64);
     xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
+    xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     delete rf;
     return XH_OK;
 }
@@ -880,6 +903,32 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
                            sizeX, maxResSqr, lpb);
         XH_LAUNCH_CHECK();
     }
+    return XH_OK;
+}
+
+
+int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, int32_t n, float *d_out)
+{
+    XH_CHECK(rf && d_imgs && h_shiftXY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images: bad argument");
+    XH_CHECK(d_imgs != d_out, XH_ERR_ARG, "xh_rf_shift_images: in-place operation is not supported");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    const int D = rf->D;
+    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n));
+    XH_HIP(hipMemcpyAsync(rf->d_shiftXY.p, h_shiftXY, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(float)))));
+    const int tiles = (D + TR - 1) / TR;
+    hipLaunchKernelGGL((k_pm_prefilter_rows<float, float>), dim3(n * tiles), dim3(64), sizeof(float) * TR * (D + 1), ctx->stream,
+                       d_imgs, (const int *)nullptr, (float *)rf->d_shiftCoef.p, D, TR, (const int *)nullptr);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_pm_prefilter_cols<float>), dim3((n * D + 63) / 64), dim3(64), 0, ctx->stream, (float *)rf->d_shiftCoef.p, D, n,
+                       (const int *)nullptr);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, (const float *)rf->d_shiftCoef.p, d_imgs,
+                       (const float2 *)rf->d_shiftXY.p, d_out, D);
+    XH_LAUNCH_CHECK();
     return XH_OK;
 }
 
