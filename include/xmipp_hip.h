@@ -110,6 +110,8 @@ typedef struct xh_rf xh_rf;
 
 int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out);
 int xh_rf_destroy(xh_rf *rf);
+/* profiling knobs ("insert_variant": 0 product path, 1 no atomics, 2 atomics only) */
+int xh_rf_set_option(xh_rf *rf, const char *name, double value);
 /* derived sizes (RFA:196-199): paddedImgSize P, maxVolumeIndexYZ mv, fft crop sizeX=mv/2, sizeY=mv */
 int xh_rf_sizes(const xh_rf *rf, int32_t *paddedImgSize, int32_t *maxVolumeIndex,
                 int32_t *fftSizeX, int32_t *fftSizeY);

@@ -140,7 +140,7 @@ def test_insert_many(gpu, oracle, data32, mode):
         c2 = np.diag([-1.0, -1.0, 1.0])
         sym = np.stack([np.eye(3), c2])
     if mode in ("ctf", "fast_ctf"):
-        ctf = rng.uniform(0.5, 2.0, ffts.shape[:3]).astype(np.float32) * rng.choice([-1, 1], ffts.shape[:3])
+        ctf = (rng.uniform(0.5, 2.0, ffts.shape[:3]) * rng.choice([-1, 1], ffts.shape[:3])).astype(np.float32)
         mod = rng.uniform(0.0, 1.0, ffts.shape[:3]).astype(np.float32)
     for i in range(n):
         w = 1.0 if weights is None else float(weights[i])

@@ -52,6 +52,7 @@ SIGNATURES = {
     "xh_ctf_defaults": (None, [C.POINTER(CtfParams)]),
     "xh_rf_create": (C.c_int, [vp, C.POINTER(RfParams), pvp]),
     "xh_rf_destroy": (C.c_int, [vp]),
+    "xh_rf_set_option": (C.c_int, [vp, C.c_char_p, d]),
     "xh_rf_sizes": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "xh_rf_tables": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "xh_rf_temp_floats": (sz, [vp]),
@@ -85,6 +86,12 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own HIP runtime; load it first so that this process ends up with ONE
+    # libamdhip64 (ours would otherwise pull /opt/rocm's next to torch's and lose the device)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise XhError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -5,6 +5,7 @@ every method is a thin call into libxmipp_hip.so.  torch provides device memory 
 the stream and torch.distributed -- plumbing only.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -36,12 +37,15 @@ class Context:
         check(L.xh_ctx_create(self.device, C.c_void_p(stream), C.byref(h)))
         self.h = h
         self.torch_device = torch.device("cuda", self.device)
+        self._children = weakref.WeakSet()   # handles must be destroyed before their context
 
     def sync(self):
         check(lib().xh_ctx_sync(self.h))
 
     def close(self):
         if getattr(self, "h", None):
+            for c in list(self._children):
+                c.close()
             lib().xh_ctx_destroy(self.h)
             self.h = None
 
@@ -75,13 +79,20 @@ class _Timer:
 
     def __del__(self):
         try:
-            lib().xh_timer_destroy(self.ctx.h, self.t)
+            if getattr(self.ctx, "h", None):
+                lib().xh_timer_destroy(self.ctx.h, self.t)
         except Exception:
             pass
 
 
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous()):
+        raise XhError("device arguments must be contiguous cuda tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise XhError(f"expected a {dtype} tensor, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
 
 
 def _np_ptr(a):
@@ -109,6 +120,7 @@ class RecFourier:
         h = C.c_void_p()
         check(lib().xh_rf_create(ctx.h, C.byref(p), C.byref(h)))
         self.h = h
+        ctx._children.add(self)
         P, mv, sx, sy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         check(lib().xh_rf_sizes(h, C.byref(P), C.byref(mv), C.byref(sx), C.byref(sy)))
         self.D, self.P, self.mv, self.sizeX, self.sizeY = int(imgSize), P.value, mv.value, sx.value, sy.value
@@ -119,7 +131,8 @@ class RecFourier:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().xh_rf_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                lib().xh_rf_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -127,6 +140,9 @@ class RecFourier:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        check(lib().xh_rf_set_option(self.h, name.encode(), float(value)))
 
     def tables(self):
         bt = np.empty(10000, np.float32)
@@ -173,7 +189,8 @@ class RecFourier:
         ang = np.ascontiguousarray(angles, np.float64).reshape(n, 3)
         w = None if weights is None else np.ascontiguousarray(weights, np.float32)
         s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
-        check(lib().xh_rf_insert(self.h, _ptr(fft), _ptr(ctf), _ptr(modulator), _np_ptr(ang), _np_ptr(w), n,
+        f32 = _torch().float32
+        check(lib().xh_rf_insert(self.h, _ptr(fft, f32), _ptr(ctf, f32), _ptr(modulator, f32), _np_ptr(ang), _np_ptr(w), n,
                                  _np_ptr(s), 0 if s is None else s.shape[0]))
 
     def insert_matrices(self, fft, ainv, weights=None, ctf=None, modulator=None, sym=None):
@@ -181,7 +198,8 @@ class RecFourier:
         a = np.ascontiguousarray(ainv, np.float64).reshape(n, 9)
         w = None if weights is None else np.ascontiguousarray(weights, np.float32)
         s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
-        check(lib().xh_rf_insert_matrices(self.h, _ptr(fft), _ptr(ctf), _ptr(modulator), _np_ptr(a), _np_ptr(w),
+        f32 = _torch().float32
+        check(lib().xh_rf_insert_matrices(self.h, _ptr(fft, f32), _ptr(ctf, f32), _ptr(modulator, f32), _np_ptr(a), _np_ptr(w),
                                           n, _np_ptr(s), 0 if s is None else s.shape[0]))
 
     def temp_spaces(self):
@@ -227,13 +245,15 @@ class ProjectionMatcher:
         m = None if Mctf is None else np.ascontiguousarray(Mctf, np.float64)
         check(lib().xh_pm_create(ctx.h, self.D, Ri, Ro, self.nrefs, _ptr(refs), _np_ptr(m), paddim, C.byref(h)))
         self.h = h
+        ctx._children.add(self)
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         check(lib().xh_pm_info(h, C.byref(a), C.byref(b), C.byref(c)))
         self.N, self.ncoef, self.nsamples = a.value, b.value, c.value
 
     def close(self):
         if getattr(self, "h", None):
-            lib().xh_pm_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                lib().xh_pm_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -268,7 +288,8 @@ class ProjectionMatcher:
         sx = torch.empty(n, dtype=torch.float64, device=dev)
         sy = torch.empty_like(sx)
         cc = torch.empty_like(sx)
-        check(lib().xh_pm_translate(self.h, _ptr(particles), n, _ptr(refno), _ptr(psi), _ptr(flip), float(max_shift),
+        check(lib().xh_pm_translate(self.h, _ptr(particles, torch.float32), n, _ptr(refno, torch.int32), _ptr(psi, torch.int32),
+                                    _ptr(flip, torch.uint8), float(max_shift),
                                     _ptr(sx), _ptr(sy), _ptr(cc)))
         return sx, sy, cc
 

@@ -217,6 +217,7 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     bool cropped;
+    int insert_variant;   // 0 = product path; 1/2 = ablation experiments (profiling only)
 };
 
 // =========================================================================== device code
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(256)
 k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__restrict__ ffts,
             const float *__restrict__ ctfs, const float *__restrict__ mods,
             const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
-            int mv, float iDeltaSqrt, double blobRadius)
+            int mv, float iDeltaSqrt, double blobRadius, int variant)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     if (!FAST) {
@@ -482,6 +483,7 @@ k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__rest
             maxX = min(maxX, sizeX - 1);
             maxY = min(maxY, sizeY - 1);
             float accW = 0.f, accR = 0.f, accI = 0.f;
+            if (variant == 2) { accW = 1.f; accR = ix; accI = iy; minY = maxY + 1; }   // experiment: atomics only
             for (int i = minY; i <= maxY; i++) {
                 const float ySqr = (iy - i) * (iy - i);
                 const float yzSqr = ySqr + zSqr;
@@ -508,7 +510,9 @@ k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__rest
                     }
                 }
             }
-            if (accW != 0.f || accR != 0.f || accI != 0.f) {
+            if (variant == 1) {   // experiment: everything but the atomics
+                if (accW == 123456.789f) tempW[0] = accR + accI;
+            } else if (accW != 0.f || accR != 0.f || accI != 0.f) {
                 const size_t vi = ((size_t)z * dim + y) * dim + x;
                 atomicAdd(&tempV[2 * vi], accR);
                 atomicAdd(&tempV[2 * vi + 1], accI);
@@ -793,6 +797,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->iDeltaFourier = 1 / deltaFourier;
     rf->d_temp = nullptr;
     rf->cropped = false;
+    rf->insert_variant = 0;
     int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
     if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     if (r == XH_OK) r = make_twiddles(ctx, rf->P, rf->d_twP32, rf->d_twP64);
@@ -810,6 +815,14 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     delete rf;
+    return XH_OK;
+}
+
+int xh_rf_set_option(xh_rf *rf, const char *name, double value)
+{
+    XH_CHECK(rf && name, XH_ERR_ARG, "null argument");
+    if (!strcmp(name, "insert_variant")) rf->insert_variant = (int)value;
+    else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
 
@@ -1012,7 +1025,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
 #define XH_INSERT(CTF_, FAST_)                                                                              \
     hipLaunchKernelGGL((k_rf_insert<CTF_, FAST_>), dim3(grid), dim3(256), 0, ctx->stream,                    \
                        (const XhSpace *)rf->d_spaces.p, ns, (const xh_cf *)d_fft, d_ctf, d_mod,              \
-                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius)
+                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius, rf->insert_variant)
     if (hasCtf && fast) XH_INSERT(true, true);
     else if (hasCtf) XH_INSERT(true, false);
     else if (fast) XH_INSERT(false, true);
