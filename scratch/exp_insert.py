@@ -11,6 +11,17 @@ fft=rf.prepare_images(imgs)
 ang=synth.random_angles(B,np.random.default_rng(0))
 ctfa=torch.rand((B,rf.sizeY,rf.sizeX),device='cuda')+0.5; moda=torch.rand((B,rf.sizeY,rf.sizeX),device='cuda')
 t=ctx.timer()
+for name,kw in (("tiles-noctf",{}),("tiles-ctf",dict(ctf=ctfa,modulator=moda))):
+    rf.reset(); rf.insert(fft,ang,**kw); ctx.sync()
+    t.start(); rf.insert(fft,ang,**kw); t.stop(); ms=t.elapsed_ms()
+    print(name,"ms",ms,"us/particle",1e3*ms/B)
+for dbg in (1,2,3,4,0):
+    rf.set_option("tile_dbg",dbg)
+    rf.insert(fft,ang); ctx.sync(); t.start(); rf.insert(fft,ang); t.stop(); print("tile_dbg",dbg,"us/particle",1e3*t.elapsed_ms()/B)
+for Bs in (64,256,512):
+    rf.insert(fft[:Bs].contiguous(),ang[:Bs]); ctx.sync(); t.start(); rf.insert(fft[:Bs].contiguous(),ang[:Bs]); t.stop(); print("B",Bs,"us/particle",1e3*t.elapsed_ms()/Bs)
+sys.exit(0)
+rf.set_option("tile_min_spaces",1<<30)
 for name,kw in (("noctf",{}),("ctf",dict(ctf=ctfa,modulator=moda))):
   for v in (0,1,2):
     rf.set_option("insert_variant",v)

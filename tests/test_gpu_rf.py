@@ -85,20 +85,25 @@ def test_ctf_arrays(gpu, oracle):
     assert np.abs(m - me).max() < 1e-6
 
 
-def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, **kw):
+def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
+    if path == "tiles":
+        rf.set_option("tile_min_spaces", 1)       # output-stationary tile kernel even for one projection
+    elif path == "scatter":
+        rf.set_option("tile_min_spaces", 1 << 30)  # atomic scatter kernel
     o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
     ffts = np.stack([o.prepare_image(im) for im in imgs])
     return rf, o, ffts
 
 
-def test_insert_single_projection_bit_exact(gpu, oracle, data32):
+@pytest.mark.parametrize("path", ["scatter", "tiles"])
+def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
     """One projection into an empty volume: the same voxels and, summing taps in the same
     order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     for i in (0, 3, 7):
-        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[i:i + 1], ang[i:i + 1])
+        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[i:i + 1], ang[i:i + 1], path=path)
         o.insert(ffts[0], synth.euler_matrix(*ang[i]).T)
         rf.insert(torch.from_numpy(ffts).cuda(), ang[i:i + 1])
         ev, ew = o.temp()
@@ -123,12 +128,15 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
+@pytest.mark.parametrize("path", ["scatter", "tiles"])
 @pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
-def test_insert_many(gpu, oracle, data32, mode):
+def test_insert_many(gpu, oracle, data32, mode, path):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     fast = mode.startswith("fast")
-    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, fast=fast)
+    if fast and path == "tiles":
+        pytest.skip("--fast always uses the scatter kernel")
+    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=path, fast=fast)
     n = len(imgs)
     rng = np.random.default_rng(5)
     weights = None
@@ -206,11 +214,24 @@ def test_end_to_end_reconstruction(gpu, oracle, data32):
     assert np.abs(again - got).max() <= 1e-5 * np.abs(got).max()
 
 
+def test_tile_kernel_is_deterministic(gpu, data32):
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    rf = xa.RecFourier(ctx, D)
+    f = rf.prepare_images(torch.from_numpy(imgs).cuda())
+    rf.insert(f, ang)
+    v1 = rf.temp.clone()
+    rf.reset()
+    rf.insert(f, ang)
+    assert torch.equal(rf.temp, v1)
+
+
 def test_linearity_of_insertion(gpu, data32):
     """Size-independent property: inserting A then B equals inserting A and B in one call."""
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     rf = xa.RecFourier(ctx, D)
+    rf.set_option("tile_min_spaces", 1)
     f = rf.prepare_images(torch.from_numpy(imgs).cuda())
     rf.insert(f, ang)
     v1 = rf.temp.clone()

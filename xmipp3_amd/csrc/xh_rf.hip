@@ -216,8 +216,14 @@ struct xh_rf {
     XhBuf d_ctfp;
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
+    XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
+    XhBuf d_cull;
+    int tile_max_spaces;
+    int ntiles;
     bool cropped;
-    int insert_variant;   // 0 = product path; 1/2 = ablation experiments (profiling only)
+    int insert_variant;   // 0 = product path; 1/2 = ablation experiments on the scatter kernel; 3 = force scatter
+    int tile_min_spaces;
+    int tile_dbg;         // ablation switch of the tile kernel (profiling only)
 };
 
 // =========================================================================== device code
@@ -522,6 +528,284 @@ k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__rest
     }
 }
 
+
+// ---- gridding, output-stationary form ------------------------------------------------------
+// HBM float atomics top out at ~19.5 G/s on MI355X (profiles/README.md): 3 per slab voxel made
+// the scatter kernel above ~60 us per 256-px projection.  Here every workgroup OWNS one 8x8x8
+// tile of the temp volume: it culls the launch's projections against the tile (plane distance
+// + half-plane extent, data staged in LDS), lets each thread gather the Kaiser-Bessel taps of
+// its single voxel from every surviving projection into registers, and finishes with one plain
+// read-modify-write.  No atomics, run-to-run deterministic; a voxel receives exactly the
+// contributions processVoxelBlob (RFA:627-700) would give it when the reference's traversal
+// (RFA:743-761: AABB rows, hit1||hit2 via getX) visits it.
+#define XH_TSZ 8
+#define XH_CHUNK 256      // projections culled per block-level pass (capacity of the LDS hit records)
+#define XH_QCAP 128       // per-wave work queue capacity (64 pending + 64 new)
+// Workgroup = one 8x8x8 tile, 8 waves; wave w owns the 4x4x4 sub-cube (w&1, (w>>1)&1, w>>2) and
+// lane l the voxel (l&3, (l>>2)&3, l>>4) of it.
+//  block level : cull the launch's projections against the tile, 256 at a time, with an ordered
+//                compaction that also stages the survivors' constants in LDS
+//  wave level  : scalar cull of each survivor against the sub-cube, then a SPARSE test pass
+//                (voxel -> image coordinates, slab / reach tests) that only enqueues
+//                (voxel, projection) items, and a DENSE pass that pops 64 items at a time so the
+//                expensive part (row-visit test + Kaiser-Bessel taps) runs with every lane busy.
+//  accumulation in wave-private LDS (ds_add_f32), one plain read-modify-write of the volume at the end.
+// Tiles are assigned statically: block b (XCD b%8) walks the tiles of z-layer class b%8 (tz mod 8),
+// raster order, stride gridDim/8 -- neighbouring tiles, which share most projections and adjacent
+// image patches, meet in one L2, and no dequeue latency sits between tiles.
+struct XhHitRec { float4 r0, r1, r2; };   // tInv rows; .w: image index, (minY | maxY<<16), (minZ | maxZ<<16)
+
+// LDS-DMA used as a prefetcher: the dword lands in a scratch LDS row (never read); what matters is
+// that the cache line is on its way to L2/L1 long before the dense pass gathers from it.
+__device__ __forceinline__ void d_prefetch(const void *g, void *ldsWaveRow)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)ldsWaveRow, 4, 0, 0);
+}
+template <bool HAS_CTF, bool SMALLBLOB>
+__global__ void __launch_bounds__(512, 4)
+k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN,
+                  const float4 *__restrict__ cullX, int nspaces, const xh_cf *__restrict__ ffts,
+                  const float *__restrict__ ctfs, const float *__restrict__ mods,
+                  const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
+                  int mv, float iDeltaSqrt, double blobRadius, const unsigned *__restrict__ tileList,
+                  const int *__restrict__ classOff, int dbg)
+{
+    __shared__ float sBlob[XH_BLOB_TABLE];
+    __shared__ XhHitRec sRec[XH_CHUNK];
+    __shared__ int sHit[XH_CHUNK];
+    __shared__ int sWaveCnt[8];
+    __shared__ float sAcc[8][3][64];
+    __shared__ float qIx[8][XH_QCAP], qIy[8][XH_QCAP], qZs[8][XH_QCAP];
+    __shared__ int qMeta[8][XH_QCAP];
+    __shared__ float sPref[8][64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < XH_BLOB_TABLE; i += 512) sBlob[i] = blobTable[i];
+    __syncthreads();
+    const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
+    const float fr = (float)blobRadius;
+    const float maxDistanceSqr = (sizeX + blobRadius) * (sizeX + blobRadius);
+    const float radiusSqr = blobRadius * blobRadius;
+    const float rho8 = 6.1f;                      // half diagonal of the 7^3 voxel-centre cube + slack
+    const float rho4 = 2.65f;                     // same for a 4^3 sub-cube (1.5*sqrt(3) = 2.598)
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ox = (wv & 1) * 4, oy = ((wv >> 1) & 1) * 4, oz = (wv >> 2) * 4;
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    float *accW = sAcc[wv][0], *accR = sAcc[wv][1], *accI = sAcc[wv][2];
+
+    // dense pass over queue items [0, n): lane l handles item l
+    auto process = [&](int n, int ty0, int tz0) {
+        if (dbg == 1) return;
+        if (lane < n) {
+            const int meta = qMeta[wv][lane];
+            const int vl = meta & 63, si = meta >> 6;
+            const float ix = qIx[wv][lane], iy = qIy[wv][lane], zSqr = qZs[wv][lane];
+            const XhSpace &S = spaces[si];
+            const int y = ty0 + ((vl >> 2) & 3), z = tz0 + (vl >> 4);
+            // the reference only visits rows that cross the top or bottom face of the slab (RFA:746-750)
+            float xa, xb;
+            const bool hit1 = d_getX(xa, (float)y, (float)z, S.u, S.v, S.p0);
+            const bool hit2 = d_getX(xb, (float)y, (float)z, S.u, S.v, S.p4);
+            if ((hit1 || hit2) && dbg != 3) {
+                int minX = (int)ceil((double)ix - blobRadius);
+                int maxX = (int)floor((double)ix + blobRadius);
+                int minY = (int)ceil((double)iy - blobRadius);
+                int maxY = (int)floor((double)iy + blobRadius);
+                minX = max(minX, 0);
+                minY = max(minY, 0);
+                maxX = min(maxX, sizeX - 1);
+                maxY = min(maxY, sizeY - 1);
+                const size_t imgOff = (size_t)S.img * sizeX * sizeY;
+                const xh_cf *img = ffts + imgOff;
+                const float dataWeight = S.weight;
+                float vW = 0.f, vR = 0.f, vI = 0.f;
+                if (SMALLBLOB) {
+                    // blob radius < 2: at most 4x4 candidate pixels. All loads are issued before any
+                    // arithmetic (one memory latency instead of sixteen); pixels outside the blob get
+                    // weight 0, which leaves the sums bit-identical to the reference's skip.
+                    const int bY = (int)ceil((double)iy - blobRadius), bX = (int)ceil((double)ix - blobRadius);
+                    xh_cf pix[4][4];
+                    float wc[4][4], wm[4][4], wb[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int i = bY + a, j = bX + b;
+                            const bool in = (i >= minY) && (i <= maxY) && (j >= minX) && (j <= maxX);
+                            const int ic = min(max(i, 0), sizeY - 1), jc = min(max(j, 0), sizeX - 1);
+                            const int o = ic * sizeX + jc;
+                            pix[a][b] = img[o];
+                            if (HAS_CTF) { wc[a][b] = ctfs[imgOff + o]; wm[a][b] = mods[imgOff + o]; }
+                            const float ySqr = (iy - i) * (iy - i);
+                            const float yzSqr = ySqr + zSqr;
+                            const float xD = ix - j;
+                            const float distanceSqr = xD * xD + yzSqr;
+                            const bool use = in && !(yzSqr > radiusSqr) && !(distanceSqr > radiusSqr);
+                            const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
+                            wb[a][b] = use ? sBlob[aux] : 0.f;
+                        }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            if (HAS_CTF) {
+                                const float weight = wb[a][b] * wm[a][b] * dataWeight;
+                                vW += weight;
+                                vR += pix[a][b].x * weight * wc[a][b];
+                                vI += pix[a][b].y * weight * wc[a][b];
+                            } else {
+                                const float weight = wb[a][b] * dataWeight;
+                                vW += weight;
+                                vR += pix[a][b].x * weight;
+                                vI += pix[a][b].y * weight;
+                            }
+                        }
+                } else
+                for (int i = minY; i <= maxY; i++) {
+                    const float ySqr = (iy - i) * (iy - i);
+                    const float yzSqr = ySqr + zSqr;
+                    if (yzSqr > radiusSqr) continue;
+                    for (int j = minX; j <= maxX; j++) {
+                        const float xD = ix - j;
+                        const float distanceSqr = xD * xD + yzSqr;
+                        if (distanceSqr > radiusSqr) continue;
+                        const int aux = (int)(distanceSqr * iDeltaSqrt + 0.5f);
+                        const float wBlob = sBlob[aux];
+                        const xh_cf pix = img[i * sizeX + j];
+                        if (HAS_CTF) {
+                            const float wCTF = ctfs[imgOff + i * sizeX + j];
+                            const float wModulator = mods[imgOff + i * sizeX + j];
+                            const float weight = wBlob * wModulator * dataWeight;
+                            vW += weight;
+                            vR += pix.x * weight * wCTF;
+                            vI += pix.y * weight * wCTF;
+                        } else {
+                            const float weight = wBlob * dataWeight;
+                            vW += weight;
+                            vR += pix.x * weight;
+                            vI += pix.y * weight;
+                        }
+                    }
+                }
+                atomicAdd(&accW[vl], vW);
+                atomicAdd(&accR[vl], vR);
+                atomicAdd(&accI[vl], vI);
+            }
+        }
+    };
+
+    const int cls = blockIdx.x & 7, rank = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    const int cBeg = classOff[cls], cEnd = classOff[cls + 1];
+    unsigned packedNext = (cBeg + rank < cEnd) ? tileList[cBeg + rank] : 0u;
+    for (int ti = cBeg + rank; ti < cEnd; ti += nb) {
+        const unsigned packed = packedNext;
+        if (ti + nb < cEnd) packedNext = tileList[ti + nb];   // prefetch: latency hides behind this tile
+        const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
+        const int x0 = tx * XH_TSZ + ox, y0 = ty * XH_TSZ + oy, z0 = tz * XH_TSZ + oz;
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        const bool inVol = (x <= mv) && (y <= mv) && (z <= mv);
+        const float cx = tx * XH_TSZ + 3.5f - mv / 2, cy = ty * XH_TSZ + 3.5f - mv / 2, cz = tz * XH_TSZ + 3.5f - mv / 2;
+        const float c4x = x0 + 1.5f - mv / 2, c4y = y0 + 1.5f - mv / 2, c4z = z0 + 1.5f - mv / 2;
+        const float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
+        const bool inSphere = inVol && !((px * px + py * py + pz * pz) > maxDistanceSqr);
+        accW[lane] = 0.f; accR[lane] = 0.f; accI[lane] = 0.f;
+        int qn = 0;   // wave-uniform queue length
+        for (int s0 = 0; s0 < nspaces; s0 += XH_CHUNK) {
+            const int s = s0 + tid;
+            bool hit = false;
+            if (tid < XH_CHUNK && s < nspaces) {
+                const float4 n = cullN[s], r0 = cullX[s];
+                const float dn = n.x * cx + n.y * cy + n.z * cz;
+                const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
+                hit = (fabsf(dn) <= fr + rho8) && (dx >= -(fr + rho8)) && (dx <= sizeX + fr + rho8);
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) sWaveCnt[wv] = __popcll(bal);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < XH_CHUNK / 64; ++w) { const int c = sWaveCnt[w]; if (w < wv) base += c; total += c; }
+            if (hit) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const XhSpace &S = spaces[s];
+                sHit[pos] = s;
+                XhHitRec r;
+                r.r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], __int_as_float(S.img));
+                r.r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], __int_as_float(S.minY | (S.maxY << 16)));
+                r.r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], __int_as_float(S.minZ | (S.maxZ << 16)));
+                sRec[pos] = r;
+            }
+            __syncthreads();
+            for (int h = 0; h < (dbg == 2 ? 0 : total); ++h) {
+                // wave-uniform cull against the 4^3 sub-cube (LDS broadcast reads)
+                const float4 r2 = sRec[h].r2, r0 = sRec[h].r0;
+                const float dn = r2.x * c4x + r2.y * c4y + r2.z * c4z;
+                const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
+                if (!((fabsf(dn) <= fr + rho4) && (dx >= -(fr + rho4)) && (dx <= sizeX + fr + rho4))) continue;
+                const float4 r1 = sRec[h].r1;
+                const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
+                bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
+                float ix = 0.f, iy = 0.f, zSqr = 0.f;
+                if (pass) {
+                    ix = r0.x * px + r0.y * py + r0.z * pz;
+                    iy = r1.x * px + r1.y * py + r1.z * pz;
+                    const float iz = r2.x * px + r2.y * py + r2.z * pz;
+                    iy += mv / 2;
+                    zSqr = iz * iz;
+                    pass = !(zSqr > radiusSqr);
+                    // a voxel with no pixel within reach adds nothing: drop it before the costly part
+                    pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
+                           ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+                }
+                const unsigned long long pb = __ballot(pass);
+                const int np = __popcll(pb);
+                if (np == 0) continue;
+                if (pass) {
+                    const int q = qn + __popcll(pb & ((1ull << lane) - 1ull));
+                    qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
+                    qMeta[wv][q] = (sHit[h] << 6) | lane;
+                    if (dbg != 4) {
+                        // start pulling the 4 rows of this voxel's footprint towards the caches
+                        const size_t imgOff = (size_t)__float_as_int(r0.w) * sizeX * sizeY;
+                        const int pj = min(max((int)(ix + 0.5f), 0), sizeX - 1);
+                        const int bY = (int)ceil((double)iy - blobRadius);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int row = min(max(bY + a, 0), sizeY - 1);
+                            const size_t o = imgOff + (size_t)row * sizeX + pj;
+                            d_prefetch(ffts + o, &sPref[wv][0]);
+                            if (HAS_CTF) { d_prefetch(ctfs + o, &sPref[wv][0]); d_prefetch(mods + o, &sPref[wv][0]); }
+                        }
+                    }
+                }
+                qn += np;
+                if (qn >= 64) {
+                    process(64, y0, z0);
+                    // move the remainder down (source index >= 64 > destination)
+                    const int rem = qn - 64;
+                    float a = 0.f, b = 0.f, c = 0.f;
+                    int m = 0;
+                    if (lane < rem) { a = qIx[wv][64 + lane]; b = qIy[wv][64 + lane]; c = qZs[wv][64 + lane]; m = qMeta[wv][64 + lane]; }
+                    if (lane < rem) { qIx[wv][lane] = a; qIy[wv][lane] = b; qZs[wv][lane] = c; qMeta[wv][lane] = m; }
+                    qn = rem;
+                }
+            }
+            __syncthreads();
+        }
+        if (qn > 0) process(qn, y0, z0);
+        const float aW = accW[lane], aR = accR[lane], aI = accI[lane];
+        if (inSphere && (aW != 0.f || aR != 0.f || aI != 0.f)) {
+            const size_t vi = ((size_t)z * dim + y) * dim + x;
+            float2 *V = reinterpret_cast<float2 *>(tempV) + vi;
+            float2 v = *V;
+            v.x += aR;
+            v.y += aI;
+            *V = v;
+            tempW[vi] += aW;
+        }
+    }
+}
+
 // ---- finaliser ---------------------------------------------------------------------------
 // mirrorAndCrop RFA:861-887 in gather form. in: (mv+1)^3, out: (mv+1)^2 (half+1)
 __global__ void k_rf_mirror(const xh_cf *__restrict__ inV, const float *__restrict__ inW,
@@ -798,9 +1082,36 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->d_temp = nullptr;
     rf->cropped = false;
     rf->insert_variant = 0;
+    rf->tile_min_spaces = 24;
+    rf->tile_dbg = 0;
+    rf->tile_max_spaces = 8192;
     int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
     if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     if (r == XH_OK) r = make_twiddles(ctx, rf->P, rf->d_twP32, rf->d_twP64);
+    rf->ntiles = 0;
+    if (r == XH_OK) {
+        // tiles that a projection can reach (sphere of radius sizeX + blob), heaviest (central) first
+        const int tpd = (rf->mv + 1 + XH_TSZ - 1) / XH_TSZ;
+        const double R = rf->sizeX + p->blob_radius + 6.1 + 1.0;
+        std::vector<unsigned> packed;
+        int classOff[9];
+        for (int c = 0; c < 8; ++c) {
+            classOff[c] = (int)packed.size();
+            for (int tz = c; tz < tpd; tz += 8)
+                for (int ty = 0; ty < tpd; ++ty)
+                    for (int tx = 0; tx < tpd; ++tx) {
+                        const double cx = tx * XH_TSZ + 3.5 - rf->mv / 2, cy = ty * XH_TSZ + 3.5 - rf->mv / 2, cz = tz * XH_TSZ + 3.5 - rf->mv / 2;
+                        if (std::sqrt(cx * cx + cy * cy + cz * cz) <= R) packed.push_back((unsigned)(tx | (ty << 8) | (tz << 16)));
+                    }
+        }
+        classOff[8] = (int)packed.size();
+        rf->ntiles = (int)packed.size();
+        r = xh_buf_alloc(ctx, rf->d_tiles, sizeof(unsigned) * packed.size());
+        if (r == XH_OK) r = (hipMemcpy(rf->d_tiles.p, packed.data(), rf->d_tiles.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+        // d_tileCounter: ints [0,8) work counters, [16,25) class offsets
+        if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 64);
+        if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 16, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+    }
     if (r != XH_OK) { xh_rf_destroy(rf); return r; }
     *out = rf;
     return XH_OK;
@@ -814,6 +1125,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
+    xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull);
     delete rf;
     return XH_OK;
 }
@@ -822,6 +1134,9 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
 {
     XH_CHECK(rf && name, XH_ERR_ARG, "null argument");
     if (!strcmp(name, "insert_variant")) rf->insert_variant = (int)value;
+    else if (!strcmp(name, "tile_min_spaces")) rf->tile_min_spaces = (int)value;
+    else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
+    else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1020,8 +1335,42 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     XH_HIP(hipStreamSynchronize(ctx->stream));
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
-    const int grid = 8 * std::max(1, (ctx->num_cus * 4) / 8);
     const bool hasCtf = d_ctf != nullptr, fast = rf->p.use_fast != 0;
+    // product path: output-stationary tiles (no atomics). The scatter kernel remains for --fast
+    // (one voxel per row, RFA:595-625) and for launches too small to amortise a volume pass.
+    const bool useTiles = !fast && rf->insert_variant == 0 && ns >= rf->tile_min_spaces && rf->mv / XH_TSZ < 255;
+    if (useTiles) {
+        const int grid = 8 * std::max(1, (ctx->num_cus * 2) / 8);
+        const bool smallBlob = rf->p.blob_radius < 2.0;
+        // cull tables (plane normal / image x axis per space), SoA for coalesced block-level culling
+        std::vector<float> cull((size_t)ns * 8);
+        for (int i = 0; i < ns; ++i) {
+            float *n = &cull[(size_t)i * 4], *x = &cull[(size_t)(ns + i) * 4];
+            n[0] = spaces[i].tInv[6]; n[1] = spaces[i].tInv[7]; n[2] = spaces[i].tInv[8]; n[3] = 0.f;
+            x[0] = spaces[i].tInv[0]; x[1] = spaces[i].tInv[1]; x[2] = spaces[i].tInv[2]; x[3] = 0.f;
+        }
+        XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
+        XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+        const int maxsp = std::max(64, rf->tile_max_spaces);
+        for (int s0 = 0; s0 < ns; s0 += maxsp) {
+            const int m = std::min(maxsp, ns - s0);
+#define XH_TILES(CTF_, SB_)                                                                                         \
+    hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
+                       (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
+                       (const float4 *)rf->d_cull.p + ns + s0, m, (const xh_cf *)d_fft, d_ctf, d_mod,                \
+                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
+                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, rf->tile_dbg)
+            if (hasCtf && smallBlob) XH_TILES(true, true);
+            else if (hasCtf) XH_TILES(true, false);
+            else if (smallBlob) XH_TILES(false, true);
+            else XH_TILES(false, false);
+#undef XH_TILES
+            XH_LAUNCH_CHECK();
+        }
+        return XH_OK;
+    }
+    const int grid = 8 * std::max(1, (ctx->num_cus * 4) / 8);
 #define XH_INSERT(CTF_, FAST_)                                                                              \
     hipLaunchKernelGGL((k_rf_insert<CTF_, FAST_>), dim3(grid), dim3(256), 0, ctx->stream,                    \
                        (const XhSpace *)rf->d_spaces.p, ns, (const xh_cf *)d_fft, d_ctf, d_mod,              \
