@@ -128,9 +128,10 @@ int xh_rf_attach_temp(xh_rf *rf, float *d_temp /* xh_rf_temp_floats() floats */)
 int xh_rf_temp_ptr(xh_rf *rf, float **d_temp);
 int xh_rf_reset(xh_rf *rf);
 /* Image::readApplyGeo(..., only_apply_shifts) (RFA:304-323): out = in translated by
- * h_shiftXY[i] = (shiftX, shiftY) pixels, cubic B-spline interpolation with wrapping. */
-int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY /* [n][2] */, int32_t n,
-                       float *d_out);
+ * h_shiftXY[i] = (shiftX, shiftY) pixels (and mirrored in x where h_flip[i] != 0; h_flip may be
+ * NULL), cubic B-spline interpolation with wrapping. */
+int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY /* [n][2] */,
+                       const uint8_t *h_flip /* [n] or NULL */, int32_t n, float *d_out);
 /* preloadBuffer + cropAndShift for n images already shifted (shifts applied):
  * d_imgs [n][D][D] float  ->  d_fft [n][mv][mv/2] complex<float> (interleaved) */
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft);

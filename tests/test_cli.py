@@ -1,0 +1,125 @@
+"""The drop-in process-level contract: same binary names, flags, error behaviour and output
+files as xmipp_angular_projection_matching / xmipp_reconstruct_fourier_accel."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import synth, xmipp_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "xmipp3_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def bins():
+    import __graft_entry__ as g
+    g.build()
+    return BIN
+
+
+def _run(args, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, **kw)
+
+
+def test_help_and_argument_errors(bins):
+    for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier"):
+        r = _run([os.path.join(bins, prog), "--help"])
+        assert r.returncode == 0 and "USAGE" in r.stderr
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-o", "x.xmd"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "-i is mandatory" in r.stderr
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", "nonexistent.xmd", "--bogus"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+
+
+def test_reference_flag_spellings_are_accepted(bins, tmp_path):
+    # the argument strings of test_programs.py:150-159,881-889 parse; failure must come from the
+    # missing input file (or, without a GPU, from the device), never from the parser
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", "input/aFewProjections.sel", "-o", str(tmp_path / "o.xmd"),
+              "--ref", "ref.stk", "--thr", "3", "--search5d_shift", "0", "--search5d_step", "2", "--Ri", "1", "--Ro", "20",
+              "--max_shift", "10", "--mem", "1", "--append"])
+    assert r.returncode != 0 and "cannot open" in r.stderr
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier"), "-i", "input/aFewProjections.sel", "-o", str(tmp_path / "rec.vol"),
+              "--sym", "c1", "--padding", "2", "2", "--max_resolution", "0.5", "--blob", "1.9", "0", "15", "--thr", "1", "--weight"])
+    assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def _write_dataset(tmp, D=32, nrefs=12, n=9, seed=4):
+    vol = synth.phantom(D, seed=seed, nblobs=10)
+    refs, dirs = synth.make_refs(vol, nrefs)
+    rng = np.random.default_rng(seed)
+    parts, _ = synth.make_particles(refs, n, rng, snr=0.5, max_shift=1)
+    xmipp_io.write_stack(str(tmp / "ref.stk"), refs)
+    xmipp_io.write_stack(str(tmp / "parts.stk"), parts)
+    # reference ids are 1-based and deliberately not in stack order
+    ids = [3 * i + 1 for i in range(nrefs)]
+    nbrs = [" ".join(str(ids[j]) for j in rng.permutation(nrefs)[:rng.integers(4, nrefs + 1)]) for _ in range(n)]
+    xmipp_io.write_xmd(str(tmp / "ref_sampling.xmd"), [
+        ("extra", ["sampling_rate", "neighborhoodRadius", "pointsAsymmetricUnit"], [[0.05, -1.01, max(ids) + 1]]),
+        ("neighbors", ["neighbor", "neighbors"], [[i + 1, " " + nbrs[i] + " "] for i in range(n)]),
+        ("projectionDirections", ["neighbor", "angleRot", "angleTilt", "anglePsi", "X", "Y", "Z"],
+         [[ids[i], f"{dirs[i][0]:.6f}", f"{dirs[i][1]:.6f}", "0.000000", 0, 0, 1] for i in range(nrefs)])])
+    xmipp_io.write_xmd(str(tmp / "exp.xmd"), [("noname", ["itemId", "image"], [[100 + i, f"{i + 1}@{tmp}/parts.stk"] for i in range(n)])])
+    return refs, dirs, parts, ids, nbrs
+
+
+def test_no_gpu_means_xmipp_error_not_fallback(bins, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _write_dataset(tmp_path)
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
+              "--ref", str(tmp_path / "ref.stk")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "no CPU fallback" in r.stderr
+    assert not (tmp_path / "out.xmd").exists()
+
+
+@pytest.mark.gpu
+def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle):
+    """project-match with the CLI, reconstruct from its output with the CLI; compare both with
+    the oracle run on the same files' contents."""
+    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path)
+    n, nrefs, D = len(parts), len(refs), refs.shape[1]
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
+              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4"])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"))
+    assert labels == ["itemId", "image", "angleRot", "angleTilt", "anglePsi", "shiftX", "shiftY", "ref", "flip", "scale", "maxCC"]
+    assert len(rows) == n
+    # oracle on the same neighbour lists (stack positions), same visiting-order parity
+    pos = {ids[i]: i for i in range(nrefs)}
+    lists = [[pos[int(v)] for v in s.split()] for s in nbrs]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    pm = oracle.PM(refs)
+    er, ep, ef, _ = pm.match(parts, off, np.concatenate(lists).astype(np.int32))
+    ex, ey, ec = pm.translate(parts, er[:, 0], ep[:, 0], ef[:, 0], 6.0)
+    c = {l: i for i, l in enumerate(labels)}
+    for i, row in enumerate(rows):
+        assert int(row[c["itemId"]]) == 100 + i
+        assert int(row[c["ref"]]) == ids[er[i, 0]]
+        assert int(row[c["flip"]]) == ef[i, 0]
+        assert abs(float(row[c["anglePsi"]]) - ep[i, 0] * 360.0 / pm.N) < 1e-5
+        assert abs(float(row[c["angleRot"]]) - dirs[er[i, 0]][0]) < 1e-5 and abs(float(row[c["angleTilt"]]) - dirs[er[i, 0]][1]) < 1e-5
+        assert abs(float(row[c["shiftX"]]) - ex[i]) < 1e-3 and abs(float(row[c["shiftY"]]) - ey[i]) < 1e-3
+        assert abs(float(row[c["maxCC"]]) - ec[i]) < 1e-5
+    # reconstruction from the assigned angles (shifts and flips applied by the program)
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "out.xmd"), "-o", str(tmp_path / "rec.vol"),
+              "--batch", "5", "--sym", "c2"])
+    assert r.returncode == 0, r.stderr
+    got = xmipp_io.read_volume(str(tmp_path / "rec.vol"))
+    assert got.shape == (D, D, D)
+    rf = oracle.RF(D)
+    c2 = np.diag([-1.0, -1.0, 1.0])
+    for i, row in enumerate(rows):
+        sx, sy, fl = float(row[c["shiftX"]]), float(row[c["shiftY"]]), int(row[c["flip"]])
+        A = np.array([[-1.0 if fl else 1.0, 0, sx], [0, 1, sy], [0, 0, 1]])
+        img = oracle.apply_geometry2d(parts[i], A, 3, False, True) if (fl or sx or sy) else parts[i]
+        ang = [float(row[c["angleRot"]]), float(row[c["angleTilt"]]), float(row[c["anglePsi"]])]
+        f = rf.prepare_image(img)
+        for R in (np.eye(3), c2):
+            rf.insert(f, synth.euler_matrix(*ang).T, R=R)
+    rf.mirror_and_crop()
+    exp = rf.finish()
+    assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()

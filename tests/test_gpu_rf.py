@@ -67,6 +67,12 @@ def test_shift_images(gpu, oracle):
         exp = oracle.translate2d(imgs[i], shifts[i, 0], shifts[i, 1], degree=3, wrap=True)
         assert np.abs(got[i] - exp).max() <= 2e-5 * np.abs(exp).max()
     assert np.array_equal(got[0], imgs[0])
+    # mirrored + shifted (flip negates the first row of the transformation matrix)
+    gotf = rf.shift_images(torch.from_numpy(imgs).cuda(), shifts, flips=np.ones(4, np.uint8)).cpu().numpy()
+    for i in range(4):
+        A = np.array([[-1.0, 0, shifts[i, 0]], [0, 1, shifts[i, 1]], [0, 0, 1]])
+        exp = oracle.apply_geometry2d(imgs[i], A, 3, False, True)
+        assert np.abs(gotf[i] - exp).max() <= 2e-5 * np.abs(exp).max()
 
 
 def test_ctf_arrays(gpu, oracle):

@@ -59,7 +59,7 @@ SIGNATURES = {
     "xh_rf_attach_temp": (C.c_int, [vp, vp]),
     "xh_rf_temp_ptr": (C.c_int, [vp, pvp]),
     "xh_rf_reset": (C.c_int, [vp]),
-    "xh_rf_shift_images": (C.c_int, [vp, vp, vp, i32, vp]),
+    "xh_rf_shift_images": (C.c_int, [vp, vp, vp, vp, i32, vp]),
     "xh_rf_prepare_images": (C.c_int, [vp, vp, i32, vp]),
     "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
     "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),

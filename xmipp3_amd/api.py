@@ -155,13 +155,14 @@ class RecFourier:
         check(lib().xh_rf_reset(self.h))
         self.cropped = False
 
-    def shift_images(self, imgs, shifts):
+    def shift_images(self, imgs, shifts, flips=None):
         """Image::readApplyGeo(only_apply_shifts): shifts [n,2] = (shiftX, shiftY) on the host."""
         torch = _torch()
         n = imgs.shape[0]
         sh = np.ascontiguousarray(shifts, np.float32).reshape(n, 2)
+        fl = None if flips is None else np.ascontiguousarray(flips, np.uint8).reshape(n)
         out = torch.empty_like(imgs)
-        check(lib().xh_rf_shift_images(self.h, _ptr(imgs), _np_ptr(sh), n, _ptr(out)))
+        check(lib().xh_rf_shift_images(self.h, _ptr(imgs, torch.float32), _np_ptr(sh), _np_ptr(fl), n, _ptr(out)))
         return out
 
     def prepare_images(self, imgs, out=None):

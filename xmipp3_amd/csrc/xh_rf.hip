@@ -305,16 +305,20 @@ k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *
 // with cubic B-spline interpolation and wrapping (xmippCore applyGeometry(BSPLINE3, ..., WRAP)).
 // out(x,y) samples the prefiltered input at (x - shiftX, y - shiftY).
 __global__ void k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
-                           const float2 *__restrict__ shifts, float *__restrict__ out, int D)
+                           const float2 *__restrict__ shifts, const unsigned char *__restrict__ flips,
+                           float *__restrict__ out, int D)
 {
     const int p = blockIdx.y;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= D * D) return;
     const float2 sh = shifts[p];
-    if (sh.x == 0.f && sh.y == 0.f) { out[(size_t)p * D * D + pix] = imgs[(size_t)p * D * D + pix]; return; }
+    const bool flip = flips && flips[p];
+    if (!flip && sh.x == 0.f && sh.y == 0.f) { out[(size_t)p * D * D + pix] = imgs[(size_t)p * D * D + pix]; return; }
     const int i = pix / D, j = pix - i * D, cen = D / 2;
     const float minp = -cen, maxp = D - cen - 1;
-    float xp = (float)(j - cen) - sh.x, yp = (float)(i - cen) - sh.y;
+    // A = [[+-1,0,sx],[0,1,sy]] (flip negates the first row of the 2x2 part, xmippCore
+    // geo2TransformationMatrix); IS_NOT_INV => sample the input at A^-1 (x,y)
+    float xp = flip ? sh.x - (float)(j - cen) : (float)(j - cen) - sh.x, yp = (float)(i - cen) - sh.y;
     if (xp < minp - 1e-6f || xp > maxp + 1e-6f) xp = d_realwrap<float>(xp, minp - 0.5f, maxp + 0.5f);
     if (yp < minp - 1e-6f || yp > maxp + 1e-6f) yp = d_realwrap<float>(yp, minp - 0.5f, maxp + 0.5f);
     out[(size_t)p * D * D + pix] = d_interp<float>(coefs + (size_t)p * D * D, D, xp, yp);
@@ -1235,7 +1239,7 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
 }
 
 
-int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, int32_t n, float *d_out)
+int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
 {
     XH_CHECK(rf && d_imgs && h_shiftXY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images: bad argument");
     XH_CHECK(d_imgs != d_out, XH_ERR_ARG, "xh_rf_shift_images: in-place operation is not supported");
@@ -1243,8 +1247,13 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, i
     xh_ctx *ctx = rf->ctx;
     const int D = rf->D;
     XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
-    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n + (size_t)n));
     XH_HIP(hipMemcpyAsync(rf->d_shiftXY.p, h_shiftXY, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    unsigned char *d_flip = nullptr;
+    if (h_flip) {
+        d_flip = (unsigned char *)rf->d_shiftXY.p + sizeof(float) * 2 * (size_t)n;
+        XH_HIP(hipMemcpyAsync(d_flip, h_flip, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
     XH_HIP(hipStreamSynchronize(ctx->stream));
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(float)))));
     const int tiles = (D + TR - 1) / TR;
@@ -1255,7 +1264,7 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, i
                        (const int *)nullptr);
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, (const float *)rf->d_shiftCoef.p, d_imgs,
-                       (const float2 *)rf->d_shiftXY.p, d_out, D);
+                       (const float2 *)rf->d_shiftXY.p, (const unsigned char *)d_flip, d_out, D);
     XH_LAUNCH_CHECK();
     return XH_OK;
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds the host programs against libxmipp_hip.so (plain g++: the host side has no HIP code).
+set -e
+cd "$(dirname "$0")"
+mkdir -p ../bin
+CXX=${CXX:-g++}
+FLAGS="-O2 -std=c++17 -Wall -Wno-unused-function"
+LINK="-L.. -lxmipp_hip -Wl,-rpath,\$ORIGIN/.. -Wl,-rpath,/opt/rocm/lib"
+$CXX $FLAGS angular_projection_matching_main.cpp -o ../bin/xmipp_angular_projection_matching $LINK &
+$CXX $FLAGS reconstruct_fourier_accel_main.cpp -o ../bin/xmipp_reconstruct_fourier_accel $LINK &
+wait
+cp -f ../bin/xmipp_reconstruct_fourier_accel ../bin/xmipp_reconstruct_fourier
+echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier}"

@@ -1,0 +1,451 @@
+// minicore.h -- the sliver of xmippCore's API surface that the two hot-path programs touch.
+//
+// xmippCore (XmippProgram, MetaData*, Image<T>, FileName, SymList ...) is a separate upstream
+// repository that is not part of the reference tree (I2PC/xmippCore @ v4).
+// The host programs in this directory keep the reference's program contract -- same flags,
+// same metadata labels, same file formats -- on top of this stand-in:
+//   * XmippProgram : the declarative argument DSL used verbatim by defineParams()
+//                    (reconstruction/angular_projection_matching.cpp:83-121,
+//                     reconstruction/reconstruct_fourier_accel.cpp:55-82), tryRun() error contract
+//   * MetaDataVec  : "# XMIPP_STAR_1" files, data_<block> / loop_ / block@file
+//                    (format: resources/test/sampling/*.xmd)
+//   * Image I/O    : Spider single/stack/volume and MRC (mode 2), n@stack addressing
+//   * SymList      : cyclic groups
+#ifndef XMIPP3_AMD_MINICORE_H
+#define XMIPP3_AMD_MINICORE_H
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mc {
+
+// ------------------------------------------------------------------ errors
+enum ErrorType { ERR_ARG_INCORRECT = 2, ERR_ARG_MISSING = 3, ERR_IO_NOTEXIST = 20, ERR_IO_NOREAD = 21,
+                 ERR_MD_NOOBJ = 30, ERR_MD_BADLABEL = 31, ERR_MULTIDIM_SIZE = 40, ERR_VALUE_INCORRECT = 50,
+                 ERR_GPU = 60, ERR_NOT_IMPLEMENTED = 61 };
+struct XmippError : public std::runtime_error {
+    int code;
+    XmippError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+#define REPORT_ERROR(code, msg) throw mc::XmippError(code, std::string(msg))
+
+inline std::string trim(const std::string &s)
+{
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+}
+inline bool fileExists(const std::string &fn) { std::ifstream f(fn); return f.good(); }
+
+// ------------------------------------------------------------------ file names
+// "n@stack.stk" (1-based n), "block@file.xmd"
+struct FileName {
+    std::string prefix, path;   // prefix = text before '@' ("" if none)
+    FileName() {}
+    FileName(const std::string &s) { size_t p = s.find('@'); if (p == std::string::npos) path = s; else { prefix = s.substr(0, p); path = s.substr(p + 1); } }
+    std::string str() const { return prefix.empty() ? path : prefix + "@" + path; }
+    bool hasNumber() const { return !prefix.empty() && std::all_of(prefix.begin(), prefix.end(), ::isdigit); }
+    size_t number() const { return hasNumber() ? (size_t)std::stoul(prefix) : 0; }
+    std::string extension() const { size_t p = path.rfind('.'); return p == std::string::npos ? "" : path.substr(p + 1); }
+    std::string removeAllExtensions() const
+    {
+        size_t slash = path.rfind('/');
+        size_t p = path.find('.', slash == std::string::npos ? 0 : slash);
+        return p == std::string::npos ? path : path.substr(0, p);
+    }
+};
+
+// ------------------------------------------------------------------ metadata
+class MetaDataVec {
+public:
+    std::vector<std::string> labels;
+    std::vector<std::vector<std::string>> rows;
+    std::string comment;
+
+    size_t size() const { return rows.size(); }
+    bool containsLabel(const std::string &l) const { return std::find(labels.begin(), labels.end(), l) != labels.end(); }
+    int col(const std::string &l) const
+    {
+        auto it = std::find(labels.begin(), labels.end(), l);
+        return it == labels.end() ? -1 : (int)(it - labels.begin());
+    }
+    void addLabel(const std::string &l) { if (!containsLabel(l)) { labels.push_back(l); for (auto &r : rows) r.push_back(""); } }
+    size_t addObject() { rows.emplace_back(labels.size()); return rows.size() - 1; }
+    void setValue(const std::string &l, const std::string &v, size_t id) { addLabel(l); rows[id].resize(labels.size()); rows[id][col(l)] = v; }
+    void setValue(const std::string &l, double v, size_t id) { char b[64]; snprintf(b, sizeof(b), "%12.6f", v); setValue(l, std::string(b), id); }
+    void setValue(const std::string &l, long v, size_t id) { setValue(l, std::to_string(v), id); }
+    bool getValue(const std::string &l, std::string &v, size_t id) const { int c = col(l); if (c < 0 || rows[id][c].empty()) return false; v = rows[id][c]; return true; }
+    bool getValue(const std::string &l, double &v, size_t id) const { std::string s; if (!getValue(l, s, id)) return false; v = atof(s.c_str()); return true; }
+    bool getValue(const std::string &l, long &v, size_t id) const { std::string s; if (!getValue(l, s, id)) return false; v = atol(s.c_str()); return true; }
+    double getDouble(const std::string &l, size_t id, double def) const { double v = def; getValue(l, v, id); return v; }
+
+    static std::vector<std::string> tokenize(const std::string &line)
+    {
+        std::vector<std::string> t;
+        size_t i = 0;
+        while (i < line.size()) {
+            while (i < line.size() && isspace((unsigned char)line[i])) ++i;
+            if (i >= line.size()) break;
+            if (line[i] == '\'' || line[i] == '"') {
+                char q = line[i];
+                size_t j = line.find(q, i + 1);
+                if (j == std::string::npos) j = line.size();
+                t.push_back(line.substr(i + 1, j - i - 1));
+                i = j + 1;
+            } else {
+                size_t j = i;
+                while (j < line.size() && !isspace((unsigned char)line[j])) ++j;
+                t.push_back(line.substr(i, j - i));
+                i = j;
+            }
+        }
+        return t;
+    }
+
+    // fn may be "block@file"; empty block => first block of the file
+    void read(const std::string &fnFull)
+    {
+        FileName fn(fnFull);
+        const std::string block = fn.hasNumber() ? "" : fn.prefix;
+        std::ifstream f(fn.path);
+        if (!f.good()) REPORT_ERROR(ERR_IO_NOTEXIST, "MetaData::read: cannot open " + fn.path);
+        labels.clear(); rows.clear();
+        std::string line;
+        bool inBlock = false, found = false, loop = false, header = true;
+        std::vector<std::string> single;
+        while (std::getline(f, line)) {
+            std::string t = trim(line);
+            if (t.empty() || t[0] == '#' || t[0] == ';') continue;
+            if (t.rfind("data_", 0) == 0) {
+                if (inBlock) break;             // next block starts: done
+                std::string name = t.substr(5);
+                if (block.empty() || name == block) { inBlock = found = true; loop = false; header = true; }
+                continue;
+            }
+            if (!inBlock) continue;
+            if (t == "loop_") { loop = true; continue; }
+            if (t[0] == '_' && header) {
+                std::vector<std::string> tk = tokenize(t);
+                labels.push_back(tk[0].substr(1));
+                if (!loop) single.push_back(tk.size() > 1 ? tk[1] : "");
+                continue;
+            }
+            header = false;
+            if (loop) {
+                std::vector<std::string> tk = tokenize(t);
+                tk.resize(labels.size());
+                rows.push_back(tk);
+            }
+        }
+        if (!found) REPORT_ERROR(ERR_MD_NOOBJ, "MetaData::read: block '" + block + "' not found in " + fn.path);
+        if (!loop && !labels.empty()) rows.push_back(single);
+    }
+
+    void write(const std::string &fnFull, bool append = false) const
+    {
+        FileName fn(fnFull);
+        const std::string block = (fn.prefix.empty() || fn.hasNumber()) ? "noname" : fn.prefix;
+        const bool exists = fileExists(fn.path);
+        std::ofstream f(fn.path, append ? std::ios::app : std::ios::trunc);
+        if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "MetaData::write: cannot write " + fn.path);
+        if (!(append && exists)) f << "# XMIPP_STAR_1 * \n# \n";
+        if (!comment.empty()) f << "# " << comment << "\n";
+        f << "data_" << block << "\nloop_\n";
+        for (auto &l : labels) f << " _" << l << "\n";
+        for (auto &r : rows) {
+            for (size_t c = 0; c < labels.size(); ++c) {
+                const std::string &v = c < r.size() ? r[c] : std::string();
+                if (v.find(' ') != std::string::npos && v.find('\'') == std::string::npos) f << " '" << v << "'";
+                else f << " " << (v.empty() ? "0" : v);
+            }
+            f << " \n";
+        }
+    }
+};
+
+// ------------------------------------------------------------------ images
+struct ImageInfo { size_t x = 0, y = 0, z = 1, n = 1; bool isStack = false; size_t headerBytes = 0, perImageHeader = 0; bool mrc = false, swap = false; };
+
+inline bool isMrcExt(const std::string &e) { return e == "mrc" || e == "mrcs" || e == "map" || e == "st"; }
+
+inline ImageInfo readInfo(const std::string &path)
+{
+    FileName fn(path);
+    std::ifstream f(fn.path, std::ios::binary);
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOTEXIST, "Image::read: cannot open " + fn.path);
+    ImageInfo I;
+    if (isMrcExt(fn.extension())) {
+        int32_t h[256];
+        f.read((char *)h, 1024);
+        if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short MRC header in " + fn.path);
+        if (h[3] != 2) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: only MRC mode 2 (float32) is supported: " + fn.path);
+        I.mrc = true; I.x = h[0]; I.y = h[1];
+        const bool stack = fn.extension() == "mrcs" || fn.extension() == "st";
+        if (stack) { I.z = 1; I.n = h[2]; I.isStack = true; } else { I.z = h[2]; I.n = 1; }
+        I.headerBytes = 1024 + (size_t)h[23];
+        return I;
+    }
+    float h[64];
+    f.read((char *)h, sizeof(h));
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short Spider header in " + fn.path);
+    // Spider header (1-based word index): 1 NZ, 2 NY, 5 IFORM, 12 NX, 13 LABREC, 22 LABBYT, 23 LENBYT, 24 ISTACK, 26 MAXIM
+    I.z = (size_t)std::max(1.f, std::fabs(h[0])); I.y = (size_t)h[1]; I.x = (size_t)h[11];
+    if (I.x == 0 || I.y == 0 || I.x > 65536 || I.y > 65536) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: not a (native-endian) Spider file: " + fn.path);
+    size_t labbyt = (size_t)h[21];
+    if (labbyt == 0) { size_t lenbyt = I.x * 4, labrec = (1024 + lenbyt - 1) / lenbyt; labbyt = labrec * lenbyt; }
+    I.headerBytes = labbyt;
+    if (h[23] > 0) { I.isStack = true; I.n = (size_t)h[25]; I.perImageHeader = labbyt; }
+    return I;
+}
+
+// reads image `index` (1-based for stacks; 0 => the only image / whole volume) as float
+inline void readImage(const std::string &name, std::vector<float> &data, ImageInfo &I)
+{
+    FileName fn(name);
+    I = readInfo(fn.path);
+    size_t idx = fn.hasNumber() ? fn.number() : 0;
+    const size_t per = I.x * I.y * I.z;
+    std::ifstream f(fn.path, std::ios::binary);
+    size_t off;
+    if (I.mrc) off = I.headerBytes + (idx > 0 ? (idx - 1) * per * 4 : 0);
+    else if (I.isStack) { if (idx == 0) idx = 1; off = I.headerBytes + (idx - 1) * (I.perImageHeader + per * 4) + I.perImageHeader; }
+    else off = I.headerBytes;
+    if (I.isStack && idx > I.n) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: image " + std::to_string(idx) + " beyond the end of " + fn.path);
+    data.resize(per);
+    f.seekg((std::streamoff)off);
+    f.read((char *)data.data(), per * 4);
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short read in " + fn.path);
+}
+
+inline void spiderHeader(std::vector<float> &h, size_t x, size_t y, size_t z, int iform, int istack, size_t maxim, size_t imgnum)
+{
+    const size_t lenbyt = x * 4, labrec = (1024 + lenbyt - 1) / lenbyt, labbyt = labrec * lenbyt;
+    h.assign(labbyt / 4, 0.f);
+    h[0] = (float)z; h[1] = (float)y; h[2] = (float)(labrec + y * z); h[4] = (float)iform; h[11] = (float)x;
+    h[12] = (float)labrec; h[21] = (float)labbyt; h[22] = (float)lenbyt; h[23] = (float)istack;
+    h[25] = (float)maxim; h[26] = (float)imgnum;
+}
+
+// writes a single image / volume (double data narrowed to float): Spider or MRC by extension
+inline void writeVolume(const std::string &path, const double *data, size_t x, size_t y, size_t z)
+{
+    FileName fn(path);
+    std::ofstream f(fn.path, std::ios::binary | std::ios::trunc);
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: cannot write " + fn.path);
+    std::vector<float> buf(x * y * z);
+    for (size_t i = 0; i < buf.size(); ++i) buf[i] = (float)data[i];
+    if (isMrcExt(fn.extension())) {
+        int32_t h[256];
+        memset(h, 0, sizeof(h));
+        h[0] = (int32_t)x; h[1] = (int32_t)y; h[2] = (int32_t)z; h[3] = 2; h[7] = (int32_t)x; h[8] = (int32_t)y; h[9] = (int32_t)z;
+        float *hf = (float *)h;
+        hf[10] = (float)x; hf[11] = (float)y; hf[12] = (float)z; hf[13] = hf[14] = hf[15] = 90.f;
+        h[16] = 1; h[17] = 2; h[18] = 3;
+        memcpy(&h[52], "MAP ", 4);
+        unsigned char stamp[4] = {0x44, 0x44, 0, 0};
+        memcpy(&h[53], stamp, 4);
+        f.write((char *)h, 1024);
+    } else {
+        std::vector<float> h;
+        spiderHeader(h, x, y, z, z > 1 ? 3 : 1, 0, 0, 0);
+        f.write((char *)h.data(), h.size() * 4);
+    }
+    f.write((char *)buf.data(), buf.size() * 4);
+}
+
+// writes a Spider stack of n images (float)
+inline void writeStack(const std::string &path, const float *data, size_t x, size_t y, size_t n)
+{
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: cannot write " + path);
+    std::vector<float> h;
+    spiderHeader(h, x, y, 1, 1, 2, n, 0);
+    f.write((char *)h.data(), h.size() * 4);
+    for (size_t i = 0; i < n; ++i) {
+        spiderHeader(h, x, y, 1, 1, 0, 0, i + 1);
+        f.write((char *)h.data(), h.size() * 4);
+        f.write((char *)(data + i * x * y), x * y * 4);
+    }
+}
+
+// ------------------------------------------------------------------ symmetries (cyclic groups)
+class SymList {
+public:
+    std::vector<std::vector<double>> R;   // 3x3 row-major, identity excluded (as SL.getMatrices)
+    void readSymmetryFile(const std::string &sym)
+    {
+        R.clear();
+        std::string s = sym;
+        std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        if (s.size() >= 2 && s[0] == 'c' && std::all_of(s.begin() + 1, s.end(), ::isdigit)) {
+            const int n = atoi(s.c_str() + 1);
+            if (n < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "SymList: bad symmetry " + sym);
+            for (int k = 1; k < n; ++k) {
+                const double a = 2 * M_PI * k / n, c = std::cos(a), sn = std::sin(a);
+                R.push_back({c, sn, 0, -sn, c, 0, 0, 0, 1});
+            }
+            return;
+        }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is not available in this build (cyclic groups cN only)");
+    }
+    int symsNo() const { return (int)R.size(); }
+};
+
+// ------------------------------------------------------------------ XmippProgram
+class XmippProgram {
+    struct ParamDef { std::string name; std::vector<std::string> aliases; std::vector<std::string> argDefaults; std::vector<bool> argHasDefault; bool optional = false; std::string help; };
+    std::vector<ParamDef> defs;
+    std::map<std::string, std::vector<std::string>> given;
+    std::vector<std::string> usage, examples;
+    std::string progName;
+
+    ParamDef *find(const std::string &n)
+    {
+        for (auto &d : defs) { if (d.name == n) return &d; for (auto &a : d.aliases) if (a == n) return &d; }
+        return nullptr;
+    }
+protected:
+    virtual void defineParams() = 0;
+    virtual void readParams() = 0;
+public:
+    int verbose = 1;
+    int errorCode = 0;
+    virtual ~XmippProgram() {}
+    virtual void run() = 0;
+    void addUsageLine(const std::string &l) { usage.push_back(l); }
+    void addSeeAlsoLine(const std::string &) {}
+    void addExampleLine(const std::string &l, bool = true) { examples.push_back(l); }
+
+    // subset of the xmippCore DSL: "  [--opt <a=1> <b>] : help", "  alias --other;", "==Section==", " : more help"
+    void addParamsLine(const std::string &line)
+    {
+        std::string t = trim(line);
+        if (t.empty() || t.rfind("==", 0) == 0) return;
+        if (t[0] == ':') { if (!defs.empty()) defs.back().help += " " + trim(t.substr(1)); return; }
+        if (t.rfind("alias", 0) == 0) {
+            std::string a = trim(t.substr(5));
+            if (!a.empty() && a.back() == ';') a.pop_back();
+            if (!defs.empty()) defs.back().aliases.push_back(trim(a));
+            return;
+        }
+        if (t.rfind("where", 0) == 0 || t.rfind("requires", 0) == 0) return;
+        ParamDef d;
+        size_t colon = std::string::npos;
+        {   // the help separator is the first ':' outside <...>
+            int depth = 0;
+            for (size_t i = 0; i < t.size(); ++i) { if (t[i] == '<') ++depth; else if (t[i] == '>') --depth; else if (t[i] == ':' && depth == 0) { colon = i; break; } }
+        }
+        std::string spec = trim(colon == std::string::npos ? t : t.substr(0, colon));
+        if (colon != std::string::npos) d.help = trim(t.substr(colon + 1));
+        if (!spec.empty() && spec[0] == '[') { d.optional = true; size_t e = spec.rfind(']'); spec = trim(spec.substr(1, e == std::string::npos ? std::string::npos : e - 1)); }
+        if (spec.empty() || spec[0] != '-') return;
+        size_t sp = spec.find_first_of(" \t");
+        d.name = spec.substr(0, sp);
+        std::string rest = sp == std::string::npos ? "" : spec.substr(sp);
+        size_t p = 0;
+        while ((p = rest.find('<', p)) != std::string::npos) {
+            size_t e = rest.find('>', p);
+            std::string a = rest.substr(p + 1, e - p - 1);
+            size_t eq = a.find('=');
+            if (eq == std::string::npos) { d.argDefaults.push_back(""); d.argHasDefault.push_back(false); }
+            else {
+                std::string v = trim(a.substr(eq + 1));
+                if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+                d.argDefaults.push_back(v); d.argHasDefault.push_back(true);
+            }
+            p = e + 1;
+        }
+        defs.push_back(d);
+    }
+
+    void showUsage() const
+    {
+        std::cerr << "PROGRAM\n   " << progName << "\nUSAGE\n";
+        for (auto &u : usage) std::cerr << "   " << u << "\n";
+        std::cerr << "OPTIONS\n";
+        for (auto &d : defs) {
+            std::cerr << "   " << (d.optional ? "[" : "") << d.name;
+            for (auto &a : d.aliases) std::cerr << ", " << a;
+            for (size_t i = 0; i < d.argDefaults.size(); ++i) std::cerr << " <" << (d.argHasDefault[i] ? "=" + d.argDefaults[i] : "arg") << ">";
+            std::cerr << (d.optional ? "]" : "") << " : " << d.help << "\n";
+        }
+        for (auto &e : examples) std::cerr << "   " << e << "\n";
+    }
+
+    void read(int argc, const char **argv)
+    {
+        progName = argc > 0 ? argv[0] : "xmipp_program";
+        defs.clear(); given.clear();
+        defineParams();
+        addParamsLine("  [-v <verbose_level=1>] : Verbosity");
+        addParamsLine("    alias --verbose;");
+        try {
+            for (int i = 1; i < argc; ++i) {
+                std::string a = argv[i];
+                if (a == "-h" || a == "--help") { showUsage(); errorCode = 0; throw XmippError(-1, ""); }
+                bool isNeg = a.size() > 1 && a[0] == '-' && (isdigit((unsigned char)a[1]) || a[1] == '.');
+                if (a.empty() || a[0] != '-' || isNeg) REPORT_ERROR(ERR_ARG_INCORRECT, "Unexpected argument '" + a + "'");
+                ParamDef *d = find(a);
+                if (!d) REPORT_ERROR(ERR_ARG_INCORRECT, "Unknown parameter '" + a + "'");
+                std::vector<std::string> vals;
+                while (i + 1 < argc) {
+                    std::string n = argv[i + 1];
+                    bool neg = n.size() > 1 && n[0] == '-' && (isdigit((unsigned char)n[1]) || n[1] == '.');
+                    if (!n.empty() && n[0] == '-' && !neg) break;
+                    if (vals.size() >= d->argDefaults.size()) break;
+                    vals.push_back(n);
+                    ++i;
+                }
+                given[d->name] = vals;
+            }
+            for (auto &d : defs)
+                if (!d.optional && !given.count(d.name)) REPORT_ERROR(ERR_ARG_MISSING, "Parameter " + d.name + " is mandatory");
+            long v = getIntParam("-v");
+            verbose = (int)v;
+            readParams();
+        } catch (XmippError &e) {
+            if (e.code == -1) { errorCode = -1; return; }
+            std::cerr << "XMIPP_ERROR " << e.code << ": " << e.what() << std::endl;
+            errorCode = e.code;
+        }
+    }
+    void read(int argc, char **argv) { read(argc, (const char **)argv); }
+
+    bool checkParam(const std::string &n) { ParamDef *d = find(n); return d && given.count(d->name); }
+    std::string getParam(const std::string &n, int idx = 0)
+    {
+        ParamDef *d = find(n);
+        if (!d) REPORT_ERROR(ERR_ARG_INCORRECT, "getParam: undefined parameter " + n);
+        auto it = given.find(d->name);
+        if (it != given.end() && idx < (int)it->second.size()) return it->second[idx];
+        if (idx < (int)d->argDefaults.size() && d->argHasDefault[idx]) return d->argDefaults[idx];
+        REPORT_ERROR(ERR_ARG_MISSING, "Parameter " + n + " needs a value");
+    }
+    long getIntParam(const std::string &n, int idx = 0) { return atol(getParam(n, idx).c_str()); }
+    double getDoubleParam(const std::string &n, int idx = 0) { return atof(getParam(n, idx).c_str()); }
+
+    // XmippProgram::tryRun: run(), map XmippError to "XMIPP_ERROR" on stderr + error code
+    int tryRun()
+    {
+        if (errorCode == -1) return 0;       // --help
+        if (errorCode != 0) return errorCode;
+        try { run(); }
+        catch (XmippError &e) { std::cerr << "XMIPP_ERROR " << e.code << ": " << e.what() << std::endl; errorCode = e.code; }
+        catch (std::exception &e) { std::cerr << "XMIPP_ERROR 1: " << e.what() << std::endl; errorCode = 1; }
+        return errorCode;
+    }
+};
+
+inline void init_progress_bar(size_t) {}
+inline void progress_bar(size_t) {}
+
+}  // namespace mc
+#endif

@@ -1,0 +1,509 @@
+// programs.h -- C++ mirrors of the two Xmipp programs on the hot path, over the C ABI.
+//
+//   ProgAngularProjectionMatching  reconstruction/angular_projection_matching.{h,cpp}
+//   ProgRecFourierAccel            reconstruction/reconstruct_fourier_accel.{h,cpp}
+//
+// Same class names, same virtual seams (defineParams / readParams / show / run, and for APM
+// produceSideInfo / processAllImages / processSomeImages / writeOutputFiles), same parameter
+// strings, same output labels.  All numerics happen behind include/xmipp_hip.h; there is no
+// CPU path here.  Extra flags: --device <id>, --batch <n>.
+#ifndef XMIPP3_AMD_PROGRAMS_H
+#define XMIPP3_AMD_PROGRAMS_H
+#include "minicore.h"
+#include "../../include/xmipp_hip.h"
+
+namespace mc {
+
+inline void xhCheck(int rc) { if (rc != XH_OK) REPORT_ERROR(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error()); }
+
+struct DeviceBuffer {
+    xh_ctx *ctx = nullptr; void *p = nullptr; size_t bytes = 0;
+    ~DeviceBuffer() { release(); }
+    void release() { if (p) xh_free(ctx, p); p = nullptr; bytes = 0; }
+    void reserve(xh_ctx *c, size_t b) { if (b <= bytes) return; release(); ctx = c; xhCheck(xh_malloc(c, b, &p)); bytes = b; }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+// Sampling::readSamplingFile (data/sampling.cpp:1592-1659): blocks extra / neighbors / projectionDirections
+struct Sampling {
+    std::vector<std::vector<size_t>> my_neighbors;
+    std::vector<size_t> no_redundant_sampling_points_index;
+    std::vector<std::vector<double>> no_redundant_sampling_points_angles;
+    size_t numberSamplesAsymmetricUnit = 0;
+    void readSamplingFile(const std::string &base)
+    {
+        const std::string fn = base + "_sampling.xmd";
+        MetaDataVec md;
+        md.read("extra@" + fn);
+        long n = 0;
+        if (md.size() && md.getValue("pointsAsymmetricUnit", n, 0)) numberSamplesAsymmetricUnit = (size_t)n;
+        md.read("neighbors@" + fn);
+        my_neighbors.resize(md.size());
+        for (size_t i = 0; i < md.size(); ++i) {
+            std::string s;
+            md.getValue("neighbors", s, i);
+            std::istringstream is(s);
+            size_t v;
+            while (is >> v) my_neighbors[i].push_back(v);
+        }
+        md.read("projectionDirections@" + fn);
+        no_redundant_sampling_points_index.resize(md.size());
+        no_redundant_sampling_points_angles.resize(md.size());
+        for (size_t i = 0; i < md.size(); ++i) {
+            long idx = 0;
+            md.getValue("neighbor", idx, i);
+            no_redundant_sampling_points_index[i] = (size_t)idx;
+            no_redundant_sampling_points_angles[i] = {md.getDouble("angleRot", i, 0), md.getDouble("angleTilt", i, 0), md.getDouble("anglePsi", i, 0)};
+            numberSamplesAsymmetricUnit = std::max(numberSamplesAsymmetricUnit, (size_t)idx + 1);
+        }
+    }
+};
+
+// ============================================================================================
+class ProgAngularProjectionMatching : public XmippProgram {
+public:
+    std::string fn_exp, fn_out, fn_ref, fn_ctf;
+    double pad = 1, max_shift = -1, avail_memory = 1;
+    int Ri = 1, Ro = -1, search5d_shift = 0, search5d_step = 2, numOrientations = 1, threads = 1;
+    bool phase_flipped = false, do_scale = false, do_append = false;
+    int device = 0, batch = 1024;
+    // side info
+    MetaDataVec DFexp, DFo;
+    Sampling mysampling;
+    std::vector<int> convert_refno_to_stack_position;
+    size_t dim = 0, total_nr_refs = 0;
+    bool loop_forward_refs = true;
+    xh_ctx *ctx = nullptr;
+    xh_pm *pm = nullptr;
+    xh_rf *shifter = nullptr;   // only used for xh_rf_shift_images (previous shifts, APM:1228-1233)
+    int N = 0;
+
+    ~ProgAngularProjectionMatching() override
+    {
+        if (pm) xh_pm_destroy(pm);
+        if (shifter) xh_rf_destroy(shifter);
+        if (ctx) xh_ctx_destroy(ctx);
+    }
+
+    void defineParams() override
+    {
+        // APM:83-121, verbatim parameter lines
+        addUsageLine("Perform a discrete angular assignment using projection matching in real space.");
+        addUsageLine("This program is relatively fast, using polar coordinates for the in-plane ");
+        addUsageLine("angular searches and the 5-dimensional search of rotation angles and origin ");
+        addUsageLine("offsets is broken in two: first the angles are search in a 3D-search; then, ");
+        addUsageLine("for the optimal orientation the origin offsets are searched (2D).");
+        addExampleLine("xmipp_angular_projection_matching -i experimental.doc -o assigned_angles.doc --ref reference.stk --search5d_step 2");
+        addParamsLine("   -i <doc_file>                : Docfile with input images");
+        addParamsLine("   -o <output_filename>         : Output filename");
+        addParamsLine("   -r <stackFile>               : Reference projections");
+        addParamsLine("     alias --ref;");
+        addParamsLine("  [--search5d_shift <s5dshift=0>]: Search range (in +/- pix) for 5D shift search");
+        addParamsLine("  [--search5d_step <s5dstep=2>]  : Step size for 5D shift search (in pix)");
+        addParamsLine("  [--Ri <ri=1>]               : Inner radius to limit rotational search");
+        addParamsLine("  [--Ro <ro=-1>]              : Outer radius to limit rotational search");
+        addParamsLine("                        : ro = -1 -> dim/2-1");
+        addParamsLine("  [-s <step=1> <n_steps=3>]    : scale step factor (1 means 0.01 in/de-crements) and number of steps around 1.");
+        addParamsLine("                               : with default values: 1 0.01 | 0.02 | 0.03");
+        addParamsLine("    alias --scale;");
+        addParamsLine("==+Extra parameters==");
+        addParamsLine("  [--mem <mem=1>]             : Available memory for reference library (Gb)");
+        addParamsLine("  [--max_shift <max_shift=-1>]   : Max. change in origin offset (+/- pixels; neg= no limit)");
+        addParamsLine("  [--ctf <filename>]            : CTF to apply to the reference projections, either a");
+        addParamsLine("                     : CTF parameter file or a 2D image with the CTF amplitudes");
+        addParamsLine("  [--pad <pad=1>]             : Padding factor (for CTF correction only)");
+        addParamsLine("  [--phase_flipped]            : Use this if the experimental images have been phase flipped");
+        addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads");
+        addParamsLine("  [--number_orientations <numOrientations=1>]  : Number of possible orientations for each experimental image");
+        addParamsLine("  [--append]                : Append (versus overwrite) data to the output file");
+        addParamsLine("  [--device <id=0>]         : HIP device");
+        addParamsLine("  [--batch <n=1024>]        : Particles per device batch");
+    }
+
+    void readParams() override
+    {
+        // APM:44-80
+        fn_exp = getParam("-i");
+        fn_out = getParam("-o");
+        fn_ref = getParam("--ref");
+        pad = std::max(1., getDoubleParam("--pad"));
+        Ri = (int)getIntParam("--Ri");
+        Ro = (int)getIntParam("--Ro");
+        search5d_shift = (int)getIntParam("--search5d_shift");
+        search5d_step = (int)getIntParam("--search5d_step");
+        max_shift = getDoubleParam("--max_shift");
+        numOrientations = (int)getIntParam("--number_orientations");
+        avail_memory = getDoubleParam("--mem");
+        if (checkParam("--ctf")) fn_ctf = getParam("--ctf");
+        phase_flipped = checkParam("--phase_flipped");
+        threads = (int)getIntParam("--thr");
+        do_scale = checkParam("--scale");
+        do_append = checkParam("--append");
+        device = (int)getIntParam("--device");
+        batch = std::max(1, (int)getIntParam("--batch"));
+    }
+
+    void show()
+    {
+        if (!verbose) return;
+        std::cout << "  Input images            : " << fn_exp << " (" << DFexp.size() << ")\n"
+                  << "  Reference projections   : " << fn_ref << " (" << total_nr_refs << ")\n"
+                  << "  Output rootname         : " << fn_out << "\n"
+                  << "  Inner radius rot-search : " << Ri << "\n  Outer radius rot-search : " << Ro << "\n"
+                  << "  Max. shift              : " << max_shift << "\n"
+                  << "  Device                  : " << device << " (" << xh_version() << ")\n";
+    }
+
+    virtual void produceSideInfo()
+    {
+        // APM:209-404
+        if (search5d_shift != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--search5d_shift > 0 is not available on the device path yet");
+        if (numOrientations != 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--number_orientations > 1 is not available on the device path yet");
+        if (do_scale) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--scale is not supported (the reference loops forever at scale 1.0, APM:947-948)");
+        if (!fn_ctf.empty()) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--ctf: filter the reference gallery beforehand (device-side filtering not available yet)");
+        DFexp.read(fn_exp);
+        if (DFexp.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "Empty input metadata " + fn_exp);
+        std::string fn_img;
+        DFexp.getValue("image", fn_img, 0);
+        ImageInfo info = readInfo(FileName(fn_img).path);
+        dim = info.x;
+        ImageInfo rinfo = readInfo(fn_ref);
+        if (rinfo.x != dim || rinfo.y != info.y)
+            REPORT_ERROR(ERR_MULTIDIM_SIZE, "Check that the reference volume and the experimental images are of the same size");
+        if (max_shift < 0) max_shift = (double)(dim / 2);
+        if (Ri < 1) Ri = 1;
+        if (Ro < 0) Ro = (int)(dim / 2) - 1;
+        mysampling.readSamplingFile(FileName(fn_ref).removeAllExtensions());
+        total_nr_refs = mysampling.no_redundant_sampling_points_angles.size();
+        if (rinfo.n < total_nr_refs) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Reference stack holds fewer images than the sampling file lists");
+        convert_refno_to_stack_position.assign(mysampling.numberSamplesAsymmetricUnit, -1);
+        for (size_t i = 0; i < mysampling.no_redundant_sampling_points_index.size(); i++)
+            convert_refno_to_stack_position[mysampling.no_redundant_sampling_points_index[i]] = (int)i;
+        loop_forward_refs = true;
+        // reference library on the device, in stack order (getCurrentReference, APM:408-528)
+        xhCheck(xh_ctx_create_private(device, &ctx));
+        std::vector<float> refs(total_nr_refs * dim * dim), one;
+        ImageInfo ii;
+        for (size_t r = 0; r < total_nr_refs; ++r) {
+            readImage(std::to_string(r + 1) + "@" + fn_ref, one, ii);
+            std::copy(one.begin(), one.end(), refs.begin() + r * dim * dim);
+        }
+        DeviceBuffer d_refs;
+        d_refs.reserve(ctx, refs.size() * sizeof(float));
+        xhCheck(xh_memcpy_h2d(ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
+        xhCheck(xh_pm_create(ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), nullptr, 0, &pm));
+        int32_t nn;
+        xhCheck(xh_pm_info(pm, &nn, nullptr, nullptr));
+        N = nn;
+    }
+
+    virtual void processAllImages()
+    {
+        std::vector<size_t> ids(DFexp.size());
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = i;
+        processSomeImages(ids);
+    }
+
+    virtual void processSomeImages(const std::vector<size_t> &imagesToProcess)
+    {
+        // APM:991-1192, batched. Row order and labels as APM:1149-1165.
+        const size_t per = dim * dim;
+        DeviceBuffer d_part, d_shifted, d_i32a, d_i32b, d_u8, d_f64;
+        std::vector<float> h_part, one;
+        for (size_t b0 = 0; b0 < imagesToProcess.size(); b0 += (size_t)batch) {
+            const size_t n = std::min((size_t)batch, imagesToProcess.size() - b0);
+            h_part.resize(n * per);
+            std::vector<float> prevShift(2 * n, 0.f);
+            std::vector<int32_t> off(n + 1, 0), idsv;
+            bool anyShift = false;
+            for (size_t k = 0; k < n; ++k) {
+                const size_t id = imagesToProcess[b0 + k];
+                std::string fn;
+                DFexp.getValue("image", fn, id);
+                ImageInfo ii;
+                readImage(fn, one, ii);
+                if (ii.x != dim || ii.y != dim) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + fn + " has a different size");
+                std::copy(one.begin(), one.end(), h_part.begin() + k * per);
+                prevShift[2 * k] = (float)DFexp.getDouble("shiftX", id, 0.);
+                prevShift[2 * k + 1] = (float)DFexp.getDouble("shiftY", id, 0.);
+                anyShift = anyShift || prevShift[2 * k] != 0.f || prevShift[2 * k + 1] != 0.f;
+                if (id >= mysampling.my_neighbors.size()) REPORT_ERROR(ERR_MD_NOOBJ, "No neighbour list for image " + std::to_string(id + 1));
+                for (size_t r : mysampling.my_neighbors[id]) {
+                    if (r >= convert_refno_to_stack_position.size() || convert_refno_to_stack_position[r] < 0)
+                        REPORT_ERROR(ERR_VALUE_INCORRECT, "Wrong reference number " + std::to_string(r));
+                    idsv.push_back(convert_refno_to_stack_position[r]);
+                }
+                off[k + 1] = (int32_t)idsv.size();
+            }
+            d_part.reserve(ctx, n * per * sizeof(float));
+            xhCheck(xh_memcpy_h2d(ctx, d_part.p, h_part.data(), n * per * sizeof(float)));
+            float *d_imgs = d_part.as<float>();
+            if (anyShift) {
+                // getCurrentImage applies the previous shifts with BSPLINE3 + WRAP (APM:1228-1233)
+                if (!shifter) {
+                    xh_rf_params p{};
+                    p.imgSize = (int)dim; p.padding_proj = p.padding_vol = 2; p.max_resolution = 0.5;
+                    p.blob_radius = 1.9; p.blob_order = 0; p.blob_alpha = 15; p.min_ctf = 0.01; p.sampling = 1;
+                    xhCheck(xh_rf_create(ctx, &p, &shifter));
+                }
+                d_shifted.reserve(ctx, n * per * sizeof(float));
+                xhCheck(xh_rf_shift_images(shifter, d_imgs, prevShift.data(), nullptr, (int)n, d_shifted.as<float>()));
+                d_imgs = d_shifted.as<float>();
+            }
+            d_i32a.reserve(ctx, n * 4); d_i32b.reserve(ctx, n * 4); d_u8.reserve(ctx, n); d_f64.reserve(ctx, n * 8 * 3);
+            if (idsv.empty()) idsv.push_back(0);
+            // the visiting order of the references flips once per image (APM:1112)
+            xhCheck(xh_pm_match(pm, d_imgs, (int)n, off.data(), idsv.data(), loop_forward_refs ? 0 : 1, d_i32a.as<int32_t>(),
+                                d_i32b.as<int32_t>(), d_u8.as<uint8_t>()));
+            if (n & 1) loop_forward_refs = !loop_forward_refs;
+            double *d_sx = d_f64.as<double>(), *d_sy = d_sx + n, *d_cc = d_sy + n;
+            xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_i32a.as<int32_t>(), d_i32b.as<int32_t>(), d_u8.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
+            std::vector<int32_t> refpos(n), psi(n);
+            std::vector<uint8_t> flip(n);
+            std::vector<double> f64(3 * n);
+            xhCheck(xh_memcpy_d2h(ctx, refpos.data(), d_i32a.p, n * 4));
+            xhCheck(xh_memcpy_d2h(ctx, psi.data(), d_i32b.p, n * 4));
+            xhCheck(xh_memcpy_d2h(ctx, flip.data(), d_u8.p, n));
+            xhCheck(xh_memcpy_d2h(ctx, f64.data(), d_f64.p, n * 8 * 3));
+            for (size_t k = 0; k < n; ++k) {
+                if (refpos[k] < 0) continue;   // no valid correlation: the reference writes no row (APM:1131)
+                const size_t id = imagesToProcess[b0 + k];
+                const size_t row = DFo.addObject();
+                std::string fn;
+                DFexp.getValue("image", fn, id);
+                long itemId = 0;
+                if (!DFexp.getValue("itemId", itemId, id)) itemId = 0;
+                const std::vector<double> &ang = mysampling.no_redundant_sampling_points_angles[refpos[k]];
+                DFo.setValue("itemId", itemId, row);
+                DFo.setValue("image", fn, row);
+                DFo.setValue("angleRot", ang[0], row);
+                DFo.setValue("angleTilt", ang[1], row);
+                DFo.setValue("anglePsi", (double)psi[k] * (360. / N), row);
+                DFo.setValue("shiftX", f64[k] + prevShift[2 * k], row);
+                DFo.setValue("shiftY", f64[n + k] + prevShift[2 * k + 1], row);
+                DFo.setValue("ref", (long)mysampling.no_redundant_sampling_points_index[refpos[k]], row);
+                DFo.setValue("flip", (long)flip[k], row);
+                DFo.setValue("scale", DFexp.getDouble("scale", id, 1.0), row);
+                DFo.setValue("maxCC", f64[2 * n + k], row);
+            }
+        }
+    }
+
+    virtual void writeOutputFiles() { DFo.write(fn_out, do_append); }
+
+    void run() override
+    {
+        produceSideInfo();
+        show();
+        processAllImages();
+        writeOutputFiles();
+        if (verbose) std::cout << "done!" << std::endl;
+    }
+};
+
+// ============================================================================================
+class ProgRecFourierAccel : public XmippProgram {
+public:
+    std::string fn_in, fn_out, fn_sym;
+    bool do_weights = false, useFast = false, useCTF = false, isPhaseFlipped = false;
+    double padding_factor_proj = 2, padding_factor_vol = 2, maxResolution = 0.5, minCTF = 0.01, Ts = 1;
+    double blob_radius = 1.9, blob_alpha = 15;
+    int blob_order = 0, bufferSize = 25, device = 0, batch = 1024;
+    MetaDataVec SF;
+    size_t imgSize = 0;
+    std::vector<double> R_repository;   // nsym x 9
+    xh_ctx *ctx = nullptr;
+    xh_rf *rf = nullptr;
+
+    ~ProgRecFourierAccel() override
+    {
+        if (rf) xh_rf_destroy(rf);
+        if (ctx) xh_ctx_destroy(ctx);
+    }
+    void setIO(const std::string &in, const std::string &out) { fn_in = in; fn_out = out; }
+
+    void defineParams() override
+    {
+        // RFA:55-82, verbatim parameter lines
+        addUsageLine("Generate 3D reconstructions from projections using direct Fourier interpolation with arbitrary geometry.");
+        addUsageLine("Kaisser-windows are used for interpolation in Fourier space.");
+        addParamsLine("   -i <md_file>                : Metadata file with input projections");
+        addParamsLine("  [-o <volume_file=\"rec_fourier.vol\">]  : Filename for output volume");
+        addParamsLine("  [--sym <symfile=c1>]              : Enforce symmetry in projections");
+        addParamsLine("  [--padding <proj=2.0> <vol=2.0>]  : Padding used for projections and volume");
+        addParamsLine("  [--max_resolution <p=0.5>]     : Max resolution (Nyquist=0.5)");
+        addParamsLine("  [--weight]                     : Use weights stored in the image metadata");
+        addParamsLine("  [--blob <radius=1.9> <order=0> <alpha=15>] : Blob parameters");
+        addParamsLine("                                 : radius in pixels, order of Bessel function in blob and parameter alpha");
+        addParamsLine("  [--fast]                       : Do the blobing at the end of the computation.");
+        addParamsLine("                                 : Gives slightly different results, but is faster.");
+        addParamsLine("  [--useCTF]                     : Use CTF information if present");
+        addParamsLine("  [--sampling <Ts=1>]            : sampling rate of the input images in Angstroms/pixel");
+        addParamsLine("                                 : It is only used when correcting for the CTF");
+        addParamsLine("  [--phaseFlipped]               : Give this flag if images have been already phase flipped");
+        addParamsLine("  [--minCTF <ctf=0.01>]          : Minimum value of the CTF that will be inverted");
+        addParamsLine("                                 : CTF values (in absolute value) below this one will not be corrected");
+        addParamsLine("  [--bufferSize <size=25>]        : Number of projection loaded in memory (will be actually 2x as much.");
+        addParamsLine("  [--thr <threads=1>]            : Accepted for compatibility with xmipp_reconstruct_fourier; unused");
+        addParamsLine("  [--device <id=0>]              : HIP device");
+        addParamsLine("  [--batch <n=1024>]             : Projections per device batch");
+        addExampleLine("   xmipp_reconstruct_fourier_accel  -i reconstruction.sel --sym c2 --weight");
+    }
+
+    void readParams() override
+    {
+        // RFA:85-103
+        fn_in = getParam("-i");
+        fn_out = getParam("-o");
+        fn_sym = getParam("--sym");
+        do_weights = checkParam("--weight");
+        padding_factor_proj = getDoubleParam("--padding", 0);
+        padding_factor_vol = getDoubleParam("--padding", 1);
+        blob_radius = getDoubleParam("--blob", 0);
+        blob_order = (int)getIntParam("--blob", 1);
+        blob_alpha = getDoubleParam("--blob", 2);
+        useFast = checkParam("--fast");
+        maxResolution = getDoubleParam("--max_resolution");
+        useCTF = checkParam("--useCTF");
+        isPhaseFlipped = checkParam("--phaseFlipped");
+        minCTF = getDoubleParam("--minCTF");
+        Ts = getDoubleParam("--sampling");
+        bufferSize = (int)getIntParam("--bufferSize");
+        device = (int)getIntParam("--device");
+        batch = std::max(1, (int)getIntParam("--batch"));
+    }
+
+    void show()
+    {
+        if (verbose <= 0) return;
+        // RFA:106-137
+        std::cout << " =====================================================================\n"
+                  << " Direct 3D reconstruction method using Kaiser windows as interpolators\n"
+                  << " =====================================================================\n"
+                  << " Input selfile             : " << fn_in << "\n padding_factor_proj       : " << padding_factor_proj
+                  << "\n padding_factor_vol        : " << padding_factor_vol << "\n Output volume             : " << fn_out << "\n";
+        if (!fn_sym.empty()) std::cout << " Symmetry file for projections : " << fn_sym << "\n";
+        std::cout << (do_weights ? " Use weights stored in the image headers or doc file\n" : " Do NOT use weights\n");
+        std::cout << "\n Interpolation Function\n   blrad                 : " << blob_radius << "\n   blord                 : " << blob_order
+                  << "\n   blalpha               : " << blob_alpha << "\n max_resolution          : " << maxResolution
+                  << "\n -----------------------------------------------------------------" << std::endl;
+    }
+
+    void produceSideinfo()
+    {
+        // RFA:175-257
+        SF.read(fn_in);
+        // removeDisabled
+        if (SF.containsLabel("enabled")) {
+            std::vector<std::vector<std::string>> keep;
+            const int c = SF.col("enabled");
+            for (auto &r : SF.rows) if (atoi(r[c].c_str()) > 0) keep.push_back(r);
+            SF.rows.swap(keep);
+        }
+        if (SF.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "No enabled images in " + fn_in);
+        std::string fnImg;
+        SF.getValue("image", fnImg, 0);
+        ImageInfo info = readInfo(FileName(fnImg).path);
+        if (info.x != info.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "This algorithm only works for squared images");
+        imgSize = info.x;
+        R_repository = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (!fn_sym.empty()) {
+            SymList SL;
+            SL.readSymmetryFile(fn_sym);
+            for (int i = 0; i < SL.symsNo(); ++i) R_repository.insert(R_repository.end(), SL.R[i].begin(), SL.R[i].end());
+        }
+        xhCheck(xh_ctx_create_private(device, &ctx));
+        xh_rf_params p{};
+        p.imgSize = (int)imgSize; p.padding_proj = padding_factor_proj; p.padding_vol = padding_factor_vol;
+        p.max_resolution = maxResolution; p.blob_radius = blob_radius; p.blob_order = blob_order; p.blob_alpha = blob_alpha;
+        p.use_fast = useFast; p.phase_flipped = isPhaseFlipped; p.min_ctf = minCTF; p.sampling = Ts;
+        xhCheck(xh_rf_create(ctx, &p, &rf));
+        xhCheck(xh_rf_reset(rf));
+    }
+
+    void processImages(size_t first, size_t last)
+    {
+        // loadImageThread/preloadBuffer + processBuffer (RFA:300-388,939-966), batched on the device
+        const size_t per = imgSize * imgSize;
+        int32_t P, mv, sx, sy;
+        xhCheck(xh_rf_sizes(rf, &P, &mv, &sx, &sy));
+        const bool hasCTF = useCTF && (SF.containsLabel("ctfModel") || SF.containsLabel("ctfDefocusU"));
+        DeviceBuffer d_img, d_shift, d_fft, d_ctf, d_mod;
+        std::vector<float> h_img, one;
+        for (size_t b0 = first; b0 <= last; b0 += (size_t)batch) {
+            const size_t n = std::min((size_t)batch, last + 1 - b0);
+            h_img.resize(n * per);
+            std::vector<double> ang(3 * n);
+            std::vector<float> w(n, 1.f), sh(2 * n, 0.f);
+            std::vector<uint8_t> fl(n, 0);
+            std::vector<xh_ctf_params> ctfs(hasCTF ? n : 0);
+            bool anyGeo = false;
+            for (size_t k = 0; k < n; ++k) {
+                const size_t id = b0 + k;
+                std::string fn;
+                SF.getValue("image", fn, id);
+                ImageInfo ii;
+                readImage(fn, one, ii);
+                if (ii.x != imgSize || ii.y != imgSize) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + fn + " has a different size");
+                std::copy(one.begin(), one.end(), h_img.begin() + k * per);
+                ang[3 * k] = SF.getDouble("angleRot", id, 0); ang[3 * k + 1] = SF.getDouble("angleTilt", id, 0); ang[3 * k + 2] = SF.getDouble("anglePsi", id, 0);
+                sh[2 * k] = (float)SF.getDouble("shiftX", id, 0); sh[2 * k + 1] = (float)SF.getDouble("shiftY", id, 0);
+                fl[k] = SF.getDouble("flip", id, 0) != 0 ? 1 : 0;
+                anyGeo = anyGeo || sh[2 * k] != 0.f || sh[2 * k + 1] != 0.f || fl[k];
+                if (do_weights) w[k] = (float)SF.getDouble("weight", id, 1.0);
+                if (hasCTF) {
+                    if (!SF.containsLabel("ctfDefocusU")) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "ctfModel files are not read by this build; put the CTF columns in the metadata");
+                    xh_ctf_params &c = ctfs[k];
+                    xh_ctf_defaults(&c);     // data/ctf.cpp:365-388
+                    c.Tm = SF.getDouble("ctfSamplingRate", id, 1); c.kV = SF.getDouble("ctfVoltage", id, 100);
+                    c.DeltafU = SF.getDouble("ctfDefocusU", id, 0); c.DeltafV = SF.getDouble("ctfDefocusV", id, c.DeltafU);
+                    c.azimuthal_angle = SF.getDouble("ctfDefocusAngle", id, 0); c.Cs = SF.getDouble("ctfSphericalAberration", id, 0);
+                    c.Ca = SF.getDouble("ctfChromaticAberration", id, 0); c.espr = SF.getDouble("ctfEnergyLoss", id, 0);
+                    c.ispr = SF.getDouble("ctfLensStability", id, 0); c.alpha = SF.getDouble("ctfConvergenceCone", id, 0);
+                    c.DeltaF = SF.getDouble("ctfLongitudinalDisplacement", id, 0); c.DeltaR = SF.getDouble("ctfTransversalDisplacement", id, 0);
+                    c.Q0 = SF.getDouble("ctfQ0", id, 0); c.K = SF.getDouble("ctfK", id, 1);
+                    c.phase_shift = SF.getDouble("ctfPhaseShift", id, 0); c.VPP_radius = SF.getDouble("ctfVPPRadius", id, 0);
+                }
+            }
+            d_img.reserve(ctx, n * per * 4);
+            xhCheck(xh_memcpy_h2d(ctx, d_img.p, h_img.data(), n * per * 4));
+            float *imgs = d_img.as<float>();
+            if (anyGeo) {   // Projection::readApplyGeo with only_apply_shifts (RFA:311-323)
+                d_shift.reserve(ctx, n * per * 4);
+                xhCheck(xh_rf_shift_images(rf, imgs, sh.data(), fl.data(), (int)n, d_shift.as<float>()));
+                imgs = d_shift.as<float>();
+            }
+            d_fft.reserve(ctx, n * (size_t)sx * sy * 8);
+            xhCheck(xh_rf_prepare_images(rf, imgs, (int)n, d_fft.as<float>()));
+            float *ctf = nullptr, *mod = nullptr;
+            if (hasCTF) {
+                d_ctf.reserve(ctx, n * (size_t)sx * sy * 4); d_mod.reserve(ctx, n * (size_t)sx * sy * 4);
+                ctf = d_ctf.as<float>(); mod = d_mod.as<float>();
+                xhCheck(xh_rf_ctf_arrays(rf, ctfs.data(), (int)n, ctf, mod));
+            }
+            xhCheck(xh_rf_insert(rf, d_fft.as<float>(), ctf, mod, ang.data(), do_weights ? w.data() : nullptr, (int)n,
+                                 R_repository.data(), (int)(R_repository.size() / 9)));
+            xhCheck(xh_ctx_sync(ctx));
+        }
+    }
+
+    void finishComputations(const std::string &out_name)
+    {
+        std::vector<double> vol(imgSize * imgSize * imgSize);
+        xhCheck(xh_rf_finish(rf, vol.data()));
+        writeVolume(out_name, vol.data(), imgSize, imgSize, imgSize);
+    }
+
+    void run() override
+    {
+        // RFA:139-156
+        show();
+        produceSideinfo();
+        processImages(0, SF.size() - 1);
+        xhCheck(xh_rf_mirror_and_crop(rf));
+        finishComputations(fn_out);
+    }
+};
+
+}  // namespace mc
+#endif
