@@ -80,7 +80,7 @@ public:
     void addLabel(const std::string &l) { if (!containsLabel(l)) { labels.push_back(l); for (auto &r : rows) r.push_back(""); } }
     size_t addObject() { rows.emplace_back(labels.size()); return rows.size() - 1; }
     void setValue(const std::string &l, const std::string &v, size_t id) { addLabel(l); rows[id].resize(labels.size()); rows[id][col(l)] = v; }
-    void setValue(const std::string &l, double v, size_t id) { char b[64]; snprintf(b, sizeof(b), "%12.6f", v); setValue(l, std::string(b), id); }
+    void setValue(const std::string &l, double v, size_t id) { char b[64]; snprintf(b, sizeof(b), "%.6f", v); setValue(l, std::string(b), id); }
     void setValue(const std::string &l, long v, size_t id) { setValue(l, std::to_string(v), id); }
     bool getValue(const std::string &l, std::string &v, size_t id) const { int c = col(l); if (c < 0 || rows[id][c].empty()) return false; v = rows[id][c]; return true; }
     bool getValue(const std::string &l, double &v, size_t id) const { std::string s; if (!getValue(l, s, id)) return false; v = atof(s.c_str()); return true; }
@@ -164,7 +164,7 @@ public:
             for (size_t c = 0; c < labels.size(); ++c) {
                 const std::string &v = c < r.size() ? r[c] : std::string();
                 if (v.find(' ') != std::string::npos && v.find('\'') == std::string::npos) f << " '" << v << "'";
-                else f << " " << (v.empty() ? "0" : v);
+                else { f << " "; f.width(12); f << (v.empty() ? "0" : v); }
             }
             f << " \n";
         }
