@@ -98,7 +98,9 @@ struct xh_pm {
     XhBuf d_sin, d_cos, d_ringOfSample, d_nsam, d_soff, d_coff, d_rstart;
     XhBuf d_tw32, d_tw64;        // ring DFT twiddles per ring, [nsamples] complex
     XhBuf d_refs64, d_refsB, d_refSigma, d_refCoef;
-    XhBuf d_W32;                 // FFT twiddles for length M (float)
+    XhBuf d_W32;                 // FFT twiddles for length M (float), M/2 entries (radix-2 kernels)
+    XhBuf d_Wfull, d_vperm;      // register-blocked S3: W_M^j, j < M; kernel spectrum in (k1,k2,k3) order
+    int R1, R2, R3;              // M = R1*R2*R3 (0 => radix-2 kernel)
     XhBuf d_chirp, d_vhat;       // Bluestein: chirp[N], vhat[M] (bit-reversed, /M)
     XhBuf d_csN;                 // cos/sin(2 pi j / N) double, for the fp64 re-scorer
     XhBuf d_WD64;                // FFT twiddles for length D (double) for S6
@@ -111,6 +113,9 @@ struct xh_pm {
     int64_t stat_rows, stat_resc_p, stat_resc_r;
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
+    int use_idft3, use_mfma;
+    XhBuf d_qoff, d_Bpack, d_Apack;
+    int totalQuads;
 };
 
 // =========================================================================== S1 kernels
@@ -282,6 +287,123 @@ k_pm_contract(const BlockDesc *__restrict__ desc, const xh_cf *__restrict__ A, c
             }
 }
 
+
+// ---- S2 on the matrix cores ---------------------------------------------------------------------
+// For one angular frequency k the four sums (ac, ad, bc, bd) of a 16-particle x 16-reference tile are
+// one 32x32 product  C_k = A_k (32 x K_k) . B_k (K_k x 32):  rows = (particle, Re|Im), columns =
+// (reference, Re|Im), K_k = rings that reach frequency k.  v_mfma_f32_32x32x2_f32 is exact fp32 (an
+// fmaf chain) at the full fp32 rate, so the numbers equal the VALU kernel's up to summation order.
+// Operands are pre-packed so that lane l's float4 feeds four consecutive MFMAs (8 rings):
+//   pack[tile][quad][l][t] = X[i = l&31][ring = r0(k) + 8*quad' + 2*t + (l>>5)],  zero past the last ring.
+typedef float xh_f32x16 __attribute__((ext_vector_type(16)));
+
+// gather A32/refsB [item][ncoef] complex -> packed tiles. One thread per packed float4.
+__global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restrict__ dst, const int *__restrict__ qoff,
+                                const int *__restrict__ rstart, const int *__restrict__ coff, const int *__restrict__ nsam,
+                                int nrings, int ncoef, int nk, int totalQuads, int nitems, const int *__restrict__ ids)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = gid & 63;
+    const size_t rest = gid >> 6;
+    const int quad = rest % totalQuads;
+    const int tile = rest / totalQuads;
+    if ((size_t)tile * 16 >= (size_t)((nitems + 15) / 16) * 16) return;
+    // frequency k of this quad: last k with qoff[k] <= quad
+    int lo = 0, hi = nk - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (qoff[mid] <= quad) lo = mid; else hi = mid - 1; }
+    const int k = lo, q = quad - qoff[k];
+    const int item = tile * 16 + ((l & 31) >> 1), part = l & 1;
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ring = rstart[k] + 8 * q + 2 * t + (l >> 5);
+        float x = 0.f;
+        if (item < nitems && ring < nrings && k <= nsam[ring] / 2) {
+            const int it = ids ? ids[item] : item;
+            const xh_cf c = src[(size_t)it * ncoef + coff[ring] + k];
+            x = part ? c.y : c.x;
+        }
+        v[t] = x;
+    }
+    dst[gid] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// one wave = one 16x16 (particle x reference) tile, all frequencies; block = 4 waves = 4 reference tiles
+__global__ void __launch_bounds__(256)
+k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
+                   const int *__restrict__ qoff, int nk, int totalQuads, int nparticles, int nq, int nqtiles)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qtile = blockIdx.x * 4 + wv, ptile = blockIdx.y;
+    if (qtile >= nqtiles) return;
+    const float4 *A = Apack + (size_t)ptile * totalQuads * 64 + lane;
+    const float4 *B = Bpack + (size_t)qtile * totalQuads * 64 + lane;
+    const int hi = lane >> 5, j = lane & 31;
+    const int qj = j >> 1, odd = j & 1;
+    const int q = qtile * 16 + qj;
+    for (int k0 = 0; k0 < nk; k0 += 4) {
+        xh_f32x16 acc[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kk][e] = 0.f;
+            const int k = k0 + kk;
+            if (k < nk) {
+                const int qb = qoff[k], qe = qoff[k + 1];
+                // software pipeline: the next quad's operands are in flight while this quad's MFMAs issue
+                float4 a = A[(size_t)qb * 64], b = B[(size_t)qb * 64];
+                for (int qd = qb; qd < qe; ++qd) {
+                    const int qn = qd + 1 < qoff[nk] ? qd + 1 : qd;    // runs into the next frequency's first quad
+                    const float4 an = A[(size_t)qn * 64], bn = B[(size_t)qn * 64];
+                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[kk], 0, 0, 0);
+                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[kk], 0, 0, 0);
+                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[kk], 0, 0, 0);
+                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[kk], 0, 0, 0);
+                    a = an;
+                    b = bn;
+                }
+            }
+        }
+        // lane (j, hi) holds column j = (reference qj, Re|Im) for rows i = (reg&3) + 8*(reg>>2) + 4*hi.
+        // even lane: (ac, bc); odd lane: (ad, bd) of the same reference. Exchange so that the even lane
+        // owns frequencies k0, k0+1 and the odd lane k0+2, k0+3 of each (particle, reference) row.
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int r0 = 4 * g + 2 * h2;               // regs r0 (Re row), r0+1 (Im row)
+                const int pi = 4 * g + 2 * hi + h2;
+                const int p = blockIdx.y * 16 + pi;
+                float mine[4][2], theirs[4][2];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { mine[kk][0] = acc[kk][r0]; mine[kk][1] = acc[kk][r0 + 1]; }
+                // send to the partner what it needs: even lane needs partner's kk=0,1; odd lane needs partner's kk=2,3
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float s0 = odd ? mine[0][c] : mine[2][c];
+                    const float s1 = odd ? mine[1][c] : mine[3][c];
+                    theirs[0][c] = __shfl_xor(s0, 1, 64);
+                    theirs[1][c] = __shfl_xor(s1, 1, 64);
+                }
+                if (p < nparticles && q < nq) {
+                    float4 *dst = raw + ((size_t)p * nq + q) * nk;
+                    const int kA = k0 + (odd ? 2 : 0);
+                    // float4 = (ac, ad, bc, bd): even lane has (ac, bc) and receives (ad, bd); odd lane the converse
+                    float4 o0, o1;
+                    if (!odd) {
+                        o0 = make_float4(mine[0][0], theirs[0][0], mine[0][1], theirs[0][1]);
+                        o1 = make_float4(mine[1][0], theirs[1][0], mine[1][1], theirs[1][1]);
+                    } else {
+                        o0 = make_float4(theirs[0][0], mine[2][0], theirs[0][1], mine[2][1]);
+                        o1 = make_float4(theirs[1][0], mine[3][0], theirs[1][1], mine[3][1]);
+                    }
+                    if (kA < nk) dst[kA] = o0;
+                    if (kA + 1 < nk) dst[kA + 1] = o1;
+                }
+            }
+    }
+}
+
 // =========================================================================== S3
 struct RowRes { float best; int idx; float second; int pad; };
 
@@ -363,6 +485,264 @@ k_pm_idft_max(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh
             res[row0 + l] = rr;
         }
         __syncthreads();
+    }
+}
+
+
+// ---- S3, register-blocked: one wave per row, three passes M = R1*R2*R3 -------------------------
+// The radix-2 kernel above spends 22 LDS round trips + barriers per row. Here a wave owns a row:
+// every pass keeps a whole radix-R butterfly in registers, LDS is only the exchange medium between
+// passes (4 round trips per row, wave-private, no barriers), the forward transform is decimation
+// in frequency and the inverse its mirror image, so no reordering pass exists and the convolution
+// kernel spectrum is simply stored in the same (k1,k2,k3) order. The forward input comes straight
+// from the S2 intermediate (pruned: only n < N is non-zero), the inverse output goes straight into
+// the per-lane top-2 search (pruned: only n < N is needed).
+template <bool INV> __device__ __forceinline__ xh_cf d_mulw(xh_cf a, float wr, float wi)
+{   // a * (wr + i*wi) forward, a * conj(.) inverse
+    xh_cf r;
+    if (!INV) { r.x = a.x * wr - a.y * wi; r.y = a.x * wi + a.y * wr; }
+    else { r.x = a.x * wr + a.y * wi; r.y = a.y * wr - a.x * wi; }
+    return r;
+}
+template <bool INV> __device__ __forceinline__ xh_cf d_mulmi(xh_cf a)
+{   // a * (-i) forward, a * (+i) inverse
+    return INV ? xh_cf{-a.y, a.x} : xh_cf{a.y, -a.x};
+}
+__device__ __forceinline__ xh_cf d_add(xh_cf a, xh_cf b) { return xh_cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ xh_cf d_sub(xh_cf a, xh_cf b) { return xh_cf{a.x - b.x, a.y - b.y}; }
+
+template <bool INV> __device__ __forceinline__ void d_fft4(xh_cf &x0, xh_cf &x1, xh_cf &x2, xh_cf &x3)
+{
+    const xh_cf a = d_add(x0, x2), b = d_sub(x0, x2), c = d_add(x1, x3), d = d_mulmi<INV>(d_sub(x1, x3));
+    x0 = d_add(a, c); x1 = d_add(b, d); x2 = d_sub(a, c); x3 = d_sub(b, d);
+}
+template <bool INV> __device__ __forceinline__ void d_fft8(xh_cf *v)
+{
+    xh_cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    d_fft4<INV>(e0, e1, e2, e3);
+    d_fft4<INV>(o0, o1, o2, o3);
+    const float h = 0.70710678118654752440f;
+    o1 = d_mulw<INV>(o1, h, -h);
+    o2 = d_mulmi<INV>(o2);
+    o3 = d_mulw<INV>(o3, -h, -h);
+    v[0] = d_add(e0, o0); v[4] = d_sub(e0, o0);
+    v[1] = d_add(e1, o1); v[5] = d_sub(e1, o1);
+    v[2] = d_add(e2, o2); v[6] = d_sub(e2, o2);
+    v[3] = d_add(e3, o3); v[7] = d_sub(e3, o3);
+}
+template <bool INV> __device__ __forceinline__ void d_fft16(xh_cf *v)
+{
+    xh_cf e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    d_fft8<INV>(e);
+    d_fft8<INV>(o);
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    o[1] = d_mulw<INV>(o[1], c1, -s1);
+    o[2] = d_mulw<INV>(o[2], h, -h);
+    o[3] = d_mulw<INV>(o[3], s1, -c1);
+    o[4] = d_mulmi<INV>(o[4]);
+    o[5] = d_mulw<INV>(o[5], -s1, -c1);
+    o[6] = d_mulw<INV>(o[6], -h, -h);
+    o[7] = d_mulw<INV>(o[7], -c1, -s1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = d_add(e[i], o[i]); v[i + 8] = d_sub(e[i], o[i]); }
+}
+template <int R, bool INV> __device__ __forceinline__ void d_fftR(xh_cf *v)
+{
+    if (R == 16) d_fft16<INV>(v);
+    else d_fft8<INV>(v);
+}
+// v[k] *= W^(b*k), k = 1..R-1, from W^b, W^2b, W^4b(, W^8b) (table) and products; INV => conj
+// W_M^j from two small LDS tables: j = 32*jh + jl  =>  W^j = Wh[jh] * Wl[jl]
+struct XhTw { const xh_cf *hi; const xh_cf *lo; int mask; };
+__device__ __forceinline__ xh_cf d_tw(const XhTw &T, int j)
+{
+    j &= T.mask;
+    return xh_cmul(T.hi[j >> 5], T.lo[j & 31]);
+}
+template <int R, bool INV> __device__ __forceinline__ void d_twiddle(xh_cf *v, const XhTw &Wt, int b, int M)
+{
+    xh_cf w[R];
+    w[1] = d_tw(Wt, b);
+    w[2] = d_tw(Wt, 2 * b);
+    w[4] = d_tw(Wt, 4 * b);
+    if (R == 16) w[8] = d_tw(Wt, 8 * b);
+    w[3] = xh_cmul(w[2], w[1]);
+    w[5] = xh_cmul(w[4], w[1]);
+    w[6] = xh_cmul(w[4], w[2]);
+    w[7] = xh_cmul(w[4], w[3]);
+    if (R == 16) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) w[8 + i] = xh_cmul(w[8], w[i]);
+    }
+#pragma unroll
+    for (int k = 1; k < R; ++k) v[k] = d_mulw<INV>(v[k], w[k].x, w[k].y);
+}
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__(256, 2)
+k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ Wfull,
+               const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vperm, int N, int nk, int nrows)
+{
+    constexpr int M = R1 * R2 * R3;
+    constexpr int S3 = R3 + 1;              // padded innermost stride (bank conflicts)
+    constexpr int S2 = R2 * S3;
+    constexpr int LDSW = R1 * S2;           // complex elements per wave
+    constexpr int NB1 = (R2 * R3) / 64;     // pass-1 butterflies per lane
+    constexpr int NZ1 = R1 / 2 + 1;         // n < N <= M/2+1  =>  only n1 <= R1/2 can be non-zero
+    __shared__ xh_cf sbuf[4 * LDSW];
+    __shared__ xh_cf sWh[M / 32], sWl[32];
+    for (int i = threadIdx.x; i < M / 32; i += 256) sWh[i] = Wfull[32 * i];
+    if (threadIdx.x < 32) sWl[threadIdx.x] = Wfull[threadIdx.x];
+    __syncthreads();
+    const XhTw Wt{sWh, sWl, M - 1};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    xh_cf *s = sbuf + (size_t)wv * LDSW;
+    float4 *sraw = reinterpret_cast<float4 *>(s);     // the row is staged here before pass 1 overwrites it
+    const int half = N / 2;
+    for (int row = blockIdx.x * 4 + wv; row < nrows; row += gridDim.x * 4) {
+        const float4 *rr = raw + (size_t)row * nk;
+        // ---- stage the row (one coalesced burst), then pull every pass-1 input into registers
+        for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
+        __builtin_amdgcn_wave_barrier();
+        xh_cf uin[NB1][NZ1];
+#pragma unroll
+        for (int t = 0; t < NB1; ++t) {
+            const int f = lane + 64 * t;
+#pragma unroll
+            for (int n1 = 0; n1 < NZ1; ++n1) {
+                const int n = n1 * (R2 * R3) + f;
+                xh_cf z = xh_cf{0.f, 0.f};
+                if (n < N) {
+                    const int k = n <= half ? n : N - n;
+                    const float4 q = sraw[k];
+                    const float fsr = q.x - q.w, fsi = q.y + q.z, fmr = q.x + q.w, fmi = q.y - q.z;
+                    xh_cf Z;
+                    if (n == 0 || n == half) Z = xh_cf{fsr, fmr};
+                    else if (n < half) Z = xh_cf{fsr - fmi, fsi + fmr};
+                    else Z = xh_cf{fsr + fmi, fmr - fsi};
+                    z = xh_cmul(Z, chirp[n]);
+                }
+                uin[t][n1] = z;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- forward pass 1: radix R1 over n1
+#pragma unroll
+        for (int t = 0; t < NB1; ++t) {
+            const int f = lane + 64 * t;
+            xh_cf v[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                // n < N <= M/2 + 1: inputs with n1 > R1/2 are structurally zero
+                const xh_cf z = n1 < NZ1 ? uin[t][n1 < NZ1 ? n1 : 0] : xh_cf{0.f, 0.f};
+                v[n1] = z;
+            }
+            d_fftR<R1, false>(v);
+            d_twiddle<R1, false>(v, Wt, f, M);
+            const int n2 = f / R3, n3 = f - n2 * R3;
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) s[k1 * S2 + n2 * S3 + n3] = v[k1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- forward pass 2: radix R2 over n2 for each (k1, n3)
+#pragma unroll 1
+        for (int j = lane; j < R1 * R3; j += 64) {
+            const int k1 = j / R3, n3 = j - k1 * R3;
+            xh_cf v[R2];
+            xh_cf *p = s + k1 * S2 + n3;
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) v[n2] = p[n2 * S3];
+            d_fftR<R2, false>(v);
+            d_twiddle<R2, false>(v, Wt, R1 * n3, M);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) p[k2 * S3] = v[k2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- forward pass 3, multiply by the kernel spectrum, inverse pass 3 (all in registers)
+#pragma unroll 1
+        for (int j = lane; j < R1 * R2; j += 64) {
+            const int k1 = j / R2, k2 = j - k1 * R2;
+            xh_cf v[R3];
+            xh_cf *p = s + k1 * S2 + k2 * S3;
+#pragma unroll
+            for (int n3 = 0; n3 < R3; ++n3) v[n3] = p[n3];
+            d_fftR<R3, false>(v);
+            const xh_cf *vp = vperm + (size_t)j * R3;
+#pragma unroll
+            for (int k3 = 0; k3 < R3; ++k3) v[k3] = xh_cmul(v[k3], vp[k3]);
+            d_fftR<R3, true>(v);
+            // conj twiddle W^(R1*n3*k2) on element n3
+            {
+                xh_cf w[R3];
+                const int b = R1 * k2;
+                w[1] = d_tw(Wt, b); w[2] = d_tw(Wt, 2 * b); w[4] = d_tw(Wt, 4 * b);
+                w[3] = xh_cmul(w[2], w[1]); w[5] = xh_cmul(w[4], w[1]); w[6] = xh_cmul(w[4], w[2]); w[7] = xh_cmul(w[4], w[3]);
+#pragma unroll
+                for (int n3 = 1; n3 < R3; ++n3) v[n3] = d_mulw<true>(v[n3], w[n3].x, w[n3].y);
+            }
+#pragma unroll
+            for (int n3 = 0; n3 < R3; ++n3) p[n3] = v[n3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- inverse pass 2: radix R2 over k2 for each (k1, n3), then conj twiddle W^((n2*R3+n3)*k1)
+#pragma unroll 1
+        for (int j = lane; j < R1 * R3; j += 64) {
+            const int k1 = j / R3, n3 = j - k1 * R3;
+            xh_cf v[R2];
+            xh_cf *p = s + k1 * S2 + n3;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k2] = p[k2 * S3];
+            d_fftR<R2, true>(v);
+            // element n2 gets W^{-(n2*R3+n3)*k1}: base exponents R3*k1 (per n2 step) and n3*k1 (offset)
+            {
+                const xh_cf w0 = d_tw(Wt, n3 * k1);
+                xh_cf w[R2];
+                const int b = R3 * k1;
+                w[1] = d_tw(Wt, b); w[2] = d_tw(Wt, 2 * b); w[4] = d_tw(Wt, 4 * b);
+                if (R2 == 16) w[8] = d_tw(Wt, 8 * b);
+                w[3] = xh_cmul(w[2], w[1]); w[5] = xh_cmul(w[4], w[1]); w[6] = xh_cmul(w[4], w[2]); w[7] = xh_cmul(w[4], w[3]);
+                if (R2 == 16) {
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) w[8 + i] = xh_cmul(w[8], w[i]);
+                }
+                v[0] = d_mulw<true>(v[0], w0.x, w0.y);
+#pragma unroll
+                for (int n2 = 1; n2 < R2; ++n2) { const xh_cf ww = xh_cmul(w[n2], w0); v[n2] = d_mulw<true>(v[n2], ww.x, ww.y); }
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) p[n2 * S3] = v[n2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- inverse pass 1: radix R1 over k1 -> y[n], z = y*chirp, top-2 over straight (Re) / mirror (Im)
+        float b1 = -3.0e38f, sec = -3.0e38f;
+        int bi = 0x7fffffff;
+#pragma unroll 1
+        for (int f = lane; f < R2 * R3; f += 64) {
+            const int n2 = f / R3, n3 = f - n2 * R3;
+            xh_cf v[R1];
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) v[k1] = s[k1 * S2 + n2 * S3 + n3];
+            d_fftR<R1, true>(v);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const int n = n1 * (R2 * R3) + f;
+                if (n < N) {
+                    const xh_cf z = xh_cmul(v[n1], chirp[n]);
+                    d_top2_insert(z.x, n, b1, bi, sec);
+                    d_top2_insert(z.y, N + n, b1, bi, sec);
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_down(b1, o, 64), os = __shfl_down(sec, o, 64);
+            const int oi = __shfl_down(bi, o, 64);
+            if (ob > b1 || (ob == b1 && oi < bi)) { sec = fmaxf(b1, os); b1 = ob; bi = oi; }
+            else sec = fmaxf(sec, ob);
+        }
+        if (lane == 0) { RowRes r; r.best = b1; r.idx = bi; r.second = sec; r.pad = 0; res[row] = r; }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -858,7 +1238,7 @@ template <typename T> static int upload(xh_ctx *ctx, XhBuf &b, const std::vector
 static void free_all(xh_pm *pm)
 {
     XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart,
-                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32,
+                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack,
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
@@ -915,6 +1295,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->scale = 0;
     for (int r = 0; r < L.nrings; ++r) pm->scale += 2. * kPI * (r + Ri);
     pm->tau_rel = 2e-5;
+    pm->use_idft3 = 1;
+    pm->use_mfma = 1;
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
@@ -970,6 +1352,23 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             for (int t = 0; t < pm->logM; ++t) if (j & (1 << t)) rev |= 1u << (pm->logM - 1 - t);
             vbr[j] = xh_cf{(float)(b[rev].x / M), (float)(b[rev].y / M)};
         }
+        // register-blocked S3 tables
+        pm->R1 = pm->R2 = pm->R3 = 0;
+        if (pm->logM == 9) { pm->R1 = 8; pm->R2 = 8; pm->R3 = 8; }
+        else if (pm->logM == 10) { pm->R1 = 16; pm->R2 = 8; pm->R3 = 8; }
+        else if (pm->logM == 11) { pm->R1 = 16; pm->R2 = 16; pm->R3 = 8; }
+        std::vector<xh_cf> Wfull(M), vperm(M);
+        for (int j = 0; j < M; ++j) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / M;
+            Wfull[j] = xh_cf{(float)cosl(a), (float)sinl(a)};
+        }
+        if (pm->R1)
+            for (int k1 = 0; k1 < pm->R1; ++k1)
+                for (int k2 = 0; k2 < pm->R2; ++k2)
+                    for (int k3 = 0; k3 < pm->R3; ++k3) {
+                        const int k = k1 + pm->R1 * k2 + pm->R1 * pm->R2 * k3;
+                        vperm[(k1 * pm->R2 + k2) * pm->R3 + k3] = xh_cf{(float)(b[k].x / M), (float)(b[k].y / M)};
+                    }
         std::vector<xh_cd> csN(N);
         for (int j = 0; j < N; ++j) {
             const long double a = 2.0L * 3.14159265358979323846264338327950288L * j / N;
@@ -991,6 +1390,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         if (rc == XH_OK) rc = upload(ctx, pm->d_tw32, tw32);
         if (rc == XH_OK) rc = upload(ctx, pm->d_tw64, tw64);
         if (rc == XH_OK) rc = upload(ctx, pm->d_W32, W32);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_Wfull, Wfull);
+        if (rc == XH_OK) rc = upload(ctx, pm->d_vperm, vperm);
         if (rc == XH_OK) rc = upload(ctx, pm->d_chirp, chirp);
         if (rc == XH_OK) rc = upload(ctx, pm->d_vhat, vbr);
         if (rc == XH_OK) rc = upload(ctx, pm->d_csN, csN);
@@ -1034,6 +1435,23 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             }
         }
         xh_buf_free(d_ringOfCoef);
+        if (rc == XH_OK) {
+            // packed operand tiles for the MFMA contraction
+            std::vector<int> qoff(L.nk + 1);
+            qoff[0] = 0;
+            for (int k = 0; k < L.nk; ++k) qoff[k + 1] = qoff[k] + (L.nrings - rstart[k] + 7) / 8;
+            pm->totalQuads = qoff[L.nk];
+            rc = upload(ctx, pm->d_qoff, qoff);
+            const int ntiles = (nrefs + 15) / 16;
+            const size_t nvec = (size_t)ntiles * pm->totalQuads * 64;
+            if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_Bpack, nvec * sizeof(float4));
+            if (rc == XH_OK) {
+                hipLaunchKernelGGL(k_pm_pack_tiles, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)pm->d_refsB.p,
+                                   (float4 *)pm->d_Bpack.p, (const int *)pm->d_qoff.p, (const int *)pm->d_rstart.p, (const int *)pm->d_coff.p,
+                                   (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, nrefs, (const int *)nullptr);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_pm_create: operand packing failed"); rc = XH_ERR_HIP; }
+            }
+        }
     }
     if (rc != XH_OK) { free_all(pm); delete pm; return rc; }
     *out = pm;
@@ -1065,6 +1483,8 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     if (!strcmp(name, "tau_rel")) pm->tau_rel = value;
     else if (!strcmp(name, "tie_rel")) pm->tie_rel = value;
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
+    else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
+    else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1117,7 +1537,17 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     XH_HIP(hipMemcpyAsync(pm->d_desc.p, desc.data(), sizeof(BlockDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(hipStreamSynchronize(ctx->stream));
     const int nt = ((L.nk + 63) / 64) * 64;
-    if (dense)
+    if (dense && pm->use_mfma && nq == pm->nrefs) {
+        const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
+        const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
+        XH_TRY(xh_buf_reserve(ctx, pm->d_Apack, nvec * sizeof(float4)));
+        hipLaunchKernelGGL(k_pm_pack_tiles, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)pm->d_A32.p,
+                           (float4 *)pm->d_Apack.p, (const int *)pm->d_qoff.p, (const int *)pm->d_rstart.p, (const int *)pm->d_coff.p,
+                           (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, ptiles), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
+                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, L.nk, pm->totalQuads, m, nq, qtiles);
+    } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,
                            (const int *)nullptr, (float4 *)pm->d_raw.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p,
@@ -1130,6 +1560,19 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     if (evMid) XH_HIP(hipEventRecord(evMid, ctx->stream));
     const int lpb = std::max(1, std::min(4, (60 * 1024) / (int)(pm->M * sizeof(xh_cf))));
     const size_t smem = (size_t)lpb * pm->M * sizeof(xh_cf);
+    if (pm->R1 && pm->use_idft3) {
+        const int grid = std::max(1, std::min((nrows + 3) / 4, ctx->num_cus * 8));
+#define XH_IDFT3(A_, B_, C_)                                                                                  \
+    hipLaunchKernelGGL((k_pm_idft_max3<A_, B_, C_>), dim3(grid), dim3(256), 0, ctx->stream, (const float4 *)pm->d_raw.p, \
+                       (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_Wfull.p, (const xh_cf *)pm->d_chirp.p,       \
+                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nrows)
+        if (pm->logM == 9) XH_IDFT3(8, 8, 8);
+        else if (pm->logM == 10) XH_IDFT3(16, 8, 8);
+        else XH_IDFT3(16, 16, 8);
+#undef XH_IDFT3
+        XH_LAUNCH_CHECK();
+        return XH_OK;
+    }
     switch (pm->logM) {
         case 6: launch_idft<6>(pm, nrows, lpb, smem); break;
         case 7: launch_idft<7>(pm, nrows, lpb, smem); break;
@@ -1158,7 +1601,8 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
             XH_CHECK(h_nbr_ids[i] >= 0 && h_nbr_ids[i] < pm->nrefs, XH_ERR_ARG, "xh_pm_match: reference id %d out of range", h_nbr_ids[i]);
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
-    const size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, (size_t)(512u << 20) / (L.nk * sizeof(float4)));
+    // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
+    const size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (L.nk * sizeof(float4)));
     const float tauAbs = (float)(pm->tau_rel * pm->scale);
     const double tieAbs = pm->tie_rel * pm->scale;
     int p0 = 0;
