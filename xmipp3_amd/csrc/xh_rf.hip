@@ -217,7 +217,7 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull;
+    XhBuf d_cull, d_pack;
     int tile_max_spaces;
     int ntiles;
     bool cropped;
@@ -542,6 +542,36 @@ k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__rest
 // read-modify-write.  No atomics, run-to-run deterministic; a voxel receives exactly the
 // contributions processVoxelBlob (RFA:627-700) would give it when the reference's traversal
 // (RFA:743-761: AABB rows, hit1||hit2 via getX) visits it.
+
+// ---- packed, padded projection records for the tile kernel -----------------------------------
+// pk[n][sizeY+8][sizeX+8], 4 pad cells on every side (zero): a voxel's 4x4 footprint can then be
+// fetched as four contiguous row segments without clamping. HAS_CTF: float4 (re, im, ctf, mod);
+// otherwise float2 (re, im).
+#define XH_PAD 4
+template <bool HAS_CTF>
+__global__ void k_rf_pack(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
+                          void *__restrict__ pk, int n, int sizeX, int sizeY)
+{
+    const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+    const size_t total = (size_t)n * SY * SX;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int x = gid % SX - XH_PAD;
+    const int y = (gid / SX) % SY - XH_PAD;
+    const size_t img = gid / ((size_t)SX * SY);
+    const bool in = x >= 0 && x < sizeX && y >= 0 && y < sizeY;
+    const size_t o = img * sizeX * sizeY + (size_t)y * sizeX + x;
+    if (HAS_CTF) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) { const xh_cf f = ffts[o]; v = make_float4(f.x, f.y, ctfs[o], mods[o]); }
+        reinterpret_cast<float4 *>(pk)[gid] = v;
+    } else {
+        float2 v = make_float2(0.f, 0.f);
+        if (in) { const xh_cf f = ffts[o]; v = make_float2(f.x, f.y); }
+        reinterpret_cast<float2 *>(pk)[gid] = v;
+    }
+}
+
 #define XH_TSZ 8
 #define XH_CHUNK 256      // projections culled per block-level pass (capacity of the LDS hit records)
 #define XH_QCAP 128       // per-wave work queue capacity (64 pending + 64 new)
@@ -569,8 +599,7 @@ __device__ __forceinline__ void d_prefetch(const void *g, void *ldsWaveRow)
 template <bool HAS_CTF, bool SMALLBLOB>
 __global__ void __launch_bounds__(512, 4)
 k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN,
-                  const float4 *__restrict__ cullX, int nspaces, const xh_cf *__restrict__ ffts,
-                  const float *__restrict__ ctfs, const float *__restrict__ mods,
+                  const float4 *__restrict__ cullX, int nspaces, const void *__restrict__ pk,
                   const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
                   int mv, float iDeltaSqrt, double blobRadius, const unsigned *__restrict__ tileList,
                   const int *__restrict__ classOff, int dbg)
@@ -582,7 +611,6 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     __shared__ float sAcc[8][3][64];
     __shared__ float qIx[8][XH_QCAP], qIy[8][XH_QCAP], qZs[8][XH_QCAP];
     __shared__ int qMeta[8][XH_QCAP];
-    __shared__ float sPref[8][64];
     const int tid = threadIdx.x;
     for (int i = tid; i < XH_BLOB_TABLE; i += 512) sBlob[i] = blobTable[i];
     __syncthreads();
@@ -619,49 +647,64 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 minY = max(minY, 0);
                 maxX = min(maxX, sizeX - 1);
                 maxY = min(maxY, sizeY - 1);
-                const size_t imgOff = (size_t)S.img * sizeX * sizeY;
-                const xh_cf *img = ffts + imgOff;
+                const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+                const size_t imgOff = (size_t)S.img * SX * SY;
                 const float dataWeight = S.weight;
                 float vW = 0.f, vR = 0.f, vI = 0.f;
                 if (SMALLBLOB) {
-                    // blob radius < 2: at most 4x4 candidate pixels. All loads are issued before any
-                    // arithmetic (one memory latency instead of sixteen); pixels outside the blob get
-                    // weight 0, which leaves the sums bit-identical to the reference's skip.
+                    // blob radius < 2: at most 4x4 candidate pixels, fetched as four contiguous row
+                    // segments of the padded record (all loads issued before any arithmetic). Pixels
+                    // outside the blob or the image get weight 0, which leaves the sums bit-identical
+                    // to the reference's "continue" (RFA:660-698).
                     const int bY = (int)ceil((double)iy - blobRadius), bX = (int)ceil((double)ix - blobRadius);
-                    xh_cf pix[4][4];
-                    float wc[4][4], wm[4][4], wb[4][4];
+                    float yz[4], xs[4];
+                    bool rv[4], cv[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = bY + a;
+                        const float ySqr = (iy - i) * (iy - i);
+                        yz[a] = ySqr + zSqr;
+                        rv[a] = (i >= minY) && (i <= maxY) && !(yz[a] > radiusSqr);
+                    }
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int i = bY + a, j = bX + b;
-                            const bool in = (i >= minY) && (i <= maxY) && (j >= minX) && (j <= maxX);
-                            const int ic = min(max(i, 0), sizeY - 1), jc = min(max(j, 0), sizeX - 1);
-                            const int o = ic * sizeX + jc;
-                            pix[a][b] = img[o];
-                            if (HAS_CTF) { wc[a][b] = ctfs[imgOff + o]; wm[a][b] = mods[imgOff + o]; }
-                            const float ySqr = (iy - i) * (iy - i);
-                            const float yzSqr = ySqr + zSqr;
-                            const float xD = ix - j;
-                            const float distanceSqr = xD * xD + yzSqr;
-                            const bool use = in && !(yzSqr > radiusSqr) && !(distanceSqr > radiusSqr);
-                            const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
-                            wb[a][b] = use ? sBlob[aux] : 0.f;
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = bX + b;
+                        const float xD = ix - j;
+                        xs[b] = xD * xD;
+                        cv[b] = (j >= minX) && (j <= maxX);
+                    }
+                    const size_t base = imgOff + (size_t)(bY + XH_PAD) * SX + (bX + XH_PAD);
+                    float pr[4][4], pi_[4][4], wc[4][4], wm[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (HAS_CTF) {
+                            const float4 *row = reinterpret_cast<const float4 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) { const float4 q = row[b]; pr[a][b] = q.x; pi_[a][b] = q.y; wc[a][b] = q.z; wm[a][b] = q.w; }
+                        } else {
+                            const float2 *row = reinterpret_cast<const float2 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) { const float2 q = row[b]; pr[a][b] = q.x; pi_[a][b] = q.y; }
                         }
+                    }
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
+                            const float distanceSqr = xs[b] + yz[a];
+                            const bool use = rv[a] && cv[b] && !(distanceSqr > radiusSqr);
+                            const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
+                            const float wBlob = use ? sBlob[aux] : 0.f;
                             if (HAS_CTF) {
-                                const float weight = wb[a][b] * wm[a][b] * dataWeight;
+                                const float weight = wBlob * wm[a][b] * dataWeight;
                                 vW += weight;
-                                vR += pix[a][b].x * weight * wc[a][b];
-                                vI += pix[a][b].y * weight * wc[a][b];
+                                vR += pr[a][b] * weight * wc[a][b];
+                                vI += pi_[a][b] * weight * wc[a][b];
                             } else {
-                                const float weight = wb[a][b] * dataWeight;
+                                const float weight = wBlob * dataWeight;
                                 vW += weight;
-                                vR += pix[a][b].x * weight;
-                                vI += pix[a][b].y * weight;
+                                vR += pr[a][b] * weight;
+                                vI += pi_[a][b] * weight;
                             }
                         }
                 } else
@@ -675,19 +718,19 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                         if (distanceSqr > radiusSqr) continue;
                         const int aux = (int)(distanceSqr * iDeltaSqrt + 0.5f);
                         const float wBlob = sBlob[aux];
-                        const xh_cf pix = img[i * sizeX + j];
+                        const size_t o = imgOff + (size_t)(i + XH_PAD) * SX + (j + XH_PAD);
                         if (HAS_CTF) {
-                            const float wCTF = ctfs[imgOff + i * sizeX + j];
-                            const float wModulator = mods[imgOff + i * sizeX + j];
-                            const float weight = wBlob * wModulator * dataWeight;
+                            const float4 q = reinterpret_cast<const float4 *>(pk)[o];
+                            const float weight = wBlob * q.w * dataWeight;
                             vW += weight;
-                            vR += pix.x * weight * wCTF;
-                            vI += pix.y * weight * wCTF;
+                            vR += q.x * weight * q.z;
+                            vI += q.y * weight * q.z;
                         } else {
+                            const float2 q = reinterpret_cast<const float2 *>(pk)[o];
                             const float weight = wBlob * dataWeight;
                             vW += weight;
-                            vR += pix.x * weight;
-                            vI += pix.y * weight;
+                            vR += q.x * weight;
+                            vI += q.y * weight;
                         }
                     }
                 }
@@ -768,19 +811,6 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                     const int q = qn + __popcll(pb & ((1ull << lane) - 1ull));
                     qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
                     qMeta[wv][q] = (sHit[h] << 6) | lane;
-                    if (dbg != 4) {
-                        // start pulling the 4 rows of this voxel's footprint towards the caches
-                        const size_t imgOff = (size_t)__float_as_int(r0.w) * sizeX * sizeY;
-                        const int pj = min(max((int)(ix + 0.5f), 0), sizeX - 1);
-                        const int bY = (int)ceil((double)iy - blobRadius);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const int row = min(max(bY + a, 0), sizeY - 1);
-                            const size_t o = imgOff + (size_t)row * sizeX + pj;
-                            d_prefetch(ffts + o, &sPref[wv][0]);
-                            if (HAS_CTF) { d_prefetch(ctfs + o, &sPref[wv][0]); d_prefetch(mods + o, &sPref[wv][0]); }
-                        }
-                    }
                 }
                 qn += np;
                 if (qn >= 64) {
@@ -1097,16 +1127,25 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
         // tiles that a projection can reach (sphere of radius sizeX + blob), heaviest (central) first
         const int tpd = (rf->mv + 1 + XH_TSZ - 1) / XH_TSZ;
         const double R = rf->sizeX + p->blob_radius + 6.1 + 1.0;
+        // Raster order (z, y, x) cut into 8 contiguous z-slabs of equal estimated work, one per XCD
+        // (block b runs on XCD b%8): a projection's patch is then pulled into one or two L2s instead
+        // of all eight. A tile at distance rho from the centre is crossed by a fraction ~1/rho of all
+        // central planes, so that is its weight.
         std::vector<unsigned> packed;
+        std::vector<double> wsum;
+        double acc = 0;
+        for (int tz = 0; tz < tpd; ++tz)
+            for (int ty = 0; ty < tpd; ++ty)
+                for (int tx = 0; tx < tpd; ++tx) {
+                    const double cx = tx * XH_TSZ + 3.5 - rf->mv / 2, cy = ty * XH_TSZ + 3.5 - rf->mv / 2, cz = tz * XH_TSZ + 3.5 - rf->mv / 2;
+                    const double d = std::sqrt(cx * cx + cy * cy + cz * cz);
+                    if (d <= R) { packed.push_back((unsigned)(tx | (ty << 8) | (tz << 16))); acc += 1.0 / std::max(d, 6.0); wsum.push_back(acc); }
+                }
         int classOff[9];
-        for (int c = 0; c < 8; ++c) {
-            classOff[c] = (int)packed.size();
-            for (int tz = c; tz < tpd; tz += 8)
-                for (int ty = 0; ty < tpd; ++ty)
-                    for (int tx = 0; tx < tpd; ++tx) {
-                        const double cx = tx * XH_TSZ + 3.5 - rf->mv / 2, cy = ty * XH_TSZ + 3.5 - rf->mv / 2, cz = tz * XH_TSZ + 3.5 - rf->mv / 2;
-                        if (std::sqrt(cx * cx + cy * cy + cz * cz) <= R) packed.push_back((unsigned)(tx | (ty << 8) | (tz << 16)));
-                    }
+        classOff[0] = 0;
+        for (int c = 1; c < 8; ++c) {
+            const double target = acc * c / 8.0;
+            classOff[c] = (int)(std::lower_bound(wsum.begin(), wsum.end(), target) - wsum.begin());
         }
         classOff[8] = (int)packed.size();
         rf->ntiles = (int)packed.size();
@@ -1129,7 +1168,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
-    xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull);
+    xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     delete rf;
     return XH_OK;
 }
@@ -1361,13 +1400,25 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
         XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
         XH_HIP(hipStreamSynchronize(ctx->stream));
+        {
+            // packed + padded projection records (re, im[, ctf, mod]) for contiguous 4-pixel row fetches
+            const size_t cells = (size_t)n * (rf->sizeX + 2 * XH_PAD) * (rf->sizeY + 2 * XH_PAD);
+            XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * (hasCtf ? sizeof(float4) : sizeof(float2))));
+            if (hasCtf)
+                hipLaunchKernelGGL((k_rf_pack<true>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
+                                   rf->d_pack.p, n, rf->sizeX, rf->sizeY);
+            else
+                hipLaunchKernelGGL((k_rf_pack<false>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
+                                   rf->d_pack.p, n, rf->sizeX, rf->sizeY);
+            XH_LAUNCH_CHECK();
+        }
         const int maxsp = std::max(64, rf->tile_max_spaces);
         for (int s0 = 0; s0 < ns; s0 += maxsp) {
             const int m = std::min(maxsp, ns - s0);
 #define XH_TILES(CTF_, SB_)                                                                                         \
     hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
-                       (const float4 *)rf->d_cull.p + ns + s0, m, (const xh_cf *)d_fft, d_ctf, d_mod,                \
+                       (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,                        \
                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
                        (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, rf->tile_dbg)
             if (hasCtf && smallBlob) XH_TILES(true, true);
