@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--box", type=int, default=256, help="particle box D")
     ap.add_argument("--nrefs", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=2048, help="particles per step per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="particles per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU sample (0 = auto)")
     ap.add_argument("--mode", default="full", choices=["full", "match", "grid"])
@@ -91,11 +91,22 @@ def main():
     refs = smooth_noise(torch, nrefs, D, genr, dev)
     dirs = synth.fibonacci_directions(nrefs)
     idx = torch.randint(0, nrefs, (B,), generator=gen, device=dev)
-    particles = (refs[idx] + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()  # SNR 0.1
+    # random in-plane rotation (as in real data) + white noise at SNR 0.1
+    th = torch.rand((B,), generator=gen, device=dev) * (2 * math.pi)
+    rot = torch.zeros((B, 2, 3), device=dev)
+    rot[:, 0, 0] = torch.cos(th); rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th); rot[:, 1, 1] = torch.cos(th)
+    particles = torch.empty((B, D, D), device=dev)
+    for b0 in range(0, B, 512):
+        sl = slice(b0, min(B, b0 + 512))
+        grid = torch.nn.functional.affine_grid(rot[sl], (rot[sl].shape[0], 1, D, D), align_corners=False)
+        particles[sl] = torch.nn.functional.grid_sample(refs[idx[sl]][:, None], grid, mode="bilinear", padding_mode="zeros",
+                                                        align_corners=False)[:, 0]
+    particles = (particles + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
     rng = np.random.default_rng(100 + rank)
     from xmipp3_amd.api import ctf_params
     ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d))
             for d in rng.uniform(10000.0, 30000.0, B)]
+    ctf_arr = xa.RecFourier.ctf_param_array(ctfs)
 
     pm = xa.ProjectionMatcher(ctx, refs) if args.mode != "grid" else None
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
@@ -117,7 +128,7 @@ def main():
             shifts = rng.uniform(-3, 3, (B, 2))
         if rf is not None:
             imgs = rf.shift_images(particles, shifts)
-            c, m = rf.ctf_arrays(ctfs)
+            c, m = rf.ctf_arrays(ctf_arr)
             fft = rf.prepare_images(imgs)
             if record:
                 t_grid.start()
@@ -186,7 +197,7 @@ def main():
         cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"])
     if rf is not None and stage["gridding_insert"] > 0:
         by = args.steps * B * bytes_grid
-        cand["k_rf_insert"] = ("hbm", by / (stage["gridding_insert"] * 1e-3) / 1e9, 8000.0, "GB/s", stage["gridding_insert"])
+        cand["k_rf_insert_tiles"] = ("hbm", by / (stage["gridding_insert"] * 1e-3) / 1e9, 8000.0, "GB/s", stage["gridding_insert"])
     dom = max(cand, key=lambda k: cand[k][4]) if cand else None
     roofline = None
     if dom:

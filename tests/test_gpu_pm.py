@@ -78,7 +78,7 @@ def test_correlation_rows_and_fp32_margin(gpu, oracle, lib64):
         worst32 = max(worst32, np.abs(got32 - exp).max() / scale)
         assert np.argmax(got64) == np.argmax(exp)
     print("fp32 coarse-pass error / scale:", worst32)
-    assert worst32 < 2e-5 / 4   # default tau_rel = 2e-5 leaves 4x headroom
+    assert worst32 < 3e-6 / 4   # default tau_rel = 3e-6 leaves >4x headroom
 
 
 @pytest.mark.parametrize("parity", [0, 1])

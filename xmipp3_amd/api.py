@@ -175,10 +175,15 @@ class RecFourier:
         check(lib().xh_rf_prepare_images(self.h, _ptr(imgs), n, _ptr(out)))
         return out
 
+    @staticmethod
+    def ctf_param_array(ctfs):
+        """Pack a list of CtfParams once (reusable across calls)."""
+        return (CtfParams * len(ctfs))(*ctfs)
+
     def ctf_arrays(self, ctfs):
         torch = _torch()
         n = len(ctfs)
-        arr = (CtfParams * n)(*ctfs)
+        arr = ctfs if isinstance(ctfs, C.Array) else (CtfParams * n)(*ctfs)
         c = torch.empty((n, self.sizeY, self.sizeX), dtype=torch.float32, device=self.ctx.torch_device)
         m = torch.empty_like(c)
         check(lib().xh_rf_ctf_arrays(self.h, arr, n, _ptr(c), _ptr(m)))

@@ -830,7 +830,7 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
                  const xh_cd *__restrict__ A64, const xh_cd *__restrict__ refs64, const double *__restrict__ refSigma,
                  const double *__restrict__ stat64, const xh_cd *__restrict__ csN, const int *__restrict__ nsamv,
                  const int *__restrict__ coff, int nrings, int Ri, int ncoef, int N, int nk,
-                 CandRes *__restrict__ out, double *__restrict__ dbgRow)
+                 CandRes *__restrict__ out, double *__restrict__ dbgRow, int denseNq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cd *Fs = reinterpret_cast<xh_cd *>(smem);
@@ -839,7 +839,7 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
     const int c = blockIdx.x;
     if (c >= counters[1]) return;
     const int row = candRow[c];
-    const int p = rowP[row];
+    const int p = rowP ? rowP[row] : row / denseNq;
     const int ref = refIds ? refIds[row] : (row - poff[p]);
     const int slot = ambSlotOfP[p];
     const xh_cd *a = A64 + (size_t)slot * ncoef;
@@ -903,7 +903,7 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
 __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restrict__ ambList,
                           const CandRes *__restrict__ cand, const int *__restrict__ rowP, const int *__restrict__ poff,
                           const int *__restrict__ refIds, int pBase, int parity, int N, double tieAbs,
-                          int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
+                          int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip, int denseNq)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= counters[0]) return;
@@ -913,11 +913,11 @@ __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restric
     const int r0 = poff[p], r1 = poff[p + 1];
     double best = -1.0e300;
     for (int c = 0; c < nc; ++c)
-        if (rowP[cand[c].row] == p && cand[c].val > best) best = cand[c].val;
+        if ((rowP ? rowP[cand[c].row] : cand[c].row / denseNq) == p && cand[c].val > best) best = cand[c].val;
     int bestRow = -1, bestIdx = 0, bestOrder = 0x7fffffff;
     for (int c = 0; c < nc; ++c) {
         const int row = cand[c].row;
-        if (rowP[row] != p) continue;
+        if ((rowP ? rowP[row] : row / denseNq) != p) continue;
         if (cand[c].val >= best - tieAbs) {
             const int order = forward ? (row - r0) : (r1 - 1 - row);
             if (order < bestOrder) { bestOrder = order; bestRow = row; bestIdx = cand[c].idx; }
@@ -1294,7 +1294,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     }
     pm->scale = 0;
     for (int r = 0; r < L.nrings; ++r) pm->scale += 2. * kPI * (r + Ri);
-    pm->tau_rel = 2e-5;
+    pm->tau_rel = 3e-6;   // measured fp32 error of a normalised row: 1.6e-7*S (D=256), 1.8e-7*S (D=64)
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
     pm->tie_rel = 1e-12;
@@ -1516,7 +1516,10 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     XH_TRY(xh_buf_reserve(ctx, pm->d_rowres, sizeof(RowRes) * (size_t)nrows));
     std::vector<BlockDesc> desc;
     const int PT = 4, QT = 4;
-    if (dense) {
+    const bool mfma = dense && pm->use_mfma && nq == pm->nrefs;
+    if (mfma) {
+        // packed-operand MFMA path needs no tile descriptors
+    } else if (dense) {
         for (int p0 = 0; p0 < m; p0 += PT)
             for (int q0 = 0; q0 < nq; q0 += QT) {
                 BlockDesc d;
@@ -1533,11 +1536,13 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                 desc.push_back(d);
             }
     }
-    XH_TRY(xh_buf_reserve(ctx, pm->d_desc, sizeof(BlockDesc) * desc.size()));
-    XH_HIP(hipMemcpyAsync(pm->d_desc.p, desc.data(), sizeof(BlockDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));
+    if (!desc.empty()) {
+        XH_TRY(xh_buf_reserve(ctx, pm->d_desc, sizeof(BlockDesc) * desc.size()));
+        XH_HIP(hipMemcpyAsync(pm->d_desc.p, desc.data(), sizeof(BlockDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+    }
     const int nt = ((L.nk + 63) / 64) * 64;
-    if (dense && pm->use_mfma && nq == pm->nrefs) {
+    if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
         XH_TRY(xh_buf_reserve(ctx, pm->d_Apack, nvec * sizeof(float4)));
@@ -1616,18 +1621,18 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
             rows += nn;
             ++m;
         }
-        std::vector<int> poff(m + 1), rowP(rows);
+        std::vector<int> poff(m + 1), rowP(dense ? 0 : rows);
         poff[0] = 0;
         for (int i = 0; i < m; ++i) {
             const int nn = dense ? pm->nrefs : (h_nbr_off[p0 + i + 1] - h_nbr_off[p0 + i]);
             poff[i + 1] = poff[i] + nn;
-            for (int r = poff[i]; r < poff[i + 1]; ++r) rowP[r] = i;
+            if (!dense) for (int r = poff[i]; r < poff[i + 1]; ++r) rowP[r] = i;
         }
         const int nrows = (int)rows;
         XH_TRY(xh_buf_reserve(ctx, pm->d_poff, sizeof(int) * (m + 1 + rows)));
-        int *d_poff = (int *)pm->d_poff.p, *d_rowP = d_poff + (m + 1);
+        int *d_poff = (int *)pm->d_poff.p, *d_rowP = dense ? nullptr : d_poff + (m + 1);   // dense: row / nrefs
         XH_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice, ctx->stream));
-        if (rows) XH_HIP(hipMemcpyAsync(d_rowP, rowP.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+        if (!dense && rows) XH_HIP(hipMemcpyAsync(d_rowP, rowP.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
         const int *d_ids = nullptr;
         if (!dense && rows) {
             XH_TRY(xh_buf_reserve(ctx, pm->d_nbr, sizeof(int) * rows));
@@ -1678,11 +1683,11 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
                                (const int *)pm->d_ambSlot.p, (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p,
                                (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p,
                                (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, L.N, L.nk,
-                               (CandRes *)pm->d_candRes.p, (double *)nullptr);
+                               (CandRes *)pm->d_candRes.p, (double *)nullptr, pm->nrefs);
             XH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_pm_pick, dim3((na + 63) / 64), dim3(64), 0, ctx->stream, (const int *)pm->d_counters.p,
                                (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, (const int *)d_rowP,
-                               (const int *)d_poff, d_ids, p0, parity, L.N, tieAbs, d_refno, d_psi, d_flip);
+                               (const int *)d_poff, d_ids, p0, parity, L.N, tieAbs, d_refno, d_psi, d_flip, pm->nrefs);
             XH_LAUNCH_CHECK();
             XH_HIP(hipEventRecord(pm->ev[5], ctx->stream));
             XH_HIP(hipEventSynchronize(pm->ev[5]));
@@ -1839,7 +1844,7 @@ int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32
                            (const int *)(m + 5), (const int *)(m + 6), (const int *)pm->d_nbr.p, (const int *)(m + 8),
                            (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p, (const double *)pm->d_refSigma.p,
                            (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p,
-                           (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, N, L.nk, (CandRes *)pm->d_candRes.p, (double *)dbg.p);
+                           (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, N, L.nk, (CandRes *)pm->d_candRes.p, (double *)dbg.p, 1);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_corr2N, dbg.p, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, ctx->stream);

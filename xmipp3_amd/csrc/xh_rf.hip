@@ -575,6 +575,7 @@ __global__ void k_rf_pack(const xh_cf *__restrict__ ffts, const float *__restric
 #define XH_TSZ 8
 #define XH_CHUNK 256      // projections culled per block-level pass (capacity of the LDS hit records)
 #define XH_QCAP 128       // per-wave work queue capacity (64 pending + 64 new)
+#define XH_GRAB 8         // tiles fetched per work-queue atomic
 // Workgroup = one 8x8x8 tile, 8 waves; wave w owns the 4x4x4 sub-cube (w&1, (w>>1)&1, w>>2) and
 // lane l the voxel (l&3, (l>>2)&3, l>>4) of it.
 //  block level : cull the launch's projections against the tile, 256 at a time, with an ordered
@@ -602,7 +603,7 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                   const float4 *__restrict__ cullX, int nspaces, const void *__restrict__ pk,
                   const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
                   int mv, float iDeltaSqrt, double blobRadius, const unsigned *__restrict__ tileList,
-                  const int *__restrict__ classOff, int dbg)
+                  const int *__restrict__ classOff, int *__restrict__ counter, int dbg)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     __shared__ XhHitRec sRec[XH_CHUNK];
@@ -741,12 +742,32 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
         }
     };
 
-    const int cls = blockIdx.x & 7, rank = blockIdx.x >> 3, nb = gridDim.x >> 3;
-    const int cBeg = classOff[cls], cEnd = classOff[cls + 1];
-    unsigned packedNext = (cBeg + rank < cEnd) ? tileList[cBeg + rank] : 0u;
-    for (int ti = cBeg + rank; ti < cEnd; ti += nb) {
-        const unsigned packed = packedNext;
-        if (ti + nb < cEnd) packedNext = tileList[ti + nb];   // prefetch: latency hides behind this tile
+    // Work distribution: tiles are queued per XCD class (contiguous z-slab of equal expected work).
+    // A block drains its own class first (L2 affinity), then steals from the others, in chunks of
+    // XH_GRAB tiles per atomic; the next chunk is requested while the current one is processed, so the
+    // dequeue latency never sits between tiles, and an anisotropic orientation distribution (all
+    // half-planes in one hemisphere) cannot idle half of the chip.
+    __shared__ int sGrab[2];
+    int cls = blockIdx.x & 7, tried = 0;
+    int pend = 0;                                  // thread 0: outstanding dequeue (index into class cls)
+    if (tid == 0) pend = atomicAdd(&counter[cls], XH_GRAB);
+    for (;;) {
+      if (tid == 0) {
+        int lo = 0, hiT = 0;
+        while (tried < 8) {
+            const int n = classOff[cls + 1] - classOff[cls];
+            if (pend < n) { lo = classOff[cls] + pend; hiT = classOff[cls] + min(pend + XH_GRAB, n); break; }
+            cls = (cls + 1) & 7;                    // class drained: steal from the next one
+            if (++tried < 8) pend = atomicAdd(&counter[cls], XH_GRAB);
+        }
+        sGrab[0] = lo; sGrab[1] = hiT;
+        if (tried < 8) pend = atomicAdd(&counter[cls], XH_GRAB);   // in flight while this chunk is processed
+      }
+      __syncthreads();
+      const int tBeg = sGrab[0], tEnd = sGrab[1];
+      if (tBeg >= tEnd) break;
+      for (int ti = tBeg; ti < tEnd; ++ti) {
+        const unsigned packed = tileList[ti];
         const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
         const int x0 = tx * XH_TSZ + ox, y0 = ty * XH_TSZ + oy, z0 = tz * XH_TSZ + oz;
         const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
@@ -837,6 +858,8 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
             *V = v;
             tempW[vi] += aW;
         }
+      }
+      __syncthreads();   // sGrab is rewritten at the top of the loop
     }
 }
 
@@ -1415,12 +1438,13 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         const int maxsp = std::max(64, rf->tile_max_spaces);
         for (int s0 = 0; s0 < ns; s0 += maxsp) {
             const int m = std::min(maxsp, ns - s0);
+            XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));
 #define XH_TILES(CTF_, SB_)                                                                                         \
     hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
                        (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,                        \
                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
-                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, rf->tile_dbg)
+                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p, rf->tile_dbg)
             if (hasCtf && smallBlob) XH_TILES(true, true);
             else if (hasCtf) XH_TILES(true, false);
             else if (smallBlob) XH_TILES(false, true);
