@@ -158,6 +158,29 @@ def test_translational_alignment(gpu, oracle, lib64):
         assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
+@pytest.mark.parametrize("pad", [1, 2])
+def test_ctf_filtered_gallery(gpu, oracle, lib64, pad):
+    """--ctf: the references are filtered (pad, FFT, x Mctf, IFFT, crop) before the polar transform (APM:457-481)."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    P = pad * D
+    f = np.fft.fftfreq(P)
+    r2 = f[:, None] ** 2 + f[None, :] ** 2
+    Mctf = -np.sin(900.0 * r2 + 0.3) * np.exp(-8.0 * r2)          # even in both axes, like generateCTF
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda(), Mctf=Mctf, paddim=P)
+    o = oracle.PM(refs, Mctf=Mctf, paddim=P)
+    for r in (0, 11):
+        c, s = pm.debug_ref(r)
+        ce, se = o.ref_coefs(r), o.ref_sigma(r)
+        assert abs(s - se) <= 1e-10 * se and np.abs(c - ce).max() <= 1e-10 * np.abs(ce).max()
+    refno, psi, flip = pm.match(torch.from_numpy(parts).cuda())
+    er, ep, ef, _ = o.match(parts)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0]) and np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    sx, sy, cc = pm.translate(torch.from_numpy(parts).cuda(), refno, psi, flip)
+    ex, ey, ec = o.translate(parts, er[:, 0], ep[:, 0], ef[:, 0])
+    assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3 and np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     refs = torch.zeros((2, 64, 64), device="cuda")

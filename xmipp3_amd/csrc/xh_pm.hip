@@ -1156,6 +1156,42 @@ k_pm_bestshift(const xh_cd *__restrict__ Rraw, const xh_cd *__restrict__ zimg, c
     }
 }
 
+
+// ---- CTF filtering of the reference gallery (APM:457-481): window to paddim, FFT, multiply the
+// spectrum by the real filter Mctf, inverse FFT, window back. fp64, once per library.
+__global__ void k_pm_pad_complex(const float *__restrict__ refs, xh_cd *__restrict__ z, int D, int P)
+{
+    const int r = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * P) return;
+    const int i = pix / P, j = pix - i * P;
+    const int o = P / 2 - D / 2;               // FIRST_XMIPP_INDEX(D) - FIRST_XMIPP_INDEX(P)
+    const int ii = i - o, jj = j - o;
+    double v = 0;
+    if (ii >= 0 && ii < D && jj >= 0 && jj < D) v = (double)refs[(size_t)r * D * D + (size_t)ii * D + jj];
+    z[(size_t)r * P * P + pix] = xh_cd{v, 0.};
+}
+__global__ void k_pm_mul_filter(xh_cd *__restrict__ z, const double *__restrict__ M, int P)
+{
+    const int r = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * P) return;
+    xh_cd v = z[(size_t)r * P * P + pix];
+    const double m = M[pix];
+    v.x *= m;
+    v.y *= m;
+    z[(size_t)r * P * P + pix] = v;
+}
+__global__ void k_pm_crop_real(const xh_cd *__restrict__ z, double *__restrict__ out, int D, int P)
+{
+    const int r = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= D * D) return;
+    const int i = pix / D, j = pix - i * D;
+    const int o = P / 2 - D / 2;
+    out[(size_t)r * D * D + pix] = z[(size_t)r * P * P + (size_t)(i + o) * P + (j + o)].x;
+}
+
 // generic strided complex line FFT (same as in xh_rf.hip; duplicated to keep TUs independent)
 template <typename T, bool INV>
 __global__ void __launch_bounds__(256)
@@ -1267,9 +1303,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
                  const double *h_Mctf, int32_t paddim, xh_pm **out)
 {
     XH_CHECK(ctx && d_refs && out && nrefs > 0, XH_ERR_ARG, "xh_pm_create: bad argument");
-    XH_CHECK(h_Mctf == nullptr, XH_ERR_UNSUPPORTED,
-             "xh_pm_create: --ctf filtering of the references (APM:457-481) is not available on the device yet; "
-             "apply it to the reference stack before upload");
+    XH_CHECK(h_Mctf == nullptr || (xh_is_pow2(paddim) && paddim >= D && paddim <= 4096), XH_ERR_UNSUPPORTED,
+             "xh_pm_create: the CTF filter size (paddim=%d) must be a power of two >= the image size %d", paddim, D);
     if (Ri < 1) Ri = 1;               // APM:266-274
     if (Ro < 0) Ro = (D / 2) - 1;
     XH_CHECK(D >= 8 && Ro >= Ri && Ro < D, XH_ERR_ARG, "xh_pm_create: bad geometry D=%d Ri=%d Ro=%d", D, Ri, Ro);
@@ -1404,10 +1439,56 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refSigma, sizeof(double) * nrefs);
         if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refCoef, sizeof(double) * (size_t)nrefs * D * D);
         std::vector<double> stat(2 * RB), sig(nrefs);
+        XhBuf d_zpad, d_WP, d_Mfull, d_refD;
+        if (h_Mctf && rc == XH_OK) {
+            const int P = paddim;
+            // full-spectrum multiplier: the reference multiplies the half spectrum (j <= P/2) index-wise; the
+            // c2r inverse mirrors it onto j > P/2. Forward normalisation 1/P^2 folded in.
+            std::vector<double> Mfull((size_t)P * P);
+            for (int i = 0; i < P; ++i)
+                for (int j = 0; j < P; ++j) {
+                    const double mv = j <= P / 2 ? h_Mctf[(size_t)i * P + j] : h_Mctf[(size_t)((P - i) % P) * P + (P - j)];
+                    Mfull[(size_t)i * P + j] = mv / ((double)P * P);
+                }
+            std::vector<xh_cd> WP(P / 2);
+            for (int j = 0; j < P / 2; ++j) {
+                const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / P;
+                WP[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
+            }
+            rc = upload(ctx, d_Mfull, Mfull);
+            if (rc == XH_OK) rc = upload(ctx, d_WP, WP);
+            if (rc == XH_OK) rc = xh_buf_alloc(ctx, d_zpad, sizeof(xh_cd) * (size_t)RB * P * P);
+            if (rc == XH_OK) rc = xh_buf_alloc(ctx, d_refD, sizeof(double) * (size_t)RB * D * D);
+        }
         for (int r0 = 0; r0 < nrefs && rc == XH_OK; r0 += RB) {
             const int m = std::min(RB, nrefs - r0);
-            rc = run_prep<double>(pm, d_refs + (size_t)r0 * D * D, true, nullptr, m, nullptr, pm->d_coef64, pm->d_polar64,
-                                  pm->d_A64, pm->d_stat64, pm->d_tw64, true, 0., 0.);
+            if (h_Mctf) {
+                // pad -> FFT -> x Mctf -> IFFT -> crop (APM:457-481), then the same preparation on the filtered image
+                const int P = paddim, logP = xh_ilog2(P);
+                const size_t perP = (size_t)P * P;
+                const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(P * sizeof(xh_cd))));
+                const size_t smemF = (size_t)lpb * P * sizeof(xh_cd);
+                const size_t nlines = (size_t)m * P;
+                xh_cd *z = (xh_cd *)d_zpad.p;
+                hipLaunchKernelGGL(k_pm_pad_complex, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream,
+                                   d_refs + (size_t)r0 * D * D, z, D, P);
+                hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
+                hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
+                hipLaunchKernelGGL(k_pm_mul_filter, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream, z, (const double *)d_Mfull.p, P);
+                hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
+                hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
+                hipLaunchKernelGGL(k_pm_crop_real, dim3((unsigned)(((size_t)D * D + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)z,
+                                   (double *)d_refD.p, D, P);
+                if (hipGetLastError() != hipSuccess) { xh_set_error("xh_pm_create: CTF filtering of the references failed"); rc = XH_ERR_HIP; break; }
+                rc = run_prep<double>(pm, d_refD.p, false, nullptr, m, nullptr, pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64,
+                                      pm->d_tw64, true, 0., 0.);
+            } else
+                rc = run_prep<double>(pm, d_refs + (size_t)r0 * D * D, true, nullptr, m, nullptr, pm->d_coef64, pm->d_polar64,
+                                      pm->d_A64, pm->d_stat64, pm->d_tw64, true, 0., 0.);
             if (rc != XH_OK) break;
             if (hipMemcpyAsync((xh_cd *)pm->d_refs64.p + (size_t)r0 * L.ncoef, pm->d_A64.p, sizeof(xh_cd) * (size_t)m * L.ncoef,
                                hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
@@ -1421,6 +1502,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             }
             for (int i = 0; i < m; ++i) sig[r0 + i] = stat[2 * i + 1];
         }
+        (void)hipStreamSynchronize(ctx->stream);
+        xh_buf_free(d_zpad); xh_buf_free(d_WP); xh_buf_free(d_Mfull); xh_buf_free(d_refD);
         if (rc == XH_OK && hipMemcpy(pm->d_refSigma.p, sig.data(), sizeof(double) * nrefs, hipMemcpyHostToDevice) != hipSuccess) {
             xh_set_error("xh_pm_create: sigma upload failed");
             rc = XH_ERR_HIP;

@@ -24,6 +24,46 @@ struct DeviceBuffer {
     template <typename T> T *as() { return (T *)p; }
 };
 
+// CTFDescription::getValueAt for the pure CTF (data/ctf.h:452-496,1002-1029; data/ctf.cpp:645-679,1392-1402);
+// host copy used only to build the gallery filter of --ctf (generateCTF, data/ctf.h:1219-1240)
+inline double bessj0_host(double x)
+{
+    double ax = std::fabs(x);
+    if (ax < 8.0) {
+        double y = x * x;
+        double a1 = 57568490574.0 + y * (-13362590354.0 + y * (651619640.7 + y * (-11214424.18 + y * (77392.33017 + y * (-184.9052456)))));
+        double a2 = 57568490411.0 + y * (1029532985.0 + y * (9494680.718 + y * (59272.64853 + y * (267.8532712 + y * 1.0))));
+        return a1 / a2;
+    }
+    double z = 8.0 / ax, y = z * z, xx = ax - 0.785398164;
+    double a1 = 1.0 + y * (-0.1098628627e-2 + y * (0.2734510407e-4 + y * (-0.2073370639e-5 + y * 0.2093887211e-6)));
+    double a2 = -0.1562499995e-1 + y * (0.1430488765e-3 + y * (-0.6911147651e-5 + y * (0.7621095161e-6 - y * 0.934935152e-7)));
+    return std::sqrt(0.636619772 / ax) * (std::cos(xx) * a1 - z * std::sin(xx) * a2);
+}
+inline double ctfValueAt(const xh_ctf_params &c, double X, double Y)
+{
+    const double PI = 3.14159265358979323846;
+    const double local_Cs = c.Cs * 1e7, local_Ca = c.Ca * 1e7, local_kV = c.kV * 1e3, local_ispr = c.ispr * 1e6;
+    const double lambda = 12.2643247 / std::sqrt(local_kV * (1. + 0.978466e-6 * local_kV));
+    const double K1 = PI * lambda, K2 = PI / 2 * local_Cs * lambda * lambda * lambda;
+    const double K3 = std::pow(0.25 * PI * local_Ca * lambda * (c.espr / c.kV + 2 * local_ispr), 2) / std::log(2.0);
+    const double K5 = PI * c.DeltaF * lambda, K6 = PI * PI * c.alpha * c.alpha, K7 = local_Cs * lambda * lambda;
+    const double Ksin = std::sqrt(1 - c.Q0 * c.Q0), Kcos = c.Q0;
+    const double ang = std::atan2(Y, X), u2 = X * X + Y * Y, u = std::sqrt(u2), u4 = u2 * u2;
+    double deltaf = 0;
+    if (!(std::fabs(X) < 1e-6 && std::fabs(Y) < 1e-6))
+        deltaf = -(c.DeltafU + c.DeltafV) * 0.5 - (c.DeltafU - c.DeltafV) * 0.5 * std::cos(2 * (ang - c.azimuthal_angle * PI / 180.));
+    double VPP = 0;
+    if (std::round(c.VPP_radius * 1000) != 0) VPP = -c.phase_shift * (1 - std::exp(-u2 / (2 * c.VPP_radius * c.VPP_radius)));
+    const double arg = VPP + K1 * deltaf * u2 + K2 * u4;
+    const double xs = u * c.DeltaR;
+    const double aux = K7 * u2 * u + deltaf * u;
+    double E = std::exp(-K3 * u4) * bessj0_host(K5 * u2) * (xs == 0 ? 1.0 : std::sin(PI * xs) / (PI * xs)) * std::exp(-K6 * aux * aux) + c.envR0 +
+               c.envR1 * u + c.envR2 * u2;
+    if (E < 0) E = 0;
+    return -c.K * (Ksin * std::sin(arg) - Kcos * std::cos(arg)) * E;
+}
+
 // Sampling::readSamplingFile (data/sampling.cpp:1592-1659): blocks extra / neighbors / projectionDirections
 struct Sampling {
     std::vector<std::vector<size_t>> my_neighbors;
@@ -160,7 +200,6 @@ public:
         if (search5d_shift != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--search5d_shift > 0 is not available on the device path yet");
         if (numOrientations != 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--number_orientations > 1 is not available on the device path yet");
         if (do_scale) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--scale is not supported (the reference loops forever at scale 1.0, APM:947-948)");
-        if (!fn_ctf.empty()) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--ctf: filter the reference gallery beforehand (device-side filtering not available yet)");
         DFexp.read(fn_exp);
         if (DFexp.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "Empty input metadata " + fn_exp);
         std::string fn_img;
@@ -191,7 +230,44 @@ public:
         DeviceBuffer d_refs;
         d_refs.reserve(ctx, refs.size() * sizeof(float));
         xhCheck(xh_memcpy_h2d(ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
-        xhCheck(xh_pm_create(ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), nullptr, 0, &pm));
+        // CTF filter of the gallery (APM:366-402): a 2-D image of amplitudes or a CTF parameter file
+        std::vector<double> Mctf;
+        const int paddim = (int)std::floor(pad * dim + 0.5);
+        if (!fn_ctf.empty()) {
+            const std::string ext = FileName(fn_ctf).extension();
+            const bool isMd = ext == "xmd" || ext == "ctfparam" || ext == "doc" || ext == "sel";
+            Mctf.resize((size_t)paddim * paddim);
+            if (!isMd) {
+                std::vector<float> im;
+                ImageInfo ci;
+                readImage(fn_ctf, im, ci);
+                if ((int)ci.x != paddim) REPORT_ERROR(ERR_VALUE_INCORRECT, "Incompatible padding factor for this CTF filter");
+                for (size_t i = 0; i < Mctf.size(); ++i) Mctf[i] = im[i];
+            } else {
+                MetaDataVec md;
+                md.read(fn_ctf);
+                xh_ctf_params c;
+                xh_ctf_defaults(&c);
+                c.Tm = md.getDouble("ctfSamplingRate", 0, 1); c.kV = md.getDouble("ctfVoltage", 0, 100);
+                c.DeltafU = md.getDouble("ctfDefocusU", 0, 0); c.DeltafV = md.getDouble("ctfDefocusV", 0, c.DeltafU);
+                c.azimuthal_angle = md.getDouble("ctfDefocusAngle", 0, 0); c.Cs = md.getDouble("ctfSphericalAberration", 0, 0);
+                c.Ca = md.getDouble("ctfChromaticAberration", 0, 0); c.espr = md.getDouble("ctfEnergyLoss", 0, 0);
+                c.ispr = md.getDouble("ctfLensStability", 0, 0); c.alpha = md.getDouble("ctfConvergenceCone", 0, 0);
+                c.DeltaF = md.getDouble("ctfLongitudinalDisplacement", 0, 0); c.DeltaR = md.getDouble("ctfTransversalDisplacement", 0, 0);
+                c.Q0 = md.getDouble("ctfQ0", 0, 0); c.K = md.getDouble("ctfK", 0, 1);
+                if (std::fabs(c.DeltafV - c.DeltafU) > 1.) REPORT_ERROR(ERR_VALUE_INCORRECT, "ERROR!! Only non-astigmatic CTFs are allowed!");
+                const double iTs = 1.0 / c.Tm;
+                for (int i = 0; i < paddim; ++i) {
+                    const double fy = (double)(i <= paddim / 2 ? i : i - paddim) / paddim * iTs;
+                    for (int j = 0; j < paddim; ++j) {
+                        const double fx = (double)(j <= paddim / 2 ? j : j - paddim) / paddim * iTs;
+                        const double v = ctfValueAt(c, fx, fy);
+                        Mctf[(size_t)i * paddim + j] = phase_flipped ? std::fabs(v) : v;
+                    }
+                }
+            }
+        }
+        xhCheck(xh_pm_create(ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), Mctf.empty() ? nullptr : Mctf.data(), paddim, &pm));
         int32_t nn;
         xhCheck(xh_pm_info(pm, &nn, nullptr, nullptr));
         N = nn;
@@ -344,7 +420,9 @@ public:
         addParamsLine("  [--minCTF <ctf=0.01>]          : Minimum value of the CTF that will be inverted");
         addParamsLine("                                 : CTF values (in absolute value) below this one will not be corrected");
         addParamsLine("  [--bufferSize <size=25>]        : Number of projection loaded in memory (will be actually 2x as much.");
-        addParamsLine("  [--thr <threads=1>]            : Accepted for compatibility with xmipp_reconstruct_fourier; unused");
+        addParamsLine("  [--thr <threads=1> <rows=1>]   : Accepted for compatibility with xmipp_reconstruct_fourier (RF:50); unused");
+        addParamsLine("  [--iter <iterations=1>]        : xmipp_reconstruct_fourier weight-correction iterations (RF:44); only 1");
+        addParamsLine("  [--prepare_fsc <fscfile>]      : xmipp_reconstruct_fourier half-set files (RF:47); not available");
         addParamsLine("  [--device <id=0>]              : HIP device");
         addParamsLine("  [--batch <n=1024>]             : Projections per device batch");
         addExampleLine("   xmipp_reconstruct_fourier_accel  -i reconstruction.sel --sym c2 --weight");
@@ -371,6 +449,8 @@ public:
         bufferSize = (int)getIntParam("--bufferSize");
         device = (int)getIntParam("--device");
         batch = std::max(1, (int)getIntParam("--batch"));
+        if (getIntParam("--iter") != 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--iter > 1 (weight correction, RF:1056-1101) is not available on the device path");
+        if (checkParam("--prepare_fsc")) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--prepare_fsc (RF:991-1053) is not available yet");
     }
 
     void show()
