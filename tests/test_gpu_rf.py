@@ -93,8 +93,9 @@ def test_ctf_arrays(gpu, oracle):
 
 def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
-    if path == "tiles":
+    if path in ("tiles", "tiles_queue"):
         rf.set_option("tile_min_spaces", 1)       # output-stationary tile kernel even for one projection
+        rf.set_option("tile_variant", 1 if path == "tiles" else 0)   # LDS-staged patches | work-queue variant
     elif path == "scatter":
         rf.set_option("tile_min_spaces", 1 << 30)  # atomic scatter kernel
     o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
@@ -102,7 +103,7 @@ def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     return rf, o, ffts
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue"])
 def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
     """One projection into an empty volume: the same voxels and, summing taps in the same
     order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
@@ -134,13 +135,13 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue"])
 @pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
 def test_insert_many(gpu, oracle, data32, mode, path):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     fast = mode.startswith("fast")
-    if fast and path == "tiles":
+    if fast and path != "scatter":
         pytest.skip("--fast always uses the scatter kernel")
     rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=path, fast=fast)
     n = len(imgs)

@@ -113,8 +113,8 @@ struct xh_pm {
     int64_t stat_rows, stat_resc_p, stat_resc_r;
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
-    int use_idft3, use_mfma;
-    XhBuf d_qoff, d_Bpack, d_Apack;
+    int use_idft3, use_mfma, contract_dbg;
+    XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
 };
 
@@ -328,38 +328,59 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
     dst[gid] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// one wave = one 16x16 (particle x reference) tile, all frequencies; block = 4 waves = 4 reference tiles
+// one wave = PW x one 16x16 (particle x reference) tiles that share the reference operand (the reference
+// bank is the large, re-streamed operand: two particle tiles per wave halve its HBM/MALL re-reads);
+// block = 4 waves = 4 reference tiles
+#define XH_PW2 1
+#define XH_KSPLIT 4        // the frequency range is cut into slices of equal work: more waves in flight
 __global__ void __launch_bounds__(256)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
-                   const int *__restrict__ qoff, int nk, int totalQuads, int nparticles, int nq, int nqtiles)
+                   const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
+                   int nq, int nqtiles, int nptiles, int dbg)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qtile = blockIdx.x * 4 + wv, ptile = blockIdx.y;
+    const int qtile = blockIdx.x * 4 + wv, ptile0 = blockIdx.y * XH_PW2;
+    const int kBeg = kbounds[blockIdx.z], kEnd = kbounds[blockIdx.z + 1];
     if (qtile >= nqtiles) return;
-    const float4 *A = Apack + (size_t)ptile * totalQuads * 64 + lane;
+    const float4 *A[XH_PW2];
+#pragma unroll
+    for (int t = 0; t < XH_PW2; ++t) A[t] = Apack + (size_t)min(ptile0 + t, nptiles - 1) * totalQuads * 64 + lane;
     const float4 *B = Bpack + (size_t)qtile * totalQuads * 64 + lane;
     const int hi = lane >> 5, j = lane & 31;
     const int qj = j >> 1, odd = j & 1;
     const int q = qtile * 16 + qj;
-    for (int k0 = 0; k0 < nk; k0 += 4) {
-        xh_f32x16 acc[4];
+    const int lastQuad = qoff[nk] - 1;
+    for (int k0 = kBeg; k0 < kEnd; k0 += 4) {
+        xh_f32x16 acc[XH_PW2][4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[kk][e] = 0.f;
+            for (int t = 0; t < XH_PW2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][kk][e] = 0.f;
             const int k = k0 + kk;
-            if (k < nk) {
+            if (k < kEnd) {
                 const int qb = qoff[k], qe = qoff[k + 1];
                 // software pipeline: the next quad's operands are in flight while this quad's MFMAs issue
-                float4 a = A[(size_t)qb * 64], b = B[(size_t)qb * 64];
+                float4 a[XH_PW2], b = B[(size_t)qb * 64];
+#pragma unroll
+                for (int t = 0; t < XH_PW2; ++t) a[t] = A[t][(size_t)qb * 64];
                 for (int qd = qb; qd < qe; ++qd) {
-                    const int qn = qd + 1 < qoff[nk] ? qd + 1 : qd;    // runs into the next frequency's first quad
-                    const float4 an = A[(size_t)qn * 64], bn = B[(size_t)qn * 64];
-                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[kk], 0, 0, 0);
-                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[kk], 0, 0, 0);
-                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[kk], 0, 0, 0);
-                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[kk], 0, 0, 0);
-                    a = an;
+                    const int qn = qd < lastQuad ? qd + 1 : qd;
+                    float4 an[XH_PW2];
+                    const float4 bn = B[(size_t)qn * 64];
+#pragma unroll
+                    for (int t = 0; t < XH_PW2; ++t) an[t] = A[t][(size_t)qn * 64];
+#pragma unroll
+                    for (int t = 0; t < XH_PW2; ++t) {
+                        if (dbg == 2) { acc[t][kk][0] += a[t].x * b.x + a[t].w * b.w; continue; }
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t][kk], 0, 0, 0);
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t][kk], 0, 0, 0);
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t][kk], 0, 0, 0);
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t][kk], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < XH_PW2; ++t) a[t] = an[t];
                     b = bn;
                 }
             }
@@ -368,16 +389,17 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
         // even lane: (ac, bc); odd lane: (ad, bd) of the same reference. Exchange so that the even lane
         // owns frequencies k0, k0+1 and the odd lane k0+2, k0+3 of each (particle, reference) row.
 #pragma unroll
+        for (int t = 0; t < XH_PW2; ++t)
+#pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int r0 = 4 * g + 2 * h2;               // regs r0 (Re row), r0+1 (Im row)
                 const int pi = 4 * g + 2 * hi + h2;
-                const int p = blockIdx.y * 16 + pi;
-                float mine[4][2], theirs[4][2];
+                const int p = (ptile0 + t) * 16 + pi;
+                float mine[4][2], theirs[2][2];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { mine[kk][0] = acc[kk][r0]; mine[kk][1] = acc[kk][r0 + 1]; }
-                // send to the partner what it needs: even lane needs partner's kk=0,1; odd lane needs partner's kk=2,3
+                for (int kk = 0; kk < 4; ++kk) { mine[kk][0] = acc[t][kk][r0]; mine[kk][1] = acc[t][kk][r0 + 1]; }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float s0 = odd ? mine[0][c] : mine[2][c];
@@ -385,10 +407,9 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                     theirs[0][c] = __shfl_xor(s0, 1, 64);
                     theirs[1][c] = __shfl_xor(s1, 1, 64);
                 }
-                if (p < nparticles && q < nq) {
+                if (ptile0 + t < nptiles && p < nparticles && q < nq && (dbg != 1 || mine[0][0] == 1234.5f)) {
                     float4 *dst = raw + ((size_t)p * nq + q) * nk;
                     const int kA = k0 + (odd ? 2 : 0);
-                    // float4 = (ac, ad, bc, bd): even lane has (ac, bc) and receives (ad, bd); odd lane the converse
                     float4 o0, o1;
                     if (!odd) {
                         o0 = make_float4(mine[0][0], theirs[0][0], mine[0][1], theirs[0][1]);
@@ -397,8 +418,8 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                         o0 = make_float4(theirs[0][0], mine[2][0], theirs[0][1], mine[2][1]);
                         o1 = make_float4(theirs[1][0], mine[3][0], theirs[1][1], mine[3][1]);
                     }
-                    if (kA < nk) dst[kA] = o0;
-                    if (kA + 1 < nk) dst[kA + 1] = o1;
+                    if (kA < kEnd) dst[kA] = o0;
+                    if (kA + 1 < kEnd) dst[kA + 1] = o1;
                 }
             }
     }
@@ -1274,7 +1295,7 @@ template <typename T> static int upload(xh_ctx *ctx, XhBuf &b, const std::vector
 static void free_all(xh_pm *pm)
 {
     XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart,
-                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack,
+                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack, &pm->d_kbounds,
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
@@ -1332,6 +1353,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tau_rel = 3e-6;   // measured fp32 error of a normalised row: 1.6e-7*S (D=256), 1.8e-7*S (D=64)
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
+    pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
@@ -1525,6 +1547,18 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             for (int k = 0; k < L.nk; ++k) qoff[k + 1] = qoff[k] + (L.nrings - rstart[k] + 7) / 8;
             pm->totalQuads = qoff[L.nk];
             rc = upload(ctx, pm->d_qoff, qoff);
+            {
+                // frequency slices of equal MFMA work, boundaries on multiples of 4 (the store blocking)
+                std::vector<int> kb(XH_KSPLIT + 1, L.nk);
+                kb[0] = 0;
+                for (int sidx = 1; sidx < XH_KSPLIT; ++sidx) {
+                    const int target = (int)((long long)pm->totalQuads * sidx / XH_KSPLIT);
+                    int k = 0;
+                    while (k < L.nk && qoff[k] < target) ++k;
+                    kb[sidx] = std::min(L.nk, (k + 3) / 4 * 4);
+                }
+                if (rc == XH_OK) rc = upload(ctx, pm->d_kbounds, kb);
+            }
             const int ntiles = (nrefs + 15) / 16;
             const size_t nvec = (size_t)ntiles * pm->totalQuads * 64;
             if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_Bpack, nvec * sizeof(float4));
@@ -1568,6 +1602,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
+    else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1633,8 +1668,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                            (float4 *)pm->d_Apack.p, (const int *)pm->d_qoff.p, (const int *)pm->d_rstart.p, (const int *)pm->d_coff.p,
                            (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, ptiles), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
-                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, L.nk, pm->totalQuads, m, nq, qtiles);
+        hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, (ptiles + XH_PW2 - 1) / XH_PW2, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
+                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, (const int *)pm->d_kbounds.p, L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg);
     } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 
 #define XH_BLOB_TABLE 10000
 
@@ -219,6 +220,7 @@ struct xh_rf {
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
     XhBuf d_cull, d_pack;
     int tile_max_spaces;
+    int tile_variant;     // 1: LDS-staged patches (blob radius < 2); 0: queue kernel
     double meanFactor2;   // cached mean of sinc^2 over the output window (< 0: not computed yet)
     int ntiles;
     bool cropped;
@@ -864,6 +866,228 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     }
 }
 
+
+// ---- gridding, output-stationary, LDS-staged patches ---------------------------------------------
+// The queue kernel above is bound by the L1's tag-lookup rate: every lane gathers its own 4x4 footprint
+// (profiles/README.md: 26 L1 accesses per vector-memory instruction). Here a wave stages, per surviving
+// projection, the bounding 12x12 patch of its 4x4x4 sub-cube's footprint into LDS with coalesced row
+// loads (~10x fewer L1 accesses); every tap then comes from LDS. Lanes keep their voxel for the whole
+// tile, so accumulation is in registers, in projection order: no LDS atomics, deterministic, and a
+// single projection is bit-identical to processVoxelBlob (RFA:627-700). Blob radius < 2 only.
+#define XH_PW 12          // patch width/height in pixels
+template <bool HAS_CTF>
+__global__ void __launch_bounds__(512, 4)
+k_rf_insert_tiles_lds(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN,
+                      const float4 *__restrict__ cullX, int nspaces, const void *__restrict__ pk,
+                      const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
+                      int mv, float iDeltaSqrt, double blobRadius, const unsigned *__restrict__ tileList,
+                      const int *__restrict__ classOff, int *__restrict__ counter)
+{
+    typedef typename std::conditional<HAS_CTF, float4, float2>::type Pix;
+    __shared__ float sBlob[XH_BLOB_TABLE];
+    __shared__ XhHitRec sRec[XH_CHUNK];
+    __shared__ int sHit[XH_CHUNK];
+    __shared__ int sWaveCnt[8];
+    __shared__ int sGrab[2];
+    __shared__ Pix sPatch[8][XH_PW * XH_PW];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < XH_BLOB_TABLE; i += 512) sBlob[i] = blobTable[i];
+    __syncthreads();
+    const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
+    const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+    const float fr = (float)blobRadius;
+    const float maxDistanceSqr = (sizeX + blobRadius) * (sizeX + blobRadius);
+    const float radiusSqr = blobRadius * blobRadius;
+    const float rho8 = 6.1f, rho4 = 2.65f;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ox = (wv & 1) * 4, oy = ((wv >> 1) & 1) * 4, oz = (wv >> 2) * 4;
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    Pix *patch = sPatch[wv];
+    const Pix *pkp = reinterpret_cast<const Pix *>(pk);
+
+    int cls = blockIdx.x & 7, tried = 0;
+    int pend = 0;
+    if (tid == 0) pend = atomicAdd(&counter[cls], XH_GRAB);
+    for (;;) {
+      if (tid == 0) {
+        int lo = 0, hiT = 0;
+        while (tried < 8) {
+            const int n = classOff[cls + 1] - classOff[cls];
+            if (pend < n) { lo = classOff[cls] + pend; hiT = classOff[cls] + min(pend + XH_GRAB, n); break; }
+            cls = (cls + 1) & 7;
+            if (++tried < 8) pend = atomicAdd(&counter[cls], XH_GRAB);
+        }
+        sGrab[0] = lo; sGrab[1] = hiT;
+        if (tried < 8) pend = atomicAdd(&counter[cls], XH_GRAB);
+      }
+      __syncthreads();
+      const int tBeg = sGrab[0], tEnd = sGrab[1];
+      if (tBeg >= tEnd) break;
+      for (int ti = tBeg; ti < tEnd; ++ti) {
+        const unsigned packed = tileList[ti];
+        const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
+        const int x0 = tx * XH_TSZ + ox, y0 = ty * XH_TSZ + oy, z0 = tz * XH_TSZ + oz;
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        const bool inVol = (x <= mv) && (y <= mv) && (z <= mv);
+        const float cx = tx * XH_TSZ + 3.5f - mv / 2, cy = ty * XH_TSZ + 3.5f - mv / 2, cz = tz * XH_TSZ + 3.5f - mv / 2;
+        const float c4x = x0 + 1.5f - mv / 2, c4y = y0 + 1.5f - mv / 2, c4z = z0 + 1.5f - mv / 2;
+        const float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
+        const bool inSphere = inVol && !((px * px + py * py + pz * pz) > maxDistanceSqr);
+        float accW = 0.f, accR = 0.f, accI = 0.f;
+        for (int s0 = 0; s0 < nspaces; s0 += XH_CHUNK) {
+            // ---- block level: cull XH_CHUNK projections against the tile, ordered compaction
+            const int s = s0 + tid;
+            bool hit = false;
+            if (tid < XH_CHUNK && s < nspaces) {
+                const float4 n = cullN[s], r0 = cullX[s];
+                const float dn = n.x * cx + n.y * cy + n.z * cz;
+                const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
+                hit = (fabsf(dn) <= fr + rho8) && (dx >= -(fr + rho8)) && (dx <= sizeX + fr + rho8);
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) sWaveCnt[wv] = __popcll(bal);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < XH_CHUNK / 64; ++w) { const int c = sWaveCnt[w]; if (w < wv) base += c; total += c; }
+            if (hit) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const XhSpace &S = spaces[s];
+                sHit[pos] = s;
+                XhHitRec r;
+                r.r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], __int_as_float(S.img));
+                r.r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], __int_as_float(S.minY | (S.maxY << 16)));
+                r.r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], __int_as_float(S.minZ | (S.maxZ << 16)));
+                sRec[pos] = r;
+            }
+            __syncthreads();
+            // ---- wave level: lanes cull up to 64 survivors at a time against the 4^3 sub-cube
+            for (int h0 = 0; h0 < total; h0 += 64) {
+                bool sub = false;
+                if (h0 + lane < total) {
+                    const float4 r2 = sRec[h0 + lane].r2, r0 = sRec[h0 + lane].r0;
+                    const float dn = r2.x * c4x + r2.y * c4y + r2.z * c4z;
+                    const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
+                    sub = (fabsf(dn) <= fr + rho4) && (dx >= -(fr + rho4)) && (dx <= sizeX + fr + rho4);
+                }
+                unsigned long long todo = __ballot(sub);
+                while (todo) {
+                    const int h = h0 + __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const float4 r0 = sRec[h].r0, r1 = sRec[h].r1, r2 = sRec[h].r2;
+                    const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
+                    bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
+                    float ix = 0.f, iy = 0.f, zSqr = 0.f;
+                    if (pass) {
+                        ix = r0.x * px + r0.y * py + r0.z * pz;
+                        iy = r1.x * px + r1.y * py + r1.z * pz;
+                        const float iz = r2.x * px + r2.y * py + r2.z * pz;
+                        iy += mv / 2;
+                        zSqr = iz * iz;
+                        pass = !(zSqr > radiusSqr);
+                        pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
+                               ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+                    }
+                    if (!__any(pass)) continue;
+                    // ---- stage the 12x12 patch that contains every candidate pixel of the sub-cube
+                    const float a0 = fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z), a1 = fabsf(r1.x) + fabsf(r1.y) + fabsf(r1.z);
+                    const float cix = r0.x * c4x + r0.y * c4y + r0.z * c4z;
+                    const float ciy = r1.x * c4x + r1.y * c4y + r1.z * c4z + mv / 2;
+                    const int bx0 = (int)floorf(cix - 1.5f * a0 - fr) - 1, by0 = (int)floorf(ciy - 1.5f * a1 - fr) - 1;
+                    const size_t imgOff = (size_t)__float_as_int(r0.w) * SX * SY;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int c = lane + 64 * t;
+                        if (c < XH_PW * XH_PW) {
+                            const int qy = c / XH_PW, qx = c - qy * XH_PW;
+                            const int j = bx0 + qx + XH_PAD, i = by0 + qy + XH_PAD;
+                            Pix v;
+                            memset(&v, 0, sizeof(v));
+                            if (j >= 0 && j < SX && i >= 0 && i < SY) v = pkp[imgOff + (size_t)i * SX + j];
+                            patch[c] = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (pass) {
+                        const int si = sHit[h];
+                        const XhSpace &S = spaces[si];
+                        float xa, xb;
+                        const bool hit1 = d_getX(xa, (float)y, (float)z, S.u, S.v, S.p0);
+                        const bool hit2 = d_getX(xb, (float)y, (float)z, S.u, S.v, S.p4);
+                        if (hit1 || hit2) {
+                            int minX = (int)ceil((double)ix - blobRadius);
+                            int maxX = (int)floor((double)ix + blobRadius);
+                            int minY = (int)ceil((double)iy - blobRadius);
+                            int maxY = (int)floor((double)iy + blobRadius);
+                            const int bY = minY, bX = minX;
+                            minX = max(minX, 0);
+                            minY = max(minY, 0);
+                            maxX = min(maxX, sizeX - 1);
+                            maxY = min(maxY, sizeY - 1);
+                            const float dataWeight = S.weight;
+                            float yz[4], xs[4];
+                            bool rv[4], cv[4];
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) {
+                                const int i = bY + a;
+                                const float ySqr = (iy - i) * (iy - i);
+                                yz[a] = ySqr + zSqr;
+                                rv[a] = (i >= minY) && (i <= maxY) && !(yz[a] > radiusSqr);
+                            }
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int j = bX + b;
+                                const float xD = ix - j;
+                                xs[b] = xD * xD;
+                                cv[b] = (j >= minX) && (j <= maxX);
+                            }
+                            const Pix *pp = patch + (bY - by0) * XH_PW + (bX - bx0);
+                            float vW = 0.f, vR = 0.f, vI = 0.f;
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const Pix q = pp[a * XH_PW + b];
+                                    const float distanceSqr = xs[b] + yz[a];
+                                    const bool use = rv[a] && cv[b] && !(distanceSqr > radiusSqr);
+                                    const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
+                                    const float wBlob = use ? sBlob[aux] : 0.f;
+                                    if constexpr (HAS_CTF) {
+                                        const float weight = wBlob * q.w * dataWeight;
+                                        vW += weight;
+                                        vR += q.x * weight * q.z;
+                                        vI += q.y * weight * q.z;
+                                    } else {
+                                        const float weight = wBlob * dataWeight;
+                                        vW += weight;
+                                        vR += q.x * weight;
+                                        vI += q.y * weight;
+                                    }
+                                }
+                            accW += vW;
+                            accR += vR;
+                            accI += vI;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+        }
+        if (inSphere && (accW != 0.f || accR != 0.f || accI != 0.f)) {
+            const size_t vi = ((size_t)z * dim + y) * dim + x;
+            float2 *V = reinterpret_cast<float2 *>(tempV) + vi;
+            float2 v = *V;
+            v.x += accR;
+            v.y += accI;
+            *V = v;
+            tempW[vi] += accW;
+        }
+      }
+      __syncthreads();
+    }
+}
+
 // ---- finaliser ---------------------------------------------------------------------------
 // mirrorAndCrop RFA:861-887 in gather form. in: (mv+1)^3, out: (mv+1)^2 (half+1)
 __global__ void k_rf_mirror(const xh_cf *__restrict__ inV, const float *__restrict__ inW,
@@ -1143,6 +1367,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->tile_min_spaces = 24;
     rf->tile_dbg = 0;
     rf->tile_max_spaces = 8192;
+    rf->tile_variant = 0;   // the LDS-staged variant measured slower (profiles/README.md)
     rf->meanFactor2 = -1;
     int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
     if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
@@ -1205,6 +1430,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "tile_min_spaces")) rf->tile_min_spaces = (int)value;
     else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
+    else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
     else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1447,7 +1673,19 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                        (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,                        \
                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
                        (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p, rf->tile_dbg)
-            if (hasCtf && smallBlob) XH_TILES(true, true);
+            if (smallBlob && rf->tile_variant == 1) {
+                if (hasCtf)
+                    hipLaunchKernelGGL((k_rf_insert_tiles_lds<true>), dim3(grid), dim3(512), 0, ctx->stream, (const XhSpace *)rf->d_spaces.p + s0,
+                                       (const float4 *)rf->d_cull.p + s0, (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,
+                                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
+                                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
+                else
+                    hipLaunchKernelGGL((k_rf_insert_tiles_lds<false>), dim3(grid), dim3(512), 0, ctx->stream, (const XhSpace *)rf->d_spaces.p + s0,
+                                       (const float4 *)rf->d_cull.p + s0, (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,
+                                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
+                                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
+            }
+            else if (hasCtf && smallBlob) XH_TILES(true, true);
             else if (hasCtf) XH_TILES(true, false);
             else if (smallBlob) XH_TILES(false, true);
             else XH_TILES(false, false);
