@@ -182,6 +182,20 @@ int xh_pm_info(const xh_pm *pm, int32_t *nsam_outer /*N*/, int32_t *ncoef, int32
 int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off,
                 const int32_t *h_nbr_ids, int32_t first_image_parity, int32_t *d_refno,
                 int32_t *d_psi_idx, uint8_t *d_flip);
+/* The general search of threadRotationallyAlignOneImage (APM:530-760), replacing its
+ * `--search5d_shift/--search5d_step` and `--number_orientations` loops:
+ *  ntrans > 0: 5-D search -- every particle is also resampled about (xoff5d[t], yoff5d[t])
+ *    (the list built at APM:334-348) and every (reference, translation) pair is a row of the
+ *    search; as in the reference only (refno, psi, flip) of the winner are kept (the shift is
+ *    re-estimated by xh_pm_translate). ntrans == 0 is the single translation (0,0).
+ *  n_orient > 1: the reference's running top-N (APM:714-735) evaluated exactly (all rows in
+ *    fp64); outputs are [n][n_orient], rank-major per particle, refno = -1 for ranks that were
+ *    never filled (counterValidCorrs, APM:1068-1090). n_orient <= 16.
+ * xh_pm_match(...) == xh_pm_match_ex(..., 1, 0, NULL, NULL, ...). */
+int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off,
+                   const int32_t *h_nbr_ids, int32_t first_image_parity, int32_t n_orient,
+                   int32_t ntrans, const int32_t *h_xoff5d, const int32_t *h_yoff5d,
+                   int32_t *d_refno, int32_t *d_psi_idx, uint8_t *d_flip);
 /* Translational step for the winners (APM:776-868): bestShift on correlation_matrix(rotated
  * reference, (mirrored) particle), rejection beyond max_shift (<0 => D/2), translate+
  * correlationIndex => maxCC. fp64 on the device. Outputs device double [n]. */

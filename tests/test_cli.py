@@ -123,3 +123,36 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle):
     rf.mirror_and_crop()
     exp = rf.finish()
     assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()
+
+
+@pytest.mark.gpu
+def test_cli_5d_search_and_number_orientations(bins, tmp_path, oracle):
+    """`--search5d_shift 2 --search5d_step 2 --number_orientations 3`: rows per image are the
+    valid ranks of the reference's running top-N, each with its own translational alignment."""
+    import xmipp3_amd as xa
+    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path)
+    n, nrefs = len(parts), len(refs)
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
+              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4", "--search5d_shift", "2", "--search5d_step", "2",
+              "--number_orientations", "3"])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"))
+    c = {l: i for i, l in enumerate(labels)}
+    pos = {ids[i]: i for i in range(nrefs)}
+    lists = [[pos[int(v)] for v in s.split()] for s in nbrs]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    xo, yo = xa.search5d_offsets(2, 2)
+    assert len(xo) == 5
+    pm = oracle.PM(refs)
+    er, ep, ef, _ = pm.match(parts, off, np.concatenate(lists).astype(np.int32), n_orient=3, xoff5d=xo, yoff5d=yo)
+    assert (er >= 0).all() and len(rows) == 3 * n
+    for i in range(n):
+        for o in range(3):
+            row = rows[3 * i + o]
+            ex, ey, ec = pm.translate(parts[i:i + 1], er[i:i + 1, o], ep[i:i + 1, o], ef[i:i + 1, o], 6.0)
+            assert int(row[c["itemId"]]) == 100 + i
+            assert int(row[c["ref"]]) == ids[er[i, o]] and int(row[c["flip"]]) == ef[i, o]
+            assert abs(float(row[c["anglePsi"]]) - ep[i, o] * 360.0 / pm.N) < 1e-5
+            assert abs(float(row[c["shiftX"]]) - ex[0]) < 1e-3 and abs(float(row[c["shiftY"]]) - ey[0]) < 1e-3
+            assert abs(float(row[c["maxCC"]]) - ec[0]) < 1e-5

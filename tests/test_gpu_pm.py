@@ -141,6 +141,79 @@ def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     assert pm.last_stats()["rescored_particles"] == 6
 
 
+@pytest.mark.parametrize("mode", ["dense", "lists"])
+def test_5d_search_indices_bit_identical(gpu, oracle, lib64, mode):
+    """--search5d_shift 3 --search5d_step 2 (APM:321-348,575-589,676): 9 extra polar transforms per
+    particle, every (reference, translation) pair competes; only (refno, psi, flip) are kept."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    xo, yo = xa.search5d_offsets(3, 2)
+    assert len(xo) == 9 and (xo[4], yo[4]) == (0, 0)
+    n = 21
+    off = ids = None
+    if mode == "lists":
+        rng = np.random.default_rng(5)
+        lists = [rng.choice(len(refs), size=int(rng.integers(1, 9)), replace=False) for _ in range(n)]
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(l) for l in lists])
+        ids = np.concatenate(lists).astype(np.int32)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    if mode == "lists":
+        pm.set_option("chunk_rows", 300)
+    o = oracle.PM(refs)
+    refno, psi, flip = pm.match(torch.from_numpy(parts[:n]).cuda(), off, ids, parity=1, shifts5d=(xo, yo))
+    er, ep, ef, _ = o.match(parts[:n], off, ids, parity=1, xoff5d=xo, yoff5d=yo)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    # the search is not a no-op: some particles pick a different orientation than without it
+    r0, p0, f0, _ = o.match(parts[:n], off, ids, parity=1)
+    print("particles whose winner changed with the 5-D search:", int((r0[:, 0] != er[:, 0]).sum() + (p0[:, 0] != ep[:, 0]).sum()))
+    assert pm.last_stats()["rows"] == (n * len(refs) * 9 if mode == "dense" else int(off[-1]) * 9)
+
+
+@pytest.mark.parametrize("n_orient,shifts", [(3, None), (5, (1, 1))])
+def test_number_orientations_running_top_n(gpu, oracle, lib64, n_orient, shifts):
+    """--number_orientations > 1 reproduces the reference's running top-N (APM:714-735), including
+    its quirks (ranks are not shifted down; rank n only accepts values below rank n-1)."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    n = 12
+    sh = xa.search5d_offsets(*shifts) if shifts else None
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    for parity in (0, 1):
+        refno, psi, flip = pm.match(torch.from_numpy(parts[:n]).cuda(), parity=parity, n_orient=n_orient, shifts5d=sh)
+        kw = dict(xoff5d=sh[0], yoff5d=sh[1]) if sh else {}
+        er, ep, ef, _ = o.match(parts[:n], parity=parity, n_orient=n_orient, **kw)
+        assert refno.shape == (n, n_orient)
+        assert np.array_equal(refno.cpu().numpy(), er)
+        valid = er >= 0
+        assert np.array_equal(psi.cpu().numpy()[valid], ep[valid])
+        assert np.array_equal(flip.cpu().numpy()[valid], ef[valid])
+        assert valid[:, 0].all()
+
+
+def test_number_orientations_with_short_lists(gpu, oracle, lib64):
+    """fewer candidates than ranks / empty lists leave refno = -1 (counterValidCorrs, APM:1068-1090)."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    n = 5
+    lists = [[7], [], [3, 9], [1, 2, 3], [40]]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate([np.asarray(l, np.int32) for l in lists]).astype(np.int32)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    refno, psi, flip = pm.match(torch.from_numpy(parts[:n]).cuda(), off, ids, n_orient=4)
+    er, ep, ef, _ = o.match(parts[:n], off, ids, n_orient=4)
+    assert np.array_equal(refno.cpu().numpy(), er)
+    assert (refno[1] == -1).all()
+    valid = er >= 0
+    assert np.array_equal(psi.cpu().numpy()[valid], ep[valid])
+    assert np.array_equal(flip.cpu().numpy()[valid], ef[valid])
+
+
 def test_translational_alignment(gpu, oracle, lib64):
     xa, ctx, torch = gpu
     D, refs, parts, truth = lib64

@@ -17,6 +17,20 @@ def _torch():
     return torch
 
 
+def search5d_offsets(search5d_shift, search5d_step=2):
+    """Translations of the 5-D search in the reference's order (APM:321-348)."""
+    if search5d_step == 0:
+        search5d_step = 1
+    fin = search5d_shift + search5d_shift % search5d_step
+    xs, ys = [], []
+    for x in range(-fin, fin + 1, search5d_step):
+        for y in range(-fin, fin + 1, search5d_step):
+            if x * x + y * y <= search5d_shift * search5d_shift:
+                xs.append(x)
+                ys.append(y)
+    return np.asarray(xs, np.int32), np.asarray(ys, np.int32)
+
+
 def shard_range(n, rank, world):
     """Contiguous particle range of `rank` ([g*N/G, (g+1)*N/G))."""
     return (rank * n) // world, ((rank + 1) * n) // world
@@ -271,20 +285,29 @@ class ProjectionMatcher:
     def set_option(self, name, value):
         check(lib().xh_pm_set_option(self.h, name.encode(), float(value)))
 
-    def match(self, particles, nbr_off=None, nbr_ids=None, parity=0):
+    def match(self, particles, nbr_off=None, nbr_ids=None, parity=0, n_orient=1, shifts5d=None):
+        """Rotational search (APM:530-760). shifts5d: (xoff[], yoff[]) integer 5-D search translations
+        (`search5d_offsets`); n_orient > 1 returns [n, n_orient] arrays (refno -1 = rank not filled)."""
         torch = _torch()
         assert particles.is_cuda and particles.dtype == torch.float32 and particles.is_contiguous()
         n = particles.shape[0]
         dev = particles.device
-        refno = torch.empty(n, dtype=torch.int32, device=dev)
-        psi = torch.empty(n, dtype=torch.int32, device=dev)
-        flip = torch.empty(n, dtype=torch.uint8, device=dev)
-        off = ids = None
+        shape = (n,) if n_orient == 1 else (n, n_orient)
+        refno = torch.empty(shape, dtype=torch.int32, device=dev)
+        psi = torch.empty(shape, dtype=torch.int32, device=dev)
+        flip = torch.empty(shape, dtype=torch.uint8, device=dev)
+        off = ids = xo = yo = None
+        nt = 0
         if nbr_off is not None:
             off = np.ascontiguousarray(nbr_off, np.int32)
             ids = np.ascontiguousarray(nbr_ids, np.int32)
-        check(lib().xh_pm_match(self.h, _ptr(particles), n, _np_ptr(off), _np_ptr(ids), int(parity), _ptr(refno),
-                                _ptr(psi), _ptr(flip)))
+        if shifts5d is not None:
+            xo = np.ascontiguousarray(shifts5d[0], np.int32)
+            yo = np.ascontiguousarray(shifts5d[1], np.int32)
+            nt = len(xo)
+            assert len(yo) == nt and nt > 0
+        check(lib().xh_pm_match_ex(self.h, _ptr(particles), n, _np_ptr(off), _np_ptr(ids), int(parity), int(n_orient), nt,
+                                   _np_ptr(xo), _np_ptr(yo), _ptr(refno), _ptr(psi), _ptr(flip)))
         return refno, psi, flip
 
     def translate(self, particles, refno, psi, flip, max_shift=-1.0):

@@ -108,7 +108,7 @@ struct xh_pm {
     XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
     XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
-    XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters;
+    XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters, d_offs5d;
     XhBuf d_t1, d_t2, d_t3;      // S6 scratch
     int64_t stat_rows, stat_resc_p, stat_resc_r;
     hipEvent_t ev[6];
@@ -139,12 +139,14 @@ __global__ void __launch_bounds__(256)
 k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restrict__ stat,
            const float *__restrict__ sinr, const float *__restrict__ cosr, const short *__restrict__ ringOf,
            const int *__restrict__ nsam, int D, int Ri, int nsamples, double xoff, double yoff,
-           const int *__restrict__ count)
+           const int *__restrict__ count, int nt, const double *__restrict__ offs)
 {
     __shared__ double red[8];
     const int slot = blockIdx.x;
-    if (count && slot >= *count) return;
-    const T *c = coefs + (size_t)slot * D * D;
+    // 5-D search (APM:575-589): slot = image*nt + itrans, every translation resamples the same coefficients
+    if (count && slot / nt >= *count) return;
+    const T *c = coefs + (size_t)(slot / nt) * D * D;
+    if (offs) { xoff = offs[2 * (slot % nt)]; yoff = offs[2 * (slot % nt) + 1]; }
     const T minp = (T)(-(D / 2)), maxp = (T)(-(D / 2) + D - 1);
     const T eps = (T)1e-6;
     double sw = 0, swv = 0, swv2 = 0;
@@ -177,11 +179,11 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2<T> *__restrict__ out,
              const xh_c2<T> *__restrict__ tw, const int *__restrict__ nsam, const int *__restrict__ soff,
-             const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, const int *__restrict__ count)
+             const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, const int *__restrict__ count, int nt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int r = blockIdx.x, slot = blockIdx.y;
-    if (count && slot >= *count) return;
+    if (count && slot / nt >= *count) return;
     const int n = nsam[r];
     T *x = reinterpret_cast<T *>(smem);
     xh_c2<T> *w = reinterpret_cast<xh_c2<T> *>(smem + sizeof(T) * ((n + 3) & ~3));
@@ -768,32 +770,39 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
 }
 
 // =========================================================================== S4
+// Row bookkeeping shared by S4/S5. A "slot" is one polar transform of a particle: slot = p*nt + itrans
+// (nt = number of 5-D search translations, APM:330-352; 1 without the 5-D search). Rows of a slot are
+// contiguous, poff[slot]..poff[slot+1]; the rows of a particle are therefore contiguous too.
+// dense (nq > 0): every slot is compared with references 0..nq-1; otherwise rowSlot/refIds give the
+// slot and the reference of every row (neighbour lists, APM:609-626).
+struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; };
+__device__ __forceinline__ int d_row_slot(const RowMap &M, int row) { return M.rowSlot ? M.rowSlot[row] : row / M.nq; }
+__device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { return M.refIds ? M.refIds[row] : row - slot * M.nq; }
+
 // one block per particle: winner over its rows, ambiguity test, candidate rows for fp64.
-// poff[p], poff[p+1]: row range (chunk-local); refOfRow via refIds (CSR) or row - poff[p] (dense)
 __global__ void __launch_bounds__(256)
-k_pm_select(const RowRes *__restrict__ res, const int *__restrict__ poff, const int *__restrict__ refIds,
-            const double *__restrict__ refSigma, const double *__restrict__ stat32, int pBase,
-            int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip, int N,
-            float tauAbs, int *__restrict__ counters, int *__restrict__ ambList, int *__restrict__ ambSlotOfP,
-            int *__restrict__ candRow)
+k_pm_select(const RowRes *__restrict__ res, RowMap M, const double *__restrict__ refSigma,
+            const double *__restrict__ stat32, int pBase, int *__restrict__ refno, int *__restrict__ psi,
+            unsigned char *__restrict__ flip, int N, float tauAbs, int *__restrict__ counters,
+            int *__restrict__ ambList, int *__restrict__ ambSlotOfP, int *__restrict__ candRow)
 {
     __shared__ float sb[256], ss[256];
     __shared__ int sr[256];
     const int p = blockIdx.x;
-    const int r0 = poff[p], r1 = poff[p + 1];
+    const int r0 = M.poff[p * M.nt], r1 = M.poff[(p + 1) * M.nt];
     const int gp = pBase + p;
     if (r1 <= r0) {
         if (threadIdx.x == 0) { refno[gp] = -1; psi[gp] = 0; flip[gp] = 0; ambSlotOfP[p] = -1; }
         return;
     }
-    const float sigImg = (float)stat32[2 * p + 1];
     // per-thread: best normalised row value, its row, and the runner-up value seen
     float b = -3.0e38f, sec = -3.0e38f;
     int br = 0x7fffffff;
     for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const RowRes rr = res[r];
-        const int ref = refIds ? refIds[r] : (r - r0);
-        const float den = (float)refSigma[ref] * sigImg;
+        const int slot = d_row_slot(M, r);
+        const int ref = d_row_ref(M, r, slot);
+        const float den = (float)refSigma[ref] * (float)stat32[2 * slot + 1];
         const float v1 = rr.best / den, v2 = rr.second / den;
         if (v1 > b || (v1 == b && r < br)) { sec = fmaxf(fmaxf(b, sec), v2); b = v1; br = r; }
         else sec = fmaxf(sec, v1);     // v2 <= v1 so v1 bounds this row
@@ -817,7 +826,7 @@ k_pm_select(const RowRes *__restrict__ res, const int *__restrict__ poff, const 
     __shared__ int sAmb;
     if (threadIdx.x == 0) {
         const RowRes rr = res[wrow];
-        refno[gp] = refIds ? refIds[wrow] : (wrow - r0);
+        refno[gp] = d_row_ref(M, wrow, d_row_slot(M, wrow));
         psi[gp] = rr.idx % N;
         flip[gp] = rr.idx >= N ? 1 : 0;
         // NaN-safe: anything that is not clearly separated is re-scored
@@ -834,8 +843,9 @@ k_pm_select(const RowRes *__restrict__ res, const int *__restrict__ poff, const 
         const float thr = G - tauAbs;
         for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
             const RowRes rr = res[r];
-            const int ref = refIds ? refIds[r] : (r - r0);
-            const float den = (float)refSigma[ref] * sigImg;
+            const int slot = d_row_slot(M, r);
+            const int ref = d_row_ref(M, r, slot);
+            const float den = (float)refSigma[ref] * (float)stat32[2 * slot + 1];
             if (!(rr.best / den < thr)) candRow[atomicAdd(&counters[1], 1)] = r;
         }
     }
@@ -844,26 +854,30 @@ k_pm_select(const RowRes *__restrict__ res, const int *__restrict__ poff, const 
 // =========================================================================== S5
 struct CandRes { double val; int idx; int row; };
 
-// fp64 correlation row (straight || mirror) of one candidate; block per candidate row
+// fp64 correlation row (straight || mirror) of one candidate; block per candidate row. Writes the K
+// largest DISTINCT values of the row in descending order, each with the first index that attains it
+// (K = 1: the row maximum under the reference's strict ">" scan, APM:718-721; K > 1 feeds the running
+// top-N of APM:714-735). candRow == null: every row is a candidate; ambSlotOfP == null: fp64 slot a = p.
 __global__ void __launch_bounds__(256)
-k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candRow, const int *__restrict__ rowP,
-                 const int *__restrict__ poff, const int *__restrict__ refIds, const int *__restrict__ ambSlotOfP,
-                 const xh_cd *__restrict__ A64, const xh_cd *__restrict__ refs64, const double *__restrict__ refSigma,
-                 const double *__restrict__ stat64, const xh_cd *__restrict__ csN, const int *__restrict__ nsamv,
-                 const int *__restrict__ coff, int nrings, int Ri, int ncoef, int N, int nk,
-                 CandRes *__restrict__ out, double *__restrict__ dbgRow, int denseNq)
+k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candRow, RowMap M,
+                 const int *__restrict__ ambSlotOfP, const xh_cd *__restrict__ A64, const xh_cd *__restrict__ refs64,
+                 const double *__restrict__ refSigma, const double *__restrict__ stat64, const xh_cd *__restrict__ csN,
+                 const int *__restrict__ nsamv, const int *__restrict__ coff, int nrings, int Ri, int ncoef, int N, int nk,
+                 CandRes *__restrict__ out, double *__restrict__ dbgRow, int K, double eps)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cd *Fs = reinterpret_cast<xh_cd *>(smem);
     xh_cd *Fm = Fs + nk;
     xh_cd *cs = Fm + nk;   // N entries
+    double *vals = reinterpret_cast<double *>(cs + N);   // 2N entries, only with K > 1
     const int c = blockIdx.x;
     if (c >= counters[1]) return;
-    const int row = candRow[c];
-    const int p = rowP ? rowP[row] : row / denseNq;
-    const int ref = refIds ? refIds[row] : (row - poff[p]);
-    const int slot = ambSlotOfP[p];
-    const xh_cd *a = A64 + (size_t)slot * ncoef;
+    const int row = candRow ? candRow[c] : c;
+    const int slot = d_row_slot(M, row);
+    const int p = slot / M.nt, it = slot - p * M.nt;
+    const int ref = d_row_ref(M, row, slot);
+    const int s64 = (ambSlotOfP ? ambSlotOfP[p] : p) * M.nt + it;
+    const xh_cd *a = A64 + (size_t)s64 * ncoef;
     const xh_cd *b = refs64 + (size_t)ref * ncoef;
     for (int i = threadIdx.x; i < N; i += blockDim.x) cs[i] = csN[i];
     // Fsum (polar.cpp:122-135), ring order ascending, straight and mirrored particle
@@ -883,7 +897,7 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
         Fm[k] = xh_cd{mr, mi};
     }
     __syncthreads();
-    const double den = refSigma[ref] * stat64[2 * slot + 1];
+    const double den = refSigma[ref] * stat64[2 * s64 + 1];
     double best = -1.0e300;
     int bi = 0x7fffffff;
     const int half = N / 2;
@@ -901,54 +915,117 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
         acc += 2.0 * t;
         const double v = acc / den;
         if (dbgRow) dbgRow[i] = v;
+        if (K > 1) vals[i] = v;
         if (v > best || (v == best && i < bi)) { best = v; bi = i; }
     }
     __shared__ double sbv[256];
     __shared__ int sbi[256];
-    sbv[threadIdx.x] = best; sbi[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const double ov = sbv[threadIdx.x + o];
-            const int oi = sbi[threadIdx.x + o];
-            if (ov > sbv[threadIdx.x] || (ov == sbv[threadIdx.x] && oi < sbi[threadIdx.x])) { sbv[threadIdx.x] = ov; sbi[threadIdx.x] = oi; }
-        }
+    for (int j = 0;; ++j) {
+        sbv[threadIdx.x] = best; sbi[threadIdx.x] = bi;
         __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                const double ov = sbv[threadIdx.x + o];
+                const int oi = sbi[threadIdx.x + o];
+                if (ov > sbv[threadIdx.x] || (ov == sbv[threadIdx.x] && oi < sbi[threadIdx.x])) { sbv[threadIdx.x] = ov; sbi[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        const double top = sbv[0];
+        const int topi = sbi[0];
+        __syncthreads();
+        if (threadIdx.x == 0) { CandRes r; r.val = top; r.idx = topi == 0x7fffffff ? -1 : topi; r.row = row; out[(size_t)c * K + j] = r; }
+        if (j + 1 >= K) break;
+        // next distinct value: the largest one below the value just written
+        best = -1.0e300; bi = 0x7fffffff;
+        if (topi != 0x7fffffff)
+            for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) {
+                const double v = vals[i];
+                if (v < top - eps && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+            }
     }
-    if (threadIdx.x == 0) { CandRes r; r.val = sbv[0]; r.idx = sbi[0]; r.row = row; out[c] = r; }
 }
 
 // exact pick for each ambiguous particle: the reference visits references forward for even images
-// and backward for odd ones and replaces the incumbent only on a strictly greater value
-// (APM:609-626,715-735,1112) => among (near-)equal maxima the earliest visited row wins.
+// and backward for odd ones, the 5-D translations innermost in ascending order, and replaces the
+// incumbent only on a strictly greater value (APM:609-626,676,715-735,1112) => among (near-)equal
+// maxima the earliest visited row wins.
+__device__ __forceinline__ int d_visit_order(const RowMap &M, int row, bool forward)
+{
+    const int slot = d_row_slot(M, row);
+    const int j = row - M.poff[slot], nn = M.poff[slot + 1] - M.poff[slot];
+    return (forward ? j : nn - 1 - j) * M.nt + slot % M.nt;
+}
 __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restrict__ ambList,
-                          const CandRes *__restrict__ cand, const int *__restrict__ rowP, const int *__restrict__ poff,
-                          const int *__restrict__ refIds, int pBase, int parity, int N, double tieAbs,
-                          int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip, int denseNq)
+                          const CandRes *__restrict__ cand, RowMap M, int pBase, int parity, int N, double tieAbs,
+                          int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= counters[0]) return;
     const int p = ambList[a];
     const int nc = counters[1];
     const bool forward = (((pBase + p + parity) & 1) == 0);
-    const int r0 = poff[p], r1 = poff[p + 1];
     double best = -1.0e300;
     for (int c = 0; c < nc; ++c)
-        if ((rowP ? rowP[cand[c].row] : cand[c].row / denseNq) == p && cand[c].val > best) best = cand[c].val;
+        if (d_row_slot(M, cand[c].row) / M.nt == p && cand[c].val > best) best = cand[c].val;
     int bestRow = -1, bestIdx = 0, bestOrder = 0x7fffffff;
     for (int c = 0; c < nc; ++c) {
         const int row = cand[c].row;
-        if ((rowP ? rowP[row] : row / denseNq) != p) continue;
+        if (d_row_slot(M, row) / M.nt != p) continue;
         if (cand[c].val >= best - tieAbs) {
-            const int order = forward ? (row - r0) : (r1 - 1 - row);
+            const int order = d_visit_order(M, row, forward);
             if (order < bestOrder) { bestOrder = order; bestRow = row; bestIdx = cand[c].idx; }
         }
     }
     if (bestRow >= 0) {
         const int gp = pBase + p;
-        refno[gp] = refIds ? refIds[bestRow] : (bestRow - r0);
+        refno[gp] = d_row_ref(M, bestRow, d_row_slot(M, bestRow));
         psi[gp] = bestIdx % N;
         flip[gp] = bestIdx >= N ? 1 : 0;
+    }
+}
+
+// --number_orientations > 1: the reference's running top-N (APM:714-735). For every visited row
+// (reference order as above, translations innermost) and every rank n: the largest value of the row
+// that lies below the rank n-1 incumbent replaces the rank n incumbent if it is greater. The ranks
+// are not shifted down on replacement -- that is the reference's behaviour, reproduced as is.
+// cand holds the K = n_orient largest distinct values of every row (all rows are candidates, c == row).
+#define XH_MAX_ORIENT 16
+__global__ void k_pm_pick_multi(const CandRes *__restrict__ cand, RowMap M, int m, int pBase, int parity, int N, int K,
+                                double eps, int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const size_t gp = (size_t)(pBase + p) * K;
+    double maxcorr[XH_MAX_ORIENT];
+    for (int n = 0; n < K; ++n) { maxcorr[n] = -99.e99; refno[gp + n] = -1; psi[gp + n] = 0; flip[gp + n] = 0; }
+    const bool forward = (((pBase + p + parity) & 1) == 0);
+    const int s0 = p * M.nt;
+    const int nn = M.poff[s0 + 1] - M.poff[s0];
+    const int nIter = K < 2 * N ? K : 2 * N;
+    for (int t = 0; t < nn; ++t) {
+        const int j = forward ? t : nn - 1 - t;
+        for (int it = 0; it < M.nt; ++it) {
+            const int row = M.poff[s0 + it] + j;
+            const int ref = d_row_ref(M, row, s0 + it);
+            const CandRes *cr = cand + (size_t)row * K;
+            double bestLast = 99e99;
+            for (int n = 0; n < nIter; ++n) {
+                for (int q = 0; q < K; ++q) {
+                    if (cr[q].idx < 0) break;
+                    if (cr[q].val < bestLast - eps) {
+                        if (cr[q].val > maxcorr[n] + eps) {
+                            maxcorr[n] = cr[q].val;
+                            refno[gp + n] = ref;
+                            psi[gp + n] = cr[q].idx % N;
+                            flip[gp + n] = cr[q].idx >= N ? 1 : 0;
+                        }
+                        break;
+                    }
+                }
+                bestLast = maxcorr[n];
+            }
+        }
     }
 }
 
@@ -1249,15 +1326,18 @@ k_pm_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int 
 template <typename T>
 static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d_gather, int nslots,
                     const int *d_count, XhBuf &coefBuf, XhBuf &polarBuf, XhBuf &outBuf, XhBuf &statBuf,
-                    const XhBuf &twBuf, bool conjugate, double xoff, double yoff)
+                    const XhBuf &twBuf, bool conjugate, double xoff, double yoff, int nt = 1,
+                    const double *d_offs = nullptr)
 {
+    // nslots images; with nt > 1 every image yields nt polar transforms (slot = image*nt + itrans)
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
     const int D = L.D;
+    const size_t nps = (size_t)nslots * nt;
     XH_TRY(xh_buf_reserve(ctx, coefBuf, sizeof(T) * (size_t)nslots * D * D));
-    XH_TRY(xh_buf_reserve(ctx, polarBuf, sizeof(T) * (size_t)nslots * L.nsamples));
-    XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * (size_t)nslots * L.ncoef));
-    XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * (size_t)nslots));
+    XH_TRY(xh_buf_reserve(ctx, polarBuf, sizeof(T) * nps * L.nsamples));
+    XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * nps * L.ncoef));
+    XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * nps));
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(T)))));
     const int tiles = (D + TR - 1) / TR;
     const size_t smem = sizeof(T) * TR * (D + 1);
@@ -1271,16 +1351,16 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     hipLaunchKernelGGL((k_pm_prefilter_cols<T>), dim3((nslots * D + 63) / 64), dim3(64), 0, ctx->stream,
                        (T *)coefBuf.p, D, nslots, d_count);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_pm_polar<T>), dim3(nslots), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
+    hipLaunchKernelGGL((k_pm_polar<T>), dim3((unsigned)nps), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
                        (double *)statBuf.p, (const float *)pm->d_sin.p, (const float *)pm->d_cos.p,
                        (const short *)pm->d_ringOfSample.p, (const int *)pm->d_nsam.p, D, L.Ri, L.nsamples, xoff, yoff,
-                       d_count);
+                       d_count, nt, d_offs);
     XH_LAUNCH_CHECK();
     const size_t smem2 = sizeof(T) * ((L.N + 3) & ~3) + sizeof(xh_c2<T>) * L.N;
-    hipLaunchKernelGGL((k_pm_ringdft<T>), dim3(L.nrings, nslots), dim3(256), smem2, ctx->stream, (const T *)polarBuf.p,
+    hipLaunchKernelGGL((k_pm_ringdft<T>), dim3(L.nrings, (unsigned)nps), dim3(256), smem2, ctx->stream, (const T *)polarBuf.p,
                        (const double *)statBuf.p, (xh_c2<T> *)outBuf.p, (const xh_c2<T> *)twBuf.p,
                        (const int *)pm->d_nsam.p, (const int *)pm->d_soff.p, (const int *)pm->d_coff.p, L.nsamples,
-                       L.ncoef, conjugate ? 1 : 0, d_count);
+                       L.ncoef, conjugate ? 1 : 0, d_count, nt);
     XH_LAUNCH_CHECK();
     return XH_OK;
 }
@@ -1299,7 +1379,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
 }
 
@@ -1709,11 +1789,15 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     return XH_OK;
 }
 
-int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off, const int32_t *h_nbr_ids,
-                int32_t parity, int32_t *d_refno, int32_t *d_psi, uint8_t *d_flip)
+int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off, const int32_t *h_nbr_ids,
+                   int32_t parity, int32_t n_orient, int32_t ntrans, const int32_t *h_xoff5d, const int32_t *h_yoff5d,
+                   int32_t *d_refno, int32_t *d_psi, uint8_t *d_flip)
 {
     XH_CHECK(pm && d_particles && d_refno && d_psi && d_flip && n >= 0, XH_ERR_ARG, "xh_pm_match: bad argument");
     XH_CHECK((h_nbr_off == nullptr) == (h_nbr_ids == nullptr), XH_ERR_ARG, "xh_pm_match: neighbour arrays go together");
+    XH_CHECK(n_orient >= 1 && n_orient <= XH_MAX_ORIENT, XH_ERR_UNSUPPORTED, "xh_pm_match: number of orientations %d outside [1,%d]",
+             n_orient, XH_MAX_ORIENT);
+    XH_CHECK(ntrans >= 0 && ntrans <= 1024 && (ntrans == 0 || (h_xoff5d && h_yoff5d)), XH_ERR_ARG, "xh_pm_match: bad 5-D translation list");
     if (n == 0) return XH_OK;
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
@@ -1722,10 +1806,24 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
     if (!dense)
         for (int i = 0; i < h_nbr_off[n]; ++i)
             XH_CHECK(h_nbr_ids[i] >= 0 && h_nbr_ids[i] < pm->nrefs, XH_ERR_ARG, "xh_pm_match: reference id %d out of range", h_nbr_ids[i]);
+    // 5-D search translations (APM:575-589); none given = the single translation (0,0)
+    const int nt = ntrans > 0 ? ntrans : 1;
+    const double *d_offs = nullptr;
+    if (ntrans > 0) {
+        std::vector<double> offs(2 * (size_t)nt);
+        for (int i = 0; i < nt; ++i) { offs[2 * i] = (double)h_xoff5d[i]; offs[2 * i + 1] = (double)h_yoff5d[i]; }
+        XH_TRY(xh_buf_reserve(ctx, pm->d_offs5d, sizeof(double) * offs.size()));
+        XH_HIP(hipMemcpyAsync(pm->d_offs5d.p, offs.data(), sizeof(double) * offs.size(), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+        d_offs = (const double *)pm->d_offs5d.p;
+    }
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
-    const size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (L.nk * sizeof(float4)));
+    size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (L.nk * sizeof(float4)));
+    // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
+    if (n_orient > 1) maxRows = std::min<size_t>(maxRows, std::max<size_t>(1024, ((size_t)1 << 30) / (sizeof(CandRes) * n_orient)));
+    const size_t maxSlots = n_orient > 1 ? 2048 : 32768;      // grid.y limit of the ring DFT / fp64 footprint
     const float tauAbs = (float)(pm->tau_rel * pm->scale);
     const double tieAbs = pm->tie_rel * pm->scale;
     int p0 = 0;
@@ -1733,38 +1831,77 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
         // particles of this chunk
         int m = 0;
         size_t rows = 0;
-        while (p0 + m < n && m < 4096) {
-            const size_t nn = dense ? (size_t)pm->nrefs : (size_t)(h_nbr_off[p0 + m + 1] - h_nbr_off[p0 + m]);
+        while (p0 + m < n && m < 4096 && (size_t)(m + 1) * nt <= std::max<size_t>(maxSlots, nt)) {
+            const size_t nn = (dense ? (size_t)pm->nrefs : (size_t)(h_nbr_off[p0 + m + 1] - h_nbr_off[p0 + m])) * nt;
             if (m > 0 && rows + nn > maxRows) break;
             rows += nn;
             ++m;
         }
-        std::vector<int> poff(m + 1), rowP(dense ? 0 : rows);
+        const int ms = m * nt;                                  // slots of this chunk
+        std::vector<int> poff(ms + 1), rowSlot(dense ? 0 : rows), ids(dense ? 0 : rows);
         poff[0] = 0;
         for (int i = 0; i < m; ++i) {
             const int nn = dense ? pm->nrefs : (h_nbr_off[p0 + i + 1] - h_nbr_off[p0 + i]);
-            poff[i + 1] = poff[i] + nn;
-            if (!dense) for (int r = poff[i]; r < poff[i + 1]; ++r) rowP[r] = i;
+            for (int it = 0; it < nt; ++it) {
+                const int sl = i * nt + it;
+                poff[sl + 1] = poff[sl] + nn;
+                if (!dense)
+                    for (int j = 0; j < nn; ++j) { rowSlot[poff[sl] + j] = sl; ids[poff[sl] + j] = h_nbr_ids[h_nbr_off[p0 + i] + j]; }
+            }
         }
         const int nrows = (int)rows;
-        XH_TRY(xh_buf_reserve(ctx, pm->d_poff, sizeof(int) * (m + 1 + rows)));
-        int *d_poff = (int *)pm->d_poff.p, *d_rowP = dense ? nullptr : d_poff + (m + 1);   // dense: row / nrefs
-        XH_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice, ctx->stream));
-        if (!dense && rows) XH_HIP(hipMemcpyAsync(d_rowP, rowP.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_poff, sizeof(int) * (ms + 1 + rows)));
+        int *d_poff = (int *)pm->d_poff.p, *d_rowSlot = dense ? nullptr : d_poff + (ms + 1);
+        XH_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int) * (ms + 1), hipMemcpyHostToDevice, ctx->stream));
+        if (!dense && rows) XH_HIP(hipMemcpyAsync(d_rowSlot, rowSlot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
         const int *d_ids = nullptr;
         if (!dense && rows) {
             XH_TRY(xh_buf_reserve(ctx, pm->d_nbr, sizeof(int) * rows));
-            XH_HIP(hipMemcpyAsync(pm->d_nbr.p, h_nbr_ids + h_nbr_off[p0], sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+            XH_HIP(hipMemcpyAsync(pm->d_nbr.p, ids.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
             d_ids = (const int *)pm->d_nbr.p;
         }
         XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
+        RowMap M;
+        M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = dense ? pm->nrefs : 0;
+        pm->stat_rows += nrows;
+        const size_t smem64 = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N) + (n_orient > 1 ? sizeof(double) * 2 * L.N : 0);
+        if (n_orient > 1) {
+            // exact path: every row in fp64, K largest distinct values per row, then the reference's running top-N
+            XH_HIP(hipEventRecord(pm->ev[4], ctx->stream));
+            if (nrows > 0) {
+                XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, nullptr, m, nullptr, pm->d_coef64, pm->d_polar64,
+                                        pm->d_A64, pm->d_stat64, pm->d_tw64, false, 0., 0., nt, d_offs));
+                XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
+                XH_TRY(xh_buf_reserve(ctx, pm->d_candRes, sizeof(CandRes) * (size_t)nrows * n_orient));
+                const int counters[4] = {m, nrows, 0, 0};
+                XH_HIP(hipMemcpyAsync(pm->d_counters.p, counters, sizeof(counters), hipMemcpyHostToDevice, ctx->stream));
+                XH_HIP(hipStreamSynchronize(ctx->stream));
+                hipLaunchKernelGGL(k_pm_rescore_row, dim3(nrows), dim3(256), smem64, ctx->stream, (const int *)pm->d_counters.p,
+                                   (const int *)nullptr, M, (const int *)nullptr, (const xh_cd *)pm->d_A64.p,
+                                   (const xh_cd *)pm->d_refs64.p, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p,
+                                   (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri,
+                                   L.ncoef, L.N, L.nk, (CandRes *)pm->d_candRes.p, (double *)nullptr, n_orient, pm->tie_rel);
+                XH_LAUNCH_CHECK();
+            }
+            hipLaunchKernelGGL(k_pm_pick_multi, dim3((m + 63) / 64), dim3(64), 0, ctx->stream, (const CandRes *)pm->d_candRes.p, M, m,
+                               p0, parity, L.N, n_orient, pm->tie_rel, d_refno, d_psi, d_flip);
+            XH_LAUNCH_CHECK();
+            XH_HIP(hipEventRecord(pm->ev[5], ctx->stream));
+            XH_HIP(hipEventSynchronize(pm->ev[5]));
+            float msf;
+            if (hipEventElapsedTime(&msf, pm->ev[4], pm->ev[5]) == hipSuccess) pm->stage_ms[4] += msf;
+            pm->stat_resc_p += m;
+            pm->stat_resc_r += nrows;
+            p0 += m;
+            continue;
+        }
         // S1 fp32
         XH_HIP(hipEventRecord(pm->ev[0], ctx->stream));
         XH_TRY(run_prep<float>(pm, d_particles + (size_t)p0 * D * D, true, nullptr, m, nullptr, pm->d_coef32, pm->d_polar32,
-                               pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0.));
+                               pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0., nt, d_offs));
         XH_HIP(hipEventRecord(pm->ev[1], ctx->stream));
         // S2 + S3
-        XH_TRY(run_rows(pm, m, poff, d_ids, dense, pm->nrefs, pm->ev[2]));
+        XH_TRY(run_rows(pm, ms, poff, d_ids, dense, pm->nrefs, pm->ev[2]));
         XH_HIP(hipEventRecord(pm->ev[3], ctx->stream));
         // S4
         XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
@@ -1773,8 +1910,8 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
         XH_TRY(xh_buf_reserve(ctx, pm->d_candRow, sizeof(int) * std::max<size_t>(1, rows)));
         XH_TRY(xh_buf_reserve(ctx, pm->d_candRes, sizeof(CandRes) * std::max<size_t>(1, rows)));
         XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_pm_select, dim3(m), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p, (const int *)d_poff,
-                           d_ids, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p, p0, d_refno, d_psi, d_flip,
+        hipLaunchKernelGGL(k_pm_select, dim3(m), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p, M,
+                           (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p, p0, d_refno, d_psi, d_flip,
                            L.N, tauAbs, (int *)pm->d_counters.p, (int *)pm->d_ambList.p, (int *)pm->d_ambSlot.p,
                            (int *)pm->d_candRow.p);
         XH_LAUNCH_CHECK();
@@ -1784,37 +1921,40 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
         XH_HIP(hipMemcpyAsync(counters, pm->d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
         XH_HIP(hipStreamSynchronize(ctx->stream));
         {
-            float ms;
+            float ms_;
             for (int e = 0; e < 4; ++e)
-                if (hipEventElapsedTime(&ms, pm->ev[e], pm->ev[e + 1]) == hipSuccess) pm->stage_ms[e] += ms;
+                if (hipEventElapsedTime(&ms_, pm->ev[e], pm->ev[e + 1]) == hipSuccess) pm->stage_ms[e] += ms_;
         }
-        pm->stat_rows += nrows;
         pm->stat_resc_p += counters[0];
         pm->stat_resc_r += counters[1];
         if (counters[0] > 0) {
             const int na = counters[0], nc = counters[1];
             XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, (const int *)pm->d_ambList.p, na, nullptr,
-                                    pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64, pm->d_tw64, false, 0., 0.));
-            const size_t smem = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N);
-            hipLaunchKernelGGL(k_pm_rescore_row, dim3(nc), dim3(256), smem, ctx->stream, (const int *)pm->d_counters.p,
-                               (const int *)pm->d_candRow.p, (const int *)d_rowP, (const int *)d_poff, d_ids,
-                               (const int *)pm->d_ambSlot.p, (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p,
-                               (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p,
-                               (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, L.N, L.nk,
-                               (CandRes *)pm->d_candRes.p, (double *)nullptr, pm->nrefs);
+                                    pm->d_coef64, pm->d_polar64, pm->d_A64, pm->d_stat64, pm->d_tw64, false, 0., 0., nt, d_offs));
+            hipLaunchKernelGGL(k_pm_rescore_row, dim3(nc), dim3(256), smem64, ctx->stream, (const int *)pm->d_counters.p,
+                               (const int *)pm->d_candRow.p, M, (const int *)pm->d_ambSlot.p, (const xh_cd *)pm->d_A64.p,
+                               (const xh_cd *)pm->d_refs64.p, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p,
+                               (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri,
+                               L.ncoef, L.N, L.nk, (CandRes *)pm->d_candRes.p, (double *)nullptr, 1, 0.0);
             XH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_pm_pick, dim3((na + 63) / 64), dim3(64), 0, ctx->stream, (const int *)pm->d_counters.p,
-                               (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, (const int *)d_rowP,
-                               (const int *)d_poff, d_ids, p0, parity, L.N, tieAbs, d_refno, d_psi, d_flip, pm->nrefs);
+                               (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, M, p0, parity, L.N, tieAbs,
+                               d_refno, d_psi, d_flip);
             XH_LAUNCH_CHECK();
             XH_HIP(hipEventRecord(pm->ev[5], ctx->stream));
             XH_HIP(hipEventSynchronize(pm->ev[5]));
-            float ms;
-            if (hipEventElapsedTime(&ms, pm->ev[4], pm->ev[5]) == hipSuccess) pm->stage_ms[4] += ms;
+            float ms_;
+            if (hipEventElapsedTime(&ms_, pm->ev[4], pm->ev[5]) == hipSuccess) pm->stage_ms[4] += ms_;
         }
         p0 += m;
     }
     return XH_OK;
+}
+
+int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h_nbr_off, const int32_t *h_nbr_ids,
+                int32_t parity, int32_t *d_refno, int32_t *d_psi, uint8_t *d_flip)
+{
+    return xh_pm_match_ex(pm, d_particles, n, h_nbr_off, h_nbr_ids, parity, 1, 0, nullptr, nullptr, d_refno, d_psi, d_flip);
 }
 
 int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *d_refno, const int32_t *d_psi,
@@ -1958,11 +2098,13 @@ int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32
     if (e == hipSuccess) {
         int *m = (int *)misc.p;
         const size_t smem = sizeof(xh_cd) * (2 * (size_t)L.nk + N);
-        hipLaunchKernelGGL(k_pm_rescore_row, dim3(1), dim3(256), smem, ctx->stream, (const int *)m, (const int *)(m + 4),
-                           (const int *)(m + 5), (const int *)(m + 6), (const int *)pm->d_nbr.p, (const int *)(m + 8),
-                           (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p, (const double *)pm->d_refSigma.p,
-                           (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p,
-                           (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, N, L.nk, (CandRes *)pm->d_candRes.p, (double *)dbg.p, 1);
+        RowMap RM;
+        RM.poff = m + 6; RM.rowSlot = m + 5; RM.refIds = (const int *)pm->d_nbr.p; RM.nt = 1; RM.nq = 0;
+        hipLaunchKernelGGL(k_pm_rescore_row, dim3(1), dim3(256), smem, ctx->stream, (const int *)m, (const int *)(m + 4), RM,
+                           (const int *)(m + 8), (const xh_cd *)pm->d_A64.p, (const xh_cd *)pm->d_refs64.p,
+                           (const double *)pm->d_refSigma.p, (const double *)pm->d_stat64.p, (const xh_cd *)pm->d_csN.p,
+                           (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri, L.ncoef, N, L.nk,
+                           (CandRes *)pm->d_candRes.p, (double *)dbg.p, 1, 0.0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_corr2N, dbg.p, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, ctx->stream);

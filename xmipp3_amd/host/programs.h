@@ -111,6 +111,7 @@ public:
     MetaDataVec DFexp, DFo;
     Sampling mysampling;
     std::vector<int> convert_refno_to_stack_position;
+    std::vector<int32_t> search5d_xoff, search5d_yoff;
     size_t dim = 0, total_nr_refs = 0;
     bool loop_forward_refs = true;
     xh_ctx *ctx = nullptr;
@@ -197,8 +198,24 @@ public:
     virtual void produceSideInfo()
     {
         // APM:209-404
-        if (search5d_shift != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--search5d_shift > 0 is not available on the device path yet");
-        if (numOrientations != 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--number_orientations > 1 is not available on the device path yet");
+        if (numOrientations < 1 || numOrientations > 16)
+            REPORT_ERROR(ERR_VALUE_INCORRECT, "--number_orientations must be in [1,16] on the device path");
+        // 5-D search translations, origin included (APM:321-348)
+        if (search5d_step == 0) {
+            std::cout << "*   ERROR: search step should be different from 0\n*   search step set to 1 \n";
+            search5d_step = 1;
+        }
+        search5d_xoff.clear();
+        search5d_yoff.clear();
+        {
+            const int myfinal = search5d_shift + search5d_shift % search5d_step;
+            for (int xoff = -myfinal; xoff <= myfinal; xoff += search5d_step)
+                for (int yoff = -myfinal; yoff <= myfinal; yoff += search5d_step)
+                    if (xoff * xoff + yoff * yoff <= search5d_shift * search5d_shift) {
+                        search5d_xoff.push_back(xoff);
+                        search5d_yoff.push_back(yoff);
+                    }
+        }
         if (do_scale) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--scale is not supported (the reference loops forever at scale 1.0, APM:947-948)");
         DFexp.read(fn_exp);
         if (DFexp.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "Empty input metadata " + fn_exp);
@@ -326,42 +343,64 @@ public:
                 xhCheck(xh_rf_shift_images(shifter, d_imgs, prevShift.data(), nullptr, (int)n, d_shifted.as<float>()));
                 d_imgs = d_shifted.as<float>();
             }
-            d_i32a.reserve(ctx, n * 4); d_i32b.reserve(ctx, n * 4); d_u8.reserve(ctx, n); d_f64.reserve(ctx, n * 8 * 3);
+            const size_t K = (size_t)numOrientations;
+            d_i32a.reserve(ctx, n * K * 4); d_i32b.reserve(ctx, n * K * 4); d_u8.reserve(ctx, n * K); d_f64.reserve(ctx, n * 8 * 3);
             if (idsv.empty()) idsv.push_back(0);
             // the visiting order of the references flips once per image (APM:1112)
-            xhCheck(xh_pm_match(pm, d_imgs, (int)n, off.data(), idsv.data(), loop_forward_refs ? 0 : 1, d_i32a.as<int32_t>(),
-                                d_i32b.as<int32_t>(), d_u8.as<uint8_t>()));
+            const int ntrans = search5d_xoff.size() > 1 ? (int)search5d_xoff.size() : 0;
+            xhCheck(xh_pm_match_ex(pm, d_imgs, (int)n, off.data(), idsv.data(), loop_forward_refs ? 0 : 1, (int)K, ntrans,
+                                   search5d_xoff.data(), search5d_yoff.data(), d_i32a.as<int32_t>(), d_i32b.as<int32_t>(),
+                                   d_u8.as<uint8_t>()));
             if (n & 1) loop_forward_refs = !loop_forward_refs;
+            std::vector<int32_t> refpos(n * K), psi(n * K);
+            std::vector<uint8_t> flip(n * K);
+            xhCheck(xh_memcpy_d2h(ctx, refpos.data(), d_i32a.p, n * K * 4));
+            xhCheck(xh_memcpy_d2h(ctx, psi.data(), d_i32b.p, n * K * 4));
+            xhCheck(xh_memcpy_d2h(ctx, flip.data(), d_u8.p, n * K));
+            // translational step per kept orientation (APM:1117-1124)
+            std::vector<double> f64(3 * n * K);
             double *d_sx = d_f64.as<double>(), *d_sy = d_sx + n, *d_cc = d_sy + n;
-            xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_i32a.as<int32_t>(), d_i32b.as<int32_t>(), d_u8.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
-            std::vector<int32_t> refpos(n), psi(n);
-            std::vector<uint8_t> flip(n);
-            std::vector<double> f64(3 * n);
-            xhCheck(xh_memcpy_d2h(ctx, refpos.data(), d_i32a.p, n * 4));
-            xhCheck(xh_memcpy_d2h(ctx, psi.data(), d_i32b.p, n * 4));
-            xhCheck(xh_memcpy_d2h(ctx, flip.data(), d_u8.p, n));
-            xhCheck(xh_memcpy_d2h(ctx, f64.data(), d_f64.p, n * 8 * 3));
-            for (size_t k = 0; k < n; ++k) {
-                if (refpos[k] < 0) continue;   // no valid correlation: the reference writes no row (APM:1131)
-                const size_t id = imagesToProcess[b0 + k];
-                const size_t row = DFo.addObject();
-                std::string fn;
-                DFexp.getValue("image", fn, id);
-                long itemId = 0;
-                if (!DFexp.getValue("itemId", itemId, id)) itemId = 0;
-                const std::vector<double> &ang = mysampling.no_redundant_sampling_points_angles[refpos[k]];
-                DFo.setValue("itemId", itemId, row);
-                DFo.setValue("image", fn, row);
-                DFo.setValue("angleRot", ang[0], row);
-                DFo.setValue("angleTilt", ang[1], row);
-                DFo.setValue("anglePsi", (double)psi[k] * (360. / N), row);
-                DFo.setValue("shiftX", f64[k] + prevShift[2 * k], row);
-                DFo.setValue("shiftY", f64[n + k] + prevShift[2 * k + 1], row);
-                DFo.setValue("ref", (long)mysampling.no_redundant_sampling_points_index[refpos[k]], row);
-                DFo.setValue("flip", (long)flip[k], row);
-                DFo.setValue("scale", DFexp.getDouble("scale", id, 1.0), row);
-                DFo.setValue("maxCC", f64[2 * n + k], row);
+            if (K == 1) {
+                xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_i32a.as<int32_t>(), d_i32b.as<int32_t>(), d_u8.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
+                xhCheck(xh_memcpy_d2h(ctx, f64.data(), d_f64.p, n * 8 * 3));
+            } else {
+                DeviceBuffer d_r1, d_p1, d_f1;
+                d_r1.reserve(ctx, n * 4); d_p1.reserve(ctx, n * 4); d_f1.reserve(ctx, n);
+                std::vector<int32_t> r1(n), p1(n);
+                std::vector<uint8_t> f1(n);
+                for (size_t o = 0; o < K; ++o) {
+                    for (size_t k = 0; k < n; ++k) { r1[k] = refpos[k * K + o]; p1[k] = psi[k * K + o]; f1[k] = flip[k * K + o]; }
+                    xhCheck(xh_memcpy_h2d(ctx, d_r1.p, r1.data(), n * 4));
+                    xhCheck(xh_memcpy_h2d(ctx, d_p1.p, p1.data(), n * 4));
+                    xhCheck(xh_memcpy_h2d(ctx, d_f1.p, f1.data(), n));
+                    xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_r1.as<int32_t>(), d_p1.as<int32_t>(), d_f1.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
+                    xhCheck(xh_memcpy_d2h(ctx, f64.data() + 3 * n * o, d_f64.p, n * 8 * 3));
+                }
             }
+            for (size_t k = 0; k < n; ++k)
+                for (size_t o = 0; o < K; ++o) {
+                    const size_t e = k * K + o;
+                    if (refpos[e] < 0) break;   // no (further) valid correlation: the reference writes no row (APM:1068-1090,1115)
+                    const double *res = f64.data() + 3 * n * o;
+                    const size_t id = imagesToProcess[b0 + k];
+                    const size_t row = DFo.addObject();
+                    std::string fn;
+                    DFexp.getValue("image", fn, id);
+                    long itemId = 0;
+                    if (!DFexp.getValue("itemId", itemId, id)) itemId = 0;
+                    const std::vector<double> &ang = mysampling.no_redundant_sampling_points_angles[refpos[e]];
+                    DFo.setValue("itemId", itemId, row);
+                    DFo.setValue("image", fn, row);
+                    DFo.setValue("angleRot", ang[0], row);
+                    DFo.setValue("angleTilt", ang[1], row);
+                    DFo.setValue("anglePsi", (double)psi[e] * (360. / N), row);
+                    DFo.setValue("shiftX", res[k] + prevShift[2 * k], row);
+                    DFo.setValue("shiftY", res[n + k] + prevShift[2 * k + 1], row);
+                    DFo.setValue("ref", (long)mysampling.no_redundant_sampling_points_index[refpos[e]], row);
+                    DFo.setValue("flip", (long)flip[e], row);
+                    DFo.setValue("scale", DFexp.getDouble("scale", id, 1.0), row);
+                    DFo.setValue("maxCC", res[2 * n + k], row);
+                }
         }
     }
 
