@@ -231,6 +231,31 @@ def test_translational_alignment(gpu, oracle, lib64):
         assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
+@pytest.mark.parametrize("D", [32, 128, 256])
+def test_translational_alignment_other_sizes(gpu, oracle, D):
+    """D = 64/128/256 take the register-blocked three-kernel path, other powers of two the radix-2 one."""
+    xa, ctx, torch = gpu
+    nrefs, n = 6, 7
+    refs = _library(D, nrefs, seed=2)
+    rng = np.random.default_rng(8)
+    parts, truth = synth.make_particles(refs, n, rng, snr=0.5, max_shift=3)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    N = o.N
+    er = rng.integers(0, nrefs, n).astype(np.int32)
+    ep = rng.integers(0, N, n).astype(np.int32)
+    ef = rng.integers(0, 2, n).astype(np.uint8)
+    for i in range(n):      # half of them at the true orientation so that real peaks are tested too
+        if i % 2 == 0:
+            er[i] = truth[i][0]
+    sx, sy, cc = pm.translate(torch.from_numpy(parts).cuda(), torch.from_numpy(er).cuda(), torch.from_numpy(ep).cuda(),
+                              torch.from_numpy(ef).cuda(), 6.0)
+    ex, ey, ec = o.translate(parts, er, ep, ef, 6.0)
+    assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3
+    assert np.abs(sy.cpu().numpy() - ey).max() <= 1e-3
+    assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+
+
 @pytest.mark.parametrize("pad", [1, 2])
 def test_ctf_filtered_gallery(gpu, oracle, lib64, pad):
     """--ctf: the references are filtered (pad, FFT, x Mctf, IFFT, crop) before the polar transform (APM:457-481)."""

@@ -1121,7 +1121,7 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
 // max_shift rejection (APM:841-842), translate(LINEAR, wrap) + correlationIndex (APM:850-851).
 // One block per particle. R = real part of the inverse FFT, un-centred (zero lag at index 0).
 __global__ void __launch_bounds__(256)
-k_pm_bestshift(const xh_cd *__restrict__ Rraw, const xh_cd *__restrict__ zimg, const int *__restrict__ refno,
+k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__restrict__ zimg, const int *__restrict__ refno,
                const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
                double *__restrict__ shiftY, double *__restrict__ maxCC)
 {
@@ -1135,11 +1135,12 @@ k_pm_bestshift(const xh_cd *__restrict__ Rraw, const xh_cd *__restrict__ zimg, c
         return;
     }
     const int n = D * D, cen = D / 2;
-    const xh_cd *R = Rraw + (size_t)p * n;
+    // rstride 1: real map; 2: real parts of an interleaved complex map
+    const double *R = Rraw + (size_t)p * n * rstride;
     // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
-#define RC(i, j) (R[(size_t)(((i) - cen) & (D - 1)) * D + (((j) - cen) & (D - 1))].x)
+#define RC(i, j) (R[((size_t)(((i) - cen) & (D - 1)) * D + (((j) - cen) & (D - 1))) * rstride])
     double s1 = 0, s2 = 0;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[t].x; s1 += v; s2 += v * v; }
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
     const double S1 = d_block_sum(s1, red), S2 = d_block_sum(s2, red);
     const double avg = S1 / n;
     double sd = sqrt(fabs(S2 / n - avg * avg));
@@ -1254,6 +1255,275 @@ k_pm_bestshift(const xh_cd *__restrict__ Rraw, const xh_cd *__restrict__ zimg, c
     }
 }
 
+
+// ---- S6, register-blocked: D = R1*R2 line FFTs in two passes ------------------------------------
+// The radix-2 kernels below spend log2(D) LDS round trips per line and the step took seven kernels
+// and ~15 MB of HBM traffic per 256-px particle. Here a thread keeps a whole radix-R butterfly in
+// registers (fp64), LDS is touched once per transform, and the step is three kernels:
+//   k_pm_tr_rows : build z = Mref + i*Mimg (APM:812-828), keep it for correlationIndex, forward row FFTs
+//   k_pm_tr_cols : forward column FFTs, cross-power spectrum of the two packed images, inverse column
+//                  FFTs -- a block owns column pairs (kx, -kx) so the Hermitian partner is in LDS
+//   k_pm_tr_irows: inverse row FFTs, real part only (the correlation map)
+// DIF forward, mirrored inverse: x[n1*R2+n2] <-> X[k1 + R1*k2]; no bit reversal anywhere.
+template <typename T, bool INV> __device__ __forceinline__ xh_c2<T> t_mulw(xh_c2<T> a, T wr, T wi)
+{
+    xh_c2<T> r;
+    if (!INV) { r.x = a.x * wr - a.y * wi; r.y = a.x * wi + a.y * wr; }
+    else { r.x = a.x * wr + a.y * wi; r.y = a.y * wr - a.x * wi; }
+    return r;
+}
+template <typename T, bool INV> __device__ __forceinline__ xh_c2<T> t_mulmi(xh_c2<T> a)
+{
+    return INV ? xh_c2<T>{-a.y, a.x} : xh_c2<T>{a.y, -a.x};
+}
+template <typename T> __device__ __forceinline__ xh_c2<T> t_add(xh_c2<T> a, xh_c2<T> b) { return xh_c2<T>{a.x + b.x, a.y + b.y}; }
+template <typename T> __device__ __forceinline__ xh_c2<T> t_sub(xh_c2<T> a, xh_c2<T> b) { return xh_c2<T>{a.x - b.x, a.y - b.y}; }
+template <typename T, bool INV> __device__ __forceinline__ void t_fft4(xh_c2<T> &x0, xh_c2<T> &x1, xh_c2<T> &x2, xh_c2<T> &x3)
+{
+    const xh_c2<T> a = t_add(x0, x2), b = t_sub(x0, x2), c = t_add(x1, x3), d = t_mulmi<T, INV>(t_sub(x1, x3));
+    x0 = t_add(a, c); x1 = t_add(b, d); x2 = t_sub(a, c); x3 = t_sub(b, d);
+}
+template <typename T, bool INV> __device__ __forceinline__ void t_fft8(xh_c2<T> *v)
+{
+    xh_c2<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    t_fft4<T, INV>(e0, e1, e2, e3);
+    t_fft4<T, INV>(o0, o1, o2, o3);
+    const T h = (T)0.70710678118654752440;
+    o1 = t_mulw<T, INV>(o1, h, -h);
+    o2 = t_mulmi<T, INV>(o2);
+    o3 = t_mulw<T, INV>(o3, -h, -h);
+    v[0] = t_add(e0, o0); v[4] = t_sub(e0, o0);
+    v[1] = t_add(e1, o1); v[5] = t_sub(e1, o1);
+    v[2] = t_add(e2, o2); v[6] = t_sub(e2, o2);
+    v[3] = t_add(e3, o3); v[7] = t_sub(e3, o3);
+}
+template <typename T, bool INV> __device__ __forceinline__ void t_fft16(xh_c2<T> *v)
+{
+    xh_c2<T> e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    t_fft8<T, INV>(e);
+    t_fft8<T, INV>(o);
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
+    o[1] = t_mulw<T, INV>(o[1], c1, -s1);
+    o[2] = t_mulw<T, INV>(o[2], h, -h);
+    o[3] = t_mulw<T, INV>(o[3], s1, -c1);
+    o[4] = t_mulmi<T, INV>(o[4]);
+    o[5] = t_mulw<T, INV>(o[5], -s1, -c1);
+    o[6] = t_mulw<T, INV>(o[6], -h, -h);
+    o[7] = t_mulw<T, INV>(o[7], -c1, -s1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = t_add(e[i], o[i]); v[i + 8] = t_sub(e[i], o[i]); }
+}
+template <typename T, int R, bool INV> __device__ __forceinline__ void t_fftR(xh_c2<T> *v)
+{
+    if (R == 16) t_fft16<T, INV>(v);
+    else t_fft8<T, INV>(v);
+}
+
+// geometry of one workgroup: LN lines of D = R1*R2 points, 256 threads; line l lives at s + l*LS,
+// element (a, b) of the R1 x R2 index grid at a*S1 + b (S1 = R2+1: padded against bank conflicts)
+template <int R1, int R2> struct TrGeom {
+    static constexpr int D = R1 * R2;
+    static constexpr int RM = R1 > R2 ? R1 : R2;
+    static constexpr int LN = 256 / RM;
+    static constexpr int S1 = R2 + 1;
+    static constexpr int LS = R1 * S1;
+    static constexpr size_t smem = sizeof(xh_cd) * ((size_t)LN * LS + D);
+};
+// forward pass 1 on registers v[n1] (thread = (line, n2)): radix R1, twiddle W^(k1*n2), to LDS
+template <int R1, int R2> __device__ __forceinline__ void tr_fwd1(xh_cd *v, xh_cd *sl, const xh_cd *sW, int n2)
+{
+    t_fftR<double, R1, false>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) { const xh_cd w = sW[k1 * n2]; v[k1] = t_mulw<double, false>(v[k1], w.x, w.y); }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) sl[k1 * TrGeom<R1, R2>::S1 + n2] = v[k1];
+}
+// forward pass 2 (thread = (line, k1)): from LDS, radix R2 -> v[k2] = X[k1 + R1*k2]
+template <int R1, int R2> __device__ __forceinline__ void tr_fwd2(xh_cd *v, const xh_cd *sl, int k1)
+{
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) v[n2] = sl[k1 * TrGeom<R1, R2>::S1 + n2];
+    t_fftR<double, R2, false>(v);
+}
+// inverse pass over k2 (thread = (line, k1)) from registers v[k2], conj twiddle, to LDS
+template <int R1, int R2> __device__ __forceinline__ void tr_inv2(xh_cd *v, xh_cd *sl, const xh_cd *sW, int k1)
+{
+    t_fftR<double, R2, true>(v);
+#pragma unroll
+    for (int n2 = 1; n2 < R2; ++n2) { const xh_cd w = sW[k1 * n2]; v[n2] = t_mulw<double, true>(v[n2], w.x, w.y); }
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) sl[k1 * TrGeom<R1, R2>::S1 + n2] = v[n2];
+}
+// inverse pass over k1 (thread = (line, n2)) from LDS -> v[n1] = x[n1*R2 + n2] (un-normalised)
+template <int R1, int R2> __device__ __forceinline__ void tr_inv1(xh_cd *v, const xh_cd *sl, int n2)
+{
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) v[k1] = sl[k1 * TrGeom<R1, R2>::S1 + n2];
+    t_fftR<double, R1, true>(v);
+}
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_pm_tr_rows(const float *__restrict__ particles, const double *__restrict__ refCoef, const int *__restrict__ refno,
+             const int *__restrict__ psi, const unsigned char *__restrict__ flip, xh_cd *__restrict__ z,
+             xh_cd *__restrict__ w, const xh_cd *__restrict__ WD, int N)
+{
+    typedef TrGeom<R1, R2> G;
+    constexpr int D = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *s = reinterpret_cast<xh_cd *>(smem);
+    xh_cd *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.y, row0 = blockIdx.x * G::LN;
+    for (int i = tid; i < D; i += 256) sW[i] = WD[i];
+    // ---- z = rotate(BSPLINE3, ref, psi, DONT_WRAP) + i * (mirrored) particle, coalesced
+    const int ref = refno[p];
+    const int cen = D / 2;
+    const double ang = (double)psi[p] * (360. / (double)N) * 3.14159265358979323846 / 180.0;
+    const double c = cos(ang), sn = sin(ang);
+    const double minp = -cen, maxp = D - cen - 1;
+    const float *img = particles + (size_t)p * D * D;
+    const bool fl = flip[p] != 0;
+    for (int e = tid; e < G::LN * D; e += 256) {
+        const int l = e / D, j = e - l * D, i = row0 + l;
+        xh_cd out = xh_cd{0., 0.};
+        if (ref >= 0) {
+            const double x = j - cen, y = i - cen;
+            const double xp = c * x - sn * y, yp = sn * x + c * y;
+            if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6))
+                out.x = d_interp<double>(refCoef + (size_t)ref * D * D, D, xp, yp);
+            if (fl) {
+                const double mx = -(double)(j - cen);
+                if (!(mx < minp - 1e-6 || mx > maxp + 1e-6)) out.y = (double)img[(size_t)i * D + (2 * cen - j)];
+            } else out.y = (double)img[(size_t)i * D + j];
+        }
+        z[((size_t)p * D + i) * D + j] = out;
+        s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = out;
+    }
+    __syncthreads();
+    xh_cd v[G::RM];
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        xh_cd *sl = s + l * G::LS;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = sl[n1 * G::S1 + n2];
+        tr_fwd1<R1, R2>(v, sl, sW, n2);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        tr_fwd2<R1, R2>(v, s + l * G::LS, k1);
+        xh_cd *dst = w + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = v[k2];
+    }
+}
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_pm_tr_cols(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD)
+{
+    typedef TrGeom<R1, R2> G;
+    constexpr int D = G::D;
+    constexpr int HP = G::LN / 2;             // column pairs per block
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *s = reinterpret_cast<xh_cd *>(smem);
+    xh_cd *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    xh_cd *img = w + (size_t)blockIdx.y * D * D;
+    for (int i = tid; i < D; i += 256) sW[i] = WD[i];
+    // line c < HP: column P = blockIdx.x*HP + c; line c >= HP: its Hermitian partner D - P.
+    // Pair 0 is special: columns 0 and D/2, each its own partner.
+    auto column = [&](int cl) {
+        const int q = cl < HP ? cl : cl - HP;
+        const int P = blockIdx.x * HP + q;
+        if (P == 0) return cl < HP ? 0 : D / 2;
+        return cl < HP ? P : D - P;
+    };
+    xh_cd v[G::RM];
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;      // neighbouring threads, neighbouring columns
+        const int col = column(cl);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = img[(size_t)(n1 * R2 + n2) * D + col];
+        tr_fwd1<R1, R2>(v, s + cl * G::LS, sW, n2);
+    }
+    __syncthreads();
+    const int cl2 = tid % G::LN, k1 = tid / G::LN;
+    const bool act2 = tid < G::LN * R1;
+    if (act2) tr_fwd2<R1, R2>(v, s + cl2 * G::LS, k1);
+    __syncthreads();
+    // natural-order spectrum back to LDS: X[k1 + R1*k2] at k1*S1' ... reuse the (a,b) grid with a = k1, b = k2
+    if (act2) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[cl2 * G::LS + k1 * G::S1 + k2] = v[k2];
+    }
+    __syncthreads();
+    if (act2) {
+        const int q = cl2 < HP ? cl2 : cl2 - HP;
+        const bool special = (blockIdx.x * HP + q) == 0;
+        const int pc = special ? cl2 : (cl2 < HP ? cl2 + HP : cl2 - HP);
+        const double inv = 1.0 / ((double)D * (double)D);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int ky = k1 + R1 * k2;
+            const int nky = (D - ky) & (D - 1);
+            const xh_cd a = v[k2];
+            const xh_cd b = s[pc * G::LS + (nky % R1) * G::S1 + (nky / R1)];
+            // F1 = (Z[k] + conj Z[-k])/2, F2 = (Z[k] - conj Z[-k])/(2i); product F1 conj(F2) / D^2
+            const xh_cd f1 = xh_cd{0.5 * (a.x + b.x), 0.5 * (a.y - b.y)};
+            const xh_cd f2 = xh_cd{0.5 * (a.y + b.y), -0.5 * (a.x - b.x)};
+            xh_cd r = xh_cmulc(f1, f2);
+            r.x *= inv;
+            r.y *= inv;
+            v[k2] = r;
+        }
+    }
+    __syncthreads();
+    if (act2) tr_inv2<R1, R2>(v, s + cl2 * G::LS, sW, k1);
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;
+        tr_inv1<R1, R2>(v, s + cl * G::LS, n2);
+        const int col = column(cl);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) img[(size_t)(n1 * R2 + n2) * D + col] = v[n1];
+    }
+}
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_cd *__restrict__ WD)
+{
+    typedef TrGeom<R1, R2> G;
+    constexpr int D = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *s = reinterpret_cast<xh_cd *>(smem);
+    xh_cd *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.y, row0 = blockIdx.x * G::LN;
+    for (int i = tid; i < D; i += 256) sW[i] = WD[i];
+    __syncthreads();
+    xh_cd v[G::RM];
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        const xh_cd *src = w + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) v[k2] = src[k1 + R1 * k2];
+        tr_inv2<R1, R2>(v, s + l * G::LS, sW, k1);
+    }
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        tr_inv1<R1, R2>(v, s + l * G::LS, n2);
+        double *dst = Rout + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) dst[n1 * R2 + n2] = v[n1].x;
+    }
+}
 
 // ---- CTF filtering of the reference gallery (APM:457-481): window to paddim, FFT, multiply the
 // spectrum by the real filter Mctf, inverse FFT, window back. fp64, once per library.
@@ -1511,8 +1781,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             const long double a = 2.0L * 3.14159265358979323846264338327950288L * j / N;
             csN[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
         }
-        std::vector<xh_cd> WD(std::max(1, D / 2));
-        for (int j = 0; j < D / 2; ++j) {
+        std::vector<xh_cd> WD(std::max(1, D));     // radix-2 kernels use j < D/2, the register-blocked ones j < D
+        for (int j = 0; j < D; ++j) {
             const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / D;
             WD[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
         }
@@ -1970,9 +2240,43 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
     if (max_shift < 0) max_shift = D / 2;    // APM:262-263
     const int logD = xh_ilog2(D);
     const size_t per = (size_t)D * D;
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)(256u << 20) / (per * sizeof(xh_cd))));
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)(1024u << 20) / (per * sizeof(xh_cd))));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t1, sizeof(xh_cd) * per * chunk));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t2, sizeof(xh_cd) * per * chunk));
+    if (D == 64 || D == 128 || D == 256) {
+        // register-blocked three-kernel path
+        XH_TRY(xh_buf_reserve(ctx, pm->d_t3, sizeof(double) * per * chunk));
+        for (int p0 = 0; p0 < n; p0 += chunk) {
+            const int m = std::min(chunk, n - p0);
+            xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
+            double *R = (double *)pm->d_t3.p;
+#define XH_TR(A_, B_)                                                                                                       \
+    {                                                                                                                       \
+        typedef TrGeom<A_, B_> G;                                                                                           \
+        if (G::smem > 64 * 1024) {                                                                                          \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_rows<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((k_pm_tr_rows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                      \
+                           d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0, d_psi + p0,       \
+                           d_flip + p0, z, w, (const xh_cd *)pm->d_WD64.p, L.N);                                            \
+        hipLaunchKernelGGL((k_pm_tr_cols<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, w,                   \
+                           (const xh_cd *)pm->d_WD64.p);                                                                    \
+        hipLaunchKernelGGL((k_pm_tr_irows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cd *)w, R, \
+                           (const xh_cd *)pm->d_WD64.p);                                                                    \
+    }
+            if (D == 64) XH_TR(8, 8)
+            else if (D == 128) XH_TR(16, 8)
+            else XH_TR(16, 16)
+#undef XH_TR
+            XH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)R, 1, (const xh_cd *)z, d_refno + p0,
+                               d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);
+            XH_LAUNCH_CHECK();
+        }
+        return XH_OK;
+    }
     const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(D * sizeof(xh_cd))));
     const size_t smem = (size_t)lpb * D * sizeof(xh_cd);
     for (int p0 = 0; p0 < n; p0 += chunk) {
@@ -2001,7 +2305,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            pw, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const xh_cd *)pw, (const xh_cd *)z, d_refno + p0,
+        hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,
                            d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);
         XH_LAUNCH_CHECK();
     }
