@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 const double kPI = 3.14159265358979323846;
@@ -209,6 +210,134 @@ k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2
         im *= inv;
         if (conjugate) im = im * (T)(-1);
         out[(size_t)slot * ncoef + coff[r] + k] = xh_c2<T>{re, im};
+    }
+}
+
+// ---- per-ring DFT as a matrix product on the matrix cores (fp32 coarse pass only) ---------------
+// out[slot][k] = (1/n) sum_s (x[slot][s] - mean[slot]) * tw[(s*k) mod n] is, per ring, the product of
+// a [slots x n] matrix with the [n x nk] DFT matrix: 54 MFLOP per 256-px particle, which the direct
+// kernel above does at VALU rate. Here a wave owns 32 slots x 32 frequencies per accumulator pair
+// (re, im) on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation). The DFT matrix is never
+// stored: every lane walks its own (s*k) mod n through the ring's n-entry twiddle table in LDS.
+// Block = (ring, 32 slots); the samples are staged through LDS in chunks (coalesced reads, mean
+// subtracted on the way in); wave w takes frequency tiles w, w+4, w+8, w+12 of each round of 16.
+typedef float xh_f32x16_rd __attribute__((ext_vector_type(16)));
+#define XH_RD_CH 256
+#define XH_RD_KT 4
+// one round of a block: NA live frequency tiles for this wave (kt0 + wv + 4*i, i < NA). Every wave of
+// the block runs the same number of barriers whatever its NA.
+template <int NA>
+__device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], const xh_cf *sT, const float *__restrict__ polar,
+                                         const float *sMean, xh_cf *__restrict__ out, int n, int nk, int kt0,
+                                         int slot0, int nslots, int nsamples, int soffr, int coffr, int ncoef, int conjugate, int dbg)
+{
+    constexpr int NR = NA > 0 ? NA : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sl = lane >> 5, kl = lane & 31;
+    xh_f32x16_rd accR[NR], accI[NR];
+    int j[NR], dj[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accR[i][e] = 0.f; accI[i][e] = 0.f; }
+        const int k = ((kt0 + wv + 4 * i) * 32 + kl) % n;
+        j[i] = (sl * k) % n;        // s = sl at the first step
+        dj[i] = (2 * k) % n;
+    }
+    // chunk c+1 travels from HBM/L2 into registers while the matrix cores work on chunk c
+    float pre[32];
+    auto fetch = [&](int sc) {
+        const int ss = min(sc + tid, n - 1);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) pre[q] = polar[(size_t)min(slot0 + q, nslots - 1) * nsamples + soffr + ss];
+    };
+    fetch(0);
+    for (int sc = 0; sc < n; sc += XH_RD_CH) {
+        __syncthreads();            // previous chunk consumed (and sT / sMean visible on the first pass)
+        const bool inRing = sc + tid < n;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) sX[q][tid] = inRing ? pre[q] - sMean[q] : 0.f;
+        __syncthreads();
+        if (sc + XH_RD_CH < n && dbg != 1) fetch(sc + XH_RD_CH);
+        if (NA > 0 && dbg != 2) {
+            const int cn = min(XH_RD_CH, n - sc);          // even
+            // operands of step t+1 are read from LDS while the matrix cores run step t
+            float a = sX[kl][sl];
+            xh_cf w[NR];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { w[i] = sT[j[i] + (j[i] >> 4)]; j[i] += dj[i]; if (j[i] >= n) j[i] -= n; }
+            for (int t = 0; t < cn; t += 2) {
+                // program order M M L M M L ...: each LDS read has the following tiles' MFMAs to land.
+                // (the reads of the last step fetch operands that are never used)
+                const float an = sX[kl][min(t + 2 + sl, XH_RD_CH)];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    accR[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[i].x, accR[i], 0, 0, 0);
+                    accI[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[i].y, accI[i], 0, 0, 0);
+                    w[i] = sT[j[i] + (j[i] >> 4)];     // one pad entry per 16: strides s*k stop piling onto one bank
+                    j[i] += dj[i];
+                    if (j[i] >= n) j[i] -= n;
+                }
+                a = an;
+                // scheduling hint; measured best of the variants tried (reads hoisted above the MFMAs: +7 %,
+                // strict M M L interleave: +6 %)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+            }
+            // undo the index advance of the unused trailing read so that the next chunk continues at s = sc + cn
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { j[i] -= dj[i]; if (j[i] < 0) j[i] += n; }
+        }
+    }
+    const float inv = 1.f / (float)n;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int k = (kt0 + wv + 4 * i) * 32 + kl;
+        if (k >= nk) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * sl;
+            if (slot0 + row >= nslots) continue;
+            float re = accR[i][e] * inv, im = accI[i][e] * inv;
+            if (conjugate) im = im * (-1.f);
+            out[(size_t)(slot0 + row) * ncoef + coffr + k] = xh_cf{re, im};
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ stat, xh_cf *__restrict__ out,
+                  const xh_cf *__restrict__ tw, const int *__restrict__ nsam, const int *__restrict__ soff,
+                  const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, int nslots, int nrings, int dbg)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float (*sX)[XH_RD_CH + 1] = reinterpret_cast<float (*)[XH_RD_CH + 1]>(smem);
+    xh_cf *sT = reinterpret_cast<xh_cf *>(smem + sizeof(float) * 32 * (XH_RD_CH + 1));
+    const int r = nrings - 1 - blockIdx.x;        // long rings first
+    const int slot0 = blockIdx.y * 32;
+    const int n = nsam[r], nk = n / 2 + 1, nkt = (nk + 31) / 32;
+    const int tid = threadIdx.x, wv = tid >> 6;
+    __shared__ float sMean[32];
+    for (int i = tid; i < n; i += 256) sT[i + (i >> 4)] = tw[soff[r] + i];
+    // slots past the end contribute nothing: their samples are read from the last valid slot and never stored
+    if (tid < 32) sMean[tid] = (float)stat[2 * min(slot0 + tid, nslots - 1)];
+    for (int kt0 = 0; kt0 < nkt; kt0 += 4 * XH_RD_KT) {
+        const int left = nkt - kt0 - wv;          // tiles kt0+wv, +4, +8, +12 that exist
+        const int nact = __builtin_amdgcn_readfirstlane(left <= 0 ? 0 : min(XH_RD_KT, (left + 3) / 4));
+#define XH_RD_GO(NA_) rd_round<NA_>(sX, sT, polar, sMean, out, n, nk, kt0, slot0, nslots, nsamples, soff[r], coff[r], ncoef, conjugate, dbg)
+#if XH_RD_KT >= 4
+        if (nact == 4) XH_RD_GO(4);
+        else if (nact == 3) XH_RD_GO(3);
+        else
+#endif
+        if (nact == 2) XH_RD_GO(2);
+        else if (nact == 1) XH_RD_GO(1);
+        else XH_RD_GO(0);
+#undef XH_RD_GO
     }
 }
 
@@ -1626,6 +1755,15 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
                        (const short *)pm->d_ringOfSample.p, (const int *)pm->d_nsam.p, D, L.Ri, L.nsamples, xoff, yoff,
                        d_count, nt, d_offs);
     XH_LAUNCH_CHECK();
+    if (std::is_same<T, float>::value && !d_count && pm->use_mfma) {
+        const size_t smemM = sizeof(float) * 32 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
+        hipLaunchKernelGGL(k_pm_ringdft_mfma, dim3(L.nrings, (unsigned)((nps + 31) / 32)), dim3(256), smemM, ctx->stream,
+                           (const float *)polarBuf.p, (const double *)statBuf.p, (xh_cf *)outBuf.p, (const xh_cf *)twBuf.p,
+                           (const int *)pm->d_nsam.p, (const int *)pm->d_soff.p, (const int *)pm->d_coff.p, L.nsamples, L.ncoef,
+                           conjugate ? 1 : 0, (int)nps, L.nrings, pm->contract_dbg);
+        XH_LAUNCH_CHECK();
+        return XH_OK;
+    }
     const size_t smem2 = sizeof(T) * ((L.N + 3) & ~3) + sizeof(xh_c2<T>) * L.N;
     hipLaunchKernelGGL((k_pm_ringdft<T>), dim3(L.nrings, (unsigned)nps), dim3(256), smem2, ctx->stream, (const T *)polarBuf.p,
                        (const double *)statBuf.p, (xh_c2<T> *)outBuf.p, (const xh_c2<T> *)twBuf.p,
