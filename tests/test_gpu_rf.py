@@ -75,13 +75,20 @@ def test_shift_images(gpu, oracle):
         assert np.abs(gotf[i] - exp).max() <= 2e-5 * np.abs(exp).max()
 
 
-def test_ctf_arrays(gpu, oracle):
+@pytest.mark.parametrize("kind", ["astigmatic", "round", "round_envelope", "astigmatic_envelope"])
+def test_ctf_arrays(gpu, oracle, kind):
+    """k_rf_ctf has per-image shortcuts (no atan2 for a round CTF, no exp without envelope terms); every
+    combination must equal the general double-precision formula (ctf.h:376-501)."""
     xa, ctx, torch = gpu
     D = 64
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.5)
     o = oracle.RF(D, min_ctf=0.01, sampling=1.5, use_ctf=True)
     from xmipp3_amd.api import ctf_params
     kw = dict(kV=300.0, Cs=2.7, Q0=0.07, DeltafU=15000.0, DeltafV=17000.0, azimuthal_angle=30.0, K=1.0)
+    if kind.startswith("round"):
+        kw["DeltafV"] = kw["DeltafU"]
+    if kind.endswith("envelope"):
+        kw.update(Ca=2.0, espr=0.6, ispr=0.3, alpha=0.1, DeltaF=3.0, DeltaR=0.5)
     c, m = rf.ctf_arrays([ctf_params(**kw)])
     ce, me = o.ctf_arrays(oracle.ctf_params(**kw))
     c, m = c.cpu().numpy()[0], m.cpu().numpy()[0]

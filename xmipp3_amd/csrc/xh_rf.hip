@@ -18,6 +18,7 @@
 //   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, k_fft_lines, k_rf_c2r_window   O(volume) once
 #include "xh_common.h"
 #include "xh_fft.h"
+#include "xh_fftreg.h"
 #include "xh_bspline.h"
 #include <algorithm>
 #include <cmath>
@@ -221,6 +222,7 @@ struct xh_rf {
     XhBuf d_cull, d_pack;
     int tile_max_spaces;
     int tile_variant;     // 1: LDS-staged patches (blob radius < 2); 0: queue kernel
+    int fft_variant;      // 0: register-blocked 2-D FFT of the projections where P allows; 1: radix-2 LDS kernels
     double meanFactor2;   // cached mean of sinc^2 over the output window (< 0: not computed yet)
     int ntiles;
     bool cropped;
@@ -332,6 +334,112 @@ struct XhCtfDev {
     double K1, K2, K3, K5, K6, K7, Ksin, Kcos, rad_azimuth, defocus_average, defocus_deviation;
     double DeltaR, K, envR0, envR1, envR2, phase_shift, VPP_radius;
 };
+// ---- register-blocked variants of k_rf_rows / k_rf_cols for P = R1*R2 (xh_fftreg.h) ---------------
+// Same arithmetic contract (pad about the Xmipp origin, CenterFFT, forward FFT, crop, 1/P^2), one LDS
+// round trip per transform instead of log2(P), no zero-fill pass: the padding is known by position.
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_rf_rows2(const float *__restrict__ imgs, xh_cf *__restrict__ rows, const xh_cf *__restrict__ W, int D, int sizeX, int totalLines)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int P = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int line0 = blockIdx.x * G::LN;
+    for (int i = tid; i < P; i += 256) sW[i] = W[i];
+    __syncthreads();
+    const int half = D / 2;
+    xh_cf v[G::RM];
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        const bool live = line0 + l < totalLines;
+        const float *src = imgs + (size_t)(line0 + l) * D;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int px = n1 * R2 + n2;          // padded, centred position: logical x = px (px < half) or px - P
+            float val = 0.f;
+            if (live) {
+                if (px < D - half) val = src[px + half];
+                else if (px >= P - half) val = src[px - P + half];
+            }
+            v[n1] = xh_cf{val, 0.f};
+        }
+        tr_fwd1<R1, R2>(v, s + l * G::LS, sW, n2);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        tr_fwd2<R1, R2>(v, s + l * G::LS, k1);
+        if (line0 + l < totalLines) {
+            xh_cf *dst = rows + (size_t)(line0 + l) * sizeX;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2)
+                if (k1 + R1 * k2 < sizeX) dst[k1 + R1 * k2] = v[k2];
+        }
+    }
+}
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_rf_cols2(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *__restrict__ W, int D, int sizeX, double maxResSqr)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int P = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int groupsPerImg = (sizeX + G::LN - 1) / G::LN;
+    const int img = blockIdx.x / groupsPerImg;
+    const int kx0 = (blockIdx.x - img * groupsPerImg) * G::LN;
+    for (int i = tid; i < P; i += 256) sW[i] = W[i];
+    __syncthreads();
+    const int half = D / 2;
+    const xh_cf *src = rows + (size_t)img * D * sizeX;
+    xh_cf v[G::RM];
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;      // neighbouring threads, neighbouring columns
+        const bool live = kx0 + cl < sizeX;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int py = n1 * R2 + n2;
+            xh_cf val = xh_cf{0.f, 0.f};
+            if (live) {
+                if (py < D - half) val = src[(size_t)(py + half) * sizeX + kx0 + cl];
+                else if (py >= P - half) val = src[(size_t)(py - P + half) * sizeX + kx0 + cl];
+            }
+            v[n1] = val;
+        }
+        tr_fwd1<R1, R2>(v, s + cl * G::LS, sW, n2);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int cl = tid % G::LN, k1 = tid / G::LN;
+        tr_fwd2<R1, R2>(v, s + cl * G::LS, k1);
+        const int j = kx0 + cl;
+        if (j < sizeX) {
+            const float scale = 1.0f / ((float)P * (float)P);
+            const int sizeY = 2 * sizeX;
+            xh_cf *dst = out + (size_t)img * sizeY * sizeX;
+            const double fx = (double)j / (double)P;                  // j <= P/2
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int ii = k1 + R1 * k2;                           // FFT row index
+                int r;                                                 // output row (myPadI)
+                if (ii < sizeX) r = ii + sizeX;
+                else if (ii >= P - sizeX) r = ii - (P - sizeX);
+                else continue;                                         // cropped away (only when P > 2*sizeX)
+                const double fy = (double)(ii <= P / 2 ? ii : ii - P) / (double)P;
+                xh_cf o = xh_cf{0.f, 0.f};
+                if (!(fx * fx + fy * fy > maxResSqr)) { o = v[k2]; o.x *= scale; o.y *= scale; }
+                dst[(size_t)r * sizeX + j] = o;
+            }
+        }
+    }
+}
+
 __device__ double d_bessj0(double x)
 {
     double ax = fabs(x);
@@ -359,23 +467,27 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
     const float freqY = (y - (P / 2.f)) / (float)P;
     float freqX = (float)((double)(x <= P / 2 ? x : x - P) / (double)P);
     const double X = freqX * iTs, Y = freqY * iTs;
-    const double ang = atan2(Y, X);
     const double u2 = X * X + Y * Y;
     const double u = sqrt(u2);
     const double u4 = u2 * u2;
+    // Per-image (block-uniform) shortcuts, each bit-identical to the general formula (ctf.h:376-501):
+    // x + 0*cos(.) == x and exp(-0*finite) == 1 exactly, so a non-astigmatic CTF needs no atan2/cos and a
+    // CTF without energy-spread / convergence-cone terms no exp.
     double deltaf;
     if (fabs(X) < 1e-6 && fabs(Y) < 1e-6) deltaf = 0;
-    else deltaf = c.defocus_average + c.defocus_deviation * cos(2 * (ang - c.rad_azimuth));
+    else if (c.defocus_deviation == 0) deltaf = c.defocus_average;
+    else deltaf = c.defocus_average + c.defocus_deviation * cos(2 * (atan2(Y, X) - c.rad_azimuth));
     double VPP = 0.0;
     if (round(c.VPP_radius * 1000) != 0) VPP = -c.phase_shift * (1 - exp(-u2 / (2 * c.VPP_radius * c.VPP_radius)));
     const double argument = VPP + c.K1 * deltaf * u2 + c.K2 * u4;
-    const double sine_part = sin(argument), cosine_part = cos(argument);
-    const double Eespr = exp(-c.K3 * u4);
+    double sine_part, cosine_part;
+    sincos(argument, &sine_part, &cosine_part);
+    const double Eespr = c.K3 == 0 ? 1.0 : exp(-c.K3 * u4);
     const double EdeltaF = d_bessj0(c.K5 * u2);
     const double xs = u * c.DeltaR;
     const double EdeltaR = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
     const double aux = (c.K7 * u2 * u + deltaf * u);
-    const double Ealpha = exp(-c.K6 * aux * aux);
+    const double Ealpha = c.K6 == 0 ? 1.0 : exp(-c.K6 * aux * aux);
     double E = Eespr * EdeltaF * EdeltaR * Ealpha + c.envR0 + c.envR1 * u + c.envR2 * u2;
     if (E < 0) E = 0;
     const double pure = -c.K * (c.Ksin * sine_part - c.Kcos * cosine_part) * E;
@@ -1302,14 +1414,15 @@ k_rf_c2r_window(const xh_cd *__restrict__ F, const xh_cd *__restrict__ W, double
 // =========================================================================== host API
 static int make_twiddles(xh_ctx *ctx, int n, XhBuf &b32, XhBuf &b64)
 {
-    std::vector<xh_cf> w32(n / 2);
+    // fp32 table: all n entries (the register-blocked kernels index j < n, the radix-2 ones j < n/2)
+    std::vector<xh_cf> w32(n);
     std::vector<xh_cd> w64(n / 2);
-    for (int j = 0; j < n / 2; ++j) {
+    for (int j = 0; j < n; ++j) {
         const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / n;
-        w64[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
-        w32[j] = xh_cf{(float)w64[j].x, (float)w64[j].y};
+        if (j < n / 2) w64[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
+        w32[j] = xh_cf{(float)cosl(a), (float)sinl(a)};
     }
-    XH_TRY(xh_buf_alloc(ctx, b32, sizeof(xh_cf) * (n / 2)));
+    XH_TRY(xh_buf_alloc(ctx, b32, sizeof(xh_cf) * n));
     XH_TRY(xh_buf_alloc(ctx, b64, sizeof(xh_cd) * (n / 2)));
     XH_HIP(hipMemcpy(b32.p, w32.data(), b32.bytes, hipMemcpyHostToDevice));
     XH_HIP(hipMemcpy(b64.p, w64.data(), b64.bytes, hipMemcpyHostToDevice));
@@ -1368,6 +1481,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->tile_dbg = 0;
     rf->tile_max_spaces = 8192;
     rf->tile_variant = 0;   // the LDS-staged variant measured slower (profiles/README.md)
+    rf->fft_variant = 0;
     rf->meanFactor2 = -1;
     int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
     if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
@@ -1431,6 +1545,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
+    else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
     else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1515,6 +1630,23 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         const int totalLines = m * D;
+        if ((P == 512 || P == 256 || P == 128) && rf->sizeY == P && rf->fft_variant == 0) {
+#define XH_RF2(A_, B_)                                                                                                          \
+    {                                                                                                                           \
+        typedef TrGeom<A_, B_, float> G;                                                                                        \
+        hipLaunchKernelGGL((k_rf_rows2<A_, B_>), dim3((totalLines + G::LN - 1) / G::LN), dim3(256), G::smem, ctx->stream,         \
+                           d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, (const xh_cf *)rf->d_twP32.p, D, sizeX, totalLines); \
+        hipLaunchKernelGGL((k_rf_cols2<A_, B_>), dim3(m * ((sizeX + G::LN - 1) / G::LN)), dim3(256), G::smem, ctx->stream,        \
+                           (const xh_cf *)rf->d_rows.p, (xh_cf *)d_fft + (size_t)i0 * rf->sizeY * sizeX,                        \
+                           (const xh_cf *)rf->d_twP32.p, D, sizeX, maxResSqr);                                                \
+    }
+            if (P == 512) XH_RF2(16, 32)
+            else if (P == 256) XH_RF2(16, 16)
+            else XH_RF2(16, 8)
+#undef XH_RF2
+            XH_LAUNCH_CHECK();
+            continue;
+        }
         hipLaunchKernelGGL(k_rf_rows, dim3((totalLines + lpb - 1) / lpb), dim3(256), smem, ctx->stream,
                            d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, (const xh_cf *)rf->d_twP32.p, D,
                            logP, sizeX, totalLines, lpb);
