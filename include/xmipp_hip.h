@@ -147,6 +147,10 @@ int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float 
 int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
                           const double *h_ainv, const float *h_weights, int32_t n,
                           const double *h_sym, int32_t nsym);
+/* HIP-event time (ms, on the context's stream) and number of launches of the output-stationary
+ * gridding kernel since the last reset -- the live per-launch duration behind bench.py's roofline.
+ * No reference counterpart (RFG times nothing). */
+int xh_rf_kernel_ms(xh_rf *rf, double *h_ms, int64_t *h_launches, int32_t reset);
 /* mirrorAndCropTempSpaces (RFA:853-887): temp -> cropped [ (mv+1)^2*(mv/2+1) complex | weights ]
  * stored at the start of the same buffer; 3*(mv+1)^2*(mv/2+1) floats are what a multi-GPU
  * host all-reduces (SUM) before xh_rf_finish. */

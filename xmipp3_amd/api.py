@@ -222,6 +222,12 @@ class RecFourier:
         check(lib().xh_rf_insert_matrices(self.h, _ptr(fft, f32), _ptr(ctf, f32), _ptr(modulator, f32), _np_ptr(a), _np_ptr(w),
                                           n, _np_ptr(s), 0 if s is None else s.shape[0]))
 
+    def kernel_ms(self, reset=True):
+        """(total ms, launches) of the gridding kernel since the last reset (HIP events on the stream)."""
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().xh_rf_kernel_ms(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
     def temp_spaces(self):
         """(volume [mv+1,mv+1,nx,2], weights [mv+1,mv+1,nx]) views of the temp tensor."""
         d = self.mv + 1
