@@ -76,10 +76,11 @@ def test_no_gpu_means_xmipp_error_not_fallback(bins, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle):
+@pytest.mark.parametrize("box", [32, 40])
+def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
     """project-match with the CLI, reconstruct from its output with the CLI; compare both with
-    the oracle run on the same files' contents."""
-    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path)
+    the oracle run on the same files' contents. box=40: no power of two anywhere on the path."""
+    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path, D=box)
     n, nrefs, D = len(parts), len(refs), refs.shape[1]
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
               "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4"])

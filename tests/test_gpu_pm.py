@@ -121,6 +121,28 @@ def test_match_with_neighbour_lists_and_chunking(gpu, oracle, lib64):
     assert np.array_equal(flip.cpu().numpy()[valid], ef[valid, 0])
 
 
+def test_match_any_box_size(gpu, oracle):
+    """D=50: nothing on the rotational path needs a power of two (ring DFTs are direct, the length-N
+    inverse DFT is Bluestein anyway); the CTF-filtered gallery uses a 75x75 Bluestein FFT (pad 1.5)."""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 50, 20, 15
+    refs = _library(D, nrefs, seed=6)
+    rng = np.random.default_rng(12)
+    parts, truth = synth.make_particles(refs, n, rng, snr=0.2, max_shift=2)
+    paddim = 75
+    fy = np.fft.fftfreq(paddim)[:, None]
+    fx = np.fft.fftfreq(paddim)[None, :]
+    Mctf = np.cos(40.0 * (fx * fx + fy * fy)) * np.exp(-6.0 * (fx * fx + fy * fy))
+    for M, pd in ((None, 0), (Mctf, paddim)):
+        pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda(), Mctf=M, paddim=pd)
+        o = oracle.PM(refs, Mctf=M, paddim=pd)
+        refno, psi, flip = pm.match(torch.from_numpy(parts).cuda())
+        er, ep, ef, _ = o.match(parts)
+        assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+        assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+        assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+
+
 def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     """Duplicated references give bit-equal correlations in the reference: the first visited
     wins, and the visiting order flips every image (APM:615-626,1112)."""
@@ -231,9 +253,10 @@ def test_translational_alignment(gpu, oracle, lib64):
         assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
-@pytest.mark.parametrize("D", [32, 128, 256])
+@pytest.mark.parametrize("D", [32, 128, 256, 50, 45])
 def test_translational_alignment_other_sizes(gpu, oracle, D):
-    """D = 64/128/256 take the register-blocked three-kernel path, other powers of two the radix-2 one."""
+    """D = 64/128/256 take the register-blocked three-kernel path, other powers of two the radix-2 one,
+    everything else (50, 45) the Bluestein line transforms of xh_plan.h."""
     xa, ctx, torch = gpu
     nrefs, n = 6, 7
     refs = _library(D, nrefs, seed=2)

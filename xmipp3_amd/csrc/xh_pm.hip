@@ -27,6 +27,7 @@
 #include "xh_common.h"
 #include "xh_fft.h"
 #include "xh_fftreg.h"
+#include "xh_plan.h"
 #include "xh_bspline.h"
 #include <algorithm>
 #include <cmath>
@@ -105,7 +106,8 @@ struct xh_pm {
     int R1, R2, R3;              // M = R1*R2*R3 (0 => radix-2 kernel)
     XhBuf d_chirp, d_vhat;       // Bluestein: chirp[N], vhat[M] (bit-reversed, /M)
     XhBuf d_csN;                 // cos/sin(2 pi j / N) double, for the fp64 re-scorer
-    XhBuf d_WD64;                // FFT twiddles for length D (double) for S6
+    XhBuf d_WD64;                // FFT twiddles W_D^j, j < D (double) for the register-blocked S6 kernels
+    XhPlanBufs<double> planD;    // generic length-D line transform (S6 at the other sizes)
     // per-call scratch
     XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
@@ -1235,7 +1237,7 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= D * D) return;
     const int i = pix / D, j = pix - i * D;
-    const int ni = (D - i) & (D - 1), nj = (D - j) & (D - 1);
+    const int ni = i ? D - i : 0, nj = j ? D - j : 0;
     const xh_cd a = Z[(size_t)p * D * D + pix];
     const xh_cd b = Z[(size_t)p * D * D + (size_t)ni * D + nj];
     const xh_cd f1 = xh_cd{0.5 * (a.x + b.x), 0.5 * (a.y - b.y)};
@@ -1268,7 +1270,7 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
     // rstride 1: real map; 2: real parts of an interleaved complex map
     const double *R = Rraw + (size_t)p * n * rstride;
     // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
-#define RC(i, j) (R[((size_t)(((i) - cen) & (D - 1)) * D + (((j) - cen) & (D - 1))) * rstride])
+#define RC(i, j) (R[((size_t)(((i) - cen + D) % D) * D + (((j) - cen + D) % D)) * rstride])
     double s1 = 0, s2 = 0;
     for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
     const double S1 = d_block_sum(s1, red), S2 = d_block_sum(s2, red);
@@ -1591,15 +1593,15 @@ __global__ void k_pm_crop_real(const xh_cd *__restrict__ z, double *__restrict__
     out[(size_t)r * D * D + pix] = z[(size_t)r * P * P + (size_t)(i + o) * P + (j + o)].x;
 }
 
-// generic strided complex line FFT (same as in xh_rf.hip; duplicated to keep TUs independent)
+// generic strided complex line FFT of any length (xh_plan.h: radix-2 for powers of two, Bluestein otherwise)
 template <typename T, bool INV>
 __global__ void __launch_bounds__(256)
-k_pm_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int logn, size_t nlinesTotal,
+k_pm_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal,
                size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
-    const int n = 1 << logn;
+    const int n = plan.n, M = 1 << plan.logM;
     const int tid = threadIdx.x, nth = blockDim.x;
     const size_t line0 = (size_t)blockIdx.x * lpb;
     const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
@@ -1610,15 +1612,15 @@ k_pm_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int 
             const size_t ln = line0 + l;
             v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
         }
-        s[l * n + xh_bitrev(e, logn)] = v;
+        s[l * M + xh_plan_pos(plan, e)] = v;
     }
     __syncthreads();
-    xh_fft_dit<T, INV>(s, logn, lpb, W, logn, tid, nth);
+    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
     for (int i = tid; i < lpb * n; i += nth) {
         const int e = i / lpb, l = i - e * lpb;
         if (l < nl) {
             const size_t ln = line0 + l;
-            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * n + e];
+            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
         }
     }
 }
@@ -1691,6 +1693,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
                      &pm->d_counters, &pm->d_offs5d, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
+    xh_plan_free(pm->planD);
 }
 
 template <int LOGM>
@@ -1714,8 +1717,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
                  const double *h_Mctf, int32_t paddim, xh_pm **out)
 {
     XH_CHECK(ctx && d_refs && out && nrefs > 0, XH_ERR_ARG, "xh_pm_create: bad argument");
-    XH_CHECK(h_Mctf == nullptr || (xh_is_pow2(paddim) && paddim >= D && paddim <= 4096), XH_ERR_UNSUPPORTED,
-             "xh_pm_create: the CTF filter size (paddim=%d) must be a power of two >= the image size %d", paddim, D);
+    XH_CHECK(h_Mctf == nullptr || (paddim >= D && paddim <= 2048), XH_ERR_UNSUPPORTED,
+             "xh_pm_create: the CTF filter size (paddim=%d) must lie in [image size %d, 2048]", paddim, D);
     if (Ri < 1) Ri = 1;               // APM:266-274
     if (Ro < 0) Ro = (D / 2) - 1;
     XH_CHECK(D >= 8 && Ro >= Ri && Ro < D, XH_ERR_ARG, "xh_pm_create: bad geometry D=%d Ri=%d Ro=%d", D, Ri, Ro);
@@ -1843,6 +1846,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         if (rc == XH_OK) rc = upload(ctx, pm->d_vhat, vbr);
         if (rc == XH_OK) rc = upload(ctx, pm->d_csN, csN);
         if (rc == XH_OK) rc = upload(ctx, pm->d_WD64, WD);
+        if (rc == XH_OK) rc = xh_plan_create<double>(ctx, D, pm->planD);
         if (rc == XH_OK) rc = upload(ctx, d_ringOfCoef, ringOfCoef);
         // reference library in fp64: getCurrentReference (APM:484-488) for every reference
         const int RB = 64;   // references per batch
@@ -1851,7 +1855,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refSigma, sizeof(double) * nrefs);
         if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_refCoef, sizeof(double) * (size_t)nrefs * D * D);
         std::vector<double> stat(2 * RB), sig(nrefs);
-        XhBuf d_zpad, d_WP, d_Mfull, d_refD;
+        XhBuf d_zpad, d_Mfull, d_refD;
+        XhPlanBufs<double> planP;
         if (h_Mctf && rc == XH_OK) {
             const int P = paddim;
             // full-spectrum multiplier: the reference multiplies the half spectrum (j <= P/2) index-wise; the
@@ -1862,13 +1867,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
                     const double mv = j <= P / 2 ? h_Mctf[(size_t)i * P + j] : h_Mctf[(size_t)((P - i) % P) * P + (P - j)];
                     Mfull[(size_t)i * P + j] = mv / ((double)P * P);
                 }
-            std::vector<xh_cd> WP(P / 2);
-            for (int j = 0; j < P / 2; ++j) {
-                const long double a = -2.0L * 3.14159265358979323846264338327950288L * j / P;
-                WP[j] = xh_cd{(double)cosl(a), (double)sinl(a)};
-            }
             rc = upload(ctx, d_Mfull, Mfull);
-            if (rc == XH_OK) rc = upload(ctx, d_WP, WP);
+            if (rc == XH_OK) rc = xh_plan_create<double>(ctx, P, planP);
             if (rc == XH_OK) rc = xh_buf_alloc(ctx, d_zpad, sizeof(xh_cd) * (size_t)RB * P * P);
             if (rc == XH_OK) rc = xh_buf_alloc(ctx, d_refD, sizeof(double) * (size_t)RB * D * D);
         }
@@ -1876,23 +1876,23 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             const int m = std::min(RB, nrefs - r0);
             if (h_Mctf) {
                 // pad -> FFT -> x Mctf -> IFFT -> crop (APM:457-481), then the same preparation on the filtered image
-                const int P = paddim, logP = xh_ilog2(P);
+                const int P = paddim;
                 const size_t perP = (size_t)P * P;
-                const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(P * sizeof(xh_cd))));
-                const size_t smemF = (size_t)lpb * P * sizeof(xh_cd);
+                const int lpb = xh_plan_lpb(planP.plan, 64 * 1024, 16);
+                const size_t smemF = ((size_t)lpb * sizeof(xh_cd)) << planP.plan.logM;
                 const size_t nlines = (size_t)m * P;
                 xh_cd *z = (xh_cd *)d_zpad.p;
                 hipLaunchKernelGGL(k_pm_pad_complex, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream,
                                    d_refs + (size_t)r0 * D * D, z, D, P);
                 hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
-                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
+                                   z, planP.plan, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
                 hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
-                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
+                                   z, planP.plan, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
                 hipLaunchKernelGGL(k_pm_mul_filter, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream, z, (const double *)d_Mfull.p, P);
                 hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
-                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
+                                   z, planP.plan, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
                 hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
-                                   z, (const xh_cd *)d_WP.p, logP, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
+                                   z, planP.plan, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
                 hipLaunchKernelGGL(k_pm_crop_real, dim3((unsigned)(((size_t)D * D + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)z,
                                    (double *)d_refD.p, D, P);
                 if (hipGetLastError() != hipSuccess) { xh_set_error("xh_pm_create: CTF filtering of the references failed"); rc = XH_ERR_HIP; break; }
@@ -1915,7 +1915,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             for (int i = 0; i < m; ++i) sig[r0 + i] = stat[2 * i + 1];
         }
         (void)hipStreamSynchronize(ctx->stream);
-        xh_buf_free(d_zpad); xh_buf_free(d_WP); xh_buf_free(d_Mfull); xh_buf_free(d_refD);
+        xh_buf_free(d_zpad); xh_plan_free(planP); xh_buf_free(d_Mfull); xh_buf_free(d_refD);
         if (rc == XH_OK && hipMemcpy(pm->d_refSigma.p, sig.data(), sizeof(double) * nrefs, hipMemcpyHostToDevice) != hipSuccess) {
             xh_set_error("xh_pm_create: sigma upload failed");
             rc = XH_ERR_HIP;
@@ -2276,9 +2276,8 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
     const int D = L.D;
-    XH_CHECK(xh_is_pow2(D) && D <= 2048, XH_ERR_UNSUPPORTED, "xh_pm_translate: image size %d must be a power of two", D);
+    XH_CHECK(D <= 2048, XH_ERR_UNSUPPORTED, "xh_pm_translate: image size %d exceeds 2048", D);
     if (max_shift < 0) max_shift = D / 2;    // APM:262-263
-    const int logD = xh_ilog2(D);
     const size_t per = (size_t)D * D;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)(1024u << 20) / (per * sizeof(xh_cd))));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t1, sizeof(xh_cd) * per * chunk));
@@ -2317,8 +2316,9 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         }
         return XH_OK;
     }
-    const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(D * sizeof(xh_cd))));
-    const size_t smem = (size_t)lpb * D * sizeof(xh_cd);
+    const XhPlan<double> &planD = pm->planD.plan;
+    const int lpb = xh_plan_lpb(planD, 64 * 1024, 16);
+    const size_t smem = ((size_t)lpb * sizeof(xh_cd)) << planD.logM;
     for (int p0 = 0; p0 < n; p0 += chunk) {
         const int m = std::min(chunk, n - p0);
         xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
@@ -2330,20 +2330,20 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         const size_t nlines = (size_t)m * D;
         // forward 2-D FFT of w: rows (contiguous), then columns
         hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           w, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
+                           w, planD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           w, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
+                           w, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
         XH_TRY(xh_buf_reserve(ctx, pm->d_t3, sizeof(xh_cd) * per * chunk));
         xh_cd *pw = (xh_cd *)pm->d_t3.p;
         hipLaunchKernelGGL(k_pm_crosspower, dim3((unsigned)((per + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)w, pw, D);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           pw, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
+                           pw, planD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           pw, (const xh_cd *)pm->d_WD64.p, logD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
+                           pw, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,
                            d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);

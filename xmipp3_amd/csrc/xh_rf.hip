@@ -19,6 +19,7 @@
 #include "xh_common.h"
 #include "xh_fft.h"
 #include "xh_fftreg.h"
+#include "xh_plan.h"
 #include "xh_bspline.h"
 #include <algorithm>
 #include <cmath>
@@ -211,6 +212,8 @@ struct xh_rf {
     XhBuf d_blob;     // float[10000]
     XhBuf d_twP32;    // float2 twiddles for length P
     XhBuf d_twP64;    // double2 twiddles for length P
+    XhPlanBufs<float> planP32;    // length-P line transforms of any P (xh_plan.h)
+    XhPlanBufs<double> planP64;
     XhBuf own_temp;   // 3*(mv+1)^3 floats when library-owned
     float *d_temp;    // active temp buffer
     XhBuf d_rows;     // intermediate of the 2-D FFT
@@ -240,57 +243,58 @@ struct xh_rf {
 // ---- 2-D r2c FFT of the zero-padded, centred image (RFA:332-345) ------------------------
 // pass 1: FFT along x of the D image rows; keeps kx < sizeX. rows[img][y][kx]
 __global__ void __launch_bounds__(256)
-k_rf_rows(const float *__restrict__ imgs, xh_cf *__restrict__ rows, const xh_cf *__restrict__ W,
-          int D, int logP, int sizeX, int totalLines, int lpb)
+k_rf_rows(const float *__restrict__ imgs, xh_cf *__restrict__ rows, XhPlan<float> plan,
+          int D, int sizeX, int totalLines, int lpb)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cf *s = reinterpret_cast<xh_cf *>(smem);
-    const int P = 1 << logP;
+    const int P = plan.n, M = 1 << plan.logM;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int line0 = blockIdx.x * lpb;
     const int nl = min(lpb, totalLines - line0);
-    for (int i = tid; i < lpb * P; i += nth) s[i] = xh_cf{0.f, 0.f};
+    for (int i = tid; i < lpb * M; i += nth) s[i] = xh_cf{0.f, 0.f};
     __syncthreads();
     const int half = D / 2;  // -FIRST_XMIPP_INDEX(D)
     for (int i = tid; i < nl * D; i += nth) {
         const int l = i / D, x = i - l * D;
         const int xl = x - half;              // logical coordinate
-        const int px = xl & (P - 1);          // (xl mod P): pad centred + CenterFFT(.,true)
-        s[l * P + xh_bitrev(px, logP)].x = imgs[(size_t)(line0 + l) * D + x];
+        const int px = xl < 0 ? xl + P : xl;  // (xl mod P): pad centred + CenterFFT(.,true)
+        s[l * M + xh_plan_pos(plan, px)].x = imgs[(size_t)(line0 + l) * D + x];
     }
     __syncthreads();
-    xh_fft_dit<float, false>(s, logP, lpb, W, logP, tid, nth);
+    xh_plan_exec<float, false>(s, plan, lpb, tid, nth);
     for (int i = tid; i < nl * sizeX; i += nth) {
         const int l = i / sizeX, k = i - l * sizeX;
-        rows[(size_t)(line0 + l) * sizeX + k] = s[l * P + k];
+        rows[(size_t)(line0 + l) * sizeX + k] = s[l * M + k];
     }
 }
 
 // pass 2: FFT along y for each kept kx, then cropAndShift (RFA:271-298):
 // out[img][myPadI][kx] for rows i < sizeX or i >= P-sizeX with freq^2 <= maxRes^2, scaled 1/P^2
 __global__ void __launch_bounds__(256)
-k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *__restrict__ W,
-          int D, int logP, int sizeX, double maxResSqr, int lpb)
+k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, XhPlan<float> plan,
+          int D, int sizeX, double maxResSqr, int lpb)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cf *s = reinterpret_cast<xh_cf *>(smem);
-    const int P = 1 << logP;
+    const int P = plan.n, M = 1 << plan.logM;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int groupsPerImg = (sizeX + lpb - 1) / lpb;
     const int img = blockIdx.x / groupsPerImg;
     const int kx0 = (blockIdx.x - img * groupsPerImg) * lpb;
     const int nl = min(lpb, sizeX - kx0);
-    for (int i = tid; i < lpb * P; i += nth) s[i] = xh_cf{0.f, 0.f};
+    for (int i = tid; i < lpb * M; i += nth) s[i] = xh_cf{0.f, 0.f};
     __syncthreads();
     const int half = D / 2;
     const xh_cf *src = rows + (size_t)img * D * sizeX;
     for (int i = tid; i < D * nl; i += nth) {
         const int y = i / nl, l = i - y * nl;
-        const int py = (y - half) & (P - 1);
-        s[l * P + xh_bitrev(py, logP)] = src[(size_t)y * sizeX + kx0 + l];
+        const int yl = y - half;
+        const int py = yl < 0 ? yl + P : yl;
+        s[l * M + xh_plan_pos(plan, py)] = src[(size_t)y * sizeX + kx0 + l];
     }
     __syncthreads();
-    xh_fft_dit<float, false>(s, logP, lpb, W, logP, tid, nth);
+    xh_plan_exec<float, false>(s, plan, lpb, tid, nth);
     const float scale = 1.0f / ((float)P * (float)P);
     const int sizeY = 2 * sizeX;
     xh_cf *dst = out + (size_t)img * sizeY * sizeX;
@@ -302,7 +306,7 @@ k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf *
         const double fy = (double)(ii <= P / 2 ? ii : ii - P) / (double)P;
         xh_cf v = xh_cf{0.f, 0.f};
         if (!(fx * fx + fy * fy > maxResSqr)) {
-            v = s[l * P + ii];
+            v = s[l * M + ii];
             v.x *= scale;
             v.y *= scale;
         }
@@ -1342,12 +1346,12 @@ __global__ void k_rf_expand(const xh_cf *__restrict__ V, xh_cd *__restrict__ out
 // 3-D inverse transform. line l -> base offset (l / inner) * outerStride + (l % inner) * innerStride
 template <typename T, bool INV>
 __global__ void __launch_bounds__(256)
-k_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int logn, size_t nlinesTotal,
+k_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal,
             size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
-    const int n = 1 << logn;
+    const int n = plan.n, M = 1 << plan.logM;
     const int tid = threadIdx.x, nth = blockDim.x;
     const size_t line0 = (size_t)blockIdx.x * lpb;
     const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
@@ -1358,15 +1362,15 @@ k_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int log
             const size_t ln = line0 + l;
             v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
         }
-        s[l * n + xh_bitrev(e, logn)] = v;
+        s[l * M + xh_plan_pos(plan, e)] = v;
     }
     __syncthreads();
-    xh_fft_dit<T, INV>(s, logn, lpb, W, logn, tid, nth);
+    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
     for (int i = tid; i < lpb * n; i += nth) {
         const int e = i / lpb, l = i - e * lpb;
         if (l < nl) {
             const size_t ln = line0 + l;
-            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * n + e];
+            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
         }
     }
 }
@@ -1374,13 +1378,13 @@ k_fft_lines(xh_c2<T> *__restrict__ data, const xh_c2<T> *__restrict__ W, int log
 // last pass of the 3-D c2r inverse + CenterFFT(.,false) + window to D^3 + blob/sinc correction
 // (RFA:1028-1052). One line = (z,y) of the padded volume; only lines inside the window run.
 __global__ void __launch_bounds__(256)
-k_rf_c2r_window(const xh_cd *__restrict__ F, const xh_cd *__restrict__ W, double *__restrict__ vol,
-                const double *__restrict__ fourierBlob, int logP, int D, double iDeltaFourier,
+k_rf_c2r_window(const xh_cd *__restrict__ F, XhPlan<double> plan, double *__restrict__ vol,
+                const double *__restrict__ fourierBlob, int D, double iDeltaFourier,
                 double ipad_relation, double meanFactor2, int lpb)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cd *s = reinterpret_cast<xh_cd *>(smem);
-    const int P = 1 << logP, xh = P / 2 + 1;
+    const int P = plan.n, M = 1 << plan.logM, xh = P / 2 + 1;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int line0 = blockIdx.x * lpb;
     const int totalLines = D * D;
@@ -1392,23 +1396,23 @@ k_rf_c2r_window(const xh_cd *__restrict__ F, const xh_cd *__restrict__ W, double
         if (l < nl) {
             const int ln = line0 + l;
             const int k = ln / D, ii = ln - k * D;          // output (z,y) index in the window
-            const int rk = (k + s0) & (P - 1), ri = (ii + s0) & (P - 1);  // raw FFT indices
+            const int rk = (k + s0 + P) % P, ri = (ii + s0 + P) % P;      // raw FFT indices
             const xh_cd *row = F + ((size_t)rk * P + ri) * xh;
             // Hermitian extension of the half row; c2r ignores Im of DC and Nyquist
             if (e < xh) { v = row[e]; if (e == 0 || 2 * e == P) v.y = 0; }
             else { v = row[P - e]; v.y = -v.y; }
         }
-        s[l * P + xh_bitrev(e, logP)] = v;
+        s[l * M + xh_plan_pos(plan, e)] = v;
     }
     __syncthreads();
-    xh_fft_dit<double, true>(s, logP, lpb, W, logP, tid, nth);
+    xh_plan_exec<double, true>(s, plan, lpb, tid, nth);
     for (int i = tid; i < nl * D; i += nth) {
         const int l = i / D, j = i - l * D;
         const int ln = line0 + l;
         const int k = ln / D, ii = ln - k * D;
         const int lk = k + s0, li = ii + s0, lj = j + s0;
-        const int rj = lj & (P - 1);
-        double val = s[l * P + rj].x;
+        const int rj = (lj + P) % P;
+        double val = s[l * M + rj].x;
         const double radius = sqrt((double)(lk * lk + li * li + lj * lj));
         const double aux = radius * iDeltaFourier;
         const double factor = fourierBlob[(int)floor(aux + 0.5)];
@@ -1480,8 +1484,8 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->mv = 2 * (int)conserveRows;
     rf->sizeX = rf->mv / 2;
     rf->sizeY = rf->mv;
-    if (!xh_is_pow2(rf->P) || rf->P > 4096 || rf->mv > rf->P) {
-        xh_set_error("xh_rf_create: padded size %d (imgSize %d x padding %g) must be a power of two <= 4096 "
+    if (rf->P > 2048 || rf->mv > rf->P) {
+        xh_set_error("xh_rf_create: padded size %d (imgSize %d x padding %g) must be <= 2048 "
                      "and max_resolution <= 0.5 for the device FFT", rf->P, rf->D, p->padding_vol);
         delete rf;
         return XH_ERR_UNSUPPORTED;
@@ -1519,6 +1523,8 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     int r = xh_buf_alloc(ctx, rf->d_blob, sizeof(float) * XH_BLOB_TABLE);
     if (r == XH_OK) r = (hipMemcpy(rf->d_blob.p, rf->blobTableSqrt.data(), rf->d_blob.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     if (r == XH_OK) r = make_twiddles(ctx, rf->P, rf->d_twP32, rf->d_twP64);
+    if (r == XH_OK) r = xh_plan_create<float>(ctx, rf->P, rf->planP32);
+    if (r == XH_OK) r = xh_plan_create<double>(ctx, rf->P, rf->planP64);
     rf->ntiles = 0;
     if (r == XH_OK) {
         // tiles that a projection can reach (sphere of radius sizeX + blob), heaviest (central) first
@@ -1562,6 +1568,7 @@ int xh_rf_destroy(xh_rf *rf)
     if (!rf) return XH_OK;
     (void)hipStreamSynchronize(rf->ctx->stream);
     xh_buf_free(rf->d_blob); xh_buf_free(rf->d_twP32); xh_buf_free(rf->d_twP64);
+    xh_plan_free(rf->planP32); xh_plan_free(rf->planP64);
     xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
@@ -1664,12 +1671,13 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
     XH_CHECK(rf && d_imgs && d_fft && n >= 0, XH_ERR_ARG, "xh_rf_prepare_images: bad argument");
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
-    const int D = rf->D, P = rf->P, logP = xh_ilog2(P), sizeX = rf->sizeX;
+    const int D = rf->D, P = rf->P, sizeX = rf->sizeX;
     // chunk so that the row-pass intermediate stays modest
     const int chunk = std::max(1, std::min(n, (int)((256u << 20) / ((size_t)D * sizeX * sizeof(xh_cf)))));
     XH_TRY(xh_buf_reserve(ctx, rf->d_rows, (size_t)chunk * D * sizeX * sizeof(xh_cf)));
-    const int lpb = std::max(1, std::min(16, (64 * 1024) / (int)(P * sizeof(xh_cf))));
-    const size_t smem = (size_t)lpb * P * sizeof(xh_cf);
+    const XhPlan<float> &plan = rf->planP32.plan;
+    const int lpb = xh_plan_lpb(plan, 64 * 1024, 16);
+    const size_t smem = ((size_t)lpb * sizeof(xh_cf)) << plan.logM;
     const double maxResSqr = rf->p.max_resolution * rf->p.max_resolution;
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
@@ -1692,13 +1700,11 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
             continue;
         }
         hipLaunchKernelGGL(k_rf_rows, dim3((totalLines + lpb - 1) / lpb), dim3(256), smem, ctx->stream,
-                           d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, (const xh_cf *)rf->d_twP32.p, D,
-                           logP, sizeX, totalLines, lpb);
+                           d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, plan, D, sizeX, totalLines, lpb);
         XH_LAUNCH_CHECK();
         const int groups = (sizeX + lpb - 1) / lpb;
         hipLaunchKernelGGL(k_rf_cols, dim3(m * groups), dim3(256), smem, ctx->stream, (const xh_cf *)rf->d_rows.p,
-                           (xh_cf *)d_fft + (size_t)i0 * rf->sizeY * sizeX, (const xh_cf *)rf->d_twP32.p, D, logP,
-                           sizeX, maxResSqr, lpb);
+                           (xh_cf *)d_fft + (size_t)i0 * rf->sizeY * sizeX, plan, D, sizeX, maxResSqr, lpb);
         XH_LAUNCH_CHECK();
     }
     return XH_OK;
@@ -1932,7 +1938,7 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     XH_CHECK(rf && h_volume, XH_ERR_ARG, "null argument");
     XH_CHECK(rf->cropped, XH_ERR_STATE, "xh_rf_finish: call xh_rf_mirror_and_crop first (RFA:149-152)");
     xh_ctx *ctx = rf->ctx;
-    const int mv = rf->mv, P = rf->P, D = rf->D, logP = xh_ilog2(P), xh = P / 2 + 1;
+    const int mv = rf->mv, P = rf->P, D = rf->D, xh = P / 2 + 1;
     const size_t d = mv + 1, nx = mv / 2 + 1, total = d * d * nx;
     xh_cf *V = (xh_cf *)rf->d_temp;
     float *W = rf->d_temp + 2 * total;
@@ -1964,20 +1970,21 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     XH_HIP_C(hipMemcpyAsync(fbt.p, rf->fourierBlobTable.data(), fbt.bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_rf_expand, dim3((unsigned)((specElems + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)V, (xh_cd *)spec.p, mv, P);
     XH_HIP_C(hipGetLastError());
-    const int lpb = std::max(1, std::min(8, (64 * 1024) / (int)(P * sizeof(xh_cd))));
-    const size_t smem = (size_t)lpb * P * sizeof(xh_cd);
+    const XhPlan<double> &plan = rf->planP64.plan;
+    const int lpb = xh_plan_lpb(plan, 64 * 1024, 8);
+    const size_t smem = ((size_t)lpb * sizeof(xh_cd)) << plan.logM;
     // inverse along z: lines (y,x), element stride P*xh
     {
         const size_t nlines = (size_t)P * xh;
         hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           (xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, logP, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
+                           (xh_cd *)spec.p, plan, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
         XH_HIP_C(hipGetLastError());
     }
     // inverse along y: lines (z,x): offset z*P*xh + x, element stride xh
     {
         const size_t nlines = (size_t)P * xh;
         hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           (xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, logP, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
+                           (xh_cd *)spec.p, plan, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
         XH_HIP_C(hipGetLastError());
     }
     // meanFactor2 = mean over the D^3 window of sinc^2(radius/(2D)) (RFA:1040-1050). It depends on D only:
@@ -2007,7 +2014,7 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     const double pr0 = rf->p.padding_proj / rf->p.padding_vol;
     const double ipad_relation = 1.0 / (pr0 * pr0 * pr0);
     hipLaunchKernelGGL(k_rf_c2r_window, dim3((unsigned)(((size_t)D * D + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                       (const xh_cd *)spec.p, (const xh_cd *)rf->d_twP64.p, (double *)vol.p, (const double *)fbt.p, logP, D,
+                       (const xh_cd *)spec.p, plan, (double *)vol.p, (const double *)fbt.p, D,
                        (double)rf->iDeltaFourier, ipad_relation, meanFactor2, lpb);
     XH_HIP_C(hipGetLastError());
     XH_HIP_C(hipMemcpyAsync(h_volume, vol.p, vol.bytes, hipMemcpyDeviceToHost, ctx->stream));
