@@ -157,3 +157,37 @@ def test_cli_5d_search_and_number_orientations(bins, tmp_path, oracle):
             assert abs(float(row[c["anglePsi"]]) - ep[i, o] * 360.0 / pm.N) < 1e-5
             assert abs(float(row[c["shiftX"]]) - ex[0]) < 1e-3 and abs(float(row[c["shiftY"]]) - ey[0]) < 1e-3
             assert abs(float(row[c["maxCC"]]) - ec[0]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_cli_symmetry_names_and_files(bins, tmp_path, oracle):
+    """--sym d2 (built-in: 2-fold about Z and about X) == the same group given as a symmetry file of
+    rot_axis lines == the oracle summing over {I, Rz(180), Rx(180), Ry(180)}."""
+    D, n = 32, 7
+    vol = synth.phantom(D, seed=9, nblobs=8)
+    ang = synth.random_angles(n, np.random.default_rng(2))
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "p.stk"), imgs)
+    xmipp_io.write_xmd(str(tmp_path / "in.xmd"), [("noname", ["image", "angleRot", "angleTilt", "anglePsi"],
+                                                  [[f"{i + 1}@{tmp_path}/p.stk"] + [f"{v:.6f}" for v in ang[i]] for i in range(n)])])
+    (tmp_path / "d2.sym").write_text("# dihedral, order 4\nrot_axis 2 0 0 1\nrot_axis 2 1 0 0\n")
+    vols = {}
+    for tag, sym in (("name", "d2"), ("file", str(tmp_path / "d2.sym"))):
+        r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / f"{tag}.vol"),
+                  "--sym", sym])
+        assert r.returncode == 0, r.stderr
+        vols[tag] = xmipp_io.read_volume(str(tmp_path / f"{tag}.vol"))
+    assert np.abs(vols["name"] - vols["file"]).max() <= 2e-6 * np.abs(vols["name"]).max()
+    rf = oracle.RF(D)
+    Rs = [np.eye(3), np.diag([-1.0, -1.0, 1.0]), np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, 1.0, -1.0])]
+    ang6 = np.round(ang, 6)          # the metadata carries 6 decimals
+    for i in range(n):
+        f = rf.prepare_image(imgs[i])
+        for R in Rs:
+            rf.insert(f, synth.euler_matrix(*ang6[i]).T, R=R)
+    rf.mirror_and_crop()
+    exp = rf.finish()
+    assert np.abs(vols["name"] - exp).max() <= 1e-4 * np.abs(exp).max()
+    # an unknown name must fail loudly, not reconstruct without symmetry
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i3"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr

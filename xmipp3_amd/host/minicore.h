@@ -278,23 +278,96 @@ inline void writeStack(const std::string &path, const float *data, size_t x, siz
 
 // ------------------------------------------------------------------ symmetries (cyclic groups)
 class SymList {
+    // rotation by 360/fold about axis (unit-normalised), Rodrigues
+    static std::vector<double> rotAxis(double ang, double x, double y, double z)
+    {
+        const double n = std::sqrt(x * x + y * y + z * z);
+        x /= n; y /= n; z /= n;
+        const double c = std::cos(ang), s = std::sin(ang), t = 1 - c;
+        return {t * x * x + c,     t * x * y - s * z, t * x * z + s * y,
+                t * x * y + s * z, t * y * y + c,     t * y * z - s * x,
+                t * x * z - s * y, t * y * z + s * x, t * z * z + c};
+    }
+    static std::vector<double> mul(const std::vector<double> &A, const std::vector<double> &B)
+    {
+        std::vector<double> C(9, 0.);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) C[i * 3 + j] += A[i * 3 + k] * B[k * 3 + j];
+        return C;
+    }
+    static bool same(const std::vector<double> &A, const std::vector<double> &B)
+    {
+        for (int i = 0; i < 9; ++i)
+            if (std::fabs(A[i] - B[i]) > 1e-6) return false;
+        return true;
+    }
+    // closure of the group generated by `gens` (what SymList::computeSubgroup does in xmippCore); identity excluded
+    void close(const std::vector<std::vector<double>> &gens)
+    {
+        const std::vector<double> I = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::vector<std::vector<double>> G = {I};
+        bool grew = true;
+        while (grew) {
+            grew = false;
+            const size_t n0 = G.size();
+            for (size_t a = 0; a < n0; ++a)
+                for (const auto &g : gens) {
+                    const auto P = mul(G[a], g);
+                    bool known = false;
+                    for (const auto &h : G)
+                        if (same(h, P)) { known = true; break; }
+                    if (!known) { G.push_back(P); grew = true; }
+                    if (G.size() > 240) REPORT_ERROR(ERR_VALUE_INCORRECT, "SymList: the generators do not close into a finite point group");
+                }
+        }
+        R.assign(G.begin() + 1, G.end());
+    }
 public:
     std::vector<std::vector<double>> R;   // 3x3 row-major, identity excluded (as SL.getMatrices)
+    // Accepts what the reference's --sym takes (RFA:243-251): a point-group name or a symmetry file with
+    // `rot_axis <fold> <x> <y> <z>` lines (xmippCore SymList::readSymmetryFile). Reconstruction sums over
+    // the whole group, so only the SET of rotations matters. Built-in names: cN, dN (N-fold about Z and,
+    // for dN, a 2-fold about X); the cubic groups come in several orientation conventions (i1..i4, ...)
+    // defined in xmippCore, whose source is not in the reference tree -- pass them as a symmetry file.
     void readSymmetryFile(const std::string &sym)
     {
         R.clear();
-        std::string s = sym;
-        std::transform(s.begin(), s.end(), s.begin(), ::tolower);
-        if (s.size() >= 2 && s[0] == 'c' && std::all_of(s.begin() + 1, s.end(), ::isdigit)) {
-            const int n = atoi(s.c_str() + 1);
-            if (n < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "SymList: bad symmetry " + sym);
-            for (int k = 1; k < n; ++k) {
-                const double a = 2 * M_PI * k / n, c = std::cos(a), sn = std::sin(a);
-                R.push_back({c, sn, 0, -sn, c, 0, 0, 0, 1});
+        std::ifstream f(sym);
+        if (f.good()) {
+            std::vector<std::vector<double>> gens;
+            std::string line;
+            while (std::getline(f, line)) {
+                line = trim(line);
+                if (line.empty() || line[0] == '#' || line[0] == ';') continue;
+                std::istringstream is(line);
+                std::string kw;
+                is >> kw;
+                if (kw == "rot_axis") {
+                    int fold = 0;
+                    double x = 0, y = 0, z = 0;
+                    if (!(is >> fold >> x >> y >> z) || fold < 2 || (x == 0 && y == 0 && z == 0))
+                        REPORT_ERROR(ERR_VALUE_INCORRECT, "SymList: bad line in " + sym + ": " + line);
+                    gens.push_back(rotAxis(2 * M_PI / fold, x, y, z));
+                } else
+                    REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: '" + kw + "' in " + sym + " (only proper rotations, rot_axis, are supported)");
             }
+            close(gens);
             return;
         }
-        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is not available in this build (cyclic groups cN only)");
+        std::string s = sym;
+        std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd') && std::all_of(s.begin() + 1, s.end(), ::isdigit)) {
+            const int n = atoi(s.c_str() + 1);
+            if (n < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "SymList: bad symmetry " + sym);
+            std::vector<std::vector<double>> gens;
+            if (n > 1) gens.push_back(rotAxis(2 * M_PI / n, 0, 0, 1));
+            if (s[0] == 'd') gens.push_back(rotAxis(M_PI, 1, 0, 0));
+            close(gens);
+            return;
+        }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is neither a readable symmetry file nor cN/dN; "
+                     "write the group's rot_axis lines to a file and pass that");
     }
     int symsNo() const { return (int)R.size(); }
 };
