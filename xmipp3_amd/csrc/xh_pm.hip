@@ -117,7 +117,8 @@ struct xh_pm {
     int64_t stat_rows, stat_resc_p, stat_resc_r;
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
-    int use_idft3, use_mfma, contract_dbg;
+    int use_idft3, use_mfma, contract_dbg, use_fir;
+    XhBuf d_firTmp, d_polarPart;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
 };
@@ -136,6 +137,58 @@ __device__ __forceinline__ double d_block_sum(double v, double *red)
     return t;
 }
 
+// ---- cubic B-spline prefilter of the fp32 coarse pass as a convolution -----------------------------
+// The recursive filter (pole z = sqrt(3)-2, half-sample-symmetric boundary; k_pm_prefilter_rows/cols)
+// is, exactly, the convolution of the mirror-extended samples with h[j] = sqrt(3) z^|j|. The recursion is
+// a 2*D-step dependent chain per line (latency-bound: 1.5 us per 256-px image); z^17 < 2e-10 is below
+// fp32 resolution, so the coarse pass uses the 33-tap form, every output independent, eight outputs per
+// thread from one 40-sample window. The fp64 paths (reference library, re-scoring) keep the recursion.
+#define XH_FIR_K 16
+#define XH_FIR_V 8
+struct XhFir { float h[XH_FIR_K + 1]; };
+template <bool COLS>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D, size_t nvec, XhFir F)
+{
+    // thread <-> XH_FIR_V consecutive outputs along the filtered axis; neighbouring threads are neighbours
+    // along x for the column pass (coalesced rows) and along the line for the row pass
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+    int x0, y0;
+    size_t img;
+    if (COLS) { x0 = t % D; y0 = (int)((t / D) % segs) * XH_FIR_V; img = t / ((size_t)D * segs); }
+    else { x0 = (int)(t % segs) * XH_FIR_V; y0 = (int)((t / segs) % D); img = t / ((size_t)segs * D); }
+    const float *src = in + img * D * D;
+    float w[XH_FIR_V + 2 * XH_FIR_K];
+    if (!COLS && (D & 3) == 0 && x0 >= XH_FIR_K && x0 + XH_FIR_V + XH_FIR_K <= D) {
+        // interior of a row: the window is 16-byte aligned (x0 and XH_FIR_K are multiples of 4), ten float4 loads
+        const float4 *v = reinterpret_cast<const float4 *>(src + (size_t)y0 * D + x0 - XH_FIR_K);
+#pragma unroll
+        for (int i = 0; i < (XH_FIR_V + 2 * XH_FIR_K) / 4; ++i) {
+            const float4 q = v[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+    } else
+#pragma unroll
+    for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
+        int p = (COLS ? y0 : x0) + i - XH_FIR_K;
+        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
+        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        w[i] = COLS ? src[(size_t)p * D + x0] : src[(size_t)y0 * D + p];
+    }
+#pragma unroll
+    for (int o = 0; o < XH_FIR_V; ++o) {
+        const int q = (COLS ? y0 : x0) + o;
+        if (q >= D) break;
+        float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+        if (COLS) out[img * D * D + (size_t)q * D + x0] = acc;
+        else out[img * D * D + (size_t)y0 * D + q] = acc;
+    }
+}
+
 // polar sampling + ring-weighted statistics; one block per particle slot.
 // stat[slot] = (mean, sigma)
 template <typename T>
@@ -143,10 +196,12 @@ __global__ void __launch_bounds__(256)
 k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restrict__ stat,
            const float *__restrict__ sinr, const float *__restrict__ cosr, const short *__restrict__ ringOf,
            const int *__restrict__ nsam, int D, int Ri, int nsamples, double xoff, double yoff,
-           const int *__restrict__ count, int nt, const double *__restrict__ offs)
+           const int *__restrict__ count, int nt, const double *__restrict__ offs, int nparts, double *__restrict__ partial)
 {
     __shared__ double red[8];
-    const int slot = blockIdx.x;
+    // nparts workgroups share a slot (the fp32 pass: a few hundred slots per launch would leave most of
+    // the chip idle); their partial sums are combined in a fixed order by k_pm_polar_stats
+    const int slot = blockIdx.x / nparts, part = blockIdx.x - slot * nparts;
     // 5-D search (APM:575-589): slot = image*nt + itrans, every translation resamples the same coefficients
     if (count && slot / nt >= *count) return;
     const T *c = coefs + (size_t)(slot / nt) * D * D;
@@ -154,7 +209,9 @@ k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restric
     const T minp = (T)(-(D / 2)), maxp = (T)(-(D / 2) + D - 1);
     const T eps = (T)1e-6;
     double sw = 0, swv = 0, swv2 = 0;
-    for (int i = threadIdx.x; i < nsamples; i += blockDim.x) {
+    const int per = (nsamples + nparts - 1) / nparts;
+    const int iEnd = min(nsamples, (part + 1) * per);
+    for (int i = part * per + threadIdx.x; i < iEnd; i += blockDim.x) {
         T xp = (T)sinr[i] + (T)xoff;
         T yp = (T)cosr[i] + (T)yoff;
         if (xp < minp - eps || xp > maxp + eps) xp = d_realwrap<T>(xp, minp - (T)0.5, maxp + (T)0.5);
@@ -170,11 +227,30 @@ k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restric
     const double S = d_block_sum(swv, red);
     const double S2 = d_block_sum(swv2, red);
     if (threadIdx.x == 0) {
-        double avg = 0, sd = 0;
-        if (N > 0) { avg = S / N; sd = sqrt(fabs(S2 / N - avg * avg)); }
-        stat[2 * slot] = avg;
-        stat[2 * slot + 1] = sd;
+        if (nparts > 1) {
+            double *o = partial + ((size_t)slot * nparts + part) * 3;
+            o[0] = N; o[1] = S; o[2] = S2;
+        } else {
+            double avg = 0, sd = 0;
+            if (N > 0) { avg = S / N; sd = sqrt(fabs(S2 / N - avg * avg)); }
+            stat[2 * slot] = avg;
+            stat[2 * slot + 1] = sd;
+        }
     }
+}
+__global__ void k_pm_polar_stats(const double *__restrict__ partial, double *__restrict__ stat, int nslots, int nparts)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    double N = 0, S = 0, S2 = 0;
+    for (int p = 0; p < nparts; ++p) {
+        const double *o = partial + ((size_t)slot * nparts + p) * 3;
+        N += o[0]; S += o[1]; S2 += o[2];
+    }
+    double avg = 0, sd = 0;
+    if (N > 0) { avg = S / N; sd = sqrt(fabs(S2 / N - avg * avg)); }
+    stat[2 * slot] = avg;
+    stat[2 * slot + 1] = sd;
 }
 
 // per-ring direct DFT of (samples - mean), divided by nsam; optional conjugation.
@@ -1641,6 +1717,19 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     XH_TRY(xh_buf_reserve(ctx, polarBuf, sizeof(T) * nps * L.nsamples));
     XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * nps * L.ncoef));
     XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * nps));
+    if (std::is_same<T, float>::value && imgsAreFloat && !d_gather && !d_count && pm->use_fir && D >= 2 * XH_FIR_K) {
+        XhFir F;
+        const double z = std::sqrt(3.0) - 2.0;
+        for (int j = 0; j <= XH_FIR_K; ++j) F.h[j] = (float)(std::sqrt(3.0) * std::pow(z, j));
+        const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+        const size_t nvec = (size_t)nslots * D * segs;
+        XH_TRY(xh_buf_reserve(ctx, pm->d_firTmp, sizeof(float) * (size_t)nslots * D * D));
+        hipLaunchKernelGGL((k_pm_prefilter_fir<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)imgs, (float *)pm->d_firTmp.p, D, nvec, F);
+        hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)pm->d_firTmp.p, (float *)coefBuf.p, D, nvec, F);
+        XH_LAUNCH_CHECK();
+    } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(T)))));
     const int tiles = (D + TR - 1) / TR;
     const size_t smem = sizeof(T) * TR * (D + 1);
@@ -1654,11 +1743,22 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     hipLaunchKernelGGL((k_pm_prefilter_cols<T>), dim3((nslots * D + 63) / 64), dim3(64), 0, ctx->stream,
                        (T *)coefBuf.p, D, nslots, d_count);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_pm_polar<T>), dim3((unsigned)nps), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
+    }
+    // fp32 pass: split every slot over a few workgroups when the launch alone cannot fill the chip
+    int nparts = 1;
+    if (std::is_same<T, float>::value && !d_count)
+        while (nparts < 8 && nps * nparts < (size_t)ctx->num_cus * 8 && L.nsamples / (2 * nparts) >= 2048) nparts *= 2;
+    if (nparts > 1) XH_TRY(xh_buf_reserve(ctx, pm->d_polarPart, sizeof(double) * 3 * nps * nparts));
+    hipLaunchKernelGGL((k_pm_polar<T>), dim3((unsigned)(nps * nparts)), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
                        (double *)statBuf.p, (const float *)pm->d_sin.p, (const float *)pm->d_cos.p,
                        (const short *)pm->d_ringOfSample.p, (const int *)pm->d_nsam.p, D, L.Ri, L.nsamples, xoff, yoff,
-                       d_count, nt, d_offs);
+                       d_count, nt, d_offs, nparts, (double *)pm->d_polarPart.p);
     XH_LAUNCH_CHECK();
+    if (nparts > 1) {
+        hipLaunchKernelGGL(k_pm_polar_stats, dim3((unsigned)((nps + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)pm->d_polarPart.p, (double *)statBuf.p, (int)nps, nparts);
+        XH_LAUNCH_CHECK();
+    }
     if (std::is_same<T, float>::value && !d_count && pm->use_mfma) {
         const size_t smemM = sizeof(float) * 32 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
         hipLaunchKernelGGL(k_pm_ringdft_mfma, dim3(L.nrings, (unsigned)((nps + 31) / 32)), dim3(256), smemM, ctx->stream,
@@ -1691,7 +1791,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -1746,6 +1846,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tau_rel = 3e-6;   // measured fp32 error of a normalised row: 1.6e-7*S (D=256), 1.8e-7*S (D=64)
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
+    pm->use_fir = 1;
     pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
@@ -1992,6 +2093,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
+    else if (!strcmp(name, "use_fir")) pm->use_fir = (int)value;
     else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
