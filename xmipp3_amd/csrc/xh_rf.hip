@@ -932,45 +932,69 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 sRec[pos] = r;
             }
             __syncthreads();
-            for (int h = 0; h < (dbg == 2 ? 0 : total); ++h) {
-                // wave-uniform cull against the 4^3 sub-cube (LDS broadcast reads)
-                const float4 r2 = sRec[h].r2, r0 = sRec[h].r0;
-                const float dn = r2.x * c4x + r2.y * c4y + r2.z * c4z;
-                const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
-                if (!((fabsf(dn) <= fr + rho4) && (dx >= -(fr + rho4)) && (dx <= sizeX + fr + rho4))) continue;
-                const float4 r1 = sRec[h].r1;
-                const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
-                bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
-                float ix = 0.f, iy = 0.f, zSqr = 0.f;
-                if (pass) {
-                    ix = r0.x * px + r0.y * py + r0.z * pz;
-                    iy = r1.x * px + r1.y * py + r1.z * pz;
-                    const float iz = r2.x * px + r2.y * py + r2.z * pz;
-                    iy += mv / 2;
-                    zSqr = iz * iz;
-                    pass = !(zSqr > radiusSqr);
-                    // a voxel with no pixel within reach adds nothing: drop it before the costly part
-                    pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
-                           ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+            // wave-level cull against the 4^3 sub-cube, 64 survivors at a time (lane <-> survivor), then only
+            // the sub-cube's own survivors are visited; the next survivor's record is fetched from LDS while
+            // the current one is tested, so its latency no longer sits between iterations
+            for (int hb = 0; hb < (dbg == 2 ? 0 : total); hb += 64) {
+                bool keep = false;
+                if (hb + lane < total) {
+                    const float4 r2 = sRec[hb + lane].r2, r0 = sRec[hb + lane].r0;
+                    const float dn = r2.x * c4x + r2.y * c4y + r2.z * c4z;
+                    const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
+                    keep = (fabsf(dn) <= fr + rho4) && (dx >= -(fr + rho4)) && (dx <= sizeX + fr + rho4);
                 }
-                const unsigned long long pb = __ballot(pass);
-                const int np = __popcll(pb);
-                if (np == 0) continue;
-                if (pass) {
-                    const int q = qn + __popcll(pb & ((1ull << lane) - 1ull));
-                    qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
-                    qMeta[wv][q] = (sHit[h] << 6) | lane;
-                }
-                qn += np;
-                if (qn >= 64) {
-                    process(64, y0, z0);
-                    // move the remainder down (source index >= 64 > destination)
-                    const int rem = qn - 64;
-                    float a = 0.f, b = 0.f, c = 0.f;
-                    int m = 0;
-                    if (lane < rem) { a = qIx[wv][64 + lane]; b = qIy[wv][64 + lane]; c = qZs[wv][64 + lane]; m = qMeta[wv][64 + lane]; }
-                    if (lane < rem) { qIx[wv][lane] = a; qIy[wv][lane] = b; qZs[wv][lane] = c; qMeta[wv][lane] = m; }
-                    qn = rem;
+                unsigned long long todo = __ballot(keep);
+                if (!todo) continue;
+                int h = hb + __builtin_ctzll(todo);
+                todo &= todo - 1;
+                float4 r0 = sRec[h].r0, r1 = sRec[h].r1, r2 = sRec[h].r2;
+                int hitId = sHit[h];
+                for (;;) {
+                    const bool more = todo != 0;
+                    float4 n0 = r0, n1 = r1, n2 = r2;
+                    int nHit = hitId;
+                    if (more) {
+                        const int hn = hb + __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        n0 = sRec[hn].r0; n1 = sRec[hn].r1; n2 = sRec[hn].r2;
+                        nHit = sHit[hn];
+                    }
+                    const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
+                    bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
+                    float ix = 0.f, iy = 0.f, zSqr = 0.f;
+                    if (pass) {
+                        ix = r0.x * px + r0.y * py + r0.z * pz;
+                        iy = r1.x * px + r1.y * py + r1.z * pz;
+                        const float iz = r2.x * px + r2.y * py + r2.z * pz;
+                        iy += mv / 2;
+                        zSqr = iz * iz;
+                        pass = !(zSqr > radiusSqr);
+                        // a voxel with no pixel within reach adds nothing: drop it before the costly part
+                        pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
+                               ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+                    }
+                    const unsigned long long pb = __ballot(pass);
+                    const int np = __popcll(pb);
+                    if (np != 0) {
+                        if (pass) {
+                            const int q = qn + __popcll(pb & ((1ull << lane) - 1ull));
+                            qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
+                            qMeta[wv][q] = (hitId << 6) | lane;
+                        }
+                        qn += np;
+                        if (qn >= 64) {
+                            process(64, y0, z0);
+                            // move the remainder down (source index >= 64 > destination)
+                            const int rem = qn - 64;
+                            float a = 0.f, b = 0.f, c = 0.f;
+                            int m = 0;
+                            if (lane < rem) { a = qIx[wv][64 + lane]; b = qIy[wv][64 + lane]; c = qZs[wv][64 + lane]; m = qMeta[wv][64 + lane]; }
+                            if (lane < rem) { qIx[wv][lane] = a; qIy[wv][lane] = b; qZs[wv][lane] = c; qMeta[wv][lane] = m; }
+                            qn = rem;
+                        }
+                    }
+                    if (!more) break;
+                    r0 = n0; r1 = n1; r2 = n2; hitId = nHit;
                 }
             }
             __syncthreads();
