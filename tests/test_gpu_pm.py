@@ -143,6 +143,29 @@ def test_match_any_box_size(gpu, oracle):
         assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
 
 
+def test_config2_shape_d128_many_references(gpu, oracle):
+    """BASELINE config 2 in small: 128-px particles (N=394, Bluestein M=1024, MFMA contraction and ring DFT,
+    register-blocked S6) against 300 references, all of them neighbours; SNR 0.1."""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 128, 300, 40
+    vol = synth.phantom(D, seed=3, nblobs=20)
+    refs, dirs = synth.make_refs(vol, nrefs)
+    rng = np.random.default_rng(17)
+    parts, truth = synth.make_particles(refs, n, rng, snr=0.1, max_shift=3)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    assert pm.N == o.N == 394
+    refno, psi, flip = pm.match(torch.from_numpy(parts).cuda(), parity=1)
+    er, ep, ef, _ = o.match(parts, parity=1)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    sx, sy, cc = pm.translate(torch.from_numpy(parts).cuda(), refno, psi, flip, 10.0)
+    ex, ey, ec = o.translate(parts, er[:, 0], ep[:, 0], ef[:, 0], 10.0)
+    assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3 and np.abs(sy.cpu().numpy() - ey).max() <= 1e-3
+    assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+
+
 def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     """Duplicated references give bit-equal correlations in the reference: the first visited
     wins, and the visiting order flips every image (APM:615-626,1112)."""
