@@ -700,6 +700,8 @@ __global__ void k_rf_pack(const xh_cf *__restrict__ ffts, const float *__restric
 #define XH_CHUNK 256      // projections culled per block-level pass (capacity of the LDS hit records)
 #define XH_QCAP 128       // per-wave work queue capacity (64 pending + 64 new)
 #define XH_GRAB 8         // tiles fetched per work-queue atomic
+#define XH_CTF_ROWS2 0
+#define XH_SEGCAP 16      // queue segments (one per projection) a dense pass can span
 // Workgroup = one 8x8x8 tile, 8 waves; wave w owns the 4x4x4 sub-cube (w&1, (w>>1)&1, w>>2) and
 // lane l the voxel (l&3, (l>>2)&3, l>>4) of it.
 //  block level : cull the launch's projections against the tile, 256 at a time, with an ordered
@@ -733,7 +735,8 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     __shared__ XhHitRec sRec[XH_CHUNK];
     __shared__ int sHit[XH_CHUNK];
     __shared__ int sWaveCnt[8];
-    __shared__ float sAcc[8][3][64];
+    __shared__ int sSegStart[8][XH_SEGCAP + 1];
+    __shared__ unsigned long long sSegMask[8][XH_SEGCAP + 1];
     __shared__ float qIx[8][XH_QCAP], qIy[8][XH_QCAP], qZs[8][XH_QCAP];
     __shared__ int qMeta[8][XH_QCAP];
     const int tid = threadIdx.x;
@@ -748,11 +751,18 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     const int lane = tid & 63, wv = tid >> 6;
     const int ox = (wv & 1) * 4, oy = ((wv >> 1) & 1) * 4, oz = (wv >> 2) * 4;
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-    float *accW = sAcc[wv][0], *accR = sAcc[wv][1], *accI = sAcc[wv][2];
+    float accW = 0.f, accR = 0.f, accI = 0.f;   // lane l accumulates voxel l of the wave's sub-cube, in registers
+    int nseg = 0;                              // wave-uniform: projections ("segments") with items in the queue
 
     // dense pass over queue items [0, n): lane l handles item l
+    // The items' sums are then handed to the lanes that own the voxels: every item writes (w, re, im) over its
+    // own queue slot, and lane l, for every segment of the batch whose ballot mask has bit l set, picks up
+    // slot start + popcount(mask below l). LDS float atomics (ds_add_f32) did this before at ~1 lane per
+    // clock -- a quarter of the kernel's time; plain LDS writes/reads are 20x cheaper, the accumulation order
+    // per voxel (projection order) is unchanged and the accumulators stay in registers.
     auto process = [&](int n, int ty0, int tz0) {
         if (dbg == 1) return;
+        float vW = 0.f, vR = 0.f, vI = 0.f;
         if (lane < n) {
             const int meta = qMeta[wv][lane];
             const int vl = meta & 63, si = meta >> 6;
@@ -775,7 +785,6 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
                 const size_t imgOff = (size_t)S.img * SX * SY;
                 const float dataWeight = S.weight;
-                float vW = 0.f, vR = 0.f, vI = 0.f;
                 if (SMALLBLOB) {
                     // blob radius < 2: at most 4x4 candidate pixels, fetched as four contiguous row
                     // segments of the padded record (all loads issued before any arithmetic). Pixels
@@ -799,43 +808,53 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                         cv[b] = (j >= minX) && (j <= maxX);
                     }
                     const size_t base = imgOff + (size_t)(bY + XH_PAD) * SX + (bX + XH_PAD);
-                    float pr[4][4], pi_[4][4], wc[4][4], wm[4][4];
+                    // rows are fetched RB at a time, all loads of a group before its arithmetic. With the CTF
+                    // planes a pixel is 16 bytes: four rows at once would need 64 live registers and spill
+                    // (the kernel is capped at 128 VGPRs by its LDS-limited occupancy), two rows do not.
+                    constexpr int RB = (HAS_CTF && XH_CTF_ROWS2) ? 2 : 4;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        // rows outside the blob are not fetched at all (exec-masked): ~1/4 fewer L1 lookups
+                    for (int a0 = 0; a0 < 4; a0 += RB) {
+                        float pr[RB][4], pi_[RB][4], wc[RB][4], wm[RB][4];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) { pr[a][b] = 0.f; pi_[a][b] = 0.f; wc[a][b] = 0.f; wm[a][b] = 0.f; }
-                        if (!rv[a] && dbg != 4) continue;
-                        if (HAS_CTF) {
-                            const float4 *row = reinterpret_cast<const float4 *>(pk) + base + (size_t)a * SX;
+                        for (int ar = 0; ar < RB; ++ar) {
+                            const int a = a0 + ar;
+                            // rows outside the blob are not fetched at all (exec-masked): ~1/4 fewer L1 lookups
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) { const float4 q = row[b]; pr[a][b] = q.x; pi_[a][b] = q.y; wc[a][b] = q.z; wm[a][b] = q.w; }
-                        } else {
-                            const float2 *row = reinterpret_cast<const float2 *>(pk) + base + (size_t)a * SX;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) { const float2 q = row[b]; pr[a][b] = q.x; pi_[a][b] = q.y; }
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const float distanceSqr = xs[b] + yz[a];
-                            const bool use = rv[a] && cv[b] && !(distanceSqr > radiusSqr);
-                            const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
-                            const float wBlob = use ? sBlob[aux] : 0.f;
+                            for (int b = 0; b < 4; ++b) { pr[ar][b] = 0.f; pi_[ar][b] = 0.f; wc[ar][b] = 0.f; wm[ar][b] = 0.f; }
+                            if (!rv[a] && dbg != 4) continue;
                             if (HAS_CTF) {
-                                const float weight = wBlob * wm[a][b] * dataWeight;
-                                vW += weight;
-                                vR += pr[a][b] * weight * wc[a][b];
-                                vI += pi_[a][b] * weight * wc[a][b];
+                                const float4 *row = reinterpret_cast<const float4 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) { const float4 q = row[b]; pr[ar][b] = q.x; pi_[ar][b] = q.y; wc[ar][b] = q.z; wm[ar][b] = q.w; }
                             } else {
-                                const float weight = wBlob * dataWeight;
-                                vW += weight;
-                                vR += pr[a][b] * weight;
-                                vI += pi_[a][b] * weight;
+                                const float2 *row = reinterpret_cast<const float2 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) { const float2 q = row[b]; pr[ar][b] = q.x; pi_[ar][b] = q.y; }
                             }
                         }
+#pragma unroll
+                        for (int ar = 0; ar < RB; ++ar) {
+                            const int a = a0 + ar;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float distanceSqr = xs[b] + yz[a];
+                                const bool use = rv[a] && cv[b] && !(distanceSqr > radiusSqr);
+                                const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
+                                const float wBlob = use ? sBlob[aux] : 0.f;
+                                if (HAS_CTF) {
+                                    const float weight = wBlob * wm[ar][b] * dataWeight;
+                                    vW += weight;
+                                    vR += pr[ar][b] * weight * wc[ar][b];
+                                    vI += pi_[ar][b] * weight * wc[ar][b];
+                                } else {
+                                    const float weight = wBlob * dataWeight;
+                                    vW += weight;
+                                    vR += pr[ar][b] * weight;
+                                    vI += pi_[ar][b] * weight;
+                                }
+                            }
+                        }
+                    }
                 } else
                 for (int i = minY; i <= maxY; i++) {
                     const float ySqr = (iy - i) * (iy - i);
@@ -863,11 +882,19 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                         }
                     }
                 }
-                atomicAdd(&accW[vl], vW);
-                atomicAdd(&accR[vl], vR);
-                atomicAdd(&accI[vl], vI);
             }
         }
+        if (lane < n) { qIx[wv][lane] = vW; qIy[wv][lane] = vR; qZs[wv][lane] = vI; }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const unsigned long long mask = sSegMask[wv][sg];
+            if ((mask >> lane) & 1ull) {
+                const int pos = sSegStart[wv][sg] + __popcll(mask & below);
+                if (pos >= 0 && pos < n) { accW += qIx[wv][pos]; accR += qIy[wv][pos]; accI += qZs[wv][pos]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     };
 
     // Work distribution: tiles are queued per XCD class (contiguous z-slab of equal expected work).
@@ -904,7 +931,8 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
         const float c4x = x0 + 1.5f - mv / 2, c4y = y0 + 1.5f - mv / 2, c4z = z0 + 1.5f - mv / 2;
         const float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
         const bool inSphere = inVol && !((px * px + py * py + pz * pz) > maxDistanceSqr);
-        accW[lane] = 0.f; accR[lane] = 0.f; accI[lane] = 0.f;
+        accW = 0.f; accR = 0.f; accI = 0.f;
+        nseg = 0;
         int qn = 0;   // wave-uniform queue length
         for (int s0 = 0; s0 < nspaces; s0 += XH_CHUNK) {
             const int s = s0 + tid;
@@ -953,8 +981,9 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                     const bool more = todo != 0;
                     float4 n0 = r0, n1 = r1, n2 = r2;
                     int nHit = hitId;
+                    int hn = h;
                     if (more) {
-                        const int hn = hb + __builtin_ctzll(todo);
+                        hn = hb + __builtin_ctzll(todo);
                         todo &= todo - 1;
                         n0 = sRec[hn].r0; n1 = sRec[hn].r1; n2 = sRec[hn].r2;
                         nHit = sHit[hn];
@@ -981,26 +1010,41 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                             qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
                             qMeta[wv][q] = (hitId << 6) | lane;
                         }
+                        if (lane == 0) { sSegStart[wv][nseg] = qn; sSegMask[wv][nseg] = pb; }
+                        ++nseg;
                         qn += np;
-                        if (qn >= 64) {
-                            process(64, y0, z0);
-                            // move the remainder down (source index >= 64 > destination)
-                            const int rem = qn - 64;
+                        if (qn >= 64 || nseg == XH_SEGCAP) {
+                            const int take = min(qn, 64);
+                            process(take, y0, z0);
+                            // move the remainder down (source index >= 64 > destination); only the last segment
+                            // can straddle the batch boundary: it stays, 64 slots further down
+                            const int rem = qn - take;
                             float a = 0.f, b = 0.f, c = 0.f;
                             int m = 0;
                             if (lane < rem) { a = qIx[wv][64 + lane]; b = qIy[wv][64 + lane]; c = qZs[wv][64 + lane]; m = qMeta[wv][64 + lane]; }
                             if (lane < rem) { qIx[wv][lane] = a; qIy[wv][lane] = b; qZs[wv][lane] = c; qMeta[wv][lane] = m; }
+                            if (rem > 0) {
+                                const int st = sSegStart[wv][nseg - 1] - 64;
+                                const unsigned long long mk = sSegMask[wv][nseg - 1];
+                                __builtin_amdgcn_wave_barrier();
+                                if (lane == 0) { sSegStart[wv][0] = st; sSegMask[wv][0] = mk; }
+                                nseg = 1;
+                            } else nseg = 0;
                             qn = rem;
+                            // the prefetched record was dead weight across the dense pass (register pressure):
+                            // fetch it again instead of keeping it live
+                            if (more) { n0 = sRec[hn].r0; n1 = sRec[hn].r1; n2 = sRec[hn].r2; nHit = sHit[hn]; }
                         }
                     }
                     if (!more) break;
+                    h = hn;
                     r0 = n0; r1 = n1; r2 = n2; hitId = nHit;
                 }
             }
             __syncthreads();
         }
         if (qn > 0) process(qn, y0, z0);
-        const float aW = accW[lane], aR = accR[lane], aI = accI[lane];
+        const float aW = accW, aR = accR, aI = accI;
         if (inSphere && (aW != 0.f || aR != 0.f || aI != 0.f)) {
             const size_t vi = ((size_t)z * dim + y) * dim + x;
             float2 *V = reinterpret_cast<float2 *>(tempV) + vi;
