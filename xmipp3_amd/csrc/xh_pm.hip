@@ -542,7 +542,7 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
 // bank is the large, re-streamed operand: two particle tiles per wave halve its HBM/MALL re-reads);
 // block = 4 waves = 4 reference tiles
 #define XH_PW2 1
-#define XH_KSPLIT 4        // the frequency range is cut into slices of equal work: more waves in flight
+#define XH_KSPLIT 8        // the frequency range is cut into slices of equal work: more waves in flight
 __global__ void __launch_bounds__(256)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
                    const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
