@@ -166,6 +166,31 @@ def test_config2_shape_d128_many_references(gpu, oracle):
     assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
+@pytest.mark.parametrize("D", [512, 24])
+def test_match_extreme_box_sizes(gpu, oracle, D):
+    """512 px: N=1602, Bluestein M=4096 (radix-2 LDS S3 kernel), 255 rings, nk=802; 24 px: M=256 (radix-2 too)."""
+    xa, ctx, torch = gpu
+    nrefs, n = (5, 3) if D == 512 else (16, 9)
+    rng = np.random.default_rng(D)
+    refs = rng.standard_normal((nrefs, D, D)).astype(np.float32)
+    f = np.fft.fftfreq(D)
+    lp = np.exp(-((f[:, None] ** 2 + f[None, :] ** 2) * (0.12 * D) ** 2))
+    refs = np.fft.ifft2(np.fft.fft2(refs) * lp).real.astype(np.float32)
+    parts = np.stack([refs[i % nrefs] + 0.5 * refs.std() * rng.standard_normal((D, D)) for i in range(n)]).astype(np.float32)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    assert pm.N == o.N
+    refno, psi, flip = pm.match(torch.from_numpy(parts).cuda())
+    er, ep, ef, _ = o.match(parts)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    sx, sy, cc = pm.translate(torch.from_numpy(parts).cuda(), refno, psi, flip, 5.0)
+    ex, ey, ec = o.translate(parts, er[:, 0], ep[:, 0], ef[:, 0], 5.0)
+    assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3 and np.abs(sy.cpu().numpy() - ey).max() <= 1e-3
+    assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+
+
 def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     """Duplicated references give bit-equal correlations in the reference: the first visited
     wins, and the visiting order flips every image (APM:615-626,1112)."""
