@@ -667,6 +667,18 @@ k_rf_insert(const XhSpace *__restrict__ spaces, int nspaces, const xh_cf *__rest
 // contributions processVoxelBlob (RFA:627-700) would give it when the reference's traversal
 // (RFA:743-761: AABB rows, hit1||hit2 via getX) visits it.
 
+// a value every lane holds identically (read from one LDS address): park it in scalar registers.
+// Only the CTF variant of the tile kernel does this: it is the one short of vector registers (float4
+// records), while the plain variant would merely trade them for scalar spills.
+template <bool ON> __device__ __forceinline__ float4 d_uniform(float4 v)
+{
+    if (!ON) return v;
+    return make_float4(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.z))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.w))));
+}
+
 // ---- packed, padded projection records for the tile kernel -----------------------------------
 // pk[n][sizeY+8][sizeX+8], 4 pad cells on every side (zero): a voxel's 4x4 footprint can then be
 // fetched as four contiguous row segments without clamping. HAS_CTF: float4 (re, im, ctf, mod);
@@ -975,8 +987,9 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 if (!todo) continue;
                 int h = hb + __builtin_ctzll(todo);
                 todo &= todo - 1;
-                float4 r0 = sRec[h].r0, r1 = sRec[h].r1, r2 = sRec[h].r2;
-                int hitId = sHit[h];
+                // the records are wave-uniform: in the CTF variant they live in scalar registers (see d_uniform)
+                float4 r0 = d_uniform<HAS_CTF>(sRec[h].r0), r1 = d_uniform<HAS_CTF>(sRec[h].r1), r2 = d_uniform<HAS_CTF>(sRec[h].r2);
+                int hitId = __builtin_amdgcn_readfirstlane(sHit[h]);
                 for (;;) {
                     const bool more = todo != 0;
                     float4 n0 = r0, n1 = r1, n2 = r2;
@@ -985,8 +998,8 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                     if (more) {
                         hn = hb + __builtin_ctzll(todo);
                         todo &= todo - 1;
-                        n0 = sRec[hn].r0; n1 = sRec[hn].r1; n2 = sRec[hn].r2;
-                        nHit = sHit[hn];
+                        n0 = d_uniform<HAS_CTF>(sRec[hn].r0); n1 = d_uniform<HAS_CTF>(sRec[hn].r1); n2 = d_uniform<HAS_CTF>(sRec[hn].r2);
+                        nHit = __builtin_amdgcn_readfirstlane(sHit[hn]);
                     }
                     const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
                     bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
@@ -1033,7 +1046,7 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                             qn = rem;
                             // the prefetched record was dead weight across the dense pass (register pressure):
                             // fetch it again instead of keeping it live
-                            if (more) { n0 = sRec[hn].r0; n1 = sRec[hn].r1; n2 = sRec[hn].r2; nHit = sHit[hn]; }
+                            if (more) { n0 = d_uniform<HAS_CTF>(sRec[hn].r0); n1 = d_uniform<HAS_CTF>(sRec[hn].r1); n2 = d_uniform<HAS_CTF>(sRec[hn].r2); nHit = __builtin_amdgcn_readfirstlane(sHit[hn]); }
                         }
                     }
                     if (!more) break;
