@@ -215,6 +215,26 @@ int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 
+/* ---- FourierProjector: central-slice projections of a volume ------------------
+ * Replaces the class FourierProjector (libraries/data/fourier_projection.h:111-172) behind
+ * xmipp_angular_project_library --method fourier <pad> <maxfreq> bspline
+ * (reconstruction/angular_project_library.cpp:194-245): the gallery of references that
+ * xh_pm_create consumes, so that volume -> references -> match -> reconstruct stays on the device.
+ *   create  == FourierProjector(V, paddFactor, maxFreq, BSPLINE3) / updateVolume
+ *              (fourier_projection.cpp:72-89,247-330); d_vol: D^3 floats, [z][y][x], Xmipp origin.
+ *   project == project(rot, tilt, psi, ctf) + projection() for n orientations at once
+ *              (fourier_projection.cpp:91-245); h_angles: n x (rot, tilt, psi) degrees; d_ctf: optional
+ *              [D][D/2+1] doubles multiplied onto the slice; d_out: n x D x D floats.
+ * Only cubic B-spline interpolation (the program's default) is implemented; degree 0/1 fail loudly. */
+typedef struct xh_fp xh_fp;
+int xh_fp_create(xh_ctx *ctx, const float *d_vol, int32_t D, double padding, double max_freq,
+                 int32_t degree, xh_fp **out);
+int xh_fp_destroy(xh_fp *fp);
+int xh_fp_info(const xh_fp *fp, int32_t *padded_size, int32_t *coef_dim, int32_t *coef_start);
+/* test hook: the cropped B-spline coefficient cubes (VfourierRealCoefs / VfourierImagCoefs), host doubles */
+int xh_fp_coefs(const xh_fp *fp, double *h_re, double *h_im);
+int xh_fp_project(xh_fp *fp, const double *h_angles, int32_t n, const double *d_ctf, float *d_out);
+
 /* ---- test hooks (used only by tests/ to localise a parity failure per stage) ---- */
 /* polar Fourier transform of one stage: precision 32 or 64; outputs on host */
 int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision,

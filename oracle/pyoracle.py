@@ -106,6 +106,13 @@ def lib():
         "xo_rf_finish": (None, [vp, c_double_p]),
         "xo_rf_hermitian_and_weights": (None, [vp]),
         "xo_num_threads": (i, []),
+        "xo_fp_create": (vp, [c_double_p, i, d, d, i]),
+        "xo_fp_destroy": (None, [vp]),
+        "xo_fp_padded_size": (i, [vp]),
+        "xo_fp_coef_dim": (i, [vp]),
+        "xo_fp_coef_start": (i, [vp]),
+        "xo_fp_coefs": (c_double_p, [vp, i]),
+        "xo_fp_project": (None, [vp, d, d, d, c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -116,7 +123,7 @@ def lib():
 
 
 def _dp(a):
-    return a.ctypes.data_as(c_double_p)
+    return None if a is None else a.ctypes.data_as(c_double_p)
 
 
 def _fp(a):
@@ -436,3 +443,36 @@ class RF:
         out = np.empty((self.D, self.D, self.D))
         lib().xo_rf_finish(self.h, _dp(out))
         return out
+
+
+class FP:
+    """FourierProjector (data/fourier_projection.cpp): vol is [z][y][x] with the Xmipp origin at D//2."""
+
+    def __init__(self, vol, padding=2.0, max_freq=0.5, degree=3):
+        vol = f64(vol)
+        self.D = vol.shape[0]
+        assert vol.shape == (self.D,) * 3
+        self.h = lib().xo_fp_create(_dp(vol), self.D, float(padding), float(max_freq), int(degree))
+        self.P = lib().xo_fp_padded_size(self.h)
+        self.cdim = lib().xo_fp_coef_dim(self.h)
+        self.cstart = lib().xo_fp_coef_start(self.h)
+
+    def coefs(self):
+        n = self.cdim ** 3
+        re = np.ctypeslib.as_array(lib().xo_fp_coefs(self.h, 0), shape=(n,)).reshape((self.cdim,) * 3).copy()
+        im = np.ctypeslib.as_array(lib().xo_fp_coefs(self.h, 1), shape=(n,)).reshape((self.cdim,) * 3).copy()
+        return re, im
+
+    def project(self, rot, tilt, psi, ctf=None):
+        out = np.empty((self.D, self.D))
+        c = None if ctf is None else f64(ctf)
+        lib().xo_fp_project(self.h, float(rot), float(tilt), float(psi), _dp(c), _dp(out))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().xo_fp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

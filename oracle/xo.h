@@ -169,6 +169,19 @@ void xo_rf_finish(xo_rf *, double *vol_out);
 void xo_rf_hermitian_and_weights(xo_rf *);
 
 int xo_num_threads(void);
+/* ---- FourierProjector (data/fourier_projection.cpp:91-330): central-slice projection, the producer of
+ * the reference gallery (angular_project_library --method fourier pad maxfreq interp) ---- */
+typedef struct xo_fp xo_fp;
+xo_fp *xo_fp_create(const double *vol /* D^3, [z][y][x] */, int D, double padding, double max_freq,
+                    int degree /* 0 nearest, 1 linear, 3 cubic B-spline */);
+void xo_fp_destroy(xo_fp *);
+int xo_fp_padded_size(const xo_fp *);
+int xo_fp_coef_dim(const xo_fp *);
+int xo_fp_coef_start(const xo_fp *);
+const double *xo_fp_coefs(const xo_fp *, int imag);
+void xo_fp_project(const xo_fp *, double rot, double tilt, double psi, const double *ctf /* nullable */,
+                   double *out /* D*D */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,20 @@ void prefilter2d(const double *in, int ydim, int xdim, double *coef)
     for (int j = 0; j < xdim; ++j) prefilter1d(coef + j, ydim, xdim);
 }
 
+// 3-D version (produceSplineCoefficients on a volume): x, then y, then z lines, in place
+void prefilter3d(double *c, int zdim, int ydim, int xdim)
+{
+#pragma omp parallel for collapse(2)
+    for (int k = 0; k < zdim; ++k)
+        for (int i = 0; i < ydim; ++i) prefilter1d(c + ((size_t)k * ydim + i) * xdim, xdim, 1);
+#pragma omp parallel for collapse(2)
+    for (int k = 0; k < zdim; ++k)
+        for (int j = 0; j < xdim; ++j) prefilter1d(c + (size_t)k * ydim * xdim + j, ydim, xdim);
+#pragma omp parallel for collapse(2)
+    for (int i = 0; i < ydim; ++i)
+        for (int j = 0; j < xdim; ++j) prefilter1d(c + (size_t)i * xdim + j, zdim, ydim * xdim);
+}
+
 static inline double bspline03(double x)
 {
     // cuda_gpu_bilib.cu:16-25 (copy of xmippCore Bspline03)

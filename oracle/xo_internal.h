@@ -10,6 +10,7 @@
 namespace xo {
 void c2c(const std::complex<double> *in, int n, int sign, std::complex<double> *out);
 void prefilter2d(const double *in, int ydim, int xdim, double *coef);
+void prefilter3d(double *c, int zdim, int ydim, int xdim);
 double interp2d(const double *coef, int ydim, int xdim, int starty, int startx, double x, double y);
 double realWRAP(double x, double x0, double xF);
 void apply_geometry2d(int degree, const double *V1, int ydim, int xdim, const double *At, bool inv,

@@ -6,6 +6,8 @@ Every expected value below is re-typed from the reference's gtest sources
 import numpy as np
 import pytest
 
+from tests import synth
+
 M3 = np.array([[1., 2., 3.], [3., 2., 1.], [4., 4., 5.]])  # fixture used by all four suites
 
 
@@ -118,3 +120,31 @@ def test_prefilter_inverts_bspline_sampling(oracle):
     rows = cp[:, :-2] * k[0] + cp[:, 1:-1] * k[1] + cp[:, 2:] * k[2]
     rec = rows[:-2] * k[0] + rows[1:-1] * k[1] + rows[2:] * k[2]
     assert np.allclose(rec, img, atol=1e-12)
+
+
+def test_fourier_projector_against_analytic_gaussians(oracle):
+    """FourierProjector (data/fourier_projection.cpp) has no unit test in the reference; the restatement is
+    pinned on physics instead: the projection of a sum of isotropic Gaussians is the sum of 2-D Gaussians of
+    weight sigma*sqrt(2 pi) centred at the first two rows of Euler(rot,tilt,psi) applied to the 3-D centres.
+    That fixes the axis order, the centring (Xmipp origin), the Euler convention and the normalisation."""
+    D = 32
+    z, y, x = np.mgrid[-(D // 2):D - D // 2, -(D // 2):D - D // 2, -(D // 2):D - D // 2].astype(float)
+    cen = [(3.0, -2.0, 4.0), (-5.0, 1.0, -2.0)]
+    sig = [2.0, 2.5]
+    amp = [1.0, 0.7]
+    vol = sum(a * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s)) for a, c, s in zip(amp, cen, sig))
+    fp = oracle.FP(vol, 2.0, 0.5, 3)
+    assert (fp.P, fp.cdim, fp.cstart) == (64, 63, -31)
+    yy, xx = np.mgrid[-(D // 2):D - D // 2, -(D // 2):D - D // 2].astype(float)
+    for ang, tol in (((0, 0, 0), 1e-6), ((30, 40, 50), 5e-4), ((90, 90, 0), 1e-4), ((123, 67, -20), 5e-4)):
+        E = synth.euler_matrix(*ang)
+        ana = np.zeros((D, D))
+        for a, c, s in zip(amp, cen, sig):
+            pc = E @ np.array(c)
+            ana += a * s * np.sqrt(2 * np.pi) * np.exp(-((xx - pc[0]) ** 2 + (yy - pc[1]) ** 2) / (2 * s * s))
+        got = fp.project(*ang)
+        assert np.abs(got - ana).max() <= tol * ana.max(), ang
+    # a CTF image multiplies the slice: a constant 0.5 halves the projection; the crop follows max_freq
+    half = fp.project(30, 40, 50, ctf=np.full((D, D // 2 + 1), 0.5))
+    assert np.allclose(half, 0.5 * fp.project(30, 40, 50), rtol=0, atol=1e-12)
+    assert oracle.FP(vol, 2.0, 0.25, 3).cdim == 2 * (int(0.25 * 64 + 10)) + 1

@@ -72,6 +72,11 @@ SIGNATURES = {
     "xh_pm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "xh_pm_match": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp]),
     "xh_rf_kernel_ms": (C.c_int, [vp, vp, vp, i32]),
+    "xh_fp_create": (C.c_int, [vp, vp, i32, C.c_double, C.c_double, i32, pvp]),
+    "xh_fp_destroy": (C.c_int, [vp]),
+    "xh_fp_info": (C.c_int, [vp, vp, vp, vp]),
+    "xh_fp_coefs": (C.c_int, [vp, vp, vp]),
+    "xh_fp_project": (C.c_int, [vp, vp, i32, vp, vp]),
     "xh_pm_match_ex": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "xh_pm_translate": (C.c_int, [vp, vp, i32, vp, vp, vp, d, vp, vp, vp]),
     "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),

@@ -258,6 +258,51 @@ def allreduce_reconstruction(rf):
         dist.all_reduce(rf.cropped_view(), op=dist.ReduceOp.SUM)
 
 
+class FourierProjector:
+    """Device side of FourierProjector (data/fourier_projection.cpp): central-slice projections of a
+    volume `[z][y][x]` (float32, cuda) with cubic B-spline interpolation in Fourier space."""
+
+    def __init__(self, ctx, vol, padding=2.0, max_freq=0.5, degree=3):
+        torch = _torch()
+        assert vol.is_cuda and vol.dtype == torch.float32 and vol.is_contiguous() and vol.dim() == 3
+        self.ctx = ctx
+        self.D = vol.shape[0]
+        h = C.c_void_p()
+        check(lib().xh_fp_create(ctx.h, _ptr(vol), self.D, float(padding), float(max_freq), int(degree), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().xh_fp_info(h, C.byref(a), C.byref(b), C.byref(c)))
+        self.P, self.cdim, self.cstart = a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_fp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def coefs(self):
+        re = np.empty((self.cdim,) * 3, np.float64)
+        im = np.empty((self.cdim,) * 3, np.float64)
+        check(lib().xh_fp_coefs(self.h, _np_ptr(re), _np_ptr(im)))
+        return re, im
+
+    def project(self, angles, ctf=None):
+        """angles: [n, 3] (rot, tilt, psi) in degrees; ctf: optional float64 cuda tensor [D, D//2+1]."""
+        torch = _torch()
+        ang = np.ascontiguousarray(angles, np.float64).reshape(-1, 3)
+        n = ang.shape[0]
+        out = torch.empty((n, self.D, self.D), dtype=torch.float32, device=self.ctx.torch_device)
+        check(lib().xh_fp_project(self.h, _np_ptr(ang), n, None if ctf is None else _ptr(ctf, torch.float64), _ptr(out)))
+        return out
+
+
 class ProjectionMatcher:
     """Device side of ProgAngularProjectionMatching
     (reconstruction/angular_projection_matching.cpp)."""
