@@ -191,3 +191,56 @@ def test_cli_symmetry_names_and_files(bins, tmp_path, oracle):
     # an unknown name must fail loudly, not reconstruct without symmetry
     r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i3"])
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gallery_then_matching(bins, tmp_path, oracle):
+    """volume -> xmipp_angular_project_library (gallery + sampling files) -> xmipp_angular_projection_matching:
+    the stack holds the FourierProjector's projections at the sampled directions (oracle parity), and particles
+    projected at gallery directions are assigned back to them."""
+    D = 32
+    vol = synth.phantom(D, seed=21, nblobs=12).astype(np.float32)
+    xmipp_io.write_volume(str(tmp_path / "in.vol"), vol)
+    # experimental images: oracle projections at three sampled directions, rotated in plane
+    fp = oracle.FP(vol, 2.0, 0.5, 3)
+    r = _run([os.path.join(bins, "xmipp_angular_project_library"), "-i", str(tmp_path / "in.vol"), "-o", str(tmp_path / "ref.stk"),
+              "--sampling_rate", "20", "--sym", "c1", "--only_create_sampling"])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "ref.doc"))
+    c = {l: i for i, l in enumerate(labels)}
+    dirs = np.array([[float(rw[c["angleRot"]]), float(rw[c["angleTilt"]])] for rw in rows])
+    picks = [(5, 40.0), (17, 200.0), (len(dirs) - 3, 0.0)]
+    parts = np.stack([fp.project(dirs[k, 0], dirs[k, 1], psi) for k, psi in picks]).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "exp.stk"), parts)
+    xmipp_io.write_xmd(str(tmp_path / "exp.xmd"), [("noname", ["image", "angleRot", "angleTilt", "anglePsi"],
+                                                   [[f"{i + 1}@{tmp_path}/exp.stk", "0.000000", "0.000000", "0.000000"] for i in range(len(picks))])])
+    r = _run([os.path.join(bins, "xmipp_angular_project_library"), "-i", str(tmp_path / "in.vol"), "-o", str(tmp_path / "ref.stk"),
+              "--sampling_rate", "20", "--sym", "c1", "--experimental_images", str(tmp_path / "exp.xmd"), "--angular_distance", "-1",
+              "--compute_neighbors", "--method", "fourier", "2", "0.5", "bspline", "--batch", "7"])
+    assert r.returncode == 0, r.stderr
+    gallery = xmipp_io.read_stack(str(tmp_path / "ref.stk"))
+    assert gallery.shape == (len(dirs), D, D)
+    for k in (0, 1, 9, len(dirs) - 1):
+        exp = fp.project(dirs[k, 0], dirs[k, 1], 0.0)
+        assert np.abs(gallery[k] - exp).max() <= 3e-7 * np.abs(exp).max()
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
+              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "3"])
+    assert r.returncode == 0, r.stderr
+    labels, orow = xmipp_io.read_xmd(str(tmp_path / "out.xmd"))
+    oc = {l: i for i, l in enumerate(labels)}
+    assert len(orow) == len(picks)
+    def direction(rot, tilt):
+        a, b = np.radians([rot, tilt])
+        return np.array([np.sin(b) * np.cos(a), np.sin(b) * np.sin(a), np.cos(b)])
+
+    for (k, psi), rw in zip(picks, orow):
+        # a projection along -d is the mirror image of the one along d: with the whole sphere in the gallery
+        # both (d, no flip) and (-d, flip) are exact matches and either may win the tie
+        dot = float(direction(float(rw[oc["angleRot"]]), float(rw[oc["angleTilt"]])) @ direction(*dirs[k]))
+        flip = int(rw[oc["flip"]])
+        assert abs(dot) > 1 - 1e-9 and flip == (1 if dot < 0 else 0)
+        if not flip:
+            assert int(rw[oc["ref"]]) == k
+            d = abs(float(rw[oc["anglePsi"]]) - psi) % 360
+            assert min(d, 360 - d) <= 360.0 / 90 + 1e-6      # within one step of the in-plane angular grid
+        assert float(rw[oc["maxCC"]]) > 0.98

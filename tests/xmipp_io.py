@@ -23,6 +23,23 @@ def write_stack(path, imgs):
             f.write(imgs[i].tobytes())
 
 
+def write_volume(path, vol):
+    vol = np.ascontiguousarray(vol, np.float32)
+    z, y, x = vol.shape
+    with open(path, "wb") as f:
+        f.write(_spider_header(x, y, z, 3, 0, 0, 0).tobytes())
+        f.write(vol.tobytes())
+
+
+def read_stack(path):
+    raw = np.fromfile(path, np.float32)
+    y, x, labbyt, n = int(raw[1]), int(raw[11]), int(raw[21]), int(raw[25])
+    hw = labbyt // 4
+    per = hw + x * y
+    body = raw[hw:hw + n * per].reshape(n, per)
+    return body[:, hw:].reshape(n, y, x).copy()
+
+
 def read_volume(path):
     raw = np.fromfile(path, np.float32)
     z, y, x, labbyt = int(abs(raw[0])), int(raw[1]), int(raw[11]), int(raw[21])
@@ -57,5 +74,25 @@ def read_xmd(path, block=None):
         if t[0] == "_" and not rows:
             labels.append(t.split()[0][1:])
             continue
-        rows.append(t.split())
+        rows.append(_split_row(t))
     return labels, rows
+
+
+def _split_row(t):
+    """whitespace-separated values; a value in single quotes may contain blanks (e.g. neighbour lists)"""
+    out, i = [], 0
+    while i < len(t):
+        if t[i].isspace():
+            i += 1
+        elif t[i] == "'":
+            j = t.find("'", i + 1)
+            j = len(t) if j < 0 else j
+            out.append(t[i + 1:j])
+            i = j + 1
+        else:
+            j = i
+            while j < len(t) and not t[j].isspace():
+                j += 1
+            out.append(t[i:j])
+            i = j
+    return out

@@ -8,6 +8,7 @@ FLAGS="-O2 -std=c++17 -Wall -Wno-unused-function"
 LINK="-L.. -lxmipp_hip -Wl,-rpath,\$ORIGIN/.. -Wl,-rpath,/opt/rocm/lib"
 $CXX $FLAGS angular_projection_matching_main.cpp -o ../bin/xmipp_angular_projection_matching $LINK &
 $CXX $FLAGS reconstruct_fourier_accel_main.cpp -o ../bin/xmipp_reconstruct_fourier_accel $LINK &
+$CXX $FLAGS angular_project_library_main.cpp -o ../bin/xmipp_angular_project_library $LINK &
 wait
 cp -f ../bin/xmipp_reconstruct_fourier_accel ../bin/xmipp_reconstruct_fourier
-echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier}"
+echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library}"

@@ -11,6 +11,7 @@
 #define XMIPP3_AMD_PROGRAMS_H
 #include "minicore.h"
 #include "../../include/xmipp_hip.h"
+#include "sampling_gen.h"
 
 namespace mc {
 
@@ -621,6 +622,187 @@ public:
         processImages(0, SF.size() - 1);
         xhCheck(xh_rf_mirror_and_crop(rf));
         finishComputations(fn_out);
+    }
+};
+
+// ============================================================================================
+// xmipp_angular_project_library (reconstruction/angular_project_library.cpp): the gallery of reference
+// projections + its sampling / neighbourhood files. Sampling on the host (sampling_gen.h), projections on
+// the device (xh_fp_*, the FourierProjector). --method fourier <pad> <maxfreq> bspline only.
+class ProgAngularProjectLibrary : public XmippProgram {
+public:
+    std::string input_volume, output_file, output_file_root, fn_sym, fn_sym_neigh, FnexperimentalImages, fn_groups;
+    double sampling = 5, psi_sampling = 360, max_tilt_angle = 180, min_tilt_angle = 0, angular_distance = 0;
+    double paddFactor = 1, maxFrequency = 0.25, perturb_projection_vector = 0;
+    bool angular_distance_bool = false, compute_closer_sampling_point_bool = false, compute_neighbors_bool = false;
+    bool remove_points_far_away_from_experimental_data_bool = false, only_winner = false, only_sampling = false;
+    int device = 0, batch = 256;
+    SamplingGen mysampling;
+
+    void defineParams() override
+    {
+        // angular_project_library.cpp:98-148
+        addUsageLine("Create a gallery of projections from a volume");
+        addParamsLine("   -i <input_volume_file>       : Input Volume");
+        addParamsLine("   -o <output_file_name>        : stack with output files");
+        addParamsLine("  [--sym <symmetry=c1>]         : Symmetry to define sampling ");
+        addParamsLine("  [--sampling_rate <Ts=5>]      : Distance in degrees between sampling points");
+        addParamsLine("==+Extra parameters==");
+        addParamsLine("  [--sym_neigh <symmetry>]      : symmetry used to define neighbors, by default same as sym");
+        addParamsLine("  [--psi_sampling <psi=360>]    : sampling in psi, 360 -> no sampling in psi");
+        addParamsLine("  [--max_tilt_angle <tmax=180>] : maximum tilt angle in degrees");
+        addParamsLine("  [--min_tilt_angle <tmin=0>]   : minimum tilt angle in degrees");
+        addParamsLine("  [--experimental_images <docfile=\"\">] : doc file with experimental data");
+        addParamsLine("  [--angular_distance <ang=20>]     : Do not search a distance larger than...");
+        addParamsLine("  [--closer_sampling_points]    : create doc file with closest sampling points");
+        addParamsLine("  [--near_exp_data]             : remove points far away from experimental data");
+        addParamsLine("  [--compute_neighbors]         : create doc file with sampling point neighbors");
+        addParamsLine("  [--method <method=fourier> <pad=1> <maxfreq=0.25> <interp=bspline>] : Projection method");
+        addParamsLine("  [--perturb <sigma=0.0>]       : gaussian noise projection unit vectors ");
+        addParamsLine("  [--groups <selfile=\"\">]     : selfile with groups");
+        addParamsLine("  [--only_winner]               : if set each experimental point will have a unique neighbor");
+        addParamsLine("  [--device <id=0>]             : HIP device");
+        addParamsLine("  [--batch <n=256>]             : projections per device batch");
+        addParamsLine("  [--only_create_sampling]      : write the sampling / angle files and stop (needs no device)");
+        addExampleLine("xmipp_angular_project_library -i in.vol -o out.stk --sym c6 --sampling_rate 2");
+    }
+    void readParams() override
+    {
+        // angular_project_library.cpp:47-95
+        input_volume = getParam("-i");
+        output_file = getParam("-o");
+        output_file_root = FileName(output_file).removeAllExtensions();
+        fn_sym = getParam("--sym");
+        fn_sym_neigh = checkParam("--sym_neigh") ? getParam("--sym_neigh") : fn_sym;
+        sampling = getDoubleParam("--sampling_rate");
+        psi_sampling = getDoubleParam("--psi_sampling");
+        max_tilt_angle = getDoubleParam("--max_tilt_angle");
+        min_tilt_angle = getDoubleParam("--min_tilt_angle");
+        angular_distance_bool = checkParam("--angular_distance");
+        if (angular_distance_bool) {
+            FnexperimentalImages = getParam("--experimental_images");
+            angular_distance = getDoubleParam("--angular_distance");
+        }
+        compute_closer_sampling_point_bool = checkParam("--closer_sampling_points");
+        if (compute_closer_sampling_point_bool) FnexperimentalImages = getParam("--experimental_images");
+        const std::string method = getParam("--method");
+        if (method != "fourier")
+            REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--method " + method + ": only the Fourier (central slice) projector is on the device");
+        paddFactor = getDoubleParam("--method", 1);
+        maxFrequency = getDoubleParam("--method", 2);
+        if (getParam("--method", 3) != "bspline")
+            REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--method fourier: only the 'bspline' interpolation kernel is on the device");
+        perturb_projection_vector = getDoubleParam("--perturb");
+        compute_neighbors_bool = checkParam("--compute_neighbors");
+        remove_points_far_away_from_experimental_data_bool = checkParam("--near_exp_data");
+        if (remove_points_far_away_from_experimental_data_bool) FnexperimentalImages = getParam("--experimental_images");
+        fn_groups = getParam("--groups");
+        only_winner = checkParam("--only_winner");
+        device = (int)getIntParam("--device");
+        batch = std::max(1, (int)getIntParam("--batch"));
+        only_sampling = checkParam("--only_create_sampling");
+    }
+    static void parseGroup(const std::string &sym, char &family, int &order)
+    {
+        std::string s = sym;
+        std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd') && std::all_of(s.begin() + 1, s.end(), ::isdigit) && atoi(s.c_str() + 1) >= 1) {
+            family = s[0];
+            order = atoi(s.c_str() + 1);
+            return;
+        }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "symmetry '" + sym + "': the sampling of the asymmetric unit is implemented for cN and dN "
+                     "(the other point groups are defined in xmippCore's SymList, which is not in the reference tree)");
+    }
+    void run() override
+    {
+        // angular_project_library.cpp:249-397
+        if (perturb_projection_vector != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--perturb is not available (it is seeded with time() in the reference)");
+        if (compute_closer_sampling_point_bool) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--closer_sampling_points is not available yet");
+        if (!fn_groups.empty()) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--groups is not available yet");
+        char fam, famN;
+        int order, orderN;
+        parseGroup(fn_sym, fam, order);
+        parseGroup(fn_sym_neigh, famN, orderN);
+        mysampling.setSampling(sampling);
+        if (angular_distance_bool) mysampling.setNeighborhoodRadius(angular_distance);
+        mysampling.computeSamplingPoints(false, max_tilt_angle, min_tilt_angle);
+        mysampling.removeRedundantPoints(fam, order);
+        SymList SLn;
+        SLn.readSymmetryFile(fn_sym_neigh);
+        mysampling.fillLRRepository(SLn);
+        if (!FnexperimentalImages.empty()) {
+            MetaDataVec DFi;
+            DFi.read(FnexperimentalImages);
+            mysampling.fillExpDataProjectionDirectionByLR(DFi);
+            if (remove_points_far_away_from_experimental_data_bool) mysampling.removePointsFarAwayFromExperimentalData();
+        }
+        mysampling.createAsymUnitFile(output_file_root);
+        if (compute_neighbors_bool) {
+            mysampling.computeNeighbors(only_winner);
+            mysampling.saveSamplingFile(output_file_root, false);
+        }
+        const size_t nDir = mysampling.no_redundant_sampling_points_angles.size();
+        int numberStepsPsi = 1;
+        if (psi_sampling < 360) numberStepsPsi = (int)(359.99999 / psi_sampling);
+        // the final docfile (angular_project_library.cpp:357-393)
+        {
+            MetaDataVec out;
+            size_t counter = 0;
+            for (double mypsi = 0; mypsi < 360; mypsi += psi_sampling)
+                for (size_t i = 0; i < nDir; ++i) {
+                    const size_t id = out.addObject();
+                    char name[32];
+                    snprintf(name, sizeof(name), "%06zu@", ++counter);
+                    out.setValue("image", std::string(name) + output_file, id);
+                    out.setValue("enabled", (long)1, id);
+                    out.setValue("angleRot", mysampling.no_redundant_sampling_points_angles[i][0], id);
+                    out.setValue("angleTilt", mysampling.no_redundant_sampling_points_angles[i][1], id);
+                    out.setValue("anglePsi", mysampling.no_redundant_sampling_points_angles[i][2] + mypsi, id);
+                    out.setValue("X", mysampling.no_redundant_sampling_points_vector[i][0], id);
+                    out.setValue("Y", mysampling.no_redundant_sampling_points_vector[i][1], id);
+                    out.setValue("Z", mysampling.no_redundant_sampling_points_vector[i][2], id);
+                    out.setValue("scale", 1.0, id);
+                    out.setValue("ref", (long)i, id);
+                }
+            out.comment = "x,y,z refer to the coordinates of the unitary vector at direction given by the euler angles";
+            if (out.size() > 0) out.write(output_file_root + ".doc");
+            else std::cout << "There are no projections within the specified angular range and sampling" << std::endl;
+        }
+        std::remove((output_file_root + "_angles.doc").c_str());
+        if (only_sampling || nDir == 0) return;
+        // projections (project_angle_vector, angular_project_library.cpp:194-245): psi-major, direction-minor
+        std::vector<float> vol;
+        ImageInfo vi;
+        readImage(input_volume, vol, vi);
+        if (vi.x != vi.y || vi.x != vi.z) REPORT_ERROR(ERR_MULTIDIM_SIZE, "the input volume must be cubic");
+        const size_t D = vi.x;
+        xh_ctx *ctx = nullptr;
+        xhCheck(xh_ctx_create_private(device, &ctx));
+        struct Guard { xh_ctx *c; xh_fp *f = nullptr; ~Guard() { if (f) xh_fp_destroy(f); if (c) xh_ctx_destroy(c); } } guard{ctx};
+        DeviceBuffer d_vol, d_out;
+        d_vol.reserve(ctx, vol.size() * sizeof(float));
+        xhCheck(xh_memcpy_h2d(ctx, d_vol.p, vol.data(), vol.size() * sizeof(float)));
+        xhCheck(xh_fp_create(ctx, d_vol.as<float>(), (int)D, paddFactor, maxFrequency, 3, &guard.f));
+        d_vol.release();
+        const size_t total = nDir * (size_t)numberStepsPsi;
+        std::vector<float> gallery(total * D * D);
+        std::vector<double> ang;
+        d_out.reserve(ctx, (size_t)batch * D * D * sizeof(float));
+        for (size_t n0 = 0; n0 < total; n0 += (size_t)batch) {
+            const size_t m = std::min((size_t)batch, total - n0);
+            ang.resize(3 * m);
+            for (size_t k = 0; k < m; ++k) {
+                const size_t n = n0 + k, psiIndex = n / nDir, index = n % nDir;
+                ang[3 * k] = mysampling.no_redundant_sampling_points_angles[index][0];
+                ang[3 * k + 1] = mysampling.no_redundant_sampling_points_angles[index][1];
+                ang[3 * k + 2] = psiIndex * psi_sampling + mysampling.no_redundant_sampling_points_angles[index][2];
+            }
+            xhCheck(xh_fp_project(guard.f, ang.data(), (int)m, nullptr, d_out.as<float>()));
+            xhCheck(xh_memcpy_d2h(ctx, gallery.data() + n0 * D * D, d_out.p, m * D * D * sizeof(float)));
+        }
+        d_out.release();
+        writeStack(output_file, gallery.data(), D, D, total);
     }
 };
 
