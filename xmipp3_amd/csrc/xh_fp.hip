@@ -32,37 +32,6 @@ __global__ void k_fp_pad(const float *__restrict__ vol, xh_cd *__restrict__ F, i
     F[idx] = xh_cd{v, 0.};
 }
 
-template <typename T, bool INV>
-__global__ void __launch_bounds__(256)
-k_fp_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal, size_t inner, size_t outerStride,
-               size_t innerStride, size_t elemStride, int lpb)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
-    const int n = plan.n, M = 1 << plan.logM;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const size_t line0 = (size_t)blockIdx.x * lpb;
-    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;
-        xh_c2<T> v = xh_c2<T>{0, 0};
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
-        }
-        s[l * M + xh_plan_pos(plan, e)] = v;
-    }
-    __syncthreads();
-    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
-        }
-    }
-}
-
 // F (raw FFT order, un-normalised) -> Re / Im volumes: completeFourierTransform's 1/P^3, ShiftFFT by
 // FIRST_XMIPP_INDEX(P) per axis, CenterFFT(.,true), K = P^3/D^2 (L257-266)
 __global__ void k_fp_center_split(const xh_cd *__restrict__ F, double *__restrict__ re, double *__restrict__ im, int P, int D)
@@ -250,13 +219,13 @@ int xh_fp_create(xh_ctx *ctx, const float *d_vol, int32_t D, double padding, dou
         const size_t nlines = (size_t)P * P;
         const unsigned gl = (unsigned)((nlines + lpb - 1) / lpb);
         // x lines: (k,i) -> offset (k*P+i)*P, element stride 1
-        hipLaunchKernelGGL((k_fp_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
                            (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
         // y lines: (k,j) -> offset k*P*P + j, element stride P
-        hipLaunchKernelGGL((k_fp_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
                            (size_t)P, (size_t)P * P, (size_t)1, (size_t)P, lpb);
         // z lines: (i,j) -> offset i*P + j, element stride P*P
-        hipLaunchKernelGGL((k_fp_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3(gl), dim3(256), smem, ctx->stream, (xh_cd *)F.p, planP.plan, nlines,
                            nlines, (size_t)0, (size_t)1, (size_t)P * P, lpb);
         hipLaunchKernelGGL(k_fp_center_split, dim3(gb), dim3(256), 0, ctx->stream, (const xh_cd *)F.p, (double *)re.p, (double *)im.p, P, D);
         // produceSplineCoefficients on both volumes: x (LDS row tiles), y (thread per column), z
@@ -340,7 +309,7 @@ int xh_fp_project(xh_fp *fp, const double *h_angles, int32_t n, const double *d_
         XH_LAUNCH_CHECK();
         // inverse along y: lines (p, j): offset p*per + j, element stride xh
         const size_t ncol = (size_t)m * xh;
-        hipLaunchKernelGGL((k_fp_fft_lines<double, true>), dim3((unsigned)((ncol + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((ncol + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            (xh_cd *)fp->d_pf.p, plan, ncol, (size_t)xh, per, (size_t)1, (size_t)xh, lpb);
         XH_LAUNCH_CHECK();
         const size_t nrows = (size_t)m * D;

@@ -69,6 +69,41 @@ __device__ __forceinline__ void xh_plan_exec(xh_c2<T> *s, const XhPlan<T> &p, in
     __syncthreads();
 }
 
+// Generic in-place strided line transform (un-normalised): line l starts at
+// (l / inner) * outerStride + (l % inner) * innerStride, its elements are elemStride apart; lpb lines per
+// 256-thread workgroup in ((lpb * sizeof(xh_c2<T>)) << logM) bytes of dynamic LDS. Used for every separable
+// 2-D / 3-D transform that is not fused into a neighbouring kernel.
+template <typename T, bool INV>
+__global__ void __launch_bounds__(256)
+xh_k_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal, size_t inner, size_t outerStride,
+               size_t innerStride, size_t elemStride, int lpb)
+{
+    extern __shared__ __align__(16) unsigned char xh_fft_lines_smem[];
+    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(xh_fft_lines_smem);
+    const int n = plan.n, M = 1 << plan.logM;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const size_t line0 = (size_t)blockIdx.x * lpb;
+    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;  // consecutive threads -> consecutive lines
+        xh_c2<T> v = xh_c2<T>{0, 0};
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
+        }
+        s[l * M + xh_plan_pos(plan, e)] = v;
+    }
+    __syncthreads();
+    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
+    for (int i = tid; i < lpb * n; i += nth) {
+        const int e = i / lpb, l = i - e * lpb;
+        if (l < nl) {
+            const size_t ln = line0 + l;
+            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
+        }
+    }
+}
+
 // ---- host side: tables of one plan, owned by the handle that created it
 template <typename T> struct XhPlanBufs {
     XhBuf W, chirp, vhat;

@@ -1669,38 +1669,6 @@ __global__ void k_pm_crop_real(const xh_cd *__restrict__ z, double *__restrict__
     out[(size_t)r * D * D + pix] = z[(size_t)r * P * P + (size_t)(i + o) * P + (j + o)].x;
 }
 
-// generic strided complex line FFT of any length (xh_plan.h: radix-2 for powers of two, Bluestein otherwise)
-template <typename T, bool INV>
-__global__ void __launch_bounds__(256)
-k_pm_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal,
-               size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
-    const int n = plan.n, M = 1 << plan.logM;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const size_t line0 = (size_t)blockIdx.x * lpb;
-    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;
-        xh_c2<T> v = xh_c2<T>{0, 0};
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
-        }
-        s[l * M + xh_plan_pos(plan, e)] = v;
-    }
-    __syncthreads();
-    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
-        }
-    }
-}
-
 // =========================================================================== host
 template <typename T>
 static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d_gather, int nslots,
@@ -1985,14 +1953,14 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
                 xh_cd *z = (xh_cd *)d_zpad.p;
                 hipLaunchKernelGGL(k_pm_pad_complex, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream,
                                    d_refs + (size_t)r0 * D * D, z, D, P);
-                hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
                                    z, planP.plan, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
-                hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
                                    z, planP.plan, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
                 hipLaunchKernelGGL(k_pm_mul_filter, dim3((unsigned)((perP + 255) / 256), m), dim3(256), 0, ctx->stream, z, (const double *)d_Mfull.p, P);
-                hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
                                    z, planP.plan, nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
-                hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
+                hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smemF, ctx->stream,
                                    z, planP.plan, nlines, (size_t)P, perP, (size_t)1, (size_t)P, lpb);
                 hipLaunchKernelGGL(k_pm_crop_real, dim3((unsigned)(((size_t)D * D + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)z,
                                    (double *)d_refD.p, D, P);
@@ -2431,20 +2399,20 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         XH_HIP(hipMemcpyAsync(w, z, sizeof(xh_cd) * per * m, hipMemcpyDeviceToDevice, ctx->stream));
         const size_t nlines = (size_t)m * D;
         // forward 2-D FFT of w: rows (contiguous), then columns
-        hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            w, planD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_pm_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            w, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
         XH_TRY(xh_buf_reserve(ctx, pm->d_t3, sizeof(xh_cd) * per * chunk));
         xh_cd *pw = (xh_cd *)pm->d_t3.p;
         hipLaunchKernelGGL(k_pm_crosspower, dim3((unsigned)((per + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cd *)w, pw, D);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            pw, planD, nlines, (size_t)1, (size_t)D, (size_t)0, (size_t)1, lpb);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_pm_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            pw, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,

@@ -15,7 +15,7 @@
 //   k_rf_rows / k_rf_cols   batched 2-D r2c FFT via LDS (pad, CenterFFT and crop fused)   HBM
 //   k_rf_ctf                CTF / modulator planes                                         VALU (fp64 sincos)
 //   k_rf_insert             gridding: slab traversal + blob gather + 3 float atomics/voxel HBM atomics  <-- dominant
-//   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, k_fft_lines, k_rf_c2r_window   O(volume) once
+//   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, xh_k_fft_lines (xh_plan.h), k_rf_c2r_window   O(volume) once
 #include "xh_common.h"
 #include "xh_fft.h"
 #include "xh_fftreg.h"
@@ -1423,39 +1423,6 @@ __global__ void k_rf_expand(const xh_cf *__restrict__ V, xh_cd *__restrict__ out
     out[idx] = acc;
 }
 
-// generic in-place strided complex line FFT (un-normalised), used for the z and y passes of the
-// 3-D inverse transform. line l -> base offset (l / inner) * outerStride + (l % inner) * innerStride
-template <typename T, bool INV>
-__global__ void __launch_bounds__(256)
-k_fft_lines(xh_c2<T> *__restrict__ data, XhPlan<T> plan, size_t nlinesTotal,
-            size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, int lpb)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    xh_c2<T> *s = reinterpret_cast<xh_c2<T> *>(smem);
-    const int n = plan.n, M = 1 << plan.logM;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const size_t line0 = (size_t)blockIdx.x * lpb;
-    const int nl = (int)min((size_t)lpb, nlinesTotal - line0);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;  // consecutive threads -> consecutive lines
-        xh_c2<T> v = xh_c2<T>{0, 0};
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            v = data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride];
-        }
-        s[l * M + xh_plan_pos(plan, e)] = v;
-    }
-    __syncthreads();
-    xh_plan_exec<T, INV>(s, plan, lpb, tid, nth);
-    for (int i = tid; i < lpb * n; i += nth) {
-        const int e = i / lpb, l = i - e * lpb;
-        if (l < nl) {
-            const size_t ln = line0 + l;
-            data[(ln / inner) * outerStride + (ln % inner) * innerStride + (size_t)e * elemStride] = s[l * M + e];
-        }
-    }
-}
-
 // last pass of the 3-D c2r inverse + CenterFFT(.,false) + window to D^3 + blob/sinc correction
 // (RFA:1028-1052). One line = (z,y) of the padded volume; only lines inside the window run.
 __global__ void __launch_bounds__(256)
@@ -2057,14 +2024,14 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     // inverse along z: lines (y,x), element stride P*xh
     {
         const size_t nlines = (size_t)P * xh;
-        hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            (xh_cd *)spec.p, plan, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
         XH_HIP_C(hipGetLastError());
     }
     // inverse along y: lines (z,x): offset z*P*xh + x, element stride xh
     {
         const size_t nlines = (size_t)P * xh;
-        hipLaunchKernelGGL((k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            (xh_cd *)spec.p, plan, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
         XH_HIP_C(hipGetLastError());
     }
