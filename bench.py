@@ -240,7 +240,7 @@ def main():
         out["rescored_fraction"] = pm.last_stats()["rescored_particles"] / float(B)
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, host cores of rank 0
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N=1 only
         from oracle import pyoracle as o
         ns = min(B, args.cpu_sample or (32 if D >= 256 else 64))
         h_refs = refs.cpu().numpy()
