@@ -6,6 +6,7 @@
 #ifndef XH_BSPLINE_H
 #define XH_BSPLINE_H
 #include <hip/hip_runtime.h>
+#include <cmath>
 
 // cubic B-spline prefilter, pole sqrt(3)-2, half-sample mirror boundary (xmippCore
 // produceSplineCoefficients; in-tree GPU twin reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41)
@@ -69,6 +70,67 @@ __global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, co
     if (slot >= nslots) return;
     if (count && slot >= *count) return;
     d_prefilter_line(coefs + (size_t)slot * D * D + x, D, D);
+}
+
+// ---- cubic B-spline prefilter in fp32 as a convolution ------------------------------------------------
+// The recursive filter (pole z = sqrt(3)-2, half-sample-symmetric boundary; k_pm_prefilter_rows/cols)
+// is, exactly, the convolution of the mirror-extended samples with h[j] = sqrt(3) z^|j|. The recursion is
+// a 2*D-step dependent chain per line (latency-bound: 1.5 us per 256-px image); z^17 < 2e-10 is below
+// fp32 resolution, so the fp32 users (coarse matching pass, image shifts before gridding) use the 33-tap
+// form, every output independent, eight outputs per thread from one 40-sample window. The fp64 paths
+// (reference library, re-scoring) keep the recursion.
+#define XH_FIR_K 16
+#define XH_FIR_V 8
+struct XhFir { float h[XH_FIR_K + 1]; };
+template <bool COLS>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D, size_t nvec, XhFir F)
+{
+    // thread <-> XH_FIR_V consecutive outputs along the filtered axis; neighbouring threads are neighbours
+    // along x for the column pass (coalesced rows) and along the line for the row pass
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+    int x0, y0;
+    size_t img;
+    if (COLS) { x0 = t % D; y0 = (int)((t / D) % segs) * XH_FIR_V; img = t / ((size_t)D * segs); }
+    else { x0 = (int)(t % segs) * XH_FIR_V; y0 = (int)((t / segs) % D); img = t / ((size_t)segs * D); }
+    const float *src = in + img * D * D;
+    float w[XH_FIR_V + 2 * XH_FIR_K];
+    if (!COLS && (D & 3) == 0 && x0 >= XH_FIR_K && x0 + XH_FIR_V + XH_FIR_K <= D) {
+        // interior of a row: the window is 16-byte aligned (x0 and XH_FIR_K are multiples of 4), ten float4 loads
+        const float4 *v = reinterpret_cast<const float4 *>(src + (size_t)y0 * D + x0 - XH_FIR_K);
+#pragma unroll
+        for (int i = 0; i < (XH_FIR_V + 2 * XH_FIR_K) / 4; ++i) {
+            const float4 q = v[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+    } else
+#pragma unroll
+    for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
+        int p = (COLS ? y0 : x0) + i - XH_FIR_K;
+        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
+        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        w[i] = COLS ? src[(size_t)p * D + x0] : src[(size_t)y0 * D + p];
+    }
+#pragma unroll
+    for (int o = 0; o < XH_FIR_V; ++o) {
+        const int q = (COLS ? y0 : x0) + o;
+        if (q >= D) break;
+        float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+        if (COLS) out[img * D * D + (size_t)q * D + x0] = acc;
+        else out[img * D * D + (size_t)y0 * D + q] = acc;
+    }
+}
+
+static inline XhFir xh_fir_taps()
+{
+    XhFir F;
+    const double z = sqrt(3.0) - 2.0;
+    for (int j = 0; j <= XH_FIR_K; ++j) F.h[j] = (float)(sqrt(3.0) * pow(z, j));
+    return F;
 }
 
 template <typename T> __device__ __forceinline__ T d_bspline03(T x)

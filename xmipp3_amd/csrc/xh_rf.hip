@@ -1775,6 +1775,16 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
         XH_HIP(hipMemcpyAsync(d_flip, h_flip, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
     XH_HIP(hipStreamSynchronize(ctx->stream));
+    if (D >= 2 * XH_FIR_K) {
+        // fp32 prefilter in its convolution form (xh_bspline.h); d_out is free until the shift kernel writes it
+        const XhFir F = xh_fir_taps();
+        const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+        const size_t nvec = (size_t)n * D * segs;
+        hipLaunchKernelGGL((k_pm_prefilter_fir<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, d_imgs, d_out, D, nvec, F);
+        hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_out,
+                           (float *)rf->d_shiftCoef.p, D, nvec, F);
+        XH_LAUNCH_CHECK();
+    } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(float)))));
     const int tiles = (D + TR - 1) / TR;
     hipLaunchKernelGGL((k_pm_prefilter_rows<float, float>), dim3(n * tiles), dim3(64), sizeof(float) * TR * (D + 1), ctx->stream,
@@ -1783,6 +1793,7 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
     hipLaunchKernelGGL((k_pm_prefilter_cols<float>), dim3((n * D + 63) / 64), dim3(64), 0, ctx->stream, (float *)rf->d_shiftCoef.p, D, n,
                        (const int *)nullptr);
     XH_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, (const float *)rf->d_shiftCoef.p, d_imgs,
                        (const float2 *)rf->d_shiftXY.p, (const unsigned char *)d_flip, d_out, D);
     XH_LAUNCH_CHECK();
