@@ -188,8 +188,18 @@ def test_cli_symmetry_names_and_files(bins, tmp_path, oracle):
     rf.mirror_and_crop()
     exp = rf.finish()
     assert np.abs(vols["name"] - exp).max() <= 1e-4 * np.abs(exp).max()
+    # octahedral group by name == its generators as written by the reference (sampling.cpp:1399-1404)
+    (tmp_path / "o.sym").write_text("rot_axis 3  .5773502  .5773502 .5773502\nrot_axis 4 0 0 1\n")
+    vo = {}
+    for tag, sym in (("oname", "o"), ("ofile", str(tmp_path / "o.sym"))):
+        r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / f"{tag}.vol"),
+                  "--sym", sym])
+        assert r.returncode == 0, r.stderr
+        vo[tag] = xmipp_io.read_volume(str(tmp_path / f"{tag}.vol"))
+    assert np.abs(vo["oname"] - vo["ofile"]).max() <= 1e-4 * np.abs(vo["oname"]).max()   # the file has 7-digit axes
+    assert np.abs(vo["oname"] - vols["name"]).max() > 1e-2 * np.abs(vo["oname"]).max()  # and it is not d2
     # an unknown name must fail loudly, not reconstruct without symmetry
-    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i3"])
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i3h"])
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
 
 

@@ -100,9 +100,115 @@ def test_cn_dn_units_and_loud_failures(prog, tmp_path):
         assert r.returncode == 0, r.stderr
         n[sym] = len(xmipp_io.read_xmd(str(tmp_path / f"{sym}.doc"))[1])
     assert 0.2 < n["c4"] / n["c1"] < 0.32 and 0.2 < n["d2"] / n["c1"] < 0.32
-    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--sym", "i3", "--only_create_sampling"],
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--sym", "i3h", "--only_create_sampling"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
     r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--method", "real_space", "--only_create_sampling"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+
+
+# ---- point groups beyond cN: generators (Sampling::createSymFile, sampling.cpp:1377-1416) and asymmetric
+# units (Sampling::removeRedundantPoints, sampling.cpp:808-1069) are both in the reference tree; that they fit
+# together -- and in which orientation i1, i3, i4 relate to i2 -- is checked here numerically.
+def _rot_axis(fold, ax):
+    ax = np.array(ax, float)
+    ax /= np.linalg.norm(ax)
+    a = 2 * np.pi / fold
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def _closure(gens):
+    G = [np.eye(3)]
+    grew = True
+    while grew:
+        grew = False
+        for a in list(G):
+            for g in gens:
+                P = a @ g
+                if not any(np.abs(P - h).max() < 1e-6 for h in G):
+                    G.append(P)
+                    grew = True
+                    assert len(G) <= 240
+    return G
+
+
+def _group(name):
+    from tests import synth
+    phi = (1 + 5 ** 0.5) / 2
+    if name == "t":
+        return _closure([_rot_axis(3, (0, 0, 1)), _rot_axis(2, (0, (2 / 3) ** 0.5, (1 / 3) ** 0.5))])
+    if name == "o":
+        return _closure([_rot_axis(3, (1, 1, 1)), _rot_axis(4, (0, 0, 1))])
+    G2 = _closure([_rot_axis(2, (0, 0, 1)), _rot_axis(5, (-phi, -1, 0)), _rot_axis(3, (-1, -phi * phi, 0))])
+    tilt = {"i1": 90.0, "i2": 0.0, "i3": 31.7174745559, "i4": -31.7174745559}[name]
+    A = synth.euler_matrix(0, tilt, 0)
+    return [A @ g @ A.T for g in G2]
+
+
+def _in_unit(name, v, eps=1e-9):
+    """the reference's asymmetric unit, open (strict) version for the uniqueness count"""
+    from tests import synth
+    u = lambda x: np.array(x, float) / np.linalg.norm(x)
+    rot = np.degrees(np.arctan2(v[1], v[0]))
+    tilt = np.degrees(np.arccos(np.clip(v[2], -1, 1)))
+    if name == "t":
+        n = [u((-0.942809, 0, 0)), u((0.471405, 0.272165, 0.7698)), u((0.471404, 0.816497, 0))]
+        return all(v @ k > eps for k in n) and 90 <= rot <= 150
+    if name == "o":
+        n = [u((0, -1, 1)), u((1, 1, 0)), u((-1, 1, 0))]
+        return all(v @ k > eps for k in n) and 45 <= rot <= 135 and tilt <= 90
+    if name == "i4":
+        A = synth.euler_matrix(0, -31.7174745559, 0)
+        n = [A @ u((0, 0, 1)), A @ u((0.187592467856686, -0.303530987314591, -0.491123477863004)),
+             A @ u((0.187592467856686, 0.303530987314591, -0.491123477863004))]
+        return all(v @ k < -eps for k in n)
+    A = synth.euler_matrix(0, {"i1": 90.0, "i2": 0.0, "i3": 31.7174745559}[name], 0)
+    n = [A @ u((0, 1, 0)), A @ u((-0.4999999839058737, -0.8090170074556163, 0.3090169861701543)),
+         A @ u((0.4999999839058737, -0.8090170074556163, 0.3090169861701543))]
+    return all(v @ k > eps for k in n)
+
+
+@pytest.mark.parametrize("name,order", [("t", 12), ("o", 24), ("i1", 60), ("i2", 60), ("i3", 60), ("i4", 60)])
+def test_cubic_groups_generators_fit_the_asymmetric_units(prog, tmp_path, name, order):
+    # (1) in-tree generators x in-tree asymmetric unit = a fundamental domain: every direction has exactly one image in it
+    G = _group(name)
+    assert len(G) == order
+    rng = np.random.default_rng(3)
+    pts = rng.standard_normal((1500, 3))
+    pts /= np.linalg.norm(pts, axis=1)[:, None]
+    assert all(sum(_in_unit(name, g @ p) for g in G) == 1 for p in pts)
+    # (2) the host program uses exactly that group and that unit
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "4", "--sym", name,
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    M = np.loadtxt(str(tmp_path / "g_symmetry.txt")).reshape(-1, 3, 3)
+    assert len(M) == order and np.allclose(M[0], np.eye(3))
+    for m in M:
+        assert np.allclose(m @ m.T, np.eye(3), atol=1e-12) and np.linalg.det(m) > 0
+        assert any(np.abs(m - g).max() < 1e-9 for g in G)
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "all.stk"), "--sampling_rate", "4", "--sym", "c1",
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    la, ra = xmipp_io.read_xmd(str(tmp_path / "all.doc"))
+    lu, ru = xmipp_io.read_xmd(str(tmp_path / "g.doc"))
+    ca, cu = {k: i for i, k in enumerate(la)}, {k: i for i, k in enumerate(lu)}
+    allv = np.array([[float(x[ca[k]]) for k in ("X", "Y", "Z")] for x in ra])
+    unit = np.array([[float(x[cu[k]]) for k in ("X", "Y", "Z")] for x in ru])
+    assert abs(len(unit) / len(allv) - 1.0 / order) < 0.6 / order       # boundary points count for several units
+    # (the docfile carries 6 decimals and i3's boundary planes pass through sampling points: keep a margin)
+    inside = np.array([_in_unit(name, v, 1e-5) for v in allv])
+    keys = {tuple(np.round(v, 6)) for v in unit}
+    assert all(tuple(np.round(v, 6)) in keys for v in allv[inside])    # every interior direction was kept
+
+
+def test_named_groups_in_symlist(prog, tmp_path):
+    for name, order in (("c5", 5), ("d7", 14), ("d2", 4), ("i", 60)):
+        r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "10", "--sym", name,
+                            "--only_create_sampling"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        M = np.loadtxt(str(tmp_path / "g_symmetry.txt")).reshape(-1, 3, 3)
+        assert len(M) == order
+        prods = {tuple(np.round((a @ b).ravel(), 6) + 0.0) for a in M for b in M}
+        assert len(prods) == order                                   # closed under multiplication

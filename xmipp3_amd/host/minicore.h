@@ -328,8 +328,8 @@ public:
     // Accepts what the reference's --sym takes (RFA:243-251): a point-group name or a symmetry file with
     // `rot_axis <fold> <x> <y> <z>` lines (xmippCore SymList::readSymmetryFile). Reconstruction sums over
     // the whole group, so only the SET of rotations matters. Built-in names: cN, dN (N-fold about Z and,
-    // for dN, a 2-fold about X); the cubic groups come in several orientation conventions (i1..i4, ...)
-    // defined in xmippCore, whose source is not in the reference tree -- pass them as a symmetry file.
+    // for dN, a 2-fold about X -- Scipion's "dihedral X" convention for Xmipp; the dead createSymFile of
+    // sampling.cpp:1361 writes Y instead, which is the same group only for even N), t, o, i1..i4.
     void readSymmetryFile(const std::string &sym)
     {
         R.clear();
@@ -366,8 +366,27 @@ public:
             close(gens);
             return;
         }
-        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is neither a readable symmetry file nor cN/dN; "
-                     "write the group's rot_axis lines to a file and pass that");
+        // Cubic groups. Generators as written by Sampling::createSymFile (data/sampling.cpp:1377-1416; the
+        // 6-digit axes there are sqrt(2/3), 1/sqrt(3), the golden ratio ...). i1, i3, i4 are i2 turned by
+        // Euler(0, 90 | 31.7174745559 | -31.7174745559, 0): the only orientations for which the asymmetric
+        // units of Sampling::removeRedundantPoints (sampling.cpp:985-1069) are fundamental domains
+        // (checked numerically, tests/test_sampling.py).
+        const double phi = (1 + std::sqrt(5.0)) / 2;
+        if (s == "t") { close({rotAxis(2 * M_PI / 3, 0, 0, 1), rotAxis(M_PI, 0, std::sqrt(2.0 / 3.0), std::sqrt(1.0 / 3.0))}); return; }
+        if (s == "o") { close({rotAxis(2 * M_PI / 3, 1, 1, 1), rotAxis(M_PI / 2, 0, 0, 1)}); return; }
+        if (s == "i" || s == "i1" || s == "i2" || s == "i3" || s == "i4") {
+            close({rotAxis(M_PI, 0, 0, 1), rotAxis(2 * M_PI / 5, -phi, -1, 0), rotAxis(2 * M_PI / 3, -1, -phi * phi, 0)});
+            const double tilt = s == "i1" ? 90. : s == "i3" ? 31.7174745559 : s == "i4" ? -31.7174745559 : 0.;
+            if (tilt != 0.) {
+                // Euler_angles2matrix(0, tilt, 0): rotation about Y
+                const double b = tilt * M_PI / 180., cb = std::cos(b), sb = std::sin(b);
+                const std::vector<double> A = {cb, 0, -sb, 0, 1, 0, sb, 0, cb}, At = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
+                for (auto &g : R) g = mul(mul(A, g), At);
+            }
+            return;
+        }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is neither a readable symmetry file nor one of cN, dN, t, o, "
+                     "i1..i4 (groups with mirrors or inversions are not available); write the group's rot_axis lines to a file and pass that");
     }
     int symsNo() const { return (int)R.size(); }
 };

@@ -702,17 +702,20 @@ public:
         batch = std::max(1, (int)getIntParam("--batch"));
         only_sampling = checkParam("--only_create_sampling");
     }
-    static void parseGroup(const std::string &sym, char &family, int &order)
+    static void parseGroup(const std::string &sym, std::string &family, int &order)
     {
         std::string s = sym;
         std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        order = 1;
         if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd') && std::all_of(s.begin() + 1, s.end(), ::isdigit) && atoi(s.c_str() + 1) >= 1) {
-            family = s[0];
+            family = std::string(1, s[0]);
             order = atoi(s.c_str() + 1);
             return;
         }
-        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "symmetry '" + sym + "': the sampling of the asymmetric unit is implemented for cN and dN "
-                     "(the other point groups are defined in xmippCore's SymList, which is not in the reference tree)");
+        if (s == "t" || s == "o" || s == "i1" || s == "i2" || s == "i3" || s == "i4") { family = s; return; }
+        if (s == "i") { family = "i2"; return; }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "symmetry '" + sym + "': the sampling of the asymmetric unit is implemented for cN, dN, t, o and "
+                     "i1..i4 (groups with mirrors or inversions are not available)");
     }
     void run() override
     {
@@ -720,7 +723,7 @@ public:
         if (perturb_projection_vector != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--perturb is not available (it is seeded with time() in the reference)");
         if (compute_closer_sampling_point_bool) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--closer_sampling_points is not available yet");
         if (!fn_groups.empty()) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--groups is not available yet");
-        char fam, famN;
+        std::string fam, famN;
         int order, orderN;
         parseGroup(fn_sym, fam, order);
         parseGroup(fn_sym_neigh, famN, orderN);
@@ -770,6 +773,12 @@ public:
             else std::cout << "There are no projections within the specified angular range and sampling" << std::endl;
         }
         std::remove((output_file_root + "_angles.doc").c_str());
+        if (only_sampling) {
+            // diagnostic: the rotations of the neighbourhood group (identity first), one 3x3 matrix per line
+            std::ofstream f(output_file_root + "_symmetry.txt");
+            f.precision(17);
+            for (const auto &Rm : mysampling.R_repository) { for (double v : Rm) f << v << ' '; f << '\n'; }
+        }
         if (only_sampling || nDir == 0) return;
         // projections (project_angle_vector, angular_project_library.cpp:194-245): psi-major, direction-minor
         std::vector<float> vol;

@@ -138,17 +138,44 @@ struct SamplingGen {
         numberSamplesAsymmetricUnit = sampling_points_vector.size();
     }
 
-    // asymmetric unit of cN (L702-712) and dN (L766-778); the other point groups live in xmippCore's SymList
-    void removeRedundantPoints(char family, int order)
+    // asymmetric units (removeRedundantPoints): cN (L702-712), dN (L766-778), T (L808-834), O (L890-917),
+    // I2 (L946-975), I1 / I3 / I4 as turned copies (L976-1069). group: "c"/"d" + order, "t", "o", "i1".."i4"
+    void removeRedundantPoints(const std::string &group, int order)
     {
         no_redundant_sampling_points_vector.clear();
         no_redundant_sampling_points_angles.clear();
         no_redundant_sampling_points_index.clear();
+        auto unit = [](Vec3 v) { const double n = std::sqrt(dot(v, v)); return Vec3{v[0] / n, v[1] / n, v[2] / n}; };
+        auto turnY = [](double tiltDeg, const Vec3 &v) {   // Euler_angles2matrix(0, tilt, 0) * v
+            const double b = tiltDeg * M_PI / 180., cb = std::cos(b), sb = std::sin(b);
+            return Vec3{cb * v[0] - sb * v[2], v[1], sb * v[0] + cb * v[2]};
+        };
+        Vec3 n1{}, n2{}, n3{};
+        double sign = 1;
+        if (group == "t") { n1 = unit({-0.942809, 0., 0.}); n2 = unit({0.471405, 0.272165, 0.7698}); n3 = unit({0.471404, 0.816497, 0.}); }
+        else if (group == "o") { n1 = unit({0., -1., 1.}); n2 = unit({1., 1., 0.}); n3 = unit({-1., 1., 0.}); }
+        else if (group == "i1" || group == "i2" || group == "i3") {
+            const double tilt = group == "i1" ? 90. : group == "i3" ? 31.7174745559 : 0.;
+            n1 = unit(turnY(tilt, {0., 1., 0.}));
+            n2 = unit(turnY(tilt, {-0.4999999839058737, -0.8090170074556163, 0.3090169861701543}));
+            n3 = unit(turnY(tilt, {0.4999999839058737, -0.8090170074556163, 0.3090169861701543}));
+        } else if (group == "i4") {
+            n1 = unit(turnY(-31.7174745559, {0., 0., 1.}));
+            n2 = unit(turnY(-31.7174745559, {0.187592467856686, -0.303530987314591, -0.491123477863004}));
+            n3 = unit(turnY(-31.7174745559, {0.187592467856686, 0.303530987314591, -0.491123477863004}));
+            sign = -1;
+        }
         for (size_t i = 0; i < sampling_points_angles.size(); i++) {
             const double rot = sampling_points_angles[i][0], tilt = sampling_points_angles[i][1];
+            const Vec3 &v = sampling_points_vector[i];
             bool keep;
-            if (family == 'c') keep = rot >= (-180. / order) && rot <= (180. / order);
-            else keep = rot >= -180. / order + 90. && rot <= 180. / order + 90. && tilt <= 90.;
+            if (group == "c") keep = rot >= (-180. / order) && rot <= (180. / order);
+            else if (group == "d") keep = rot >= -180. / order + 90. && rot <= 180. / order + 90. && tilt <= 90.;
+            else {
+                keep = sign * dot(v, n1) >= 0 && sign * dot(v, n2) >= 0 && sign * dot(v, n3) >= 0;
+                if (group == "t") keep = keep && ((rot >= 90. && rot <= 150.) || rot == 0);
+                if (group == "o") keep = keep && ((rot >= 45. && rot <= 135. && tilt <= 90.) || rot == 0.);
+            }
             if (keep) {
                 no_redundant_sampling_points_angles.push_back(sampling_points_angles[i]);
                 no_redundant_sampling_points_vector.push_back(sampling_points_vector[i]);
