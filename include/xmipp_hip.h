@@ -18,9 +18,11 @@
  *    (e.g. a torch tensor) -- the library never frees caller memory.
  *  - all work is enqueued on the context's HIP stream; calls return when the
  *    work is enqueued unless stated otherwise ("synchronous").
- *  - one host thread per context; handles are not thread-safe (same contract
- *    as reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:46-157, one
- *    stream per host thread).
+ *  - one host thread at a time per context; handles are not thread-safe (same
+ *    contract as reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:46-157, one
+ *    stream per host thread).  Every entry point makes its context's device
+ *    current on the calling thread, so a process may drive several devices
+ *    from several threads (xmipp3_amd/host: --gpus).
  *  - images are row-major float32, D x D, logical (Xmipp) origin at pixel
  *    (D/2, D/2) as after MultidimArray::setXmippOrigin().
  */
@@ -156,6 +158,22 @@ int xh_rf_kernel_ms(xh_rf *rf, double *h_ms, int64_t *h_launches, int32_t reset)
  * host all-reduces (SUM) before xh_rf_finish. */
 int xh_rf_mirror_and_crop(xh_rf *rf);
 size_t xh_rf_cropped_floats(const xh_rf *rf);
+/* The cropped spaces as data (xh_rf_cropped_floats() floats on the handle's device):
+ *  - export: copy them out (asynchronous on the handle's stream);
+ *  - import: load (add = 0; the handle then counts as cropped) or accumulate (add != 0) a buffer of
+ *    the same layout that lives on the handle's device.
+ * This is what ProgRecFourier's --prepare_fsc does through its <fsc>_1_Fourier.vol / _1_Weights.vol
+ * files (reconstruction/reconstruct_fourier.cpp:991-1045): keep half 1, rebuild from zero for half 2,
+ * then sum both. xh_rf_finish consumes the cropped spaces (weights are divided in place), so export
+ * before finishing whatever has to be summed later. */
+int xh_rf_cropped_export(xh_rf *rf, float *d_dst);
+int xh_rf_cropped_import(xh_rf *rf, const float *d_src, int32_t add);
+/* Sum the cropped spaces of n handles (any mix of devices of this node) into rfs[0]: binary tree,
+ * peer copies over xGMI into the receiver's scratch + one add kernel per pair; synchronous. Replaces
+ * the 2*(mv+1)^2 MPI_Reduce calls of mpi_reconstruct_fourier_accel.cpp:245-266 for a single-process,
+ * thread-per-device host (the torch.distributed host all-reduces the same buffer instead, see
+ * xh_rf_attach_temp). Handles other than rfs[0] keep their own partial sums (level-wise). */
+int xh_rf_reduce(xh_rf *const *rfs, int32_t n);
 /* finishComputations (RFA:1002-1055): synchronous; writes D^3 doubles, [z][y][x] */
 int xh_rf_finish(xh_rf *rf, double *h_volume);
 

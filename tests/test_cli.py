@@ -127,6 +127,69 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
 
 
 @pytest.mark.gpu
+def test_cli_several_devices_give_the_single_device_answer(bins, tmp_path):
+    """--gpus / --devices: one host thread per device slot, contiguous particle ranges, the visiting-order
+    parity carried across the ranges, one tree reduction of the volumes. The box has one GPU, so the slots
+    all sit on device 0 (--devices 0,0,0): same threads, contexts, streams and reduction as on a node."""
+    _write_dataset(tmp_path, D=32, n=11)
+    apm = os.path.join(bins, "xmipp_angular_projection_matching")
+    base = [apm, "-i", str(tmp_path / "exp.xmd"), "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "2"]
+    r1 = _run(base + ["-o", str(tmp_path / "one.xmd")])
+    r3 = _run(base + ["-o", str(tmp_path / "three.xmd"), "--devices", "0,0,0"])
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stderr + r3.stderr
+    assert "Devices                 : 0,0,0" in r3.stdout
+    assert open(tmp_path / "one.xmd").read() == open(tmp_path / "three.xmd").read()
+    rfa = os.path.join(bins, "xmipp_reconstruct_fourier_accel")
+    a = _run([rfa, "-i", str(tmp_path / "one.xmd"), "-o", str(tmp_path / "one.vol"), "--batch", "3"])
+    b = _run([rfa, "-i", str(tmp_path / "one.xmd"), "-o", str(tmp_path / "three.vol"), "--batch", "3", "--devices", "0,0,0"])
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    v1, v3 = xmipp_io.read_volume(str(tmp_path / "one.vol")), xmipp_io.read_volume(str(tmp_path / "three.vol"))
+    assert np.abs(v1 - v3).max() <= 1e-5 * np.abs(v1).max()
+    # more device slots than images: the empty ranges contribute nothing
+    c = _run([rfa, "-i", str(tmp_path / "one.xmd"), "-o", str(tmp_path / "many.vol"), "--devices", ",".join(["0"] * 13)])
+    assert c.returncode == 0, c.stderr
+    assert np.abs(xmipp_io.read_volume(str(tmp_path / "many.vol")) - v1).max() <= 1e-5 * np.abs(v1).max()
+    # a device this node does not have is an argument error, not a silent clamp
+    d = _run(base + ["-o", str(tmp_path / "x.xmd"), "--gpus", "64"])
+    assert d.returncode != 0 and "XMIPP_ERROR" in d.stderr and "requested but this node has" in d.stderr
+    e = _run(base + ["-o", str(tmp_path / "x.xmd"), "--devices", "0,a"])
+    assert e.returncode != 0 and "XMIPP_ERROR" in e.stderr
+
+
+@pytest.mark.gpu
+def test_cli_prepare_fsc_writes_the_two_half_set_volumes(bins, tmp_path):
+    """xmipp_reconstruct_fourier --prepare_fsc <root> (RF:846,991-1045): images 0..(n-1)/2 -> <root>_1_recons.vol,
+    the rest -> <root>_2_recons.vol, output volume = reconstruction from the summed halves."""
+    D, n = 32, 9
+    vol = synth.phantom(D, seed=8, nblobs=10)
+    ang = synth.random_angles(n, np.random.default_rng(5))
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "p.stk"), imgs)
+
+    def write(name, idx):
+        xmipp_io.write_xmd(str(tmp_path / name), [("noname", ["image", "angleRot", "angleTilt", "anglePsi"],
+                           [[f"{i + 1}@{tmp_path}/p.stk"] + [f"{v:.6f}" for v in ang[i]] for i in idx])])
+    write("all.xmd", range(n))
+    split = (n - 1) // 2          # FSCIndex, included in half 1
+    write("h1.xmd", range(0, split + 1))
+    write("h2.xmd", range(split + 1, n))
+    rf = os.path.join(bins, "xmipp_reconstruct_fourier")
+    r = _run([rf, "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "all.vol"), "--prepare_fsc", str(tmp_path / "fsc"), "--devices", "0,0"])
+    assert r.returncode == 0, r.stderr
+    for name in ("plain", "h1", "h2"):
+        q = _run([rf, "-i", str(tmp_path / ("all.xmd" if name == "plain" else name + ".xmd")), "-o", str(tmp_path / (name + ".vol"))])
+        assert q.returncode == 0, q.stderr
+    rd = lambda f: xmipp_io.read_volume(str(tmp_path / f))
+    full = rd("plain.vol")
+    tol = 1e-5 * np.abs(full).max()
+    assert np.abs(rd("all.vol") - full).max() <= tol
+    assert np.abs(rd("fsc_1_recons.vol") - rd("h1.vol")).max() <= tol
+    assert np.abs(rd("fsc_2_recons.vol") - rd("h2.vol")).max() <= tol
+    # the reference deletes its intermediate <root>_{1,2}_{Fourier,Weights}.vol; nothing of the kind is left here
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("fsc")) == ["fsc_1_recons.vol", "fsc_2_recons.vol"]
+
+
+@pytest.mark.gpu
 def test_cli_5d_search_and_number_orientations(bins, tmp_path, oracle):
     """`--search5d_shift 2 --search5d_step 2 --number_orientations 3`: rows per image are the
     valid ranks of the reference's running top-N, each with its own translational alignment."""

@@ -282,6 +282,66 @@ def test_linearity_of_insertion(gpu, data32):
     assert (rf.temp - v1).abs().max().item() <= 2e-6 * v1.abs().max().item()
 
 
+def test_reduce_of_partial_reconstructions(gpu, data32):
+    """Thread-per-device hosts sum their partial cropped spaces with xh_rf_reduce (here three handles on
+    the one GPU of the box: same code path minus the peer copy). Float sum order differs from the
+    single-handle run, hence a float tolerance on the volume."""
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    one = xa.RecFourier(ctx, D)
+    f = one.prepare_images(torch.from_numpy(imgs).cuda())
+    one.insert(f, ang)
+    one.mirror_and_crop()
+    ref_cropped = one.cropped_view().clone()
+    ref = one.finish()
+    parts = []
+    for g in range(3):
+        lo, hi = xa.shard_range(len(imgs), g, 3)
+        rf = xa.RecFourier(ctx, D)
+        rf.insert(f[lo:hi].contiguous(), ang[lo:hi])
+        rf.mirror_and_crop()
+        parts.append(rf)
+    xa.reduce_reconstructions(parts)
+    summed = parts[0].cropped_view()
+    assert (summed - ref_cropped).abs().max().item() <= 2e-6 * ref_cropped.abs().max().item()
+    got = parts[0].finish()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(xa.XhError):
+        xa.reduce_reconstructions([parts[1], parts[1]])
+    with pytest.raises(xa.XhError):
+        xa.reduce_reconstructions([parts[1], xa.RecFourier(ctx, D)])   # second one not cropped yet
+
+
+def test_half_sets_sum_to_the_full_reconstruction(gpu, data32):
+    """--prepare_fsc bookkeeping (RF:991-1045): half 1 and half 2 are reconstructed from zeroed spaces,
+    their Fourier volumes + weights are kept and summed for the final volume."""
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    rf = xa.RecFourier(ctx, D)
+    f = rf.prepare_images(torch.from_numpy(imgs).cuda())
+    rf.insert(f, ang)
+    rf.mirror_and_crop()
+    full = rf.finish()
+    h = len(imgs) // 2
+    rf.reset()
+    rf.insert(f[:h].contiguous(), ang[:h])
+    rf.mirror_and_crop()
+    keep1 = rf.export_cropped()
+    v1 = rf.finish()
+    rf.reset()
+    rf.insert(f[h:].contiguous(), ang[h:])
+    rf.mirror_and_crop()
+    keep2 = rf.export_cropped()
+    v2 = rf.finish()
+    rf.import_cropped(keep1)
+    rf.import_cropped(keep2, add=True)
+    both = rf.finish()
+    assert np.abs(both - full).max() <= 1e-5 * np.abs(full).max()
+    # the halves are genuinely different reconstructions of the same object
+    assert np.abs(v1 - v2).max() > 1e-3 * np.abs(full).max()
+    assert np.corrcoef(v1.ravel(), v2.ravel())[0, 1] > 0.9
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     with pytest.raises(xa.XhError):

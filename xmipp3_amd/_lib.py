@@ -66,6 +66,9 @@ SIGNATURES = {
     "xh_rf_insert_matrices": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
     "xh_rf_mirror_and_crop": (C.c_int, [vp]),
     "xh_rf_cropped_floats": (sz, [vp]),
+    "xh_rf_cropped_export": (C.c_int, [vp, vp]),
+    "xh_rf_cropped_import": (C.c_int, [vp, vp, i32]),
+    "xh_rf_reduce": (C.c_int, [pvp, i32]),
     "xh_rf_finish": (C.c_int, [vp, vp]),
     "xh_pm_create": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, i32, pvp]),
     "xh_pm_destroy": (C.c_int, [vp]),

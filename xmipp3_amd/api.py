@@ -244,10 +244,30 @@ class RecFourier:
         assert self.cropped
         return self.temp[:lib().xh_rf_cropped_floats(self.h)]
 
+    def export_cropped(self):
+        """Copy of the cropped spaces (a torch tensor on the handle's device); finish() consumes the
+        originals, so this is how a half-set is kept for the later sum (RF:991-1045)."""
+        torch = _torch()
+        out = torch.empty(lib().xh_rf_cropped_floats(self.h), dtype=torch.float32, device=self.ctx.torch_device)
+        check(lib().xh_rf_cropped_export(self.h, _ptr(out)))
+        return out
+
+    def import_cropped(self, buf, add=False):
+        assert buf.dtype == _torch().float32 and buf.numel() == lib().xh_rf_cropped_floats(self.h)
+        check(lib().xh_rf_cropped_import(self.h, _ptr(buf), 1 if add else 0))
+        self.cropped = True
+
     def finish(self):
         out = np.empty((self.D, self.D, self.D), np.float64)
         check(lib().xh_rf_finish(self.h, _np_ptr(out)))
         return out
+
+
+def reduce_reconstructions(rfs):
+    """Sum the cropped spaces of several handles of this process (one per device) into rfs[0]:
+    the thread-per-device counterpart of allreduce_reconstruction (xh_rf_reduce)."""
+    arr = (C.c_void_p * len(rfs))(*[r.h for r in rfs])
+    check(lib().xh_rf_reduce(arr, len(rfs)))
 
 
 def allreduce_reconstruction(rf):

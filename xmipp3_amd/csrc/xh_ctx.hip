@@ -108,6 +108,7 @@ int xh_ctx_destroy(xh_ctx *ctx)
 int xh_ctx_sync(xh_ctx *ctx)
 {
     XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
     XH_HIP(hipStreamSynchronize(ctx->stream));
     return XH_OK;
 }
@@ -127,6 +128,7 @@ int xh_malloc(xh_ctx *ctx, size_t bytes, void **d_ptr)
 int xh_free(xh_ctx *ctx, void *d_ptr)
 {
     XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
     XH_HIP(hipStreamSynchronize(ctx->stream));
     XH_HIP(hipFree(d_ptr));
     return XH_OK;
@@ -134,12 +136,14 @@ int xh_free(xh_ctx *ctx, void *d_ptr)
 int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes)
 {
     XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
     XH_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
     return XH_OK;
 }
 int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
     XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
     XH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(hipStreamSynchronize(ctx->stream));
     return XH_OK;
@@ -147,6 +151,7 @@ int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
     XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
     XH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XH_HIP(hipStreamSynchronize(ctx->stream));
     return XH_OK;
@@ -158,6 +163,7 @@ struct XhTimer {
 int xh_timer_create(xh_ctx *ctx, void **timer)
 {
     XH_CHECK(ctx && timer, XH_ERR_ARG, "null argument");
+    XH_HIP(hipSetDevice(ctx->device));
     XhTimer *t = new XhTimer;
     XH_HIP(hipEventCreate(&t->a));
     XH_HIP(hipEventCreate(&t->b));

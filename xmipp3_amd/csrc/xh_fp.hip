@@ -259,6 +259,7 @@ int xh_fp_create(xh_ctx *ctx, const float *d_vol, int32_t D, double padding, dou
 int xh_fp_destroy(xh_fp *fp)
 {
     if (!fp) return XH_OK;
+    (void)hipSetDevice(fp->ctx->device);
     (void)hipStreamSynchronize(fp->ctx->stream);
     xh_buf_free(fp->d_re); xh_buf_free(fp->d_im); xh_buf_free(fp->d_pf); xh_buf_free(fp->d_eul);
     xh_plan_free(fp->planD);
@@ -278,6 +279,7 @@ int xh_fp_info(const xh_fp *fp, int32_t *P, int32_t *cdim, int32_t *cstart)
 int xh_fp_coefs(const xh_fp *fp, double *h_re, double *h_im)
 {
     XH_CHECK(fp && h_re && h_im, XH_ERR_ARG, "xh_fp_coefs: bad argument");
+    XH_HIP(hipSetDevice(fp->ctx->device));
     XH_HIP(hipMemcpyAsync(h_re, fp->d_re.p, fp->d_re.bytes, hipMemcpyDeviceToHost, fp->ctx->stream));
     XH_HIP(hipMemcpyAsync(h_im, fp->d_im.p, fp->d_im.bytes, hipMemcpyDeviceToHost, fp->ctx->stream));
     XH_HIP(hipStreamSynchronize(fp->ctx->stream));
@@ -287,6 +289,7 @@ int xh_fp_coefs(const xh_fp *fp, double *h_re, double *h_im)
 int xh_fp_project(xh_fp *fp, const double *h_angles, int32_t n, const double *d_ctf, float *d_out)
 {
     XH_CHECK(fp && h_angles && d_out && n >= 0, XH_ERR_ARG, "xh_fp_project: bad argument");
+    XH_HIP(hipSetDevice(fp->ctx->device));
     if (n == 0) return XH_OK;
     xh_ctx *ctx = fp->ctx;
     const int D = fp->D, xh = D / 2 + 1;

@@ -1983,6 +1983,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
 int xh_pm_destroy(xh_pm *pm)
 {
     if (!pm) return XH_OK;
+    (void)hipSetDevice(pm->ctx->device);
     (void)hipStreamSynchronize(pm->ctx->stream);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(pm->ev[i]);
     free_all(pm);
@@ -2120,6 +2121,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
                    int32_t *d_refno, int32_t *d_psi, uint8_t *d_flip)
 {
     XH_CHECK(pm && d_particles && d_refno && d_psi && d_flip && n >= 0, XH_ERR_ARG, "xh_pm_match: bad argument");
+    XH_HIP(hipSetDevice(pm->ctx->device));
     XH_CHECK((h_nbr_off == nullptr) == (h_nbr_ids == nullptr), XH_ERR_ARG, "xh_pm_match: neighbour arrays go together");
     XH_CHECK(n_orient >= 1 && n_orient <= XH_MAX_ORIENT, XH_ERR_UNSUPPORTED, "xh_pm_match: number of orientations %d outside [1,%d]",
              n_orient, XH_MAX_ORIENT);
@@ -2288,6 +2290,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
 {
     XH_CHECK(pm && d_particles && d_refno && d_psi && d_flip && d_sx && d_sy && d_cc && n >= 0, XH_ERR_ARG,
              "xh_pm_translate: bad argument");
+    XH_HIP(hipSetDevice(pm->ctx->device));
     if (n == 0) return XH_OK;
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
@@ -2372,6 +2375,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
 int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision, double *h_coefs, double *h_sigma)
 {
     XH_CHECK(pm && d_particles && h_coefs && h_sigma && n > 0, XH_ERR_ARG, "bad argument");
+    XH_HIP(hipSetDevice(pm->ctx->device));
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
     std::vector<double> stat(2 * (size_t)n);
@@ -2397,6 +2401,7 @@ int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t 
 int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs, double *h_sigma)
 {
     XH_CHECK(pm && h_coefs && h_sigma && ref >= 0 && ref < pm->nrefs, XH_ERR_ARG, "bad argument");
+    XH_HIP(hipSetDevice(pm->ctx->device));
     xh_ctx *ctx = pm->ctx;
     XH_HIP(hipMemcpyAsync(h_coefs, (const xh_cd *)pm->d_refs64.p + (size_t)ref * pm->L.ncoef, sizeof(xh_cd) * pm->L.ncoef,
                           hipMemcpyDeviceToHost, ctx->stream));
@@ -2408,6 +2413,7 @@ int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs, double *h_sigma)
 int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32_t precision, double *h_corr2N)
 {
     XH_CHECK(pm && d_particle && h_corr2N && ref >= 0 && ref < pm->nrefs, XH_ERR_ARG, "bad argument");
+    XH_HIP(hipSetDevice(pm->ctx->device));
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
     const int N = L.N;

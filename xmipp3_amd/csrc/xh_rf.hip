@@ -1614,6 +1614,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
 int xh_rf_destroy(xh_rf *rf)
 {
     if (!rf) return XH_OK;
+    (void)hipSetDevice(rf->ctx->device);
     (void)hipStreamSynchronize(rf->ctx->stream);
     xh_buf_free(rf->d_blob); xh_buf_free(rf->d_twP32); xh_buf_free(rf->d_twP64);
     xh_plan_free(rf->planP32); xh_plan_free(rf->planP64);
@@ -1700,6 +1701,7 @@ static int ensure_temp(xh_rf *rf)
 int xh_rf_temp_ptr(xh_rf *rf, float **d_temp)
 {
     XH_CHECK(rf && d_temp, XH_ERR_ARG, "null argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     XH_TRY(ensure_temp(rf));
     *d_temp = rf->d_temp;
     return XH_OK;
@@ -1708,6 +1710,7 @@ int xh_rf_temp_ptr(xh_rf *rf, float **d_temp)
 int xh_rf_reset(xh_rf *rf)
 {
     XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     XH_TRY(ensure_temp(rf));
     XH_HIP(hipMemsetAsync(rf->d_temp, 0, sizeof(float) * xh_rf_temp_floats(rf), rf->ctx->stream));
     rf->cropped = false;
@@ -1717,6 +1720,7 @@ int xh_rf_reset(xh_rf *rf)
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft)
 {
     XH_CHECK(rf && d_imgs && d_fft && n >= 0, XH_ERR_ARG, "xh_rf_prepare_images: bad argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
     const int D = rf->D, P = rf->P, sizeX = rf->sizeX;
@@ -1762,6 +1766,7 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
 int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
 {
     XH_CHECK(rf && d_imgs && h_shiftXY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images: bad argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     XH_CHECK(d_imgs != d_out, XH_ERR_ARG, "xh_rf_shift_images: in-place operation is not supported");
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
@@ -1803,6 +1808,7 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
 int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod)
 {
     XH_CHECK(rf && h_ctf && d_ctf && d_mod && n >= 0, XH_ERR_ARG, "xh_rf_ctf_arrays: bad argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
     std::vector<XhCtfDev> hc(n);
@@ -1843,6 +1849,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     XH_CHECK(rf && d_fft && h_ainv && n >= 0, XH_ERR_ARG, "xh_rf_insert: bad argument");
     XH_CHECK((d_ctf == nullptr) == (d_mod == nullptr), XH_ERR_ARG, "xh_rf_insert: ctf and modulator go together");
     XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert: temp spaces already mirrored/cropped; call xh_rf_reset");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     XH_TRY(ensure_temp(rf));
     xh_ctx *ctx = rf->ctx;
@@ -1977,6 +1984,7 @@ int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float 
 int xh_rf_mirror_and_crop(xh_rf *rf)
 {
     XH_CHECK(rf, XH_ERR_ARG, "null handle");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_mirror_and_crop: already cropped");
     XH_TRY(ensure_temp(rf));
     xh_ctx *ctx = rf->ctx;
@@ -1992,9 +2000,106 @@ int xh_rf_mirror_and_crop(xh_rf *rf)
     return XH_OK;
 }
 
+// ---- the cropped spaces as data: half-set bookkeeping (RF:991-1053) and the sum of per-device partial
+// reconstructions on one node (what mpi_reconstruct_fourier_accel.cpp:245-266 does with MPI_Reduce)
+__global__ void __launch_bounds__(256) k_rf_add(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+__global__ void __launch_bounds__(256) k_rf_add_tail(float *__restrict__ dst, const float *__restrict__ src, size_t first, size_t n)
+{
+    const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+static int rf_add_into(xh_rf *rf, const float *d_src)
+{
+    xh_ctx *ctx = rf->ctx;
+    const size_t n = xh_rf_cropped_floats(rf), n4 = n / 4;
+    hipLaunchKernelGGL(k_rf_add, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->num_cus * 16)), dim3(256), 0, ctx->stream,
+                       (float4 *)rf->d_temp, (const float4 *)d_src, n4);
+    XH_LAUNCH_CHECK();
+    if (n4 * 4 < n) {
+        hipLaunchKernelGGL(k_rf_add_tail, dim3(1), dim3(256), 0, ctx->stream, rf->d_temp, d_src, n4 * 4, n);
+        XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+}
+
+int xh_rf_cropped_export(xh_rf *rf, float *d_dst)
+{
+    XH_CHECK(rf && d_dst, XH_ERR_ARG, "null argument");
+    XH_CHECK(rf->cropped, XH_ERR_STATE, "xh_rf_cropped_export: call xh_rf_mirror_and_crop first");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    XH_HIP(hipMemcpyAsync(d_dst, rf->d_temp, sizeof(float) * xh_rf_cropped_floats(rf), hipMemcpyDeviceToDevice, rf->ctx->stream));
+    return XH_OK;
+}
+
+int xh_rf_cropped_import(xh_rf *rf, const float *d_src, int32_t add)
+{
+    XH_CHECK(rf && d_src, XH_ERR_ARG, "null argument");
+    XH_CHECK(!add || rf->cropped, XH_ERR_STATE, "xh_rf_cropped_import(add): nothing cropped to add to");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    XH_TRY(ensure_temp(rf));
+    if (add) return rf_add_into(rf, d_src);
+    XH_HIP(hipMemcpyAsync(rf->d_temp, d_src, sizeof(float) * xh_rf_cropped_floats(rf), hipMemcpyDeviceToDevice, rf->ctx->stream));
+    rf->cropped = true;
+    return XH_OK;
+}
+
+int xh_rf_reduce(xh_rf *const *rfs, int32_t n)
+{
+    XH_CHECK(rfs && n >= 1, XH_ERR_ARG, "xh_rf_reduce: no handles");
+    for (int i = 0; i < n; ++i) {
+        XH_CHECK(rfs[i], XH_ERR_ARG, "xh_rf_reduce: null handle");
+        XH_CHECK(rfs[i]->cropped, XH_ERR_STATE, "xh_rf_reduce: call xh_rf_mirror_and_crop on every handle first");
+        XH_CHECK(rfs[i]->mv == rfs[0]->mv, XH_ERR_ARG, "xh_rf_reduce: handles of different geometry");
+        for (int j = 0; j < i; ++j) XH_CHECK(rfs[j] != rfs[i], XH_ERR_ARG, "xh_rf_reduce: the same handle twice");
+    }
+    const size_t bytes = sizeof(float) * xh_rf_cropped_floats(rfs[0]);
+    // binary tree over the handles; the pairs of one level run concurrently on their own streams
+    // (different devices: one xGMI link per pair), the staging copy lands in the receiver's d_fin scratch
+    for (int stride = 1; stride < n; stride <<= 1) {
+        for (int i = 0; i + stride < n; i += 2 * stride) {
+            xh_rf *src = rfs[i + stride];
+            XH_HIP(hipSetDevice(src->ctx->device));
+            XH_HIP(hipStreamSynchronize(src->ctx->stream));
+        }
+        for (int i = 0; i + stride < n; i += 2 * stride) {
+            xh_rf *dst = rfs[i], *src = rfs[i + stride];
+            XH_HIP(hipSetDevice(dst->ctx->device));
+            const float *from = src->d_temp;
+            if (src->ctx->device != dst->ctx->device) {
+                XH_TRY(xh_buf_reserve(dst->ctx, dst->d_fin, bytes));
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dst->ctx->device, src->ctx->device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(src->ctx->device, 0);   // already enabled is fine
+                (void)hipGetLastError();
+                XH_HIP(hipMemcpyPeerAsync(dst->d_fin.p, dst->ctx->device, src->d_temp, src->ctx->device, bytes, dst->ctx->stream));
+                from = (const float *)dst->d_fin.p;
+            }
+            XH_TRY(rf_add_into(dst, from));
+        }
+        for (int i = 0; i + stride < n; i += 2 * stride) {
+            xh_rf *dst = rfs[i];
+            XH_HIP(hipSetDevice(dst->ctx->device));
+            XH_HIP(hipStreamSynchronize(dst->ctx->stream));
+        }
+    }
+    XH_HIP(hipSetDevice(rfs[0]->ctx->device));
+    return XH_OK;
+}
+
 int xh_rf_finish(xh_rf *rf, double *h_volume)
 {
     XH_CHECK(rf && h_volume, XH_ERR_ARG, "null argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
     XH_CHECK(rf->cropped, XH_ERR_STATE, "xh_rf_finish: call xh_rf_mirror_and_crop first (RFA:149-152)");
     xh_ctx *ctx = rf->ctx;
     const int mv = rf->mv, P = rf->P, D = rf->D, xh = P / 2 + 1;

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p ../bin
 CXX=${CXX:-g++}
-FLAGS="-O2 -std=c++17 -Wall -Wno-unused-function"
+FLAGS="-O2 -std=c++17 -pthread -Wall -Wno-unused-function"
 LINK="-L.. -lxmipp_hip -Wl,-rpath,\$ORIGIN/.. -Wl,-rpath,/opt/rocm/lib"
 $CXX $FLAGS angular_projection_matching_main.cpp -o ../bin/xmipp_angular_projection_matching $LINK &
 $CXX $FLAGS reconstruct_fourier_accel_main.cpp -o ../bin/xmipp_reconstruct_fourier_accel $LINK &

@@ -6,16 +6,57 @@
 // Same class names, same virtual seams (defineParams / readParams / show / run, and for APM
 // produceSideInfo / processAllImages / processSomeImages / writeOutputFiles), same parameter
 // strings, same output labels.  All numerics happen behind include/xmipp_hip.h; there is no
-// CPU path here.  Extra flags: --device <id>, --batch <n>.
+// CPU path here.  Extra flags: --device <id>, --gpus <n>, --devices <list>, --batch <n>.
 #ifndef XMIPP3_AMD_PROGRAMS_H
 #define XMIPP3_AMD_PROGRAMS_H
 #include "minicore.h"
 #include "../../include/xmipp_hip.h"
 #include "sampling_gen.h"
+#include <exception>
+#include <thread>
 
 namespace mc {
 
 inline void xhCheck(int rc) { if (rc != XH_OK) REPORT_ERROR(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error()); }
+
+// --device <id> / --gpus <n> / --devices <list>: the HIP devices one program drives, one host thread each
+// (cf. the --device/--gpus flags of reconstruct_fourier_gpu, RFG:56-57). --devices may repeat an id.
+inline std::vector<int> parseDevices(int device, int gpus, const std::string &list)
+{
+    std::vector<int> d;
+    if (!list.empty()) {
+        std::string tok;
+        std::istringstream is(list);
+        while (std::getline(is, tok, ',')) {
+            tok = trim(tok);
+            if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos)
+                REPORT_ERROR(ERR_ARG_INCORRECT, "--devices expects a comma-separated list of device ids, got '" + list + "'");
+            d.push_back(atoi(tok.c_str()));
+        }
+    } else {
+        if (gpus < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "--gpus must be at least 1");
+        for (int g = 0; g < gpus; ++g) d.push_back(device + g);
+    }
+    if (d.empty()) REPORT_ERROR(ERR_ARG_INCORRECT, "no device selected");
+    int count = 0;
+    if (xh_device_count(&count) == XH_OK)
+        for (int id : d)
+            if (id < 0 || id >= count)
+                REPORT_ERROR(ERR_ARG_INCORRECT, "device " + std::to_string(id) + " requested but this node has " + std::to_string(count));
+    return d;
+}
+
+// f(g) for g < n, one host thread per device slot; the first exception is re-thrown on the caller's thread
+template <class F> inline void runOnSlots(size_t n, F f)
+{
+    if (n == 1) { f((size_t)0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(n);
+    for (size_t g = 0; g < n; ++g)
+        th.emplace_back([&, g] { try { f(g); } catch (...) { err[g] = std::current_exception(); } });
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < n; ++g) if (err[g]) std::rethrow_exception(err[g]);
+}
 
 struct DeviceBuffer {
     xh_ctx *ctx = nullptr; void *p = nullptr; size_t bytes = 0;
@@ -107,7 +148,8 @@ public:
     double pad = 1, max_shift = -1, avail_memory = 1;
     int Ri = 1, Ro = -1, search5d_shift = 0, search5d_step = 2, numOrientations = 1, threads = 1;
     bool phase_flipped = false, do_scale = false, do_append = false;
-    int device = 0, batch = 1024;
+    int device = 0, gpus = 1, batch = 1024;
+    std::string deviceList;
     // side info
     MetaDataVec DFexp, DFo;
     Sampling mysampling;
@@ -115,16 +157,23 @@ public:
     std::vector<int32_t> search5d_xoff, search5d_yoff;
     size_t dim = 0, total_nr_refs = 0;
     bool loop_forward_refs = true;
-    xh_ctx *ctx = nullptr;
-    xh_pm *pm = nullptr;
-    xh_rf *shifter = nullptr;   // only used for xh_rf_shift_images (previous shifts, APM:1228-1233)
+    // one slot per device, each with the whole reference bank (particles are independent)
+    struct Slot {
+        int device = 0;
+        xh_ctx *ctx = nullptr;
+        xh_pm *pm = nullptr;
+        xh_rf *shifter = nullptr;   // only used for xh_rf_shift_images (previous shifts, APM:1228-1233)
+    };
+    std::vector<Slot> slots;
     int N = 0;
 
     ~ProgAngularProjectionMatching() override
     {
-        if (pm) xh_pm_destroy(pm);
-        if (shifter) xh_rf_destroy(shifter);
-        if (ctx) xh_ctx_destroy(ctx);
+        for (Slot &s : slots) {
+            if (s.pm) xh_pm_destroy(s.pm);
+            if (s.shifter) xh_rf_destroy(s.shifter);
+            if (s.ctx) xh_ctx_destroy(s.ctx);
+        }
     }
 
     void defineParams() override
@@ -158,7 +207,9 @@ public:
         addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads");
         addParamsLine("  [--number_orientations <numOrientations=1>]  : Number of possible orientations for each experimental image");
         addParamsLine("  [--append]                : Append (versus overwrite) data to the output file");
-        addParamsLine("  [--device <id=0>]         : HIP device");
+        addParamsLine("  [--device <id=0>]         : first HIP device");
+        addParamsLine("  [--gpus <n=1>]            : number of consecutive HIP devices, one host thread each");
+        addParamsLine("  [--devices <list=\"\">]    : explicit comma-separated device ids (overrides --device/--gpus)");
         addParamsLine("  [--batch <n=1024>]        : Particles per device batch");
     }
 
@@ -182,6 +233,8 @@ public:
         do_scale = checkParam("--scale");
         do_append = checkParam("--append");
         device = (int)getIntParam("--device");
+        gpus = (int)getIntParam("--gpus");
+        deviceList = getParam("--devices");
         batch = std::max(1, (int)getIntParam("--batch"));
     }
 
@@ -193,7 +246,9 @@ public:
                   << "  Output rootname         : " << fn_out << "\n"
                   << "  Inner radius rot-search : " << Ri << "\n  Outer radius rot-search : " << Ro << "\n"
                   << "  Max. shift              : " << max_shift << "\n"
-                  << "  Device                  : " << device << " (" << xh_version() << ")\n";
+                  << "  Devices                 : ";
+        for (size_t g = 0; g < slots.size(); ++g) std::cout << (g ? "," : "") << slots[g].device;
+        std::cout << " (" << xh_version() << ")\n";
     }
 
     virtual void produceSideInfo()
@@ -238,16 +293,12 @@ public:
             convert_refno_to_stack_position[mysampling.no_redundant_sampling_points_index[i]] = (int)i;
         loop_forward_refs = true;
         // reference library on the device, in stack order (getCurrentReference, APM:408-528)
-        xhCheck(xh_ctx_create_private(device, &ctx));
         std::vector<float> refs(total_nr_refs * dim * dim), one;
         ImageInfo ii;
         for (size_t r = 0; r < total_nr_refs; ++r) {
             readImage(std::to_string(r + 1) + "@" + fn_ref, one, ii);
             std::copy(one.begin(), one.end(), refs.begin() + r * dim * dim);
         }
-        DeviceBuffer d_refs;
-        d_refs.reserve(ctx, refs.size() * sizeof(float));
-        xhCheck(xh_memcpy_h2d(ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
         // CTF filter of the gallery (APM:366-402): a 2-D image of amplitudes or a CTF parameter file
         std::vector<double> Mctf;
         const int paddim = (int)std::floor(pad * dim + 0.5);
@@ -285,9 +336,20 @@ public:
                 }
             }
         }
-        xhCheck(xh_pm_create(ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), Mctf.empty() ? nullptr : Mctf.data(), paddim, &pm));
+        for (int d : parseDevices(device, gpus, deviceList)) {
+            slots.emplace_back();
+            slots.back().device = d;
+        }
+        runOnSlots(slots.size(), [&](size_t g) {
+            Slot &s = slots[g];
+            xhCheck(xh_ctx_create_private(s.device, &s.ctx));
+            DeviceBuffer d_refs;
+            d_refs.reserve(s.ctx, refs.size() * sizeof(float));
+            xhCheck(xh_memcpy_h2d(s.ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
+            xhCheck(xh_pm_create(s.ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), Mctf.empty() ? nullptr : Mctf.data(), paddim, &s.pm));
+        });
         int32_t nn;
-        xhCheck(xh_pm_info(pm, &nn, nullptr, nullptr));
+        xhCheck(xh_pm_info(slots[0].pm, &nn, nullptr, nullptr));
         N = nn;
     }
 
@@ -298,9 +360,35 @@ public:
         processSomeImages(ids);
     }
 
+    // The images go to the devices in contiguous ranges and the rows come back in the same order, so the output
+    // does not depend on the number of devices: the reference visiting order alternates per image (APM:1112),
+    // hence each range starts with the parity its first image would have had in a single sequential run.
     virtual void processSomeImages(const std::vector<size_t> &imagesToProcess)
     {
+        const size_t G = slots.size(), count = imagesToProcess.size();
+        std::vector<MetaDataVec> out(G);
+        const bool forward0 = loop_forward_refs;
+        runOnSlots(G, [&](size_t g) {
+            const size_t lo = (g * count) / G, hi = ((g + 1) * count) / G;
+            if (hi == lo) return;
+            std::vector<size_t> mine(imagesToProcess.begin() + lo, imagesToProcess.begin() + hi);
+            processShard(slots[g], mine, (lo & 1) ? !forward0 : forward0, out[g]);
+        });
+        if (count & 1) loop_forward_refs = !loop_forward_refs;
+        for (MetaDataVec &o : out) {
+            if (o.rows.empty()) continue;
+            if (DFo.labels.empty()) DFo.labels = o.labels;
+            if (DFo.labels != o.labels) REPORT_ERROR(ERR_VALUE_INCORRECT, "internal: per-device result tables differ in labels");
+            for (auto &r : o.rows) DFo.rows.push_back(std::move(r));
+        }
+    }
+
+    void processShard(Slot &slot, const std::vector<size_t> &imagesToProcess, bool loop_forward_refs, MetaDataVec &DFo)
+    {
         // APM:991-1192, batched. Row order and labels as APM:1149-1165.
+        xh_ctx *ctx = slot.ctx;
+        xh_pm *pm = slot.pm;
+        xh_rf *&shifter = slot.shifter;
         const size_t per = dim * dim;
         DeviceBuffer d_part, d_shifted, d_i32a, d_i32b, d_u8, d_f64;
         std::vector<float> h_part, one;
@@ -424,17 +512,21 @@ public:
     bool do_weights = false, useFast = false, useCTF = false, isPhaseFlipped = false;
     double padding_factor_proj = 2, padding_factor_vol = 2, maxResolution = 0.5, minCTF = 0.01, Ts = 1;
     double blob_radius = 1.9, blob_alpha = 15;
-    int blob_order = 0, bufferSize = 25, device = 0, batch = 1024;
+    int blob_order = 0, bufferSize = 25, device = 0, gpus = 1, batch = 1024;
+    std::string deviceList, fn_fsc;
     MetaDataVec SF;
     size_t imgSize = 0;
     std::vector<double> R_repository;   // nsym x 9
-    xh_ctx *ctx = nullptr;
-    xh_rf *rf = nullptr;
+    // one slot per device: its own context (stream), gridding handle and temp spaces; slot 0 finishes
+    struct Slot { int device = 0; xh_ctx *ctx = nullptr; xh_rf *rf = nullptr; };
+    std::vector<Slot> slots;
 
     ~ProgRecFourierAccel() override
     {
-        if (rf) xh_rf_destroy(rf);
-        if (ctx) xh_ctx_destroy(ctx);
+        for (Slot &s : slots) {
+            if (s.rf) xh_rf_destroy(s.rf);
+            if (s.ctx) xh_ctx_destroy(s.ctx);
+        }
     }
     void setIO(const std::string &in, const std::string &out) { fn_in = in; fn_out = out; }
 
@@ -462,8 +554,10 @@ public:
         addParamsLine("  [--bufferSize <size=25>]        : Number of projection loaded in memory (will be actually 2x as much.");
         addParamsLine("  [--thr <threads=1> <rows=1>]   : Accepted for compatibility with xmipp_reconstruct_fourier (RF:50); unused");
         addParamsLine("  [--iter <iterations=1>]        : xmipp_reconstruct_fourier weight-correction iterations (RF:44); only 1");
-        addParamsLine("  [--prepare_fsc <fscfile>]      : xmipp_reconstruct_fourier half-set files (RF:47); not available");
-        addParamsLine("  [--device <id=0>]              : HIP device");
+        addParamsLine("  [--prepare_fsc <fscfile>]      : Filename root for FSC files (RF:47): <root>_1_recons.vol, <root>_2_recons.vol");
+        addParamsLine("  [--device <id=0>]              : first HIP device");
+        addParamsLine("  [--gpus <n=1>]                 : number of consecutive HIP devices, one host thread each");
+        addParamsLine("  [--devices <list=\"\">]         : explicit comma-separated device ids (overrides --device/--gpus)");
         addParamsLine("  [--batch <n=1024>]             : Projections per device batch");
         addExampleLine("   xmipp_reconstruct_fourier_accel  -i reconstruction.sel --sym c2 --weight");
     }
@@ -488,9 +582,11 @@ public:
         Ts = getDoubleParam("--sampling");
         bufferSize = (int)getIntParam("--bufferSize");
         device = (int)getIntParam("--device");
+        gpus = (int)getIntParam("--gpus");
+        deviceList = getParam("--devices");
         batch = std::max(1, (int)getIntParam("--batch"));
+        if (checkParam("--prepare_fsc")) fn_fsc = getParam("--prepare_fsc");
         if (getIntParam("--iter") != 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--iter > 1 (weight correction, RF:1056-1101) is not available on the device path");
-        if (checkParam("--prepare_fsc")) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--prepare_fsc (RF:991-1053) is not available yet");
     }
 
     void show()
@@ -503,6 +599,7 @@ public:
                   << " Input selfile             : " << fn_in << "\n padding_factor_proj       : " << padding_factor_proj
                   << "\n padding_factor_vol        : " << padding_factor_vol << "\n Output volume             : " << fn_out << "\n";
         if (!fn_sym.empty()) std::cout << " Symmetry file for projections : " << fn_sym << "\n";
+        if (!fn_fsc.empty()) std::cout << " File root for FSC files: " << fn_fsc << "\n";
         std::cout << (do_weights ? " Use weights stored in the image headers or doc file\n" : " Do NOT use weights\n");
         std::cout << "\n Interpolation Function\n   blrad                 : " << blob_radius << "\n   blord                 : " << blob_order
                   << "\n   blalpha               : " << blob_alpha << "\n max_resolution          : " << maxResolution
@@ -532,18 +629,50 @@ public:
             SL.readSymmetryFile(fn_sym);
             for (int i = 0; i < SL.symsNo(); ++i) R_repository.insert(R_repository.end(), SL.R[i].begin(), SL.R[i].end());
         }
-        xhCheck(xh_ctx_create_private(device, &ctx));
         xh_rf_params p{};
         p.imgSize = (int)imgSize; p.padding_proj = padding_factor_proj; p.padding_vol = padding_factor_vol;
         p.max_resolution = maxResolution; p.blob_radius = blob_radius; p.blob_order = blob_order; p.blob_alpha = blob_alpha;
         p.use_fast = useFast; p.phase_flipped = isPhaseFlipped; p.min_ctf = minCTF; p.sampling = Ts;
-        xhCheck(xh_rf_create(ctx, &p, &rf));
-        xhCheck(xh_rf_reset(rf));
+        for (int d : parseDevices(device, gpus, deviceList)) {
+            slots.emplace_back();
+            Slot &s = slots.back();
+            s.device = d;
+            xhCheck(xh_ctx_create_private(d, &s.ctx));
+            xhCheck(xh_rf_create(s.ctx, &p, &s.rf));
+            xhCheck(xh_rf_reset(s.rf));
+        }
     }
 
+    // Images first..last (inclusive) go to the devices in contiguous ranges (the reference's
+    // job farm, mpi_reconstruct_fourier_accel.cpp:285-294, hands out blocks of mpi_job_size instead)
     void processImages(size_t first, size_t last)
     {
+        if (last < first || last == (size_t)-1) return;
+        const size_t count = last - first + 1, G = slots.size();
+        runOnSlots(G, [&](size_t g) {
+            const size_t lo = first + (g * count) / G, hi = first + ((g + 1) * count) / G;
+            if (hi > lo) processShard(slots[g], lo, hi - 1);
+        });
+    }
+
+    // every device's partial sums -> slot 0 (mirrorAndCropTempSpaces on each, then one tree reduction)
+    void gatherCropped()
+    {
+        std::vector<xh_rf *> h;
+        for (Slot &s : slots) {
+            xhCheck(xh_rf_mirror_and_crop(s.rf));
+            h.push_back(s.rf);
+        }
+        if (h.size() > 1) xhCheck(xh_rf_reduce(h.data(), (int)h.size()));
+    }
+
+    void resetSpaces() { for (Slot &s : slots) xhCheck(xh_rf_reset(s.rf)); }
+
+    void processShard(Slot &slot, size_t first, size_t last)
+    {
         // loadImageThread/preloadBuffer + processBuffer (RFA:300-388,939-966), batched on the device
+        xh_ctx *ctx = slot.ctx;
+        xh_rf *rf = slot.rf;
         const size_t per = imgSize * imgSize;
         int32_t P, mv, sx, sy;
         xhCheck(xh_rf_sizes(rf, &P, &mv, &sx, &sy));
@@ -610,7 +739,7 @@ public:
     void finishComputations(const std::string &out_name)
     {
         std::vector<double> vol(imgSize * imgSize * imgSize);
-        xhCheck(xh_rf_finish(rf, vol.data()));
+        xhCheck(xh_rf_finish(slots[0].rf, vol.data()));
         writeVolume(out_name, vol.data(), imgSize, imgSize, imgSize);
     }
 
@@ -619,8 +748,35 @@ public:
         // RFA:139-156
         show();
         produceSideinfo();
-        processImages(0, SF.size() - 1);
-        xhCheck(xh_rf_mirror_and_crop(rf));
+        const size_t last = SF.size() - 1;
+        if (fn_fsc.empty()) {
+            processImages(0, last);
+            gatherCropped();
+            finishComputations(fn_out);
+            return;
+        }
+        // --prepare_fsc (RF:846,991-1045): images 0..FSCIndex make <root>_1_recons.vol, the rest
+        // <root>_2_recons.vol, each from zeroed spaces; the final volume is the sum of both halves' Fourier
+        // volumes and weights. The reference parks the halves in <root>_{1,2}_{Fourier,Weights}.vol and deletes
+        // them afterwards; here they stay in device memory.
+        const size_t FSCIndex = last / 2;
+        xh_ctx *ctx0 = slots[0].ctx;
+        xh_rf *rf0 = slots[0].rf;
+        const size_t bytes = sizeof(float) * xh_rf_cropped_floats(rf0);
+        DeviceBuffer half1, half2;
+        half1.reserve(ctx0, bytes);
+        half2.reserve(ctx0, bytes);
+        processImages(0, FSCIndex);
+        gatherCropped();
+        xhCheck(xh_rf_cropped_export(rf0, half1.as<float>()));
+        finishComputations(fn_fsc + "_1_recons.vol");
+        resetSpaces();
+        if (FSCIndex + 1 <= last) processImages(FSCIndex + 1, last);
+        gatherCropped();
+        xhCheck(xh_rf_cropped_export(rf0, half2.as<float>()));
+        finishComputations(fn_fsc + "_2_recons.vol");
+        xhCheck(xh_rf_cropped_import(rf0, half1.as<float>(), 0));
+        xhCheck(xh_rf_cropped_import(rf0, half2.as<float>(), 1));
         finishComputations(fn_out);
     }
 };
