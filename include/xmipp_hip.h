@@ -253,6 +253,19 @@ int xh_fp_info(const xh_fp *fp, int32_t *padded_size, int32_t *coef_dim, int32_t
 int xh_fp_coefs(const xh_fp *fp, double *h_re, double *h_im);
 int xh_fp_project(xh_fp *fp, const double *h_angles, int32_t n, const double *d_ctf, float *d_out);
 
+/* ------------------------------------------------- Fourier shell correlation
+ * Replaces the frc_dpr(refI(), img(), sam, freq, frc, frc_noise, dpr, error_l2, do_dpr, do_rfactor,
+ * min_samp, sam/max_sam, &rFactor) call of ProgResolutionFsc::process_img
+ * (reconstruction/resolution_fsc.cpp:179-203; frc_dpr itself is xmippCore's xmipp_fftw.cpp).
+ * d_m1 (the reference map) and d_m2: [Z][Y][X] doubles on the device (Z = 1 for images), sizes <= 1024.
+ * Outputs on the host, X/2+1 doubles each (h_dpr / h_rfactor only touched when requested): digital
+ * frequency / sampling_rate, FRC, 2/sqrt(shell count), differential phase residual (degrees), mean
+ * |F1 - F2|; R-factor over minFreq <= R <= maxFreq (digital frequencies). Synchronous. */
+int xh_frc_dpr(xh_ctx *ctx, const double *d_m1, const double *d_m2, int32_t Z, int32_t Y, int32_t X,
+               double sampling_rate, int32_t do_dpr, int32_t do_rfactor, double minFreq, double maxFreq,
+               double *h_freq, double *h_frc, double *h_frc_noise, double *h_dpr, double *h_error_l2,
+               double *h_rfactor);
+
 /* ---- test hooks (used only by tests/ to localise a parity failure per stage) ---- */
 /* polar Fourier transform of one stage: precision 32 or 64; outputs on host */
 int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision,

@@ -113,6 +113,8 @@ def lib():
         "xo_fp_coef_start": (i, [vp]),
         "xo_fp_coefs": (c_double_p, [vp, i]),
         "xo_fp_project": (None, [vp, d, d, d, c_double_p, c_double_p]),
+        "xo_frc_dpr": (i, [c_double_p, c_double_p, i, i, i, d, i, i, d, d, c_double_p, c_double_p, c_double_p,
+                           c_double_p, c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -443,6 +445,22 @@ class RF:
         out = np.empty((self.D, self.D, self.D))
         lib().xo_rf_finish(self.h, _dp(out))
         return out
+
+
+def frc_dpr(m1, m2, sampling_rate=1.0, do_dpr=False, do_rfactor=False, min_freq=0.0, max_freq=0.5):
+    """frc_dpr of xmippCore as called by resolution_fsc.cpp:179-203 -> dict of shell arrays (+ rfactor)."""
+    m1, m2 = f64(m1), f64(m2)
+    assert m1.shape == m2.shape
+    shp = (1,) * (3 - m1.ndim) + m1.shape
+    L = shp[2] // 2 + 1
+    out = {k: np.zeros(L) for k in ("freq", "frc", "frc_noise", "dpr", "error_l2")}
+    rf = np.full(1, -1.0)
+    n = lib().xo_frc_dpr(_dp(m1), _dp(m2), shp[0], shp[1], shp[2], sampling_rate, int(do_dpr), int(do_rfactor),
+                         min_freq, max_freq, _dp(out["freq"]), _dp(out["frc"]), _dp(out["frc_noise"]),
+                         _dp(out["dpr"]), _dp(out["error_l2"]), _dp(rf))
+    assert n == L
+    out["rfactor"] = float(rf[0])
+    return out
 
 
 class FP:

@@ -182,6 +182,12 @@ const double *xo_fp_coefs(const xo_fp *, int imag);
 void xo_fp_project(const xo_fp *, double rot, double tilt, double psi, const double *ctf /* nullable */,
                    double *out /* D*D */);
 
+/* ---- Fourier shell correlation (xo_frc.cpp): frc_dpr of xmippCore as called by
+ * reconstruction/resolution_fsc.cpp:179-203. Arrays of X/2+1 doubles; returns that length. */
+int xo_frc_dpr(const double *m1, const double *m2, int Z, int Y, int X, double sampling_rate, int dodpr,
+               int dorfactor, double minFreq, double maxFreq, double *freq, double *frc, double *frc_noise,
+               double *dpr /* nullable */, double *error_l2, double *rFactor /* nullable */);
+
 #ifdef __cplusplus
 }
 #endif

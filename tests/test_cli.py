@@ -24,7 +24,8 @@ def _run(args, **kw):
 
 
 def test_help_and_argument_errors(bins):
-    for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier"):
+    for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier",
+                 "xmipp_angular_project_library", "xmipp_resolution_fsc"):
         r = _run([os.path.join(bins, prog), "--help"])
         assert r.returncode == 0 and "USAGE" in r.stderr
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-o", "x.xmd"])
@@ -187,6 +188,61 @@ def test_cli_prepare_fsc_writes_the_two_half_set_volumes(bins, tmp_path):
     assert np.abs(rd("fsc_2_recons.vol") - rd("h2.vol")).max() <= tol
     # the reference deletes its intermediate <root>_{1,2}_{Fourier,Weights}.vol; nothing of the kind is left here
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("fsc")) == ["fsc_1_recons.vol", "fsc_2_recons.vol"]
+
+
+@pytest.mark.gpu
+def test_cli_half_sets_then_resolution_fsc(bins, tmp_path, oracle):
+    """reconstruct_fourier --prepare_fsc -> resolution_fsc on the two half maps (the use SURVEY.md 8f rank 2 names):
+    the .frc file carries the oracle's curve for the same two volumes; flags of test_programs.py:898-900."""
+    D, n = 32, 40
+    vol = synth.phantom(D, seed=3, nblobs=10)
+    ang = synth.random_angles(n, np.random.default_rng(9))
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "p.stk"), imgs)
+    xmipp_io.write_xmd(str(tmp_path / "all.xmd"), [("noname", ["image", "angleRot", "angleTilt", "anglePsi"],
+                       [[f"{i + 1}@{tmp_path}/p.stk"] + [f"{v:.6f}" for v in ang[i]] for i in range(n)])])
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier"), "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "all.vol"),
+              "--prepare_fsc", str(tmp_path / "fsc")])
+    assert r.returncode == 0, r.stderr
+    fsc = os.path.join(bins, "xmipp_resolution_fsc")
+    r = _run([fsc, "--ref", str(tmp_path / "fsc_1_recons.vol"), "-i", str(tmp_path / "fsc_2_recons.vol"), "-s", "5.6", "--do_dpr",
+              "--oroot", str(tmp_path / "halves")])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "halves.frc"))
+    assert labels == ["resolutionFreqFourier", "resolutionFRC", "resolutionDPR", "resolutionErrorL2", "resolutionFRCRandomNoise",
+                      "resolutionFreqReal"]
+    assert len(rows) == D // 2                      # shell 0 is not written (resolution_fsc.cpp:136)
+    got = np.array(rows, float)
+    v1, v2 = xmipp_io.read_volume(str(tmp_path / "fsc_1_recons.vol")), xmipp_io.read_volume(str(tmp_path / "fsc_2_recons.vol"))
+    exp = oracle.frc_dpr(v1, v2, 5.6, do_dpr=True, max_freq=0.5)
+    for col, key, tol in ((0, "freq", 1e-6), (1, "frc", 2e-6), (2, "dpr", 1e-4), (3, "error_l2", 1e-6), (4, "frc_noise", 1e-6)):
+        assert np.abs(got[:, col] - exp[key][1:]).max() <= tol, key      # the file holds 6 decimals
+    assert np.allclose(got[:, 5], 1.0 / exp["freq"][1:], atol=1e-5)
+    # two halves of one noiseless data set agree at low resolution
+    assert got[0, 1] > 0.9 and got[:4, 1].min() > 0.5
+    # R-factor block (row format) and the cut-offs of writeFiles
+    _, rf_rows = xmipp_io.read_xmd(str(tmp_path / "halves.frc"), block="rfactor")
+    assert open(tmp_path / "halves.frc").read().rstrip().endswith("_resolutionRfactor -1.000000")
+    r = _run([fsc, "--ref", str(tmp_path / "fsc_1_recons.vol"), "-i", str(tmp_path / "fsc_2_recons.vol"), "-s", "5.6", "--do_rfactor",
+              "--max_sam", "40", "--min_sam", "100", "-o", str(tmp_path / "cut.frc")])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "cut.frc"))
+    assert "resolutionDPR" not in labels
+    cut = np.array(rows, float)
+    c = {l: i for i, l in enumerate(labels)}
+    res = cut[:, c["resolutionFreqReal"]]
+    assert np.all(cut[(res < 40) | (res > 100), c["resolutionFRC"]] == 0.0)
+    keep = (res >= 40) & (res <= 100)
+    assert keep.any() and np.abs(cut[keep, c["resolutionFRC"]] - got[keep, 1]).max() <= 1e-6
+    exp_rf = oracle.frc_dpr(v1, v2, 5.6, do_rfactor=True, min_freq=5.6 / 100, max_freq=5.6 / 40)["rfactor"]
+    tail = open(tmp_path / "cut.frc").read().split()
+    assert tail[-2] == "_resolutionRfactor" and abs(float(tail[-1]) - exp_rf) <= 1e-6
+    # different shapes are an error; --set_of_images fails loudly
+    xmipp_io.write_volume(str(tmp_path / "small.vol"), np.zeros((16, 16, 16), np.float32))
+    r = _run([fsc, "--ref", str(tmp_path / "small.vol"), "-i", str(tmp_path / "fsc_2_recons.vol")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "different shapes" in r.stderr
+    r = _run([fsc, "--set_of_images", str(tmp_path / "all.xmd")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "not available" in r.stderr
 
 
 @pytest.mark.gpu

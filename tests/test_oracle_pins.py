@@ -148,3 +148,52 @@ def test_fourier_projector_against_analytic_gaussians(oracle):
     half = fp.project(30, 40, 50, ctf=np.full((D, D // 2 + 1), 0.5))
     assert np.allclose(half, 0.5 * fp.project(30, 40, 50), rtol=0, atol=1e-12)
     assert oracle.FP(vol, 2.0, 0.25, 3).cdim == 2 * (int(0.25 * 64 + 10)) + 1
+
+
+def _frc_pin_volumes():
+    # test_resolution_frc.cpp:20-88
+    v1 = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26.4, 27.5, 28.5],
+                  float).reshape(3, 3, 3)
+    v2 = np.zeros((3, 3, 3))
+    v2[2] = np.array([1.5, 2.4, 3.3, 4.6, 5.7, 6.4, 7.3, 8.2, 9.5]).reshape(3, 3)
+    v2[1] = np.array([10.2, 11.4, 12.5, 13.6, 14.5, 15.7, 17.3, 18.2, 19.4]).reshape(3, 3)
+    v2[0] = np.array([20.3, 21.4, 22.5, 23.4, 24.5, 25.6, 26.7, 24, 23]).reshape(3, 3)
+    return v1, v2
+
+
+def test_frc_rfactor_pin(oracle):
+    """test_resolution_frc.cpp:120-130: sam=2, min_sam=-1, max_sam=2 -> minFreq=-2, maxFreq=1, Rfactor 0.134661 +- 1e-5."""
+    v1, v2 = _frc_pin_volumes()
+    sam, min_sam, max_sam = 2.0, -1.0, 2.0
+    r = oracle.frc_dpr(v1, v2, sam, do_dpr=False, do_rfactor=True, min_freq=sam / min_sam, max_freq=sam / max_sam)
+    assert abs(r["rfactor"] - 0.134661) < 0.00001
+    assert r["frc"][0] == pytest.approx(1.0, abs=1e-14)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (8, 8, 8), (6, 10, 9), (1, 12, 12)])
+def test_frc_shells_against_numpy(oracle, shape):
+    """Independent numpy statement of the same definition (rfftn / size, shells of round(R * xsize))."""
+    rng = np.random.default_rng(sum(shape))
+    a = rng.normal(size=shape)
+    b = a + 0.5 * rng.normal(size=shape)
+    Z, Y, X = shape
+    F1, F2 = np.fft.rfftn(a) / a.size, np.fft.rfftn(b) / b.size
+    fz, fy, fx = np.fft.fftfreq(Z)[:, None, None], np.fft.fftfreq(Y)[None, :, None], np.abs(np.fft.fftfreq(X))[None, None, :X // 2 + 1]
+    R = np.sqrt(fz ** 2 + fy ** 2 + fx ** 2)
+    idx = np.floor(R * X + 0.5).astype(int)      # C round(): halves away from zero
+    L = X // 2 + 1
+    keep = (R ** 2 <= 0.25) & (idx < L)
+    def shell(v):
+        return np.bincount(idx[keep], weights=v[keep], minlength=L)
+    frc = shell((np.conj(F1) * F2).real) / np.sqrt(shell(np.abs(F1) ** 2) * shell(np.abs(F2) ** 2))
+    cnt = shell(np.ones(R.shape))
+    dphi = np.degrees(np.angle(F1) - np.angle(F2))
+    dphi = (dphi + 180.0) % 360.0 - 180.0
+    w = np.abs(F1) + np.abs(F2)
+    r = oracle.frc_dpr(a.reshape(shape), b.reshape(shape), 1.5, do_dpr=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert np.allclose(r["frc"], frc, atol=1e-12, equal_nan=True)
+        assert np.allclose(r["frc_noise"], 2 / np.sqrt(cnt), equal_nan=True)
+        assert np.allclose(r["error_l2"], shell(np.abs(F1 - F2)) / cnt, atol=1e-14, equal_nan=True)
+        assert np.allclose(r["dpr"], np.sqrt(shell(w * dphi ** 2) / shell(w)), atol=1e-7, equal_nan=True)
+    assert np.allclose(r["freq"], np.arange(L) / (X * 1.5))

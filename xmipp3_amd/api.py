@@ -270,6 +270,23 @@ def reduce_reconstructions(rfs):
     check(lib().xh_rf_reduce(arr, len(rfs)))
 
 
+def frc_dpr(ctx, m1, m2, sampling_rate=1.0, do_dpr=False, do_rfactor=False, min_freq=0.0, max_freq=0.5):
+    """Fourier ring/shell correlation of two float64 device tensors of equal shape (2-D or 3-D): xh_frc_dpr,
+    the core of xmipp_resolution_fsc (resolution_fsc.cpp:179-203). m1 is the reference map."""
+    torch = _torch()
+    assert m1.shape == m2.shape and m1.dtype == m2.dtype == torch.float64 and m1.is_cuda and m2.is_cuda
+    m1, m2 = m1.contiguous(), m2.contiguous()
+    shp = (1,) * (3 - m1.dim()) + tuple(m1.shape)
+    L = shp[2] // 2 + 1
+    out = {k: np.zeros(L) for k in ("freq", "frc", "frc_noise", "dpr", "error_l2")}
+    rfac = np.full(1, -1.0)
+    check(lib().xh_frc_dpr(ctx.h, _ptr(m1), _ptr(m2), shp[0], shp[1], shp[2], sampling_rate, int(do_dpr), int(do_rfactor),
+                           min_freq, max_freq, _np_ptr(out["freq"]), _np_ptr(out["frc"]), _np_ptr(out["frc_noise"]),
+                           _np_ptr(out["dpr"]), _np_ptr(out["error_l2"]), _np_ptr(rfac)))
+    out["rfactor"] = float(rfac[0])
+    return out
+
+
 def allreduce_reconstruction(rf):
     """The one exchange step of the sharded path: SUM of [volume | weights] over ranks
     (replaces the per-row MPI_Reduce of parallel/mpi_reconstruct_fourier_accel.cpp:249-267)."""

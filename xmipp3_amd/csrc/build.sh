@@ -11,6 +11,8 @@ $HIPCC $COMMON -ffp-contract=off -c xh_rf.hip -o build/xh_rf.o & pids+=($!)
 $HIPCC $COMMON -c xh_ctx.hip -o build/xh_ctx.o & pids+=($!)
 if [ -f xh_pm.hip ]; then $HIPCC $COMMON -c xh_pm.hip -o build/xh_pm.o & pids+=($!); fi
 $HIPCC $COMMON -c xh_fp.hip -o build/xh_fp.o & pids+=($!)
+# shell membership of the FSC is decided in double arithmetic that must round like the scalar code
+$HIPCC $COMMON -ffp-contract=off -c xh_fsc.hip -o build/xh_fsc.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libxmipp_hip.so build/*.o
 echo "built $(cd .. && pwd)/libxmipp_hip.so"

@@ -9,6 +9,7 @@ LINK="-L.. -lxmipp_hip -Wl,-rpath,\$ORIGIN/.. -Wl,-rpath,/opt/rocm/lib"
 $CXX $FLAGS angular_projection_matching_main.cpp -o ../bin/xmipp_angular_projection_matching $LINK &
 $CXX $FLAGS reconstruct_fourier_accel_main.cpp -o ../bin/xmipp_reconstruct_fourier_accel $LINK &
 $CXX $FLAGS angular_project_library_main.cpp -o ../bin/xmipp_angular_project_library $LINK &
+$CXX $FLAGS resolution_fsc_main.cpp -o ../bin/xmipp_resolution_fsc $LINK &
 wait
 cp -f ../bin/xmipp_reconstruct_fourier_accel ../bin/xmipp_reconstruct_fourier
-echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library}"
+echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library,resolution_fsc}"

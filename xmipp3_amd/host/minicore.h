@@ -393,7 +393,7 @@ public:
 
 // ------------------------------------------------------------------ XmippProgram
 class XmippProgram {
-    struct ParamDef { std::string name; std::vector<std::string> aliases; std::vector<std::string> argDefaults; std::vector<bool> argHasDefault; bool optional = false; std::string help; };
+    struct ParamDef { std::string name; std::vector<std::string> aliases; std::vector<std::string> argDefaults; std::vector<bool> argHasDefault; bool optional = false; std::string help; int group = -1; };
     std::vector<ParamDef> defs;
     std::map<std::string, std::vector<std::string>> given;
     std::vector<std::string> usage, examples;
@@ -429,6 +429,16 @@ public:
             return;
         }
         if (t.rfind("where", 0) == 0 || t.rfind("requires", 0) == 0) return;
+        if (t.rfind("or ", 0) == 0 && !defs.empty()) {   // "or --other <arg>": alternative to the previous parameter
+            const size_t prev = defs.size() - 1;
+            addParamsLine(t.substr(3));
+            if (defs.size() == prev + 2) {
+                if (defs[prev].group < 0) defs[prev].group = (int)prev;
+                defs.back().group = defs[prev].group;
+                defs.back().optional = defs[prev].optional;
+            }
+            return;
+        }
         ParamDef d;
         size_t colon = std::string::npos;
         {   // the help separator is the first ':' outside <...>
@@ -464,7 +474,7 @@ public:
         for (auto &u : usage) std::cerr << "   " << u << "\n";
         std::cerr << "OPTIONS\n";
         for (auto &d : defs) {
-            std::cerr << "   " << (d.optional ? "[" : "") << d.name;
+            std::cerr << "   " << (d.group >= 0 && d.group != (int)(&d - defs.data()) ? "or " : "") << (d.optional ? "[" : "") << d.name;
             for (auto &a : d.aliases) std::cerr << ", " << a;
             for (size_t i = 0; i < d.argDefaults.size(); ++i) std::cerr << " <" << (d.argHasDefault[i] ? "=" + d.argDefaults[i] : "arg") << ">";
             std::cerr << (d.optional ? "]" : "") << " : " << d.help << "\n";
@@ -498,8 +508,13 @@ public:
                 }
                 given[d->name] = vals;
             }
-            for (auto &d : defs)
-                if (!d.optional && !given.count(d.name)) REPORT_ERROR(ERR_ARG_MISSING, "Parameter " + d.name + " is mandatory");
+            for (auto &d : defs) {
+                if (d.optional || given.count(d.name)) continue;
+                bool alt = false;
+                if (d.group >= 0)
+                    for (auto &o : defs) alt = alt || (o.group == d.group && given.count(o.name));
+                if (!alt) REPORT_ERROR(ERR_ARG_MISSING, "Parameter " + d.name + " is mandatory");
+            }
             long v = getIntParam("-v");
             verbose = (int)v;
             readParams();

@@ -971,5 +971,123 @@ public:
     }
 };
 
+// ============================================================================================
+// xmipp_resolution_fsc (reconstruction/resolution_fsc.{h,cpp}): Fourier shell correlation of a map against a
+// reference map, SURVEY.md 8f rank 2. The shell sums run on the device (xh_frc_dpr); --set_of_images
+// (getFourierStatistics, xmippCore) is not available.
+class ProgResolutionFsc : public XmippProgram {
+public:
+    std::string fn_ref, fn_img, fn_sel, fn_root, fn_out;
+    double sam = 1, max_sam = -1, min_sam = -1;
+    bool do_dpr = false, do_set_of_images = false, do_o = false, do_rfactor = false, apply_geo = true;
+    int device = 0;
+
+    void defineParams() override
+    {
+        // resolution_fsc.cpp:34-82, verbatim parameter lines
+        addUsageLine("Calculate the resolution of one or more volumes or images with respect to a single reference.");
+        addUsageLine("+ Three methods are employed:");
+        addUsageLine("+ * Differential Phase Residual (DPR), Fourier Ring Correlation (FRC), Spectral Signal-to-Noise Ratio (SSNR)");
+        addParamsLine("   -i <input_file>           : either an image or a volume");
+        addParamsLine("   requires --ref;");
+        addParamsLine("or --set_of_images <selfile> : selfile containing a set of 2D-images");
+        addParamsLine("   [--oroot <root_file=\"\">] : Root of the output metadata. If not set, input file rootname is taken.");
+        addParamsLine("   [-o <output_file=\"\">]   : Output file name.");
+        addParamsLine("   [--ref <input_file>]      : filename for reference image/volume");
+        addParamsLine("   [--sampling_rate <Ts=1>]  : Pixel size (Angstrom)");
+        addParamsLine("  alias -s;");
+        addParamsLine("   [--dont_apply_geo]        : for 2D-images: do not apply transformation stored in the header");
+        addParamsLine("   [--do_dpr]                : compute dpr, by default only frc is computed");
+        addParamsLine("   [--max_sam <max_sr=-1>]   : set fsc to 0 for frequencies above this one (Angstrom), -1 -> all fequencies");
+        addParamsLine("                             : --max_sam = 10A -> frequencies higher than 0.1 A^-1 =0");
+        addParamsLine("   [--do_rfactor]            : compute R-factor for input volumes");
+        addParamsLine("   [--min_sam <min_sr=-1>]   : minimum frequency may use for calculating R-factor (Angstrom)");
+        addParamsLine("                             : --min_sam = 10A -> frequencies smaller than 0.1 A^-1 =0");
+        addParamsLine("   [--device <id=0>]         : HIP device");
+        addExampleLine("xmipp_resolution_fsc --ref subset1.vol  -i subset2.vol --sampling_rate 5.6 ");
+    }
+
+    void readParams() override
+    {
+        // resolution_fsc.cpp:84-118
+        sam = getDoubleParam("--sampling_rate");
+        apply_geo = !checkParam("--dont_apply_geo");
+        max_sam = getDoubleParam("--max_sam");
+        do_dpr = checkParam("--do_dpr");
+        do_set_of_images = checkParam("--set_of_images");
+        min_sam = getDoubleParam("--min_sam");
+        do_rfactor = checkParam("--do_rfactor");
+        if (do_set_of_images) {
+            fn_sel = getParam("--set_of_images");
+            if (checkParam("-i") || checkParam("--ref")) REPORT_ERROR(ERR_ARG_INCORRECT, "--set_of_images should not be provided with -i or --ref");
+        } else {
+            if (!checkParam("-i")) REPORT_ERROR(ERR_ARG_MISSING, "-i is mandatory");
+            if (!checkParam("--ref")) REPORT_ERROR(ERR_ARG_MISSING, "-i requires --ref");
+            fn_ref = getParam("--ref");
+            fn_img = getParam("-i");
+        }
+        do_o = checkParam("-o");
+        if (do_o) fn_out = getParam("-o");
+        else fn_root = getParam("--oroot");
+        device = (int)getIntParam("--device");
+    }
+
+    // resolution_fsc.cpp:120-170
+    void writeFiles(const std::string &fnRoot, const std::vector<double> &freq, std::vector<double> &frc, const std::vector<double> &frc_noise,
+                    std::vector<double> &dpr, const std::vector<double> &error_l2, double rFactor)
+    {
+        MetaDataVec MD;
+        const std::string fn_frc = do_o ? fn_out : fnRoot + ".frc";
+        for (size_t i = 1; i < freq.size(); ++i) {
+            const size_t id = MD.addObject();
+            if (max_sam > 0 && (1. / freq[i]) < max_sam) { if (do_dpr) dpr[i] = 0.; frc[i] = 0.; }
+            if (min_sam > 0 && (1. / freq[i]) > min_sam) { if (do_dpr) dpr[i] = 0.; frc[i] = 0.; }
+            MD.setValue("resolutionFreqFourier", freq[i], id);
+            MD.setValue("resolutionFRC", frc[i], id);
+            if (do_dpr) MD.setValue("resolutionDPR", dpr[i], id);
+            MD.setValue("resolutionErrorL2", error_l2[i], id);
+            MD.setValue("resolutionFRCRandomNoise", frc_noise[i], id);
+            MD.setValue("resolutionFreqReal", 1. / freq[i], id);
+        }
+        MD.write(fn_frc);
+        // second block, row format (MD2.setColumnFormat(false); MD_APPEND)
+        std::ofstream f(FileName(fn_frc).path, std::ios::app);
+        char b[64];
+        snprintf(b, sizeof(b), "%.6f", rFactor);
+        f << "data_rfactor\n _resolutionRfactor " << b << "\n";
+    }
+
+    void run() override
+    {
+        if (do_set_of_images) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--set_of_images (getFourierStatistics, resolution_fsc.cpp:205-214) is not available on the device path");
+        // process_img, resolution_fsc.cpp:172-203
+        std::vector<float> r32, i32;
+        ImageInfo ri, ii;
+        readImage(fn_ref, r32, ri);
+        readImage(fn_img, i32, ii);
+        if (ri.x != ii.x || ri.y != ii.y || ri.z != ii.z) REPORT_ERROR(ERR_MULTIDIM_SIZE, "MultidimArrays have different shapes!");
+        std::vector<double> m1(r32.begin(), r32.end()), m2(i32.begin(), i32.end());
+        double min_samp = sam / min_sam;
+        if (min_sam < 0) min_samp = 0.;
+        if (max_sam < 0) max_sam = 2 * sam;
+        xh_ctx *ctx = nullptr;
+        xhCheck(xh_ctx_create_private(device, &ctx));
+        struct Guard { xh_ctx *c; ~Guard() { if (c) xh_ctx_destroy(c); } } guard{ctx};
+        const size_t L = ri.x / 2 + 1;
+        std::vector<double> freq(L), frc(L), frc_noise(L), dpr(L, 0.), error_l2(L);
+        double rFactor = -1.;
+        {
+            DeviceBuffer d1, d2;
+            d1.reserve(ctx, m1.size() * sizeof(double));
+            d2.reserve(ctx, m2.size() * sizeof(double));
+            xhCheck(xh_memcpy_h2d(ctx, d1.p, m1.data(), m1.size() * sizeof(double)));
+            xhCheck(xh_memcpy_h2d(ctx, d2.p, m2.data(), m2.size() * sizeof(double)));
+            xhCheck(xh_frc_dpr(ctx, d1.as<double>(), d2.as<double>(), (int)ri.z, (int)ri.y, (int)ri.x, sam, do_dpr, do_rfactor, min_samp,
+                               sam / max_sam, freq.data(), frc.data(), frc_noise.data(), dpr.data(), error_l2.data(), &rFactor));
+        }
+        writeFiles(fn_root.empty() ? fn_img : fn_root, freq, frc, frc_noise, dpr, error_l2, rFactor);
+    }
+};
+
 }  // namespace mc
 #endif
