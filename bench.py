@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU sample (0 = auto)")
     ap.add_argument("--mode", default="full", choices=["full", "match", "grid"])
+    ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
+                    help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
+    ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     return ap.parse_args()
 
 
@@ -58,6 +61,25 @@ def smooth_noise(torch, n, D, gen, device, sigma_px=3.0):
     mask = ((r2[:, None] + r2[None, :]) < (0.42 * D) ** 2).float()
     y = y * mask
     return (y / y.std()).contiguous()
+
+
+def phantom_volume(torch, D, gen, device, nblobs=20):
+    """BASELINE config 1/3 phantom: 20 3-D Gaussians, sigma in [2,5] voxels and centres within radius 20 of a 64^3
+    box, scaled to D; amplitudes U[0.5,1]. Data generation only."""
+    ax = torch.arange(D, device=device, dtype=torch.float32) - D // 2
+    sc = D / 64.0
+    vol = torch.zeros((D, D, D), device=device)
+    u = torch.rand((nblobs, 6), generator=gen, device=device).cpu().numpy()
+    for b in range(nblobs):
+        r = 20.0 * sc * u[b, 0] ** (1.0 / 3.0)
+        ct, ph = 2 * u[b, 1] - 1, 2 * math.pi * u[b, 2]
+        st = math.sqrt(max(0.0, 1 - ct * ct))
+        c = (r * st * math.cos(ph), r * st * math.sin(ph), r * ct)
+        sg = (2.0 + 3.0 * u[b, 3]) * sc
+        amp = 0.5 + 0.5 * u[b, 4]
+        g = [torch.exp(-(ax - ci) ** 2 / (2 * sg * sg)) for ci in c]
+        vol += amp * g[2][:, None, None] * g[1][None, :, None] * g[0][None, None, :]
+    return vol.contiguous()
 
 
 def main():
@@ -88,13 +110,24 @@ def main():
     genr.manual_seed(7)
 
     # ---- synthetic inputs, resident in HBM before the timed region
-    refs = smooth_noise(torch, nrefs, D, genr, dev)
     dirs = synth.fibonacci_directions(nrefs)
+    if args.refs == "phantom":
+        # BASELINE config 2/4: the gallery = projections of the phantom at Fibonacci-sphere directions, made with the
+        # library's own central-slice projector (xh_fp_*, the xmipp_angular_project_library path)
+        fpj = xa.FourierProjector(ctx, phantom_volume(torch, D, genr, dev), 2.0, 0.5, 3)
+        refs = fpj.project(np.concatenate([dirs, np.zeros((nrefs, 1))], 1))
+        fpj.close()
+        refs = ((refs - refs.mean()) / refs.std()).contiguous()
+    else:
+        refs = smooth_noise(torch, nrefs, D, genr, dev)
     idx = torch.randint(0, nrefs, (B,), generator=gen, device=dev)
-    # random in-plane rotation (as in real data) + white noise at SNR 0.1
+    # particle = reference, random in-plane rotation, mirror with p = 0.5, shift U{-3..3}^2, white noise at SNR 0.1
     th = torch.rand((B,), generator=gen, device=dev) * (2 * math.pi)
+    mir = (torch.rand((B,), generator=gen, device=dev) < 0.5).float() * 2 - 1          # -1: mirrored in x
+    shf = torch.randint(-3, 4, (B, 2), generator=gen, device=dev).float()
     rot = torch.zeros((B, 2, 3), device=dev)
-    rot[:, 0, 0] = torch.cos(th); rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th); rot[:, 1, 1] = torch.cos(th)
+    rot[:, 0, 0] = torch.cos(th) * mir; rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th) * mir; rot[:, 1, 1] = torch.cos(th)
+    rot[:, :, 2] = shf * (2.0 / D)
     particles = torch.empty((B, D, D), device=dev)
     for b0 in range(0, B, 512):
         sl = slice(b0, min(B, b0 + 512))
@@ -109,6 +142,9 @@ def main():
     ctf_arr = xa.RecFourier.ctf_param_array(ctfs)
 
     pm = xa.ProjectionMatcher(ctx, refs) if args.mode != "grid" else None
+    if pm is not None and args.no_prune:
+        pm.set_option("prune", 0)
+    rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     t_grid = ctx.timer()
     grid_ms = []
@@ -118,6 +154,9 @@ def main():
         imgs = particles
         if pm is not None:
             refno, psi, flip = pm.match(particles)
+            if record:
+                st = pm.last_stats()
+                rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
             sx, sy, cc = pm.translate(particles, refno, psi, flip)
             h_ref = refno.cpu().numpy()
             h_psi = psi.cpu().numpy()
@@ -195,7 +234,7 @@ def main():
     cand = {}
     if pm is not None and stage.get("idft_max", 0) > 0:
         # packed complex inverse DFT of length N per (particle, reference): 5 N log2 N flops
-        fl = rows * 5.0 * N * math.log2(N)
+        fl = (rows - rows_seen[1]) * 5.0 * N * math.log2(N)   # rows actually transformed
         cand["k_pm_idft_max"] = ("mfma", fl / (stage["idft_max"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["idft_max"])
         fl2 = rows * 8.0 * ncoef                            # 4 real FMAs per ring coefficient
         cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"])
@@ -231,13 +270,16 @@ def main():
         "vs_baseline": None, "dtype": "f32 (coarse search, gridding) + f64 (exact re-score, shifts, finaliser)",
         "data": "synthetic",
         "config": {"workload": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references",
-                   "mode": args.mode, "box": D, "nrefs": nrefs, "particles_per_step_per_gpu": B,
+                   "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
         "stage_ms": stage, "finish_and_allreduce_s": finish_s,
     }
     if pm is not None:
         out["rescored_fraction"] = pm.last_stats()["rescored_particles"] / float(B)
+        # exact branch and bound of the row transforms: rows whose coefficient moduli cannot reach the
+        # particle's best value are not transformed; the fraction depends on the data
+        out["s3_rows_pruned_fraction"] = rows_seen[1] / float(max(1, rows_seen[0]))
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, host cores of rank 0
     if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N=1 only

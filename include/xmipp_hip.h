@@ -230,6 +230,11 @@ int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rescored_particles
 /* accumulated device time (HIP events) per stage of xh_pm_match since the last reset:
  * h_ms[8] = { prep32, contract, idft_max, select, rescore_fp64, 0, 0, 0 } milliseconds */
 int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset);
+/* rows of the last xh_pm_match[_ex] call that the S3 branch and bound skipped: a correlation row whose
+ * coefficient moduli sum to less than (best value found for the particle - 2 tau) is never transformed.
+ * Same results with set_option("prune", 0); no reference counterpart (the reference transforms every row,
+ * polar.cpp:136-146). */
+int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 

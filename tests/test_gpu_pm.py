@@ -166,6 +166,44 @@ def test_config2_shape_d128_many_references(gpu, oracle):
     assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
+@pytest.mark.parametrize("kind", ["phantom", "noise", "flat", "pure_noise_particles"])
+def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kind):
+    """S3 skips rows whose coefficient moduli cannot reach the particle's best value minus two ambiguity margins
+    (k_pm_prune_plan). Same indices with the pruning on and off, both equal to the oracle; how much is pruned depends
+    on the data: references that look alike (phantom) or not at all (noise), particles without any signal."""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 64, 96, 24
+    rng = np.random.default_rng(5)
+    if kind == "noise":
+        refs = rng.standard_normal((nrefs, D, D))
+        f = np.fft.fftfreq(D)
+        lp = np.exp(-((f[:, None] ** 2 + f[None, :] ** 2) * (0.12 * D) ** 2))
+        refs = np.fft.ifft2(np.fft.fft2(refs) * lp).real
+        refs = (refs / refs.std()).astype(np.float32)
+    else:
+        refs, _ = synth.make_refs(synth.phantom(D, seed=2, nblobs=14), nrefs)
+        if kind == "flat":
+            refs = (refs + 10.0).astype(np.float32)        # a large constant: every row is dominated by its DC term
+    if kind == "pure_noise_particles":
+        parts = rng.standard_normal((n, D, D)).astype(np.float32)
+    else:
+        parts, _ = synth.make_particles(refs, n, rng, snr=0.1, max_shift=2)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    dp = torch.from_numpy(parts).cuda()
+    on = [t.cpu().numpy() for t in pm.match(dp)]
+    st = pm.last_stats()
+    assert st["rows"] == n * nrefs and 0 <= st["pruned_rows"] < st["rows"]
+    pm.set_option("prune", 0)
+    off = [t.cpu().numpy() for t in pm.match(dp)]
+    assert pm.last_stats()["pruned_rows"] == 0
+    er, ep, ef, _ = oracle.PM(refs).match(parts)
+    for a, b, e in zip(on, off, (er[:, 0], ep[:, 0], ef[:, 0])):
+        assert np.array_equal(a, b) and np.array_equal(a, e)
+    if kind == "noise":
+        assert st["pruned_rows"] > 0.5 * st["rows"]        # unrelated references: almost nothing can reach the true match
+    print(kind, "pruned", st["pruned_rows"], "of", st["rows"], "rescored rows", st["rescored_rows"])
+
+
 @pytest.mark.parametrize("D", [512, 24])
 def test_match_extreme_box_sizes(gpu, oracle, D):
     """512 px: N=1602, Bluestein M=4096 (radix-2 LDS S3 kernel), 255 rings, nk=802; 24 px: M=256 (radix-2 too)."""

@@ -418,7 +418,9 @@ class ProjectionMatcher:
     def last_stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         check(lib().xh_pm_last_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"rows": a.value, "rescored_particles": b.value, "rescored_rows": c.value}
+        d = C.c_int64()
+        check(lib().xh_pm_rows_pruned(self.h, C.byref(d)))
+        return {"rows": a.value, "rescored_particles": b.value, "rescored_rows": c.value, "pruned_rows": d.value}
 
     # ---- test hooks
     def debug_prepare(self, particles, precision=32):

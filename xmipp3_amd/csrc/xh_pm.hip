@@ -118,6 +118,9 @@ struct xh_pm {
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
+    int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
+    XhBuf d_bpart, d_rowBound, d_topRows, d_thr;
+    int64_t stat_pruned;
     XhBuf d_firTmp, d_polarPart;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
@@ -494,7 +497,7 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
 __global__ void __launch_bounds__(256)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
                    const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
-                   int nq, int nqtiles, int nptiles, int dbg)
+                   int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int qtile = blockIdx.x * 4 + wv, ptile0 = blockIdx.y * XH_PW2;
@@ -508,6 +511,18 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
     const int qj = j >> 1, odd = j & 1;
     const int q = qtile * 16 + qj;
     const int lastQuad = qoff[nk] - 1;
+    // branch-and-bound of S3 (k_pm_prune_plan): sum over this slice's frequencies of the moduli of the straight
+    // and mirror coefficients of each (particle, reference) row this lane writes
+    float bndS[XH_PW2][4][2], bndM[XH_PW2][4][2];
+#pragma unroll
+    for (int t = 0; t < XH_PW2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { bndS[t][g][0] = bndS[t][g][1] = 0.f; bndM[t][g][0] = bndM[t][g][1] = 0.f; }
+    auto modulus = [&](const float4 &o, int k, float &bs, float &bm) {
+        const float fsr = o.x - o.w, fsi = o.y + o.z, fmr = o.x + o.w, fmi = o.y - o.z;
+        if (k == 0 || k == nk - 1) { bs += fabsf(fsr); bm += fabsf(fmr); }     // c2r drops their imaginary parts
+        else { bs += 2.f * sqrtf(fsr * fsr + fsi * fsi); bm += 2.f * sqrtf(fmr * fmr + fmi * fmi); }
+    };
     for (int k0 = kBeg; k0 < kEnd; k0 += 4) {
         xh_f32x16 acc[XH_PW2][4];
 #pragma unroll
@@ -578,8 +593,27 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                     }
                     if (kA < kEnd) dst[kA] = o0;
                     if (kA + 1 < kEnd) dst[kA + 1] = o1;
+                    if (bpart) {
+                        if (kA < kEnd) modulus(o0, kA, bndS[t][g][h2], bndM[t][g][h2]);
+                        if (kA + 1 < kEnd) modulus(o1, kA + 1, bndS[t][g][h2], bndM[t][g][h2]);
+                    }
                 }
             }
+    }
+    if (bpart) {
+        const size_t nrowsTotal = (size_t)nparticles * nq;
+#pragma unroll
+        for (int t = 0; t < XH_PW2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const float bs = bndS[t][g][h2] + __shfl_xor(bndS[t][g][h2], 1, 64);
+                    const float bm = bndM[t][g][h2] + __shfl_xor(bndM[t][g][h2], 1, 64);
+                    const int p = (ptile0 + t) * 16 + 4 * g + 2 * hi + h2;
+                    if (!odd && ptile0 + t < nptiles && p < nparticles && q < nq)
+                        bpart[(size_t)blockIdx.z * nrowsTotal + (size_t)p * nq + q] = make_float2(bs, bm);
+                }
     }
 }
 
@@ -762,7 +796,9 @@ template <int R, bool INV> __device__ __forceinline__ void d_twiddle(xh_cf *v, c
 template <int R1, int R2, int R3>
 __global__ void __launch_bounds__(256, 2)
 k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ Wfull,
-               const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vperm, int N, int nk, int nrows)
+               const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vperm, int N, int nk, int nrows,
+               const int *__restrict__ rowList, const float *__restrict__ rowBound, const float *__restrict__ thr,
+               int rowsPerParticle, int *__restrict__ prunedCounter)
 {
     constexpr int M = R1 * R2 * R3;
     constexpr int S3 = R3 + 1;              // padded innermost stride (bank conflicts)
@@ -780,7 +816,15 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
     xh_cf *s = sbuf + (size_t)wv * LDSW;
     float4 *sraw = reinterpret_cast<float4 *>(s);     // the row is staged here before pass 1 overwrites it
     const int half = N / 2;
-    for (int row = blockIdx.x * 4 + wv; row < nrows; row += gridDim.x * 4) {
+    int skipped = 0;
+    for (int it = blockIdx.x * 4 + wv; it < nrows; it += gridDim.x * 4) {
+        const int row = rowList ? rowList[it] : it;
+        // branch and bound: the row cannot reach (best of its particle - 2 tau), see k_pm_prune_plan
+        if (rowBound && rowBound[row] < thr[row / rowsPerParticle]) {
+            if (lane == 0) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
+            ++skipped;
+            continue;
+        }
         const float4 *rr = raw + (size_t)row * nk;
         // ---- stage the row (one coalesced burst), then pull every pass-1 input into registers
         for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
@@ -923,6 +967,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
         if (lane == 0) { RowRes r; r.best = b1; r.idx = bi; r.second = sec; r.pad = 0; res[row] = r; }
         __builtin_amdgcn_wave_barrier();
     }
+    if (prunedCounter && lane == 0 && skipped) atomicAdd(prunedCounter, skipped);
 }
 
 // =========================================================================== S4
@@ -934,6 +979,81 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
 struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; };
 __device__ __forceinline__ int d_row_slot(const RowMap &M, int row) { return M.rowSlot ? M.rowSlot[row] : row / M.nq; }
 __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { return M.refIds ? M.refIds[row] : row - slot * M.nq; }
+
+// ---- S3 branch and bound ---------------------------------------------------------------------------
+// A correlation row is a trigonometric polynomial, so no sample of it exceeds the sum of the moduli of its
+// coefficients: B = |F_0| + |F_N/2| + 2 sum |F_k| (taken for the straight and the mirrored particle, the larger
+// of the two bounds the packed row). S2 leaves B per row (XH_KSPLIT partial sums); here every row gets its
+// normalised bound and the XH_PRUNE_T rows of each particle with the largest bounds are listed. Those are
+// transformed first; their best value is a lower bound of the particle's maximum, and the main S3 launch skips
+// every row whose bound lies more than 2 tau below it (tau: the ambiguity margin of S4, so a skipped row can
+// be neither the winner nor a candidate for the fp64 re-score). The result is identical with or without
+// pruning; what is saved depends on the data (rows whose bound stays above the best are still transformed).
+#define XH_PRUNE_T 4
+__global__ void __launch_bounds__(256)
+k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
+                const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows)
+{
+    __shared__ float sv[256];
+    __shared__ int sr[256];
+    __shared__ int chosen[XH_PRUNE_T];
+    const int p = blockIdx.x;
+    const int r0 = M.poff[p * M.nt], r1 = M.poff[(p + 1) * M.nt];
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        float bs = 0.f, bm = 0.f;
+        for (int sl = 0; sl < nslices; ++sl) { const float2 v = bpart[(size_t)sl * nrowsTotal + r]; bs += v.x; bm += v.y; }
+        const int slot = d_row_slot(M, r);
+        const int ref = d_row_ref(M, r, slot);
+        const float den = (float)refSigma[ref] * (float)stat32[2 * slot + 1];
+        // 1e-4: rounding of the fp32 sums, of sqrtf and of the fp32 transform itself (all ~1e-6 relative)
+        rowBound[r] = fmaxf(bs, bm) * 1.0001f / den;
+    }
+    __syncthreads();
+    for (int t = 0; t < XH_PRUNE_T; ++t) {
+        float b = -3.0e38f;
+        int br = -1;
+        for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            bool taken = false;
+            for (int u = 0; u < t; ++u) taken = taken || chosen[u] == r;
+            const float v = rowBound[r];
+            if (!taken && v > b) { b = v; br = r; }
+        }
+        sv[threadIdx.x] = b; sr[threadIdx.x] = br;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o && sv[threadIdx.x + o] > sv[threadIdx.x]) { sv[threadIdx.x] = sv[threadIdx.x + o]; sr[threadIdx.x] = sr[threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            // fewer than XH_PRUNE_T rows (or NaN bounds): repeat the first pick, the list stays valid
+            const int pick = sr[0] >= 0 ? sr[0] : (t > 0 ? chosen[0] : r0);
+            chosen[t] = pick;
+            topRows[p * XH_PRUNE_T + t] = pick;
+        }
+        __syncthreads();
+    }
+}
+
+// thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned
+__global__ void k_pm_prune_thr(const RowRes *__restrict__ res, const int *__restrict__ topRows, RowMap M,
+                               const double *__restrict__ refSigma, const double *__restrict__ stat32, int m, float tau2,
+                               float *__restrict__ thr)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    float lb = -3.0e38f;
+    bool ok = true;
+    for (int t = 0; t < XH_PRUNE_T; ++t) {
+        const int r = topRows[p * XH_PRUNE_T + t];
+        const int slot = d_row_slot(M, r);
+        const int ref = d_row_ref(M, r, slot);
+        const float v = res[r].best / ((float)refSigma[ref] * (float)stat32[2 * slot + 1]);
+        ok = ok && (v == v);
+        lb = fmaxf(lb, v);
+    }
+    thr[p] = ok ? lb - tau2 : -3.0e38f;
+}
+
 
 // one block per particle: winner over its rows, ambiguity test, candidate rows for fp64.
 __global__ void __launch_bounds__(256)
@@ -1705,7 +1825,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_topRows, &pm->d_thr, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -1760,6 +1880,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tau_rel = 3e-6;   // measured fp32 error of a normalised row: 1.6e-7*S (D=256), 1.8e-7*S (D=64)
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
+    pm->use_prune = 1;
+    pm->stat_pruned = 0;
     pm->use_fir = 1;
     pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
@@ -2008,6 +2130,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
+    else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
     else if (!strcmp(name, "use_fir")) pm->use_fir = (int)value;
     else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
@@ -2021,6 +2144,13 @@ int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset)
     return XH_OK;
 }
 
+int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned)
+{
+    XH_CHECK(pm && rows_pruned, XH_ERR_ARG, "null argument");
+    *rows_pruned = pm->stat_pruned;
+    return XH_OK;
+}
+
 int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 {
     XH_CHECK(pm, XH_ERR_ARG, "null handle");
@@ -2031,7 +2161,10 @@ int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 }
 
 // S2+S3 for a prepared chunk. h_poff: chunk-local row offsets [m+1]; d_ids device ref ids per row or null (dense)
-static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq, hipEvent_t evMid = nullptr)
+// prune: row map of the chunk for the S3 branch and bound (null: every row is transformed); nparticles and tau2
+// (= 2 tau, normalised units) go with it; d_pruned counts the skipped rows
+static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq, hipEvent_t evMid = nullptr,
+                    const RowMap *prune = nullptr, int nparticles = 0, float tau2 = 0.f, int *d_pruned = nullptr)
 {
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
@@ -2067,6 +2200,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
         XH_HIP(hipStreamSynchronize(ctx->stream));
     }
     const int nt = ((L.nk + 63) / 64) * 64;
+    const bool pruning = mfma && prune && pm->use_prune && pm->R1 && pm->use_idft3 && nparticles > 0 && nrows % nparticles == 0;
+    if (pruning) XH_TRY(xh_buf_reserve(ctx, pm->d_bpart, sizeof(float2) * (size_t)XH_KSPLIT * nrows));
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
@@ -2076,7 +2211,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                            (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, (ptiles + XH_PW2 - 1) / XH_PW2, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
-                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, (const int *)pm->d_kbounds.p, L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg);
+                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, (const int *)pm->d_kbounds.p, L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg,
+                           pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr);
     } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,
@@ -2091,14 +2227,47 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     const int lpb = std::max(1, std::min(4, (60 * 1024) / (int)(pm->M * sizeof(xh_cf))));
     const size_t smem = (size_t)lpb * pm->M * sizeof(xh_cf);
     if (pm->R1 && pm->use_idft3) {
-        const int grid = std::max(1, std::min((nrows + 3) / 4, ctx->num_cus * 8));
 #define XH_IDFT3(A_, B_, C_)                                                                                  \
     hipLaunchKernelGGL((k_pm_idft_max3<A_, B_, C_>), dim3(grid), dim3(256), 0, ctx->stream, (const float4 *)pm->d_raw.p, \
                        (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_Wfull.p, (const xh_cf *)pm->d_chirp.p,       \
-                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nrows)
-        if (pm->logM == 9) XH_IDFT3(8, 8, 8);
-        else if (pm->logM == 10) XH_IDFT3(16, 8, 8);
-        else XH_IDFT3(16, 16, 8);
+                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nr, rowList, rowBound, thr, rowsPer, prunedCnt)
+#define XH_IDFT3_ANY()                                  \
+    do {                                                \
+        if (pm->logM == 9) XH_IDFT3(8, 8, 8);           \
+        else if (pm->logM == 10) XH_IDFT3(16, 8, 8);    \
+        else XH_IDFT3(16, 16, 8);                       \
+    } while (0)
+        int nr = nrows, rowsPer = 1;
+        const int *rowList = nullptr;
+        const float *rowBound = nullptr, *thr = nullptr;
+        int *prunedCnt = nullptr;
+        int grid;
+        if (pruning) {
+            // bounds + the most promising rows of every particle, those rows first, then everything that can still win
+            XH_TRY(xh_buf_reserve(ctx, pm->d_rowBound, sizeof(float) * (size_t)nrows));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_topRows, sizeof(int) * (size_t)nparticles * XH_PRUNE_T));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_thr, sizeof(float) * (size_t)nparticles));
+            hipLaunchKernelGGL(k_pm_prune_plan, dim3(nparticles), dim3(256), 0, ctx->stream, (const float2 *)pm->d_bpart.p, XH_KSPLIT,
+                               (size_t)nrows, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
+                               (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p);
+            XH_LAUNCH_CHECK();
+            nr = nparticles * XH_PRUNE_T;
+            rowList = (const int *)pm->d_topRows.p;
+            grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
+            XH_IDFT3_ANY();
+            XH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_pm_prune_thr, dim3((nparticles + 255) / 256), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p,
+                               (const int *)pm->d_topRows.p, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
+                               nparticles, tau2, (float *)pm->d_thr.p);
+            XH_LAUNCH_CHECK();
+            nr = nrows; rowList = nullptr;
+            rowBound = (const float *)pm->d_rowBound.p; thr = (const float *)pm->d_thr.p;
+            rowsPer = nrows / nparticles;
+            prunedCnt = d_pruned;
+        }
+        grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
+        XH_IDFT3_ANY();
+#undef XH_IDFT3_ANY
 #undef XH_IDFT3
         XH_LAUNCH_CHECK();
         return XH_OK;
@@ -2146,6 +2315,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         d_offs = (const double *)pm->d_offs5d.p;
     }
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    pm->stat_pruned = 0;
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
     size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (L.nk * sizeof(float4)));
@@ -2229,15 +2399,15 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
                                pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0., nt, d_offs));
         XH_HIP(hipEventRecord(pm->ev[1], ctx->stream));
         // S2 + S3
-        XH_TRY(run_rows(pm, ms, poff, d_ids, dense, pm->nrefs, pm->ev[2]));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
+        XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
+        XH_TRY(run_rows(pm, ms, poff, d_ids, dense, pm->nrefs, pm->ev[2], &M, m, 2.f * tauAbs, (int *)pm->d_counters.p + 2));
         XH_HIP(hipEventRecord(pm->ev[3], ctx->stream));
         // S4
-        XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
         XH_TRY(xh_buf_reserve(ctx, pm->d_ambList, sizeof(int) * m));
         XH_TRY(xh_buf_reserve(ctx, pm->d_ambSlot, sizeof(int) * m));
         XH_TRY(xh_buf_reserve(ctx, pm->d_candRow, sizeof(int) * std::max<size_t>(1, rows)));
         XH_TRY(xh_buf_reserve(ctx, pm->d_candRes, sizeof(CandRes) * std::max<size_t>(1, rows)));
-        XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
         hipLaunchKernelGGL(k_pm_select, dim3(m), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p, M,
                            (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p, p0, d_refno, d_psi, d_flip,
                            L.N, tauAbs, (int *)pm->d_counters.p, (int *)pm->d_ambList.p, (int *)pm->d_ambSlot.p,
@@ -2255,6 +2425,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         }
         pm->stat_resc_p += counters[0];
         pm->stat_resc_r += counters[1];
+        pm->stat_pruned += counters[2];
         if (counters[0] > 0) {
             const int na = counters[0], nc = counters[1];
             XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, (const int *)pm->d_ambList.p, na, nullptr,
