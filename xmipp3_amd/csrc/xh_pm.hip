@@ -1439,43 +1439,53 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    {
+        // The reference grows a (2n+1)^2 window around the maximum until some element of it leaves the map or drops
+        // below max/1.414, re-scanning the whole window for every n (FIL:1659-1689). The windows are nested, so the n
+        // it stops at is the smallest Chebyshev distance from the maximum to a failing element: one parallel pass
+        // instead of a serial O(n^3) walk (smooth maps reach n of several tens).
         const int start = -cen, fin = start + D - 1;
         const int imax = si[0] / D + start, jmax = si[0] % D + start;
         const double mx = sv[0];
+        const double thr = mx / 1.414;
 #define MC(li, lj) (a * RC((li) - start, (lj) - start) + b)
-        bool neighbourhood = true;
-        int n_max = -1;
-        while (neighbourhood) {
-            n_max++;
-            for (int i = -n_max; i <= n_max && neighbourhood; i++) {
-                const int ia = i + imax;
-                if (ia < start || ia > fin) { neighbourhood = false; break; }
-                for (int j = -n_max; j <= n_max && neighbourhood; j++) {
-                    const int ja = j + jmax;
-                    if (ja < start || ja > fin) { neighbourhood = false; break; }
-                    else if (mx / 1.414 > MC(ia, ja)) { neighbourhood = false; break; }
-                }
-            }
+        int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
+        for (int t = threadIdx.x; t < n; t += blockDim.x) {
+            const int i = t / D, j = t - i * D;
+            if (thr > a * RC(i, j) + b) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
         }
+        __syncthreads();
+        si[threadIdx.x] = nf;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) si[threadIdx.x] = min(si[threadIdx.x], si[threadIdx.x + o]);
+            __syncthreads();
+        }
+        int n_max = si[0];
+        __syncthreads();
         if (imax - n_max < start) n_max = min(imax - start, n_max);
         if (imax + n_max > fin) n_max = min(fin - imax, n_max);
         if (jmax - n_max < start) n_max = min(jmax - start, n_max);
         if (jmax + n_max > fin) n_max = min(fin - jmax, n_max);
+        // centre of mass of the window (FIL:1700-1716)
         double xmax = 0, ymax = 0, sumcorr = 0;
-        for (int i = -n_max; i <= n_max; i++)
-            for (int j = -n_max; j <= n_max; j++) {
-                const int ia = i + imax, ja = j + jmax;
-                const double val = MC(ia, ja);
-                ymax += ia * val;
-                xmax += ja * val;
-                sumcorr += val;
-            }
-        double ox = 0, oy = 0;
-        if (sumcorr != 0) { ox = xmax / sumcorr; oy = ymax / sumcorr; }
-        if (!(maxShift > 0)) ox = oy = 0.;
-        if (ox * ox + oy * oy > maxShift * maxShift) ox = oy = 0.;
-        sh[0] = ox; sh[1] = oy;
+        const int wd = 2 * n_max + 1;
+        for (int t = threadIdx.x; t < wd * wd; t += blockDim.x) {
+            const int i = t / wd - n_max, j = t % wd - n_max;
+            const int ia = i + imax, ja = j + jmax;
+            const double val = MC(ia, ja);
+            ymax += ia * val;
+            xmax += ja * val;
+            sumcorr += val;
+        }
+        const double YM = d_block_sum(ymax, red), XM = d_block_sum(xmax, red), SC = d_block_sum(sumcorr, red);
+        if (threadIdx.x == 0) {
+            double ox = 0, oy = 0;
+            if (SC != 0) { ox = XM / SC; oy = YM / SC; }
+            if (!(maxShift > 0)) ox = oy = 0.;
+            if (ox * ox + oy * oy > maxShift * maxShift) ox = oy = 0.;
+            sh[0] = ox; sh[1] = oy;
+        }
 #undef MC
     }
     __syncthreads();
