@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--mode", default="full", choices=["full", "match", "grid"])
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
+    ap.add_argument("--k0", type=int, default=-1, help="two-level contraction cut (0 auto, >= nk off); default: automatic")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     return ap.parse_args()
 
@@ -144,6 +145,8 @@ def main():
     pm = xa.ProjectionMatcher(ctx, refs) if args.mode != "grid" else None
     if pm is not None and args.no_prune:
         pm.set_option("prune", 0)
+    if pm is not None and args.k0 >= 0:
+        pm.set_option("k0", args.k0)
     rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     t_grid = ctx.timer()
@@ -280,6 +283,7 @@ def main():
         # exact branch and bound of the row transforms: rows whose coefficient moduli cannot reach the
         # particle's best value are not transformed; the fraction depends on the data
         out["s3_rows_pruned_fraction"] = rows_seen[1] / float(max(1, rows_seen[0]))
+        out["s2_two_level_cut"] = dict(zip(("K0", "nk"), pm.two_level_cut()))
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, host cores of rank 0
     if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N=1 only

@@ -235,6 +235,12 @@ int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset);
  * Same results with set_option("prune", 0); no reference counterpart (the reference transforms every row,
  * polar.cpp:136-146). */
 int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned);
+/* Two-level contraction: the angular frequency K0 at which the MFMA contraction of the dense search stops
+ * (the reference bank holds < 1e-5 of its summed coefficient norms above it); rows that survive the branch and
+ * bound get their frequencies K0..nk-1 from the wave that transforms them, all others are covered by a
+ * Cauchy-Schwarz term in their bound. K0 == nk: the bank is not band limited, everything is contracted.
+ * set_option("k0", v) overrides (0 = automatic). Identical results for every K0. */
+int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 

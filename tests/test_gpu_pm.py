@@ -193,15 +193,27 @@ def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kin
     on = [t.cpu().numpy() for t in pm.match(dp)]
     st = pm.last_stats()
     assert st["rows"] == n * nrefs and 0 <= st["pruned_rows"] < st["rows"]
+    K0, nk = pm.two_level_cut()
+    assert 8 <= K0 <= nk
+    # the two-level contraction at other cuts (and switched off): same indices
+    others = []
+    for k0 in (8, 20, nk):
+        pm.set_option("k0", k0)
+        others.append([t.cpu().numpy() for t in pm.match(dp)])
+    pm.set_option("k0", 0)
+    assert pm.two_level_cut()[0] == K0
     pm.set_option("prune", 0)
     off = [t.cpu().numpy() for t in pm.match(dp)]
     assert pm.last_stats()["pruned_rows"] == 0
+    for o_ in others:
+        for a, b in zip(o_, off):
+            assert np.array_equal(a, b)
     er, ep, ef, _ = oracle.PM(refs).match(parts)
     for a, b, e in zip(on, off, (er[:, 0], ep[:, 0], ef[:, 0])):
         assert np.array_equal(a, b) and np.array_equal(a, e)
     if kind == "noise":
         assert st["pruned_rows"] > 0.5 * st["rows"]        # unrelated references: almost nothing can reach the true match
-    print(kind, "pruned", st["pruned_rows"], "of", st["rows"], "rescored rows", st["rescored_rows"])
+    print(kind, "pruned", st["pruned_rows"], "of", st["rows"], "rescored rows", st["rescored_rows"], "K0", K0, "of", nk)
 
 
 @pytest.mark.parametrize("D", [512, 24])

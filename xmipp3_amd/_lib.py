@@ -86,6 +86,7 @@ SIGNATURES = {
     "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "xh_pm_stage_ms": (C.c_int, [vp, vp, i32]),
     "xh_pm_rows_pruned": (C.c_int, [vp, vp]),
+    "xh_pm_two_level_cut": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "xh_pm_set_option": (C.c_int, [vp, C.c_char_p, d]),
     "xh_pm_debug_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
     "xh_pm_debug_ref": (C.c_int, [vp, i32, vp, vp]),

@@ -415,6 +415,12 @@ class ProjectionMatcher:
         check(lib().xh_pm_stage_ms(self.h, _np_ptr(ms), int(reset)))
         return dict(zip(("prep32", "contract", "idft_max", "select", "rescore_fp64"), ms[:5].tolist()))
 
+    def two_level_cut(self):
+        """(K0, nk): the contraction of the dense search stops at angular frequency K0 (xh_pm_two_level_cut)."""
+        a, b = C.c_int32(), C.c_int32()
+        check(lib().xh_pm_two_level_cut(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         check(lib().xh_pm_last_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))

@@ -119,8 +119,11 @@ struct xh_pm {
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
-    XhBuf d_bpart, d_rowBound, d_topRows, d_thr;
+    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr;
     int64_t stat_pruned;
+    // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
+    int K0, K0auto, quadsLow;
+    XhBuf d_bT, d_aT, d_kboundsLow;
     XhBuf d_firTmp, d_polarPart;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
@@ -461,7 +464,8 @@ typedef float xh_f32x16 __attribute__((ext_vector_type(16)));
 // gather A32/refsB [item][ncoef] complex -> packed tiles. One thread per packed float4.
 __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restrict__ dst, const int *__restrict__ qoff,
                                 const int *__restrict__ rstart, const int *__restrict__ coff, const int *__restrict__ nsam,
-                                int nrings, int ncoef, int nk, int totalQuads, int nitems, const int *__restrict__ ids)
+                                int nrings, int ncoef, int nk, int totalQuads, int nitems, const int *__restrict__ ids,
+                                int quadLimit)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = gid & 63;
@@ -469,6 +473,7 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
     const int quad = rest % totalQuads;
     const int tile = rest / totalQuads;
     if ((size_t)tile * 16 >= (size_t)((nitems + 15) / 16) * 16) return;
+    if (quad >= quadLimit) return;        // frequencies the two-level contraction leaves to S3
     // frequency k of this quad: last k with qoff[k] <= quad
     int lo = 0, hi = nk - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (qoff[mid] <= quad) lo = mid; else hi = mid - 1; }
@@ -793,12 +798,68 @@ template <int R, bool INV> __device__ __forceinline__ void d_twiddle(xh_cf *v, c
     for (int k = 1; k < R; ++k) v[k] = d_mulw<INV>(v[k], w[k].x, w[k].y);
 }
 
+// ---- two-level S2 -----------------------------------------------------------------------------------
+// References are band limited, so above some angular frequency K0 their ring coefficients are tiny. The MFMA
+// contraction then stops at K0; for the bound of the S3 branch and bound the missing part of a row is covered by
+// Cauchy-Schwarz per frequency, |F_k| = |sum_r P_rk (w_r R_rk)| <= sqrt(sum_r |P_rk|^2) sqrt(sum_r |w_r R_rk|^2)
+// (the same for the mirrored particle), i.e. a dot product of two short vectors per row; only the rows that
+// survive the pruning get their coefficients k >= K0, computed by the wave that transforms them (d_row_high).
+// X [items][ncoef] -> out[item * strideItem + k * strideK] = sqrt(sum_r |X_rk|^2), kmin <= k < nk
+__global__ void k_pm_tail_norms(const xh_cf *__restrict__ X, float *__restrict__ out, const int *__restrict__ coff,
+                                const int *__restrict__ rstart, int nrings, int ncoef, int nk, int kmin, int nitems,
+                                size_t strideItem, size_t strideK)
+{
+    const int k = kmin + blockIdx.x * blockDim.x + threadIdx.x;
+    const int item = blockIdx.y;
+    if (k >= nk || item >= nitems) return;
+    const xh_cf *x = X + (size_t)item * ncoef + k;
+    float acc = 0.f;
+    for (int r = rstart[k]; r < nrings; ++r) { const xh_cf v = x[coff[r]]; acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); }
+    out[(size_t)item * strideItem + (size_t)k * strideK] = sqrtf(acc) * 1.000001f;
+}
+
+struct XhHigh {          // what S3 needs to finish a row the contraction left at K0 (K0 >= nk: nothing to do)
+    const xh_cf *A, *B;  // particle slots [slot][ncoef], weighted references [ref][ncoef]
+    const int *coff, *rstart;
+    int nrings, ncoef, K0, nq;
+    int zeroHigh;        // 1: leave them zero (lower bounds from the low part alone, see k_pm_prune_thr)
+};
+// the four real sums (ac, ad, bc, bd) of frequency k for (slot, ref), ring order ascending like k_pm_contract
+__device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref, int k)
+{
+    const xh_cf *a = H.A + (size_t)slot * H.ncoef + k, *b = H.B + (size_t)ref * H.ncoef + k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = H.rstart[k];
+    // eight rings per step: sixteen independent loads in flight (the loop is latency bound otherwise)
+    for (; r + 8 <= H.nrings; r += 8) {
+        xh_cf x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int o = H.coff[r + u]; x[u] = a[o]; y[u] = b[o]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x = fmaf(x[u].x, y[u].x, acc.x);
+            acc.y = fmaf(x[u].x, y[u].y, acc.y);
+            acc.z = fmaf(x[u].y, y[u].x, acc.z);
+            acc.w = fmaf(x[u].y, y[u].y, acc.w);
+        }
+    }
+    for (; r < H.nrings; ++r) {
+        const int o = H.coff[r];
+        const xh_cf x = a[o], y = b[o];
+        acc.x = fmaf(x.x, y.x, acc.x);
+        acc.y = fmaf(x.x, y.y, acc.y);
+        acc.z = fmaf(x.y, y.x, acc.z);
+        acc.w = fmaf(x.y, y.y, acc.w);
+    }
+    return acc;
+}
+
 template <int R1, int R2, int R3>
 __global__ void __launch_bounds__(256, 2)
 k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ Wfull,
                const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vperm, int N, int nk, int nrows,
                const int *__restrict__ rowList, const float *__restrict__ rowBound, const float *__restrict__ thr,
-               int rowsPerParticle, int *__restrict__ prunedCounter)
+               int rowsPerParticle, int *__restrict__ prunedCounter, XhHigh H)
 {
     constexpr int M = R1 * R2 * R3;
     constexpr int S3 = R3 + 1;              // padded innermost stride (bank conflicts)
@@ -827,7 +888,13 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
         }
         const float4 *rr = raw + (size_t)row * nk;
         // ---- stage the row (one coalesced burst), then pull every pass-1 input into registers
-        for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
+        if (H.K0 >= nk) {
+            for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
+        } else {
+            const int slot = row / H.nq, ref = row - slot * H.nq;
+            for (int k = lane; k < nk; k += 64)
+                sraw[k] = k < H.K0 ? rr[k] : (H.zeroHigh ? make_float4(0.f, 0.f, 0.f, 0.f) : d_row_high(H, slot, ref, k));
+        }
         __builtin_amdgcn_wave_barrier();
         xh_cf uin[NB1][NZ1];
 #pragma unroll
@@ -992,21 +1059,51 @@ __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { r
 #define XH_PRUNE_T 4
 __global__ void __launch_bounds__(256)
 k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
-                const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows)
+                const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows,
+                const float *__restrict__ aT, const float *__restrict__ bT, int K0, int nk, int nrefs, float *__restrict__ rowTail)
 {
     __shared__ float sv[256];
     __shared__ int sr[256];
     __shared__ int chosen[XH_PRUNE_T];
     const int p = blockIdx.x;
     const int r0 = M.poff[p * M.nt], r1 = M.poff[(p + 1) * M.nt];
-    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        float bs = 0.f, bm = 0.f;
-        for (int sl = 0; sl < nslices; ++sl) { const float2 v = bpart[(size_t)sl * nrowsTotal + r]; bs += v.x; bm += v.y; }
-        const int slot = d_row_slot(M, r);
-        const int ref = d_row_ref(M, r, slot);
-        const float den = (float)refSigma[ref] * (float)stat32[2 * slot + 1];
-        // 1e-4: rounding of the fp32 sums, of sqrtf and of the fp32 transform itself (all ~1e-6 relative)
-        rowBound[r] = fmaxf(bs, bm) * 1.0001f / den;
+    // frequencies the contraction did not compute: Cauchy-Schwarz per frequency (see k_pm_tail_norms); slot by slot,
+    // the slot's norms staged in LDS, four rows per thread so that one LDS read feeds four independent FMA chains
+    __shared__ float sA[1024];
+    const int nhigh = nk - K0;
+    for (int it = 0; it < M.nt; ++it) {
+        const int slot = p * M.nt + it;
+        const int s0 = M.poff[slot], s1 = M.poff[slot + 1];
+        __syncthreads();
+        for (int k = threadIdx.x; k < nhigh; k += blockDim.x) sA[k] = aT[(size_t)slot * nk + K0 + k];
+        __syncthreads();
+        for (int base = s0; base < s1; base += 4 * (int)blockDim.x) {
+            int rr[4], ref[4];
+            float tail[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rr[j] = base + j * (int)blockDim.x + (int)threadIdx.x;
+                ref[j] = rr[j] < s1 ? d_row_ref(M, rr[j], slot) : 0;
+                tail[j] = 0.f;
+            }
+            for (int k = 0; k < nhigh; ++k) {
+                const float av = sA[k];
+                const float *bk = bT + (size_t)(K0 + k) * nrefs;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tail[j] = fmaf(av, bk[ref[j]], tail[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = rr[j];
+                if (r >= s1) continue;
+                float bs = 0.f, bm = 0.f;
+                for (int sl = 0; sl < nslices; ++sl) { const float2 v = bpart[(size_t)sl * nrowsTotal + r]; bs += v.x; bm += v.y; }
+                const float den = (float)refSigma[ref[j]] * (float)stat32[2 * slot + 1];
+                // 1e-4: rounding of the fp32 sums, of sqrtf and of the fp32 transform itself (all ~1e-6 relative)
+                rowBound[r] = (fmaxf(bs, bm) + 2.f * tail[j]) * 1.0001f / den;
+                rowTail[r] = 2.f * tail[j] * 1.0001f / den;
+            }
+        }
     }
     __syncthreads();
     for (int t = 0; t < XH_PRUNE_T; ++t) {
@@ -1034,10 +1131,12 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
     }
 }
 
-// thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned
+// thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned.
+// With the two-level contraction the listed rows were transformed without their frequencies >= K0: every sample of
+// the full row is within rowTail of what was found, so (found - rowTail) is still a lower bound of the row maximum.
 __global__ void k_pm_prune_thr(const RowRes *__restrict__ res, const int *__restrict__ topRows, RowMap M,
                                const double *__restrict__ refSigma, const double *__restrict__ stat32, int m, float tau2,
-                               float *__restrict__ thr)
+                               float *__restrict__ thr, const float *__restrict__ rowTail)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
@@ -1047,7 +1146,7 @@ __global__ void k_pm_prune_thr(const RowRes *__restrict__ res, const int *__rest
         const int r = topRows[p * XH_PRUNE_T + t];
         const int slot = d_row_slot(M, r);
         const int ref = d_row_ref(M, r, slot);
-        const float v = res[r].best / ((float)refSigma[ref] * (float)stat32[2 * slot + 1]);
+        const float v = res[r].best / ((float)refSigma[ref] * (float)stat32[2 * slot + 1]) - rowTail[r];
         ok = ok && (v == v);
         lb = fmaxf(lb, v);
     }
@@ -1835,7 +1934,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_topRows, &pm->d_thr, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -1856,6 +1955,29 @@ static void launch_idft_dump(xh_pm *pm, float *d_out, size_t smem)
 }
 
 extern "C" {
+
+// frequency slices of equal MFMA work over [0, K0), boundaries on multiples of 4 (the store blocking)
+static int set_k0(xh_pm *pm, int K0)
+{
+    const Layout &L = pm->L;
+    K0 = std::max(4, std::min(L.nk, (K0 + 3) / 4 * 4));
+    std::vector<int> qoff(L.nk + 1);
+    XH_HIP(hipMemcpy(qoff.data(), pm->d_qoff.p, sizeof(int) * (L.nk + 1), hipMemcpyDeviceToHost));
+    const int quads = qoff[K0];
+    std::vector<int> kb(XH_KSPLIT + 1, K0);
+    kb[0] = 0;
+    for (int sidx = 1; sidx < XH_KSPLIT; ++sidx) {
+        const int target = (int)((long long)quads * sidx / XH_KSPLIT);
+        int k = 0;
+        while (k < K0 && qoff[k] < target) ++k;
+        kb[sidx] = std::min(K0, (k + 3) / 4 * 4);
+    }
+    XH_TRY(xh_buf_reserve(pm->ctx, pm->d_kboundsLow, sizeof(int) * kb.size()));
+    XH_HIP(hipMemcpy(pm->d_kboundsLow.p, kb.data(), sizeof(int) * kb.size(), hipMemcpyHostToDevice));
+    pm->K0 = K0;
+    pm->quadsLow = quads;
+    return XH_OK;
+}
 
 int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, const float *d_refs,
                  const double *h_Mctf, int32_t paddim, xh_pm **out)
@@ -2102,8 +2224,42 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             if (rc == XH_OK) {
                 hipLaunchKernelGGL(k_pm_pack_tiles, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)pm->d_refsB.p,
                                    (float4 *)pm->d_Bpack.p, (const int *)pm->d_qoff.p, (const int *)pm->d_rstart.p, (const int *)pm->d_coff.p,
-                                   (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, nrefs, (const int *)nullptr);
+                                   (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, nrefs, (const int *)nullptr, pm->totalQuads);
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_pm_create: operand packing failed"); rc = XH_ERR_HIP; }
+            }
+            // two-level S2: per-frequency norms of the weighted reference coefficients and the cut K0
+            pm->K0 = pm->K0auto = L.nk;
+            pm->quadsLow = pm->totalQuads;
+            if (rc == XH_OK) rc = xh_buf_alloc(ctx, pm->d_bT, sizeof(float) * (size_t)L.nk * nrefs);
+            if (rc == XH_OK) {
+                hipLaunchKernelGGL(k_pm_tail_norms, dim3((L.nk + 63) / 64, nrefs), dim3(64), 0, ctx->stream, (const xh_cf *)pm->d_refsB.p,
+                                   (float *)pm->d_bT.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p, L.nrings, L.ncoef, L.nk, 0,
+                                   nrefs, (size_t)1, (size_t)nrefs);
+                std::vector<float> bT((size_t)L.nk * nrefs);
+                if (hipGetLastError() != hipSuccess || hipMemcpy(bT.data(), pm->d_bT.p, pm->d_bT.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+                    xh_set_error("xh_pm_create: reference norms failed");
+                    rc = XH_ERR_HIP;
+                } else {
+                    // smallest cut whose tail holds less than 1e-5 of the summed norms; not worth it above 0.6 nk
+                    std::vector<double> mean(L.nk, 0.);
+                    double all = 0;
+                    for (int k = 0; k < L.nk; ++k) {
+                        for (int r = 0; r < nrefs; ++r) mean[k] += bT[(size_t)k * nrefs + r];
+                        all += mean[k];
+                    }
+                    double tailSum = 0;
+                    int K0 = L.nk;
+                    for (int k = L.nk - 1; k >= 0; --k) {
+                        tailSum += mean[k];
+                        if (!(tailSum <= 1e-5 * all)) break;
+                        K0 = k;
+                    }
+                    K0 = std::min(L.nk, (K0 + 3) / 4 * 4);
+                    if (K0 < 8) K0 = 8;
+                    if (K0 > (int)(0.6 * L.nk)) K0 = L.nk;
+                    pm->K0auto = K0;
+                    rc = set_k0(pm, K0);
+                }
             }
         }
     }
@@ -2141,6 +2297,11 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
+    else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
+        XH_HIP(hipSetDevice(pm->ctx->device));
+        XH_HIP(hipStreamSynchronize(pm->ctx->stream));
+        XH_TRY(set_k0(pm, value <= 0 ? pm->K0auto : (int)value));
+    }
     else if (!strcmp(name, "use_fir")) pm->use_fir = (int)value;
     else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
@@ -2151,6 +2312,14 @@ int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset)
 {
     XH_CHECK(pm && h_ms, XH_ERR_ARG, "null argument");
     for (int i = 0; i < 8; ++i) { h_ms[i] = pm->stage_ms[i]; if (reset) pm->stage_ms[i] = 0; }
+    return XH_OK;
+}
+
+int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk)
+{
+    XH_CHECK(pm, XH_ERR_ARG, "null handle");
+    if (K0) *K0 = pm->K0;
+    if (nk) *nk = pm->L.nk;
     return XH_OK;
 }
 
@@ -2212,16 +2381,22 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     const int nt = ((L.nk + 63) / 64) * 64;
     const bool pruning = mfma && prune && pm->use_prune && pm->R1 && pm->use_idft3 && nparticles > 0 && nrows % nparticles == 0;
     if (pruning) XH_TRY(xh_buf_reserve(ctx, pm->d_bpart, sizeof(float2) * (size_t)XH_KSPLIT * nrows));
+    const int K0 = pruning ? pm->K0 : L.nk;          // two-level S2 needs the bounds
+    XhHigh H;
+    H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
+    H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
         XH_TRY(xh_buf_reserve(ctx, pm->d_Apack, nvec * sizeof(float4)));
         hipLaunchKernelGGL(k_pm_pack_tiles, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)pm->d_A32.p,
                            (float4 *)pm->d_Apack.p, (const int *)pm->d_qoff.p, (const int *)pm->d_rstart.p, (const int *)pm->d_coff.p,
-                           (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr);
+                           (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr,
+                           K0 < L.nk ? pm->quadsLow : pm->totalQuads);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, (ptiles + XH_PW2 - 1) / XH_PW2, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
-                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p, (const int *)pm->d_kbounds.p, L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg,
+                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,
+                           (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg,
                            pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr);
     } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
@@ -2240,7 +2415,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
 #define XH_IDFT3(A_, B_, C_)                                                                                  \
     hipLaunchKernelGGL((k_pm_idft_max3<A_, B_, C_>), dim3(grid), dim3(256), 0, ctx->stream, (const float4 *)pm->d_raw.p, \
                        (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_Wfull.p, (const xh_cf *)pm->d_chirp.p,       \
-                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nr, rowList, rowBound, thr, rowsPer, prunedCnt)
+                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nr, rowList, rowBound, thr, rowsPer, prunedCnt, H)
 #define XH_IDFT3_ANY()                                  \
     do {                                                \
         if (pm->logM == 9) XH_IDFT3(8, 8, 8);           \
@@ -2255,20 +2430,31 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
         if (pruning) {
             // bounds + the most promising rows of every particle, those rows first, then everything that can still win
             XH_TRY(xh_buf_reserve(ctx, pm->d_rowBound, sizeof(float) * (size_t)nrows));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_rowTail, sizeof(float) * (size_t)nrows));
             XH_TRY(xh_buf_reserve(ctx, pm->d_topRows, sizeof(int) * (size_t)nparticles * XH_PRUNE_T));
             XH_TRY(xh_buf_reserve(ctx, pm->d_thr, sizeof(float) * (size_t)nparticles));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_aT, sizeof(float) * (size_t)m * L.nk));
+            if (K0 < L.nk) {
+                hipLaunchKernelGGL(k_pm_tail_norms, dim3((L.nk - K0 + 63) / 64, m), dim3(64), 0, ctx->stream, (const xh_cf *)pm->d_A32.p,
+                                   (float *)pm->d_aT.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p, L.nrings, L.ncoef, L.nk, K0,
+                                   m, (size_t)L.nk, (size_t)1);
+                XH_LAUNCH_CHECK();
+            }
             hipLaunchKernelGGL(k_pm_prune_plan, dim3(nparticles), dim3(256), 0, ctx->stream, (const float2 *)pm->d_bpart.p, XH_KSPLIT,
                                (size_t)nrows, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
-                               (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p);
+                               (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p, (const float *)pm->d_aT.p, (const float *)pm->d_bT.p,
+                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p);
             XH_LAUNCH_CHECK();
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
             grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
+            H.zeroHigh = 1;
             XH_IDFT3_ANY();
+            H.zeroHigh = 0;
             XH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_pm_prune_thr, dim3((nparticles + 255) / 256), dim3(256), 0, ctx->stream, (const RowRes *)pm->d_rowres.p,
                                (const int *)pm->d_topRows.p, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
-                               nparticles, tau2, (float *)pm->d_thr.p);
+                               nparticles, tau2, (float *)pm->d_thr.p, (const float *)pm->d_rowTail.p);
             XH_LAUNCH_CHECK();
             nr = nrows; rowList = nullptr;
             rowBound = (const float *)pm->d_rowBound.p; thr = (const float *)pm->d_thr.p;
