@@ -6,6 +6,7 @@ bench.py's cpu_baseline leg; the product package (xmipp3_amd) never imports it.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
