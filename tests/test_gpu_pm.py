@@ -121,6 +121,31 @@ def test_match_with_neighbour_lists_and_chunking(gpu, oracle, lib64):
     assert np.array_equal(flip.cpu().numpy()[valid], ef[valid, 0])
 
 
+def test_lists_that_name_every_reference_in_order_are_the_dense_search(gpu, oracle, lib64):
+    """A global search written as neighbour lists (what the gallery's sampling file holds with --angular_distance -1)
+    takes the dense MFMA path with its branch and bound; a single list in another order does not."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    n, nrefs = len(parts), len(refs)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    dp = torch.from_numpy(parts).cuda()
+    dense = [t.cpu().numpy() for t in pm.match(dp, parity=1)]
+    dense_pruned = pm.last_stats()["pruned_rows"]
+    off = (np.arange(n + 1) * nrefs).astype(np.int32)
+    ids = np.tile(np.arange(nrefs, dtype=np.int32), n)
+    same = [t.cpu().numpy() for t in pm.match(dp, off, ids, parity=1)]
+    assert pm.last_stats()["pruned_rows"] == dense_pruned > 0
+    for a, b in zip(dense, same):
+        assert np.array_equal(a, b)
+    ids2 = ids.copy()
+    ids2[:nrefs] = ids2[:nrefs][::-1]                  # particle 0 visits the bank backwards
+    other = [t.cpu().numpy() for t in pm.match(dp, off, ids2, parity=1)]
+    assert pm.last_stats()["pruned_rows"] == 0
+    er, ep, ef, _ = oracle.PM(refs).match(parts, off, ids2, parity=1)
+    for a, e in zip(other, (er[:, 0], ep[:, 0], ef[:, 0])):
+        assert np.array_equal(a, e)
+
+
 def test_match_any_box_size(gpu, oracle):
     """D=50: nothing on the rotational path needs a power of two (ring DFTs are direct, the length-N
     inverse DFT is Bluestein anyway); the CTF-filtered gallery uses a 75x75 Bluestein FFT (pad 1.5)."""

@@ -2495,10 +2495,19 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
     const int D = L.D;
-    const bool dense = h_nbr_off == nullptr;
-    if (!dense)
+    bool dense = h_nbr_off == nullptr;
+    if (!dense) {
         for (int i = 0; i < h_nbr_off[n]; ++i)
             XH_CHECK(h_nbr_ids[i] >= 0 && h_nbr_ids[i] < pm->nrefs, XH_ERR_ARG, "xh_pm_match: reference id %d out of range", h_nbr_ids[i]);
+        // a global search written as lists (every particle: all references in bank order, what a sampling file with
+        // --angular_distance -1 holds) is the dense search: same rows in the same visiting order, on the MFMA path
+        bool identity = true;
+        for (int p = 0; p < n && identity; ++p) {
+            identity = h_nbr_off[p + 1] - h_nbr_off[p] == pm->nrefs;
+            for (int j = 0; j < pm->nrefs && identity; ++j) identity = h_nbr_ids[h_nbr_off[p] + j] == j;
+        }
+        dense = identity;
+    }
     // 5-D search translations (APM:575-589); none given = the single translation (0,0)
     const int nt = ntrans > 0 ? ntrans : 1;
     const double *d_offs = nullptr;
