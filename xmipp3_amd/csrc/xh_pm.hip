@@ -119,7 +119,7 @@ struct xh_pm {
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
-    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr;
+    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
     int64_t stat_pruned;
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
@@ -502,7 +502,7 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
 __global__ void __launch_bounds__(256)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
                    const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
-                   int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart)
+                   int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart, int rawStride)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int qtile = blockIdx.x * 4 + wv, ptile0 = blockIdx.y * XH_PW2;
@@ -586,7 +586,7 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                     theirs[1][c] = __shfl_xor(s1, 1, 64);
                 }
                 if (ptile0 + t < nptiles && p < nparticles && q < nq && (dbg != 1 || mine[0][0] == 1234.5f)) {
-                    float4 *dst = raw + ((size_t)p * nq + q) * nk;
+                    float4 *dst = raw + ((size_t)p * nq + q) * rawStride;
                     const int kA = k0 + (odd ? 2 : 0);
                     float4 o0, o1;
                     if (!odd) {
@@ -823,6 +823,7 @@ struct XhHigh {          // what S3 needs to finish a row the contraction left a
     const int *coff, *rstart;
     int nrings, ncoef, K0, nq;
     int zeroHigh;        // 1: leave them zero (lower bounds from the low part alone, see k_pm_prune_thr)
+    int rawStride;       // float4 per row of the S2 -> S3 intermediate: K0 with the two-level contraction, else nk
 };
 // the four real sums (ac, ad, bc, bd) of frequency k for (slot, ref), ring order ascending like k_pm_contract
 __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref, int k)
@@ -859,7 +860,7 @@ __global__ void __launch_bounds__(256, 2)
 k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ Wfull,
                const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vperm, int N, int nk, int nrows,
                const int *__restrict__ rowList, const float *__restrict__ rowBound, const float *__restrict__ thr,
-               int rowsPerParticle, int *__restrict__ prunedCounter, XhHigh H)
+               int rowsPerParticle, int *__restrict__ prunedCounter, XhHigh H, const int *__restrict__ nrowsDev)
 {
     constexpr int M = R1 * R2 * R3;
     constexpr int S3 = R3 + 1;              // padded innermost stride (bank conflicts)
@@ -878,6 +879,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
     float4 *sraw = reinterpret_cast<float4 *>(s);     // the row is staged here before pass 1 overwrites it
     const int half = N / 2;
     int skipped = 0;
+    if (nrowsDev) nrows = *nrowsDev;     // length of rowList decided on the device (k_pm_survivors)
     for (int it = blockIdx.x * 4 + wv; it < nrows; it += gridDim.x * 4) {
         const int row = rowList ? rowList[it] : it;
         // branch and bound: the row cannot reach (best of its particle - 2 tau), see k_pm_prune_plan
@@ -886,7 +888,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
             ++skipped;
             continue;
         }
-        const float4 *rr = raw + (size_t)row * nk;
+        const float4 *rr = raw + (size_t)row * H.rawStride;
         // ---- stage the row (one coalesced burst), then pull every pass-1 input into registers
         if (H.K0 >= nk) {
             for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
@@ -1129,6 +1131,28 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
         }
         __syncthreads();
     }
+}
+
+// The rows that can still win, compacted: the main S3 launch then hands every wave one surviving row at a time
+// (left in place, the few survivors of a round-robin row assignment pile up on some waves and the launch waits
+// for those). Pruned rows get the "no value" result here.
+__global__ void __launch_bounds__(256)
+k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr, int rowsPerParticle, int nrows,
+               RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count, int *__restrict__ pruned)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = row < nrows;
+    const bool keep = valid && !(rowBound[row] < thr[row / rowsPerParticle]);
+    if (valid && !keep) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
+    const unsigned long long kb = __ballot(keep), pb = __ballot(valid && !keep);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) {
+        if (kb) base = atomicAdd(count, __popcll(kb));
+        if (pb) atomicAdd(pruned, __popcll(pb));
+    }
+    base = __shfl(base, 0, 64);
+    if (keep) list[base + __popcll(kb & ((1ull << lane) - 1ull))] = row;
 }
 
 // thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned.
@@ -1934,7 +1958,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2349,7 +2373,6 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     const Layout &L = pm->L;
     const int nrows = poff[m];
     if (nrows == 0) return XH_OK;
-    XH_TRY(xh_buf_reserve(ctx, pm->d_raw, sizeof(float4) * (size_t)nrows * L.nk));
     XH_TRY(xh_buf_reserve(ctx, pm->d_rowres, sizeof(RowRes) * (size_t)nrows));
     std::vector<BlockDesc> desc;
     const int PT = 4, QT = 4;
@@ -2382,9 +2405,11 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     const bool pruning = mfma && prune && pm->use_prune && pm->R1 && pm->use_idft3 && nparticles > 0 && nrows % nparticles == 0;
     if (pruning) XH_TRY(xh_buf_reserve(ctx, pm->d_bpart, sizeof(float2) * (size_t)XH_KSPLIT * nrows));
     const int K0 = pruning ? pm->K0 : L.nk;          // two-level S2 needs the bounds
+    const int rawStride = std::min(K0, L.nk);
+    XH_TRY(xh_buf_reserve(ctx, pm->d_raw, sizeof(float4) * (size_t)nrows * rawStride));
     XhHigh H;
     H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
-    H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0;
+    H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
@@ -2397,7 +2422,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
         hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, (ptiles + XH_PW2 - 1) / XH_PW2, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
                            (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,
                            (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg,
-                           pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr);
+                           pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr, rawStride);
     } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,
@@ -2415,7 +2440,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
 #define XH_IDFT3(A_, B_, C_)                                                                                  \
     hipLaunchKernelGGL((k_pm_idft_max3<A_, B_, C_>), dim3(grid), dim3(256), 0, ctx->stream, (const float4 *)pm->d_raw.p, \
                        (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_Wfull.p, (const xh_cf *)pm->d_chirp.p,       \
-                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nr, rowList, rowBound, thr, rowsPer, prunedCnt, H)
+                       (const xh_cf *)pm->d_vperm.p, L.N, L.nk, nr, rowList, rowBound, thr, rowsPer, prunedCnt, H, nrDev)
 #define XH_IDFT3_ANY()                                  \
     do {                                                \
         if (pm->logM == 9) XH_IDFT3(8, 8, 8);           \
@@ -2423,7 +2448,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
         else XH_IDFT3(16, 16, 8);                       \
     } while (0)
         int nr = nrows, rowsPer = 1;
-        const int *rowList = nullptr;
+        const int *rowList = nullptr, *nrDev = nullptr;
         const float *rowBound = nullptr, *thr = nullptr;
         int *prunedCnt = nullptr;
         int grid;
@@ -2456,10 +2481,13 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                                (const int *)pm->d_topRows.p, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
                                nparticles, tau2, (float *)pm->d_thr.p, (const float *)pm->d_rowTail.p);
             XH_LAUNCH_CHECK();
-            nr = nrows; rowList = nullptr;
-            rowBound = (const float *)pm->d_rowBound.p; thr = (const float *)pm->d_thr.p;
-            rowsPer = nrows / nparticles;
-            prunedCnt = d_pruned;
+            // survivors, compacted on the device; d_pruned[0] counts the pruned rows, d_pruned[1] the survivors
+            XH_TRY(xh_buf_reserve(ctx, pm->d_survList, sizeof(int) * (size_t)nrows));
+            hipLaunchKernelGGL(k_pm_survivors, dim3((nrows + 255) / 256), dim3(256), 0, ctx->stream, (const float *)pm->d_rowBound.p,
+                               (const float *)pm->d_thr.p, nrows / nparticles, nrows, (RowRes *)pm->d_rowres.p, (int *)pm->d_survList.p,
+                               d_pruned + 1, d_pruned);
+            XH_LAUNCH_CHECK();
+            nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
         }
         grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
         XH_IDFT3_ANY();
@@ -2523,7 +2551,10 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     pm->stat_pruned = 0;
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
-    size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (L.nk * sizeof(float4)));
+    // (with the two-level contraction a row only holds the frequencies below K0: far more rows per chunk)
+    const bool willPrune = dense && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1;
+    const size_t rawStride = willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
+    size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (rawStride * sizeof(float4)));
     // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
     if (n_orient > 1) maxRows = std::min<size_t>(maxRows, std::max<size_t>(1024, ((size_t)1 << 30) / (sizeof(CandRes) * n_orient)));
     const size_t maxSlots = n_orient > 1 ? 2048 : 32768;      // grid.y limit of the ring DFT / fp64 footprint
