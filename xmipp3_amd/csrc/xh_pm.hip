@@ -121,6 +121,7 @@ struct xh_pm {
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
     int64_t stat_pruned;
+    int lastPruneRows;           // rows of the last chunk that went through k_pm_survivors (0: none)
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
     XhBuf d_bT, d_aT, d_kboundsLow;
@@ -1138,19 +1139,17 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
 // for those). Pruned rows get the "no value" result here.
 __global__ void __launch_bounds__(256)
 k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr, int rowsPerParticle, int nrows,
-               RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count, int *__restrict__ pruned)
+               RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = row < nrows;
     const bool keep = valid && !(rowBound[row] < thr[row / rowsPerParticle]);
     if (valid && !keep) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
-    const unsigned long long kb = __ballot(keep), pb = __ballot(valid && !keep);
+    const unsigned long long kb = __ballot(keep);
+    if (!kb) return;                       // most waves: nothing survives, no atomic
     const int lane = threadIdx.x & 63;
     int base = 0;
-    if (lane == 0) {
-        if (kb) base = atomicAdd(count, __popcll(kb));
-        if (pb) atomicAdd(pruned, __popcll(pb));
-    }
+    if (lane == 0) base = atomicAdd(count, __popcll(kb));
     base = __shfl(base, 0, 64);
     if (keep) list[base + __popcll(kb & ((1ull << lane) - 1ull))] = row;
 }
@@ -2038,6 +2037,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma = 1;
     pm->use_prune = 1;
     pm->stat_pruned = 0;
+    pm->lastPruneRows = 0;
     pm->use_fir = 1;
     pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
@@ -2481,12 +2481,13 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                                (const int *)pm->d_topRows.p, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
                                nparticles, tau2, (float *)pm->d_thr.p, (const float *)pm->d_rowTail.p);
             XH_LAUNCH_CHECK();
-            // survivors, compacted on the device; d_pruned[0] counts the pruned rows, d_pruned[1] the survivors
+            // survivors, compacted on the device; d_pruned[1] counts them (the host derives the pruned rows)
             XH_TRY(xh_buf_reserve(ctx, pm->d_survList, sizeof(int) * (size_t)nrows));
             hipLaunchKernelGGL(k_pm_survivors, dim3((nrows + 255) / 256), dim3(256), 0, ctx->stream, (const float *)pm->d_rowBound.p,
                                (const float *)pm->d_thr.p, nrows / nparticles, nrows, (RowRes *)pm->d_rowres.p, (int *)pm->d_survList.p,
-                               d_pruned + 1, d_pruned);
+                               d_pruned + 1);
             XH_LAUNCH_CHECK();
+            pm->lastPruneRows = nrows;
             nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
         }
         grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
@@ -2637,6 +2638,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         // S2 + S3
         XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
         XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
+        pm->lastPruneRows = 0;
         XH_TRY(run_rows(pm, ms, poff, d_ids, dense, pm->nrefs, pm->ev[2], &M, m, 2.f * tauAbs, (int *)pm->d_counters.p + 2));
         XH_HIP(hipEventRecord(pm->ev[3], ctx->stream));
         // S4
@@ -2661,7 +2663,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         }
         pm->stat_resc_p += counters[0];
         pm->stat_resc_r += counters[1];
-        pm->stat_pruned += counters[2];
+        if (pm->lastPruneRows > 0) pm->stat_pruned += pm->lastPruneRows - counters[3];
         if (counters[0] > 0) {
             const int na = counters[0], nc = counters[1];
             XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, (const int *)pm->d_ambList.p, na, nullptr,
