@@ -210,10 +210,22 @@ inline ImageInfo readInfo(const std::string &path)
 inline void readImage(const std::string &name, std::vector<float> &data, ImageInfo &I)
 {
     FileName fn(name);
-    I = readInfo(fn.path);
+    // consecutive reads usually hit the same stack: keep its header and its stream (one per host thread; a file
+    // that is rewritten between reads of the same process must not be read through this cache -- none is)
+    struct Cached { std::string path; ImageInfo info; std::ifstream f; };
+    static thread_local Cached cache;
+    if (cache.path != fn.path || !cache.f.is_open()) {
+        cache.info = readInfo(fn.path);
+        cache.f.close();
+        cache.f.clear();
+        cache.f.open(fn.path, std::ios::binary);
+        cache.path = fn.path;
+    }
+    I = cache.info;
+    std::ifstream &f = cache.f;
+    f.clear();
     size_t idx = fn.hasNumber() ? fn.number() : 0;
     const size_t per = I.x * I.y * I.z;
-    std::ifstream f(fn.path, std::ios::binary);
     size_t off;
     if (I.mrc) off = I.headerBytes + (idx > 0 ? (idx - 1) * per * 4 : 0);
     else if (I.isStack) { if (idx == 0) idx = 1; off = I.headerBytes + (idx - 1) * (I.perImageHeader + per * 4) + I.perImageHeader; }

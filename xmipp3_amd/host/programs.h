@@ -148,7 +148,7 @@ public:
     double pad = 1, max_shift = -1, avail_memory = 1;
     int Ri = 1, Ro = -1, search5d_shift = 0, search5d_step = 2, numOrientations = 1, threads = 1;
     bool phase_flipped = false, do_scale = false, do_append = false;
-    int device = 0, gpus = 1, batch = 1024;
+    int device = 0, gpus = 1, batch = 4096;
     std::string deviceList;
     // side info
     MetaDataVec DFexp, DFo;
@@ -210,7 +210,7 @@ public:
         addParamsLine("  [--device <id=0>]         : first HIP device");
         addParamsLine("  [--gpus <n=1>]            : number of consecutive HIP devices, one host thread each");
         addParamsLine("  [--devices <list=\"\">]    : explicit comma-separated device ids (overrides --device/--gpus)");
-        addParamsLine("  [--batch <n=1024>]        : Particles per device batch");
+        addParamsLine("  [--batch <n=4096>]        : Particles per device batch");
     }
 
     void readParams() override
@@ -512,7 +512,7 @@ public:
     bool do_weights = false, useFast = false, useCTF = false, isPhaseFlipped = false;
     double padding_factor_proj = 2, padding_factor_vol = 2, maxResolution = 0.5, minCTF = 0.01, Ts = 1;
     double blob_radius = 1.9, blob_alpha = 15;
-    int blob_order = 0, bufferSize = 25, device = 0, gpus = 1, batch = 1024;
+    int blob_order = 0, bufferSize = 25, device = 0, gpus = 1, batch = 4096;
     std::string deviceList, fn_fsc;
     MetaDataVec SF;
     size_t imgSize = 0;
@@ -558,7 +558,7 @@ public:
         addParamsLine("  [--device <id=0>]              : first HIP device");
         addParamsLine("  [--gpus <n=1>]                 : number of consecutive HIP devices, one host thread each");
         addParamsLine("  [--devices <list=\"\">]         : explicit comma-separated device ids (overrides --device/--gpus)");
-        addParamsLine("  [--batch <n=1024>]             : Projections per device batch");
+        addParamsLine("  [--batch <n=4096>]             : Projections per device batch");
         addExampleLine("   xmipp_reconstruct_fourier_accel  -i reconstruction.sel --sym c2 --weight");
     }
 
