@@ -267,6 +267,27 @@ def test_tile_kernel_is_deterministic(gpu, data32):
     assert torch.equal(rf.temp, v1)
 
 
+@pytest.mark.parametrize("D,n", [(64, 300), (40, 64)])
+def test_two_level_culling_changes_nothing(gpu, D, n):
+    """k_rf_supercull hands every tile the projections that reach its 32^3 super-tile, in launch order: the temp spaces
+    are bit-identical with and without it (same projections per voxel, same order)."""
+    xa, ctx, torch = gpu
+    g = torch.Generator(device="cuda").manual_seed(D)
+    imgs = torch.randn((n, D, D), generator=g, device="cuda")
+    ang = synth.random_angles(n, np.random.default_rng(D))
+    rf = xa.RecFourier(ctx, D)
+    f = rf.prepare_images(imgs)
+    c = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda") + 0.5
+    m = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda")
+    rf.insert(f, ang, ctf=c, modulator=m)
+    on = rf.temp.clone()
+    rf.reset()
+    rf.set_option("supercull", 0)
+    rf.insert(f, ang, ctf=c, modulator=m)
+    assert torch.equal(rf.temp, on)
+    assert on.abs().max().item() > 0
+
+
 def test_linearity_of_insertion(gpu, data32):
     """Size-independent property: inserting A then B equals inserting A and B in one call."""
     xa, ctx, torch = gpu

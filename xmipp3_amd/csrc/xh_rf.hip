@@ -222,7 +222,8 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull, d_pack;
+    XhBuf d_cull, d_pack, d_superList, d_superCount;
+    int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 1: LDS-staged patches (blob radius < 2); 0: queue kernel
     int fft_variant;      // 0: register-blocked 2-D FFT of the projections where P allows; 1: radix-2 LDS kernels
@@ -735,13 +736,54 @@ __device__ __forceinline__ void d_prefetch(const void *g, void *ldsWaveRow)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)ldsWaveRow, 4, 0, 0);
 }
+// Two-level culling: one block per 32^3 super-tile (4x4x4 tiles) lists, in launch order, the projections whose
+// slab comes within reach of it; a tile then tests ~12 % of the launch instead of all of it. The super-tile test
+// is the tile test with the half diagonal of the larger cube: centres of a super-tile's tiles lie within
+// 12*sqrt(3) = 20.8 of its centre, so fr + 6.1 + 20.8 <= fr + 27.2 keeps every projection a tile would keep.
+__global__ void __launch_bounds__(256)
+k_rf_supercull(const float4 *__restrict__ cullN, const float4 *__restrict__ cullX, int nspaces, int mv, float fr,
+               int superDim, int superCap, int *__restrict__ superList, int *__restrict__ superCount)
+{
+    __shared__ int sCnt[4];
+    __shared__ int sBase;
+    const int sup = blockIdx.x;
+    const int sx = sup % superDim, sy = (sup / superDim) % superDim, sz = sup / (superDim * superDim);
+    const float cx = sx * 32 + 15.5f - mv / 2, cy = sy * 32 + 15.5f - mv / 2, cz = sz * 32 + 15.5f - mv / 2;
+    const float rho = 27.2f, sizeX = (float)(mv / 2);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sBase = 0;
+    __syncthreads();
+    int *lst = superList + (size_t)sup * superCap;
+    for (int s0 = 0; s0 < nspaces; s0 += 256) {
+        const int s = s0 + threadIdx.x;
+        bool hit = false;
+        if (s < nspaces) {
+            const float4 n = cullN[s], r0 = cullX[s];
+            const float dn = n.x * cx + n.y * cy + n.z * cz;
+            const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
+            hit = (fabsf(dn) <= fr + rho) && (dx >= -(fr + rho)) && (dx <= sizeX + fr + rho);
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) sCnt[wv] = __popcll(bal);
+        __syncthreads();
+        int base = sBase, total = 0;
+        for (int w = 0; w < 4; ++w) { const int c = sCnt[w]; if (w < wv) base += c; total += c; }
+        if (hit) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) sBase += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) superCount[sup] = sBase;
+}
+
 template <bool HAS_CTF, bool SMALLBLOB>
 __global__ void __launch_bounds__(512, 4)
 k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN,
                   const float4 *__restrict__ cullX, int nspaces, const void *__restrict__ pk,
                   const float *__restrict__ blobTable, float *__restrict__ tempV, float *__restrict__ tempW,
                   int mv, float iDeltaSqrt, double blobRadius, const unsigned *__restrict__ tileList,
-                  const int *__restrict__ classOff, int *__restrict__ counter, int dbg)
+                  const int *__restrict__ classOff, int *__restrict__ counter, int dbg,
+                  const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     __shared__ XhHitRec sRec[XH_CHUNK];
@@ -946,10 +988,16 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
         accW = 0.f; accR = 0.f; accI = 0.f;
         nseg = 0;
         int qn = 0;   // wave-uniform queue length
-        for (int s0 = 0; s0 < nspaces; s0 += XH_CHUNK) {
-            const int s = s0 + tid;
+        // the tile only looks at the projections that reach its 32^3 super-tile (k_rf_supercull), in launch order
+        const int sup = superList ? ((tz >> 2) * superDim + (ty >> 2)) * superDim + (tx >> 2) : 0;
+        const int nlist = superList ? superCount[sup] : nspaces;
+        const int *lst = superList ? superList + (size_t)sup * superCap : nullptr;
+        for (int s0 = 0; s0 < nlist; s0 += XH_CHUNK) {
+            const int li = s0 + tid;
+            int s = -1;
             bool hit = false;
-            if (tid < XH_CHUNK && s < nspaces) {
+            if (tid < XH_CHUNK && li < nlist) {
+                s = lst ? lst[li] : li;
                 const float4 n = cullN[s], r0 = cullX[s];
                 const float dn = n.x * cx + n.y * cy + n.z * cz;
                 const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
@@ -1563,6 +1611,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->tile_dbg = 0;
     rf->tile_max_spaces = 8192;
     rf->tile_variant = 0;   // the LDS-staged variant measured slower (profiles/README.md)
+    rf->use_supercull = 1;
     rf->fft_variant = 0;
     rf->evUsed = 0;
     rf->kernelMs = 0;
@@ -1622,6 +1671,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
+    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -1645,6 +1695,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
+    else if (!strcmp(name, "supercull")) rf->use_supercull = (int)value;
     else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
     else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
@@ -1917,13 +1968,28 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
             XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));
             if (rf->evUsed >= 256) drain_events(rf);
             hipEvent_t ev0 = next_event(rf), ev1 = next_event(rf);
+            // super-tile lists of this launch (part of the gridding time the roofline is priced on)
+            const int superDim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + 3) / 4;
+            const int nsuper = superDim * superDim * superDim;
+            const int *superList = nullptr, *superCount = nullptr;
             if (ev0 && ev1) XH_HIP(hipEventRecord(ev0, ctx->stream));
+            if (rf->use_supercull && m >= 32) {
+                XH_TRY(xh_buf_reserve(ctx, rf->d_superList, sizeof(int) * (size_t)nsuper * m));
+                XH_TRY(xh_buf_reserve(ctx, rf->d_superCount, sizeof(int) * (size_t)nsuper));
+                hipLaunchKernelGGL(k_rf_supercull, dim3(nsuper), dim3(256), 0, ctx->stream, (const float4 *)rf->d_cull.p + s0,
+                                   (const float4 *)rf->d_cull.p + ns + s0, m, rf->mv, (float)rf->p.blob_radius, superDim, m,
+                                   (int *)rf->d_superList.p, (int *)rf->d_superCount.p);
+                XH_LAUNCH_CHECK();
+                superList = (const int *)rf->d_superList.p;
+                superCount = (const int *)rf->d_superCount.p;
+            }
 #define XH_TILES(CTF_, SB_)                                                                                         \
     hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
                        (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,                        \
                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
-                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p, rf->tile_dbg)
+                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p, rf->tile_dbg, \
+                       superList, superCount, superDim, m)
             if (smallBlob && rf->tile_variant == 1) {
                 if (hasCtf)
                     hipLaunchKernelGGL((k_rf_insert_tiles_lds<true>), dim3(grid), dim3(512), 0, ctx->stream, (const XhSpace *)rf->d_spaces.p + s0,
