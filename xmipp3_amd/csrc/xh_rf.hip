@@ -761,7 +761,9 @@ k_rf_supercull(const float4 *__restrict__ cullN, const float4 *__restrict__ cull
             const float4 n = cullN[s], r0 = cullX[s];
             const float dn = n.x * cx + n.y * cy + n.z * cz;
             const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
-            hit = (fabsf(dn) <= fr + rho) && (dx >= -(fr + rho)) && (dx <= sizeX + fr + rho);
+            // box bounds (voxel centres within +-15.5 of the super-tile centre per axis), never wider than the sphere bound
+            const float hn = fminf(rho, 15.5f * n.w + 0.05f), hx = fminf(rho, 15.5f * r0.w + 0.05f);
+            hit = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
         }
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) sCnt[wv] = __popcll(bal);
@@ -1001,7 +1003,9 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 const float4 n = cullN[s], r0 = cullX[s];
                 const float dn = n.x * cx + n.y * cy + n.z * cz;
                 const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
-                hit = (fabsf(dn) <= fr + rho8) && (dx >= -(fr + rho8)) && (dx <= sizeX + fr + rho8);
+                // box bound of the tile (centres within +-3.5 per axis), never wider than the sphere bound
+                const float hn = fminf(rho8, 3.5f * n.w + 0.02f), hx = fminf(rho8, 3.5f * r0.w + 0.02f);
+                hit = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
             }
             const unsigned long long bal = __ballot(hit);
             if (lane == 0) sWaveCnt[wv] = __popcll(bal);
@@ -1029,7 +1033,10 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                     const float4 r2 = sRec[hb + lane].r2, r0 = sRec[hb + lane].r0;
                     const float dn = r2.x * c4x + r2.y * c4y + r2.z * c4z;
                     const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
-                    keep = (fabsf(dn) <= fr + rho4) && (dx >= -(fr + rho4)) && (dx <= sizeX + fr + rho4);
+                    // box bound of the sub-cube (centres within +-1.5 per axis), never wider than the sphere bound
+                    const float hn = fminf(rho4, 1.5f * (fabsf(r2.x) + fabsf(r2.y) + fabsf(r2.z)) + 0.02f);
+                    const float hx = fminf(rho4, 1.5f * (fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z)) + 0.02f);
+                    keep = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
                 }
                 unsigned long long todo = __ballot(keep);
                 if (!todo) continue;
@@ -1196,7 +1203,9 @@ k_rf_insert_tiles_lds(const XhSpace *__restrict__ spaces, const float4 *__restri
                 const float4 n = cullN[s], r0 = cullX[s];
                 const float dn = n.x * cx + n.y * cy + n.z * cz;
                 const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
-                hit = (fabsf(dn) <= fr + rho8) && (dx >= -(fr + rho8)) && (dx <= sizeX + fr + rho8);
+                // box bound of the tile (centres within +-3.5 per axis), never wider than the sphere bound
+                const float hn = fminf(rho8, 3.5f * n.w + 0.02f), hx = fminf(rho8, 3.5f * r0.w + 0.02f);
+                hit = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
             }
             const unsigned long long bal = __ballot(hit);
             if (lane == 0) sWaveCnt[wv] = __popcll(bal);
@@ -1944,8 +1953,9 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         std::vector<float> cull((size_t)ns * 8);
         for (int i = 0; i < ns; ++i) {
             float *n = &cull[(size_t)i * 4], *x = &cull[(size_t)(ns + i) * 4];
-            n[0] = spaces[i].tInv[6]; n[1] = spaces[i].tInv[7]; n[2] = spaces[i].tInv[8]; n[3] = 0.f;
-            x[0] = spaces[i].tInv[0]; x[1] = spaces[i].tInv[1]; x[2] = spaces[i].tInv[2]; x[3] = 0.f;
+            // .w: the 1-norm, i.e. the support function of a unit cube: |v . delta| <= h * |v|_1 for |delta_i| <= h
+            n[0] = spaces[i].tInv[6]; n[1] = spaces[i].tInv[7]; n[2] = spaces[i].tInv[8]; n[3] = std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2]);
+            x[0] = spaces[i].tInv[0]; x[1] = spaces[i].tInv[1]; x[2] = spaces[i].tInv[2]; x[3] = std::fabs(x[0]) + std::fabs(x[1]) + std::fabs(x[2]);
         }
         XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
         XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
