@@ -229,7 +229,7 @@ def main():
     stage = pm.stage_ms(reset=False) if pm is not None else {}
     stage["gridding_insert"] = float(sum(grid_ms))          # pack + spaces upload + kernel
     k_ms, k_launches = rf.kernel_ms(reset=False) if rf is not None else (0.0, 0)
-    stage["k_rf_insert_tiles"] = k_ms                        # HIP events around the kernel launches only
+    stage["k_rf_insert_cubes"] = k_ms                        # HIP events around the kernel launches only
     # ---- roofline of the dominant kernel (per launch = per chunk; reported per particle-second)
     N = pm.N if pm is not None else 2 * int(math.pi * (D // 2 - 1))
     ncoef = pm.ncoef if pm is not None else 0
@@ -246,26 +246,26 @@ def main():
         cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"])
     if rf is not None and k_ms > 0:
         by = args.steps * B * bytes_grid
-        cand["k_rf_insert_tiles"] = ("hbm", by / (k_ms * 1e-3) / 1e9, 8000.0, "GB/s", k_ms)
+        cand["k_rf_insert_cubes"] = ("hbm", by / (k_ms * 1e-3) / 1e9, 8000.0, "GB/s", k_ms)
     dom = max(cand, key=lambda k: cand[k][4]) if cand else None
     roofline = None
     if dom:
         b, ach, peak, unit, ms = cand[dom]
         roofline = {"kernel": dom, "bound": b, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                     "traffic": None, "ms_in_timed_region": ms}
-        if dom == "k_rf_insert_tiles":
+        if dom == "k_rf_insert_cubes":
             roofline["launches"] = k_launches
             roofline["avg_launch_ms"] = k_ms / max(1, k_launches)
             roofline["algorithmic_bytes_per_launch"] = B * bytes_grid
             roofline["algorithmic_MB_per_projection"] = bytes_grid / 1e6
             # HBM bytes per launch from the PMC passes of tools/collect_traffic.sh over this same command
             # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); PMC cannot be read from inside the process
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_rf_insert_tiles.json")
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_rf_insert_cubes.json")
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 if tj.get("projections_per_launch") == B:
                     roofline["traffic"] = tj["traffic_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/traffic_k_rf_insert_tiles.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    roofline["traffic_source"] = "profiles/traffic_k_rf_insert_cubes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     others = {k: {"bound": v[0], "achieved": v[1], "peak": v[2], "unit": v[3], "frac": v[1] / v[2], "ms": v[4]}
               for k, v in cand.items() if k != dom}
 

@@ -105,9 +105,10 @@ def test_ctf_arrays(gpu, oracle, kind):
 
 def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
-    if path in ("tiles", "tiles_queue"):
-        rf.set_option("tile_min_spaces", 1)       # output-stationary tile kernel even for one projection
-        rf.set_option("tile_variant", 1 if path == "tiles" else 0)   # LDS-staged patches | work-queue variant
+    if path in ("tiles", "tiles_queue", "cubes"):
+        rf.set_option("tile_min_spaces", 1)       # output-stationary kernels even for one projection
+        # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes (the product path)
+        rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2}[path])
     elif path == "scatter":
         rf.set_option("tile_min_spaces", 1 << 30)  # atomic scatter kernel
     o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
@@ -115,7 +116,7 @@ def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     return rf, o, ffts
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes"])
 def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
     """One projection into an empty volume: the same voxels and, summing taps in the same
     order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
@@ -147,7 +148,7 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes"])
 @pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
 def test_insert_many(gpu, oracle, data32, mode, path):
     xa, ctx, torch = gpu

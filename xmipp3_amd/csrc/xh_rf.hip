@@ -222,10 +222,10 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull, d_pack, d_superList, d_superCount;
+    XhBuf d_cull, d_pack, d_superList, d_superCount, d_recs;
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
-    int tile_variant;     // 1: LDS-staged patches (blob radius < 2); 0: queue kernel
+    int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
     int fft_variant;      // 0: register-blocked 2-D FFT of the projections where P allows; 1: radix-2 LDS kernels
     // HIP-event bracket of every gridding-kernel launch (bench.py's roofline), drained lazily
     std::vector<hipEvent_t> evPool;
@@ -1128,6 +1128,306 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
 }
 
 
+// ---- gridding, output-stationary, wave-independent form ------------------------------------------------
+// Same arithmetic as k_rf_insert_tiles (its dense pass is reused verbatim), different control: a WAVE owns a 4x4x4
+// sub-cube from start to finish. It culls its super-tile's projection list against the sub-cube itself (lane <->
+// projection, 64 at a time), fetches the survivors' records with scalar loads (the index is wave-uniform), runs the
+// sparse and dense passes and writes its 64 voxels. Nothing is shared between the waves of a workgroup but the blob
+// table: no block-level cull, no record staging, no barrier inside the work loop -- in the tile kernel every chunk of
+// the list ended in a barrier at which seven waves waited for the slowest sub-cube. Work units (sub-cubes, eight per
+// tile of the tile list, same XCD classes) are handed out per wave, the next grab in flight while a unit is processed.
+struct XhRec { float4 r0, r1, r2; };     // XhHitRec layout, one per traverse space, in global memory
+template <bool HAS_CTF, bool SMALLBLOB>
+__global__ void __launch_bounds__(512, 4)
+k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN, const float4 *__restrict__ cullX,
+                  const XhRec *__restrict__ recs, int nspaces, const void *__restrict__ pk, const float *__restrict__ blobTable,
+                  float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
+                  const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter, int dbg,
+                  const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap)
+{
+    __shared__ float sBlob[XH_BLOB_TABLE];
+    __shared__ int sSegStart[8][XH_SEGCAP + 1];
+    __shared__ unsigned long long sSegMask[8][XH_SEGCAP + 1];
+    __shared__ float qIx[8][XH_QCAP], qIy[8][XH_QCAP], qZs[8][XH_QCAP];
+    __shared__ int qMeta[8][XH_QCAP];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < XH_BLOB_TABLE; i += 512) sBlob[i] = blobTable[i];
+    __syncthreads();
+    const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
+    const float fr = (float)blobRadius;
+    const float maxDistanceSqr = (sizeX + blobRadius) * (sizeX + blobRadius);
+    const float radiusSqr = blobRadius * blobRadius;
+    const float rho4 = 2.65f;                     // half diagonal of the 3^3 voxel-centre cube + slack
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    float accW = 0.f, accR = 0.f, accI = 0.f;   // lane l accumulates voxel l of the wave's sub-cube, in registers
+    int nseg = 0;                              // wave-uniform: projections ("segments") with items in the queue
+
+    auto process = [&](int n, int ty0, int tz0) {
+        if (dbg == 1) return;
+        float vW = 0.f, vR = 0.f, vI = 0.f;
+        if (lane < n) {
+            const int meta = qMeta[wv][lane];
+            const int vl = meta & 63, si = meta >> 6;
+            const float ix = qIx[wv][lane], iy = qIy[wv][lane], zSqr = qZs[wv][lane];
+            const XhSpace &S = spaces[si];
+            const int y = ty0 + ((vl >> 2) & 3), z = tz0 + (vl >> 4);
+            // the reference only visits rows that cross the top or bottom face of the slab (RFA:746-750)
+            float xa, xb;
+            const bool hit1 = d_getX(xa, (float)y, (float)z, S.u, S.v, S.p0);
+            const bool hit2 = d_getX(xb, (float)y, (float)z, S.u, S.v, S.p4);
+            if ((hit1 || hit2) && dbg != 3) {
+                int minX = (int)ceil((double)ix - blobRadius);
+                int maxX = (int)floor((double)ix + blobRadius);
+                int minY = (int)ceil((double)iy - blobRadius);
+                int maxY = (int)floor((double)iy + blobRadius);
+                minX = max(minX, 0);
+                minY = max(minY, 0);
+                maxX = min(maxX, sizeX - 1);
+                maxY = min(maxY, sizeY - 1);
+                const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+                const size_t imgOff = (size_t)S.img * SX * SY;
+                const float dataWeight = S.weight;
+                if (SMALLBLOB) {
+                    // blob radius < 2: at most 4x4 candidate pixels, fetched as four contiguous row
+                    // segments of the padded record (all loads issued before any arithmetic). Pixels
+                    // outside the blob or the image get weight 0, which leaves the sums bit-identical
+                    // to the reference's "continue" (RFA:660-698).
+                    const int bY = (int)ceil((double)iy - blobRadius), bX = (int)ceil((double)ix - blobRadius);
+                    float yz[4], xs[4];
+                    bool rv[4], cv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = bY + a;
+                        const float ySqr = (iy - i) * (iy - i);
+                        yz[a] = ySqr + zSqr;
+                        rv[a] = (i >= minY) && (i <= maxY) && !(yz[a] > radiusSqr);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = bX + b;
+                        const float xD = ix - j;
+                        xs[b] = xD * xD;
+                        cv[b] = (j >= minX) && (j <= maxX);
+                    }
+                    const size_t base = imgOff + (size_t)(bY + XH_PAD) * SX + (bX + XH_PAD);
+                    // rows are fetched RB at a time, all loads of a group before its arithmetic. With the CTF
+                    // planes a pixel is 16 bytes: four rows at once would need 64 live registers and spill
+                    // (the kernel is capped at 128 VGPRs by its LDS-limited occupancy), two rows do not.
+                    constexpr int RB = (HAS_CTF && XH_CTF_ROWS2) ? 2 : 4;
+#pragma unroll
+                    for (int a0 = 0; a0 < 4; a0 += RB) {
+                        float pr[RB][4], pi_[RB][4], wc[RB][4], wm[RB][4];
+#pragma unroll
+                        for (int ar = 0; ar < RB; ++ar) {
+                            const int a = a0 + ar;
+                            // rows outside the blob are not fetched at all (exec-masked): ~1/4 fewer L1 lookups
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) { pr[ar][b] = 0.f; pi_[ar][b] = 0.f; wc[ar][b] = 0.f; wm[ar][b] = 0.f; }
+                            if (!rv[a] && dbg != 4) continue;
+                            if (HAS_CTF) {
+                                const float4 *row = reinterpret_cast<const float4 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) { const float4 q = row[b]; pr[ar][b] = q.x; pi_[ar][b] = q.y; wc[ar][b] = q.z; wm[ar][b] = q.w; }
+                            } else {
+                                const float2 *row = reinterpret_cast<const float2 *>(pk) + base + (size_t)a * SX;
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) { const float2 q = row[b]; pr[ar][b] = q.x; pi_[ar][b] = q.y; }
+                            }
+                        }
+#pragma unroll
+                        for (int ar = 0; ar < RB; ++ar) {
+                            const int a = a0 + ar;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float distanceSqr = xs[b] + yz[a];
+                                const bool use = rv[a] && cv[b] && !(distanceSqr > radiusSqr);
+                                const int aux = use ? (int)(distanceSqr * iDeltaSqrt + 0.5f) : 0;
+                                const float wBlob = use ? sBlob[aux] : 0.f;
+                                if (HAS_CTF) {
+                                    const float weight = wBlob * wm[ar][b] * dataWeight;
+                                    vW += weight;
+                                    vR += pr[ar][b] * weight * wc[ar][b];
+                                    vI += pi_[ar][b] * weight * wc[ar][b];
+                                } else {
+                                    const float weight = wBlob * dataWeight;
+                                    vW += weight;
+                                    vR += pr[ar][b] * weight;
+                                    vI += pi_[ar][b] * weight;
+                                }
+                            }
+                        }
+                    }
+                } else
+                for (int i = minY; i <= maxY; i++) {
+                    const float ySqr = (iy - i) * (iy - i);
+                    const float yzSqr = ySqr + zSqr;
+                    if (yzSqr > radiusSqr) continue;
+                    for (int j = minX; j <= maxX; j++) {
+                        const float xD = ix - j;
+                        const float distanceSqr = xD * xD + yzSqr;
+                        if (distanceSqr > radiusSqr) continue;
+                        const int aux = (int)(distanceSqr * iDeltaSqrt + 0.5f);
+                        const float wBlob = sBlob[aux];
+                        const size_t o = imgOff + (size_t)(i + XH_PAD) * SX + (j + XH_PAD);
+                        if (HAS_CTF) {
+                            const float4 q = reinterpret_cast<const float4 *>(pk)[o];
+                            const float weight = wBlob * q.w * dataWeight;
+                            vW += weight;
+                            vR += q.x * weight * q.z;
+                            vI += q.y * weight * q.z;
+                        } else {
+                            const float2 q = reinterpret_cast<const float2 *>(pk)[o];
+                            const float weight = wBlob * dataWeight;
+                            vW += weight;
+                            vR += q.x * weight;
+                            vI += q.y * weight;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane < n) { qIx[wv][lane] = vW; qIy[wv][lane] = vR; qZs[wv][lane] = vI; }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const unsigned long long mask = sSegMask[wv][sg];
+            if ((mask >> lane) & 1ull) {
+                const int pos = sSegStart[wv][sg] + __popcll(mask & below);
+                if (pos >= 0 && pos < n) { accW += qIx[wv][pos]; accR += qIy[wv][pos]; accI += qZs[wv][pos]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+
+    // work distribution: units = sub-cubes, eight per tile; a wave drains its block's XCD class first, then steals
+    constexpr int UG = 4;                          // units per grab
+    int cls = blockIdx.x & 7, tried = 0;
+    int pend = 0;
+    if (lane == 0) pend = atomicAdd(&counter[cls], UG);
+    for (;;) {
+        int lo = 0, hi = 0;
+        if (lane == 0) {
+            while (tried < 8) {
+                const int n = 8 * (classOff[cls + 1] - classOff[cls]);
+                if (pend < n) { lo = 8 * classOff[cls] + pend; hi = 8 * classOff[cls] + min(pend + UG, n); break; }
+                cls = (cls + 1) & 7;
+                if (++tried < 8) pend = atomicAdd(&counter[cls], UG);
+            }
+            if (tried < 8) pend = atomicAdd(&counter[cls], UG);    // in flight while this grab is processed
+        }
+        lo = __builtin_amdgcn_readfirstlane(lo);
+        hi = __builtin_amdgcn_readfirstlane(hi);
+        if (lo >= hi) break;
+        for (int u = lo; u < hi; ++u) {
+            const unsigned packed = tileList[u >> 3];
+            const int sub = u & 7;
+            const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
+            const int x0 = tx * XH_TSZ + (sub & 1) * 4, y0 = ty * XH_TSZ + ((sub >> 1) & 1) * 4, z0 = tz * XH_TSZ + (sub >> 2) * 4;
+            const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+            const bool inVol = (x <= mv) && (y <= mv) && (z <= mv);
+            const float c4x = x0 + 1.5f - mv / 2, c4y = y0 + 1.5f - mv / 2, c4z = z0 + 1.5f - mv / 2;
+            const float px = x - mv / 2, py = y - mv / 2, pz = z - mv / 2;
+            const bool inSphere = inVol && !((px * px + py * py + pz * pz) > maxDistanceSqr);
+            if (!__ballot(inSphere)) continue;
+            accW = 0.f; accR = 0.f; accI = 0.f;
+            nseg = 0;
+            int qn = 0;   // wave-uniform queue length
+            const int sup = superList ? ((tz >> 2) * superDim + (ty >> 2)) * superDim + (tx >> 2) : 0;
+            const int nlist = superList ? superCount[sup] : nspaces;
+            const int *lst = superList ? superList + (size_t)sup * superCap : nullptr;
+            for (int hb = 0; hb < nlist; hb += 64) {
+                // cull against the sub-cube: lane <-> projection of the list
+                bool keep = false;
+                int sIdx = 0;
+                if (hb + lane < nlist) {
+                    sIdx = lst ? lst[hb + lane] : hb + lane;
+                    const float4 n = cullN[sIdx], r0 = cullX[sIdx];
+                    const float dn = n.x * c4x + n.y * c4y + n.z * c4z;
+                    const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
+                    const float hn = fminf(rho4, 1.5f * n.w + 0.02f), hx = fminf(rho4, 1.5f * r0.w + 0.02f);
+                    keep = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
+                }
+                unsigned long long todo = __ballot(keep);
+                if (!todo || dbg == 2) continue;
+                // the records are wave-uniform: scalar loads, the next one in flight while the current one is tested
+                int hitId = __builtin_amdgcn_readlane(sIdx, __builtin_ctzll(todo));
+                todo &= todo - 1;
+                float4 r0 = recs[hitId].r0, r1 = recs[hitId].r1, r2 = recs[hitId].r2;
+                for (;;) {
+                    const bool more = todo != 0;
+                    float4 n0 = r0, n1 = r1, n2 = r2;
+                    int nHit = hitId;
+                    if (more) {
+                        nHit = __builtin_amdgcn_readlane(sIdx, __builtin_ctzll(todo));
+                        todo &= todo - 1;
+                        n0 = recs[nHit].r0; n1 = recs[nHit].r1; n2 = recs[nHit].r2;
+                    }
+                    const int yy = __float_as_int(r1.w), zz = __float_as_int(r2.w);
+                    bool pass = inSphere && !(y < (yy & 0xffff) || y > (yy >> 16) || z < (zz & 0xffff) || z > (zz >> 16));
+                    float ix = 0.f, iy = 0.f, zSqr = 0.f;
+                    if (pass) {
+                        ix = r0.x * px + r0.y * py + r0.z * pz;
+                        iy = r1.x * px + r1.y * py + r1.z * pz;
+                        const float iz = r2.x * px + r2.y * py + r2.z * pz;
+                        iy += mv / 2;
+                        zSqr = iz * iz;
+                        pass = !(zSqr > radiusSqr);
+                        // a voxel with no pixel within reach adds nothing: drop it before the costly part
+                        pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
+                               ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+                    }
+                    const unsigned long long pb = __ballot(pass);
+                    const int np = __popcll(pb);
+                    if (np != 0) {
+                        if (pass) {
+                            const int q = qn + __popcll(pb & ((1ull << lane) - 1ull));
+                            qIx[wv][q] = ix; qIy[wv][q] = iy; qZs[wv][q] = zSqr;
+                            qMeta[wv][q] = (hitId << 6) | lane;
+                        }
+                        if (lane == 0) { sSegStart[wv][nseg] = qn; sSegMask[wv][nseg] = pb; }
+                        ++nseg;
+                        qn += np;
+                        if (qn >= 64 || nseg == XH_SEGCAP) {
+                            const int take = min(qn, 64);
+                            process(take, y0, z0);
+                            // move the remainder down; only the last segment can straddle the batch boundary
+                            const int rem = qn - take;
+                            float a = 0.f, b = 0.f, c = 0.f;
+                            int m = 0;
+                            if (lane < rem) { a = qIx[wv][64 + lane]; b = qIy[wv][64 + lane]; c = qZs[wv][64 + lane]; m = qMeta[wv][64 + lane]; }
+                            if (lane < rem) { qIx[wv][lane] = a; qIy[wv][lane] = b; qZs[wv][lane] = c; qMeta[wv][lane] = m; }
+                            if (rem > 0) {
+                                const int st = sSegStart[wv][nseg - 1] - 64;
+                                const unsigned long long mk = sSegMask[wv][nseg - 1];
+                                __builtin_amdgcn_wave_barrier();
+                                if (lane == 0) { sSegStart[wv][0] = st; sSegMask[wv][0] = mk; }
+                                nseg = 1;
+                            } else nseg = 0;
+                            qn = rem;
+                        }
+                    }
+                    if (!more) break;
+                    r0 = n0; r1 = n1; r2 = n2; hitId = nHit;
+                }
+            }
+            if (qn > 0) process(qn, y0, z0);
+            const float aW = accW, aR = accR, aI = accI;
+            if (inSphere && (aW != 0.f || aR != 0.f || aI != 0.f)) {
+                const size_t vi = ((size_t)z * dim + y) * dim + x;
+                float2 *V = reinterpret_cast<float2 *>(tempV) + vi;
+                float2 v = *V;
+                v.x += aR;
+                v.y += aI;
+                *V = v;
+                tempW[vi] += aW;
+            }
+        }
+    }
+}
+
+
 // ---- gridding, output-stationary, LDS-staged patches ---------------------------------------------
 // The queue kernel above is bound by the L1's tag-lookup rate: every lane gathers its own 4x4 footprint
 // (profiles/README.md: 26 L1 accesses per vector-memory instruction). Here a wave stages, per surviving
@@ -1619,7 +1919,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->tile_min_spaces = 24;
     rf->tile_dbg = 0;
     rf->tile_max_spaces = 8192;
-    rf->tile_variant = 0;   // the LDS-staged variant measured slower (profiles/README.md)
+    rf->tile_variant = 2;   // 2: wave-independent sub-cubes (product); 0: tile kernel with block-level staging; 1: LDS patches
     rf->use_supercull = 1;
     rf->fft_variant = 0;
     rf->evUsed = 0;
@@ -1680,7 +1980,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
-    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount);
+    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_recs);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -1959,6 +2259,19 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         }
         XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
         XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
+        // compact records of the traverse spaces for the wave-independent kernel (scalar loads)
+        std::vector<XhRec> recs(ns);
+        for (int i = 0; i < ns; ++i) {
+            const XhSpace &S = spaces[i];
+            int im = S.img, yy = S.minY | (S.maxY << 16), zz = S.minZ | (S.maxZ << 16);
+            float fi, fy, fz;
+            memcpy(&fi, &im, 4); memcpy(&fy, &yy, 4); memcpy(&fz, &zz, 4);
+            recs[i].r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], fi);
+            recs[i].r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], fy);
+            recs[i].r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], fz);
+        }
+        XH_TRY(xh_buf_reserve(ctx, rf->d_recs, sizeof(XhRec) * (size_t)ns));
+        XH_HIP(hipMemcpyAsync(rf->d_recs.p, recs.data(), sizeof(XhRec) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         XH_HIP(hipStreamSynchronize(ctx->stream));
         {
             // packed + padded projection records (re, im[, ctf, mod]) for contiguous 4-pixel row fetches
@@ -1978,11 +2291,10 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
             XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));
             if (rf->evUsed >= 256) drain_events(rf);
             hipEvent_t ev0 = next_event(rf), ev1 = next_event(rf);
-            // super-tile lists of this launch (part of the gridding time the roofline is priced on)
+            // super-tile lists of this launch
             const int superDim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + 3) / 4;
             const int nsuper = superDim * superDim * superDim;
             const int *superList = nullptr, *superCount = nullptr;
-            if (ev0 && ev1) XH_HIP(hipEventRecord(ev0, ctx->stream));
             if (rf->use_supercull && m >= 32) {
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superList, sizeof(int) * (size_t)nsuper * m));
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superCount, sizeof(int) * (size_t)nsuper));
@@ -1993,6 +2305,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                 superList = (const int *)rf->d_superList.p;
                 superCount = (const int *)rf->d_superCount.p;
             }
+            if (ev0 && ev1) XH_HIP(hipEventRecord(ev0, ctx->stream));    // the events bracket the gridding kernel alone
 #define XH_TILES(CTF_, SB_)                                                                                         \
     hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
@@ -2011,6 +2324,20 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                                        (const float4 *)rf->d_cull.p + s0, (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,
                                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
                                        (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
+            }
+            else if (rf->tile_variant == 2) {
+#define XH_CUBES(CTF_, SB_)                                                                                         \
+    hipLaunchKernelGGL((k_rf_insert_cubes<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
+                       (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
+                       (const float4 *)rf->d_cull.p + ns + s0, (const XhRec *)rf->d_recs.p + s0, m,                   \
+                       (const void *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, \
+                       rf->p.blob_radius, (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16,      \
+                       (int *)rf->d_tileCounter.p, rf->tile_dbg, superList, superCount, superDim, m)
+                if (hasCtf && smallBlob) XH_CUBES(true, true);
+                else if (hasCtf) XH_CUBES(true, false);
+                else if (smallBlob) XH_CUBES(false, true);
+                else XH_CUBES(false, false);
+#undef XH_CUBES
             }
             else if (hasCtf && smallBlob) XH_TILES(true, true);
             else if (hasCtf) XH_TILES(true, false);
