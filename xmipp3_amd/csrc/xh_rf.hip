@@ -222,7 +222,7 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull, d_pack, d_superList, d_superCount, d_recs;
+    XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs;
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -736,33 +736,39 @@ __device__ __forceinline__ void d_prefetch(const void *g, void *ldsWaveRow)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)ldsWaveRow, 4, 0, 0);
 }
-// Two-level culling: one block per 32^3 super-tile (4x4x4 tiles) lists, in launch order, the projections whose
-// slab comes within reach of it; a tile then tests ~12 % of the launch instead of all of it. The super-tile test
-// is the tile test with the half diagonal of the larger cube: centres of a super-tile's tiles lie within
-// 12*sqrt(3) = 20.8 of its centre, so fr + 6.1 + 20.8 <= fr + 27.2 keeps every projection a tile would keep.
+// Two-level culling: one block per 16^3 super-tile (2x2x2 tiles) lists, in launch order, the projections whose
+// slab comes within reach of it; a tile / sub-cube then tests ~6 % of the launch instead of all of it. The
+// super-tile test is the finer test with the half extent of the larger cube: the centres of a super-tile's tiles
+// lie within 4 per axis (4*sqrt(3) = 6.93) of its centre, those of its sub-cubes within 6 per axis (10.4), so with the
+// half extent 7.5 (sphere 13.3) it keeps every projection a tile (3.5 / 6.1) or a sub-cube (1.5 / 2.65) would keep.
+#define XH_SUPERSHIFT 1                        // tiles per super-tile edge = 1 << XH_SUPERSHIFT
+#define XH_SUPER (XH_TSZ << XH_SUPERSHIFT)     // voxels per super-tile edge
+#define XH_SUPERH 7.5f                         // half extent of the cube of voxel centres
+#define XH_SUPERRHO 13.3f                      // its half diagonal (12.99) + slack
 __global__ void __launch_bounds__(256)
 k_rf_supercull(const float4 *__restrict__ cullN, const float4 *__restrict__ cullX, int nspaces, int mv, float fr,
-               int superDim, int superCap, int *__restrict__ superList, int *__restrict__ superCount)
+               int superDim, int superCap, int *__restrict__ superList, int *__restrict__ superCount,
+               float4 *__restrict__ superN, float4 *__restrict__ superX)
 {
     __shared__ int sCnt[4];
     __shared__ int sBase;
     const int sup = blockIdx.x;
     const int sx = sup % superDim, sy = (sup / superDim) % superDim, sz = sup / (superDim * superDim);
-    const float cx = sx * 32 + 15.5f - mv / 2, cy = sy * 32 + 15.5f - mv / 2, cz = sz * 32 + 15.5f - mv / 2;
-    const float rho = 27.2f, sizeX = (float)(mv / 2);
+    const float cx = sx * XH_SUPER + XH_SUPERH - mv / 2, cy = sy * XH_SUPER + XH_SUPERH - mv / 2, cz = sz * XH_SUPER + XH_SUPERH - mv / 2;
+    const float rho = XH_SUPERRHO, sizeX = (float)(mv / 2);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) sBase = 0;
     __syncthreads();
-    int *lst = superList + (size_t)sup * superCap;
     for (int s0 = 0; s0 < nspaces; s0 += 256) {
         const int s = s0 + threadIdx.x;
         bool hit = false;
+        float4 n = make_float4(0.f, 0.f, 0.f, 0.f), r0 = n;
         if (s < nspaces) {
-            const float4 n = cullN[s], r0 = cullX[s];
+            n = cullN[s]; r0 = cullX[s];
             const float dn = n.x * cx + n.y * cy + n.z * cz;
             const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
-            // box bounds (voxel centres within +-15.5 of the super-tile centre per axis), never wider than the sphere bound
-            const float hn = fminf(rho, 15.5f * n.w + 0.05f), hx = fminf(rho, 15.5f * r0.w + 0.05f);
+            // box bounds (voxel centres within +-XH_SUPERH of the super-tile centre per axis), never wider than the sphere bound
+            const float hn = fminf(rho, XH_SUPERH * n.w + 0.05f), hx = fminf(rho, XH_SUPERH * r0.w + 0.05f);
             hit = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
         }
         const unsigned long long bal = __ballot(hit);
@@ -770,7 +776,11 @@ k_rf_supercull(const float4 *__restrict__ cullN, const float4 *__restrict__ cull
         __syncthreads();
         int base = sBase, total = 0;
         for (int w = 0; w < 4; ++w) { const int c = sCnt[w]; if (w < wv) base += c; total += c; }
-        if (hit) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        if (hit) {
+            const size_t o = (size_t)sup * superCap + base + __popcll(bal & ((1ull << lane) - 1ull));
+            superList[o] = s;
+            if (superN) { superN[o] = n; superX[o] = r0; }    // inline copies: the sub-cube cull streams them, no gather
+        }
         __syncthreads();
         if (threadIdx.x == 0) sBase += total;
         __syncthreads();
@@ -990,8 +1000,8 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
         accW = 0.f; accR = 0.f; accI = 0.f;
         nseg = 0;
         int qn = 0;   // wave-uniform queue length
-        // the tile only looks at the projections that reach its 32^3 super-tile (k_rf_supercull), in launch order
-        const int sup = superList ? ((tz >> 2) * superDim + (ty >> 2)) * superDim + (tx >> 2) : 0;
+        // the tile only looks at the projections that reach its super-tile (k_rf_supercull), in launch order
+        const int sup = superList ? ((tz >> XH_SUPERSHIFT) * superDim + (ty >> XH_SUPERSHIFT)) * superDim + (tx >> XH_SUPERSHIFT) : 0;
         const int nlist = superList ? superCount[sup] : nspaces;
         const int *lst = superList ? superList + (size_t)sup * superCap : nullptr;
         for (int s0 = 0; s0 < nlist; s0 += XH_CHUNK) {
@@ -1143,7 +1153,8 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                   const XhRec *__restrict__ recs, int nspaces, const void *__restrict__ pk, const float *__restrict__ blobTable,
                   float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
                   const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter, int dbg,
-                  const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap)
+                  const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
+                  const float4 *__restrict__ superN, const float4 *__restrict__ superX)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     __shared__ int sSegStart[8][XH_SEGCAP + 1];
@@ -1301,27 +1312,39 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     };
 
 
-    // work distribution: units = sub-cubes, eight per tile; a wave drains its block's XCD class first, then steals
-    constexpr int UG = 4;                          // units per grab
-    int cls = blockIdx.x & 7, tried = 0;
+    // work distribution: units = sub-cubes, eight per tile. Every XCD class of the tile list is dealt into NSUB
+    // interleaved streams (tile t of the class belongs to stream t % NSUB), each with its own counter, and a wave takes
+    // ONE unit per grab. Both matter (4096-projection launch, ms): one counter per class and 1 / 2 / 4 / 8 / 16 units
+    // per grab: 75.5 / 50.3 / 46.7 / 53.7 / 71 -- same-address atomics serialise in the L2, and the larger the grab the
+    // wider the band of tiles the chip works on at any moment, while the projections' patches are shared through the
+    // L2. With 8 streams per class (64 waves per counter): 38.4 / 42.7 / 46.4 at 1 / 2 / 4 units per grab (4 or 16
+    // streams: 39.4 / 39.1). A wave drains its block's stream first, then steals from the following ones.
+    constexpr int UG = 1, NSUB = 8;
+    int stream = (blockIdx.x & 7) * NSUB + ((blockIdx.x >> 3) & (NSUB - 1)), tried = 0;
     int pend = 0;
-    if (lane == 0) pend = atomicAdd(&counter[cls], UG);
+    auto streamUnits = [&](int st) {
+        const int c = st / NSUB, j = st % NSUB, nt = classOff[c + 1] - classOff[c];
+        return nt > j ? 8 * ((nt - j + NSUB - 1) / NSUB) : 0;
+    };
+    if (lane == 0) pend = atomicAdd(&counter[stream], UG);
     for (;;) {
-        int lo = 0, hi = 0;
+        int lo = 0, hi = 0, cur = stream;
         if (lane == 0) {
-            while (tried < 8) {
-                const int n = 8 * (classOff[cls + 1] - classOff[cls]);
-                if (pend < n) { lo = 8 * classOff[cls] + pend; hi = 8 * classOff[cls] + min(pend + UG, n); break; }
-                cls = (cls + 1) & 7;
-                if (++tried < 8) pend = atomicAdd(&counter[cls], UG);
+            while (tried < 8 * NSUB) {
+                const int n = streamUnits(stream);
+                if (pend < n) { lo = pend; hi = min(pend + UG, n); cur = stream; break; }
+                stream = (stream + 1) % (8 * NSUB);
+                if (++tried < 8 * NSUB) pend = atomicAdd(&counter[stream], UG);
             }
-            if (tried < 8) pend = atomicAdd(&counter[cls], UG);    // in flight while this grab is processed
+            if (tried < 8 * NSUB) pend = atomicAdd(&counter[stream], UG);    // in flight while this grab is processed
         }
         lo = __builtin_amdgcn_readfirstlane(lo);
         hi = __builtin_amdgcn_readfirstlane(hi);
+        cur = __builtin_amdgcn_readfirstlane(cur);
         if (lo >= hi) break;
+        const int tileBase = classOff[cur / NSUB] + cur % NSUB;
         for (int u = lo; u < hi; ++u) {
-            const unsigned packed = tileList[u >> 3];
+            const unsigned packed = tileList[tileBase + (u >> 3) * NSUB];
             const int sub = u & 7;
             const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
             const int x0 = tx * XH_TSZ + (sub & 1) * 4, y0 = ty * XH_TSZ + ((sub >> 1) & 1) * 4, z0 = tz * XH_TSZ + (sub >> 2) * 4;
@@ -1334,19 +1357,25 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
             accW = 0.f; accR = 0.f; accI = 0.f;
             nseg = 0;
             int qn = 0;   // wave-uniform queue length
-            const int sup = superList ? ((tz >> 2) * superDim + (ty >> 2)) * superDim + (tx >> 2) : 0;
-            const int nlist = superList ? superCount[sup] : nspaces;
+            const int sup = superList ? ((tz >> XH_SUPERSHIFT) * superDim + (ty >> XH_SUPERSHIFT)) * superDim + (tx >> XH_SUPERSHIFT) : 0;
+            const int nlist = dbg == 5 ? 0 : (superList ? superCount[sup] : nspaces);
             const int *lst = superList ? superList + (size_t)sup * superCap : nullptr;
+            const float4 *lstN = superList ? superN + (size_t)sup * superCap : cullN;
+            const float4 *lstX = superList ? superX + (size_t)sup * superCap : cullX;
+            // the list entries of the next 64 projections are requested before the current ones are worked on
+            int sNext = 0;
+            float4 nNext = make_float4(0.f, 0.f, 0.f, 0.f), xNext = nNext;
+            if (lane < nlist) { sNext = lst ? lst[lane] : lane; nNext = lstN[lane]; xNext = lstX[lane]; }
             for (int hb = 0; hb < nlist; hb += 64) {
                 // cull against the sub-cube: lane <-> projection of the list
                 bool keep = false;
-                int sIdx = 0;
+                const int sIdx = sNext;
+                const float4 n = nNext, xv = xNext;
+                if (hb + 64 + lane < nlist) { sNext = lst ? lst[hb + 64 + lane] : hb + 64 + lane; nNext = lstN[hb + 64 + lane]; xNext = lstX[hb + 64 + lane]; }
                 if (hb + lane < nlist) {
-                    sIdx = lst ? lst[hb + lane] : hb + lane;
-                    const float4 n = cullN[sIdx], r0 = cullX[sIdx];
                     const float dn = n.x * c4x + n.y * c4y + n.z * c4z;
-                    const float dx = r0.x * c4x + r0.y * c4y + r0.z * c4z;
-                    const float hn = fminf(rho4, 1.5f * n.w + 0.02f), hx = fminf(rho4, 1.5f * r0.w + 0.02f);
+                    const float dx = xv.x * c4x + xv.y * c4y + xv.z * c4z;
+                    const float hn = fminf(rho4, 1.5f * n.w + 0.02f), hx = fminf(rho4, 1.5f * xv.w + 0.02f);
                     keep = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
                 }
                 unsigned long long todo = __ballot(keep);
@@ -1961,7 +1990,8 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
         r = xh_buf_alloc(ctx, rf->d_tiles, sizeof(unsigned) * packed.size());
         if (r == XH_OK) r = (hipMemcpy(rf->d_tiles.p, packed.data(), rf->d_tiles.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
         // d_tileCounter: ints [0,8) work counters, [16,25) class offsets
-        if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 64);
+        // (+ [128,384): the stream counters of the wave-independent kernel)
+        if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 512);
         if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 16, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     }
     if (r != XH_OK) { xh_rf_destroy(rf); return r; }
@@ -1980,7 +2010,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
-    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_recs);
+    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -2285,22 +2315,33 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                                    rf->d_pack.p, n, rf->sizeX, rf->sizeY);
             XH_LAUNCH_CHECK();
         }
-        const int maxsp = std::max(64, rf->tile_max_spaces);
+        // the super-tile lists are sized for the worst case (every projection of the launch in every list): bound the
+        // launch so that they stay within 8 GB
+        const int sdim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + (1 << XH_SUPERSHIFT) - 1) >> XH_SUPERSHIFT;
+        const size_t listBytesPerSpace = (size_t)sdim * sdim * sdim * 36;
+        const int maxByLists = (int)std::max<size_t>(256, ((size_t)8 << 30) / listBytesPerSpace);
+        const int maxsp = std::min(std::max(64, rf->tile_max_spaces), rf->use_supercull ? maxByLists : (1 << 30));
         for (int s0 = 0; s0 < ns; s0 += maxsp) {
             const int m = std::min(maxsp, ns - s0);
             XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));
+            XH_HIP(hipMemsetAsync((int *)rf->d_tileCounter.p + 128, 0, sizeof(int) * 256, ctx->stream));
             if (rf->evUsed >= 256) drain_events(rf);
             hipEvent_t ev0 = next_event(rf), ev1 = next_event(rf);
             // super-tile lists of this launch
-            const int superDim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + 3) / 4;
+            const int superDim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + (1 << XH_SUPERSHIFT) - 1) >> XH_SUPERSHIFT;
             const int nsuper = superDim * superDim * superDim;
             const int *superList = nullptr, *superCount = nullptr;
+            float4 *superN = nullptr, *superX = nullptr;
             if (rf->use_supercull && m >= 32) {
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superList, sizeof(int) * (size_t)nsuper * m));
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superCount, sizeof(int) * (size_t)nsuper));
+                const bool inlineVecs = rf->tile_variant == 2;
+                if (inlineVecs) XH_TRY(xh_buf_reserve(ctx, rf->d_superVec, 2 * sizeof(float4) * (size_t)nsuper * m));
+                superN = inlineVecs ? (float4 *)rf->d_superVec.p : nullptr;
+                superX = inlineVecs ? superN + (size_t)nsuper * m : nullptr;
                 hipLaunchKernelGGL(k_rf_supercull, dim3(nsuper), dim3(256), 0, ctx->stream, (const float4 *)rf->d_cull.p + s0,
                                    (const float4 *)rf->d_cull.p + ns + s0, m, rf->mv, (float)rf->p.blob_radius, superDim, m,
-                                   (int *)rf->d_superList.p, (int *)rf->d_superCount.p);
+                                   (int *)rf->d_superList.p, (int *)rf->d_superCount.p, superN, superX);
                 XH_LAUNCH_CHECK();
                 superList = (const int *)rf->d_superList.p;
                 superCount = (const int *)rf->d_superCount.p;
@@ -2332,7 +2373,8 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                        (const float4 *)rf->d_cull.p + ns + s0, (const XhRec *)rf->d_recs.p + s0, m,                   \
                        (const void *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, \
                        rf->p.blob_radius, (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16,      \
-                       (int *)rf->d_tileCounter.p, rf->tile_dbg, superList, superCount, superDim, m)
+                       (int *)rf->d_tileCounter.p + 128, rf->tile_dbg, superList, superCount, superDim, m,            \
+                       (const float4 *)superN, (const float4 *)superX)
                 if (hasCtf && smallBlob) XH_CUBES(true, true);
                 else if (hasCtf) XH_CUBES(true, false);
                 else if (smallBlob) XH_CUBES(false, true);
