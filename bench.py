@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--mode", default="full", choices=["full", "match", "grid"])
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
+    ap.add_argument("--tr-chunk-mb", type=int, default=0, help="S6 scratch per pass in MB (0: library default)")
     ap.add_argument("--chunk-rows", type=float, default=0, help="correlation rows per chunk of the matcher (0: library default)")
     ap.add_argument("--k0", type=int, default=-1, help="two-level contraction cut (0 auto, >= nk off); default: automatic")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
@@ -146,6 +147,8 @@ def main():
     pm = xa.ProjectionMatcher(ctx, refs) if args.mode != "grid" else None
     if pm is not None and args.no_prune:
         pm.set_option("prune", 0)
+    if pm is not None and args.tr_chunk_mb > 0:
+        pm.set_option("tr_chunk_mb", args.tr_chunk_mb)
     if pm is not None and args.chunk_rows > 0:
         pm.set_option("chunk_rows", args.chunk_rows)
     if pm is not None and args.k0 >= 0:

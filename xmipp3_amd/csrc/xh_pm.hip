@@ -118,6 +118,7 @@ struct xh_pm {
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
+    int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
     int64_t stat_pruned;
@@ -2036,6 +2037,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
     pm->use_prune = 1;
+    pm->tr_chunk_mb = 0;
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
     pm->use_fir = 1;
@@ -2321,6 +2323,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
+    else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
     else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
         XH_HIP(hipSetDevice(pm->ctx->device));
         XH_HIP(hipStreamSynchronize(pm->ctx->stream));
@@ -2707,7 +2710,9 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
     XH_CHECK(D <= 2048, XH_ERR_UNSUPPORTED, "xh_pm_translate: image size %d exceeds 2048", D);
     if (max_shift < 0) max_shift = D / 2;    // APM:262-263
     const size_t per = (size_t)D * D;
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, (size_t)(1024u << 20) / (per * sizeof(xh_cd))));
+    // particles per pass: z, w (c128) and R (f64) of a pass are written by one kernel and read by the next
+    const size_t trBytes = pm->tr_chunk_mb > 0 ? (size_t)pm->tr_chunk_mb << 20 : (size_t)4096u << 20;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, trBytes / (per * sizeof(xh_cd))));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t1, sizeof(xh_cd) * per * chunk));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t2, sizeof(xh_cd) * per * chunk));
     if (D == 64 || D == 128 || D == 256) {
