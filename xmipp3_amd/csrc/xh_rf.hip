@@ -464,16 +464,10 @@ __device__ double d_bessj0(double x)
     double a2 = -0.1562499995e-1 + y * (0.1430488765e-3 + y * (-0.6911147651e-5 + y * (0.7621095161e-6 - y * 0.934935152e-7)));
     return sqrt(0.636619772 / ax) * (cos(xx) * a1 - z * sin(xx) * a2);
 }
-__global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ctf, float *__restrict__ mod,
-                         int n, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+// one pixel of preloadCTF (RFA:548-592 / RFG:552-593): CTF factor and modulator
+__device__ __forceinline__ void d_ctf_pixel(const XhCtfDev &c, int x, int y, int P, double iTs, double minCTF, int phaseFlipped,
+                                            float &ctfOut, float &modOut)
 {
-    const size_t per = (size_t)sizeX * sizeY;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= per * n) return;
-    const int img = idx / per;
-    const int rem = idx - (size_t)img * per;
-    const int y = rem / sizeX, x = rem - y * sizeX;
-    const XhCtfDev c = cp[img];
     const float freqY = (y - (P / 2.f)) / (float)P;
     float freqX = (float)((double)(x <= P / 2 ? x : x - P) / (double)P);
     const double X = freqX * iTs, Y = freqY * iTs;
@@ -512,8 +506,39 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
         CTFVal = (CTFVal >= 0) ? 1.f : -1.f;
     } else CTFVal = (float)(1.0 / (double)CTFVal);
     if (phaseFlipped) CTFVal = fabsf(CTFVal);
-    ctf[idx] = CTFVal;
-    mod[idx] = modulatorVal;
+    ctfOut = CTFVal;
+    modOut = modulatorVal;
+}
+// thread per pixel of the rows at or above the DC row; its mirror row (-freqY) is written by the same thread: a
+// non-astigmatic CTF depends on (X, Y) through X*X + Y*Y only, so the value is the same bit for bit and is computed once
+__global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ctf, float *__restrict__ mod,
+                         int n, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+{
+    const int dc = P / 2;                                   // row of freqY = 0
+    const int up = max(sizeY - dc, dc + 1);                 // rows dc .. dc+up-1 cover every pair (dc+k, dc-k)
+    const size_t perHalf = (size_t)sizeX * up;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= perHalf * n) return;
+    const int img = idx / perHalf;
+    const int rem = idx - (size_t)img * perHalf;
+    const int k = rem / sizeX, x = rem - k * sizeX;
+    const XhCtfDev c = cp[img];
+    const size_t base = (size_t)img * sizeX * sizeY;
+    const int y1 = dc + k, y2 = dc - k;
+    float cv = 0.f, mv_ = 0.f;
+    bool have = false;
+    if (y1 < sizeY) {
+        d_ctf_pixel(c, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        ctf[base + (size_t)y1 * sizeX + x] = cv;
+        mod[base + (size_t)y1 * sizeX + x] = mv_;
+        have = true;
+    }
+    if (k > 0 && y2 >= 0 && y2 < sizeY) {
+        // rows dc+k and dc-k have opposite freqY only for even P (freqY = (y - P/2)/P)
+        if (!(have && c.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_pixel(c, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        ctf[base + (size_t)y2 * sizeX + x] = cv;
+        mod[base + (size_t)y2 * sizeX + x] = mv_;
+    }
 }
 
 // ---- gridding (RFA:627-700 processVoxelBlob, :595-625 processVoxel, :710-763 traversal) --
@@ -2233,7 +2258,8 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
     XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
     XH_HIP(hipMemcpyAsync(rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(hipStreamSynchronize(ctx->stream));  // hc is a stack-lifetime buffer
-    const size_t total = (size_t)n * rf->sizeX * rf->sizeY;
+    const int dcRow = rf->P / 2;
+    const size_t total = (size_t)n * rf->sizeX * std::max(rf->sizeY - dcRow, dcRow + 1);
     hipLaunchKernelGGL(k_rf_ctf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const XhCtfDev *)rf->d_ctfp.p, d_ctf, d_mod, n, rf->sizeX, rf->sizeY, rf->P,
                        1.0 / rf->p.sampling, rf->p.min_ctf, rf->p.phase_flipped);
