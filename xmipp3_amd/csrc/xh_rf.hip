@@ -222,7 +222,7 @@ struct xh_rf {
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs;
+    XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs, d_dense, d_wimg;
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -1172,6 +1172,16 @@ k_rf_insert_tiles(const XhSpace *__restrict__ spaces, const float4 *__restrict__
 // the list ended in a barrier at which seven waves waited for the slowest sub-cube. Work units (sub-cubes, eight per
 // tile of the tile list, same XCD classes) are handed out per wave, the next grab in flight while a unit is processed.
 struct XhRec { float4 r0, r1, r2; };     // XhHitRec layout, one per traverse space, in global memory
+// what the dense pass needs of a traverse space, compact (three loads per item instead of ten dwords scattered over
+// the 100-byte XhSpace): (u.y, u.z, v.y, v.z), (p0.y, p0.z, p4.y, p4.z) and (weight, image index)
+struct XhDense { float4 a, b; };
+// hit part of getX (RFA:479-490; the x it would return is not needed): same operations in the same order as d_getX
+__device__ __forceinline__ bool d_hit(float y, float z, float a1, float a2, float b1, float b2, float y0, float z0)
+{
+    const float u = ((z - z0) * a1 + (y0 - y) * a2) / (a1 * b2 - b1 * a2);
+    const float t = (-y0 + y - u * b1) / (a1);
+    return (t > 0.f) && (t < 1.f) && (u > 0.f) && (u < 1.f);
+}
 template <bool HAS_CTF, bool SMALLBLOB>
 __global__ void __launch_bounds__(512, 4)
 k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN, const float4 *__restrict__ cullX,
@@ -1179,7 +1189,8 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                   float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
                   const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter, int dbg,
                   const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
-                  const float4 *__restrict__ superN, const float4 *__restrict__ superX)
+                  const float4 *__restrict__ superN, const float4 *__restrict__ superX,
+                  const XhDense *__restrict__ dense, const float2 *__restrict__ wimg)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     __shared__ int sSegStart[8][XH_SEGCAP + 1];
@@ -1206,12 +1217,12 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
             const int meta = qMeta[wv][lane];
             const int vl = meta & 63, si = meta >> 6;
             const float ix = qIx[wv][lane], iy = qIy[wv][lane], zSqr = qZs[wv][lane];
-            const XhSpace &S = spaces[si];
+            const XhDense dn = dense[si];
+            const float2 wi = wimg[si];
             const int y = ty0 + ((vl >> 2) & 3), z = tz0 + (vl >> 4);
             // the reference only visits rows that cross the top or bottom face of the slab (RFA:746-750)
-            float xa, xb;
-            const bool hit1 = d_getX(xa, (float)y, (float)z, S.u, S.v, S.p0);
-            const bool hit2 = d_getX(xb, (float)y, (float)z, S.u, S.v, S.p4);
+            const bool hit1 = d_hit((float)y, (float)z, dn.a.x, dn.a.y, dn.a.z, dn.a.w, dn.b.x, dn.b.y);
+            const bool hit2 = d_hit((float)y, (float)z, dn.a.x, dn.a.y, dn.a.z, dn.a.w, dn.b.z, dn.b.w);
             if ((hit1 || hit2) && dbg != 3) {
                 int minX = (int)ceil((double)ix - blobRadius);
                 int maxX = (int)floor((double)ix + blobRadius);
@@ -1222,8 +1233,8 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                 maxX = min(maxX, sizeX - 1);
                 maxY = min(maxY, sizeY - 1);
                 const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
-                const size_t imgOff = (size_t)S.img * SX * SY;
-                const float dataWeight = S.weight;
+                const size_t imgOff = (size_t)__float_as_int(wi.y) * SX * SY;
+                const float dataWeight = wi.x;
                 if (SMALLBLOB) {
                     // blob radius < 2: at most 4x4 candidate pixels, fetched as four contiguous row
                     // segments of the padded record (all loads issued before any arithmetic). Pixels
@@ -2043,7 +2054,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
-    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs);
+    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs); xh_buf_free(rf->d_dense); xh_buf_free(rf->d_wimg);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -2336,6 +2347,21 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         }
         XH_TRY(xh_buf_reserve(ctx, rf->d_recs, sizeof(XhRec) * (size_t)ns));
         XH_HIP(hipMemcpyAsync(rf->d_recs.p, recs.data(), sizeof(XhRec) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<XhDense> dense(ns);
+        std::vector<float2> wimg(ns);
+        for (int i = 0; i < ns; ++i) {
+            const XhSpace &S = spaces[i];
+            dense[i].a = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
+            dense[i].b = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
+            int im = S.img;
+            float fi;
+            memcpy(&fi, &im, 4);
+            wimg[i] = make_float2(S.weight, fi);
+        }
+        XH_TRY(xh_buf_reserve(ctx, rf->d_dense, sizeof(XhDense) * (size_t)ns));
+        XH_TRY(xh_buf_reserve(ctx, rf->d_wimg, sizeof(float2) * (size_t)ns));
+        XH_HIP(hipMemcpyAsync(rf->d_dense.p, dense.data(), sizeof(XhDense) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(hipMemcpyAsync(rf->d_wimg.p, wimg.data(), sizeof(float2) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         XH_HIP(hipStreamSynchronize(ctx->stream));
         {
             // packed + padded projection records (re, im[, ctf, mod]) for contiguous 4-pixel row fetches
@@ -2408,7 +2434,8 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                        (const void *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, \
                        rf->p.blob_radius, (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16,      \
                        (int *)rf->d_tileCounter.p + 128, rf->tile_dbg, superList, superCount, superDim, m,            \
-                       (const float4 *)superN, (const float4 *)superX)
+                       (const float4 *)superN, (const float4 *)superX, (const XhDense *)rf->d_dense.p + s0,            \
+                       (const float2 *)rf->d_wimg.p + s0)
                 if (hasCtf && smallBlob) XH_CUBES(true, true);
                 else if (hasCtf) XH_CUBES(true, false);
                 else if (smallBlob) XH_CUBES(false, true);
