@@ -1179,8 +1179,19 @@ struct XhDense { float4 a, b; };
 __device__ __forceinline__ bool d_hit(float y, float z, float a1, float a2, float b1, float b2, float y0, float z0)
 {
     const float u = ((z - z0) * a1 + (y0 - y) * a2) / (a1 * b2 - b1 * a2);
-    const float t = (-y0 + y - u * b1) / (a1);
-    return (t > 0.f) && (t < 1.f) && (u > 0.f) && (u < 1.f);
+    // t = tn / a1 is only compared with 0 and 1. For IEEE division, round to nearest: fl(tn/a1) > 0 <=> tn and a1 have the
+    // same sign (unless the quotient underflows: left to the division), and fl(tn/a1) < 1 <=> |tn| < |a1| for a positive
+    // quotient (two floats with |tn| < |a1| have a quotient <= 1 - 2^-24, which never rounds up to 1; with |tn| > |a1| it
+    // is >= 1 + 2^-23 (1 - 2^-24)^-1 ... > 1 + 2^-24 and never rounds down to 1). NaN / zero operands: both forms say no.
+    const float tn = -y0 + y - u * b1;
+    bool tOk;
+    if (fabsf(tn) > 1e-30f && fabsf(a1) < 1e6f)      // the quotient cannot underflow: at least 1e-36
+        tOk = ((tn > 0.f) == (a1 > 0.f)) && (fabsf(tn) < fabsf(a1));
+    else {
+        const float t = tn / a1;
+        tOk = (t > 0.f) && (t < 1.f);
+    }
+    return tOk && (u > 0.f) && (u < 1.f);
 }
 template <bool HAS_CTF, bool SMALLBLOB>
 __global__ void __launch_bounds__(512, 4)
