@@ -12,7 +12,9 @@
 #include "minicore.h"
 #include "../../include/xmipp_hip.h"
 #include "sampling_gen.h"
+#include <chrono>
 #include <exception>
+#include <future>
 #include <thread>
 
 namespace mc {
@@ -57,6 +59,32 @@ template <class F> inline void runOnSlots(size_t n, F f)
     for (auto &t : th) t.join();
     for (size_t g = 0; g < n; ++g) if (err[g]) std::rethrow_exception(err[g]);
 }
+
+// The images of one device batch, read by a few threads (each with its own stream on the stack files) while the device
+// works on the previous batch: the loader of the reference (loadImageThread, RFA:300-388) with more than one reader.
+struct ImageBatchLoader {
+    size_t dim = 0;
+    int readers = 4;
+    std::future<std::vector<float>> pending;
+    static std::vector<float> load(std::vector<std::string> names, size_t dim, int readers)
+    {
+        const size_t n = names.size(), per = dim * dim;
+        std::vector<float> out(n * per);
+        const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)readers, (n + 255) / 256));
+        runOnSlots(T, [&](size_t t) {
+            std::vector<float> one;
+            ImageInfo ii;
+            for (size_t k = (t * n) / T; k < ((t + 1) * n) / T; ++k) {
+                readImage(names[k], one, ii);
+                if (ii.x != dim || ii.y != dim || ii.z != 1) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + names[k] + " has a different size");
+                std::copy(one.begin(), one.end(), out.begin() + k * per);
+            }
+        });
+        return out;
+    }
+    void request(std::vector<std::string> names) { pending = std::async(std::launch::async, load, std::move(names), dim, readers); }
+    std::vector<float> take() { return pending.get(); }     // re-throws what a reader threw
+};
 
 struct DeviceBuffer {
     xh_ctx *ctx = nullptr; void *p = nullptr; size_t bytes = 0;
@@ -391,21 +419,28 @@ public:
         xh_rf *&shifter = slot.shifter;
         const size_t per = dim * dim;
         DeviceBuffer d_part, d_shifted, d_i32a, d_i32b, d_u8, d_f64;
-        std::vector<float> h_part, one;
+        std::vector<float> h_part;
+        ImageBatchLoader loader;
+        loader.dim = dim;
+        auto namesOf = [&](size_t b0) {
+            std::vector<std::string> names;
+            for (size_t k = b0; k < std::min(b0 + (size_t)batch, imagesToProcess.size()); ++k) {
+                std::string fn;
+                DFexp.getValue("image", fn, imagesToProcess[k]);
+                names.push_back(fn);
+            }
+            return names;
+        };
+        if (!imagesToProcess.empty()) loader.request(namesOf(0));
         for (size_t b0 = 0; b0 < imagesToProcess.size(); b0 += (size_t)batch) {
             const size_t n = std::min((size_t)batch, imagesToProcess.size() - b0);
-            h_part.resize(n * per);
+            h_part = loader.take();
+            if (b0 + (size_t)batch < imagesToProcess.size()) loader.request(namesOf(b0 + (size_t)batch));   // read ahead
             std::vector<float> prevShift(2 * n, 0.f);
             std::vector<int32_t> off(n + 1, 0), idsv;
             bool anyShift = false;
             for (size_t k = 0; k < n; ++k) {
                 const size_t id = imagesToProcess[b0 + k];
-                std::string fn;
-                DFexp.getValue("image", fn, id);
-                ImageInfo ii;
-                readImage(fn, one, ii);
-                if (ii.x != dim || ii.y != dim) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + fn + " has a different size");
-                std::copy(one.begin(), one.end(), h_part.begin() + k * per);
                 prevShift[2 * k] = (float)DFexp.getDouble("shiftX", id, 0.);
                 prevShift[2 * k + 1] = (float)DFexp.getDouble("shiftY", id, 0.);
                 anyShift = anyShift || prevShift[2 * k] != 0.f || prevShift[2 * k + 1] != 0.f;
@@ -497,10 +532,20 @@ public:
 
     void run() override
     {
+        // XMIPP_HIP_TIMING=1: wall-clock seconds of the three phases on stderr
+        const bool timing = getenv("XMIPP_HIP_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         produceSideInfo();
+        const auto t1 = std::chrono::steady_clock::now();
         show();
         processAllImages();
+        const auto t2 = std::chrono::steady_clock::now();
         writeOutputFiles();
+        const auto t3 = std::chrono::steady_clock::now();
+        if (timing) {
+            auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+            std::cerr << "timing: side info " << sec(t0, t1) << " s, images " << sec(t1, t2) << " s, output " << sec(t2, t3) << " s" << std::endl;
+        }
         if (verbose) std::cout << "done!" << std::endl;
     }
 };
@@ -678,10 +723,23 @@ public:
         xhCheck(xh_rf_sizes(rf, &P, &mv, &sx, &sy));
         const bool hasCTF = useCTF && (SF.containsLabel("ctfModel") || SF.containsLabel("ctfDefocusU"));
         DeviceBuffer d_img, d_shift, d_fft, d_ctf, d_mod;
-        std::vector<float> h_img, one;
+        std::vector<float> h_img;
+        ImageBatchLoader loader;
+        loader.dim = imgSize;
+        auto namesOf = [&](size_t b0) {
+            std::vector<std::string> names;
+            for (size_t id = b0; id <= std::min(b0 + (size_t)batch - 1, last); ++id) {
+                std::string fn;
+                SF.getValue("image", fn, id);
+                names.push_back(fn);
+            }
+            return names;
+        };
+        loader.request(namesOf(first));
         for (size_t b0 = first; b0 <= last; b0 += (size_t)batch) {
             const size_t n = std::min((size_t)batch, last + 1 - b0);
-            h_img.resize(n * per);
+            h_img = loader.take();
+            if (b0 + (size_t)batch <= last) loader.request(namesOf(b0 + (size_t)batch));   // read ahead
             std::vector<double> ang(3 * n);
             std::vector<float> w(n, 1.f), sh(2 * n, 0.f);
             std::vector<uint8_t> fl(n, 0);
@@ -689,12 +747,6 @@ public:
             bool anyGeo = false;
             for (size_t k = 0; k < n; ++k) {
                 const size_t id = b0 + k;
-                std::string fn;
-                SF.getValue("image", fn, id);
-                ImageInfo ii;
-                readImage(fn, one, ii);
-                if (ii.x != imgSize || ii.y != imgSize) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + fn + " has a different size");
-                std::copy(one.begin(), one.end(), h_img.begin() + k * per);
                 ang[3 * k] = SF.getDouble("angleRot", id, 0); ang[3 * k + 1] = SF.getDouble("angleTilt", id, 0); ang[3 * k + 2] = SF.getDouble("anglePsi", id, 0);
                 sh[2 * k] = (float)SF.getDouble("shiftX", id, 0); sh[2 * k + 1] = (float)SF.getDouble("shiftY", id, 0);
                 fl[k] = SF.getDouble("flip", id, 0) != 0 ? 1 : 0;
