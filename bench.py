@@ -317,7 +317,7 @@ def main():
                 orf.insert(orf.prepare_image(img), synth.euler_matrix(*oang[i]).T, ctf=c, modulator=m)
         tb2 = time.perf_counter()
         out["cpu_baseline"] = {
-            "value": ns / (tb2 - tb1), "unit": "particles/s", "cores": o.lib().xo_num_threads(), "kind": "port",
+            "value": ns / (tb2 - tb1), "unit": "particles/s", "cores": min(o.lib().xo_num_threads(), ns), "kind": "port",
             "sample": f"{ns} of the same {D}x{D} particles vs the same {nrefs} references: oracle match+translate "
                       f"(OpenMP over particles) then shift+CTF+FFT+gridding (1 thread, like RFA's single compute thread); "
                       f"library setup {tb_setup:.1f}s excluded on both sides; finaliser excluded"}
