@@ -1366,32 +1366,58 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
     // wider the band of tiles the chip works on at any moment, while the projections' patches are shared through the
     // L2. With 8 streams per class (64 waves per counter): 38.4 / 42.7 / 46.4 at 1 / 2 / 4 units per grab (4 or 16
     // streams: 39.4 / 39.1). A wave drains its block's stream first, then steals from the following ones.
-    constexpr int UG = 1, NSUB = 8;
-    int stream = (blockIdx.x & 7) * NSUB + ((blockIdx.x >> 3) & (NSUB - 1)), tried = 0;
-    int pend = 0;
-    auto streamUnits = [&](int st) {
+    constexpr int NSUB = 8, RS = 8;
+    // Within a workgroup the eight waves share a ring of tiles: one global grab per tile (not per sub-cube), and the
+    // eight sub-cubes of a tile are worked on by the eight waves at the same time -- the tightest band the L2 can get --
+    // without any barrier: a wave draws a ticket (LDS atomic) = (tile sequence, sub-cube); whoever draws sub-cube 0 of
+    // sequence q first fetches the tile of sequence q + 2 into its ring slot; a wave that is early moves on to the next
+    // tile's sub-cubes. Slot q % RS is rewritten for q + RS only after 48 more tickets have been drawn.
+    __shared__ int sTile[RS], sReady[RS];
+    __shared__ int sTicket, sHop;
+    const int home = (blockIdx.x & 7) * NSUB + ((blockIdx.x >> 3) & (NSUB - 1));
+    auto streamTiles = [&](int st) {
         const int c = st / NSUB, j = st % NSUB, nt = classOff[c + 1] - classOff[c];
-        return nt > j ? 8 * ((nt - j + NSUB - 1) / NSUB) : 0;
+        return nt > j ? (nt - j + NSUB - 1) / NSUB : 0;
     };
-    if (lane == 0) pend = atomicAdd(&counter[stream], UG);
-    for (;;) {
-        int lo = 0, hi = 0, cur = stream;
-        if (lane == 0) {
-            while (tried < 8 * NSUB) {
-                const int n = streamUnits(stream);
-                if (pend < n) { lo = pend; hi = min(pend + UG, n); cur = stream; break; }
-                stream = (stream + 1) % (8 * NSUB);
-                if (++tried < 8 * NSUB) pend = atomicAdd(&counter[stream], UG);
-            }
-            if (tried < 8 * NSUB) pend = atomicAdd(&counter[stream], UG);    // in flight while this grab is processed
+    auto produce = [&](int q) {          // one lane: the tile of block sequence q, -1 when every stream is drained
+        // sequences are produced in order (wait for q - 1): after the first -1 every later sequence is -1 too, so a wave
+        // may leave at the first -1 it meets without stranding a tile that a concurrent producer still found
+        while (q > 0 && atomicAdd(&sReady[(q - 1) % RS], 0) != q) __builtin_amdgcn_s_sleep(1);
+        int tile = -1;
+        for (;;) {
+            const int hop = atomicAdd(&sHop, 0);
+            if (hop >= 8 * NSUB) break;
+            const int st = (home + hop) % (8 * NSUB);
+            const int k = atomicAdd(&counter[st], 1);
+            if (k < streamTiles(st)) { tile = (int)tileList[classOff[st / NSUB] + st % NSUB + k * NSUB]; break; }
+            atomicMax(&sHop, hop + 1);
         }
-        lo = __builtin_amdgcn_readfirstlane(lo);
-        hi = __builtin_amdgcn_readfirstlane(hi);
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        if (lo >= hi) break;
-        const int tileBase = classOff[cur / NSUB] + cur % NSUB;
-        for (int u = lo; u < hi; ++u) {
-            const unsigned packed = tileList[tileBase + (u >> 3) * NSUB];
+        sTile[q % RS] = tile;
+        __threadfence_block();
+        atomicExch(&sReady[q % RS], q + 1);
+    };
+    if (tid == 0) {
+        sTicket = 0; sHop = 0;
+        for (int i = 0; i < RS; ++i) sReady[i] = 0;
+        produce(0);
+        produce(1);
+    }
+    __syncthreads();
+    for (;;) {
+        int t = 0, tileP = 0;
+        if (lane == 0) {
+            t = atomicAdd(&sTicket, 1);
+            const int q = t >> 3;
+            if ((t & 7) == 0) produce(q + 2);
+            while (atomicAdd(&sReady[q % RS], 0) != q + 1) __builtin_amdgcn_s_sleep(1);
+            tileP = atomicAdd(&sTile[q % RS], 0);
+        }
+        t = __builtin_amdgcn_readfirstlane(t);
+        tileP = __builtin_amdgcn_readfirstlane(tileP);
+        if (tileP < 0) break;
+        {
+            const unsigned packed = (unsigned)tileP;
+            const int u = t;
             const int sub = u & 7;
             const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
             const int x0 = tx * XH_TSZ + (sub & 1) * 4, y0 = ty * XH_TSZ + ((sub >> 1) & 1) * 4, z0 = tz * XH_TSZ + (sub >> 2) * 4;
