@@ -1201,7 +1201,7 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                   const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter, int dbg,
                   const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
                   const float4 *__restrict__ superN, const float4 *__restrict__ superX,
-                  const XhDense *__restrict__ dense, const float2 *__restrict__ wimg)
+                  const XhDense *__restrict__ dense, const float2 *__restrict__ wimg, float4 reach)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
     __shared__ int sSegStart[8][XH_SEGCAP + 1];
@@ -1476,9 +1476,11 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                         iy += mv / 2;
                         zSqr = iz * iz;
                         pass = !(zSqr > radiusSqr);
-                        // a voxel with no pixel within reach adds nothing: drop it before the costly part
-                        pass = pass && ((double)ix + blobRadius >= 0.0) && ((double)ix - blobRadius <= (double)(sizeX - 1)) &&
-                               ((double)iy + blobRadius >= 0.0) && ((double)iy - blobRadius <= (double)(sizeY - 1));
+                        // a voxel with no pixel within reach adds nothing: drop it before the costly part. The four tests
+                        //   (double)ix + r >= 0, (double)ix - r <= sizeX - 1, (double)iy + r >= 0, (double)iy - r <= sizeY - 1
+                        // are monotone in the float ix / iy: the host found, with the same double expressions, the smallest
+                        // and largest floats that pass (reach.x..w), so four float compares decide the same thing
+                        pass = pass && (ix >= reach.x) && (ix <= reach.y) && (iy >= reach.z) && (iy <= reach.w);
                     }
                     const unsigned long long pb = __ballot(pass);
                     const int np = __popcll(pb);
@@ -2464,6 +2466,26 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                                        (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
             }
             else if (rf->tile_variant == 2) {
+                // float thresholds equivalent to the double reach tests of the sparse pass (see the kernel): walk the
+                // floats around the boundary with the very expressions the tests use
+                const double br = rf->p.blob_radius;
+                auto lowest = [&](auto ok, float guess) {      // smallest float f with ok(f); ok is monotone (false.. true)
+                    float f = guess;
+                    while (ok(f)) f = std::nextafterf(f, -INFINITY);
+                    while (!ok(f)) f = std::nextafterf(f, INFINITY);
+                    return f;
+                };
+                auto highest = [&](auto ok, float guess) {     // largest float f with ok(f); ok is monotone (true.. false)
+                    float f = guess;
+                    while (ok(f)) f = std::nextafterf(f, INFINITY);
+                    while (!ok(f)) f = std::nextafterf(f, -INFINITY);
+                    return f;
+                };
+                const int sX = rf->sizeX, sY = rf->sizeY;
+                const float4 reach = make_float4(lowest([&](float f) { return (double)f + br >= 0.0; }, (float)-br),
+                                                 highest([&](float f) { return (double)f - br <= (double)(sX - 1); }, (float)(sX - 1 + br)),
+                                                 lowest([&](float f) { return (double)f + br >= 0.0; }, (float)-br),
+                                                 highest([&](float f) { return (double)f - br <= (double)(sY - 1); }, (float)(sY - 1 + br)));
 #define XH_CUBES(CTF_, SB_)                                                                                         \
     hipLaunchKernelGGL((k_rf_insert_cubes<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
@@ -2472,7 +2494,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                        rf->p.blob_radius, (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16,      \
                        (int *)rf->d_tileCounter.p + 128, rf->tile_dbg, superList, superCount, superDim, m,            \
                        (const float4 *)superN, (const float4 *)superX, (const XhDense *)rf->d_dense.p + s0,            \
-                       (const float2 *)rf->d_wimg.p + s0)
+                       (const float2 *)rf->d_wimg.p + s0, reach)
                 if (hasCtf && smallBlob) XH_CUBES(true, true);
                 else if (hasCtf) XH_CUBES(true, false);
                 else if (smallBlob) XH_CUBES(false, true);
