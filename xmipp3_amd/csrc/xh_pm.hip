@@ -98,7 +98,7 @@ struct xh_pm {
     double tau_rel, scale, tie_rel;
     size_t chunk_rows;
     // static device data
-    XhBuf d_sin, d_cos, d_ringOfSample, d_nsam, d_soff, d_coff, d_rstart;
+    XhBuf d_sin, d_cos, d_ringOfSample, d_nsam, d_soff, d_coff, d_rstart, d_ringW;
     XhBuf d_tw32, d_tw64;        // ring DFT twiddles per ring, [nsamples] complex
     XhBuf d_refs64, d_refsB, d_refSigma, d_refCoef;
     XhBuf d_W32;                 // FFT twiddles for length M (float), M/2 entries (radix-2 kernels)
@@ -151,7 +151,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restrict__ stat,
            const float *__restrict__ sinr, const float *__restrict__ cosr, const short *__restrict__ ringOf,
-           const int *__restrict__ nsam, int D, int Ri, int nsamples, double xoff, double yoff,
+           const double *__restrict__ ringW, int D, int Ri, int nsamples, double xoff, double yoff,
            const int *__restrict__ count, int nt, const double *__restrict__ offs, int nparts, double *__restrict__ partial)
 {
     __shared__ double red[8];
@@ -174,8 +174,8 @@ k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restric
         if (yp < minp - eps || yp > maxp + eps) yp = d_realwrap<T>(yp, minp - (T)0.5, maxp + (T)0.5);
         const T v = d_interp<T>(c, D, xp, yp);
         polar[(size_t)slot * nsamples + i] = v;
-        const int r = ringOf[i];
-        const double w = (6.2831853071795864769 * (double)(r + Ri)) / (double)nsam[r];
+        // ring weight 2 pi r / nsam_r (polar.h:488-534): the same double the division here produced, tabulated per ring
+        const double w = ringW[ringOf[i]];
         const double dv = (double)v;
         sw += w; swv += w * dv; swv2 += w * dv * dv;
     }
@@ -1918,7 +1918,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     if (nparts > 1) XH_TRY(xh_buf_reserve(ctx, pm->d_polarPart, sizeof(double) * 3 * nps * nparts));
     hipLaunchKernelGGL((k_pm_polar<T>), dim3((unsigned)(nps * nparts)), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
                        (double *)statBuf.p, (const float *)pm->d_sin.p, (const float *)pm->d_cos.p,
-                       (const short *)pm->d_ringOfSample.p, (const int *)pm->d_nsam.p, D, L.Ri, L.nsamples, xoff, yoff,
+                       (const short *)pm->d_ringOfSample.p, (const double *)pm->d_ringW.p, D, L.Ri, L.nsamples, xoff, yoff,
                        d_count, nt, d_offs, nparts, (double *)pm->d_polarPart.p);
     XH_LAUNCH_CHECK();
     if (nparts > 1) {
@@ -1953,7 +1953,7 @@ template <typename T> static int upload(xh_ctx *ctx, XhBuf &b, const std::vector
 
 static void free_all(xh_pm *pm)
 {
-    XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart,
+    XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart, &pm->d_ringW,
                      &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack, &pm->d_kbounds,
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
@@ -2129,6 +2129,11 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         if (rc == XH_OK) rc = upload(ctx, pm->d_cos, cs);
         if (rc == XH_OK) rc = upload(ctx, pm->d_ringOfSample, ringOf);
         if (rc == XH_OK) rc = upload(ctx, pm->d_nsam, L.nsam);
+        if (rc == XH_OK) {
+            std::vector<double> ringW(L.nrings);
+            for (int r = 0; r < L.nrings; ++r) ringW[r] = (6.2831853071795864769 * (double)(r + L.Ri)) / (double)L.nsam[r];
+            rc = upload(ctx, pm->d_ringW, ringW);
+        }
         if (rc == XH_OK) rc = upload(ctx, pm->d_soff, L.soff);
         if (rc == XH_OK) rc = upload(ctx, pm->d_coff, L.coff);
         if (rc == XH_OK) rc = upload(ctx, pm->d_rstart, rstart);
