@@ -1193,8 +1193,12 @@ __device__ __forceinline__ bool d_hit(float y, float z, float a1, float a2, floa
     }
     return tOk && (u > 0.f) && (u < 1.f);
 }
+#ifndef XH_CUBE_NW
+#define XH_CUBE_NW 8      // waves per workgroup of the wave-independent kernel
+#define XH_CUBE_WPS 4     // waves per SIMD the register allocation is sized for
+#endif
 template <bool HAS_CTF, bool SMALLBLOB>
-__global__ void __launch_bounds__(512, 4)
+__global__ void __launch_bounds__(64 * XH_CUBE_NW, XH_CUBE_WPS)
 k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__ cullN, const float4 *__restrict__ cullX,
                   const XhRec *__restrict__ recs, int nspaces, const void *__restrict__ pk, const float *__restrict__ blobTable,
                   float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
@@ -1204,12 +1208,12 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
                   const XhDense *__restrict__ dense, const float2 *__restrict__ wimg, float4 reach)
 {
     __shared__ float sBlob[XH_BLOB_TABLE];
-    __shared__ int sSegStart[8][XH_SEGCAP + 1];
-    __shared__ unsigned long long sSegMask[8][XH_SEGCAP + 1];
-    __shared__ float qIx[8][XH_QCAP], qIy[8][XH_QCAP], qZs[8][XH_QCAP];
-    __shared__ int qMeta[8][XH_QCAP];
+    __shared__ int sSegStart[XH_CUBE_NW][XH_SEGCAP + 1];
+    __shared__ unsigned long long sSegMask[XH_CUBE_NW][XH_SEGCAP + 1];
+    __shared__ float qIx[XH_CUBE_NW][XH_QCAP], qIy[XH_CUBE_NW][XH_QCAP], qZs[XH_CUBE_NW][XH_QCAP];
+    __shared__ int qMeta[XH_CUBE_NW][XH_QCAP];
     const int tid = threadIdx.x;
-    for (int i = tid; i < XH_BLOB_TABLE; i += 512) sBlob[i] = blobTable[i];
+    for (int i = tid; i < XH_BLOB_TABLE; i += 64 * XH_CUBE_NW) sBlob[i] = blobTable[i];
     __syncthreads();
     const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
     const float fr = (float)blobRadius;
@@ -2487,7 +2491,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                                                  lowest([&](float f) { return (double)f + br >= 0.0; }, (float)-br),
                                                  highest([&](float f) { return (double)f - br <= (double)(sY - 1); }, (float)(sY - 1 + br)));
 #define XH_CUBES(CTF_, SB_)                                                                                         \
-    hipLaunchKernelGGL((k_rf_insert_cubes<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
+    hipLaunchKernelGGL((k_rf_insert_cubes<CTF_, SB_>), dim3(grid), dim3(64 * XH_CUBE_NW), 0, ctx->stream,                        \
                        (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
                        (const float4 *)rf->d_cull.p + ns + s0, (const XhRec *)rf->d_recs.p + s0, m,                   \
                        (const void *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, \
