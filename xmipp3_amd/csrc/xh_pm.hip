@@ -225,21 +225,30 @@ k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2
     xh_c2<T> *w = reinterpret_cast<xh_c2<T> *>(smem + sizeof(T) * ((n + 3) & ~3));
     const T mean = (T)stat[2 * slot];
     const T *src = polar + (size_t)slot * nsamples + soff[r];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        x[i] = src[i] - mean;
-        w[i] = tw[soff[r] + i];
+    // real input, even n: the samples s and n - s meet the same cosine and opposite sines, so the sum runs over half
+    // of the ring on e[s] = x[s] + x[n-s] (stored at x[s]) and o[s] = x[s] - x[n-s] (stored at x[n-s])
+    const int h = n / 2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = tw[soff[r] + i];
+    for (int i = threadIdx.x; i <= h; i += blockDim.x) {
+        const T a = src[i] - mean;
+        if (i == 0 || i == h) x[i] = a;
+        else {
+            const T b = src[n - i] - mean;
+            x[i] = a + b;
+            x[n - i] = a - b;
+        }
     }
     __syncthreads();
     const T inv = (T)1 / (T)n;
-    for (int k = threadIdx.x; k <= n / 2; k += blockDim.x) {
-        T re = 0, im = 0;
+    for (int k = threadIdx.x; k <= h; k += blockDim.x) {
+        T re = x[0] + ((k & 1) ? -x[h] : x[h]), im = 0;
         int j = 0;
-        for (int s = 0; s < n; ++s) {
-            const xh_c2<T> t = w[j];
-            re += x[s] * t.x;
-            im += x[s] * t.y;
+        for (int s = 1; s < h; ++s) {
             j += k;
             if (j >= n) j -= n;
+            const xh_c2<T> t = w[j];
+            re += x[s] * t.x;
+            im += x[n - s] * t.y;
         }
         re *= inv;
         im *= inv;
