@@ -46,6 +46,23 @@ def test_reference_flag_spellings_are_accepted(bins, tmp_path):
     assert r.returncode != 0 and "cannot open" in r.stderr
 
 
+def test_resolution_fsc_argument_rules(bins):
+    """resolution_fsc.cpp:34-118: -i needs --ref, --set_of_images excludes both ("or" alternative of the parameter DSL)."""
+    fsc = os.path.join(bins, "xmipp_resolution_fsc")
+    r = _run([fsc, "-s", "2"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "-i is mandatory" in r.stderr
+    r = _run([fsc, "-i", "a.vol"])
+    assert r.returncode != 0 and "requires --ref" in r.stderr
+    r = _run([fsc, "--set_of_images", "s.sel", "-i", "x", "--ref", "y"])
+    assert r.returncode != 0 and "should not be provided with -i or --ref" in r.stderr
+    r = _run([fsc, "--set_of_images", "s.sel"])
+    assert r.returncode != 0 and "not available" in r.stderr
+    r = _run([fsc, "--ref", "missing_a.vol", "-i", "missing_b.vol", "-s", "5.6", "--do_dpr", "--oroot", "x"])
+    assert r.returncode != 0 and "cannot open" in r.stderr          # the flags of test_programs.py:898-900 parse
+    r = _run([fsc, "--help"])
+    assert r.returncode == 0 and "or --set_of_images" in r.stderr
+
+
 def _write_dataset(tmp, D=32, nrefs=12, n=9, seed=4):
     vol = synth.phantom(D, seed=seed, nblobs=10)
     refs, dirs = synth.make_refs(vol, nrefs)
