@@ -241,6 +241,45 @@ def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kin
     print(kind, "pruned", st["pruned_rows"], "of", st["rows"], "rescored rows", st["rescored_rows"], "K0", K0, "of", nk)
 
 
+@pytest.mark.parametrize("kind", ["phantom", "noise"])
+def test_branch_and_bound_at_full_size(gpu, kind):
+    """BASELINE config 4 shape (256 px, 1000 references, 2048 particles at SNR 0.1): the pruned, two-level search and
+    the exhaustive one give the same (reference, angle, mirror) for every particle, and so do other cuts K0."""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 256, 1000, 2048
+    g = torch.Generator(device="cuda").manual_seed(11)
+    if kind == "phantom":
+        vol = torch.from_numpy(synth.phantom(D, seed=4, nblobs=20).astype(np.float32)).cuda()
+        fp = xa.FourierProjector(ctx, vol, 2.0, 0.5, 3)
+        dirs = synth.fibonacci_directions(nrefs)
+        refs = fp.project(np.concatenate([dirs, np.zeros((nrefs, 1))], 1))
+        fp.close()
+        refs = ((refs - refs.mean()) / refs.std()).contiguous()
+    else:
+        x = torch.randn((nrefs, D, D), generator=g, device="cuda")
+        f = torch.fft.rfft2(x)
+        ky = torch.fft.fftfreq(D, device="cuda")[:, None]
+        kx = torch.fft.rfftfreq(D, device="cuda")[None, :]
+        refs = torch.fft.irfft2(f * torch.exp(-2 * (np.pi * 3.0) ** 2 * (kx * kx + ky * ky)), s=(D, D))
+        refs = (refs / refs.std()).contiguous()
+    idx = torch.randint(0, nrefs, (n,), generator=g, device="cuda")
+    parts = (refs[idx] + np.sqrt(10.0) * torch.randn((n, D, D), generator=g, device="cuda")).contiguous()
+    pm = xa.ProjectionMatcher(ctx, refs)
+    on = [t.cpu().numpy() for t in pm.match(parts)]
+    st = pm.last_stats()
+    K0, nk = pm.two_level_cut()
+    assert st["pruned_rows"] > 0.9 * st["rows"]
+    pm.set_option("k0", 64 if K0 != 64 else 96)
+    other = [t.cpu().numpy() for t in pm.match(parts)]
+    pm.set_option("prune", 0)
+    off = [t.cpu().numpy() for t in pm.match(parts)]
+    for a, b, c in zip(on, other, off):
+        assert np.array_equal(a, c) and np.array_equal(b, c)
+    if kind == "noise":       # unrelated references: the true one wins (neighbouring phantom projections look alike)
+        assert (on[0] == idx.cpu().numpy()).mean() > 0.95
+    print(kind, "pruned", st["pruned_rows"] / st["rows"], "K0", K0, "of", nk, "rescored particles", st["rescored_particles"])
+
+
 @pytest.mark.parametrize("D", [512, 24])
 def test_match_extreme_box_sizes(gpu, oracle, D):
     """512 px: N=1602, Bluestein M=4096 (radix-2 LDS S3 kernel), 255 rings, nk=802; 24 px: M=256 (radix-2 too)."""
