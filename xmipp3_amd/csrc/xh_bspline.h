@@ -125,6 +125,55 @@ k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D,
     }
 }
 
+// The same convolution in fp64 for the re-scoring path and the reference bank: z^33 = 1.3e-19 is below double resolution,
+// so 65 taps reproduce the recursion to rounding (the recursion's own 2*D-step chain carries that much error), with every
+// output independent. in: float or double images [src][D][D] (gather: source image of slot, nullable; count: number of
+// live slots on the device, nullable); out: [slot][D][D] double. One thread per XH_FIR64_V outputs.
+#define XH_FIR64_K 32
+#define XH_FIR64_V 8
+struct XhFir64 { double h[XH_FIR64_K + 1]; };
+template <bool COLS, typename TIN>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_fir64(const TIN *__restrict__ in, double *__restrict__ out, int D, size_t nvec, XhFir64 F,
+                     const int *__restrict__ gather, const int *__restrict__ count)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvec) return;
+    const int segs = (D + XH_FIR64_V - 1) / XH_FIR64_V;
+    int x0, y0;
+    size_t slot;
+    if (COLS) { x0 = t % D; y0 = (int)((t / D) % segs) * XH_FIR64_V; slot = t / ((size_t)D * segs); }
+    else { x0 = (int)(t % segs) * XH_FIR64_V; y0 = (int)((t / segs) % D); slot = t / ((size_t)segs * D); }
+    if (count && (int)slot >= *count) return;
+    const TIN *src = in + (size_t)(gather ? gather[slot] : (int)slot) * D * D;
+    double w[XH_FIR64_V + 2 * XH_FIR64_K];
+#pragma unroll
+    for (int i = 0; i < XH_FIR64_V + 2 * XH_FIR64_K; ++i) {
+        int p = (COLS ? y0 : x0) + i - XH_FIR64_K;
+        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
+        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        w[i] = (double)(COLS ? src[(size_t)p * D + x0] : src[(size_t)y0 * D + p]);
+    }
+#pragma unroll
+    for (int o = 0; o < XH_FIR64_V; ++o) {
+        const int q = (COLS ? y0 : x0) + o;
+        if (q >= D) break;
+        double acc = F.h[0] * w[o + XH_FIR64_K];
+#pragma unroll
+        for (int j = 1; j <= XH_FIR64_K; ++j) acc += F.h[j] * (w[o + XH_FIR64_K - j] + w[o + XH_FIR64_K + j]);
+        if (COLS) out[slot * D * D + (size_t)q * D + x0] = acc;
+        else out[slot * D * D + (size_t)y0 * D + q] = acc;
+    }
+}
+
+static inline XhFir64 xh_fir64_taps()
+{
+    XhFir64 F;
+    const long double z = sqrtl(3.0L) - 2.0L;
+    for (int j = 0; j <= XH_FIR64_K; ++j) F.h[j] = (double)(sqrtl(3.0L) * powl(z, j));
+    return F;
+}
+
 static inline XhFir xh_fir_taps()
 {
     XhFir F;

@@ -118,6 +118,8 @@ struct xh_pm {
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
+    int use_fir64;               // fp64 prefilter as a 65-tap convolution (1) or the recursion (0)
+    XhBuf d_firTmp64;
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
@@ -1905,6 +1907,21 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float *)pm->d_firTmp.p, (float *)coefBuf.p, D, nvec, F);
         XH_LAUNCH_CHECK();
+    } else if (std::is_same<T, double>::value && pm->use_fir64 && D >= 16) {
+        // fp64: the 65-tap convolution form (source images gathered, device-side count honoured)
+        const XhFir64 F = xh_fir64_taps();
+        const int segs = (D + XH_FIR64_V - 1) / XH_FIR64_V;
+        const size_t nvec = (size_t)nslots * D * segs;
+        XH_TRY(xh_buf_reserve(ctx, pm->d_firTmp64, sizeof(double) * (size_t)nslots * D * D));
+        if (imgsAreFloat)
+            hipLaunchKernelGGL((k_pm_prefilter_fir64<false, float>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float *)imgs, (double *)pm->d_firTmp64.p, D, nvec, F, d_gather, d_count);
+        else
+            hipLaunchKernelGGL((k_pm_prefilter_fir64<false, double>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double *)imgs, (double *)pm->d_firTmp64.p, D, nvec, F, d_gather, d_count);
+        hipLaunchKernelGGL((k_pm_prefilter_fir64<true, double>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)pm->d_firTmp64.p, (double *)coefBuf.p, D, nvec, F, (const int *)nullptr, d_count);
+        XH_LAUNCH_CHECK();
     } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(T)))));
     const int tiles = (D + TR - 1) / TR;
@@ -1967,7 +1984,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2050,6 +2067,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
     pm->use_fir = 1;
+    pm->use_fir64 = 1;
     pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
@@ -2344,6 +2362,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
         XH_TRY(set_k0(pm, value <= 0 ? pm->K0auto : (int)value));
     }
     else if (!strcmp(name, "use_fir")) pm->use_fir = (int)value;
+    else if (!strcmp(name, "use_fir64")) pm->use_fir64 = (int)value;
     else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
