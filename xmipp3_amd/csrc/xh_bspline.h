@@ -78,7 +78,7 @@ __global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, co
 // a 2*D-step dependent chain per line (latency-bound: 1.5 us per 256-px image); z^17 < 2e-10 is below
 // fp32 resolution, so the fp32 users (coarse matching pass, image shifts before gridding) use the 33-tap
 // form, every output independent, eight outputs per thread from one 40-sample window. The fp64 paths
-// (reference library, re-scoring) keep the recursion.
+// (reference library, re-scoring) use the 65-tap form below; the gallery projector keeps the recursion.
 #define XH_FIR_K 16
 #define XH_FIR_V 8
 struct XhFir { float h[XH_FIR_K + 1]; };
