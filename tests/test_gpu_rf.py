@@ -105,10 +105,10 @@ def test_ctf_arrays(gpu, oracle, kind):
 
 def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
-    if path in ("tiles", "tiles_queue", "cubes"):
+    if path in ("tiles", "tiles_queue", "cubes", "grid"):
         rf.set_option("tile_min_spaces", 1)       # output-stationary kernels even for one projection
-        # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes (the product path)
-        rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2}[path])
+        # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes | LDS-fed units
+        rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2, "grid": 3}[path])
     elif path == "scatter":
         rf.set_option("tile_min_spaces", 1 << 30)  # atomic scatter kernel
     o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
@@ -116,7 +116,7 @@ def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
     return rf, o, ffts
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes", "grid"])
 def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
     """One projection into an empty volume: the same voxels and, summing taps in the same
     order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
@@ -130,6 +130,13 @@ def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
         gv, gw = rf.temp_spaces()
         gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
         assert (ew > 0).sum() > 1000
+        if path == "grid":
+            # same voxels, same taps, same table entries; the products inside a tap are re-associated (records carry
+            # re*ctf*mod*w) and fused: float rounding
+            assert np.array_equal(gw != 0, ew != 0)
+            assert np.abs(gw - ew).max() <= 1e-6 * np.abs(ew).max()
+            assert np.abs(gv - ev).max() <= 1e-6 * np.abs(ev).max()
+            continue
         assert np.array_equal(gw, ew)
         assert np.array_equal(gv, ev)
 
@@ -148,7 +155,7 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes"])
+@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes", "grid"])
 @pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
 def test_insert_many(gpu, oracle, data32, mode, path):
     xa, ctx, torch = gpu

@@ -223,6 +223,7 @@ struct xh_rf {
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
     XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs, d_dense, d_wimg;
+    XhBuf d_gtiles, d_grecs, d_gweights;   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -1536,6 +1537,8 @@ k_rf_insert_cubes(const XhSpace *__restrict__ spaces, const float4 *__restrict__
 }
 
 
+#include "xh_rf_grid.h"
+
 // ---- gridding, output-stationary, LDS-staged patches ---------------------------------------------
 // The queue kernel above is bound by the L1's tag-lookup rate: every lane gathers its own 4x4 footprint
 // (profiles/README.md: 26 L1 accesses per vector-memory instruction). Here a wave stages, per surviving
@@ -2081,6 +2084,34 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
         if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 512);
         if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 16, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     }
+    if (r == XH_OK) {
+        // k_rf_grid: 16 x 16 x 8 tiles (eight 8 x 8 x 4 units), same ordering rules; class offsets at d_tileCounter + 32
+        const int tpx = (rf->mv + 1 + 15) / 16, tpz = (rf->mv + 1 + 7) / 8;
+        const double R = rf->sizeX + p->blob_radius + 11.2 + 1.0;
+        std::vector<unsigned> packed;
+        std::vector<double> wsum;
+        double acc = 0;
+        for (int tz = 0; tz < tpz; ++tz)
+            for (int ty = 0; ty < tpx; ++ty)
+                for (int tx = 0; tx < tpx; ++tx) {
+                    const double cx = tx * 16 + 7.5 - rf->mv / 2, cy = ty * 16 + 7.5 - rf->mv / 2, cz = tz * 8 + 3.5 - rf->mv / 2;
+                    const double d = std::sqrt(cx * cx + cy * cy + cz * cz);
+                    if (d <= R) { packed.push_back((unsigned)(tx | (ty << 8) | (tz << 16))); acc += 1.0 / std::max(d, 8.0); wsum.push_back(acc); }
+                }
+        int classOff[9];
+        classOff[0] = 0;
+        for (int c = 1; c < 8; ++c)
+            classOff[c] = (int)(std::lower_bound(wsum.begin(), wsum.end(), acc * c / 8.0) - wsum.begin());
+        classOff[8] = (int)packed.size();
+        auto spread = [](unsigned v) { unsigned long long x = v & 0x3ff; x = (x | x << 16) & 0x30000ffULL; x = (x | x << 8) & 0x300f00fULL; x = (x | x << 4) & 0x30c30c3ULL; x = (x | x << 2) & 0x9249249ULL; return x; };
+        // Morton order on (x, y, z / 2): tiles are half as tall as wide
+        auto key = [&](unsigned t) { return (spread(t & 0xff) | spread((t >> 8) & 0xff) << 1 | spread((t >> 17) & 0x7f) << 2) << 1 | ((t >> 16) & 1); };
+        for (int c = 0; c < 8; ++c)
+            std::sort(packed.begin() + classOff[c], packed.begin() + classOff[c + 1], [&](unsigned u, unsigned v) { return key(u) < key(v); });
+        r = xh_buf_alloc(ctx, rf->d_gtiles, sizeof(unsigned) * std::max<size_t>(1, packed.size()));
+        if (r == XH_OK) r = (hipMemcpy(rf->d_gtiles.p, packed.data(), sizeof(unsigned) * packed.size(), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+        if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 32, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+    }
     if (r != XH_OK) { xh_rf_destroy(rf); return r; }
     *out = rf;
     return XH_OK;
@@ -2098,6 +2129,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs); xh_buf_free(rf->d_dense); xh_buf_free(rf->d_wimg);
+    xh_buf_free(rf->d_gtiles); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -2363,7 +2395,8 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     const bool hasCtf = d_ctf != nullptr, fast = rf->p.use_fast != 0;
     // product path: output-stationary tiles (no atomics). The scatter kernel remains for --fast
     // (one voxel per row, RFA:595-625) and for launches too small to amortise a volume pass.
-    const bool useTiles = !fast && rf->insert_variant == 0 && ns >= rf->tile_min_spaces && rf->mv / XH_TSZ < 255;
+    const bool useTiles = !fast && rf->insert_variant == 0 && ns >= rf->tile_min_spaces && rf->mv / XH_TSZ < 255 &&
+                          !(rf->tile_variant == 3 && rf->p.blob_radius >= 2.0 && (rf->tile_variant = 2));
     if (useTiles) {
         const int grid = 8 * std::max(1, (ctx->num_cus * 2) / 8);
         const bool smallBlob = rf->p.blob_radius < 2.0;
@@ -2405,8 +2438,31 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         XH_TRY(xh_buf_reserve(ctx, rf->d_wimg, sizeof(float2) * (size_t)ns));
         XH_HIP(hipMemcpyAsync(rf->d_dense.p, dense.data(), sizeof(XhDense) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
         XH_HIP(hipMemcpyAsync(rf->d_wimg.p, wimg.data(), sizeof(float2) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<XgRec> grecs;
+        std::vector<float> gweights;
+        if (rf->tile_variant == 3) {
+            grecs.resize(ns);
+            for (int i = 0; i < ns; ++i) {
+                const XhSpace &S = spaces[i];
+                grecs[i].r0 = recs[i].r0; grecs[i].r1 = recs[i].r1; grecs[i].r2 = recs[i].r2;
+                grecs[i].da = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
+                grecs[i].db = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
+            }
+            gweights.resize(n);
+            for (int i = 0; i < n; ++i) gweights[i] = h_weights ? h_weights[i] : 1.0f;
+            XH_TRY(xh_buf_reserve(ctx, rf->d_grecs, sizeof(XgRec) * (size_t)ns));
+            XH_TRY(xh_buf_reserve(ctx, rf->d_gweights, sizeof(float) * (size_t)n));
+            XH_HIP(hipMemcpyAsync(rf->d_grecs.p, grecs.data(), sizeof(XgRec) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
+            XH_HIP(hipMemcpyAsync(rf->d_gweights.p, gweights.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        }
         XH_HIP(hipStreamSynchronize(ctx->stream));
-        {
+        if (rf->tile_variant == 3) {
+            const size_t cells = (size_t)n * (rf->sizeX + 2 * XH_PAD) * (rf->sizeY + 2 * XH_PAD);
+            XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(float4)));
+            hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
+                               (const float *)rf->d_gweights.p, (float4 *)rf->d_pack.p, n, rf->sizeX, rf->sizeY);
+            XH_LAUNCH_CHECK();
+        } else {
             // packed + padded projection records (re, im[, ctf, mod]) for contiguous 4-pixel row fetches
             const size_t cells = (size_t)n * (rf->sizeX + 2 * XH_PAD) * (rf->sizeY + 2 * XH_PAD);
             XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * (hasCtf ? sizeof(float4) : sizeof(float2))));
@@ -2435,10 +2491,10 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
             const int nsuper = superDim * superDim * superDim;
             const int *superList = nullptr, *superCount = nullptr;
             float4 *superN = nullptr, *superX = nullptr;
-            if (rf->use_supercull && m >= 32) {
+            if ((rf->use_supercull && m >= 32) || rf->tile_variant == 3) {
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superList, sizeof(int) * (size_t)nsuper * m));
                 XH_TRY(xh_buf_reserve(ctx, rf->d_superCount, sizeof(int) * (size_t)nsuper));
-                const bool inlineVecs = rf->tile_variant == 2;
+                const bool inlineVecs = rf->tile_variant >= 2;
                 if (inlineVecs) XH_TRY(xh_buf_reserve(ctx, rf->d_superVec, 2 * sizeof(float4) * (size_t)nsuper * m));
                 superN = inlineVecs ? (float4 *)rf->d_superVec.p : nullptr;
                 superX = inlineVecs ? superN + (size_t)nsuper * m : nullptr;
@@ -2469,7 +2525,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                                        (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
                                        (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
             }
-            else if (rf->tile_variant == 2) {
+            else if (rf->tile_variant == 2 || rf->tile_variant == 3) {
                 // float thresholds equivalent to the double reach tests of the sparse pass (see the kernel): walk the
                 // floats around the boundary with the very expressions the tests use
                 const double br = rf->p.blob_radius;
@@ -2499,7 +2555,13 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
                        (int *)rf->d_tileCounter.p + 128, rf->tile_dbg, superList, superCount, superDim, m,            \
                        (const float4 *)superN, (const float4 *)superX, (const XhDense *)rf->d_dense.p + s0,            \
                        (const float2 *)rf->d_wimg.p + s0, reach)
-                if (hasCtf && smallBlob) XH_CUBES(true, true);
+                if (rf->tile_variant == 3)
+                    hipLaunchKernelGGL(k_rf_grid, dim3(8 * std::max(1, ctx->num_cus / 8)), dim3(64 * XG_NW), 0, ctx->stream, (const XgRec *)rf->d_grecs.p + s0,
+                                       (const float4 *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt,
+                                       rf->p.blob_radius, (const unsigned *)rf->d_gtiles.p, (const int *)rf->d_tileCounter.p + 32,
+                                       (int *)rf->d_tileCounter.p + 128, superList, superCount, superDim, m,
+                                       (const float4 *)superN, (const float4 *)superX, reach, rf->tile_dbg);
+                else if (hasCtf && smallBlob) XH_CUBES(true, true);
                 else if (hasCtf) XH_CUBES(true, false);
                 else if (smallBlob) XH_CUBES(false, true);
                 else XH_CUBES(false, false);
