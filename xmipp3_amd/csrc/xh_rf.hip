@@ -2445,8 +2445,10 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
             for (int i = 0; i < ns; ++i) {
                 const XhSpace &S = spaces[i];
                 grecs[i].r0 = recs[i].r0; grecs[i].r1 = recs[i].r1; grecs[i].r2 = recs[i].r2;
-                grecs[i].da = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
-                grecs[i].db = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
+                xg_fill_hit(grecs[i], S, rf->p.blob_radius);
+                // image extent of a unit (half extents 3.5, 3.5, 1.5 voxels) + blob radius: where its first footprint pixel lies
+                grecs[i].h2.z = 3.5f * (std::fabs(S.tInv[0]) + std::fabs(S.tInv[1])) + 1.5f * std::fabs(S.tInv[2]) + 0.01f + (float)rf->p.blob_radius;
+                grecs[i].h2.w = 3.5f * (std::fabs(S.tInv[3]) + std::fabs(S.tInv[4])) + 1.5f * std::fabs(S.tInv[5]) + 0.01f + (float)rf->p.blob_radius;
             }
             gweights.resize(n);
             for (int i = 0; i < n; ++i) gweights[i] = h_weights ? h_weights[i] : 1.0f;
@@ -2480,6 +2482,8 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
         const size_t listBytesPerSpace = (size_t)sdim * sdim * sdim * 36;
         const int maxByLists = (int)std::max<size_t>(256, ((size_t)8 << 30) / listBytesPerSpace);
         const int maxsp = std::min(std::max(64, rf->tile_max_spaces), rf->use_supercull ? maxByLists : (1 << 30));
+        if (rf->tile_variant == 3)
+            XH_CHECK((size_t)n * (rf->sizeX + 2 * XH_PAD) * (rf->sizeY + 2 * XH_PAD) < ((size_t)1 << 31), XH_ERR_ARG, "xh_rf_insert: more than 2^31 record cells in one call; insert in smaller batches");
         for (int s0 = 0; s0 < ns; s0 += maxsp) {
             const int m = std::min(maxsp, ns - s0);
             XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));

@@ -30,51 +30,39 @@
 #ifndef XG_NW
 #define XG_NW 12                // waves per workgroup (= per CU: the LDS budget admits one workgroup)
 #endif
-#define XG_NBUF 1               // patch buffers per wave
 #define XG_KCAP 256             // surviving projections listed per cull phase
-#define XG_PATCH_BYTES 4096     // 16 x 16 pixels x 16 B
-#define XG_LDS_PATCH 0                                   // [XG_NW][2][4096]; first, so that LDS-DMA bases stay below 64 KB
-#define XG_LDS_BLOB (XG_NW * XG_NBUF * XG_PATCH_BYTES)         // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
+#define XG_PW 18                // patch row stride in pixels: 16 are needed, 18 skews consecutive rows by two bank groups
+#define XG_NDMA 5               // LDS-DMA instructions per patch: 320 slots = 17.8 rows of 18 pixels
+#define XG_PATCH_BYTES (XG_NDMA * 1024)
+#define XG_LDS_PATCH 0                                   // [XG_NW][XG_PATCH_BYTES]; first, so that LDS-DMA bases stay below 64 KB
+#define XG_LDS_BLOB (XG_NW * XG_PATCH_BYTES)             // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
 #define XG_LDS_ACC (XG_LDS_BLOB + 4 * (XH_BLOB_TABLE + 4))   // [XG_NW][3][256] float
 #define XG_LDS_KEPT (XG_LDS_ACC + XG_NW * 3 * 256 * 4)   // [XG_NW][XG_KCAP] int
-#define XG_LDS_QUEUE (XG_LDS_KEPT + XG_NW * XG_KCAP * 4) // [XG_NW][256] uchar
-#define XG_LDS_RING (XG_LDS_QUEUE + XG_NW * 256)         // tile ring: int[8] tiles, int[8] ready, ticket, hop
+#define XG_LDS_QUEUE (XG_LDS_KEPT + XG_NW * XG_KCAP * 4) // [XG_NW][256] int
+#define XG_LDS_RING (XG_LDS_QUEUE + XG_NW * 1024)        // tile ring: int[8] tiles, int[8] ready, ticket, hop
 #define XG_LDS_TOTAL (XG_LDS_RING + 4 * 32)
 
-struct XgRec { float4 r0, r1, r2, da, db; };   // tInv rows (.w: image index, minY | maxY << 16, minZ | maxZ << 16), getX operands
+// One traverse space (projection x symmetry placement) as the kernel reads it, through scalar loads:
+//   r0, r1, r2  rows of the inverse transform (RFA:643-647); .w: image index, minY | maxY << 16, minZ | maxZ << 16 (AABB rows)
+//   h0, h1, h2  the row-visit test (getX, RFA:479-490) as affine forms of (y, z), see xg_hit: (Uy, Uz, U0, dU), (Ty, Tz, T0, dT),
+//               (band of u, band of t, image extent of a unit in x + r, in y + r)
+//   da, db      getX operands for the exact evaluation (d_hit): (u.y, u.z, v.y, v.z), (p0.y, p0.z, p4.y, p4.z)
+struct XgRec { float4 r0, r1, r2, h0, h1, h2, da, db; };
 
-// one LDS-DMA instruction: every lane's 16 bytes at g land at ldsBase + 16 * lane (ldsBase wave-uniform, in an SGPR)
-__device__ __forceinline__ void xg_dma16(const void *g, unsigned ldsBase)
+// the patch copy: XG_NDMA LDS-DMA instructions, every lane's 16 bytes at base + off[i] land at ldsBase + 1024 i + 16 lane
+// (base, ldsBase wave-uniform). M0 carries the LDS address; the compiler keeps nothing in M0 across a statement.
+__device__ __forceinline__ void xg_dma_patch(const void *base, const unsigned (&off)[5], unsigned ldsBase)
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(ldsBase) : "memory");
-}
-// the same with a wave-uniform 64-bit base (SGPR pair) and a 32-bit byte offset per lane
-__device__ __forceinline__ void xg_dma16s(const void *base, unsigned off, unsigned ldsBase)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(base), "s"(ldsBase) : "memory");
-}
-typedef float xg_v2f __attribute__((ext_vector_type(2)));
-typedef float xg_v4f __attribute__((ext_vector_type(4)));
-// hit part of getX without the two IEEE divisions: u in (0, 1) is decided exactly from the signs and moduli of numerator
-// and denominator; t needs the value of u, taken as num * (1 / den) -- whenever t comes within the error of that
-// shortcut of 0 or 1 the lane asks for the exact evaluation (d_hit)
-__device__ __forceinline__ bool xg_hit_fast(float y, float z, float a1, float a2, float b1, float y0, float z0, float den, float rden, bool &near)
-{
-    const float num = (z - z0) * a1 + (y0 - y) * a2;
-    const bool uOk = ((num > 0.f && den > 0.f) || (num < 0.f && den < 0.f)) && (fabsf(num) < fabsf(den));
-    const float yy = -y0 + y;
-    const float ub = (num * rden) * b1;
-    const float tn = yy - ub;
-    const float tol = 6e-7f * (fabsf(ub) + fabsf(yy));
-    const float atn = fabsf(tn), aa1 = fabsf(a1);
-    near = near || (uOk && (atn < tol + 1e-30f || fabsf(atn - aa1) < tol || !(aa1 < 1e6f)));
-    return uOk && ((tn > 0.f) == (a1 > 0.f)) && (atn < aa1);
+    asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5"
+                 :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(base), "s"(ldsBase) : "memory", "scc");
 }
 __device__ __forceinline__ void xg_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+typedef float xg_v2f __attribute__((ext_vector_type(2)));
+typedef float xg_v4f __attribute__((ext_vector_type(4)));
 
 // float4 (re*ctf*mod*w, im*ctf*mod*w, mod*w, 0) per pixel, XH_PAD zero cells on every side
 __global__ void k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
@@ -100,6 +88,40 @@ __global__ void k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__re
     pk[gid] = v;
 }
 
+// Host side of the row-visit test. getX (RFA:479-490) intersects the voxel row (y, z) with a face of the slab:
+//   u = ((z - z0) a1 + (y0 - y) a2) / (a1 b2 - b1 a2),  t = (y - y0 - u b1) / a1,  row visited iff 0 < u, t < 1 on either face.
+// Both are affine in (y, z); the device evaluates the affine forms and only where a value comes within a band of 0 or 1
+// -- the band covers the rounding of both evaluations -- does the lane repeat the reference's own float arithmetic.
+static void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
+{
+    const double a1 = S.u[1], a2 = S.u[2], b1 = S.v[1], b2 = S.v[2];
+    const double den = a1 * b2 - b1 * a2;
+    const double y01 = S.p0[1], z01 = S.p0[2], y02 = S.p4[1], z02 = S.p4[2];
+    const float huge = 1e30f;
+    G.da = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
+    G.db = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
+    if (!(std::fabs(den) > 1e-20) || !(std::fabs(a1) > 1e-20) || !std::isfinite(den)) {
+        G.h0 = make_float4(0.f, 0.f, 0.5f, 0.f);
+        G.h1 = make_float4(0.f, 0.f, 0.5f, 0.f);
+        G.h2.x = huge; G.h2.y = huge;            // every lane takes the exact path
+        return;
+    }
+    const double Uz = a1 / den, Uy = -a2 / den;
+    const double U01 = (-z01 * a1 + y01 * a2) / den, U02 = (-z02 * a1 + y02 * a2) / den;
+    const double Ty = (1.0 - Uy * b1) / a1, Tz = -Uz * b1 / a1;
+    const double T01 = (-y01 - U01 * b1) / a1, T02 = (-y02 - U02 * b1) / a1;
+    G.h0 = make_float4((float)Uy, (float)Uz, (float)U01, (float)(U02 - U01));
+    G.h1 = make_float4((float)Ty, (float)Tz, (float)T01, (float)(T02 - T01));
+    // bands: a dozen roundings of 2^-24 on the largest intermediate of either evaluation (coordinates stay below 1100)
+    const double eps = 16.0 / 16777216.0, L = 1100.0;
+    const double mu = L * (std::fabs(Uy) + std::fabs(Uz)) + std::fabs(U01) + std::fabs(U02) + 1.0;
+    const double numMax = L * (std::fabs(a1) + std::fabs(a2)) + std::fabs(z01 * a1) + std::fabs(y01 * a2) + std::fabs(z02 * a1) + std::fabs(y02 * a2);
+    const double bu = eps * (mu + numMax / std::fabs(den));
+    const double mt = L * (std::fabs(Ty) + std::fabs(Tz)) + std::fabs(T01) + std::fabs(T02) + 1.0;
+    const double bt = eps * (mt + (L + std::fabs(y01) + std::fabs(y02) + (mu + 1.0) * std::fabs(b1)) / std::fabs(a1)) + bu * std::fabs(b1 / a1);
+    G.h2.x = (float)std::min(bu, 1e30); G.h2.y = (float)std::min(bt, 1e30);
+}
+
 __global__ void __launch_bounds__(64 * XG_NW, (XG_NW + 3) / 4)
 k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const float *__restrict__ blobTable,
           float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
@@ -113,9 +135,9 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     float *sBlob = reinterpret_cast<float *>(lds + XG_LDS_BLOB);
     float *sAcc = reinterpret_cast<float *>(lds + XG_LDS_ACC) + wv * 3 * 256;
     int *sKept = reinterpret_cast<int *>(lds + XG_LDS_KEPT) + wv * XG_KCAP;
-    unsigned char *sQueue = lds + XG_LDS_QUEUE + wv * 256;
+    int *sQueue = reinterpret_cast<int *>(lds + XG_LDS_QUEUE) + wv * 256;
     int *sTile = reinterpret_cast<int *>(lds + XG_LDS_RING), *sReady = sTile + 8, *sTicket = sTile + 16, *sHop = sTile + 17;
-    const unsigned char *sPatch = lds + XG_LDS_PATCH + wv * XG_NBUF * XG_PATCH_BYTES;
+    const unsigned char *sPatch = lds + XG_LDS_PATCH + wv * XG_PATCH_BYTES;
     const unsigned patchBase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)sPatch;
     const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
     const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
@@ -129,11 +151,12 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     const xg_v2f idel2 = {iDeltaSqrt, iDeltaSqrt}, half2 = {0.5f, 0.5f};
     const float limf = (float)XH_BLOB_TABLE;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // which pixel of a patch lane l of DMA instruction i fetches: LDS slot 64 i + l holds row (64 i + l) / 16 and, rows
-    // being rotated by their index against bank conflicts, column ((64 i + l) - row) mod 16
-    unsigned dOff[4];
+    // which pixel of a patch lane l of DMA instruction i fetches: LDS slot s = 64 i + l holds pixel (s / 18, s % 18)
+    unsigned dOff[XG_NDMA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int slot = 64 * i + lane, row = slot >> 4, col = (slot - row) & 15; dOff[i] = (unsigned)(row * SX + col) * 16u; }
+    for (int i = 0; i < XG_NDMA; ++i) { const int slot = 64 * i + lane, row = slot / XG_PW, col = slot - row * XG_PW; dOff[i] = (unsigned)(row * SX + col) * 16u; }
+    // queue word of this lane's voxel zi: x | y << 8 | z << 16 | accumulator index << 24 (bytes feed v_cvt_f32_ubyteN)
+    const int qword = lx | (ly << 8) | (lane << 24);
 
     // ---- work distribution: the tile ring of the previous kernel (tiles = 2 x 2 x 2 units, eight XCD classes dealt into
     // NSUB interleaved streams, one global grab per tile, eight tickets per tile drawn by the waves of the workgroup)
@@ -196,6 +219,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
 #pragma unroll
         for (int i = 0; i < 12; ++i) sAcc[i * 64 + lane] = 0.f;
         const float fx0 = (float)(x0 - mv / 2), fy0 = (float)(y0 - mv / 2), fz0 = (float)(z0 - mv / 2);
+        const xg_v2f pz01 = {fz0, fz0 + 1.f}, pz23 = {fz0 + 2.f, fz0 + 3.f};
         const float ucx = x0 + 3.5f - mv / 2, ucy = y0 + 3.5f - mv / 2, ucz = z0 + 1.5f - mv / 2;
         const int sup = ((tz >> 1) * superDim + ty) * superDim + tx;
         const int nlist = superCount[sup];
@@ -231,85 +255,99 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
             if (nk == 0) continue;
             __builtin_amdgcn_wave_barrier();
 
-            // ---- visits. patchOf(rec): origin of the 16 x 16 patch = first footprint pixel of the block's corner with the
-            // smallest image coordinates (the block's image extent is < 10.4 pixels, its footprints span < 16)
-            auto issue = [&](const XgRec &R, int buf) {
-                const float cix = R.r0.x * ucx + R.r0.y * ucy + R.r0.z * ucz;
-                const float ciy = R.r1.x * ucx + R.r1.y * ucy + R.r1.z * ucz + (float)(mv / 2);
-                const float ex = 3.5f * (fabsf(R.r0.x) + fabsf(R.r0.y)) + 1.5f * fabsf(R.r0.z) + 0.01f;
-                const float ey = 3.5f * (fabsf(R.r1.x) + fabsf(R.r1.y)) + 1.5f * fabsf(R.r1.z) + 0.01f;
-                // the patch stays inside the padded record: footprints never leave it, so an origin moved inwards
-                // still covers them
-                const int ox = min(max(__builtin_amdgcn_readfirstlane((int)ceilf(cix - ex - fr)), -XH_PAD), SX - XH_PAD - 16);
-                const int oy = min(max(__builtin_amdgcn_readfirstlane((int)ceilf(ciy - ey - fr)), -XH_PAD), SY - XH_PAD - 16);
-                if (dbg == 3) return make_int2(ox, oy);
-                const size_t cell = ((size_t)__float_as_int(R.r0.w) * SY + (oy + XH_PAD)) * SX + (ox + XH_PAD);
-                const float4 *base = pk + cell;
-                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base);
-                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
-                const void *sb = (const void *)(((uintptr_t)hi << 32) | lo);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xg_dma16s(sb, dOff[i], patchBase + buf * XG_PATCH_BYTES + i * 1024);
-                return make_int2(ox, oy);
-            };
-            // records travel through scalar registers, one visit ahead (unconditional loads: a select would make the
-            // compiler wait for them on the spot); the index of the record after that is read from LDS meanwhile
-            XgRec R = recs[__builtin_amdgcn_readfirstlane(sKept[0])];
+            // ---- visits. Records travel through scalar registers, one visit ahead (unconditional loads: a select would
+            // make the compiler wait for them on the spot); the index of the record after that is read from LDS meanwhile
+            int kid = __builtin_amdgcn_readfirstlane(sKept[0]);
             int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]);
+            float4 R0 = recs[kid].r0, R1 = recs[kid].r1, R2 = recs[kid].r2, H0 = recs[kid].h0, H1 = recs[kid].h1, H2 = recs[kid].h2;
             for (int k = 0; k < nk; ++k) {
-                const XgRec Rn = recs[kidN];
+                const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2, NH0 = recs[kidN].h0, NH1 = recs[kidN].h1, NH2 = recs[kidN].h2;
                 const int kidNN = sKept[min(k + 2, nk - 1)];
-                const int2 org = issue(R, 0);     // the patch buffer is free: the previous dense pass has consumed its reads
-                // ---- sparse pass (RFA:631-653 and the reach of the footprint)
-                const int yy = __float_as_int(R.r1.w), zz = __float_as_int(R.r2.w);
+                // ---- the 16 x 16 patch that covers the unit's footprints: it starts at the first footprint pixel of the
+                // corner with the smallest image coordinates (the unit's image extent is < 10.4 pixels; H2.zw = extent + r).
+                // It stays inside the padded record: footprints never leave that, so an origin moved inwards still
+                // covers them. The patch buffer is free: the previous dense pass has consumed its reads.
+                const float cix = R0.x * ucx + R0.y * ucy + R0.z * ucz;
+                const float ciy = R1.x * ucx + R1.y * ucy + R1.z * ucz + fmvh;
+                const float oxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(cix - H2.z))));
+                const float oyf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(ciy - H2.w))));
+                const int ox = min(max((int)oxf, -XH_PAD), SX - XH_PAD - XG_PW);
+                const int oy = min(max((int)oyf, -XH_PAD), SY - XH_PAD - XG_PW);
+                if (dbg != 3) {
+                    // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
+                    const unsigned cell = ((unsigned)__float_as_int(R0.w) * (unsigned)SY + (unsigned)(oy + XH_PAD)) * (unsigned)SX + (unsigned)(ox + XH_PAD);
+                    xg_dma_patch(pk + cell, dOff, patchBase);
+                }
+                // ---- sparse pass (RFA:631-653 and the reach of the footprint), two z at a time
+                const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
-                const float ax = R.r0.x * px + R.r0.y * py, ay = R.r1.x * px + R.r1.y * py, az = R.r2.x * px + R.r2.y * py;
+                const float ax = R0.x * px + R0.y * py, ay = R1.x * px + R1.y * py, az = R2.x * px + R2.y * py;
                 int qn = 0;
 #pragma unroll
-                for (int zi = 0; zi < 4; ++zi) {
-                    const int z = z0 + zi;
-                    const float pz = z - mv / 2;
-                    const float ix = ax + R.r0.z * pz;
-                    float iy = ay + R.r1.z * pz;
-                    const float iz = az + R.r2.z * pz;
-                    iy += mv / 2;
-                    const float zSqr = iz * iz;
-                    const bool zok = !(z < (zz & 0xffff) || z > (zz >> 16));
-                    const bool pass = ((sph >> zi) & 1) && yok && zok && !(zSqr > radiusSqr) &&
-                                      (ix >= reach.x) && (ix <= reach.y) && (iy >= reach.z) && (iy <= reach.w);
-                    const unsigned long long pb = __ballot(pass);
-                    if (pass) sQueue[qn + __popcll(pb & below)] = (unsigned char)((zi << 6) | lane);
-                    qn += __popcll(pb);
+                for (int zp = 0; zp < 2; ++zp) {
+                    const xg_v2f pz2 = zp ? pz23 : pz01;
+                    const xg_v2f ix2 = (xg_v2f){ax, ax} + (xg_v2f){R0.z, R0.z} * pz2;
+                    xg_v2f iy2 = (xg_v2f){ay, ay} + (xg_v2f){R1.z, R1.z} * pz2;
+                    const xg_v2f iz2 = (xg_v2f){az, az} + (xg_v2f){R2.z, R2.z} * pz2;
+                    iy2 += (xg_v2f){fmvh, fmvh};
+                    const xg_v2f zs2 = iz2 * iz2;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int zi = 2 * zp + h, z = z0 + zi;
+                        const float ix = h ? ix2.y : ix2.x, iy = h ? iy2.y : iy2.x, zSqr = h ? zs2.y : zs2.x;
+                        const bool zok = !(z < (zz & 0xffff) || z > (zz >> 16));
+                        const bool pass = ((sph >> zi) & 1) && yok && zok && !(zSqr > radiusSqr) &&
+                                          (ix >= reach.x) && (ix <= reach.y) && (iy >= reach.z) && (iy <= reach.w);
+                        const unsigned long long pb = __ballot(pass);
+                        if (pass) sQueue[qn + __popcll(pb & below)] = qword + zi * 0x40010000;
+                        qn += __popcll(pb);
+                    }
                 }
+                if (dbg == 5 && lane == 0) atomicAdd(reinterpret_cast<int *>(tempV) + min(qn, 256), 1);   // profiling: items per visit
                 // ---- the patch of this visit has landed
                 if (dbg != 1) xg_wait_vm0();
                 // ---- dense pass
-                const float hden = R.da.x * R.da.w - R.da.z * R.da.y;      // a1 * b2 - b1 * a2, as d_hit forms it
-                const float hrden = __builtin_amdgcn_rcpf(hden);
-                const xg_v2f r01x = {R.r0.x, R.r1.x}, r01y = {R.r0.y, R.r1.y}, r01z = {R.r0.z, R.r1.z};
-                const unsigned patchAddr = patchBase;
+                const xg_v2f r01x = {R0.x, R1.x}, r01y = {R0.y, R1.y}, r01z = {R0.z, R1.z};
+                const float uLo = 0.5f - H2.x, uHi = 0.5f + H2.x, tLo = 0.5f - H2.y, tHi = 0.5f + H2.y;
+                // every row of the unit crosses a face when u and t of the unit's centre row keep their distance from 0 and 1
+                // by more than they vary over the unit (3.5 rows in y, 1.5 in z): no per-voxel test then
+                bool allHit;
+                {
+                    const float yc = (float)y0 + 3.5f, zc = (float)z0 + 1.5f;
+                    const float u1 = H0.x * yc + H0.y * zc + H0.z, t1 = H1.x * yc + H1.y * zc + H1.z;
+                    const float eu = 3.5f * fabsf(H0.x) + 1.5f * fabsf(H0.y) + H2.x + 1e-4f, et = 3.5f * fabsf(H1.x) + 1.5f * fabsf(H1.y) + H2.y + 1e-4f;
+                    const bool a1 = (fabsf(u1 - 0.5f) + eu < 0.5f) && (fabsf(t1 - 0.5f) + et < 0.5f);
+                    const bool a2 = (fabsf(u1 + H0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + H1.w - 0.5f) + et < 0.5f);
+                    allHit = __builtin_amdgcn_readfirstlane((int)(a1 || a2)) != 0;
+                }
                 if (dbg != 2) for (int b0 = 0; b0 < qn; b0 += 64) {
                     if (b0 + lane < qn) {
                         const int id = sQueue[b0 + lane];
-                        const float qx = fx0 + (float)(id & 7), qy = fy0 + (float)((id >> 3) & 7), qz = fz0 + (float)(id >> 6);
+                        const float qx = fx0 + (float)(id & 0xff), qy = fy0 + (float)((id >> 8) & 0xff), qz = fz0 + (float)((id >> 16) & 0xff);
                         // image coordinates of the voxel, (x, y) packed, with the reference's own operation order (RFA:643-647):
                         // a float coordinate near 256 has an ulp of 3e-5, which d2 * iDelta turns into 0.3 table entries
                         xg_v2f ixy = r01x * (xg_v2f){qx, qx} + r01y * (xg_v2f){qy, qy} + r01z * (xg_v2f){qz, qz};
                         ixy += (xg_v2f){0.f, fmvh};
-                        const float iz = R.r2.x * qx + R.r2.y * qy + R.r2.z * qz;
+                        const float iz = R2.x * qx + R2.y * qy + R2.z * qz;
                         float zSqr = iz * iz;
-                        // the reference only visits rows that cross the top or bottom face of the slab (RFA:746-750)
-                        bool near = false;
-                        bool hit1 = xg_hit_fast(qy + fmvh, qz + fmvh, R.da.x, R.da.y, R.da.z, R.db.x, R.db.y, hden, hrden, near);
-                        bool hit2 = xg_hit_fast(qy + fmvh, qz + fmvh, R.da.x, R.da.y, R.da.z, R.db.z, R.db.w, hden, hrden, near);
-                        if (__ballot(near)) {
-                            if (near) {
-                                hit1 = d_hit(qy + fmvh, qz + fmvh, R.da.x, R.da.y, R.da.z, R.da.w, R.db.x, R.db.y);
-                                hit2 = d_hit(qy + fmvh, qz + fmvh, R.da.x, R.da.y, R.da.z, R.da.w, R.db.z, R.db.w);
+                        // the reference only visits rows that cross the top or bottom face of the slab (RFA:746-750): affine
+                        // forms of u and t, exact evaluation where one of them lies within its band of 0 or 1
+                        if (!allHit) {
+                            const float vy = qy + fmvh, vz = qz + fmvh;
+                            const xg_v2f ut1 = (xg_v2f){H0.x, H1.x} * (xg_v2f){vy, vy} + (xg_v2f){H0.y, H1.y} * (xg_v2f){vz, vz} + (xg_v2f){H0.z, H1.z};
+                            const xg_v2f ut2 = ut1 + (xg_v2f){H0.w, H1.w};
+                            const float cu1 = fabsf(ut1.x - 0.5f), ct1 = fabsf(ut1.y - 0.5f), cu2 = fabsf(ut2.x - 0.5f), ct2 = fabsf(ut2.y - 0.5f);
+                            bool hit = (cu1 < uLo && ct1 < tLo) || (cu2 < uLo && ct2 < tLo);
+                            const bool unsure = !((cu1 < uLo || cu1 > uHi) && (ct1 < tLo || ct1 > tHi) && (cu2 < uLo || cu2 > uHi) && (ct2 < tLo || ct2 > tHi));
+                            if (__ballot(unsure)) {
+                                if (unsure) {
+                                    const float4 da = recs[kid].da, db = recs[kid].db;
+                                    hit = d_hit(vy, vz, da.x, da.y, da.z, da.w, db.x, db.y) || d_hit(vy, vz, da.x, da.y, da.z, da.w, db.z, db.w);
+                                }
                             }
+                            if (!hit) zSqr = 3.0e38f;      // every tap fails the distance test
                         }
-                        if (!(hit1 || hit2)) zSqr = 3.0e38f;      // every tap fails the distance test
-                        // first pixel of the 4 x 4 footprint, ceil(i - r) (RFA:655-658), and the offsets from it
+                        // first pixel of the 4 x 4 footprint, ceil(i - r) (RFA:655-658)
                         const float fbx = ceilf(ixy.x - fr), fby = ceilf(ixy.y - fr);
                         // distances to the footprint's columns and rows as the reference forms them, i - (float)j (RFA:663,673)
                         const xg_v2f ix2 = {ixy.x, ixy.x}, iy2 = {ixy.y, ixy.y}, fbx2 = {fbx, fbx}, fby2 = {fby, fby};
@@ -319,12 +357,9 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                         const xg_v2f z2 = {zSqr, zSqr};
                         const xg_v2f yz01 = ya * ya + z2, yz23 = yb * yb + z2;
                         const float yz[4] = {yz01.x, yz01.y, yz23.x, yz23.y};
-                        const int ry = (int)fby - org.y, cx = (int)fbx - org.x;       // 0..12 each
-                        const unsigned rowBase = patchAddr + (unsigned)ry * 256u;     // low 8 bits clear
-                        const int c16 = (cx + ry) << 4;
-                        unsigned colAddr[7];
-#pragma unroll
-                        for (int s = 0; s < 7; ++s) colAddr[s] = ((unsigned)(c16 + 16 * s) & 0xf0u) | rowBase;
+                        const int ry = (int)fby - oy, cx = (int)fbx - ox;       // 0..12 each
+                        const __attribute__((address_space(3))) xg_v4f *tap =
+                            (const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)patchBase + (ry * XG_PW + cx);
                         // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
                         int aux[16];
 #pragma unroll
@@ -343,7 +378,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                         for (int t = 0; t < 16; ++t) wB[t] = sBlob[aux[t]];
 #pragma unroll
                         for (int t = 0; t < 16; ++t)
-                            q[t] = *(const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)(colAddr[(t >> 2) + (t & 3)] + (t >> 2) * 256);
+                            q[t] = tap[(t >> 2) * XG_PW + (t & 3)];
                         // (re, im) and (weight, 0) as two packed FMAs per tap; the fourth component is 0 in every record
                         xg_v2f accRI = {0.f, 0.f}, accWZ = {0.f, 0.f};
 #pragma unroll
@@ -353,14 +388,15 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                             accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[t].z, q[t].w}, accWZ);
                         }
                         const float vW = accWZ.x + accWZ.y, vR = accRI.x, vI = accRI.y;
-                        const int ai = id;
+                        const int ai = (unsigned)id >> 24;
                         sAcc[ai] += vW;
                         sAcc[256 + ai] += vR;
                         sAcc[512 + ai] += vI;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                R = Rn;
+                R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
+                kid = kidN;
                 kidN = __builtin_amdgcn_readfirstlane(kidNN);
             }
         }
