@@ -104,14 +104,20 @@ def test_ctf_arrays(gpu, oracle, kind):
 
 
 def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
-    rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
-    if path in ("tiles", "tiles_queue", "cubes", "grid"):
-        rf.set_option("tile_min_spaces", 1)       # output-stationary kernels even for one projection
-        # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes | LDS-fed units
-        rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2, "grid": 3}[path])
-    elif path == "scatter":
-        rf.set_option("tile_min_spaces", 1 << 30)  # atomic scatter kernel
-    o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order")})
+    rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order", "blob_radius")})
+    if path not in (None, "grid"):
+        # the earlier forms of the gridding kernel only exist in XH_EXPERIMENTS=1 builds of the library
+        try:
+            rf.set_option("require_experiments", 1)
+        except xa.XhError:
+            pytest.skip("library built without -DXH_EXPERIMENTS")
+        if path == "scatter":
+            rf.set_option("insert_variant", 3)   # atomic scatter kernel
+        else:
+            rf.set_option("tile_min_spaces", 1)   # output-stationary kernels even for one projection
+            # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes
+            rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2}[path])
+    o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order", "blob_radius")})
     ffts = np.stack([o.prepare_image(im) for im in imgs])
     return rf, o, ffts
 
@@ -161,8 +167,8 @@ def test_insert_many(gpu, oracle, data32, mode, path):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     fast = mode.startswith("fast")
-    if fast and path != "scatter":
-        pytest.skip("--fast always uses the scatter kernel")
+    if fast and path not in ("scatter", "grid"):
+        pytest.skip("--fast: the scatter kernel or the product kernel")
     rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=path, fast=fast)
     n = len(imgs)
     rng = np.random.default_rng(5)
@@ -194,6 +200,25 @@ def test_insert_many(gpu, oracle, data32, mode, path):
     assert ((ew != 0) == (gw != 0)).all()
     assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
     assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+
+
+def test_insert_wide_blob(gpu, oracle, data32):
+    """Blob radius in [2, 3): 6 x 6 footprints (the W = 6 instantiation of the gridding kernel)."""
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
+    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[:12], ang[:12], blob_radius=2.4)
+    for i in range(12):
+        o.insert(ffts[i], synth.euler_matrix(*ang[i]).T)
+    rf.insert(torch.from_numpy(ffts).cuda(), ang[:12])
+    ev, ew = o.temp()
+    gv, gw = rf.temp_spaces()
+    gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+    assert ((ew != 0) == (gw != 0)).all()
+    assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
+    assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+    with pytest.raises(xa.XhError):
+        rf3 = xa.RecFourier(ctx, D, blob_radius=3.2)
+        rf3.insert(torch.from_numpy(ffts[:1]).cuda(), ang[:1])
 
 
 def test_mirror_crop_and_finish_given_same_temp(gpu, oracle, data32):
@@ -276,9 +301,9 @@ def test_tile_kernel_is_deterministic(gpu, data32):
 
 
 @pytest.mark.parametrize("D,n", [(64, 300), (40, 64)])
-def test_two_level_culling_changes_nothing(gpu, D, n):
-    """k_rf_supercull hands every tile the projections that reach its 32^3 super-tile, in launch order: the temp spaces
-    are bit-identical with and without it (same projections per voxel, same order)."""
+def test_launch_chunking_changes_little(gpu, D, n):
+    """tile_max_spaces cuts a call into several launches (each with its own super-tile lists): the same projections reach
+    every voxel in the same order, only the grouping of the float sums changes."""
     xa, ctx, torch = gpu
     g = torch.Generator(device="cuda").manual_seed(D)
     imgs = torch.randn((n, D, D), generator=g, device="cuda")
@@ -288,12 +313,13 @@ def test_two_level_culling_changes_nothing(gpu, D, n):
     c = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda") + 0.5
     m = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda")
     rf.insert(f, ang, ctf=c, modulator=m)
-    on = rf.temp.clone()
+    one = rf.temp.clone()
     rf.reset()
-    rf.set_option("supercull", 0)
+    rf.set_option("tile_max_spaces", 64)
     rf.insert(f, ang, ctf=c, modulator=m)
-    assert torch.equal(rf.temp, on)
-    assert on.abs().max().item() > 0
+    assert ((rf.temp != 0) == (one != 0))[-(rf.mv + 1) ** 3:].all()        # weights: the same voxels
+    assert (rf.temp - one).abs().max().item() <= 2e-6 * one.abs().max().item()
+    assert one.abs().max().item() > 0
 
 
 def test_linearity_of_insertion(gpu, data32):

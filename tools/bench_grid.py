@@ -72,7 +72,11 @@ def main():
         ref = rf.temp
         sc = ref.abs().max().item()
         out["check_vs_variant2_rel"] = (got / args.reps - ref).abs().max().item() / sc
-        out["voxel_sets_equal"] = bool(((got != 0) == (ref != 0)).all().item())
+        d = (got != 0) != (ref != 0)
+        out["voxel_sets_equal"] = not bool(d.any().item())
+        out["voxel_set_diffs"] = int(d.sum().item())
+        if d.any():
+            out["max_abs_at_diffs"] = [got[d].abs().max().item(), ref[d].abs().max().item()]
     print(json.dumps(out))
 
 

@@ -31,6 +31,7 @@
 #define XG_NW 12                // waves per workgroup (= per CU: the LDS budget admits one workgroup)
 #endif
 #define XG_KCAP 256             // surviving projections listed per cull phase
+#define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
 #define XG_PW 18                // patch row stride in pixels: 16 are needed, 18 skews consecutive rows by two bank groups
 #define XG_NDMA 5               // LDS-DMA instructions per patch: 320 slots = 17.8 rows of 18 pixels
 #define XG_PATCH_BYTES (XG_NDMA * 1024)
@@ -46,8 +47,8 @@
 //   r0, r1, r2  rows of the inverse transform (RFA:643-647); .w: image index, minY | maxY << 16, minZ | maxZ << 16 (AABB rows)
 //   h0, h1, h2  the row-visit test (getX, RFA:479-490) as affine forms of (y, z), see xg_hit: (Uy, Uz, U0, dU), (Ty, Tz, T0, dT),
 //               (band of u, band of t, image extent of a unit in x + r, in y + r)
-//   da, db      getX operands for the exact evaluation (d_hit): (u.y, u.z, v.y, v.z), (p0.y, p0.z, p4.y, p4.z)
-struct XgRec { float4 r0, r1, r2, h0, h1, h2, da, db; };
+//   da, db, dc  getX operands for the exact evaluation (d_hit, d_getX): (u.y, u.z, v.y, v.z), (p0.y, p0.z, p4.y, p4.z), (u.x, v.x, p0.x, 0)
+struct XgRec { float4 r0, r1, r2, h0, h1, h2, da, db, dc; };
 
 // the patch copy: XG_NDMA LDS-DMA instructions, every lane's 16 bytes at base + off[i] land at ldsBase + 1024 i + 16 lane
 // (base, ldsBase wave-uniform). M0 carries the LDS address; the compiler keeps nothing in M0 across a statement.
@@ -64,16 +65,16 @@ __device__ __forceinline__ void xg_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)
 typedef float xg_v2f __attribute__((ext_vector_type(2)));
 typedef float xg_v4f __attribute__((ext_vector_type(4)));
 
-// float4 (re*ctf*mod*w, im*ctf*mod*w, mod*w, 0) per pixel, XH_PAD zero cells on every side
+// float4 (re*ctf*mod*w, im*ctf*mod*w, mod*w, 0) per pixel, XG_PAD zero cells on every side
 __global__ void k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
                                const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
 {
-    const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+    const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
     const size_t total = (size_t)n * SY * SX;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    const int x = gid % SX - XH_PAD;
-    const int y = (gid / SX) % SY - XH_PAD;
+    const int x = gid % SX - XG_PAD;
+    const int y = (gid / SX) % SY - XG_PAD;
     const size_t img = gid / ((size_t)SX * SY);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x >= 0 && x < sizeX && y >= 0 && y < sizeY) {
@@ -100,6 +101,7 @@ static void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
     const float huge = 1e30f;
     G.da = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
     G.db = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
+    G.dc = make_float4(S.u[0], S.v[0], S.p0[0], 0.f);
     if (!(std::fabs(den) > 1e-20) || !(std::fabs(a1) > 1e-20) || !std::isfinite(den)) {
         G.h0 = make_float4(0.f, 0.f, 0.5f, 0.f);
         G.h1 = make_float4(0.f, 0.f, 0.5f, 0.f);
@@ -122,6 +124,8 @@ static void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
     G.h2.x = (float)std::min(bu, 1e30); G.h2.y = (float)std::min(bt, 1e30);
 }
 
+// W: footprint width (4 for a blob radius below 2, 6 below 3). FAST: processVoxel (RFA:595-625), nearest pixel, one voxel per row.
+template <int W, bool FAST>
 __global__ void __launch_bounds__(64 * XG_NW, (XG_NW + 3) / 4)
 k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const float *__restrict__ blobTable,
           float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
@@ -140,11 +144,12 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     const unsigned char *sPatch = lds + XG_LDS_PATCH + wv * XG_PATCH_BYTES;
     const unsigned patchBase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)sPatch;
     const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
-    const int SX = sizeX + 2 * XH_PAD, SY = sizeY + 2 * XH_PAD;
+    const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
 
     for (int i = tid; i < XH_BLOB_TABLE + 4; i += 64 * XG_NW) sBlob[i] = i < XH_BLOB_TABLE ? blobTable[i] : 0.f;
-    const float fr = (float)blobRadius;
-    const float maxDistanceSqr = (sizeX + blobRadius) * (sizeX + blobRadius);
+    const float fr = FAST ? 0.f : (float)blobRadius;
+    const float frCull = FAST ? 0.5f : fr;       // --fast: the voxel nearest to the crossing lies up to half a voxel off the plane
+    const float maxDistanceSqr = (sizeX + (FAST ? 0.0 : blobRadius)) * (sizeX + (FAST ? 0.0 : blobRadius));
     const float radiusSqr = blobRadius * blobRadius;
     const int lx = lane & 7, ly = lane >> 3;
     const float fmvh = (float)(mv / 2);
@@ -203,7 +208,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
         if (tileP < 0) break;
         const unsigned packed = (unsigned)tileP;
         const int sub = t & 7;
-        const int tx = packed & 0xff, ty = (packed >> 8) & 0xff, tz = (packed >> 16) & 0xff;
+        const int tx = packed & 0x3ff, ty = (packed >> 10) & 0x3ff, tz = (packed >> 20) & 0x3ff;
         const int x0 = tx * 16 + (sub & 1) * 8, y0 = ty * 16 + ((sub >> 1) & 1) * 8, z0 = tz * 8 + (sub >> 2) * 4;
         const int x = x0 + lx, y = y0 + ly;
         const float px = x - mv / 2, py = y - mv / 2;
@@ -245,7 +250,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     // support function of the box of voxel centres (half extents 3.5, 3.5, 1.5), never wider than its sphere
                     const float hn = fminf(5.2f, 3.5f * (fabsf(n.x) + fabsf(n.y)) + 1.5f * fabsf(n.z) + 0.02f);
                     const float hx = fminf(5.2f, 3.5f * (fabsf(xv.x) + fabsf(xv.y)) + 1.5f * fabsf(xv.z) + 0.02f);
-                    keep = (fabsf(dn) <= fr + hn) && (dx >= -(fr + hx)) && (dx <= sizeX + fr + hx);
+                    keep = (fabsf(dn) <= frCull + hn) && (dx >= -(frCull + hx)) && (dx <= sizeX + frCull + hx);
                 }
                 const unsigned long long bal = __ballot(keep);
                 if (keep) sKept[nk + __popcll(bal & below)] = sIdx;
@@ -263,6 +268,41 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
             for (int k = 0; k < nk; ++k) {
                 const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2, NH0 = recs[kidN].h0, NH1 = recs[kidN].h1, NH2 = recs[kidN].h2;
                 const int kidNN = sKept[min(k + 2, nk - 1)];
+                if constexpr (FAST) {
+                    // processVoxel (RFA:595-625) over the traversal of a zero-thickness slab (RFA:743-761): every row (y, z)
+                    // that crosses the image plane gives its voxel nearest to the crossing the nearest pixel. lane <-> row.
+                    if (lane < 32) {
+                        const int ry = lane & 7, rz = lane >> 3, vy = y0 + ry, vz = z0 + rz;
+                        const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
+                        const float4 da = recs[kid].da, db = recs[kid].db, dc = recs[kid].dc;
+                        const float ua[3] = {dc.x, da.x, da.y}, va[3] = {dc.y, da.z, da.w}, p0[3] = {dc.z, db.x, db.y};
+                        float hitX;
+                        const bool in = !(vy < (yy & 0xffff) || vy > (yy >> 16) || vz < (zz & 0xffff) || vz > (zz >> 16)) && vy <= mv && vz <= mv;
+                        if (in && d_getX(hitX, (float)vy, (float)vz, ua, va, p0)) {
+                            const int vx = (int)(hitX + 0.5f);
+                            const float qx = vx - mv / 2, qy = vy - mv / 2, qz = vz - mv / 2;
+                            if (vx >= x0 && vx < x0 + 8 && vx <= mv && !(qx * qx + qy * qy + qz * qz > maxDistanceSqr)) {
+                                const float ix = R0.x * qx + R0.y * qy + R0.z * qz;
+                                const float iy = R1.x * qx + R1.y * qy + R1.z * qz;
+                                int imgX = (int)(ix + 0.5f);
+                                imgX = imgX > sizeX - 1 ? sizeX - 1 : imgX;
+                                imgX = imgX < 0 ? 0 : imgX;
+                                int imgY = (int)(iy + 0.5f + mv / 2);
+                                imgY = imgY > sizeY - 1 ? sizeY - 1 : imgY;
+                                imgY = imgY < 0 ? 0 : imgY;
+                                const float4 q = pk[((size_t)__float_as_int(R0.w) * SY + (imgY + XG_PAD)) * SX + (imgX + XG_PAD)];
+                                const int ai = rz * 64 + ry * 8 + (vx - x0);
+                                sAcc[ai] += q.z;
+                                sAcc[256 + ai] += q.x;
+                                sAcc[512 + ai] += q.y;
+                            }
+                        }
+                    }
+                    R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
+                    kid = kidN;
+                    kidN = __builtin_amdgcn_readfirstlane(kidNN);
+                    continue;
+                }
                 // ---- the 16 x 16 patch that covers the unit's footprints: it starts at the first footprint pixel of the
                 // corner with the smallest image coordinates (the unit's image extent is < 10.4 pixels; H2.zw = extent + r).
                 // It stays inside the padded record: footprints never leave that, so an origin moved inwards still
@@ -271,11 +311,11 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 const float ciy = R1.x * ucx + R1.y * ucy + R1.z * ucz + fmvh;
                 const float oxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(cix - H2.z))));
                 const float oyf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(ciy - H2.w))));
-                const int ox = min(max((int)oxf, -XH_PAD), SX - XH_PAD - XG_PW);
-                const int oy = min(max((int)oyf, -XH_PAD), SY - XH_PAD - XG_PW);
+                const int ox = min(max((int)oxf, -XG_PAD), SX - XG_PAD - XG_PW);       // floats: the conversion then runs on the scalar side
+                const int oy = min(max((int)oyf, -XG_PAD), SY - XG_PAD - XG_PW);
                 if (dbg != 3) {
                     // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
-                    const unsigned cell = ((unsigned)__float_as_int(R0.w) * (unsigned)SY + (unsigned)(oy + XH_PAD)) * (unsigned)SX + (unsigned)(ox + XH_PAD);
+                    const unsigned cell = ((unsigned)__float_as_int(R0.w) * (unsigned)SY + (unsigned)(oy + XG_PAD)) * (unsigned)SX + (unsigned)(ox + XG_PAD);
                     xg_dma_patch(pk + cell, dOff, patchBase);
                 }
                 // ---- sparse pass (RFA:631-653 and the reach of the footprint), two z at a time
@@ -347,45 +387,71 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                             }
                             if (!hit) zSqr = 3.0e38f;      // every tap fails the distance test
                         }
-                        // first pixel of the 4 x 4 footprint, ceil(i - r) (RFA:655-658)
+                        // first pixel of the W x W footprint, ceil(i - r) (RFA:655-658)
                         const float fbx = ceilf(ixy.x - fr), fby = ceilf(ixy.y - fr);
-                        // distances to the footprint's columns and rows as the reference forms them, i - (float)j (RFA:663,673)
-                        const xg_v2f ix2 = {ixy.x, ixy.x}, iy2 = {ixy.y, ixy.y}, fbx2 = {fbx, fbx}, fby2 = {fby, fby};
-                        const xg_v2f xa = ix2 - (fbx2 + (xg_v2f){0.f, 1.f}), xb = ix2 - (fbx2 + (xg_v2f){2.f, 3.f});
-                        const xg_v2f ya = iy2 - (fby2 + (xg_v2f){0.f, 1.f}), yb = iy2 - (fby2 + (xg_v2f){2.f, 3.f});
-                        const xg_v2f xs01 = xa * xa, xs23 = xb * xb;
-                        const xg_v2f z2 = {zSqr, zSqr};
-                        const xg_v2f yz01 = ya * ya + z2, yz23 = yb * yb + z2;
-                        const float yz[4] = {yz01.x, yz01.y, yz23.x, yz23.y};
                         const int ry = (int)fby - oy, cx = (int)fbx - ox;       // 0..12 each
                         const __attribute__((address_space(3))) xg_v4f *tap =
                             (const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)patchBase + (ry * XG_PW + cx);
-                        // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
-                        int aux[16];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const xg_v2f ya2 = {yz[a], yz[a]};
-                            const xg_v2f d01 = xs01 + ya2, d23 = xs23 + ya2;
-                            const xg_v2f t01 = d01 * idel2 + half2, t23 = d23 * idel2 + half2;
-                            aux[a * 4 + 0] = (int)(d01.x > radiusSqr ? limf : t01.x);
-                            aux[a * 4 + 1] = (int)(d01.y > radiusSqr ? limf : t01.y);
-                            aux[a * 4 + 2] = (int)(d23.x > radiusSqr ? limf : t23.x);
-                            aux[a * 4 + 3] = (int)(d23.y > radiusSqr ? limf : t23.y);
-                        }
-                        float wB[16];
-                        xg_v4f q[16];
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) wB[t] = sBlob[aux[t]];
-#pragma unroll
-                        for (int t = 0; t < 16; ++t)
-                            q[t] = tap[(t >> 2) * XG_PW + (t & 3)];
                         // (re, im) and (weight, 0) as two packed FMAs per tap; the fourth component is 0 in every record
                         xg_v2f accRI = {0.f, 0.f}, accWZ = {0.f, 0.f};
+                        if constexpr (W == 4) {
+                            // distances to the footprint's columns and rows as the reference forms them, i - (float)j (RFA:663,673)
+                            const xg_v2f ix2 = {ixy.x, ixy.x}, iy2 = {ixy.y, ixy.y}, fbx2 = {fbx, fbx}, fby2 = {fby, fby};
+                            const xg_v2f xa = ix2 - (fbx2 + (xg_v2f){0.f, 1.f}), xb = ix2 - (fbx2 + (xg_v2f){2.f, 3.f});
+                            const xg_v2f ya = iy2 - (fby2 + (xg_v2f){0.f, 1.f}), yb = iy2 - (fby2 + (xg_v2f){2.f, 3.f});
+                            const xg_v2f xs01 = xa * xa, xs23 = xb * xb;
+                            const xg_v2f z2 = {zSqr, zSqr};
+                            const xg_v2f yz01 = ya * ya + z2, yz23 = yb * yb + z2;
+                            const float yz[4] = {yz01.x, yz01.y, yz23.x, yz23.y};
+                            // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
+                            int aux[16];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const xg_v2f w2 = {wB[t], wB[t]};
-                            accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[t].x, q[t].y}, accRI);
-                            accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[t].z, q[t].w}, accWZ);
+                            for (int a = 0; a < 4; ++a) {
+                                const xg_v2f ya2 = {yz[a], yz[a]};
+                                const xg_v2f d01 = xs01 + ya2, d23 = xs23 + ya2;
+                                const xg_v2f t01 = d01 * idel2 + half2, t23 = d23 * idel2 + half2;
+                                aux[a * 4 + 0] = (int)(d01.x > radiusSqr ? limf : t01.x);
+                                aux[a * 4 + 1] = (int)(d01.y > radiusSqr ? limf : t01.y);
+                                aux[a * 4 + 2] = (int)(d23.x > radiusSqr ? limf : t23.x);
+                                aux[a * 4 + 3] = (int)(d23.y > radiusSqr ? limf : t23.y);
+                            }
+                            float wB[16];
+                            xg_v4f q[16];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) wB[t] = sBlob[aux[t]];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t)
+                                q[t] = tap[(t >> 2) * XG_PW + (t & 3)];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) {
+                                const xg_v2f w2 = {wB[t], wB[t]};
+                                accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[t].x, q[t].y}, accRI);
+                                accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[t].z, q[t].w}, accWZ);
+                            }
+                        } else {
+                            // wider blobs: the same taps row by row
+                            float xs[W];
+#pragma unroll
+                            for (int b = 0; b < W; ++b) { const float xD = ixy.x - (fbx + (float)b); xs[b] = xD * xD; }
+#pragma unroll
+                            for (int a = 0; a < W; ++a) {
+                                const float yD = ixy.y - (fby + (float)a);
+                                const float yzS = yD * yD + zSqr;
+                                float wB[W];
+                                xg_v4f q[W];
+#pragma unroll
+                                for (int b = 0; b < W; ++b) {
+                                    const float d2 = xs[b] + yzS;
+                                    wB[b] = sBlob[(int)(d2 > radiusSqr ? limf : d2 * iDeltaSqrt + 0.5f)];
+                                    q[b] = tap[a * XG_PW + b];
+                                }
+#pragma unroll
+                                for (int b = 0; b < W; ++b) {
+                                    const xg_v2f w2 = {wB[b], wB[b]};
+                                    accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[b].x, q[b].y}, accRI);
+                                    accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[b].z, q[b].w}, accWZ);
+                                }
+                            }
                         }
                         const float vW = accWZ.x + accWZ.y, vR = accRI.x, vI = accRI.y;
                         const int ai = (unsigned)id >> 24;
