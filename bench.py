@@ -15,14 +15,23 @@ region.  Weak scaling: per-GPU work is fixed as N grows.
 
 One JSON line on rank 0 (see the driver contract in the task statement), with
   roofline      -- the kernel that dominates the timed region, algorithmic work / HIP-event time
+  worst_case    -- the same step with the data-dependent shortcuts of the matcher switched off
+  value_with_h2d -- the same steps with every batch streamed from page-locked host memory
   cpu_baseline  -- the CPU oracle ("port" of the reference algorithm; Xmipp itself cannot be
                    built here: xmippCore/FFTW absent) timed on a bounded sample on rank 0.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes, one per
+GPU, rendezvous on 127.0.0.1) and relays rank 0's line; under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,7 +41,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -49,7 +58,47 @@ def parse():
     ap.add_argument("--chunk-rows", type=float, default=0, help="correlation rows per chunk of the matcher (0: library default)")
     ap.add_argument("--k0", type=int, default=-1, help="two-level contraction cut (0 auto, >= nk off); default: automatic")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
-    return ap.parse_args()
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
+    ap.add_argument("--unique-batches", type=int, default=0, help="--mode grid: distinct particle batches cycled (0: 4 = 16384 projections at --batch 4096)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(script, argv, n, python=sys.executable, extra_env=None, timeout=None):
+    """Start n fresh processes of `script argv` as ranks 0..n-1 of one node (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR =
+    127.0.0.1, MASTER_PORT = a free port). Rank 0 inherits stdout, the others write theirs to stderr. Returns 0 when
+    every rank exits 0, else the first non-zero exit code (the surviving ranks are terminated). The caller must not have
+    touched the GPU: the children are new processes, nothing is exec'ed over an initialised runtime."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([python, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:
+                    other.terminate()
+        if t_end is not None and time.time() > t_end:
+            for other in live:
+                other.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
 
 
 def smooth_noise(torch, n, D, gen, device, sigma_px=3.0):
@@ -85,21 +134,44 @@ def phantom_volume(torch, D, gen, device, nblobs=20):
     return vol.contiguous()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: build once (a child process, nothing here touches the GPU), then start the ranks
+        rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, stdout=sys.stderr)
+        if rc != 0:
+            sys.exit(rc)
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0 or not os.path.exists(os.path.join(ROOT, 'xmipp3_amd', 'libxmipp_hip.so')):
-        ge.build()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself; under torchrun pass the same N)")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus
+        # one rank per node builds (csrc/build.sh and host/build.sh write into shared directories), the others wait
+        if local == 0:
+            ge.build()
         dist.barrier()
+    else:
+        ge.build()
     import xmipp3_amd as xa
     from tests import synth
 
@@ -123,21 +195,27 @@ def main():
         refs = ((refs - refs.mean()) / refs.std()).contiguous()
     else:
         refs = smooth_noise(torch, nrefs, D, genr, dev)
-    idx = torch.randint(0, nrefs, (B,), generator=gen, device=dev)
-    # particle = reference, random in-plane rotation, mirror with p = 0.5, shift U{-3..3}^2, white noise at SNR 0.1
-    th = torch.rand((B,), generator=gen, device=dev) * (2 * math.pi)
-    mir = (torch.rand((B,), generator=gen, device=dev) < 0.5).float() * 2 - 1          # -1: mirrored in x
-    shf = torch.randint(-3, 4, (B, 2), generator=gen, device=dev).float()
-    rot = torch.zeros((B, 2, 3), device=dev)
-    rot[:, 0, 0] = torch.cos(th) * mir; rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th) * mir; rot[:, 1, 1] = torch.cos(th)
-    rot[:, :, 2] = shf * (2.0 / D)
-    particles = torch.empty((B, D, D), device=dev)
-    for b0 in range(0, B, 512):
-        sl = slice(b0, min(B, b0 + 512))
-        grid = torch.nn.functional.affine_grid(rot[sl], (rot[sl].shape[0], 1, D, D), align_corners=False)
-        particles[sl] = torch.nn.functional.grid_sample(refs[idx[sl]][:, None], grid, mode="bilinear", padding_mode="zeros",
-                                                        align_corners=False)[:, 0]
-    particles = (particles + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
+    def make_batch():
+        """particle = reference, random in-plane rotation, mirror with p = 0.5, shift U{-3..3}^2, white noise at SNR 0.1"""
+        idx = torch.randint(0, nrefs, (B,), generator=gen, device=dev)
+        th = torch.rand((B,), generator=gen, device=dev) * (2 * math.pi)
+        mir = (torch.rand((B,), generator=gen, device=dev) < 0.5).float() * 2 - 1          # -1: mirrored in x
+        shf = torch.randint(-3, 4, (B, 2), generator=gen, device=dev).float()
+        rot = torch.zeros((B, 2, 3), device=dev)
+        rot[:, 0, 0] = torch.cos(th) * mir; rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th) * mir; rot[:, 1, 1] = torch.cos(th)
+        rot[:, :, 2] = shf * (2.0 / D)
+        out = torch.empty((B, D, D), device=dev)
+        for b0 in range(0, B, 512):
+            sl = slice(b0, min(B, b0 + 512))
+            grid = torch.nn.functional.affine_grid(rot[sl], (rot[sl].shape[0], 1, D, D), align_corners=False)
+            out[sl] = torch.nn.functional.grid_sample(refs[idx[sl]][:, None], grid, mode="bilinear", padding_mode="zeros",
+                                                      align_corners=False)[:, 0]
+        return (out + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
+
+    # --mode grid is BASELINE config 3: >= 16384 distinct projections cycled, fresh orientations per use
+    nuniq = (args.unique_batches or 4) if args.mode == "grid" else 1
+    batches = [make_batch() for _ in range(nuniq)]
+    particles = batches[0]
     rng = np.random.default_rng(100 + rank)
     from xmipp3_amd.api import ctf_params
     ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d))
@@ -157,16 +235,20 @@ def main():
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     t_grid = ctx.timer()
     grid_ms = []
+    step_no = [0]
 
-    def step(record):
+    def step(record, parts=None):
         ang = None
-        imgs = particles
+        if parts is None:
+            parts = batches[step_no[0] % nuniq]
+        step_no[0] += 1
+        imgs = parts
         if pm is not None:
-            refno, psi, flip = pm.match(particles)
+            refno, psi, flip = pm.match(parts)
             if record:
                 st = pm.last_stats()
                 rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
-            sx, sy, cc = pm.translate(particles, refno, psi, flip)
+            sx, sy, cc = pm.translate(parts, refno, psi, flip)
             h_ref = refno.cpu().numpy()
             h_psi = psi.cpu().numpy()
             shifts = np.stack([sx.cpu().numpy(), sy.cpu().numpy()], 1)
@@ -175,7 +257,7 @@ def main():
             ang = synth.random_angles(B, rng)
             shifts = rng.uniform(-3, 3, (B, 2))
         if rf is not None:
-            imgs = rf.shift_images(particles, shifts)
+            imgs = rf.shift_images(parts, shifts)
             c, m = rf.ctf_arrays(ctf_arr)
             fft = rf.prepare_images(imgs)
             if record:
@@ -221,6 +303,74 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    stage = pm.stage_ms(reset=False) if pm is not None else {}
+    k_ms, k_launches = rf.kernel_ms(reset=False) if rf is not None else (0.0, 0)
+    stats_timed = pm.last_stats() if pm is not None else None
+
+    # ---- extra legs, outside the timed region (every rank runs them: same collectives, same barriers)
+    extra = {}
+    if not args.no_extra_legs:
+        # (1) every batch streamed from page-locked host memory: two device buffers, the copy of batch k+1 on its own
+        # stream while batch k is worked on
+        nh = max(2, min(args.steps, 4))
+        host = [b.cpu().pin_memory() for b in batches[:2]] if nuniq > 1 else [particles.cpu().pin_memory()]
+        dbuf = [torch.empty_like(particles), torch.empty_like(particles)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def fetch(k):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done[k & 1])
+                dbuf[k & 1].copy_(host[k % len(host)], non_blocking=True)
+                ready[k & 1].record(copy_stream)
+        for e in done:
+            e.record()
+        barrier()
+        th0 = time.perf_counter()
+        fetch(0)
+        for k in range(nh):
+            if k + 1 < nh:
+                fetch(k + 1)
+            torch.cuda.current_stream().wait_event(ready[k & 1])
+            step(False, dbuf[k & 1])
+            done[k & 1].record()
+        finish()
+        barrier()
+        th1 = time.perf_counter()
+        el = th1 - th0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        extra["value_with_h2d"] = nh * B * world / el
+        extra["h2d_leg"] = {"steps": nh, "bytes_per_step_per_gpu": B * D * D * 4,
+                            "what": "same steps + finish, every batch copied from page-locked host memory on a second stream"}
+        del host, dbuf
+        # (2) the matcher without its data-dependent shortcuts: every correlation row contracted over all frequencies and
+        # transformed (S3 branch and bound off, two-level cut off)
+        if pm is not None and not args.no_prune:
+            pm.set_option("prune", 0)
+            pm.set_option("k0", 1 << 20)
+            step(False)            # warm-up of the other code path
+            finish()
+            barrier()
+            tw0 = time.perf_counter()
+            nw = 2
+            for _ in range(nw):
+                step(False)
+            finish()
+            barrier()
+            el = time.perf_counter() - tw0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            extra["worst_case"] = {"value": nw * B * world / el, "unit": "particles/s", "steps": nw,
+                                   "what": "branch and bound of the row transforms off, contraction over all frequencies: "
+                                           "what a gallery and particles with flat correlation peaks would cost"}
+            pm.set_option("prune", 1)
+            pm.set_option("k0", 0 if args.k0 < 0 else args.k0)
 
     if rank != 0:
         if world > 1:
@@ -229,10 +379,8 @@ def main():
 
     total_particles = args.steps * B * world
     value = total_particles / elapsed
-    stage = pm.stage_ms(reset=False) if pm is not None else {}
     stage["gridding_insert"] = float(sum(grid_ms))          # pack + spaces upload + kernel
-    k_ms, k_launches = rf.kernel_ms(reset=False) if rf is not None else (0.0, 0)
-    stage["k_rf_insert_cubes"] = k_ms                        # HIP events around the kernel launches only
+    stage["k_rf_grid"] = k_ms                                # HIP events around the kernel launches only
     # ---- roofline of the dominant kernel (per launch = per chunk; reported per particle-second)
     N = pm.N if pm is not None else 2 * int(math.pi * (D // 2 - 1))
     ncoef = pm.ncoef if pm is not None else 0
@@ -242,34 +390,41 @@ def main():
     bytes_grid = 4 * D * D + nvox * 24                     # image read + 12 B read + 12 B write per voxel
     cand = {}
     if pm is not None and stage.get("idft_max", 0) > 0:
-        # packed complex inverse DFT of length N per (particle, reference): 5 N log2 N flops
-        fl = (rows - rows_seen[1]) * 5.0 * N * math.log2(N)   # rows actually transformed
-        cand["k_pm_idft_max"] = ("mfma", fl / (stage["idft_max"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["idft_max"])
-        fl2 = rows * 8.0 * ncoef                            # 4 real FMAs per ring coefficient
-        cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"])
+        # EXECUTED work only. Rows transformed: 5 N log2 N flops of a packed complex inverse DFT each; contraction:
+        # 4 real FMAs per (row, ring coefficient below the two-level cut K0) -- the rows that survive the branch and
+        # bound get their remaining frequencies inside k_pm_idft_max, counted there
+        K0, nk = pm.two_level_cut()
+        surv = rows - rows_seen[1]
+        frac_low = min(1.0, K0 / float(nk))
+        fl = surv * (5.0 * N * math.log2(N) + 8.0 * ncoef * (1.0 - frac_low))
+        cand["k_pm_idft_max"] = ("mfma", fl / (stage["idft_max"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["idft_max"],
+                                 f"{surv} of {rows} rows transformed (the rest pruned by the branch and bound)")
+        fl2 = rows * 8.0 * ncoef * frac_low
+        cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"],
+                                 f"frequencies below the two-level cut K0 = {K0} of {nk}")
     if rf is not None and k_ms > 0:
         by = args.steps * B * bytes_grid
-        cand["k_rf_insert_cubes"] = ("hbm", by / (k_ms * 1e-3) / 1e9, 8000.0, "GB/s", k_ms)
+        cand["k_rf_grid"] = ("hbm", by / (k_ms * 1e-3) / 1e9, 8000.0, "GB/s", k_ms, "algorithmic bytes of SURVEY.md 8d")
     dom = max(cand, key=lambda k: cand[k][4]) if cand else None
     roofline = None
     if dom:
-        b, ach, peak, unit, ms = cand[dom]
+        b, ach, peak, unit, ms, note = cand[dom]
         roofline = {"kernel": dom, "bound": b, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                    "traffic": None, "ms_in_timed_region": ms}
-        if dom == "k_rf_insert_cubes":
+                    "traffic": None, "ms_in_timed_region": ms, "counted": note}
+        if dom == "k_rf_grid":
             roofline["launches"] = k_launches
             roofline["avg_launch_ms"] = k_ms / max(1, k_launches)
             roofline["algorithmic_bytes_per_launch"] = B * bytes_grid
             roofline["algorithmic_MB_per_projection"] = bytes_grid / 1e6
             # HBM bytes per launch from the PMC passes of tools/collect_traffic.sh over this same command
             # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); PMC cannot be read from inside the process
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_rf_insert_cubes.json")
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_rf_grid.json")
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 if tj.get("projections_per_launch") == B:
                     roofline["traffic"] = tj["traffic_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/traffic_k_rf_insert_cubes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-    others = {k: {"bound": v[0], "achieved": v[1], "peak": v[2], "unit": v[3], "frac": v[1] / v[2], "ms": v[4]}
+                    roofline["traffic_source"] = "profiles/traffic_k_rf_grid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    others = {k: {"bound": v[0], "achieved": v[1], "peak": v[2], "unit": v[3], "frac": v[1] / v[2], "ms": v[4], "counted": v[5]}
               for k, v in cand.items() if k != dom}
 
     out = {
@@ -280,12 +435,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references",
                    "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "particles_per_step_per_gpu": B,
-                   "particles_total": total_particles, "parallelism": f"particle shards x{world}, one all-reduce"},
+                   "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
+                   "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
         "stage_ms": stage, "finish_and_allreduce_s": finish_s,
     }
+    out.update(extra)
     if pm is not None:
-        out["rescored_fraction"] = pm.last_stats()["rescored_particles"] / float(B)
+        out["rescored_fraction"] = stats_timed["rescored_particles"] / float(B)
         # exact branch and bound of the row transforms: rows whose coefficient moduli cannot reach the
         # particle's best value are not transformed; the fraction depends on the data
         out["s3_rows_pruned_fraction"] = rows_seen[1] / float(max(1, rows_seen[0]))
@@ -294,13 +451,16 @@ def main():
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, host cores of rank 0
     if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N=1 only
         from oracle import pyoracle as o
-        ns = min(B, args.cpu_sample or (32 if D >= 256 else 64))
+        ns = min(B, args.cpu_sample or (256 if D >= 256 else 512))
+        ncores = o.lib().xo_num_threads()
         h_refs = refs.cpu().numpy()
         h_parts = particles[:ns].cpu().numpy()
         tb0 = time.perf_counter()
         opm = o.PM(h_refs) if args.mode != "grid" else None
         tb_setup = time.perf_counter() - tb0
-        orf = o.RF(D, use_ctf=True, min_ctf=0.01) if args.mode != "match" else None
+        # gridding: one private volume per thread, like RF's worker threads (1.6 GB each at 256 px): at most 8
+        nthr = max(1, min(8, ncores, ns)) if args.mode != "match" else 0
+        orfs = [o.RF(D, use_ctf=True, min_ctf=0.01) for _ in range(nthr)]
         tb1 = time.perf_counter()
         if opm is not None:
             er, ep, ef, _ = opm.match(h_parts)
@@ -309,24 +469,56 @@ def main():
         else:
             oang = synth.random_angles(ns, rng)
             ex = ey = np.zeros(ns)
-        if orf is not None:
-            for i in range(ns):
+        tb_match = time.perf_counter()
+
+        def grid_worker(t):
+            orf = orfs[t]
+            for i in range(t, ns, nthr):            # the ctypes calls release the GIL
                 img = o.translate2d(h_parts[i], ex[i], ey[i], degree=3, wrap=True)
                 cpar = o.ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=ctfs[i].DeltafU, DeltafV=ctfs[i].DeltafV)
                 c, m = orf.ctf_arrays(cpar)
                 orf.insert(orf.prepare_image(img), synth.euler_matrix(*oang[i]).T, ctf=c, modulator=m)
+        thr = [threading.Thread(target=grid_worker, args=(t,)) for t in range(nthr)]
+        for t in thr:
+            t.start()
+        for t in thr:
+            t.join()
         tb2 = time.perf_counter()
         out["cpu_baseline"] = {
-            "value": ns / (tb2 - tb1), "unit": "particles/s", "cores": min(o.lib().xo_num_threads(), ns), "kind": "port",
+            "value": ns / (tb2 - tb1), "unit": "particles/s", "cores": max(min(ncores, ns), nthr), "kind": "port",
+            "cpu": cpu_model(), "match_s": tb_match - tb1, "gridding_s": tb2 - tb_match, "gridding_threads": nthr,
             "sample": f"{ns} of the same {D}x{D} particles vs the same {nrefs} references: oracle match+translate "
-                      f"(OpenMP over particles) then shift+CTF+FFT+gridding (1 thread, like RFA's single compute thread); "
-                      f"library setup {tb_setup:.1f}s excluded on both sides; finaliser excluded"}
+                      f"(OpenMP over particles, {ncores} threads) then shift+CTF+FFT+gridding on {nthr} threads with a private "
+                      f"volume each; library setup {tb_setup:.1f}s excluded on both sides; finaliser excluded"}
         if opm is not None and pm is not None:
-            # the sample doubles as a parity spot check at full size
+            # the sample doubles as a parity spot check at full size: orientations ...
             g_ref, g_psi, g_flip = pm.match(particles[:ns].contiguous())
             out["parity_sample_identical"] = bool(np.array_equal(g_ref.cpu().numpy(), er[:, 0]) and
                                                   np.array_equal(g_psi.cpu().numpy(), ep[:, 0]) and
                                                   np.array_equal(g_flip.cpu().numpy(), ef[:, 0]))
+            out["parity_sample_particles"] = ns
+        if rf is not None and nthr > 0:
+            # ... and the gridded Fourier volume: the device grids the first particles of the sample with the oracle's
+            # orientations and shifts (shift, CTF planes, FFT, insertion) and the temp spaces are compared
+            nv = min(ns, 32)
+            chk = o.RF(D, use_ctf=True, min_ctf=0.01)
+            for i in range(nv):
+                img = o.translate2d(h_parts[i], ex[i], ey[i], degree=3, wrap=True)
+                cpar = o.ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=ctfs[i].DeltafU, DeltafV=ctfs[i].DeltafV)
+                c, m = chk.ctf_arrays(cpar)
+                chk.insert(chk.prepare_image(img), synth.euler_matrix(*oang[i]).T, ctf=c, modulator=m)
+            ev, ew = chk.temp()
+            rf.reset()
+            simg = rf.shift_images(particles[:nv].contiguous(), np.stack([ex[:nv], ey[:nv]], 1))
+            c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs[:nv]))
+            rf.insert(rf.prepare_images(simg), oang[:nv], ctf=c, modulator=m)
+            gv, gw = rf.temp_spaces()
+            gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+            out["parity_volume_rel_err"] = float(np.abs(gv - ev).max() / np.abs(ev).max())
+            out["parity_weights_rel_err"] = float(np.abs(gw - ew).max() / np.abs(ew).max())
+            out["parity_volume_voxel_sets_equal"] = bool(((gw != 0) == (ew != 0)).all())
+            out["parity_volume_particles"] = nv
+            rf.reset()
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -71,3 +71,42 @@ def test_allreduce_of_sharded_reconstruction_gloo_world2(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert "ok 50" in outs[0] + outs[1] and "ok 51" in outs[0] + outs[1]
+
+
+STUB = textwrap.dedent('''
+    import os, sys
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == int(sys.argv[1]) and rank == int(os.environ["LOCAL_RANK"])
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if len(sys.argv) > 2 and sys.argv[2] == "fail" and rank == 1:
+        sys.exit(3)
+    dist.barrier()
+    if rank == 0:
+        print("sum", t.item())
+    dist.destroy_process_group()
+''')
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher: bench.spawn_ranks starts N fresh ranks (here a gloo stub instead of
+    the GPU body), relays rank 0's output and fails when any rank fails."""
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    out = subprocess.run([sys.executable, "-c",
+                          f"import sys; sys.path.insert(0, {ROOT!r}); import bench; sys.exit(bench.spawn_ranks({str(stub)!r}, ['2'], 2, timeout=120))"],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "sum 3.0" in out.stdout
+    rc = bench.spawn_ranks(str(stub), ["2", "fail"], 2, timeout=120)
+    assert rc == 3
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
