@@ -168,11 +168,14 @@ size_t xh_rf_cropped_floats(const xh_rf *rf);
  * before finishing whatever has to be summed later. */
 int xh_rf_cropped_export(xh_rf *rf, float *d_dst);
 int xh_rf_cropped_import(xh_rf *rf, const float *d_src, int32_t add);
-/* Sum the cropped spaces of n handles (any mix of devices of this node) into rfs[0]: binary tree,
- * peer copies over xGMI into the receiver's scratch + one add kernel per pair; synchronous. Replaces
- * the 2*(mv+1)^2 MPI_Reduce calls of mpi_reconstruct_fourier_accel.cpp:245-266 for a single-process,
- * thread-per-device host (the torch.distributed host all-reduces the same buffer instead, see
- * xh_rf_attach_temp). Handles other than rfs[0] keep their own partial sums (level-wise). */
+/* Sum the cropped spaces of n handles (any mix of devices of this node) into rfs[0]; synchronous. Handles
+ * that share a device are added there first; the first handle of every device then takes part in ONE
+ * in-place RCCL all-reduce (ncclCommInitAll over the devices, grouped ncclAllReduce, float sum) over all
+ * xGMI links, so each of those ends up with the total. RCCL is bound at run time; if it cannot be loaded
+ * or initialised the call says so on stderr and falls back to a binary tree of peer copies + adds. Replaces
+ * the 2*(mv+1)^2 MPI_Reduce calls of mpi_reconstruct_fourier_accel.cpp:245-266 (GPU variant:
+ * parallel_adapt_cuda/mpi_reconstruct_fourier_gpu.cpp:250-268) for a single-process, thread-per-device
+ * host (the torch.distributed host all-reduces the same buffer instead, see xh_rf_attach_temp). */
 int xh_rf_reduce(xh_rf *const *rfs, int32_t n);
 /* finishComputations (RFA:1002-1055): synchronous; writes D^3 doubles, [z][y][x] */
 int xh_rf_finish(xh_rf *rf, double *h_volume);

@@ -367,6 +367,34 @@ def test_reduce_of_partial_reconstructions(gpu, data32):
         xa.reduce_reconstructions([parts[1], xa.RecFourier(ctx, D)])   # second one not cropped yet
 
 
+def test_reduce_across_devices_is_one_rccl_allreduce(gpu, data32):
+    """Two or more GPUs in the box: the partial reconstructions live on different devices and xh_rf_reduce sums them with
+    one in-place RCCL all-reduce (every participating handle ends up with the total). Skipped on single-GPU boxes."""
+    xa, ctx, torch = gpu
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    D, vol, ang, imgs = data32
+    one = xa.RecFourier(ctx, D)
+    f = one.prepare_images(torch.from_numpy(imgs).cuda())
+    one.insert(f, ang)
+    one.mirror_and_crop()
+    ref_cropped = one.cropped_view().clone()
+    ndev = min(4, torch.cuda.device_count())
+    ctxs = [ctx] + [xa.Context(d) for d in range(1, ndev)]
+    parts = []
+    for g in range(ndev):
+        lo, hi = xa.shard_range(len(imgs), g, ndev)
+        with torch.cuda.device(g):
+            rf = xa.RecFourier(ctxs[g], D)
+            rf.insert(rf.prepare_images(torch.from_numpy(imgs[lo:hi]).cuda(g)), ang[lo:hi])
+            rf.mirror_and_crop()
+        parts.append(rf)
+    xa.reduce_reconstructions(parts)
+    tol = 2e-6 * ref_cropped.abs().max().item()
+    for g in range(ndev):          # an all-reduce: every device holds the sum
+        assert (parts[g].cropped_view().to(ref_cropped.device) - ref_cropped).abs().max().item() <= tol
+
+
 def test_half_sets_sum_to_the_full_reconstruction(gpu, data32):
     """--prepare_fsc bookkeeping (RF:991-1045): half 1 and half 2 are reconstructed from zeroed spaces,
     their Fourier volumes + weights are kept and summed for the final volume."""
@@ -456,6 +484,52 @@ def test_linearity_of_insertion_at_full_size(gpu):
     scale = one.abs().max().item()
     assert (rf.temp - one).abs().max().item() <= 2e-6 * scale
     assert scale > 0
+
+
+def test_gridding_at_full_size_against_the_oracle(gpu, oracle):
+    """SURVEY.md 8d config 3 at its own box: 64 CTF-weighted projections into the 513^3 temp spaces. At this size the
+    kernel runs with all eight XCD classes, work stealing between tile streams and super-tile lists of hundreds of
+    entries, none of which the 32-px tests reach. Temp spaces: same voxels, 2e-6; finished volume: 1e-4 of the peak and
+    FSC >= 0.999 up to 0.9 Nyquist."""
+    xa, ctx, torch = gpu
+    D, n = 256, 64
+    rng = np.random.default_rng(11)
+    vol = synth.phantom(64, seed=3, nblobs=12)
+    ang = synth.random_angles(n, rng)
+    small = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    # 64-px projections of the phantom in the middle of a noisy 256-px box: structure at low and high frequencies
+    imgs = (0.05 * rng.standard_normal((n, D, D))).astype(np.float32)
+    imgs[:, 96:160, 96:160] += small
+    rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
+    o = oracle.RF(D, use_ctf=True, min_ctf=0.01)
+    from xmipp3_amd.api import ctf_params
+    defocus = rng.uniform(10000.0, 30000.0, n)
+    ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d)) for d in defocus]
+    weights = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs))
+    f = rf.prepare_images(torch.from_numpy(imgs).cuda())
+    hf, hc, hm = f.cpu().numpy(), c.cpu().numpy(), m.cpu().numpy()
+    # the oracle grids the device's spectra and CTF planes: this test is about the insertion (the front end has its own)
+    for i in range(n):
+        o.insert(hf[i], synth.euler_matrix(*ang[i]).T, weight=float(weights[i]), ctf=hc[i], modulator=hm[i])
+    rf.insert(f, ang, weights=weights, ctf=c, modulator=m)
+    ev, ew = o.temp()
+    gv, gw = rf.temp_spaces()
+    gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+    assert (ew != 0).sum() > 10_000_000
+    assert ((ew != 0) == (gw != 0)).all()
+    assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
+    assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+    del ev, ew, gv, gw
+    o.mirror_and_crop()
+    exp = o.finish()
+    rf.mirror_and_crop()
+    got = rf.finish()
+    assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()
+    res = xa.frc_dpr(ctx, torch.from_numpy(got).cuda(), torch.from_numpy(exp).cuda())
+    freq, frc = np.asarray(res["freq"]), np.asarray(res["frc"])
+    sel = (freq > 0) & (freq <= 0.45)
+    assert sel.sum() > 50 and frc[sel].min() >= 0.999
 
 
 def test_errors_are_loud(gpu):

@@ -2745,7 +2745,8 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
     const size_t per = (size_t)D * D;
     // particles per pass: z, w (c128) and R (f64) of a pass are written by one kernel and read by the next
     const size_t trBytes = pm->tr_chunk_mb > 0 ? (size_t)pm->tr_chunk_mb << 20 : (size_t)4096u << 20;
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(n, trBytes / (per * sizeof(xh_cd))));
+    // grid.y carries the particle index: at most 65535 per launch
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n, 65535), trBytes / (per * sizeof(xh_cd))));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t1, sizeof(xh_cd) * per * chunk));
     XH_TRY(xh_buf_reserve(ctx, pm->d_t2, sizeof(xh_cd) * per * chunk));
     if (D == 64 || D == 128 || D == 256) {

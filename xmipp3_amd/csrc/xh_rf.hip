@@ -26,6 +26,8 @@
 #include <cstring>
 #include <limits>
 #include <type_traits>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #define XH_BLOB_TABLE 10000
 
@@ -1640,18 +1642,43 @@ int xh_rf_cropped_import(xh_rf *rf, const float *d_src, int32_t add)
     return XH_OK;
 }
 
-int xh_rf_reduce(xh_rf *const *rfs, int32_t n)
+// ---- sum over the devices of one process: one RCCL all-reduce (parallel/mpi_reconstruct_fourier_accel.cpp:245-266) ----
+// RCCL is bound at run time (dlopen): a process that already carries a copy (torch ships one) keeps using it, and a
+// single-device run never loads it.
+namespace {
+struct XhRccl {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<int> devs;             // the communicators below span these devices, in this order
+    std::vector<ncclComm_t> comms;
+};
+XhRccl g_rccl;
+bool rccl_load()
 {
-    XH_CHECK(rfs && n >= 1, XH_ERR_ARG, "xh_rf_reduce: no handles");
-    for (int i = 0; i < n; ++i) {
-        XH_CHECK(rfs[i], XH_ERR_ARG, "xh_rf_reduce: null handle");
-        XH_CHECK(rfs[i]->cropped, XH_ERR_STATE, "xh_rf_reduce: call xh_rf_mirror_and_crop on every handle first");
-        XH_CHECK(rfs[i]->mv == rfs[0]->mv, XH_ERR_ARG, "xh_rf_reduce: handles of different geometry");
-        for (int j = 0; j < i; ++j) XH_CHECK(rfs[j] != rfs[i], XH_ERR_ARG, "xh_rf_reduce: the same handle twice");
-    }
-    const size_t bytes = sizeof(float) * xh_rf_cropped_floats(rfs[0]);
-    // binary tree over the handles; the pairs of one level run concurrently on their own streams
-    // (different devices: one xGMI link per pair), the staging copy lands in the receiver's d_fin scratch
+    if (g_rccl.lib) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;      // a copy the process already has
+    if (!h) for (const char *nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return false;
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(h, "ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) return false;
+    g_rccl.lib = h;
+    return true;
+}
+// the earlier exchange, kept as the loud fallback: binary tree, peer copies into the receiver's scratch + one add kernel
+int reduce_tree(xh_rf *const *rfs, int n, size_t bytes)
+{
     for (int stride = 1; stride < n; stride <<= 1) {
         for (int i = 0; i + stride < n; i += 2 * stride) {
             xh_rf *src = rfs[i + stride];
@@ -1677,6 +1704,63 @@ int xh_rf_reduce(xh_rf *const *rfs, int32_t n)
             xh_rf *dst = rfs[i];
             XH_HIP(hipSetDevice(dst->ctx->device));
             XH_HIP(hipStreamSynchronize(dst->ctx->stream));
+        }
+    }
+    return XH_OK;
+}
+}  // namespace
+
+int xh_rf_reduce(xh_rf *const *rfs, int32_t n)
+{
+    XH_CHECK(rfs && n >= 1, XH_ERR_ARG, "xh_rf_reduce: no handles");
+    for (int i = 0; i < n; ++i) {
+        XH_CHECK(rfs[i], XH_ERR_ARG, "xh_rf_reduce: null handle");
+        XH_CHECK(rfs[i]->cropped, XH_ERR_STATE, "xh_rf_reduce: call xh_rf_mirror_and_crop on every handle first");
+        XH_CHECK(rfs[i]->mv == rfs[0]->mv, XH_ERR_ARG, "xh_rf_reduce: handles of different geometry");
+        for (int j = 0; j < i; ++j) XH_CHECK(rfs[j] != rfs[i], XH_ERR_ARG, "xh_rf_reduce: the same handle twice");
+    }
+    const size_t count = xh_rf_cropped_floats(rfs[0]);
+    const size_t bytes = sizeof(float) * count;
+    // handles that share a device are summed there first (one streaming add each); the first handle of every device
+    // then takes part in the exchange, rfs[0] among them
+    std::vector<xh_rf *> lead;
+    for (int i = 0; i < n; ++i) {
+        xh_rf *l = nullptr;
+        for (xh_rf *c : lead) if (c->ctx->device == rfs[i]->ctx->device) l = c;
+        if (!l) { lead.push_back(rfs[i]); continue; }
+        XH_HIP(hipSetDevice(l->ctx->device));
+        XH_HIP(hipStreamSynchronize(rfs[i]->ctx->stream));
+        XH_TRY(rf_add_into(l, rfs[i]->d_temp));
+    }
+    const int nd = (int)lead.size();
+    for (xh_rf *l : lead) { XH_HIP(hipSetDevice(l->ctx->device)); XH_HIP(hipStreamSynchronize(l->ctx->stream)); }
+    if (nd > 1) {
+        std::vector<int> devs(nd);
+        for (int i = 0; i < nd; ++i) devs[i] = lead[i]->ctx->device;
+        bool ok = rccl_load();
+        if (ok && g_rccl.devs != devs) {
+            for (ncclComm_t c : g_rccl.comms) g_rccl.CommDestroy(c);
+            g_rccl.comms.assign(nd, nullptr);
+            g_rccl.devs.clear();
+            const ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), nd, devs.data());
+            if (r == ncclSuccess) g_rccl.devs = devs;
+            else { g_rccl.comms.clear(); ok = false; fprintf(stderr, "xh_rf_reduce: ncclCommInitAll failed (%s)\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+        }
+        if (ok) {
+            // ONE in-place all-reduce of [volume | weights] over every xGMI link; every leader ends up with the sum
+            ncclResult_t r = g_rccl.GroupStart();
+            for (int i = 0; i < nd && r == ncclSuccess; ++i)
+                r = g_rccl.AllReduce(lead[i]->d_temp, lead[i]->d_temp, count, ncclFloat, ncclSum, g_rccl.comms[i], lead[i]->ctx->stream);
+            const ncclResult_t r2 = g_rccl.GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess) {
+                xh_set_error("xh_rf_reduce: RCCL all-reduce failed (%s)", g_rccl.GetErrorString ? g_rccl.GetErrorString(r != ncclSuccess ? r : r2) : "?");
+                return XH_ERR_HIP;
+            }
+            for (xh_rf *l : lead) { XH_HIP(hipSetDevice(l->ctx->device)); XH_HIP(hipStreamSynchronize(l->ctx->stream)); }
+        } else {
+            fprintf(stderr, "xh_rf_reduce: RCCL is not available in this process; falling back to the peer-copy tree "
+                            "(one xGMI link per pair and level instead of all of them)\n");
+            XH_TRY(reduce_tree(lead.data(), nd, bytes));
         }
     }
     XH_HIP(hipSetDevice(rfs[0]->ctx->device));

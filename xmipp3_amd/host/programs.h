@@ -443,6 +443,10 @@ public:
                 const size_t id = imagesToProcess[b0 + k];
                 prevShift[2 * k] = (float)DFexp.getDouble("shiftX", id, 0.);
                 prevShift[2 * k + 1] = (float)DFexp.getDouble("shiftY", id, 0.);
+                // getCurrentImage folds MDL_SCALE into the transformation it applies (APM:1222-1233); only shifts are
+                // resampled here, so a scaled input row would silently give other matches than the reference
+                if (std::fabs(DFexp.getDouble("scale", id, 1.0) - 1.0) > 1e-9)
+                    REPORT_ERROR(ERR_NOT_IMPLEMENTED, "input image " + std::to_string(id + 1) + " carries scale != 1: scaled inputs are not resampled by this build");
                 anyShift = anyShift || prevShift[2 * k] != 0.f || prevShift[2 * k + 1] != 0.f;
                 if (id >= mysampling.my_neighbors.size()) REPORT_ERROR(ERR_MD_NOOBJ, "No neighbour list for image " + std::to_string(id + 1));
                 for (size_t r : mysampling.my_neighbors[id]) {
