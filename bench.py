@@ -257,7 +257,8 @@ def main():
             ang = synth.random_angles(B, rng)
             shifts = rng.uniform(-3, 3, (B, 2))
         if rf is not None:
-            imgs = rf.shift_images(parts, shifts)
+            # the matcher has just computed the particles' B-spline coefficients: the shift reuses them
+            imgs = rf.shift_images(parts, shifts, coefs=pm.last_coefficients(B) if pm is not None else None)
             c, m = rf.ctf_arrays(ctf_arr)
             fft = rf.prepare_images(imgs)
             if record:

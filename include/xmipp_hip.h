@@ -134,6 +134,12 @@ int xh_rf_reset(xh_rf *rf);
  * NULL), cubic B-spline interpolation with wrapping. */
 int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY /* [n][2] */,
                        const uint8_t *h_flip /* [n] or NULL */, int32_t n, float *d_out);
+/* The same from cubic B-spline coefficients the caller already holds (produceSplineCoefficients of
+ * d_imgs, [n][D][D] float): in one refinement iteration the matcher has just computed them for the same
+ * particles (xh_pm_last_coefficients), the reference's two programs each compute their own
+ * (APM:569, RFA:304-323 through readApplyGeo). */
+int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float *h_shiftXY,
+                             const uint8_t *h_flip, int32_t n, float *d_out);
 /* preloadBuffer + cropAndShift for n images already shifted (shifts applied):
  * d_imgs [n][D][D] float  ->  d_fft [n][mv][mv/2] complex<float> (interleaved) */
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft);
@@ -227,6 +233,10 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
 int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *d_refno,
                     const int32_t *d_psi_idx, const uint8_t *d_flip, double max_shift,
                     double *d_shiftX, double *d_shiftY, double *d_maxCC);
+/* fp32 cubic B-spline coefficients (produceSplineCoefficients, APM:569) of the particles of the last
+ * xh_pm_match[_ex] call, [count][D][D] float on the device, valid until the next call on this handle;
+ * first = index of the first particle they belong to (0 and count = n when the call ran in one chunk). */
+int xh_pm_last_coefficients(const xh_pm *pm, const float **d_coefs, int32_t *first, int32_t *count);
 /* statistics of the last xh_pm_match call: rows evaluated, particles re-scored in fp64 */
 int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rescored_particles,
                      int64_t *rescored_rows);

@@ -80,6 +80,25 @@ def test_shift_images(gpu, oracle):
         assert np.abs(gotf[i] - exp).max() <= 2e-5 * np.abs(exp).max()
 
 
+def test_shift_reuses_the_matchers_coefficients(gpu):
+    """One refinement iteration prefilters every particle twice in the reference (matching, then readApplyGeo before
+    gridding); here the gridding side can take the matcher's coefficients: same bits."""
+    xa, ctx, torch = gpu
+    D = 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    refs = torch.randn((6, D, D), generator=g, device="cuda")
+    parts = torch.randn((10, D, D), generator=g, device="cuda")
+    pm = xa.ProjectionMatcher(ctx, refs)
+    pm.match(parts)
+    coefs = pm.last_coefficients(10)
+    assert coefs is not None and pm.last_coefficients(9) is None
+    rf = xa.RecFourier(ctx, D)
+    shifts = np.random.default_rng(1).uniform(-3, 3, (10, 2)).astype(np.float32)
+    a = rf.shift_images(parts, shifts)
+    b = rf.shift_images(parts, shifts, coefs=coefs)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["astigmatic", "round", "round_envelope", "astigmatic_envelope"])
 def test_ctf_arrays(gpu, oracle, kind):
     """k_rf_ctf has per-image shortcuts (no atan2 for a round CTF, no exp without envelope terms); every

@@ -60,6 +60,7 @@ SIGNATURES = {
     "xh_rf_temp_ptr": (C.c_int, [vp, pvp]),
     "xh_rf_reset": (C.c_int, [vp]),
     "xh_rf_shift_images": (C.c_int, [vp, vp, vp, vp, i32, vp]),
+    "xh_rf_shift_images_coefs": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "xh_rf_prepare_images": (C.c_int, [vp, vp, i32, vp]),
     "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
     "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "xh_pm_match_ex": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "xh_pm_translate": (C.c_int, [vp, vp, i32, vp, vp, vp, d, vp, vp, vp]),
     "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "xh_pm_last_coefficients": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]),
     "xh_pm_stage_ms": (C.c_int, [vp, vp, i32]),
     "xh_pm_rows_pruned": (C.c_int, [vp, vp]),
     "xh_pm_two_level_cut": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),

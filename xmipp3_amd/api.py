@@ -169,14 +169,16 @@ class RecFourier:
         check(lib().xh_rf_reset(self.h))
         self.cropped = False
 
-    def shift_images(self, imgs, shifts, flips=None):
-        """Image::readApplyGeo(only_apply_shifts): shifts [n,2] = (shiftX, shiftY) on the host."""
+    def shift_images(self, imgs, shifts, flips=None, coefs=None):
+        """Image::readApplyGeo(only_apply_shifts): shifts [n,2] = (shiftX, shiftY) on the host. coefs: device pointer
+        (int) to the fp32 B-spline coefficients of imgs when the caller has them (ProjectionMatcher.last_coefficients)."""
         torch = _torch()
         n = imgs.shape[0]
         sh = np.ascontiguousarray(shifts, np.float32).reshape(n, 2)
         fl = None if flips is None else np.ascontiguousarray(flips, np.uint8).reshape(n)
         out = torch.empty_like(imgs)
-        check(lib().xh_rf_shift_images(self.h, _ptr(imgs, torch.float32), _np_ptr(sh), _np_ptr(fl), n, _ptr(out)))
+        check(lib().xh_rf_shift_images_coefs(self.h, _ptr(imgs, torch.float32), C.c_void_p(coefs) if coefs else None,
+                                             _np_ptr(sh), _np_ptr(fl), n, _ptr(out)))
         return out
 
     def prepare_images(self, imgs, out=None):
@@ -426,6 +428,13 @@ class ProjectionMatcher:
         a, b = C.c_int32(), C.c_int32()
         check(lib().xh_pm_two_level_cut(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_coefficients(self, n):
+        """Device pointer to the fp32 B-spline coefficients of the n particles of the last match() call, or None when
+        that call ran in several chunks (or with the recursive prefilter): valid until the next call on this matcher."""
+        p, a, b = C.c_void_p(), C.c_int32(), C.c_int32()
+        check(lib().xh_pm_last_coefficients(self.h, C.byref(p), C.byref(a), C.byref(b)))
+        return p.value if (p.value and a.value == 0 and b.value == n) else None
 
     def last_stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

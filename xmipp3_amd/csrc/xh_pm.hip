@@ -110,11 +110,13 @@ struct xh_pm {
     XhPlanBufs<double> planD;    // generic length-D line transform (S6 at the other sizes)
     // per-call scratch
     XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
+    XhBuf d_trAngles;                               // S6: cos / sin per particle
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
     XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
     XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters, d_offs5d;
     XhBuf d_t1, d_t2, d_t3;      // S6 scratch
     int64_t stat_rows, stat_resc_p, stat_resc_r;
+    int coefFirst, coefCount;      // particles whose fp32 B-spline coefficients d_coef32 holds (last match call)
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
@@ -1685,7 +1687,84 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
 //                  FFTs -- a block owns column pairs (kx, -kx) so the Hermitian partner is in LDS
 //   k_pm_tr_irows: inverse row FFTs, real part only (the correlation map)
 // DIF forward, mirrored inverse: x[n1*R2+n2] <-> X[k1 + R1*k2]; no bit reversal anywhere.
-template <int R1, int R2>
+// z = rotate(BSPLINE3, ref, psi, DONT_WRAP) + i * (mirrored) particle (APM:812-828) for a 16 x 16 output tile per block. The
+// 16 taps of a pixel used to be gathered from the 512-KB coefficient image in global memory (the L1's tag lookups bound
+// k_pm_tr_rows: 6.9 ms per 4096 particles of 256 px); the rotated tile only reaches a 28 x 28 patch of it, staged here in
+// LDS with the mirror boundary already applied. Same weights, same summation order as d_interp: same bits.
+#define XH_TRB 16
+#define XH_TRBW 30          // 2 * 8 * sqrt(2) + 4 taps + slack
+// cos / sin of the in-plane angles, once per particle in double precision
+__global__ void k_pm_tr_angles(const int *__restrict__ psi, double2 *__restrict__ cs, int n, int N)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double ang = (double)psi[p] * (360. / (double)N) * 3.14159265358979323846 / 180.0;
+    cs[p] = make_double2(cos(ang), sin(ang));
+}
+__global__ void __launch_bounds__(256)
+k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ refCoef, const int *__restrict__ refno,
+              const double2 *__restrict__ cs, const unsigned char *__restrict__ flip, xh_cd *__restrict__ z, int D)
+{
+    __shared__ double sC[XH_TRBW * XH_TRBW];
+    const int tid = threadIdx.x, p = blockIdx.y;
+    const int tpr = D / XH_TRB;
+    const int ti0 = (blockIdx.x / tpr) * XH_TRB, tj0 = (blockIdx.x % tpr) * XH_TRB;
+    const int ref = refno[p];
+    const int cen = D / 2;
+    const double c = cs[p].x, sn = cs[p].y;
+    const double minp = -cen, maxp = D - cen - 1;
+    // source position of the tile centre and the reach of the rotated tile: first tap column / row of the patch
+    const double xc = (tj0 + 7.5) - cen, yc = (ti0 + 7.5) - cen;
+    const double xpc = c * xc - sn * yc + cen, ypc = sn * xc + c * yc + cen;      // in index space (x - start)
+    const double ext = 7.5 * (fabs(c) + fabs(sn)) + 1e-6;
+    const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
+    if (ref >= 0) {
+        const double *coef = refCoef + (size_t)ref * D * D;
+        for (int e = tid; e < XH_TRBW * XH_TRBW; e += 256) {
+            const int m = mmin + e / XH_TRBW, l = lmin + e % XH_TRBW;
+            // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
+            int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+            em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
+            sC[e] = coef[(size_t)em * D + el];
+        }
+    }
+    __syncthreads();
+    const int i = ti0 + (tid >> 4), j = tj0 + (tid & 15);
+    const float *img = particles + (size_t)p * D * D;
+    const bool fl = flip[p] != 0;
+    xh_cd out = xh_cd{0., 0.};
+    if (ref >= 0) {
+        const double x = j - cen, y = i - cen;
+        double xp = c * x - sn * y, yp = sn * x + c * y;
+        if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6)) {
+            // d_interp<double> on the staged patch
+            xp -= (double)(-cen);
+            yp -= (double)(-cen);
+            const int l1 = (int)ceil(xp - 2.0), m1 = (int)ceil(yp - 2.0);
+            double wx[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wx[t] = d_bspline03<double>(xp - (double)(l1 + t));
+            const double *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
+            double columns = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double *row = base + t * XH_TRBW;
+                double rows = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
+                columns += rows * d_bspline03<double>(yp - (double)(m1 + t));
+            }
+            out.x = columns;
+        }
+        if (fl) {
+            const double mx = -(double)(j - cen);
+            if (!(mx < minp - 1e-6 || mx > maxp + 1e-6)) out.y = (double)img[(size_t)i * D + (2 * cen - j)];
+        } else out.y = (double)img[(size_t)i * D + j];
+    }
+    z[((size_t)p * D + i) * D + j] = out;
+}
+
+template <int R1, int R2, bool PREBUILT = false>
 __global__ void __launch_bounds__(256)
 k_pm_tr_rows(const float *__restrict__ particles, const double *__restrict__ refCoef, const int *__restrict__ refno,
              const int *__restrict__ psi, const unsigned char *__restrict__ flip, xh_cd *__restrict__ z,
@@ -1709,6 +1788,10 @@ k_pm_tr_rows(const float *__restrict__ particles, const double *__restrict__ ref
     const bool fl = flip[p] != 0;
     for (int e = tid; e < G::LN * D; e += 256) {
         const int l = e / D, j = e - l * D, i = row0 + l;
+        if (PREBUILT) {          // z comes from k_pm_tr_build
+            s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = z[((size_t)p * D + i) * D + j];
+            continue;
+        }
         xh_cd out = xh_cd{0., 0.};
         if (ref >= 0) {
             const double x = j - cen, y = i - cen;
@@ -1984,7 +2067,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2072,6 +2155,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tie_rel = 1e-12;
     pm->chunk_rows = 0;
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    pm->coefFirst = pm->coefCount = 0;
     for (int i = 0; i < 8; ++i) pm->stage_ms[i] = 0;
     for (int i = 0; i < 6; ++i) (void)hipEventCreate(&pm->ev[i]);
     int rc = XH_OK;
@@ -2390,6 +2474,15 @@ int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned)
     return XH_OK;
 }
 
+int xh_pm_last_coefficients(const xh_pm *pm, const float **d_coefs, int32_t *first, int32_t *count)
+{
+    XH_CHECK(pm && d_coefs && first && count, XH_ERR_ARG, "null argument");
+    *d_coefs = pm->coefCount > 0 ? (const float *)pm->d_coef32.p : nullptr;
+    *first = pm->coefFirst;
+    *count = pm->coefCount;
+    return XH_OK;
+}
+
 int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 {
     XH_CHECK(pm, XH_ERR_ARG, "null handle");
@@ -2585,6 +2678,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         d_offs = (const double *)pm->d_offs5d.p;
     }
     pm->stat_rows = pm->stat_resc_p = pm->stat_resc_r = 0;
+    pm->coefFirst = pm->coefCount = 0;
     pm->stat_pruned = 0;
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
@@ -2670,6 +2764,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         XH_HIP(hipEventRecord(pm->ev[0], ctx->stream));
         XH_TRY(run_prep<float>(pm, d_particles + (size_t)p0 * D * D, true, nullptr, m, nullptr, pm->d_coef32, pm->d_polar32,
                                pm->d_A32, pm->d_stat32, pm->d_tw32, false, 0., 0., nt, d_offs));
+        pm->coefFirst = p0; pm->coefCount = (pm->use_fir && D >= 2 * XH_FIR_K) ? m : 0;   // the recursive form rounds differently
         XH_HIP(hipEventRecord(pm->ev[1], ctx->stream));
         // S2 + S3
         XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
@@ -2755,16 +2850,22 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         for (int p0 = 0; p0 < n; p0 += chunk) {
             const int m = std::min(chunk, n - p0);
             xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
+            XH_TRY(xh_buf_reserve(ctx, pm->d_trAngles, sizeof(double2) * (size_t)chunk));
             double *R = (double *)pm->d_t3.p;
 #define XH_TR(A_, B_)                                                                                                       \
     {                                                                                                                       \
         typedef TrGeom<A_, B_> G;                                                                                           \
         if (G::smem > 64 * 1024) {                                                                                          \
-            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_rows<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_rows<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
         }                                                                                                                   \
-        hipLaunchKernelGGL((k_pm_tr_rows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                      \
+        hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d_psi + p0,                     \
+                           (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
+        hipLaunchKernelGGL(k_pm_tr_build, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,                   \
+                           d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0,                   \
+                           (const double2 *)pm->d_trAngles.p, d_flip + p0, z, D);                                           \
+        hipLaunchKernelGGL((k_pm_tr_rows<A_, B_, true>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                \
                            d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0, d_psi + p0,       \
                            d_flip + p0, z, w, (const xh_cd *)pm->d_WD64.p, L.N);                                            \
         hipLaunchKernelGGL((k_pm_tr_cols<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, w,                   \

@@ -1148,7 +1148,7 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
 }
 
 
-int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
+int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
 {
     XH_CHECK(rf && d_imgs && h_shiftXY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images: bad argument");
     XH_HIP(hipSetDevice(rf->ctx->device));
@@ -1156,7 +1156,7 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
     const int D = rf->D;
-    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
+    if (!d_coefs) XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
     XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n + (size_t)n));
     XH_HIP(hipMemcpyAsync(rf->d_shiftXY.p, h_shiftXY, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     unsigned char *d_flip = nullptr;
@@ -1165,7 +1165,9 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
         XH_HIP(hipMemcpyAsync(d_flip, h_flip, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
     XH_HIP(hipStreamSynchronize(ctx->stream));
-    if (D >= 2 * XH_FIR_K) {
+    if (d_coefs) {
+        // the caller's coefficients
+    } else if (D >= 2 * XH_FIR_K) {
         // fp32 prefilter in its convolution form (xh_bspline.h); d_out is free until the shift kernel writes it
         const XhFir F = xh_fir_taps();
         const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
@@ -1184,10 +1186,15 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
                        (const int *)nullptr);
     XH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, (const float *)rf->d_shiftCoef.p, d_imgs,
+    hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p, d_imgs,
                        (const float2 *)rf->d_shiftXY.p, (const unsigned char *)d_flip, d_out, D);
     XH_LAUNCH_CHECK();
     return XH_OK;
+}
+
+int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
+{
+    return xh_rf_shift_images_coefs(rf, d_imgs, nullptr, h_shiftXY, h_flip, n, d_out);
 }
 
 int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod)
