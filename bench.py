@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--chunk-rows", type=float, default=0, help="correlation rows per chunk of the matcher (0: library default)")
     ap.add_argument("--k0", type=int, default=-1, help="two-level contraction cut (0 auto, >= nk off); default: automatic")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
+    ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
     ap.add_argument("--unique-batches", type=int, default=0, help="--mode grid: distinct particle batches cycled (0: 4 = 16384 projections at --batch 4096)")
     return ap.parse_args(argv)
@@ -231,6 +232,8 @@ def main():
         pm.set_option("chunk_rows", args.chunk_rows)
     if pm is not None and args.k0 >= 0:
         pm.set_option("k0", args.k0)
+    if pm is not None and args.tau_rel > 0:
+        pm.set_option("tau_rel", args.tau_rel)
     rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     t_grid = ctx.timer()

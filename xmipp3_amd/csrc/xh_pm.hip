@@ -2142,7 +2142,11 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     }
     pm->scale = 0;
     for (int r = 0; r < L.nrings; ++r) pm->scale += 2. * kPI * (r + Ri);
-    pm->tau_rel = 3e-6;   // measured fp32 error of a normalised row: 1.6e-7*S (D=256), 1.8e-7*S (D=64)
+    // ambiguity margin of the coarse pass. Measured error of a normalised fp32 row against fp64 (tools/measure_tau.py, 1.9 M
+    // samples of the bench workload at 256 px): rms 2.4e-8 S, largest 1.04e-7 S, the tail bounded (rounding, not Gaussian);
+    // two candidates can be misordered only if their errors differ by more than the margin: 1e-6 S = 42 rms = 4.8 x the
+    // largest possible difference seen. (Round 1 used 3e-6; with the smooth phantom gallery that re-scored 17 % of the particles, now 6 %.)
+    pm->tau_rel = 1e-6;
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
     pm->use_prune = 1;
