@@ -107,6 +107,17 @@ def lib():
         "xo_rf_finish": (None, [vp, c_double_p]),
         "xo_rf_hermitian_and_weights": (None, [vp]),
         "xo_num_threads": (i, []),
+        "xo_rf2_create": (vp, [i, d, d, d, d, i, d, i]),
+        "xo_rf2_destroy": (None, [vp]),
+        "xo_rf2_weights": (c_double_p, [vp]),
+        "xo_rf2_fourier": (c_double_p, [vp]),
+        "xo_rf2_vol_pad": (i, [vp]),
+        "xo_rf2_insert": (None, [vp, c_double_p, c_double_p, c_double_p, d, C.POINTER(CtfParams), d, d, i, i]),
+        "xo_rf2_weights_begin": (None, [vp]),
+        "xo_rf2_weights_iter_begin": (None, [vp]),
+        "xo_rf2_weights_iter_end": (None, [vp]),
+        "xo_rf2_weights_end": (None, [vp]),
+        "xo_rf2_finish": (None, [vp, c_double_p]),
         "xo_fp_create": (vp, [c_double_p, i, d, d, i]),
         "xo_fp_destroy": (None, [vp]),
         "xo_fp_padded_size": (i, [vp]),
@@ -495,3 +506,46 @@ class FP:
                 self.h = None
         except Exception:
             pass
+
+
+class RF2:
+    """ProgRecFourier (reconstruction/reconstruct_fourier.cpp), the double-precision scatter variant: images are kept so
+    that the weight correction (--iter, NiterWeight) can replay them."""
+
+    def __init__(self, D, padding_proj=2.0, padding_vol=2.0, max_resolution=0.5, blob_radius=1.9, blob_order=0,
+                 blob_alpha=15.0, niter_weight=1):
+        self.D, self.niter = D, niter_weight
+        self.h = lib().xo_rf2_create(D, padding_proj, padding_vol, max_resolution, blob_radius, blob_order, blob_alpha,
+                                     niter_weight)
+        self.images = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().xo_rf2_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _insert(self, img, A, R, weight, reprocess):
+        lib().xo_rf2_insert(self.h, _dp(img), _dp(A), _dp(R), float(weight), None, 1.0, 0.01, 0, int(reprocess))
+
+    def insert(self, img, euler_T, R=None, weight=1.0):
+        img = f64(img)
+        A = f64(euler_T)
+        R = f64(np.eye(3) if R is None else R)
+        self.images.append((img, A, R, weight))
+        self._insert(img, A, R, weight, 0)
+
+    def finish(self):
+        L = lib()
+        L.xo_rf2_weights_begin(self.h)                      # correctWeight, RF:1056-1101
+        for _ in range(1, self.niter):
+            L.xo_rf2_weights_iter_begin(self.h)
+            for img, A, R, w in self.images:
+                self._insert(img, A, R, w, 1)
+            L.xo_rf2_weights_iter_end(self.h)
+        L.xo_rf2_weights_end(self.h)
+        out = np.empty((self.D,) * 3, np.float64)
+        L.xo_rf2_finish(self.h, _dp(out))
+        return out

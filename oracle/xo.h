@@ -168,6 +168,22 @@ void xo_rf_finish(xo_rf *, double *vol_out);
 /* helper exposing only forceHermitianSymmetry+processWeights on the cropped spaces */
 void xo_rf_hermitian_and_weights(xo_rf *);
 
+/* ---- ProgRecFourier, the double-precision scatter variant (RF: reconstruction/reconstruct_fourier.cpp), xo_recfourier2.cpp */
+typedef struct xo_rf2 xo_rf2;
+xo_rf2 *xo_rf2_create(int D, double pad_proj, double pad_vol, double max_resolution, double blob_radius, int blob_order,
+                      double blob_alpha, int niter_weight);
+void xo_rf2_destroy(xo_rf2 *);
+double *xo_rf2_weights(xo_rf2 *);      /* [V][V][V/2+1] */
+double *xo_rf2_fourier(xo_rf2 *);      /* the same, complex interleaved */
+int xo_rf2_vol_pad(const xo_rf2 *);
+void xo_rf2_insert(xo_rf2 *, const double *img, const double *localAInv, const double *Rsym, double weight,
+                   const xo_ctf_params *ctf, double iTs, double minCTF, int phaseFlipped, int reprocess);
+void xo_rf2_weights_begin(xo_rf2 *);
+void xo_rf2_weights_iter_begin(xo_rf2 *);
+void xo_rf2_weights_iter_end(xo_rf2 *);
+void xo_rf2_weights_end(xo_rf2 *);
+void xo_rf2_finish(xo_rf2 *, double *vol);
+
 int xo_num_threads(void);
 /* ---- FourierProjector (data/fourier_projection.cpp:91-330): central-slice projection, the producer of
  * the reference gallery (angular_project_library --method fourier pad maxfreq interp) ---- */

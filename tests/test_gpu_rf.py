@@ -551,6 +551,29 @@ def test_gridding_at_full_size_against_the_oracle(gpu, oracle):
     assert sel.sum() > 50 and frc[sel].min() >= 0.999
 
 
+def test_device_volume_against_the_double_precision_program(gpu, oracle):
+    """BASELINE config 1 is quoted on xmipp_reconstruct_fourier (ProgRecFourier, RF); the device runs the accel
+    arithmetic under that name too. Against the RF restatement (double scatter, FFTW layout, correctWeight): 2e-3 of
+    the peak, correlation 0.99999+ (the two CPU restatements differ by as much, tests/test_oracle_pins.py)."""
+    xa, ctx, torch = gpu
+    D, n = 64, 400
+    vol = synth.phantom(D, seed=5, nblobs=16)
+    rng = np.random.default_rng(6)
+    ang = synth.random_angles(n, rng)
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    ref = oracle.RF2(D)
+    for i in range(n):
+        ref.insert(imgs[i], synth.euler_matrix(*ang[i]).T)
+    exp = ref.finish()
+    rf = xa.RecFourier(ctx, D)
+    rf.insert(rf.prepare_images(torch.from_numpy(imgs).cuda()), ang)
+    rf.mirror_and_crop()
+    got = rf.finish()
+    peak = np.abs(exp).max()
+    assert np.abs(got - exp).max() <= 2e-3 * peak
+    assert np.corrcoef(got.ravel(), exp.ravel())[0, 1] > 0.99999
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     with pytest.raises(xa.XhError):

@@ -191,6 +191,22 @@ template <typename T> __device__ __forceinline__ T d_bspline03(T x)
     return (T)0;
 }
 
+// The four weights d_bspline03(x - (l1 + t)), t = 0..3, of a footprint that starts at l1 = ceil(x - 2): the arguments lie in
+// (1, 2], (0, 1], (-1, 0], (-2, -1], so the piece of the spline each of them takes is known and no lane has to branch (the
+// generic form costs eight divergent branches per sample). Same expressions, same order as d_bspline03; the selects keep the
+// values at the breakpoints (integer x) bit-identical to it.
+template <typename T> __device__ __forceinline__ void d_bspline03_w4(T x, int l1, T w[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const T a = fabs(x - (T)(l1 + t));
+        const T b = a - (T)2;
+        const T outer = b * b * b * (T)(-1.0 / 6.0);
+        if (t == 0 || t == 3) w[t] = a < (T)2 ? outer : (T)0;
+        else w[t] = a < (T)1 ? a * a * (a - (T)2) * (T)0.5 + (T)(2.0 / 3.0) : outer;
+    }
+}
+
 // interpolatedElementBSpline2D degree 3 at logical (x,y); reconstruction_cuda/cuda_gpu_multidim_array.cu:78-157
 template <typename T>
 __device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T y)
@@ -200,11 +216,12 @@ __device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T 
     y -= (T)start;
     const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
     int el[4];
-    T wx[4];
+    T wx[4], wy[4];
+    d_bspline03_w4<T>(x, l1, wx);
+    d_bspline03_w4<T>(y, m1, wy);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int l = l1 + t;
-        wx[t] = d_bspline03<T>(x - (T)l);
         el[t] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
     }
     T columns = 0;
@@ -216,7 +233,7 @@ __device__ __forceinline__ T d_interp(const T *__restrict__ coef, int D, T x, T 
         T rows = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) rows += ref[el[u]] * wx[u];
-        columns += rows * d_bspline03<T>(y - (T)m);
+        columns += rows * wy[t];
     }
     return columns;
 }

@@ -1741,9 +1741,9 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
             xp -= (double)(-cen);
             yp -= (double)(-cen);
             const int l1 = (int)ceil(xp - 2.0), m1 = (int)ceil(yp - 2.0);
-            double wx[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wx[t] = d_bspline03<double>(xp - (double)(l1 + t));
+            double wx[4], wy[4];
+            d_bspline03_w4<double>(xp, l1, wx);
+            d_bspline03_w4<double>(yp, m1, wy);
             const double *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
             double columns = 0;
 #pragma unroll
@@ -1752,7 +1752,7 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
                 double rows = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
-                columns += rows * d_bspline03<double>(yp - (double)(m1 + t));
+                columns += rows * wy[t];
             }
             out.x = columns;
         }
