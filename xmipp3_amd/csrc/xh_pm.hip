@@ -111,6 +111,8 @@ struct xh_pm {
     // per-call scratch
     XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
     XhBuf d_trAngles;                               // S6: cos / sin per particle
+    XhBuf d_cellStart, d_cellSamples, d_cellOrg;    // k_pm_polar_cells: samples per image cell
+    int ncells, use_cells;
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
     XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
     XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters, d_offs5d;
@@ -198,10 +200,87 @@ k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restric
         }
     }
 }
+// The same sampling, cell by cell. k_pm_polar walks the samples ring by ring: the 64 lanes of a wave sit on an arc, every one
+// of the 16 tap loads touches ~50 cache lines of the row-major coefficient image and the L1's tag lookups bound the kernel
+// (3.25 G lookups, 4.2 ms per 4096 particles of 256 px, the vector ALUs 28 % busy). Here a workgroup takes the samples that
+// fall into one XH_PC x XH_PC pixel cell of the image (host-built lists, ~1000 samples per cell), stages the cell's
+// (XH_PC + 4)^2 coefficient patch in LDS with the mirror boundary applied, and interpolates from there: same weights, same
+// summation order as d_interp, same bits. Zero offsets only (no 5-D search translation, no wrap): the others keep k_pm_polar.
+#define XH_PC 32
+#define XH_PCW (XH_PC + 4)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float *__restrict__ sinr, const float *__restrict__ cosr,
+                 const short *__restrict__ ringOf, const double *__restrict__ ringW, int D, int nsamples,
+                 const int *__restrict__ cellStart, const int *__restrict__ cellSamples, const int2 *__restrict__ cellOrg,
+                 int ncells, const int *__restrict__ count, double *__restrict__ partial)
+{
+    __shared__ T sC[XH_PCW * XH_PCW];
+    __shared__ double red[8];
+    const int slot = blockIdx.x / ncells, cell = blockIdx.x - slot * ncells;
+    if (count && slot >= *count) return;
+    const T *c = coefs + (size_t)slot * D * D;
+    const int2 org = cellOrg[cell];                      // first tap column / row of the patch, image index space
+    for (int e = threadIdx.x; e < XH_PCW * XH_PCW; e += 256) {
+        const int m = org.y + e / XH_PCW, l = org.x + e % XH_PCW;
+        int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+        em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
+        sC[e] = c[(size_t)em * D + el];
+    }
+    __syncthreads();
+    double sw = 0, swv = 0, swv2 = 0;
+    const T start = (T)(-(D / 2));
+    for (int q = cellStart[cell] + threadIdx.x; q < cellStart[cell + 1]; q += 256) {
+        const int i = cellSamples[q];
+        const T x = (T)sinr[i] - start, y = (T)cosr[i] - start;
+        const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
+        T wx[4], wy[4];
+        d_bspline03_w4<T>(x, l1, wx);
+        d_bspline03_w4<T>(y, m1, wy);
+        const T *base = sC + (m1 - org.y) * XH_PCW + (l1 - org.x);
+        T columns = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const T *row = base + t * XH_PCW;
+            T rows = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
+            columns += rows * wy[t];
+        }
+        polar[(size_t)slot * nsamples + i] = columns;
+        const double w = ringW[ringOf[i]];
+        const double dv = (double)columns;
+        sw += w; swv += w * dv; swv2 += w * dv * dv;
+    }
+    const double N = d_block_sum(sw, red);
+    const double S = d_block_sum(swv, red);
+    const double S2 = d_block_sum(swv2, red);
+    if (threadIdx.x == 0) {
+        double *o = partial + ((size_t)slot * ncells + cell) * 3;
+        o[0] = N; o[1] = S; o[2] = S2;
+    }
+}
+
 __global__ void k_pm_polar_stats(const double *__restrict__ partial, double *__restrict__ stat, int nslots, int nparts)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nslots) return;
+    double N = 0, S = 0, S2 = 0;
+    for (int p = 0; p < nparts; ++p) {
+        const double *o = partial + ((size_t)slot * nparts + p) * 3;
+        N += o[0]; S += o[1]; S2 += o[2];
+    }
+    double avg = 0, sd = 0;
+    if (N > 0) { avg = S / N; sd = sqrt(fabs(S2 / N - avg * avg)); }
+    stat[2 * slot] = avg;
+    stat[2 * slot + 1] = sd;
+}
+
+__global__ void k_pm_polar_stats_counted(const double *__restrict__ partial, double *__restrict__ stat, int nslots, int nparts,
+                                         const int *__restrict__ count)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots || (count && slot >= *count)) return;
     double N = 0, S = 0, S2 = 0;
     for (int p = 0; p < nparts; ++p) {
         const double *o = partial + ((size_t)slot * nparts + p) * 3;
@@ -2020,6 +2099,19 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
                        (T *)coefBuf.p, D, nslots, d_count);
     XH_LAUNCH_CHECK();
     }
+    if (pm->use_cells && nt == 1 && !d_offs && xoff == 0. && yoff == 0. && D >= 64 && L.Ro <= D / 2 - 1) {
+        // zero offsets: sampling cell by cell from LDS-staged patches
+        const int nc = pm->ncells;
+        XH_TRY(xh_buf_reserve(ctx, pm->d_polarPart, sizeof(double) * 3 * nps * nc));
+        hipLaunchKernelGGL((k_pm_polar_cells<T>), dim3((unsigned)(nps * nc)), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
+                           (const float *)pm->d_sin.p, (const float *)pm->d_cos.p, (const short *)pm->d_ringOfSample.p,
+                           (const double *)pm->d_ringW.p, D, L.nsamples, (const int *)pm->d_cellStart.p,
+                           (const int *)pm->d_cellSamples.p, (const int2 *)pm->d_cellOrg.p, nc, d_count, (double *)pm->d_polarPart.p);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pm_polar_stats_counted, dim3((unsigned)((nps + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)pm->d_polarPart.p, (double *)statBuf.p, (int)nps, nc, d_count);
+        XH_LAUNCH_CHECK();
+    } else {
     // fp32 pass: split every slot over a few workgroups when the launch alone cannot fill the chip
     int nparts = 1;
     if (std::is_same<T, float>::value && !d_count)
@@ -2034,6 +2126,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         hipLaunchKernelGGL(k_pm_polar_stats, dim3((unsigned)((nps + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double *)pm->d_polarPart.p, (double *)statBuf.p, (int)nps, nparts);
         XH_LAUNCH_CHECK();
+    }
     }
     if (std::is_same<T, float>::value && !d_count && pm->use_mfma) {
         const size_t smemM = sizeof(float) * 32 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
@@ -2067,7 +2160,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2242,6 +2335,34 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
         XhBuf d_ringOfCoef;
         if (rc == XH_OK) rc = upload(ctx, pm->d_sin, sn);
         if (rc == XH_OK) rc = upload(ctx, pm->d_cos, cs);
+        {
+            // k_pm_polar_cells: samples binned by the image cell their position (x - start, y - start) falls into; the
+            // patch of a cell starts two pixels before it (footprints begin at ceil(p - 2)) and is XH_PC + 4 wide
+            const int cpr = (D + XH_PC - 1) / XH_PC;
+            std::vector<std::vector<int>> bins((size_t)cpr * cpr);
+            const float start = (float)(-(D / 2));
+            for (int i = 0; i < L.nsamples; ++i) {
+                const float x = sn[i] - start, y = cs[i] - start;
+                int cx = (int)std::floor(x / XH_PC), cy = (int)std::floor(y / XH_PC);
+                cx = std::min(std::max(cx, 0), cpr - 1); cy = std::min(std::max(cy, 0), cpr - 1);
+                bins[(size_t)cy * cpr + cx].push_back(i);
+            }
+            std::vector<int> cstart(1, 0), csamp;
+            std::vector<int2> corg;
+            for (int cy = 0; cy < cpr; ++cy)
+                for (int cx = 0; cx < cpr; ++cx) {
+                    const std::vector<int> &b = bins[(size_t)cy * cpr + cx];
+                    if (b.empty()) continue;
+                    csamp.insert(csamp.end(), b.begin(), b.end());
+                    cstart.push_back((int)csamp.size());
+                    corg.push_back(make_int2(cx * XH_PC - 2, cy * XH_PC - 2));
+                }
+            pm->ncells = (int)corg.size();
+            pm->use_cells = 1;
+            if (rc == XH_OK) rc = upload(ctx, pm->d_cellStart, cstart);
+            if (rc == XH_OK) rc = upload(ctx, pm->d_cellSamples, csamp);
+            if (rc == XH_OK) rc = upload(ctx, pm->d_cellOrg, corg);
+        }
         if (rc == XH_OK) rc = upload(ctx, pm->d_ringOfSample, ringOf);
         if (rc == XH_OK) rc = upload(ctx, pm->d_nsam, L.nsam);
         if (rc == XH_OK) {
@@ -2438,6 +2559,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
 {
     XH_CHECK(pm && name, XH_ERR_ARG, "null argument");
     if (!strcmp(name, "tau_rel")) pm->tau_rel = value;
+    else if (!strcmp(name, "polar_cells")) pm->use_cells = (int)value;
     else if (!strcmp(name, "tie_rel")) pm->tie_rel = value;
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
