@@ -262,11 +262,9 @@ def main():
         if rf is not None:
             # the matcher has just computed the particles' B-spline coefficients: the shift reuses them
             imgs = rf.shift_images(parts, shifts, coefs=pm.last_coefficients(B) if pm is not None else None)
-            c, m = rf.ctf_arrays(ctf_arr)
-            fft = rf.prepare_images(imgs)
             if record:
                 t_grid.start()
-            rf.insert(fft, ang, ctf=c, modulator=m)
+            rf.insert_images(imgs, ang, ctf_array=ctf_arr)      # CTF planes + FFT + records + gridding
             if record:
                 t_grid.stop()
                 grid_ms.append(t_grid.elapsed_ms())
@@ -383,7 +381,7 @@ def main():
 
     total_particles = args.steps * B * world
     value = total_particles / elapsed
-    stage["gridding_insert"] = float(sum(grid_ms))          # pack + spaces upload + kernel
+    stage["gridding_insert_images"] = float(sum(grid_ms))   # CTF planes + FFT + records + spaces upload + kernel
     stage["k_rf_grid"] = k_ms                                # HIP events around the kernel launches only
     # ---- roofline of the dominant kernel (per launch = per chunk; reported per particle-second)
     N = pm.N if pm is not None else 2 * int(math.pi * (D // 2 - 1))

@@ -151,6 +151,13 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
 int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
                  const double *h_angles, const float *h_weights, int32_t n, const double *h_sym,
                  int32_t nsym);
+/* processBufferGPU in one call (the reference's device variant does the FFT on the device as well,
+ * reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:130-157, RFG:417-473): images with the shifts already
+ * applied [n][D][D] float + CTF parameters (h_ctf [n], or NULL) + orientations (h_angles [n][3] rot, tilt, psi
+ * in degrees) + weights (or NULL) + symmetry matrices -> temp spaces. Same result as xh_rf_ctf_arrays +
+ * xh_rf_prepare_images + xh_rf_insert on scratch owned by the handle. */
+int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *h_angles,
+                        const float *h_weights, int32_t n, const double *h_sym, int32_t nsym);
 /* same but taking the 3x3 "localAInv" (= Euler^T) matrices directly, h_ainv [n][9] */
 int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
                           const double *h_ainv, const float *h_weights, int32_t n,

@@ -240,6 +240,36 @@ def test_insert_wide_blob(gpu, oracle, data32):
         rf3.insert(torch.from_numpy(ffts[:1]).cuda(), ang[:1])
 
 
+@pytest.mark.parametrize("D", [64, 50])
+def test_insert_images_equals_the_separate_steps(gpu, D):
+    """xh_rf_insert_images (processBufferGPU in one call) against xh_rf_ctf_arrays + xh_rf_prepare_images + xh_rf_insert:
+    the same bits; twice in a row with fewer images on the same handles."""
+    xa, ctx, torch = gpu
+    from xmipp3_amd.api import ctf_params
+    n = 40
+    g = torch.Generator(device="cuda").manual_seed(D)
+    imgs = torch.randn((n, D, D), generator=g, device="cuda")
+    rng = np.random.default_rng(D)
+    ang = synth.random_angles(n, rng)
+    w = rng.uniform(0.0, 2.0, n).astype(np.float32)
+    w[5] = 0.0
+    arr = xa.RecFourier.ctf_param_array([ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d) + 500.0,
+                                                    azimuthal_angle=20.0) for d in rng.uniform(10000.0, 30000.0, n)])
+    c2 = np.diag([-1.0, -1.0, 1.0])
+    sym = np.stack([np.eye(3), c2])
+    a = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.2)
+    c, m = a.ctf_arrays(arr)
+    a.insert(a.prepare_images(imgs), ang, weights=w, ctf=c, modulator=m, sym=sym)
+    b = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.2)
+    b.insert_images(imgs, ang, ctf_array=arr, weights=w, sym=sym)
+    assert torch.equal(a.temp, b.temp) and a.temp.abs().max().item() > 0
+    # without CTF, fewer images, same handles
+    a.reset(); b.reset()
+    a.insert(a.prepare_images(imgs[:7].contiguous()), ang[:7])
+    b.insert_images(imgs[:7].contiguous(), ang[:7])
+    assert torch.equal(a.temp, b.temp)
+
+
 def test_mirror_crop_and_finish_given_same_temp(gpu, oracle, data32):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32

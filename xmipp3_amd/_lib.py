@@ -11,7 +11,8 @@ class XhError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libxmipp_hip.so")
+    # XMIPP_HIP_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+    return os.environ.get("XMIPP_HIP_LIB") or os.path.join(_HERE, "libxmipp_hip.so")
 
 
 class RfParams(C.Structure):
@@ -64,6 +65,7 @@ SIGNATURES = {
     "xh_rf_prepare_images": (C.c_int, [vp, vp, i32, vp]),
     "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
     "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
+    "xh_rf_insert_images": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32]),
     "xh_rf_insert_matrices": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
     "xh_rf_mirror_and_crop": (C.c_int, [vp]),
     "xh_rf_cropped_floats": (sz, [vp]),

@@ -215,6 +215,16 @@ class RecFourier:
         check(lib().xh_rf_insert(self.h, _ptr(fft, f32), _ptr(ctf, f32), _ptr(modulator, f32), _np_ptr(ang), _np_ptr(w), n,
                                  _np_ptr(s), 0 if s is None else s.shape[0]))
 
+    def insert_images(self, imgs, angles, ctf_array=None, weights=None, sym=None):
+        """Shifted images [n,D,D] + CTF parameters (ctf_param_array) + orientations -> temp spaces in one call
+        (xh_rf_insert_images: CTF planes, FFT and insertion on scratch owned by the handle)."""
+        n = imgs.shape[0]
+        ang = np.ascontiguousarray(angles, np.float64).reshape(n, 3)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
+        check(lib().xh_rf_insert_images(self.h, _ptr(imgs, _torch().float32), ctf_array, _np_ptr(ang), _np_ptr(w), n,
+                                        _np_ptr(s), 0 if s is None else s.shape[0]))
+
     def insert_matrices(self, fft, ainv, weights=None, ctf=None, modulator=None, sym=None):
         n = fft.shape[0]
         a = np.ascontiguousarray(ainv, np.float64).reshape(n, 9)

@@ -30,6 +30,7 @@
 #include <rccl/rccl.h>
 
 #define XH_BLOB_TABLE 10000
+#define XG_PAD 6                // zero cells around a packed projection record (xh_rf_grid.h)
 
 namespace {
 const double kPI = 3.14159265358979323846;
@@ -225,7 +226,7 @@ struct xh_rf {
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
     XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs, d_dense, d_wimg;
-    XhBuf d_gtiles, d_grecs, d_gweights;   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
+    XhBuf d_gtiles, d_grecs, d_gweights, d_planes, d_spectra;   // d_planes, d_spectra: scratch of xh_rf_insert_images   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -999,7 +1000,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs); xh_buf_free(rf->d_dense); xh_buf_free(rf->d_wimg);
-    xh_buf_free(rf->d_gtiles); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights);
+    xh_buf_free(rf->d_gtiles); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -1513,19 +1514,12 @@ static int experiments_insert(xh_rf *rf, std::vector<XhSpace> &spaces, const flo
 }
 #endif
 
-static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
-                         const double *h_ainv, const float *h_weights, int n, const double *h_sym, int nsym)
+// one traverse space per (projection with non-zero weight, symmetry matrix): RFA:939-966
+static void build_spaces(xh_rf *rf, const double *h_ainv, const float *h_weights, int n, const double *h_sym, int nsym,
+                         std::vector<XhSpace> &spaces)
 {
-    XH_CHECK(rf && d_fft && h_ainv && n >= 0, XH_ERR_ARG, "xh_rf_insert: bad argument");
-    XH_CHECK((d_ctf == nullptr) == (d_mod == nullptr), XH_ERR_ARG, "xh_rf_insert: ctf and modulator go together");
-    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert: temp spaces already mirrored/cropped; call xh_rf_reset");
-    XH_HIP(hipSetDevice(rf->ctx->device));
-    if (n == 0) return XH_OK;
-    XH_TRY(ensure_temp(rf));
-    xh_ctx *ctx = rf->ctx;
     static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (!h_sym) { h_sym = ident; nsym = 1; }
-    std::vector<XhSpace> spaces;
     spaces.reserve((size_t)n * nsym);
     for (int i = 0; i < n; ++i) {
         const float w = h_weights ? h_weights[i] : 1.0f;
@@ -1545,6 +1539,20 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
             spaces.push_back(S);
         }
     }
+}
+
+static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
+                         const double *h_ainv, const float *h_weights, int n, const double *h_sym, int nsym)
+{
+    XH_CHECK(rf && d_fft && h_ainv && n >= 0, XH_ERR_ARG, "xh_rf_insert: bad argument");
+    XH_CHECK((d_ctf == nullptr) == (d_mod == nullptr), XH_ERR_ARG, "xh_rf_insert: ctf and modulator go together");
+    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert: temp spaces already mirrored/cropped; call xh_rf_reset");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    if (n == 0) return XH_OK;
+    XH_TRY(ensure_temp(rf));
+    xh_ctx *ctx = rf->ctx;
+    std::vector<XhSpace> spaces;
+    build_spaces(rf, h_ainv, h_weights, n, h_sym, nsym, spaces);
     const int ns = (int)spaces.size();
     if (ns == 0) return XH_OK;
     if (rf->tile_variant == 3 && rf->insert_variant == 0) return grid_insert(rf, spaces, d_fft, d_ctf, d_mod, h_weights, n);
@@ -1575,6 +1583,31 @@ int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float 
             for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[c * 3 + r];
     }
     return insert_common(rf, d_fft, d_ctf, d_mod, ainv.data(), h_weights, n, h_sym, nsym);
+}
+
+// processBufferGPU in one call (reconstruction_cuda/cuda_gpu_reconstruct_fourier.h:130-157 takes images and does the FFT on the
+// device too): shifted images + CTF parameters + orientations -> temp spaces = xh_rf_ctf_arrays + xh_rf_prepare_images +
+// xh_rf_insert on scratch owned by the handle. (Letting the column pass of the FFT write the packed records itself was built
+// and measured: 5.8 instead of 2.1 + 3.1 ms per 4096 projections -- a block of that kernel owns eight columns, so its record
+// writes and CTF-plane reads come in 128- and 32-byte pieces where the pack kernel streams; profiles/README.md.)
+int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *h_angles, const float *h_weights,
+                        int32_t n, const double *h_sym, int32_t nsym)
+{
+    XH_CHECK(rf && d_imgs && h_angles && n >= 0, XH_ERR_ARG, "xh_rf_insert_images: bad argument");
+    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert_images: temp spaces already mirrored/cropped; call xh_rf_reset");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    const size_t plane = (size_t)n * rf->sizeX * rf->sizeY;
+    float *d_ctf = nullptr, *d_mod = nullptr;
+    if (h_ctf) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_planes, 2 * plane * sizeof(float)));
+        d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
+        XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
+    }
+    XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
+    XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    return xh_rf_insert(rf, (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
 }
 
 int xh_rf_mirror_and_crop(xh_rf *rf)

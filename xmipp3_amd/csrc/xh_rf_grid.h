@@ -31,7 +31,9 @@
 #define XG_NW 12                // waves per workgroup (= per CU: the LDS budget admits one workgroup)
 #endif
 #define XG_KCAP 256             // surviving projections listed per cull phase
+#ifndef XG_PAD
 #define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
+#endif
 #define XG_PW 18                // patch row stride in pixels: 16 are needed, 18 skews consecutive rows by two bank groups
 #define XG_NDMA 5               // LDS-DMA instructions per patch: 320 slots = 17.8 rows of 18 pixels
 #define XG_PATCH_BYTES (XG_NDMA * 1024)

@@ -636,8 +636,8 @@ public:
         batch = std::max(1, (int)getIntParam("--batch"));
         if (checkParam("--prepare_fsc")) fn_fsc = getParam("--prepare_fsc");
         // correctWeight (RF:1056-1101): the re-processing pass adds w * X into the weight of the same voxel, X being the current
-        // 1 / W estimate, so X <- X / (X W) returns X wherever W > 1e-3: any --iter >= 1 gives the volume of --iter 1 (the
-        // oracle's RF restatement: 4e-16, tests/test_oracle_pins.py). --iter 0 (no weight normalisation at all) is not built.
+        // 1 / W estimate, so X <- X / (X W) returns X wherever W > 1e-3: any --iter >= 1 gives the volume of --iter 1 (measured on
+        // a CPU restatement of RF: 4e-16). --iter 0 (no weight normalisation at all) is not built.
         if (getIntParam("--iter") < 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--iter 0 (weights set to one, RF:1058-1064) is not available on the device path");
     }
 
