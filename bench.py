@@ -187,6 +187,7 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region
     dirs = synth.fibonacci_directions(nrefs)
+    dirs_dev = torch.from_numpy(np.ascontiguousarray(dirs[:, :2], np.float64)).to(dev)
     if args.refs == "phantom":
         # BASELINE config 2/4: the gallery = projections of the phantom at Fibonacci-sphere directions, made with the
         # library's own central-slice projector (xh_fp_*, the xmipp_angular_project_library path)
@@ -241,7 +242,7 @@ def main():
     step_no = [0]
 
     def step(record, parts=None):
-        ang = None
+        ang = flips = None
         if parts is None:
             parts = batches[step_no[0] % nuniq]
         step_no[0] += 1
@@ -252,16 +253,16 @@ def main():
                 st = pm.last_stats()
                 rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
             sx, sy, cc = pm.translate(parts, refno, psi, flip)
-            h_ref = refno.cpu().numpy()
-            h_psi = psi.cpu().numpy()
-            shifts = np.stack([sx.cpu().numpy(), sy.cpu().numpy()], 1)
-            ang = np.stack([dirs[h_ref, 0], dirs[h_ref, 1], h_psi * (360.0 / pm.N)], 1)
+            # the orientations stay on the device: (rot, tilt) of the matched reference, psi from the sample index
+            ang = torch.cat([dirs_dev[refno.long()], (psi.double() * (360.0 / pm.N))[:, None]], 1).contiguous()
+            shifts = (sx, sy)
+            flips = flip
         else:
             ang = synth.random_angles(B, rng)
             shifts = rng.uniform(-3, 3, (B, 2))
         if rf is not None:
             # the matcher has just computed the particles' B-spline coefficients: the shift reuses them
-            imgs = rf.shift_images(parts, shifts, coefs=pm.last_coefficients(B) if pm is not None else None)
+            imgs = rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B) if pm is not None else None)
             if record:
                 t_grid.start()
             rf.insert_images(imgs, ang, ctf_array=ctf_arr)      # CTF planes + FFT + records + gridding

@@ -140,6 +140,11 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY /*
  * (APM:569, RFA:304-323 through readApplyGeo). */
 int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float *h_shiftXY,
                              const uint8_t *h_flip, int32_t n, float *d_out);
+/* The same with the shifts and flips where xh_pm_translate / xh_pm_match left them (device memory: d_shiftX, d_shiftY
+ * [n] doubles, d_flip [n] bytes or NULL; d_coefs may be NULL): no host copy of the matcher's outputs is needed
+ * between the two programs (the reference passes them through a metadata file, APM:820-880 -> RFA:296-323). */
+int xh_rf_shift_images_dev(xh_rf *rf, const float *d_imgs, const float *d_coefs, const double *d_shiftX,
+                           const double *d_shiftY, const uint8_t *d_flip, int32_t n, float *d_out);
 /* preloadBuffer + cropAndShift for n images already shifted (shifts applied):
  * d_imgs [n][D][D] float  ->  d_fft [n][mv][mv/2] complex<float> (interleaved) */
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft);
@@ -158,6 +163,12 @@ int xh_rf_insert(xh_rf *rf, const float *d_fft, const float *d_ctf, const float 
  * xh_rf_prepare_images + xh_rf_insert on scratch owned by the handle. */
 int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *h_angles,
                         const float *h_weights, int32_t n, const double *h_sym, int32_t nsym);
+/* xh_rf_insert_images with the orientations where the matcher left them: d_angles [n][3] doubles (rot, tilt, psi in
+ * degrees) and d_weights [n] floats (or NULL) in device memory. The traverse spaces (RFA:939-966, 430-522) are built
+ * by a kernel from the functions the host path uses, so the two forms give the same temp spaces; a weight of 0 drops
+ * the projection (RFA:327-329). The call enqueues and returns: it never waits for the stream. */
+int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *d_angles,
+                            const float *d_weights, int32_t n, const double *h_sym, int32_t nsym);
 /* same but taking the 3x3 "localAInv" (= Euler^T) matrices directly, h_ainv [n][9] */
 int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
                           const double *h_ainv, const float *h_weights, int32_t n,

@@ -270,6 +270,47 @@ def test_insert_images_equals_the_separate_steps(gpu, D):
     assert torch.equal(a.temp, b.temp)
 
 
+@pytest.mark.parametrize("D", [64, 50])
+def test_device_side_orientations_give_the_host_forms_temp_spaces(gpu, D):
+    """xh_rf_shift_images_dev / xh_rf_insert_images_dev (shifts, flips, angles, weights in device memory, the traverse spaces
+    built by a kernel) against the host-array forms: same voxel sets, values to float rounding (the device's double sin/cos
+    may differ from libm's in the last place before the cast to float); symmetry, zero weights, CTF, --fast too."""
+    xa, ctx, torch = gpu
+    from xmipp3_amd.api import ctf_params
+    n = 48
+    g = torch.Generator(device="cuda").manual_seed(D + 1)
+    imgs = torch.randn((n, D, D), generator=g, device="cuda")
+    rng = np.random.default_rng(D + 1)
+    ang = synth.random_angles(n, rng)
+    ang[3] = (0.0, 0.0, 0.0)
+    ang[4] = (90.0, 90.0, 0.0)            # axis-aligned slabs: the degenerate branches of the row test
+    w = rng.uniform(0.0, 2.0, n).astype(np.float32)
+    w[5] = 0.0; w[17] = 0.0
+    sx = rng.uniform(-3, 3, n); sy = rng.uniform(-3, 3, n)
+    fl = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    arr = xa.RecFourier.ctf_param_array([ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d) + 500.0,
+                                                    azimuthal_angle=20.0) for d in rng.uniform(10000.0, 30000.0, n)])
+    sym = np.stack([np.eye(3), np.diag([-1.0, -1.0, 1.0])])
+    for fast in (False, True):
+        a = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.2, fast=fast)
+        b = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.2, fast=fast)
+        sa = a.shift_images(imgs, np.stack([sx, sy], 1), flips=fl)
+        sb = b.shift_images(imgs, (torch.from_numpy(sx).cuda(), torch.from_numpy(sy).cuda()), flips=torch.from_numpy(fl).cuda())
+        assert torch.equal(sa, sb)
+        a.insert_images(sa, ang, ctf_array=arr, weights=w, sym=sym)
+        b.insert_images(sb, torch.from_numpy(ang).cuda(), ctf_array=arr, weights=torch.from_numpy(w).cuda(), sym=sym)
+        ta, tb = a.temp, b.temp
+        assert ta.abs().max().item() > 0
+        assert torch.equal(ta != 0, tb != 0)
+        assert (ta - tb).abs().max().item() <= 1e-6 * ta.abs().max().item()
+        # no weights, no symmetry, no CTF, fewer images on the same handles
+        a.reset(); b.reset()
+        a.insert_images(sa[:9].contiguous(), ang[:9])
+        b.insert_images(sb[:9].contiguous(), torch.from_numpy(ang[:9].copy()).cuda())
+        assert torch.equal(a.temp != 0, b.temp != 0)
+        assert (a.temp - b.temp).abs().max().item() <= 1e-6 * a.temp.abs().max().item()
+
+
 def test_mirror_crop_and_finish_given_same_temp(gpu, oracle, data32):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32

@@ -66,6 +66,8 @@ SIGNATURES = {
     "xh_rf_ctf_arrays": (C.c_int, [vp, C.POINTER(CtfParams), i32, vp, vp]),
     "xh_rf_insert": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
     "xh_rf_insert_images": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32]),
+    "xh_rf_insert_images_dev": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32]),
+    "xh_rf_shift_images_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "xh_rf_insert_matrices": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32]),
     "xh_rf_mirror_and_crop": (C.c_int, [vp]),
     "xh_rf_cropped_floats": (sz, [vp]),

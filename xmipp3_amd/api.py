@@ -174,6 +174,13 @@ class RecFourier:
         (int) to the fp32 B-spline coefficients of imgs when the caller has them (ProjectionMatcher.last_coefficients)."""
         torch = _torch()
         n = imgs.shape[0]
+        if isinstance(shifts, tuple) and torch.is_tensor(shifts[0]) and shifts[0].is_cuda:
+            # (shiftX, shiftY) float64 tensors as ProjectionMatcher.translate returns them; flips: a uint8 tensor
+            out = torch.empty_like(imgs)
+            check(lib().xh_rf_shift_images_dev(self.h, _ptr(imgs, torch.float32), C.c_void_p(coefs) if coefs else None,
+                                               _ptr(shifts[0], torch.float64), _ptr(shifts[1], torch.float64),
+                                               _ptr(flips, torch.uint8), n, _ptr(out)))
+            return out
         sh = np.ascontiguousarray(shifts, np.float32).reshape(n, 2)
         fl = None if flips is None else np.ascontiguousarray(flips, np.uint8).reshape(n)
         out = torch.empty_like(imgs)
@@ -219,9 +226,16 @@ class RecFourier:
         """Shifted images [n,D,D] + CTF parameters (ctf_param_array) + orientations -> temp spaces in one call
         (xh_rf_insert_images: CTF planes, FFT and insertion on scratch owned by the handle)."""
         n = imgs.shape[0]
+        torch = _torch()
+        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
+        if torch.is_tensor(angles) and angles.is_cuda:
+            # orientations (float64 [n,3]) and weights (float32 [n]) that never left the device
+            assert angles.shape == (n, 3) and angles.is_contiguous()
+            check(lib().xh_rf_insert_images_dev(self.h, _ptr(imgs, torch.float32), ctf_array, _ptr(angles, torch.float64),
+                                                _ptr(weights, torch.float32), n, _np_ptr(s), 0 if s is None else s.shape[0]))
+            return
         ang = np.ascontiguousarray(angles, np.float64).reshape(n, 3)
         w = None if weights is None else np.ascontiguousarray(weights, np.float32)
-        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
         check(lib().xh_rf_insert_images(self.h, _ptr(imgs, _torch().float32), ctf_array, _np_ptr(ang), _np_ptr(w), n,
                                         _np_ptr(s), 0 if s is None else s.shape[0]))
 

@@ -117,7 +117,7 @@ double h_kaiser_fourier(double w, double a, double alpha, int m)
 }
 
 // xmippCore Euler_angles2matrix (closed form in applications/tests/function_tests/test_geometry_main.cpp:46-65)
-void h_euler(double rot, double tilt, double psi, double *A)
+__host__ __device__ inline void h_euler(double rot, double tilt, double psi, double *A)
 {
     const double a = rot * kPI / 180., b = tilt * kPI / 180., g = psi * kPI / 180.;
     const double ca = std::cos(a), cb = std::cos(b), cg = std::cos(g);
@@ -127,7 +127,7 @@ void h_euler(double rot, double tilt, double psi, double *A)
     A[3] = -sg * cc - cg * sa; A[4] = -sg * cs + cg * ca; A[5] = sg * sb;
     A[6] = sc; A[7] = ss; A[8] = cb;
 }
-void h_inv3(const double *A, double *B)
+__host__ __device__ inline void h_inv3(const double *A, double *B)
 {
     const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
@@ -149,7 +149,7 @@ struct XhSpace {
 };
 
 struct f3 { float x, y, z; };
-inline void h_mul(const float t[9], f3 &p)
+__host__ __device__ inline void h_mul(const float t[9], f3 &p)
 {
     float a = t[0] * p.x + t[1] * p.y + t[2] * p.z;
     float b = t[3] * p.x + t[4] * p.y + t[5] * p.z;
@@ -158,8 +158,8 @@ inline void h_mul(const float t[9], f3 &p)
 }
 
 // RFA:430-442,492-522,258-269,724-741 in float, same operation order
-void h_make_space(XhSpace &S, const double *A_SL, const double *A_SLInv, int mv, double blobRadius,
-                  bool useFast, float weight, int img)
+__host__ __device__ inline void h_make_space(XhSpace &S, const double *A_SL, const double *A_SLInv, int mv, double blobRadius,
+                                             bool useFast, float weight, int img)
 {
     float tr[9];
     for (int i = 0; i < 9; ++i) { tr[i] = A_SL[i]; S.tInv[i] = A_SLInv[i]; }
@@ -203,6 +203,19 @@ void h_make_space(XhSpace &S, const double *A_SL, const double *A_SLInv, int mv,
     S.weight = weight;
     S.img = img;
 }
+// one traverse space from a symmetry matrix and the projection's inverse orientation (RFA:939-966)
+__host__ __device__ inline void h_place(XhSpace &S, const double *R, const double *Ainv, int mv, double blobRadius, bool useFast, float w, int img)
+{
+    double A_SL[9], A_SLInv[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += R[r * 3 + k] * Ainv[k * 3 + c];
+            A_SL[r * 3 + c] = acc;
+        }
+    h_inv3(A_SL, A_SLInv);
+    h_make_space(S, A_SL, A_SLInv, mv, blobRadius, useFast, w, img);
+}
 }  // namespace
 
 struct xh_rf {
@@ -227,6 +240,12 @@ struct xh_rf {
     XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
     XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs, d_dense, d_wimg;
     XhBuf d_gtiles, d_grecs, d_gweights, d_planes, d_spectra;   // d_planes, d_spectra: scratch of xh_rf_insert_images   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
+    // pinned staging of the small host arrays (records, shifts, CTF parameters): uploads never wait for the stream
+    unsigned char *h_stage = nullptr;
+    size_t stageCap = 0, stageUsed = 0;
+    hipEvent_t stageEv = nullptr;
+    bool stagePending = false;
+    XhBuf d_sym, d_angles;          // device-side inputs of k_rf_spaces
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -243,6 +262,32 @@ struct xh_rf {
     int tile_min_spaces;
     int tile_dbg;         // ablation switch of the tile kernel (profiling only)
 };
+
+// Copies a host array to the device behind everything already enqueued, without waiting for the stream: the bytes pass
+// through a pinned area owned by the handle, which is only waited for (its last copy, not the stream) when it wraps.
+static int stage_upload(xh_rf *rf, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (bytes == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (!rf->stageEv) XH_HIP(hipEventCreateWithFlags(&rf->stageEv, hipEventDisableTiming));
+    if (rf->stageUsed + need > rf->stageCap) {
+        if (rf->stagePending) { XH_HIP(hipEventSynchronize(rf->stageEv)); rf->stagePending = false; }
+        if (need > rf->stageCap) {
+            if (rf->h_stage) XH_HIP(hipHostFree(rf->h_stage));
+            rf->h_stage = nullptr;
+            rf->stageCap = std::max(need, std::max<size_t>(2 * rf->stageCap, (size_t)4 << 20));
+            XH_HIP(hipHostMalloc((void **)&rf->h_stage, rf->stageCap, hipHostMallocDefault));
+        }
+        rf->stageUsed = 0;
+    }
+    memcpy(rf->h_stage + rf->stageUsed, h_src, bytes);
+    XH_HIP(hipMemcpyAsync(d_dst, rf->h_stage + rf->stageUsed, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rf->stageUsed += need;
+    XH_HIP(hipEventRecord(rf->stageEv, ctx->stream));
+    rf->stagePending = true;
+    return XH_OK;
+}
 
 // =========================================================================== device code
 // ---- 2-D r2c FFT of the zero-padded, centred image (RFA:332-345) ------------------------
@@ -1000,6 +1045,9 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs); xh_buf_free(rf->d_dense); xh_buf_free(rf->d_wimg);
+    xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles);
+    if (rf->h_stage) (void)hipHostFree(rf->h_stage);
+    if (rf->stageEv) (void)hipEventDestroy(rf->stageEv);
     xh_buf_free(rf->d_gtiles); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
@@ -1149,6 +1197,9 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
 }
 
 
+// shifts as [n] float2 and flips as [n] bytes (or null) already on the device
+static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float2 *d_shiftXY, const unsigned char *d_flip, int n, float *d_out);
+
 int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float *h_shiftXY, const uint8_t *h_flip, int32_t n, float *d_out)
 {
     XH_CHECK(rf && d_imgs && h_shiftXY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images: bad argument");
@@ -1156,16 +1207,42 @@ int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coef
     XH_CHECK(d_imgs != d_out, XH_ERR_ARG, "xh_rf_shift_images: in-place operation is not supported");
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
-    const int D = rf->D;
-    if (!d_coefs) XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
     XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n + (size_t)n));
-    XH_HIP(hipMemcpyAsync(rf->d_shiftXY.p, h_shiftXY, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    XH_TRY(stage_upload(rf, rf->d_shiftXY.p, h_shiftXY, sizeof(float) * 2 * (size_t)n));
     unsigned char *d_flip = nullptr;
     if (h_flip) {
         d_flip = (unsigned char *)rf->d_shiftXY.p + sizeof(float) * 2 * (size_t)n;
-        XH_HIP(hipMemcpyAsync(d_flip, h_flip, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        XH_TRY(stage_upload(rf, d_flip, h_flip, (size_t)n));
     }
-    XH_HIP(hipStreamSynchronize(ctx->stream));
+    return shift_images_run(rf, d_imgs, d_coefs, (const float2 *)rf->d_shiftXY.p, d_flip, n, d_out);
+}
+
+// the matcher's outputs as they lie on the device (xh_pm_translate: double shifts; xh_pm_match: flips)
+__global__ void k_rf_shift_args(const double *__restrict__ sx, const double *__restrict__ sy, float2 *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float2((float)sx[i], (float)sy[i]);
+}
+
+int xh_rf_shift_images_dev(xh_rf *rf, const float *d_imgs, const float *d_coefs, const double *d_shiftX, const double *d_shiftY,
+                           const uint8_t *d_flip, int32_t n, float *d_out)
+{
+    XH_CHECK(rf && d_imgs && d_shiftX && d_shiftY && d_out && n >= 0, XH_ERR_ARG, "xh_rf_shift_images_dev: bad argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    XH_CHECK(d_imgs != d_out, XH_ERR_ARG, "xh_rf_shift_images_dev: in-place operation is not supported");
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    XH_TRY(xh_buf_reserve(ctx, rf->d_shiftXY, sizeof(float) * 2 * (size_t)n + (size_t)n));
+    hipLaunchKernelGGL(k_rf_shift_args, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_shiftX, d_shiftY, (float2 *)rf->d_shiftXY.p, n);
+    XH_LAUNCH_CHECK();
+    return shift_images_run(rf, d_imgs, d_coefs, (const float2 *)rf->d_shiftXY.p, d_flip, n, d_out);
+}
+
+static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs, const float2 *d_shiftXY, const unsigned char *d_flip, int n, float *d_out)
+{
+    xh_ctx *ctx = rf->ctx;
+    const int D = rf->D;
+    if (!d_coefs) XH_TRY(xh_buf_reserve(ctx, rf->d_shiftCoef, sizeof(float) * (size_t)n * D * D));
     if (d_coefs) {
         // the caller's coefficients
     } else if (D >= 2 * XH_FIR_K) {
@@ -1188,7 +1265,7 @@ int xh_rf_shift_images_coefs(xh_rf *rf, const float *d_imgs, const float *d_coef
     XH_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p, d_imgs,
-                       (const float2 *)rf->d_shiftXY.p, (const unsigned char *)d_flip, d_out, D);
+                       d_shiftXY, d_flip, d_out, D);
     XH_LAUNCH_CHECK();
     return XH_OK;
 }
@@ -1226,8 +1303,7 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
         d.phase_shift = c.phase_shift; d.VPP_radius = c.VPP_radius;
     }
     XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
-    XH_HIP(hipMemcpyAsync(rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));  // hc is a stack-lifetime buffer
+    XH_TRY(stage_upload(rf, rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n));
     const int dcRow = rf->P / 2;
     const size_t total = (size_t)n * rf->sizeX * std::max(rf->sizeY - dcRow, dcRow + 1);
     hipLaunchKernelGGL(k_rf_ctf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1240,11 +1316,35 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
 // ---- the product path: k_rf_grid ------------------------------------------------------------------------------------
 // spaces -> records + cull vectors (host), packed projection records, super-tile lists (k_rf_supercull), one launch per
 // chunk of at most tile_max_spaces traverse spaces
+static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, const float *d_mod, const float *d_weights, int n);
+
 static int grid_insert(xh_rf *rf, std::vector<XhSpace> &spaces, const float *d_fft, const float *d_ctf, const float *d_mod,
                        const float *h_weights, int n)
 {
     xh_ctx *ctx = rf->ctx;
     const int ns = (int)spaces.size();
+    const double br = rf->p.blob_radius;
+    // cull vectors, records, per-image weights
+    std::vector<float4> cull((size_t)ns * 2);
+    std::vector<XgRec> grecs(ns);
+    for (int i = 0; i < ns; ++i) xg_fill_rec(grecs[i], cull[i], cull[(size_t)ns + i], spaces[i], br);
+    XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float4) * cull.size()));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_grecs, sizeof(XgRec) * (size_t)ns));
+    XH_TRY(stage_upload(rf, rf->d_cull.p, cull.data(), sizeof(float4) * cull.size()));
+    XH_TRY(stage_upload(rf, rf->d_grecs.p, grecs.data(), sizeof(XgRec) * (size_t)ns));
+    const float *d_weights = nullptr;
+    if (h_weights) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_gweights, sizeof(float) * (size_t)n));
+        XH_TRY(stage_upload(rf, rf->d_gweights.p, h_weights, sizeof(float) * (size_t)n));
+        d_weights = (const float *)rf->d_gweights.p;
+    }
+    return grid_run(rf, ns, d_fft, d_ctf, d_mod, d_weights, n);
+}
+
+// the device side: d_cull ([2][ns] float4) and d_grecs ([ns]) are in place
+static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, const float *d_mod, const float *d_weights, int n)
+{
+    xh_ctx *ctx = rf->ctx;
     const double br = rf->p.blob_radius;
     const bool fast = rf->p.use_fast != 0;
     XH_CHECK(br < 3.0, XH_ERR_UNSUPPORTED, "xh_rf_insert: blob radius %g: the gridding kernel covers footprints up to 6 x 6 pixels (radius < 3)", br);
@@ -1254,38 +1354,9 @@ static int grid_insert(xh_rf *rf, std::vector<XhSpace> &spaces, const float *d_f
     XH_CHECK(cells < ((size_t)1 << 31), XH_ERR_ARG, "xh_rf_insert: more than 2^31 record cells in one call; insert in smaller batches");
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
-    // cull vectors (plane normal, image x axis; .w: their 1-norms), records, per-image weights
-    std::vector<float> cull((size_t)ns * 8);
-    std::vector<XgRec> grecs(ns);
-    for (int i = 0; i < ns; ++i) {
-        const XhSpace &S = spaces[i];
-        float *nv = &cull[(size_t)i * 4], *xv = &cull[(size_t)(ns + i) * 4];
-        nv[0] = S.tInv[6]; nv[1] = S.tInv[7]; nv[2] = S.tInv[8]; nv[3] = std::fabs(nv[0]) + std::fabs(nv[1]) + std::fabs(nv[2]);
-        xv[0] = S.tInv[0]; xv[1] = S.tInv[1]; xv[2] = S.tInv[2]; xv[3] = std::fabs(xv[0]) + std::fabs(xv[1]) + std::fabs(xv[2]);
-        int im = S.img, yy = S.minY | (S.maxY << 16), zz = S.minZ | (S.maxZ << 16);
-        float fi, fy, fz;
-        memcpy(&fi, &im, 4); memcpy(&fy, &yy, 4); memcpy(&fz, &zz, 4);
-        XgRec &G = grecs[i];
-        G.r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], fi);
-        G.r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], fy);
-        G.r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], fz);
-        xg_fill_hit(G, S, br);
-        // image extent of a unit (half extents 3.5, 3.5, 1.5 voxels) + blob radius: where its first footprint pixel lies
-        G.h2.z = 3.5f * (std::fabs(S.tInv[0]) + std::fabs(S.tInv[1])) + 1.5f * std::fabs(S.tInv[2]) + 0.01f + (float)br;
-        G.h2.w = 3.5f * (std::fabs(S.tInv[3]) + std::fabs(S.tInv[4])) + 1.5f * std::fabs(S.tInv[5]) + 0.01f + (float)br;
-    }
-    std::vector<float> gweights(n);
-    for (int i = 0; i < n; ++i) gweights[i] = h_weights ? h_weights[i] : 1.0f;
-    XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
-    XH_TRY(xh_buf_reserve(ctx, rf->d_grecs, sizeof(XgRec) * (size_t)ns));
-    XH_TRY(xh_buf_reserve(ctx, rf->d_gweights, sizeof(float) * (size_t)n));
-    XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipMemcpyAsync(rf->d_grecs.p, grecs.data(), sizeof(XgRec) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipMemcpyAsync(rf->d_gweights.p, gweights.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));       // the host vectors go out of scope
     XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(float4)));
     hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
-                       (const float *)rf->d_gweights.p, (float4 *)rf->d_pack.p, n, rf->sizeX, rf->sizeY);
+                       d_weights, (float4 *)rf->d_pack.p, n, rf->sizeX, rf->sizeY);
     XH_LAUNCH_CHECK();
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds
     // nothing): (double)ix + r >= 0, (double)ix - r <= sizeX - 1, the same for iy, are monotone in the float, so the
@@ -1525,17 +1596,8 @@ static void build_spaces(xh_rf *rf, const double *h_ainv, const float *h_weights
         const float w = h_weights ? h_weights[i] : 1.0f;
         if (h_weights && w == 0.f) continue;  // RFA:327-329
         for (int s = 0; s < nsym; ++s) {
-            double A_SL[9], A_SLInv[9];
-            const double *R = h_sym + 9 * s, *Ainv = h_ainv + 9 * (size_t)i;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) {
-                    double acc = 0;
-                    for (int k = 0; k < 3; ++k) acc += R[r * 3 + k] * Ainv[k * 3 + c];
-                    A_SL[r * 3 + c] = acc;
-                }
-            h_inv3(A_SL, A_SLInv);
             XhSpace S;
-            h_make_space(S, A_SL, A_SLInv, rf->mv, rf->p.blob_radius, rf->p.use_fast != 0, w, i);
+            h_place(S, h_sym + 9 * s, h_ainv + 9 * (size_t)i, rf->mv, rf->p.blob_radius, rf->p.use_fast != 0, w, i);
             spaces.push_back(S);
         }
     }
@@ -1608,6 +1670,45 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
     XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
     XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
     return xh_rf_insert(rf, (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
+}
+
+// The same with the orientations where the matcher left them: d_angles [n][3] doubles (rot, tilt, psi in degrees),
+// d_weights [n] or null. The records are built on the device (k_rf_spaces: the host's own functions, compiled for both);
+// nothing in the call waits for the stream.
+int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *d_angles, const float *d_weights,
+                            int32_t n, const double *h_sym, int32_t nsym)
+{
+    XH_CHECK(rf && d_imgs && d_angles && n >= 0, XH_ERR_ARG, "xh_rf_insert_images_dev: bad argument");
+    XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert_images_dev: temp spaces already mirrored/cropped; call xh_rf_reset");
+    XH_CHECK(rf->tile_variant == 3 && rf->insert_variant == 0, XH_ERR_UNSUPPORTED, "xh_rf_insert_images_dev: only the gridding kernel of the product path takes device-side orientations");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    if (n == 0) return XH_OK;
+    XH_TRY(ensure_temp(rf));
+    xh_ctx *ctx = rf->ctx;
+    if (!h_sym) nsym = 1;
+    XH_CHECK(nsym >= 1 && (size_t)n * nsym < ((size_t)1 << 30), XH_ERR_ARG, "xh_rf_insert_images_dev: bad symmetry count");
+    const size_t plane = (size_t)n * rf->sizeX * rf->sizeY;
+    float *d_ctf = nullptr, *d_mod = nullptr;
+    if (h_ctf) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_planes, 2 * plane * sizeof(float)));
+        d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
+        XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
+    }
+    XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
+    XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    const int ns = n * nsym;
+    const double *d_sym = nullptr;
+    if (h_sym) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_sym, sizeof(double) * 9 * (size_t)nsym));
+        XH_TRY(stage_upload(rf, rf->d_sym.p, h_sym, sizeof(double) * 9 * (size_t)nsym));
+        d_sym = (const double *)rf->d_sym.p;
+    }
+    XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float4) * 2 * (size_t)ns));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_grecs, sizeof(XgRec) * (size_t)ns));
+    hipLaunchKernelGGL(k_rf_spaces, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, d_angles, d_weights, d_sym, n, nsym, rf->mv,
+                       rf->p.blob_radius, rf->p.use_fast, (XgRec *)rf->d_grecs.p, (float4 *)rf->d_cull.p, (float4 *)rf->d_cull.p + ns);
+    XH_LAUNCH_CHECK();
+    return grid_run(rf, ns, (const float *)rf->d_spectra.p, d_ctf, d_mod, d_weights, n);
 }
 
 int xh_rf_mirror_and_crop(xh_rf *rf)

@@ -95,7 +95,7 @@ __global__ void k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__re
 //   u = ((z - z0) a1 + (y0 - y) a2) / (a1 b2 - b1 a2),  t = (y - y0 - u b1) / a1,  row visited iff 0 < u, t < 1 on either face.
 // Both are affine in (y, z); the device evaluates the affine forms and only where a value comes within a band of 0 or 1
 // -- the band covers the rounding of both evaluations -- does the lane repeat the reference's own float arithmetic.
-static void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
+__host__ __device__ static inline void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
 {
     const double a1 = S.u[1], a2 = S.u[2], b1 = S.v[1], b2 = S.v[2];
     const double den = a1 * b2 - b1 * a2;
@@ -124,6 +124,52 @@ static void xg_fill_hit(XgRec &G, const XhSpace &S, double blobRadius)
     const double mt = L * (std::fabs(Ty) + std::fabs(Tz)) + std::fabs(T01) + std::fabs(T02) + 1.0;
     const double bt = eps * (mt + (L + std::fabs(y01) + std::fabs(y02) + (mu + 1.0) * std::fabs(b1)) / std::fabs(a1)) + bu * std::fabs(b1 / a1);
     G.h2.x = (float)std::min(bu, 1e30); G.h2.y = (float)std::min(bt, 1e30);
+}
+
+// The record of a traverse space and its two cull vectors (plane normal, image x axis; .w: their 1-norms, the support
+// function of a unit cube).
+__host__ __device__ static inline void xg_fill_rec(XgRec &G, float4 &nv, float4 &xv, const XhSpace &S, double blobRadius)
+{
+    nv = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], std::fabs(S.tInv[6]) + std::fabs(S.tInv[7]) + std::fabs(S.tInv[8]));
+    xv = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], std::fabs(S.tInv[0]) + std::fabs(S.tInv[1]) + std::fabs(S.tInv[2]));
+    G.r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], __builtin_bit_cast(float, S.img));
+    G.r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], __builtin_bit_cast(float, S.minY | (S.maxY << 16)));
+    G.r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], __builtin_bit_cast(float, S.minZ | (S.maxZ << 16)));
+    xg_fill_hit(G, S, blobRadius);
+    // image extent of a unit (half extents 3.5, 3.5, 1.5 voxels) + blob radius: where its first footprint pixel lies
+    G.h2.z = 3.5f * (std::fabs(S.tInv[0]) + std::fabs(S.tInv[1])) + 1.5f * std::fabs(S.tInv[2]) + 0.01f + (float)blobRadius;
+    G.h2.w = 3.5f * (std::fabs(S.tInv[3]) + std::fabs(S.tInv[4])) + 1.5f * std::fabs(S.tInv[5]) + 0.01f + (float)blobRadius;
+}
+
+// The same on the device, from Euler angles that never left it (xh_rf_insert_images_dev): one thread per (projection,
+// symmetry matrix). A projection of weight 0 keeps its slot with NaN cull vectors, which no list admits (RFA:327-329).
+__global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ angles, const float *__restrict__ weights,
+                                                   const double *__restrict__ sym, int n, int nsym, int mv, double blobRadius,
+                                                   int useFast, XgRec *__restrict__ recs, float4 *__restrict__ cullN,
+                                                   float4 *__restrict__ cullX)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * nsym) return;
+    const int i = idx / nsym, s = idx - i * nsym;
+    const float w = weights ? weights[i] : 1.0f;
+    double A[9], T[9], R[9];
+    h_euler(angles[3 * i], angles[3 * i + 1], angles[3 * i + 2], A);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[c * 3 + r];   // localAInv = A^T (RFA:348-350)
+    for (int k = 0; k < 9; ++k) R[k] = sym ? sym[9 * s + k] : (k % 4 == 0 ? 1.0 : 0.0);
+    XhSpace S;
+    h_place(S, R, T, mv, blobRadius, useFast != 0, w, i);
+    XgRec G;
+    float4 nv, xv;
+    xg_fill_rec(G, nv, xv, S, blobRadius);
+    if (weights && w == 0.f) {
+        const float q = __builtin_nanf("");
+        nv = make_float4(q, q, q, q);
+        xv = nv;
+    }
+    recs[idx] = G;
+    cullN[idx] = nv;
+    cullX[idx] = xv;
 }
 
 // W: footprint width (4 for a blob radius below 2, 6 below 3). FAST: processVoxel (RFA:595-625), nearest pixel, one voxel per row.
