@@ -84,20 +84,22 @@ __global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, co
 struct XhFir { float h[XH_FIR_K + 1]; };
 template <bool COLS>
 __global__ void __launch_bounds__(256)
-k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D, size_t nvec, XhFir F)
+k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D, XhFir F)
 {
     // thread <-> XH_FIR_V consecutive outputs along the filtered axis; neighbouring threads are neighbours
-    // along x for the column pass (coalesced rows) and along the line for the row pass
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nvec) return;
-    const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+    // along x for the column pass (coalesced rows) and along the line for the row pass. blockIdx.y: image
+    // (32-bit index arithmetic throughout: a 64-bit division costs more than the filter itself)
+    const unsigned segs = (D + XH_FIR_V - 1) / XH_FIR_V;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (unsigned)D * segs) return;
     int x0, y0;
-    size_t img;
-    if (COLS) { x0 = t % D; y0 = (int)((t / D) % segs) * XH_FIR_V; img = t / ((size_t)D * segs); }
-    else { x0 = (int)(t % segs) * XH_FIR_V; y0 = (int)((t / segs) % D); img = t / ((size_t)segs * D); }
-    const float *src = in + img * D * D;
+    if (COLS) { const unsigned q = t / (unsigned)D; x0 = t - q * D; y0 = q * XH_FIR_V; }
+    else { const unsigned q = t / segs; x0 = (t - q * segs) * XH_FIR_V; y0 = q; }
+    const size_t base = (size_t)blockIdx.y * D * D;
+    const float *src = in + base;
     float w[XH_FIR_V + 2 * XH_FIR_K];
-    if (!COLS && (D & 3) == 0 && x0 >= XH_FIR_K && x0 + XH_FIR_V + XH_FIR_K <= D) {
+    const bool vec = !COLS && (D & 3) == 0;
+    if (vec && x0 >= XH_FIR_K && x0 + XH_FIR_V + XH_FIR_K <= D) {
         // interior of a row: the window is 16-byte aligned (x0 and XH_FIR_K are multiples of 4), ten float4 loads
         const float4 *v = reinterpret_cast<const float4 *>(src + (size_t)y0 * D + x0 - XH_FIR_K);
 #pragma unroll
@@ -113,15 +115,26 @@ k_pm_prefilter_fir(const float *__restrict__ in, float *__restrict__ out, int D,
         while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
         w[i] = COLS ? src[(size_t)p * D + x0] : src[(size_t)y0 * D + p];
     }
+    float res[XH_FIR_V];
+#pragma unroll
+    for (int o = 0; o < XH_FIR_V; ++o) {
+        float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+        res[o] = acc;
+    }
+    if (vec && x0 + XH_FIR_V <= D) {
+        float4 *d = reinterpret_cast<float4 *>(out + base + (size_t)y0 * D + x0);
+#pragma unroll
+        for (int i = 0; i < XH_FIR_V / 4; ++i) d[i] = make_float4(res[4 * i], res[4 * i + 1], res[4 * i + 2], res[4 * i + 3]);
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < XH_FIR_V; ++o) {
         const int q = (COLS ? y0 : x0) + o;
         if (q >= D) break;
-        float acc = F.h[0] * w[o + XH_FIR_K];
-#pragma unroll
-        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
-        if (COLS) out[img * D * D + (size_t)q * D + x0] = acc;
-        else out[img * D * D + (size_t)y0 * D + q] = acc;
+        if (COLS) out[base + (size_t)q * D + x0] = res[o];
+        else out[base + (size_t)y0 * D + q] = res[o];
     }
 }
 
@@ -180,6 +193,19 @@ static inline XhFir xh_fir_taps()
     const double z = sqrt(3.0) - 2.0;
     for (int j = 0; j <= XH_FIR_K; ++j) F.h[j] = (float)(sqrt(3.0) * pow(z, j));
     return F;
+}
+
+// both passes over n images [n][D][D]: in -> tmp (rows) -> out (columns); tmp may be any scratch of the same size
+static inline void xh_prefilter_fir_launch(hipStream_t stream, const float *in, float *tmp, float *out, int D, size_t n)
+{
+    const XhFir F = xh_fir_taps();
+    const unsigned segs = (D + XH_FIR_V - 1) / XH_FIR_V, blocks = ((unsigned)D * segs + 255) / 256;
+    const size_t img = (size_t)D * D;
+    for (size_t i0 = 0; i0 < n; i0 += 65535) {
+        const unsigned m = (unsigned)std::min<size_t>(65535, n - i0);
+        hipLaunchKernelGGL((k_pm_prefilter_fir<false>), dim3(blocks, m), dim3(256), 0, stream, in + i0 * img, tmp + i0 * img, D, F);
+        hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3(blocks, m), dim3(256), 0, stream, (const float *)(tmp + i0 * img), out + i0 * img, D, F);
+    }
 }
 
 template <typename T> __device__ __forceinline__ T d_bspline03(T x)

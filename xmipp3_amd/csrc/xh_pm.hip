@@ -354,7 +354,7 @@ typedef float xh_f32x16_rd __attribute__((ext_vector_type(16)));
 // one round of a block: NA live frequency tiles for this wave (kt0 + wv + 4*i, i < NA). Every wave of
 // the block runs the same number of barriers whatever its NA.
 template <int NA>
-__device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], const xh_cf *sT, const float *__restrict__ polar,
+__device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], float (*sO)[XH_RD_CH + 1], const xh_cf *sT, const float *__restrict__ polar,
                                          const float *sMean, xh_cf *__restrict__ out, int n, int nk, int kt0,
                                          int slot0, int nslots, int nsamples, int soffr, int coffr, int ncoef, int conjugate, int dbg)
 {
@@ -371,44 +371,58 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], const xh_cf 
         j[i] = (sl * k) % n;        // s = sl at the first step
         dj[i] = (2 * k) % n;
     }
+    // The samples are real: with E[s] = x[s] + x[n-s], O[s] = x[s] - x[n-s] (E[0] = x[0], E[n/2] = x[n/2], O = 0 there)
+    //   Re X[k] = sum_{s=0}^{n/2} E[s] tw[sk].x,   Im X[k] = sum_{s=0}^{n/2} O[s] tw[sk].y
+    // -- half the matrix-core work of the plain sum over n samples. The fold happens on the way into LDS.
+    const int nh = n >> 1, nf = nh + 1;
     // chunk c+1 travels from HBM/L2 into registers while the matrix cores work on chunk c
-    float pre[32];
+    float preA[32], preB[32];
     auto fetch = [&](int sc) {
-        const int ss = min(sc + tid, n - 1);
+        const int ss = min(sc + tid, nh);
+        const int sb = ss == 0 ? 0 : n - ss;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) pre[q] = polar[(size_t)min(slot0 + q, nslots - 1) * nsamples + soffr + ss];
+        for (int q = 0; q < 32; ++q) {
+            const float *row = polar + (size_t)min(slot0 + q, nslots - 1) * nsamples + soffr;
+            preA[q] = row[ss];
+            preB[q] = row[sb];
+        }
     };
     fetch(0);
-    for (int sc = 0; sc < n; sc += XH_RD_CH) {
+    for (int sc = 0; sc < nf; sc += XH_RD_CH) {
         __syncthreads();            // previous chunk consumed (and sT / sMean visible on the first pass)
-        const bool inRing = sc + tid < n;
+        const int ss = sc + tid;
+        const bool inRing = ss < nf, edge = ss == 0 || ss == nh;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) sX[q][tid] = inRing ? pre[q] - sMean[q] : 0.f;
+        for (int q = 0; q < 32; ++q) {
+            const float xa = preA[q] - sMean[q], xb = preB[q] - sMean[q];
+            sX[q][tid] = inRing ? (edge ? xa : xa + xb) : 0.f;
+            sO[q][tid] = inRing && !edge ? xa - xb : 0.f;
+        }
         __syncthreads();
-        if (sc + XH_RD_CH < n && dbg != 1) fetch(sc + XH_RD_CH);
+        if (sc + XH_RD_CH < nf && dbg != 1) fetch(sc + XH_RD_CH);
         if (NA > 0 && dbg != 2) {
-            const int cn = min(XH_RD_CH, n - sc);          // even
+            const int cn = min(XH_RD_CH, nf - sc);          // an odd count runs one step into the zero padding
             // operands of step t+1 are read from LDS while the matrix cores run step t
-            float a = sX[kl][sl];
+            float ae = sX[kl][sl], ao = sO[kl][sl];
             xh_cf w[NR];
 #pragma unroll
             for (int i = 0; i < NA; ++i) { w[i] = sT[j[i] + (j[i] >> 4)]; j[i] += dj[i]; if (j[i] >= n) j[i] -= n; }
             for (int t = 0; t < cn; t += 2) {
                 // program order M M L M M L ...: each LDS read has the following tiles' MFMAs to land.
                 // (the reads of the last step fetch operands that are never used)
-                const float an = sX[kl][min(t + 2 + sl, XH_RD_CH)];
+                const float ane = sX[kl][min(t + 2 + sl, XH_RD_CH)], ano = sO[kl][min(t + 2 + sl, XH_RD_CH)];
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    accR[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[i].x, accR[i], 0, 0, 0);
-                    accI[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[i].y, accI[i], 0, 0, 0);
+                    accR[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, w[i].x, accR[i], 0, 0, 0);
+                    accI[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, w[i].y, accI[i], 0, 0, 0);
                     w[i] = sT[j[i] + (j[i] >> 4)];     // one pad entry per 16: strides s*k stop piling onto one bank
                     j[i] += dj[i];
                     if (j[i] >= n) j[i] -= n;
                 }
-                a = an;
+                ae = ane; ao = ano;
                 // scheduling hint; measured best of the variants tried (reads hoisted above the MFMAs: +7 %,
                 // strict M M L interleave: +6 %)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -443,7 +457,8 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float (*sX)[XH_RD_CH + 1] = reinterpret_cast<float (*)[XH_RD_CH + 1]>(smem);
-    xh_cf *sT = reinterpret_cast<xh_cf *>(smem + sizeof(float) * 32 * (XH_RD_CH + 1));
+    float (*sO)[XH_RD_CH + 1] = sX + 32;
+    xh_cf *sT = reinterpret_cast<xh_cf *>(smem + sizeof(float) * 64 * (XH_RD_CH + 1));
     const int r = nrings - 1 - blockIdx.x;        // long rings first
     const int slot0 = blockIdx.y * 32;
     const int n = nsam[r], nk = n / 2 + 1, nkt = (nk + 31) / 32;
@@ -455,7 +470,7 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
     for (int kt0 = 0; kt0 < nkt; kt0 += 4 * XH_RD_KT) {
         const int left = nkt - kt0 - wv;          // tiles kt0+wv, +4, +8, +12 that exist
         const int nact = __builtin_amdgcn_readfirstlane(left <= 0 ? 0 : min(XH_RD_KT, (left + 3) / 4));
-#define XH_RD_GO(NA_) rd_round<NA_>(sX, sT, polar, sMean, out, n, nk, kt0, slot0, nslots, nsamples, soff[r], coff[r], ncoef, conjugate, dbg)
+#define XH_RD_GO(NA_) rd_round<NA_>(sX, sO, sT, polar, sMean, out, n, nk, kt0, slot0, nslots, nsamples, soff[r], coff[r], ncoef, conjugate, dbg)
 #if XH_RD_KT >= 4
         if (nact == 4) XH_RD_GO(4);
         else if (nact == 3) XH_RD_GO(3);
@@ -2060,14 +2075,8 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * nps * L.ncoef));
     XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * nps));
     if (std::is_same<T, float>::value && imgsAreFloat && !d_gather && !d_count && pm->use_fir && D >= 2 * XH_FIR_K) {
-        const XhFir F = xh_fir_taps();
-        const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
-        const size_t nvec = (size_t)nslots * D * segs;
         XH_TRY(xh_buf_reserve(ctx, pm->d_firTmp, sizeof(float) * (size_t)nslots * D * D));
-        hipLaunchKernelGGL((k_pm_prefilter_fir<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float *)imgs, (float *)pm->d_firTmp.p, D, nvec, F);
-        hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float *)pm->d_firTmp.p, (float *)coefBuf.p, D, nvec, F);
+        xh_prefilter_fir_launch(ctx->stream, (const float *)imgs, (float *)pm->d_firTmp.p, (float *)coefBuf.p, D, (size_t)nslots);
         XH_LAUNCH_CHECK();
     } else if (std::is_same<T, double>::value && pm->use_fir64 && D >= 16) {
         // fp64: the 65-tap convolution form (source images gathered, device-side count honoured)
@@ -2129,7 +2138,8 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     }
     }
     if (std::is_same<T, float>::value && !d_count && pm->use_mfma) {
-        const size_t smemM = sizeof(float) * 32 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
+        const size_t smemM = sizeof(float) * 64 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
+        XH_HIP(hipFuncSetAttribute((const void *)k_pm_ringdft_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemM));
         hipLaunchKernelGGL(k_pm_ringdft_mfma, dim3(L.nrings, (unsigned)((nps + 31) / 32)), dim3(256), smemM, ctx->stream,
                            (const float *)polarBuf.p, (const double *)statBuf.p, (xh_cf *)outBuf.p, (const xh_cf *)twBuf.p,
                            (const int *)pm->d_nsam.p, (const int *)pm->d_soff.p, (const int *)pm->d_coff.p, L.nsamples, L.ncoef,

@@ -368,24 +368,81 @@ k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, XhPlan<float>
 // ---- Image::readApplyGeo with only_apply_shifts (RFA:304-323): translation by (shiftX, shiftY)
 // with cubic B-spline interpolation and wrapping (xmippCore applyGeometry(BSPLINE3, ..., WRAP)).
 // out(x,y) samples the prefiltered input at (x - shiftX, y - shiftY).
-__global__ void k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
-                           const float2 *__restrict__ shifts, const unsigned char *__restrict__ flips,
-                           float *__restrict__ out, int D)
+// A thread owns XH_SHIFT_V vertically adjacent output pixels: they share the column x, hence the four source columns and
+// their weights, and their footprints overlap in all but one row each, so the row sums (the inner loop of
+// interpolatedElementBSpline2D) are formed once per source row -- XH_SHIFT_V + 3 of them instead of 4 XH_SHIFT_V -- with the
+// expressions and the order d_interp uses: same bits.
+#define XH_SHIFT_V 4
+__global__ void __launch_bounds__(256)
+k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
+           const float2 *__restrict__ shifts, const unsigned char *__restrict__ flips,
+           float *__restrict__ out, int D)
 {
     const int p = blockIdx.y;
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= D * D) return;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned groups = (D + XH_SHIFT_V - 1) / XH_SHIFT_V;
+    if (t >= groups * (unsigned)D) return;
+    const int g = t / (unsigned)D, j = t - g * D, i0 = g * XH_SHIFT_V;
     const float2 sh = shifts[p];
     const bool flip = flips && flips[p];
-    if (!flip && sh.x == 0.f && sh.y == 0.f) { out[(size_t)p * D * D + pix] = imgs[(size_t)p * D * D + pix]; return; }
-    const int i = pix / D, j = pix - i * D, cen = D / 2;
+    const size_t base = (size_t)p * D * D;
+    if (!flip && sh.x == 0.f && sh.y == 0.f) {
+#pragma unroll
+        for (int k = 0; k < XH_SHIFT_V; ++k)
+            if (i0 + k < D) out[base + (size_t)(i0 + k) * D + j] = imgs[base + (size_t)(i0 + k) * D + j];
+        return;
+    }
+    const int cen = D / 2;
     const float minp = -cen, maxp = D - cen - 1;
     // A = [[+-1,0,sx],[0,1,sy]] (flip negates the first row of the 2x2 part, xmippCore
     // geo2TransformationMatrix); IS_NOT_INV => sample the input at A^-1 (x,y)
-    float xp = flip ? sh.x - (float)(j - cen) : (float)(j - cen) - sh.x, yp = (float)(i - cen) - sh.y;
+    float xp = flip ? sh.x - (float)(j - cen) : (float)(j - cen) - sh.x;
     if (xp < minp - 1e-6f || xp > maxp + 1e-6f) xp = d_realwrap<float>(xp, minp - 0.5f, maxp + 0.5f);
-    if (yp < minp - 1e-6f || yp > maxp + 1e-6f) yp = d_realwrap<float>(yp, minp - 0.5f, maxp + 0.5f);
-    out[(size_t)p * D * D + pix] = d_interp<float>(coefs + (size_t)p * D * D, D, xp, yp);
+    float yp[XH_SHIFT_V], ys[XH_SHIFT_V];
+    int m1[XH_SHIFT_V];
+    bool chain = true;
+#pragma unroll
+    for (int k = 0; k < XH_SHIFT_V; ++k) {
+        yp[k] = (float)(i0 + k - cen) - sh.y;
+        if (yp[k] < minp - 1e-6f || yp[k] > maxp + 1e-6f) yp[k] = d_realwrap<float>(yp[k], minp - 0.5f, maxp + 0.5f);
+        ys[k] = yp[k] - (float)(-cen);                 // d_interp: y -= start
+        m1[k] = (int)ceilf(ys[k] - 2.f);
+        chain = chain && m1[k] == m1[0] + k;
+    }
+    const float *cf = coefs + base;
+    if (!chain || i0 + XH_SHIFT_V > D) {               // a wrap inside the group (or the last, partial group): pixel by pixel
+#pragma unroll
+        for (int k = 0; k < XH_SHIFT_V; ++k)
+            if (i0 + k < D) out[base + (size_t)(i0 + k) * D + j] = d_interp<float>(cf, D, xp, yp[k]);
+        return;
+    }
+    const float xs = xp - (float)(-cen);
+    const int l1 = (int)ceilf(xs - 2.f);
+    float wx[4];
+    d_bspline03_w4<float>(xs, l1, wx);
+    int el[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int l = l1 + u; el[u] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l); }
+    float rows[XH_SHIFT_V + 3];
+#pragma unroll
+    for (int r = 0; r < XH_SHIFT_V + 3; ++r) {
+        const int m = m1[0] + r;
+        const int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
+        const float *ref = cf + (size_t)em * D;
+        float acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += ref[el[u]] * wx[u];
+        rows[r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < XH_SHIFT_V; ++k) {
+        float wy[4];
+        d_bspline03_w4<float>(ys[k], m1[k], wy);
+        float columns = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) columns += rows[k + tt] * wy[tt];
+        out[base + (size_t)(i0 + k) * D + j] = columns;
+    }
 }
 
 // ---- CTF planes (RFA:548-592; data/ctf.h:452-502,1002-1029; data/ctf.cpp:645-679,1392-1402)
@@ -517,8 +574,11 @@ __device__ double d_bessj0(double x)
 __device__ __forceinline__ void d_ctf_pixel(const XhCtfDev &c, int x, int y, int P, double iTs, double minCTF, int phaseFlipped,
                                             float &ctfOut, float &modOut)
 {
-    const float freqY = (y - (P / 2.f)) / (float)P;
-    float freqX = (float)((double)(x <= P / 2 ? x : x - P) / (double)P);
+    // a power-of-two P divides exactly: the products by 1/P are the quotients, bit for bit
+    const bool pow2 = (P & (P - 1)) == 0;
+    const float freqY = pow2 ? (y - (P / 2.f)) * (1.0f / (float)P) : (y - (P / 2.f)) / (float)P;
+    const double xr = (double)(x <= P / 2 ? x : x - P);
+    float freqX = (float)(pow2 ? xr * (1.0 / (double)P) : xr / (double)P);
     const double X = freqX * iTs, Y = freqY * iTs;
     const double u2 = X * X + Y * Y;
     const double u = sqrt(u2);
@@ -536,7 +596,8 @@ __device__ __forceinline__ void d_ctf_pixel(const XhCtfDev &c, int x, int y, int
     double sine_part, cosine_part;
     sincos(argument, &sine_part, &cosine_part);
     const double Eespr = c.K3 == 0 ? 1.0 : exp(-c.K3 * u4);
-    const double EdeltaF = d_bessj0(c.K5 * u2);
+    // d_bessj0(0) is the quotient of the two leading coefficients (not 1): the compiler folds the same IEEE division
+    const double EdeltaF = c.K5 == 0 ? 57568490574.0 / 57568490411.0 : d_bessj0(c.K5 * u2);
     const double xs = u * c.DeltaR;
     const double EdeltaR = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
     const double aux = (c.K7 * u2 * u + deltaf * u);
@@ -565,12 +626,10 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
 {
     const int dc = P / 2;                                   // row of freqY = 0
     const int up = max(sizeY - dc, dc + 1);                 // rows dc .. dc+up-1 cover every pair (dc+k, dc-k)
-    const size_t perHalf = (size_t)sizeX * up;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= perHalf * n) return;
-    const int img = idx / perHalf;
-    const int rem = idx - (size_t)img * perHalf;
-    const int k = rem / sizeX, x = rem - k * sizeX;
+    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= (unsigned)sizeX * up) return;
+    const int img = blockIdx.y;
+    const int k = rem / (unsigned)sizeX, x = rem - k * sizeX;
     const XhCtfDev c = cp[img];
     const size_t base = (size_t)img * sizeX * sizeY;
     const int y1 = dc + k, y2 = dc - k;
@@ -1247,12 +1306,7 @@ static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs
         // the caller's coefficients
     } else if (D >= 2 * XH_FIR_K) {
         // fp32 prefilter in its convolution form (xh_bspline.h); d_out is free until the shift kernel writes it
-        const XhFir F = xh_fir_taps();
-        const int segs = (D + XH_FIR_V - 1) / XH_FIR_V;
-        const size_t nvec = (size_t)n * D * segs;
-        hipLaunchKernelGGL((k_pm_prefilter_fir<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, d_imgs, d_out, D, nvec, F);
-        hipLaunchKernelGGL((k_pm_prefilter_fir<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_out,
-                           (float *)rf->d_shiftCoef.p, D, nvec, F);
+        xh_prefilter_fir_launch(ctx->stream, d_imgs, d_out, (float *)rf->d_shiftCoef.p, D, (size_t)n);
         XH_LAUNCH_CHECK();
     } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(float)))));
@@ -1264,7 +1318,7 @@ static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs
                        (const int *)nullptr);
     XH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rf_shift, dim3((D * D + 255) / 256, n), dim3(256), 0, ctx->stream, d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p, d_imgs,
+    hipLaunchKernelGGL(k_rf_shift, dim3((D * ((D + XH_SHIFT_V - 1) / XH_SHIFT_V) + 255) / 256, n), dim3(256), 0, ctx->stream, d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p, d_imgs,
                        d_shiftXY, d_flip, d_out, D);
     XH_LAUNCH_CHECK();
     return XH_OK;
@@ -1305,10 +1359,14 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
     XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
     XH_TRY(stage_upload(rf, rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n));
     const int dcRow = rf->P / 2;
-    const size_t total = (size_t)n * rf->sizeX * std::max(rf->sizeY - dcRow, dcRow + 1);
-    hipLaunchKernelGGL(k_rf_ctf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const XhCtfDev *)rf->d_ctfp.p, d_ctf, d_mod, n, rf->sizeX, rf->sizeY, rf->P,
-                       1.0 / rf->p.sampling, rf->p.min_ctf, rf->p.phase_flipped);
+    const unsigned perImg = (unsigned)rf->sizeX * std::max(rf->sizeY - dcRow, dcRow + 1);
+    for (int i0 = 0; i0 < n; i0 += 65535) {            // blockIdx.y: image
+        const int m = std::min(65535, n - i0);
+        const size_t o = (size_t)i0 * rf->sizeX * rf->sizeY;
+        hipLaunchKernelGGL(k_rf_ctf, dim3((perImg + 255) / 256, m), dim3(256), 0, ctx->stream,
+                           (const XhCtfDev *)rf->d_ctfp.p + i0, d_ctf + o, d_mod + o, m, rf->sizeX, rf->sizeY, rf->P,
+                           1.0 / rf->p.sampling, rf->p.min_ctf, rf->p.phase_flipped);
+    }
     XH_LAUNCH_CHECK();
     return XH_OK;
 }
@@ -1355,9 +1413,14 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
     XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(float4)));
-    hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
-                       d_weights, (float4 *)rf->d_pack.p, n, rf->sizeX, rf->sizeY);
-    XH_LAUNCH_CHECK();
+    for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
+        const int m = std::min(65535, n - i0);
+        const size_t o = (size_t)i0 * rf->sizeX * rf->sizeY;
+        hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((SXp * SYp + XG_PACK_CELLS - 1) / XG_PACK_CELLS), m), dim3(256), 0, ctx->stream,
+                           (const xh_cf *)d_fft + o, d_ctf ? d_ctf + o : nullptr, d_mod ? d_mod + o : nullptr, d_weights ? d_weights + i0 : nullptr,
+                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
+        XH_LAUNCH_CHECK();
+    }
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds
     // nothing): (double)ix + r >= 0, (double)ix - r <= sizeX - 1, the same for iy, are monotone in the float, so the
     // smallest / largest floats that pass, found with the very expressions, decide the same thing

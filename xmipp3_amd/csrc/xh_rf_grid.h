@@ -67,28 +67,47 @@ __device__ __forceinline__ void xg_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)
 typedef float xg_v2f __attribute__((ext_vector_type(2)));
 typedef float xg_v4f __attribute__((ext_vector_type(4)));
 
-// float4 (re*ctf*mod*w, im*ctf*mod*w, mod*w, 0) per pixel, XG_PAD zero cells on every side
-__global__ void k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
-                               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
+// float4 (re*ctf*mod*w, im*ctf*mod*w, mod*w, 0) per pixel, XG_PAD zero cells on every side. blockIdx.y: image;
+// a block writes XG_PACK_CELLS consecutive cells of the padded record (a kilobyte per wave and store instruction).
+#define XG_PACK_CELLS 1024
+__global__ void __launch_bounds__(256)
+k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
+               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
 {
-    const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
-    const size_t total = (size_t)n * SY * SX;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int x = gid % SX - XG_PAD;
-    const int y = (gid / SX) % SY - XG_PAD;
-    const size_t img = gid / ((size_t)SX * SY);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 0 && x < sizeX && y >= 0 && y < sizeY) {
-        const size_t o = img * sizeX * sizeY + (size_t)y * sizeX + x;
-        const xh_cf f = ffts[o];
-        const float w = weights ? weights[img] : 1.f;
-        if (ctfs) {
-            const float mw = mods[o] * w, c = ctfs[o];
-            v = make_float4(f.x * mw * c, f.y * mw * c, mw, 0.f);
-        } else v = make_float4(f.x * w, f.y * w, w, 0.f);
+    const unsigned SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD, cells = SX * SY;
+    const unsigned img = blockIdx.y;
+    const float w = weights ? weights[img] : 1.f;
+    const size_t src = (size_t)img * sizeX * sizeY;
+    float4 *dst = pk + (size_t)img * cells;
+    // all loads of the thread's four cells first (bytes in flight are what a streaming kernel runs on), then the stores
+    constexpr int NC = XG_PACK_CELLS / 256;
+    xh_cf f[NC];
+    float cm[NC], cc[NC];
+    bool in[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const unsigned c = blockIdx.x * XG_PACK_CELLS + k * 256 + threadIdx.x;
+        const unsigned row = c / SX;
+        const int x = (int)(c - row * SX) - XG_PAD, y = (int)row - XG_PAD;
+        in[k] = x >= 0 && x < sizeX && y >= 0 && y < sizeY;     // false beyond the last cell too (y >= sizeY)
+        const size_t o = src + (size_t)(in[k] ? y * sizeX + x : 0);
+        f[k] = xh_cf{0.f, 0.f}; cm[k] = 1.f; cc[k] = 1.f;
+        if (in[k]) {
+            f[k] = ffts[o];
+            if (ctfs) { cm[k] = mods[o]; cc[k] = ctfs[o]; }
+        }
     }
-    pk[gid] = v;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const unsigned c = blockIdx.x * XG_PACK_CELLS + k * 256 + threadIdx.x;
+        if (c >= cells) break;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[k]) {
+            if (ctfs) { const float mw = cm[k] * w; v = make_float4(f[k].x * mw * cc[k], f[k].y * mw * cc[k], mw, 0.f); }
+            else v = make_float4(f[k].x * w, f[k].y * w, w, 0.f);
+        }
+        dst[c] = v;
+    }
 }
 
 // Host side of the row-visit test. getX (RFA:479-490) intersects the voxel row (y, z) with a face of the slab:
