@@ -26,6 +26,7 @@ int xh_buf_alloc(xh_ctx *ctx, XhBuf &b, size_t bytes)
         return XH_ERR_NOMEM;
     }
     b.bytes = bytes;
+    if (getenv("XH_ALLOC_TRACE")) fprintf(stderr, "xh_buf_alloc %zu bytes -> %p\n", bytes, b.p);
     return XH_OK;
 }
 void xh_buf_free(XhBuf &b)

@@ -246,6 +246,7 @@ struct xh_rf {
     hipEvent_t stageEv = nullptr;
     bool stagePending = false;
     XhBuf d_sym, d_angles;          // device-side inputs of k_rf_spaces
+    bool packCtf = false;           // xh_rf_insert_images: the pack kernel evaluates the CTF of d_ctfp itself
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -261,6 +262,7 @@ struct xh_rf {
     int insert_variant;   // 0 = product path; 1/2 = ablation experiments on the scatter kernel; 3 = force scatter
     int tile_min_spaces;
     int tile_dbg;         // ablation switch of the tile kernel (profiling only)
+    int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
 };
 
 // Copies a host array to the device behind everything already enqueued, without waiting for the stream: the bytes pass
@@ -1129,6 +1131,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     if (!strcmp(name, "insert_variant")) rf->insert_variant = (int)value;
     else if (!strcmp(name, "tile_min_spaces")) rf->tile_min_spaces = (int)value;
     else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
+    else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
     else if (!strcmp(name, "supercull")) rf->use_supercull = (int)value;
@@ -1329,11 +1332,9 @@ int xh_rf_shift_images(xh_rf *rf, const float *d_imgs, const float *h_shiftXY, c
     return xh_rf_shift_images_coefs(rf, d_imgs, nullptr, h_shiftXY, h_flip, n, d_out);
 }
 
-int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod)
+// produceSideInfo of n CTF descriptions -> rf->d_ctfp (device)
+static int ctf_params_upload(xh_rf *rf, const xh_ctf_params *h_ctf, int n)
 {
-    XH_CHECK(rf && h_ctf && d_ctf && d_mod && n >= 0, XH_ERR_ARG, "xh_rf_ctf_arrays: bad argument");
-    XH_HIP(hipSetDevice(rf->ctx->device));
-    if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
     std::vector<XhCtfDev> hc(n);
     for (int i = 0; i < n; ++i) {
@@ -1358,6 +1359,16 @@ int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_
     }
     XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
     XH_TRY(stage_upload(rf, rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n));
+    return XH_OK;
+}
+
+int xh_rf_ctf_arrays(xh_rf *rf, const xh_ctf_params *h_ctf, int32_t n, float *d_ctf, float *d_mod)
+{
+    XH_CHECK(rf && h_ctf && d_ctf && d_mod && n >= 0, XH_ERR_ARG, "xh_rf_ctf_arrays: bad argument");
+    XH_HIP(hipSetDevice(rf->ctx->device));
+    if (n == 0) return XH_OK;
+    xh_ctx *ctx = rf->ctx;
+    XH_TRY(ctf_params_upload(rf, h_ctf, n));
     const int dcRow = rf->P / 2;
     const unsigned perImg = (unsigned)rf->sizeX * std::max(rf->sizeY - dcRow, dcRow + 1);
     for (int i0 = 0; i0 < n; i0 += 65535) {            // blockIdx.y: image
@@ -1416,9 +1427,16 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
         const int m = std::min(65535, n - i0);
         const size_t o = (size_t)i0 * rf->sizeX * rf->sizeY;
+        if (rf->packCtf) {
+            const int dc = rf->P / 2, K = std::max(rf->sizeY + XG_PAD - dc, dc + XG_PAD + 1);
+            hipLaunchKernelGGL(k_rf_pack_grid_ctf, dim3((unsigned)((K * SXp + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft + o,
+                               (const XhCtfDev *)rf->d_ctfp.p + i0, d_weights ? d_weights + i0 : nullptr,
+                               (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, rf->sizeX, rf->sizeY, rf->P, 1.0 / rf->p.sampling,
+                               rf->p.min_ctf, rf->p.phase_flipped);
+        } else
         hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((SXp * SYp + XG_PACK_CELLS - 1) / XG_PACK_CELLS), m), dim3(256), 0, ctx->stream,
                            (const xh_cf *)d_fft + o, d_ctf ? d_ctf + o : nullptr, d_mod ? d_mod + o : nullptr, d_weights ? d_weights + i0 : nullptr,
-                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
+                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY, rf->tile_dbg);
         XH_LAUNCH_CHECK();
     }
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds
@@ -1725,14 +1743,19 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
     xh_ctx *ctx = rf->ctx;
     const size_t plane = (size_t)n * rf->sizeX * rf->sizeY;
     float *d_ctf = nullptr, *d_mod = nullptr;
-    if (h_ctf) {
+    const bool fuse = h_ctf && rf->tile_variant == 3 && rf->insert_variant == 0 && rf->fuse_ctf;
+    if (fuse) XH_TRY(ctf_params_upload(rf, h_ctf, n));      // the pack kernel evaluates the CTF: no planes
+    else if (h_ctf) {
         XH_TRY(xh_buf_reserve(ctx, rf->d_planes, 2 * plane * sizeof(float)));
         d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
         XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
     }
     XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
     XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
-    return xh_rf_insert(rf, (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
+    rf->packCtf = fuse;
+    const int rc = xh_rf_insert(rf, (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
+    rf->packCtf = false;
+    return rc;
 }
 
 // The same with the orientations where the matcher left them: d_angles [n][3] doubles (rot, tilt, psi in degrees),
@@ -1752,7 +1775,9 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
     XH_CHECK(nsym >= 1 && (size_t)n * nsym < ((size_t)1 << 30), XH_ERR_ARG, "xh_rf_insert_images_dev: bad symmetry count");
     const size_t plane = (size_t)n * rf->sizeX * rf->sizeY;
     float *d_ctf = nullptr, *d_mod = nullptr;
-    if (h_ctf) {
+    const bool fuse = h_ctf && rf->fuse_ctf;
+    if (fuse) XH_TRY(ctf_params_upload(rf, h_ctf, n));      // the pack kernel evaluates the CTF: no planes
+    else if (h_ctf) {
         XH_TRY(xh_buf_reserve(ctx, rf->d_planes, 2 * plane * sizeof(float)));
         d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
         XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
@@ -1771,7 +1796,10 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
     hipLaunchKernelGGL(k_rf_spaces, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, d_angles, d_weights, d_sym, n, nsym, rf->mv,
                        rf->p.blob_radius, rf->p.use_fast, (XgRec *)rf->d_grecs.p, (float4 *)rf->d_cull.p, (float4 *)rf->d_cull.p + ns);
     XH_LAUNCH_CHECK();
-    return grid_run(rf, ns, (const float *)rf->d_spectra.p, d_ctf, d_mod, d_weights, n);
+    rf->packCtf = fuse;
+    const int rc = grid_run(rf, ns, (const float *)rf->d_spectra.p, d_ctf, d_mod, d_weights, n);
+    rf->packCtf = false;
+    return rc;
 }
 
 int xh_rf_mirror_and_crop(xh_rf *rf)

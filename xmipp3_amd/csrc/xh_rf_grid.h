@@ -72,7 +72,7 @@ typedef float xg_v4f __attribute__((ext_vector_type(4)));
 #define XG_PACK_CELLS 1024
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
-               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
+               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY, int dbg)
 {
     const unsigned SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD, cells = SX * SY;
     const unsigned img = blockIdx.y;
@@ -92,7 +92,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
         in[k] = x >= 0 && x < sizeX && y >= 0 && y < sizeY;     // false beyond the last cell too (y >= sizeY)
         const size_t o = src + (size_t)(in[k] ? y * sizeX + x : 0);
         f[k] = xh_cf{0.f, 0.f}; cm[k] = 1.f; cc[k] = 1.f;
-        if (in[k]) {
+        if (in[k] && dbg != 10) {
             f[k] = ffts[o];
             if (ctfs) { cm[k] = mods[o]; cc[k] = ctfs[o]; }
         }
@@ -106,8 +106,51 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
             if (ctfs) { const float mw = cm[k] * w; v = make_float4(f[k].x * mw * cc[k], f[k].y * mw * cc[k], mw, 0.f); }
             else v = make_float4(f[k].x * w, f[k].y * w, w, 0.f);
         }
-        dst[c] = v;
+        if (dbg != 11 || v.x == 123.456f) dst[c] = v;
     }
+}
+
+// The same records with the CTF planes never written: the CTF factor and the modulator of a pixel (preloadCTF, RFA:548-592)
+// are evaluated here by the function k_rf_ctf uses, so the records equal those packed from xh_rf_ctf_arrays' planes bit for
+// bit, and 2 x 8 bytes per pixel of plane traffic (written, then read back) disappear. A thread owns the pixel (x, dc + k)
+// and its mirror row (x, dc - k): a non-astigmatic CTF is the same on both, evaluated once (see k_rf_ctf).
+__global__ void __launch_bounds__(256)
+k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ cp, const float *__restrict__ weights,
+                   float4 *__restrict__ pk, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+{
+    const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
+    const int dc = P / 2;
+    const int K = max(sizeY + XG_PAD - dc, dc + XG_PAD + 1);       // rows dc + k up to the lower frame, dc - k up to the upper
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (unsigned)K * SX) return;
+    const int k = c / (unsigned)SX, x = (int)(c - k * SX) - XG_PAD;
+    const unsigned img = blockIdx.y;
+    const XhCtfDev par = cp[img];
+    const float w = weights ? weights[img] : 1.f;
+    const xh_cf *src = ffts + (size_t)img * sizeX * sizeY;
+    float4 *dst = pk + (size_t)img * SX * SY;
+    const int y1 = dc + k, y2 = dc - k;
+    const bool row1 = y1 < sizeY + XG_PAD, row2 = k > 0 && y2 >= -XG_PAD && y2 < sizeY + XG_PAD;
+    const bool inx = x >= 0 && x < sizeX;
+    const bool in1 = inx && y1 < sizeY, in2 = inx && k > 0 && y2 >= 0 && y2 < sizeY;
+    xh_cf f1 = xh_cf{0.f, 0.f}, f2 = f1;
+    if (in1) f1 = src[(size_t)y1 * sizeX + x];
+    if (in2) f2 = src[(size_t)y2 * sizeX + x];
+    float cv = 0.f, mv_ = 0.f;
+    float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
+    if (in1) {
+        d_ctf_pixel(par, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        const float mw = mv_ * w;
+        v1 = make_float4(f1.x * mw * cv, f1.y * mw * cv, mw, 0.f);
+    }
+    if (in2) {
+        // rows dc+k and dc-k have opposite freqY only for even P (freqY = (y - P/2)/P)
+        if (!(in1 && par.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_pixel(par, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        const float mw = mv_ * w;
+        v2 = make_float4(f2.x * mw * cv, f2.y * mw * cv, mw, 0.f);
+    }
+    if (row1) dst[(size_t)(y1 + XG_PAD) * SX + (x + XG_PAD)] = v1;
+    if (row2) dst[(size_t)(y2 + XG_PAD) * SX + (x + XG_PAD)] = v2;
 }
 
 // Host side of the row-visit test. getX (RFA:479-490) intersects the voxel row (y, z) with a face of the slab:
