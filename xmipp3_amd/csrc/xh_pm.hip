@@ -2075,8 +2075,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     XH_TRY(xh_buf_reserve(ctx, outBuf, sizeof(xh_c2<T>) * nps * L.ncoef));
     XH_TRY(xh_buf_reserve(ctx, statBuf, sizeof(double) * 2 * nps));
     if (std::is_same<T, float>::value && imgsAreFloat && !d_gather && !d_count && pm->use_fir && D >= 2 * XH_FIR_K) {
-        XH_TRY(xh_buf_reserve(ctx, pm->d_firTmp, sizeof(float) * (size_t)nslots * D * D));
-        xh_prefilter_fir_launch(ctx->stream, (const float *)imgs, (float *)pm->d_firTmp.p, (float *)coefBuf.p, D, (size_t)nslots);
+        xh_prefilter_fir_launch(ctx->stream, (const float *)imgs, (float *)coefBuf.p, D, (size_t)nslots);
         XH_LAUNCH_CHECK();
     } else if (std::is_same<T, double>::value && pm->use_fir64 && D >= 16) {
         // fp64: the 65-tap convolution form (source images gathered, device-side count honoured)

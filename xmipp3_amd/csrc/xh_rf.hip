@@ -1309,7 +1309,7 @@ static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs
         // the caller's coefficients
     } else if (D >= 2 * XH_FIR_K) {
         // fp32 prefilter in its convolution form (xh_bspline.h); d_out is free until the shift kernel writes it
-        xh_prefilter_fir_launch(ctx->stream, d_imgs, d_out, (float *)rf->d_shiftCoef.p, D, (size_t)n);
+        xh_prefilter_fir_launch(ctx->stream, d_imgs, (float *)rf->d_shiftCoef.p, D, (size_t)n);
         XH_LAUNCH_CHECK();
     } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(float)))));
