@@ -247,6 +247,7 @@ struct xh_rf {
     bool stagePending = false;
     XhBuf d_sym, d_angles;          // device-side inputs of k_rf_spaces
     bool packCtf = false;           // xh_rf_insert_images: the pack kernel evaluates the CTF of d_ctfp itself
+    const float *packImgs = nullptr; // ... and the records come straight from the images (k_rf_colsA + k_rf_rowsB<PACK>)
     int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
     int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
@@ -263,6 +264,7 @@ struct xh_rf {
     int tile_min_spaces;
     int tile_dbg;         // ablation switch of the tile kernel (profiling only)
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
+    int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)
 };
 
 // Copies a host array to the device behind everything already enqueued, without waiting for the stream: the bytes pass
@@ -558,6 +560,88 @@ k_rf_cols2(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, const xh_cf 
     }
 }
 
+// ---- the same transform, columns first (k_rf_colsA), rows last (k_rf_rowsB) ------------------------------------------
+// The projections are real: the column pass transforms two image columns per complex line and keeps ky = 0 .. sizeX
+// ([m][sizeX + 1][D] complex, as many bytes as the row-first intermediate); the row pass then runs over contiguous lines
+// and every transformed line ky gives two output rows, F(kx, ky) and F(kx, -ky) = conj F(-kx, ky), each written as one
+// contiguous row -- of the half spectrum (xh_rf_prepare_images) or, with PACK, of the padded records the gridding kernel
+// reads, CTF factor and modulator evaluated on the spot (xh_rf_insert_images: the half spectra and the CTF planes are
+// never written). Same conventions as k_rf_rows2 / k_rf_cols2: pad about the Xmipp origin, CenterFFT, forward FFT, crop,
+// 1/P^2, cut beyond max_resolution.
+// where k_rf_colsA<.., LN> stores image column x of a line of T
+template <int LN> __device__ __forceinline__ int xh_rf_tpos(int x)
+{
+    const int xl = x & (4 * LN - 1);
+    return (x - xl) + 2 * LN * ((xl >> 1) & 1) + 2 * (xl >> 2) + (xl & 1);
+}
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_rf_colsA(const float *__restrict__ imgs, xh_cf *__restrict__ T, const xh_cf *__restrict__ W, int D, int TD, int sizeX)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int P = G::D, ZS = P + 1;                      // ZS: line stride of the natural-order copy
+    constexpr int NC = 4 * G::LN;                            // image columns of a block: two rounds of LN column pairs
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int groupsPerImg = (D + NC - 1) / NC;
+    const int img = blockIdx.x / groupsPerImg;
+    const int x0 = (blockIdx.x - img * groupsPerImg) * NC;
+    for (int i = tid; i < P; i += 256) sW[i] = W[i];
+    const int half = D / 2;
+    const float *src = imgs + (size_t)img * D * D;
+    xh_cf *dst = T + (size_t)img * (sizeX + 1) * TD;
+    // a thread fetches four neighbouring columns of its rows at once (16 bytes; eight threads cover a 128-byte line): the
+    // first two are its line of round 0, the other two of round 1
+    float4 q[R1];
+    const int cl = tid % G::LN, n2 = tid / G::LN;            // neighbouring threads, neighbouring column quadruples
+    const int xa = x0 + 4 * cl;
+    if (tid < G::LN * R2) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int py = n1 * R2 + n2;                     // padded, centred position along y
+            int row = -1;
+            if (py < D - half) row = py + half;
+            else if (py >= P - half) row = py - P + half;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0) {
+                const float *r = src + (size_t)row * D + xa;
+                if (xa + 3 < D && (D & 3) == 0) val = *reinterpret_cast<const float4 *>(r);
+                else { if (xa < D) val.x = r[0]; if (xa + 1 < D) val.y = r[1]; if (xa + 2 < D) val.z = r[2]; if (xa + 3 < D) val.w = r[3]; }
+            }
+            q[n1] = val;
+        }
+    }
+    for (int round = 0; round < 2; ++round) {
+        __syncthreads();                                     // sW ready / the previous round's lines consumed
+        xh_cf v[G::RM];
+        if (tid < G::LN * R2) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[n1] = round ? xh_cf{q[n1].z, q[n1].w} : xh_cf{q[n1].x, q[n1].y};
+            tr_fwd1<R1, R2>(v, s + cl * G::LS, sW, n2);
+        }
+        __syncthreads();
+        if (tid < G::LN * R1) tr_fwd2<R1, R2>(v, s + (tid % G::LN) * G::LS, tid / G::LN);
+        __syncthreads();
+        if (tid < G::LN * R1) {
+            const int c2 = tid % G::LN, k1 = tid / G::LN;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) s[c2 * ZS + k1 + R1 * k2] = v[k2];
+        }
+        __syncthreads();
+        // Z = FFT(g_a + i g_b)  ->  G_a[k] = (Z[k] + conj Z[-k]) / 2,  G_b[k] = (Z[k] - conj Z[-k]) / 2i
+        // line c2 of this round holds the image columns x0 + 4 c2 + 2 round (+ 1); they are stored round by round (the
+        // columns of a line of T are permuted within the block's NC, xh_rf_tpos: k_rf_rowsB reads them back the same way),
+        // so that every (ky, round) is one contiguous piece
+        for (int it = tid; it < (sizeX + 1) * 2 * G::LN; it += 256) {
+            const int c = it % (2 * G::LN), ky = it / (2 * G::LN);
+            const xh_cf a = s[(c >> 1) * ZS + ky], bq = s[(c >> 1) * ZS + ((P - ky) & (P - 1))];
+            dst[(size_t)ky * TD + x0 + 2 * G::LN * round + c] = (c & 1) ? xh_cf{0.5f * (a.y + bq.y), -0.5f * (a.x - bq.x)} : xh_cf{0.5f * (a.x + bq.x), 0.5f * (a.y - bq.y)};
+        }
+    }
+}
+
 __device__ double d_bessj0(double x)
 {
     double ax = fabs(x);
@@ -648,6 +732,109 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
         if (!(have && c.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_pixel(c, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
         ctf[base + (size_t)y2 * sizeX + x] = cv;
         mod[base + (size_t)y2 * sizeX + x] = mv_;
+    }
+}
+
+template <int R1, int R2, bool PACK>
+__global__ void __launch_bounds__(256)
+k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, float4 *__restrict__ pk, const XhCtfDev *__restrict__ cp,
+           const float *__restrict__ weights, const xh_cf *__restrict__ W, int D, int TD, int sizeX, double maxResSqr, int nlines,
+           double iTs, double minCTF, int phaseFlipped)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int P = G::D, ZS = P + 1;
+    constexpr int PAD = PACK ? XG_PAD : 0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int groupsPerImg = (nlines + G::LN - 1) / G::LN;    // nlines = sizeX + 1 (+ PAD: the zero rows of the frame)
+    const int img = blockIdx.x / groupsPerImg;
+    const int k0 = (blockIdx.x - img * groupsPerImg) * G::LN;
+    for (int i = tid; i < P; i += 256) sW[i] = W[i];
+    __syncthreads();
+    const int half = D / 2, sizeY = 2 * sizeX;
+    const xh_cf *src = T + (size_t)img * (sizeX + 1) * TD;
+    xh_cf v[G::RM];
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        const bool live = k0 + l <= sizeX;
+        const xh_cf *line = src + (size_t)(k0 + l) * TD;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int px = n1 * R2 + n2;
+            xh_cf val = xh_cf{0.f, 0.f};
+            if (live) {
+                if (px < D - half) val = line[xh_rf_tpos<G::LN>(px + half)];
+                else if (px >= P - half) val = line[xh_rf_tpos<G::LN>(px - P + half)];
+            }
+            v[n1] = val;
+        }
+        tr_fwd1<R1, R2>(v, s + l * G::LS, sW, n2);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        tr_fwd2<R1, R2>(v, s + l * G::LS, k1);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[l * ZS + k1 + R1 * k2] = v[k2];
+    }
+    __syncthreads();
+    const float scale = 1.0f / ((float)P * (float)P);
+    const int SX = sizeX + 2 * PAD, SY = sizeY + 2 * PAD;
+    XhCtfDev par;
+    float w = 1.f;
+    if (PACK) { par = cp[img]; w = weights ? weights[img] : 1.f; }
+    for (int l = 0; l < G::LN; ++l) {
+        const int k = k0 + l;
+        if (k >= nlines) break;
+        const int r1 = sizeX + k, r2 = sizeX - k;            // output rows of ky = k and ky = -k
+        const bool row1 = r1 < sizeY + PAD, row2 = k >= 1 && r2 >= -PAD;
+        const double fy = (double)k / (double)P;
+        if (PACK && tid < 2 * PAD) {                          // the frame cells left and right of the two rows
+            const int xc = tid < PAD ? tid : sizeX + tid;
+            float4 *dst = pk + (size_t)img * SX * SY;
+            if (row1) dst[(size_t)(r1 + PAD) * SX + xc] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row2) dst[(size_t)(r2 + PAD) * SX + xc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int j = tid; j < sizeX; j += 256) {             // thread <-> kx: every wave has the same number of CTF values to find
+            const int xc = j + PAD;
+            const bool in1 = r1 < sizeY, in2 = k >= 1 && r2 >= 0;
+            xh_cf o1 = xh_cf{0.f, 0.f}, o2 = o1;
+            if (in1 || in2) {
+                const double fx = (double)j / (double)P;     // j <= P/2
+                if (!(fx * fx + fy * fy > maxResSqr)) {
+                    const xh_cf a = s[l * ZS + j], b = s[l * ZS + ((P - j) & (P - 1))];
+                    o1 = xh_cf{a.x * scale, a.y * scale};
+                    o2 = xh_cf{b.x * scale, -b.y * scale};
+                }
+            }
+            if constexpr (!PACK) {
+                if (in1) out[((size_t)img * sizeY + r1) * sizeX + j] = o1;
+                if (in2) out[((size_t)img * sizeY + r2) * sizeX + j] = o2;
+            } else {
+                float cv = 0.f, mv_ = 0.f;
+                float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
+                if (in1) {
+                    d_ctf_pixel(par, j, r1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+                    const float mw = mv_ * w;
+                    v1 = make_float4(o1.x * mw * cv, o1.y * mw * cv, mw, 0.f);
+                }
+                if (in2) {
+                    // rows sizeX + k and sizeX - k have opposite freqY (sizeX = P / 2, P even): see k_rf_ctf
+                    if (!(in1 && par.defocus_deviation == 0)) d_ctf_pixel(par, j, r2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+                    const float mw = mv_ * w;
+                    v2 = make_float4(o2.x * mw * cv, o2.y * mw * cv, mw, 0.f);
+                }
+                float4 *dst = pk + (size_t)img * SX * SY;
+                if (row1) dst[(size_t)(r1 + PAD) * SX + xc] = v1;
+                if (row2) dst[(size_t)(r2 + PAD) * SX + xc] = v2;
+            }
+        }
     }
 }
 
@@ -1132,6 +1319,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "tile_min_spaces")) rf->tile_min_spaces = (int)value;
     else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
+    else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
     else if (!strcmp(name, "supercull")) rf->use_supercull = (int)value;
@@ -1213,12 +1401,59 @@ int xh_rf_reset(xh_rf *rf)
     return XH_OK;
 }
 
+// can the projections take the columns-first / rows-last transform (k_rf_colsA, k_rf_rowsB)?
+static bool fft_cols_rows_ok(const xh_rf *rf)
+{
+    return (rf->P == 512 || rf->P == 256 || rf->P == 128) && rf->sizeY == rf->P && rf->fft_variant == 0;
+}
+// n images -> half spectra (d_fft) or, with d_pk, the gridding kernel's padded records (CTF of rf->d_ctfp, weights or null)
+static int fft_cols_rows(xh_rf *rf, const float *d_imgs, int n, xh_cf *d_fft, float4 *d_pk, const float *d_weights)
+{
+    xh_ctx *ctx = rf->ctx;
+    const int D = rf->D, P = rf->P, sizeX = rf->sizeX;
+    // a line of T holds the D columns in blocks of NC = 4 LN, LN lines per workgroup of the FFT (xh_fftreg.h): 8 at P = 512, else 16
+    const int NC = P == 512 ? 32 : 64, TD = (D + NC - 1) / NC * NC;
+    const size_t perImg = (size_t)(sizeX + 1) * TD * sizeof(xh_cf);
+    const int chunk = std::max(1, std::min(n, (int)((256u << 20) / perImg)));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_rows, (size_t)chunk * perImg));
+    const double maxResSqr = rf->p.max_resolution * rf->p.max_resolution;
+    const int nlines = sizeX + 1 + (d_pk ? XG_PAD : 0);
+    const size_t recCells = (size_t)(sizeX + 2 * XG_PAD) * (rf->sizeY + 2 * XG_PAD);
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+#define XH_RFB(A_, B_)                                                                                                              \
+    {                                                                                                                               \
+        typedef TrGeom<A_, B_, float> G;                                                                                            \
+        hipLaunchKernelGGL((k_rf_colsA<A_, B_>), dim3(m * ((D + 4 * G::LN - 1) / (4 * G::LN))), dim3(256), G::smem, ctx->stream,      \
+                           d_imgs + (size_t)i0 * D * D, (xh_cf *)rf->d_rows.p, (const xh_cf *)rf->d_twP32.p, D, TD, sizeX);          \
+        if (d_pk)                                                                                                                   \
+            hipLaunchKernelGGL((k_rf_rowsB<A_, B_, true>), dim3(m * ((nlines + G::LN - 1) / G::LN)), dim3(256), G::smem, ctx->stream, \
+                               (const xh_cf *)rf->d_rows.p, (xh_cf *)nullptr, d_pk + (size_t)i0 * recCells,                          \
+                               (const XhCtfDev *)rf->d_ctfp.p + i0, d_weights ? d_weights + i0 : nullptr,                           \
+                               (const xh_cf *)rf->d_twP32.p, D, TD, sizeX, maxResSqr, nlines, 1.0 / rf->p.sampling, rf->p.min_ctf,    \
+                               rf->p.phase_flipped);                                                                                \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((k_rf_rowsB<A_, B_, false>), dim3(m * ((nlines + G::LN - 1) / G::LN)), dim3(256), G::smem, ctx->stream, \
+                               (const xh_cf *)rf->d_rows.p, d_fft + (size_t)i0 * rf->sizeY * sizeX, (float4 *)nullptr,               \
+                               (const XhCtfDev *)nullptr, (const float *)nullptr, (const xh_cf *)rf->d_twP32.p, D, TD, sizeX, maxResSqr, \
+                               nlines, 0.0, 0.0, 0);                                                                                \
+    }
+        if (P == 512) XH_RFB(16, 32)
+        else if (P == 256) XH_RFB(16, 16)
+        else XH_RFB(16, 8)
+#undef XH_RFB
+        XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+}
+
 int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft)
 {
     XH_CHECK(rf && d_imgs && d_fft && n >= 0, XH_ERR_ARG, "xh_rf_prepare_images: bad argument");
     XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
+    if (fft_cols_rows_ok(rf)) return fft_cols_rows(rf, d_imgs, n, (xh_cf *)d_fft, nullptr, nullptr);
     const int D = rf->D, P = rf->P, sizeX = rf->sizeX;
     // chunk so that the row-pass intermediate stays modest
     const int chunk = std::max(1, std::min(n, (int)((256u << 20) / ((size_t)D * sizeX * sizeof(xh_cf)))));
@@ -1230,7 +1465,7 @@ int xh_rf_prepare_images(xh_rf *rf, const float *d_imgs, int32_t n, float *d_fft
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         const int totalLines = m * D;
-        if ((P == 512 || P == 256 || P == 128) && rf->sizeY == P && rf->fft_variant == 0) {
+        if ((P == 512 || P == 256 || P == 128) && rf->sizeY == P && rf->fft_variant == 2) {     // the row-first form, kept for A/B
 #define XH_RF2(A_, B_)                                                                                                          \
     {                                                                                                                           \
         typedef TrGeom<A_, B_, float> G;                                                                                        \
@@ -1424,6 +1659,8 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
     XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(float4)));
+    if (rf->packImgs) XH_TRY(fft_cols_rows(rf, rf->packImgs, n, nullptr, (float4 *)rf->d_pack.p, d_weights));
+    else
     for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
         const int m = std::min(65535, n - i0);
         const size_t o = (size_t)i0 * rf->sizeX * rf->sizeY;
@@ -1750,11 +1987,16 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
         d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
         XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
     }
-    XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
-    XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    const bool fromImages = fuse && rf->records_from_images && fft_cols_rows_ok(rf);   // records straight from the images (A/B)
+    if (!fromImages) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
+        XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    }
     rf->packCtf = fuse;
-    const int rc = xh_rf_insert(rf, (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
+    rf->packImgs = fromImages ? d_imgs : nullptr;
+    const int rc = xh_rf_insert(rf, fromImages ? d_imgs : (const float *)rf->d_spectra.p, d_ctf, d_mod, h_angles, h_weights, n, h_sym, nsym);
     rf->packCtf = false;
+    rf->packImgs = nullptr;
     return rc;
 }
 
@@ -1782,8 +2024,11 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
         d_ctf = (float *)rf->d_planes.p; d_mod = d_ctf + plane;
         XH_TRY(xh_rf_ctf_arrays(rf, h_ctf, n, d_ctf, d_mod));
     }
-    XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
-    XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    const bool fromImages = fuse && rf->records_from_images && fft_cols_rows_ok(rf);   // records straight from the images (A/B)
+    if (!fromImages) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
+        XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+    }
     const int ns = n * nsym;
     const double *d_sym = nullptr;
     if (h_sym) {
@@ -1797,8 +2042,10 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
                        rf->p.blob_radius, rf->p.use_fast, (XgRec *)rf->d_grecs.p, (float4 *)rf->d_cull.p, (float4 *)rf->d_cull.p + ns);
     XH_LAUNCH_CHECK();
     rf->packCtf = fuse;
-    const int rc = grid_run(rf, ns, (const float *)rf->d_spectra.p, d_ctf, d_mod, d_weights, n);
+    rf->packImgs = fromImages ? d_imgs : nullptr;
+    const int rc = grid_run(rf, ns, fromImages ? d_imgs : (const float *)rf->d_spectra.p, d_ctf, d_mod, d_weights, n);
     rf->packCtf = false;
+    rf->packImgs = nullptr;
     return rc;
 }
 
