@@ -16,6 +16,8 @@ passes=(
  "FETCH_SIZE"
  "WRITE_SIZE"
  "GRBM_GUI_ACTIVE SQ_WAVES"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"
+ "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA"
 )
 i=0
 for p in "${passes[@]}"; do

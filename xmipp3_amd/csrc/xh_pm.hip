@@ -350,11 +350,12 @@ k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2
 // subtracted on the way in); wave w takes frequency tiles w, w+4, w+8, w+12 of each round of 16.
 typedef float xh_f32x16_rd __attribute__((ext_vector_type(16)));
 #define XH_RD_CH 256
+#define XH_RD_LD (XH_RD_CH + 3)      // row stride of the staged samples: odd multiple of banks apart, three zero columns behind a chunk
 #define XH_RD_KT 4
 // one round of a block: NA live frequency tiles for this wave (kt0 + wv + 4*i, i < NA). Every wave of
 // the block runs the same number of barriers whatever its NA.
 template <int NA>
-__device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], float (*sO)[XH_RD_CH + 1], const xh_cf *sT, const float *__restrict__ polar,
+__device__ __forceinline__ void rd_round(float (*sX)[XH_RD_LD], float (*sO)[XH_RD_LD], const xh_cf *sT, const float *__restrict__ polar,
                                          const float *sMean, xh_cf *__restrict__ out, int n, int nk, int kt0,
                                          int slot0, int nslots, int nsamples, int soffr, int coffr, int ncoef, int conjugate, int dbg)
 {
@@ -362,14 +363,14 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], float (*sO)[
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sl = lane >> 5, kl = lane & 31;
     xh_f32x16_rd accR[NR], accI[NR];
-    int j[NR], dj[NR];
+    int j[NR], dj[NR], kq[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { accR[i][e] = 0.f; accI[i][e] = 0.f; }
-        const int k = ((kt0 + wv + 4 * i) * 32 + kl) % n;
-        j[i] = (sl * k) % n;        // s = sl at the first step
-        dj[i] = (2 * k) % n;
+        kq[i] = ((kt0 + wv + 4 * i) * 32 + kl) % n;
+        j[i] = 0;
+        dj[i] = (2 * kq[i]) % n;
     }
     // The samples are real: with E[s] = x[s] + x[n-s], O[s] = x[s] - x[n-s] (E[0] = x[0], E[n/2] = x[n/2], O = 0 there)
     //   Re X[k] = sum_{s=0}^{n/2} E[s] tw[sk].x,   Im X[k] = sum_{s=0}^{n/2} O[s] tw[sk].y
@@ -401,38 +402,42 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_CH + 1], float (*sO)[
         __syncthreads();
         if (sc + XH_RD_CH < nf && dbg != 1) fetch(sc + XH_RD_CH);
         if (NA > 0 && dbg != 2) {
-            const int cn = min(XH_RD_CH, nf - sc);          // an odd count runs one step into the zero padding
-            // operands of step t+1 are read from LDS while the matrix cores run step t
-            float ae = sX[kl][sl], ao = sO[kl][sl];
-            xh_cf w[NR];
+            // A step takes two samples (lanes 0-31 the first, 32-63 the second) through 2 NA matrix instructions. Its
+            // operands -- the sample pair and NA twiddles -- are read from LDS one whole step ahead, into the other of two
+            // register sets (the loop body is two steps), at the top of the step before: the wave never waits for LDS
+            // while the matrix core has work. Steps beyond the chunk's samples meet the zero columns behind them.
+            const int steps = (min(XH_RD_CH, nf - sc) + 1) >> 1;
+            const float *pe = &sX[kl][sl], *po = &sO[kl][sl];
+            xh_cf w0[NR], w1[NR];
+            float e0, o0, e1 = 0.f, o1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { w[i] = sT[j[i] + (j[i] >> 4)]; j[i] += dj[i]; if (j[i] >= n) j[i] -= n; }
-            for (int t = 0; t < cn; t += 2) {
-                // program order M M L M M L ...: each LDS read has the following tiles' MFMAs to land.
-                // (the reads of the last step fetch operands that are never used)
-                const float ane = sX[kl][min(t + 2 + sl, XH_RD_CH)], ano = sO[kl][min(t + 2 + sl, XH_RD_CH)];
+            for (int i = 0; i < NA; ++i) w1[i] = xh_cf{0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    accR[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, w[i].x, accR[i], 0, 0, 0);
-                    accI[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, w[i].y, accI[i], 0, 0, 0);
-                    w[i] = sT[j[i] + (j[i] >> 4)];     // one pad entry per 16: strides s*k stop piling onto one bank
-                    j[i] += dj[i];
-                    if (j[i] >= n) j[i] -= n;
-                }
-                ae = ane; ao = ano;
-                // scheduling hint; measured best of the variants tried (reads hoisted above the MFMAs: +7 %,
-                // strict M M L interleave: +6 %)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                }
+            for (int i = 0; i < NA; ++i) {
+                j[i] = ((sc + sl) * kq[i]) % n;                 // sample sc + sl opens the chunk
+                w0[i] = sT[j[i] + (j[i] >> 4)];                 // one pad entry per 16: strides s*k stop piling onto one bank
+                j[i] += dj[i];
+                if (j[i] >= n) j[i] -= n;
             }
-            // undo the index advance of the unused trailing read so that the next chunk continues at s = sc + cn
-#pragma unroll
-            for (int i = 0; i < NA; ++i) { j[i] -= dj[i]; if (j[i] < 0) j[i] += n; }
+            e0 = pe[0]; o0 = po[0];
+            pe += 2; po += 2;
+            for (int t = 0; t < steps; t += 2) {
+#define XH_RD_STEP(WC, WN, EC, OC, EN, ON)                                                              \
+                EN = pe[0]; ON = po[0];                                                                 \
+                _Pragma("unroll") for (int i = 0; i < NA; ++i) WN[i] = sT[j[i] + (j[i] >> 4)];          \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                        \
+                    accR[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(EC, WC[i].x, accR[i], 0, 0, 0);      \
+                    accI[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(OC, WC[i].y, accI[i], 0, 0, 0);      \
+                    j[i] += dj[i];                                                                      \
+                    if (j[i] >= n) j[i] -= n;                                                           \
+                }                                                                                       \
+                pe += 2; po += 2;                                                                       \
+                __builtin_amdgcn_sched_barrier(0);
+                XH_RD_STEP(w0, w1, e0, o0, e1, o1)
+                XH_RD_STEP(w1, w0, e1, o1, e0, o0)
+#undef XH_RD_STEP
+            }
         }
     }
     const float inv = 1.f / (float)n;
@@ -456,9 +461,9 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
                   const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, int nslots, int nrings, int dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float (*sX)[XH_RD_CH + 1] = reinterpret_cast<float (*)[XH_RD_CH + 1]>(smem);
-    float (*sO)[XH_RD_CH + 1] = sX + 32;
-    xh_cf *sT = reinterpret_cast<xh_cf *>(smem + sizeof(float) * 64 * (XH_RD_CH + 1));
+    float (*sX)[XH_RD_LD] = reinterpret_cast<float (*)[XH_RD_LD]>(smem);
+    float (*sO)[XH_RD_LD] = sX + 32;
+    xh_cf *sT = reinterpret_cast<xh_cf *>(smem + sizeof(float) * 64 * XH_RD_LD);
     const int r = nrings - 1 - blockIdx.x;        // long rings first
     const int slot0 = blockIdx.y * 32;
     const int n = nsam[r], nk = n / 2 + 1, nkt = (nk + 31) / 32;
@@ -467,6 +472,7 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
     for (int i = tid; i < n; i += 256) sT[i + (i >> 4)] = tw[soff[r] + i];
     // slots past the end contribute nothing: their samples are read from the last valid slot and never stored
     if (tid < 32) sMean[tid] = (float)stat[2 * min(slot0 + tid, nslots - 1)];
+    if (tid < 64 * 3) sX[tid / 3][XH_RD_CH + tid % 3] = 0.f;     // the zero columns behind a chunk (sX and sO are contiguous)
     for (int kt0 = 0; kt0 < nkt; kt0 += 4 * XH_RD_KT) {
         const int left = nkt - kt0 - wv;          // tiles kt0+wv, +4, +8, +12 that exist
         const int nact = __builtin_amdgcn_readfirstlane(left <= 0 ? 0 : min(XH_RD_KT, (left + 3) / 4));
@@ -2137,7 +2143,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
     }
     }
     if (std::is_same<T, float>::value && !d_count && pm->use_mfma) {
-        const size_t smemM = sizeof(float) * 64 * (XH_RD_CH + 1) + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
+        const size_t smemM = sizeof(float) * 64 * XH_RD_LD + sizeof(xh_cf) * (L.N + L.N / 16 + 1);
         XH_HIP(hipFuncSetAttribute((const void *)k_pm_ringdft_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemM));
         hipLaunchKernelGGL(k_pm_ringdft_mfma, dim3(L.nrings, (unsigned)((nps + 31) / 32)), dim3(256), smemM, ctx->stream,
                            (const float *)polarBuf.p, (const double *)statBuf.p, (xh_cf *)outBuf.p, (const xh_cf *)twBuf.p,
