@@ -132,7 +132,7 @@ struct xh_pm {
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
     XhBuf d_bT, d_aT, d_kboundsLow;
-    XhBuf d_firTmp, d_polarPart;
+    XhBuf d_firTmp, d_polarPart, d_trPart;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
 };
@@ -1608,6 +1608,9 @@ __global__ void k_pm_rot_mirror(const float *__restrict__ particles, const doubl
     z[(size_t)p * D * D + pix] = out;
 }
 
+// partial statistics of a correlation map (k_pm_tr_irows -> k_pm_bestshift)
+struct XhTrPart { double s1, s2, maxv; int maxi; };
+
 // product FFT1 * conj(FFT2) * N from the packed spectrum Z (FFT of Mref + i Mimg), in place.
 // F1[k] = (Z[k] + conj(Z[-k]))/2, F2[k] = (Z[k] - conj(Z[-k]))/(2i); forward FFTs are /N in the
 // reference and the product is multiplied by N (xmippCore correlation_matrix) => net 1/N.
@@ -1635,11 +1638,11 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
 __global__ void __launch_bounds__(256)
 k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__restrict__ zimg, const int *__restrict__ refno,
                const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
-               double *__restrict__ shiftY, double *__restrict__ maxCC)
+               double *__restrict__ shiftY, double *__restrict__ maxCC, const XhTrPart *__restrict__ part, int nparts)
 {
     __shared__ double red[8];
     __shared__ double sv[256];
-    __shared__ int si[256];
+    __shared__ int si[256], si2[256];
     __shared__ double sh[2];
     const int p = blockIdx.x;
     if (refno[p] < 0) {
@@ -1651,12 +1654,35 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
     const double *R = Rraw + (size_t)p * n * rstride;
     // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
 #define RC(i, j) (R[((size_t)(((i) - cen + D) % D) * D + (((j) - cen + D) % D)) * rstride])
-    double s1 = 0, s2 = 0;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
-    const double S1 = d_block_sum(s1, red), S2 = d_block_sum(s2, red);
+    double S1, S2;
+    if (part) {
+        // sums and the raw maximum came with the map (k_pm_tr_irows), block by block
+        if (threadIdx.x == 0) {
+            double a1 = 0, a2 = 0, mv = -1.0e300;
+            int mi = 0x7fffffff;
+            for (int q = 0; q < nparts; ++q) {
+                const XhTrPart P = part[(size_t)p * nparts + q];
+                a1 += P.s1; a2 += P.s2;
+                if (P.maxv > mv || (P.maxv == mv && P.maxi < mi)) { mv = P.maxv; mi = P.maxi; }
+            }
+            red[0] = a1; red[1] = a2; red[2] = mv; si[0] = mi;
+        }
+        __syncthreads();
+        S1 = red[0]; S2 = red[1];
+    } else {
+        double s1 = 0, s2 = 0;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
+        S1 = d_block_sum(s1, red); S2 = d_block_sum(s2, red);
+    }
     const double avg = S1 / n;
     double sd = sqrt(fabs(S2 / n - avg * avg));
     const double a = sd != 0 ? 1.0 / sd : 0.0, b = sd != 0 ? -avg * a : 0.0;   // statisticsAdjust(0,1)
+    if (part) {
+        // a >= 0: the adjusted map is a non-decreasing function of the raw one, so the raw maximum is a maximum of the
+        // adjusted map; whether an earlier element rounds onto the same adjusted value is checked by the pass below
+        if (threadIdx.x == 0) sv[0] = a * red[2] + b;
+        __syncthreads();
+    } else {
     // first maximum in raster order of the centred map
     double bv = -1.0e300;
     int bi = 0x7fffffff;
@@ -1675,26 +1701,41 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
         }
         __syncthreads();
     }
+    }
     {
         // The reference grows a (2n+1)^2 window around the maximum until some element of it leaves the map or drops
         // below max/1.414, re-scanning the whole window for every n (FIL:1659-1689). The windows are nested, so the n
         // it stops at is the smallest Chebyshev distance from the maximum to a failing element: one parallel pass
         // instead of a serial O(n^3) walk (smooth maps reach n of several tens).
         const int start = -cen, fin = start + D - 1;
-        const int imax = si[0] / D + start, jmax = si[0] % D + start;
+        int tmax = si[0];
         const double mx = sv[0];
         const double thr = mx / 1.414;
+        __syncthreads();
 #define MC(li, lj) (a * RC((li) - start, (lj) - start) + b)
-        int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
-        for (int t = threadIdx.x; t < n; t += blockDim.x) {
-            const int i = t / D, j = t - i * D;
-            if (thr > a * RC(i, j) + b) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
-        }
-        __syncthreads();
-        si[threadIdx.x] = nf;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) si[threadIdx.x] = min(si[threadIdx.x], si[threadIdx.x + o]);
+        int imax, jmax;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            imax = tmax / D + start; jmax = tmax % D + start;
+            int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
+            int tfirst = tmax;
+            for (int t = threadIdx.x; t < n; t += blockDim.x) {
+                const int i = t / D, j = t - i * D;
+                const double v = a * RC(i, j) + b;
+                if (thr > v) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
+                if (v == mx && t < tfirst) tfirst = t;      // an earlier element that rounds onto the maximum (part != nullptr only)
+            }
+            si[threadIdx.x] = nf; si2[threadIdx.x] = tfirst;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    si[threadIdx.x] = min(si[threadIdx.x], si[threadIdx.x + o]);
+                    si2[threadIdx.x] = min(si2[threadIdx.x], si2[threadIdx.x + o]);
+                }
+                __syncthreads();
+            }
+            const int tf = si2[0];
+            if (tf == tmax) break;
+            tmax = tf;                                      // the reference's "first maximum in raster order"; once more around it
             __syncthreads();
         }
         int n_max = si[0];
@@ -2000,7 +2041,7 @@ k_pm_tr_cols(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD)
 
 template <int R1, int R2>
 __global__ void __launch_bounds__(256)
-k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_cd *__restrict__ WD)
+k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_cd *__restrict__ WD, XhTrPart *__restrict__ part)
 {
     typedef TrGeom<R1, R2> G;
     constexpr int D = G::D;
@@ -2027,6 +2068,38 @@ k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_c
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) dst[n1 * R2 + n2] = v[n1].x;
     }
+    // What bestShift needs of the whole map before it can look at single elements -- sum and sum of squares
+    // (statisticsAdjust) and the first maximum in raster order of the centred map -- leaves with the map: one partial result
+    // per block, combined in block order by k_pm_bestshift, which then reads the map once instead of three times.
+    double s1 = 0, s2 = 0, bv = -1.0e300;
+    int bi = 0x7fffffff;
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        const int ci = ((row0 + l + D / 2) % D) * D;          // centred row (CenterFFT(R, true)) of this raw row
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const double x = v[n1].x;
+            const int t = ci + (n1 * R2 + n2 + D / 2) % D;
+            s1 += x; s2 += x * x;
+            if (x > bv || (x == bv && t < bi)) { bv = x; bi = t; }
+        }
+    }
+    __syncthreads();                                          // the exchange area is free again
+    double *red = reinterpret_cast<double *>(smem);
+    int *redi = reinterpret_cast<int *>(red + 3 * 256);
+    red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; redi[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[tid] += red[tid + o];
+            red[256 + tid] += red[256 + tid + o];
+            const double ov = red[512 + tid + o];
+            const int oi = redi[tid + o];
+            if (ov > red[512 + tid] || (ov == red[512 + tid] && oi < redi[tid])) { red[512 + tid] = ov; redi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) part[(size_t)p * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
 }
 
 // ---- CTF filtering of the reference gallery (APM:457-481): window to paddim, FFT, multiply the
@@ -2175,7 +2248,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2992,7 +3065,9 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             const int m = std::min(chunk, n - p0);
             xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
             XH_TRY(xh_buf_reserve(ctx, pm->d_trAngles, sizeof(double2) * (size_t)chunk));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_trPart, sizeof(XhTrPart) * (size_t)chunk * 64));
             double *R = (double *)pm->d_t3.p;
+            int nparts = 0;
 #define XH_TR(A_, B_)                                                                                                       \
     {                                                                                                                       \
         typedef TrGeom<A_, B_> G;                                                                                           \
@@ -3012,7 +3087,8 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         hipLaunchKernelGGL((k_pm_tr_cols<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, w,                   \
                            (const xh_cd *)pm->d_WD64.p);                                                                    \
         hipLaunchKernelGGL((k_pm_tr_irows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cd *)w, R, \
-                           (const xh_cd *)pm->d_WD64.p);                                                                    \
+                           (const xh_cd *)pm->d_WD64.p, (XhTrPart *)pm->d_trPart.p);                                        \
+        nparts = D / G::LN;                                                                                                 \
     }
             if (D == 64) XH_TR(8, 8)
             else if (D == 128) XH_TR(16, 8)
@@ -3020,7 +3096,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
 #undef XH_TR
             XH_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)R, 1, (const xh_cd *)z, d_refno + p0,
-                               d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);
+                               d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0, (const XhTrPart *)pm->d_trPart.p, nparts);
             XH_LAUNCH_CHECK();
         }
         return XH_OK;
@@ -3055,7 +3131,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
                            pw, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,
-                           d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0);
+                           d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0, (const XhTrPart *)nullptr, 0);
         XH_LAUNCH_CHECK();
     }
     return XH_OK;
