@@ -1832,8 +1832,8 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
 // 16 taps of a pixel used to be gathered from the 512-KB coefficient image in global memory (the L1's tag lookups bound
 // k_pm_tr_rows: 6.9 ms per 4096 particles of 256 px); the rotated tile only reaches a 28 x 28 patch of it, staged here in
 // LDS with the mirror boundary already applied. Same weights, same summation order as d_interp: same bits.
-#define XH_TRB 16
-#define XH_TRBW 30          // 2 * 8 * sqrt(2) + 4 taps + slack
+#define XH_TRB 32           // output tile edge: four pixels per thread
+#define XH_TRBW 52          // 2 * 15.5 * sqrt(2) + 6 (taps, ceilings) + slack
 // cos / sin of the in-plane angles, once per particle in double precision
 __global__ void k_pm_tr_angles(const int *__restrict__ psi, double2 *__restrict__ cs, int n, int N)
 {
@@ -1855,9 +1855,10 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
     const double c = cs[p].x, sn = cs[p].y;
     const double minp = -cen, maxp = D - cen - 1;
     // source position of the tile centre and the reach of the rotated tile: first tap column / row of the patch
-    const double xc = (tj0 + 7.5) - cen, yc = (ti0 + 7.5) - cen;
+    const double hc = 0.5 * (XH_TRB - 1);
+    const double xc = (tj0 + hc) - cen, yc = (ti0 + hc) - cen;
     const double xpc = c * xc - sn * yc + cen, ypc = sn * xc + c * yc + cen;      // in index space (x - start)
-    const double ext = 7.5 * (fabs(c) + fabs(sn)) + 1e-6;
+    const double ext = hc * (fabs(c) + fabs(sn)) + 1e-6;
     const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
     if (ref >= 0) {
         const double *coef = refCoef + (size_t)ref * D * D;
@@ -1870,39 +1871,53 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
         }
     }
     __syncthreads();
-    const int i = ti0 + (tid >> 4), j = tj0 + (tid & 15);
     const float *img = particles + (size_t)p * D * D;
     const bool fl = flip[p] != 0;
-    xh_cd out = xh_cd{0., 0.};
-    if (ref >= 0) {
-        const double x = j - cen, y = i - cen;
-        double xp = c * x - sn * y, yp = sn * x + c * y;
-        if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6)) {
-            // d_interp<double> on the staged patch
-            xp -= (double)(-cen);
-            yp -= (double)(-cen);
-            const int l1 = (int)ceil(xp - 2.0), m1 = (int)ceil(yp - 2.0);
-            double wx[4], wy[4];
-            d_bspline03_w4<double>(xp, l1, wx);
-            d_bspline03_w4<double>(yp, m1, wy);
-            const double *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
-            double columns = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double *row = base + t * XH_TRBW;
-                double rows = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
-                columns += rows * wy[t];
-            }
-            out.x = columns;
-        }
-        if (fl) {
-            const double mx = -(double)(j - cen);
-            if (!(mx < minp - 1e-6 || mx > maxp + 1e-6)) out.y = (double)img[(size_t)i * D + (2 * cen - j)];
-        } else out.y = (double)img[(size_t)i * D + j];
+    const int j = tj0 + (tid & (XH_TRB - 1));
+    // the particle's pixels first: four independent loads in flight under the interpolation
+    float pix[XH_TRB * XH_TRB / 256];
+    bool pixOk = ref >= 0;
+    int jsrc = j;
+    if (fl) {
+        const double mx = -(double)(j - cen);
+        pixOk = pixOk && !(mx < minp - 1e-6 || mx > maxp + 1e-6);
+        jsrc = 2 * cen - j;
     }
-    z[((size_t)p * D + i) * D + j] = out;
+#pragma unroll
+    for (int k = 0; k < XH_TRB * XH_TRB / 256; ++k) {
+        const int i = ti0 + (tid / XH_TRB) + (256 / XH_TRB) * k;
+        pix[k] = pixOk ? img[(size_t)i * D + jsrc] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < XH_TRB * XH_TRB / 256; ++k) {
+        const int i = ti0 + (tid / XH_TRB) + (256 / XH_TRB) * k;
+        xh_cd out = xh_cd{0., (double)pix[k]};
+        if (ref >= 0) {
+            const double x = j - cen, y = i - cen;
+            double xp = c * x - sn * y, yp = sn * x + c * y;
+            if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6)) {
+                // d_interp<double> on the staged patch
+                xp -= (double)(-cen);
+                yp -= (double)(-cen);
+                const int l1 = (int)ceil(xp - 2.0), m1 = (int)ceil(yp - 2.0);
+                double wx[4], wy[4];
+                d_bspline03_w4<double>(xp, l1, wx);
+                d_bspline03_w4<double>(yp, m1, wy);
+                const double *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
+                double columns = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double *row = base + t * XH_TRBW;
+                    double rows = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
+                    columns += rows * wy[t];
+                }
+                out.x = columns;
+            }
+        }
+        z[((size_t)p * D + i) * D + j] = out;
+    }
 }
 
 template <int R1, int R2, bool PREBUILT = false>
