@@ -57,6 +57,10 @@ def parse(argv=None):
     ap.add_argument("--tr-chunk-mb", type=int, default=0, help="S6 scratch per pass in MB (0: library default)")
     ap.add_argument("--chunk-rows", type=float, default=0, help="correlation rows per chunk of the matcher (0: library default)")
     ap.add_argument("--k0", type=int, default=-1, help="two-level contraction cut (0 auto, >= nk off); default: automatic")
+    ap.add_argument("--neighbours", type=int, default=0,
+                    help="local search (APM:615-631): every particle is matched against the K references nearest to its true "
+                         "direction only (ascending lists, as a sampling file holds them); 0: the whole bank")
+    ap.add_argument("--pm-opt", action="append", default=[], help="name=value passed to xh_pm_set_option (A/B runs)")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
@@ -212,12 +216,22 @@ def main():
             grid = torch.nn.functional.affine_grid(rot[sl], (rot[sl].shape[0], 1, D, D), align_corners=False)
             out[sl] = torch.nn.functional.grid_sample(refs[idx[sl]][:, None], grid, mode="bilinear", padding_mode="zeros",
                                                       align_corners=False)[:, 0]
-        return (out + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
+        return (out + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous(), idx
 
     # --mode grid is BASELINE config 3: >= 16384 distinct projections cycled, fresh orientations per use
     nuniq = (args.unique_batches or 4) if args.mode == "grid" else 1
-    batches = [make_batch() for _ in range(nuniq)]
+    made = [make_batch() for _ in range(nuniq)]
+    batches = [b for b, _ in made]
     particles = batches[0]
+    # --neighbours K: the K references nearest (angular distance of the projection directions) to the particle's own
+    nbr = None
+    if args.neighbours > 0 and args.mode != "grid":
+        K = min(args.neighbours, nrefs)
+        rt = np.radians(dirs[:, :2])
+        v = np.stack([np.sin(rt[:, 1]) * np.cos(rt[:, 0]), np.sin(rt[:, 1]) * np.sin(rt[:, 0]), np.cos(rt[:, 1])], 1)
+        table = np.sort(np.argsort(-(v @ v.T), axis=1, kind="stable")[:, :K], axis=1).astype(np.int32)
+        h_idx = made[0][1].cpu().numpy()
+        nbr = ((np.arange(B + 1) * K).astype(np.int32), np.ascontiguousarray(table[h_idx].ravel()))
     rng = np.random.default_rng(100 + rank)
     from xmipp3_amd.api import ctf_params
     ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d))
@@ -225,6 +239,9 @@ def main():
     ctf_arr = xa.RecFourier.ctf_param_array(ctfs)
 
     pm = xa.ProjectionMatcher(ctx, refs) if args.mode != "grid" else None
+    for o_ in (args.pm_opt if pm is not None else []):
+        k_, v_ = o_.split("=")
+        pm.set_option(k_, float(v_))
     if pm is not None and args.no_prune:
         pm.set_option("prune", 0)
     if pm is not None and args.tr_chunk_mb > 0:
@@ -248,7 +265,7 @@ def main():
         step_no[0] += 1
         imgs = parts
         if pm is not None:
-            refno, psi, flip = pm.match(parts)
+            refno, psi, flip = pm.match(parts, *nbr) if nbr is not None else pm.match(parts)
             if record:
                 st = pm.last_stats()
                 rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
@@ -437,7 +454,8 @@ def main():
         "vs_baseline": None, "dtype": "f32 (coarse search, gridding) + f64 (exact re-score, shifts, finaliser)",
         "data": "synthetic",
         "config": {"workload": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references",
-                   "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "particles_per_step_per_gpu": B,
+                   "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "neighbours": args.neighbours or None,
+                   "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
@@ -466,7 +484,7 @@ def main():
         orfs = [o.RF(D, use_ctf=True, min_ctf=0.01) for _ in range(nthr)]
         tb1 = time.perf_counter()
         if opm is not None:
-            er, ep, ef, _ = opm.match(h_parts)
+            er, ep, ef, _ = opm.match(h_parts, nbr[0][:ns + 1], nbr[1][:nbr[0][ns]]) if nbr is not None else opm.match(h_parts)
             ex, ey, ec = opm.translate(h_parts, er[:, 0], ep[:, 0], ef[:, 0])
             oang = np.stack([dirs[er[:, 0], 0], dirs[er[:, 0], 1], ep[:, 0] * (360.0 / opm.N)], 1)
         else:
@@ -495,7 +513,8 @@ def main():
                       f"volume each; library setup {tb_setup:.1f}s excluded on both sides; finaliser excluded"}
         if opm is not None and pm is not None:
             # the sample doubles as a parity spot check at full size: orientations ...
-            g_ref, g_psi, g_flip = pm.match(particles[:ns].contiguous())
+            g_ref, g_psi, g_flip = (pm.match(particles[:ns].contiguous(), nbr[0][:ns + 1], nbr[1][:nbr[0][ns]]) if nbr is not None
+                                    else pm.match(particles[:ns].contiguous()))
             out["parity_sample_identical"] = bool(np.array_equal(g_ref.cpu().numpy(), er[:, 0]) and
                                                   np.array_equal(g_psi.cpu().numpy(), ep[:, 0]) and
                                                   np.array_equal(g_flip.cpu().numpy(), ef[:, 0]))

@@ -121,6 +121,36 @@ def test_match_with_neighbour_lists_and_chunking(gpu, oracle, lib64):
     assert np.array_equal(flip.cpu().numpy()[valid], ef[valid, 0])
 
 
+def test_ascending_neighbour_lists_run_over_the_bank_with_a_mask(gpu, oracle, lib64):
+    """A local search whose lists are non-empty and ascending (a sampling file's) goes through the matrix-core contraction
+    of the whole bank, the off-list references dropped by the branch and bound: same answers as the oracle's list search
+    and as the gather path, rows counted as listed; several chunks."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    rng = np.random.default_rng(12)
+    n, nrefs = len(parts), len(refs)
+    lists = [np.sort(rng.choice(nrefs, size=int(rng.integers(1, 12)), replace=False)) for _ in range(n)]
+    lists[3] = np.array([7])      # a single neighbour
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists).astype(np.int32)
+    dp = torch.from_numpy(parts).cuda()
+    o = oracle.PM(refs)
+    er, ep, ef, ecc = o.match(parts, off, ids, parity=1)
+    for chunk_rows in (0, 3 * nrefs):
+        pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+        if chunk_rows:
+            pm.set_option("chunk_rows", chunk_rows)
+        got = [t.cpu().numpy() for t in pm.match(dp, off, ids, parity=1)]
+        st = pm.last_stats()
+        assert st["rows"] == len(ids) and st["pruned_rows"] >= 0
+        assert np.array_equal(got[0], er[:, 0]) and np.array_equal(got[1], ep[:, 0]) and np.array_equal(got[2], ef[:, 0])
+        pm.set_option("mask_lists", 0)
+        gather = [t.cpu().numpy() for t in pm.match(dp, off, ids, parity=1)]
+        for a, b in zip(got, gather):
+            assert np.array_equal(a, b)
+
+
 def test_lists_that_name_every_reference_in_order_are_the_dense_search(gpu, oracle, lib64):
     """A global search written as neighbour lists (what the gallery's sampling file holds with --angular_distance -1)
     takes the dense MFMA path with its branch and bound; a single list in another order does not."""

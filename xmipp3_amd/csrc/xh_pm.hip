@@ -126,13 +126,14 @@ struct xh_pm {
     XhBuf d_firTmp64;
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
+    int use_mask_lists;          // neighbour-list searches over the whole bank with the off-list references masked (0: gather path)
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
     int64_t stat_pruned;
     int lastPruneRows;           // rows of the last chunk that went through k_pm_survivors (0: none)
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
     XhBuf d_bT, d_aT, d_kboundsLow;
-    XhBuf d_firTmp, d_polarPart, d_trPart;
+    XhBuf d_firTmp, d_polarPart, d_trPart, d_listMask;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
 };
@@ -1177,7 +1178,8 @@ __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { r
 __global__ void __launch_bounds__(256)
 k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
                 const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows,
-                const float *__restrict__ aT, const float *__restrict__ bT, int K0, int nk, int nrefs, float *__restrict__ rowTail)
+                const float *__restrict__ aT, const float *__restrict__ bT, int K0, int nk, int nrefs, float *__restrict__ rowTail,
+                const unsigned *__restrict__ mask, int maskW)
 {
     __shared__ float sv[256];
     __shared__ int sr[256];
@@ -1219,6 +1221,9 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
                 // 1e-4: rounding of the fp32 sums, of sqrtf and of the fp32 transform itself (all ~1e-6 relative)
                 rowBound[r] = (fmaxf(bs, bm) + 2.f * tail[j]) * 1.0001f / den;
                 rowTail[r] = 2.f * tail[j] * 1.0001f / den;
+                // a neighbour-list search run over the whole bank (xh_pm_match_ex): a reference that is not on the particle's
+                // list can never be picked, listed first or survive -- it is not a row of the search
+                if (mask && !((mask[(size_t)p * maskW + (ref[j] >> 5)] >> (ref[j] & 31)) & 1u)) { rowBound[r] = -INFINITY; rowTail[r] = 0.f; }
             }
         }
     }
@@ -2263,7 +2268,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2346,6 +2351,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
     pm->use_prune = 1;
+    pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
@@ -2668,6 +2674,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
+    else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
     else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
         XH_HIP(hipSetDevice(pm->ctx->device));
@@ -2725,7 +2732,8 @@ int xh_pm_last_stats(const xh_pm *pm, int64_t *rows, int64_t *rp, int64_t *rr)
 // prune: row map of the chunk for the S3 branch and bound (null: every row is transformed); nparticles and tau2
 // (= 2 tau, normalised units) go with it; d_pruned counts the skipped rows
 static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d_ids, bool dense, int nq, hipEvent_t evMid = nullptr,
-                    const RowMap *prune = nullptr, int nparticles = 0, float tau2 = 0.f, int *d_pruned = nullptr)
+                    const RowMap *prune = nullptr, int nparticles = 0, float tau2 = 0.f, int *d_pruned = nullptr,
+                    const unsigned *d_mask = nullptr, int maskW = 0, int listedRows = 0)
 {
     xh_ctx *ctx = pm->ctx;
     const Layout &L = pm->L;
@@ -2761,6 +2769,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     }
     const int nt = ((L.nk + 63) / 64) * 64;
     const bool pruning = mfma && prune && pm->use_prune && pm->R1 && pm->use_idft3 && nparticles > 0 && nrows % nparticles == 0;
+    XH_CHECK(!d_mask || pruning, XH_ERR_STATE, "xh_pm_match: internal error, a masked search must take the pruning path");
     if (pruning) XH_TRY(xh_buf_reserve(ctx, pm->d_bpart, sizeof(float2) * (size_t)XH_KSPLIT * nrows));
     const int K0 = pruning ? pm->K0 : L.nk;          // two-level S2 needs the bounds
     const int rawStride = std::min(K0, L.nk);
@@ -2826,7 +2835,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             hipLaunchKernelGGL(k_pm_prune_plan, dim3(nparticles), dim3(256), 0, ctx->stream, (const float2 *)pm->d_bpart.p, XH_KSPLIT,
                                (size_t)nrows, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
                                (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p, (const float *)pm->d_aT.p, (const float *)pm->d_bT.p,
-                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p);
+                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p, d_mask, maskW);
             XH_LAUNCH_CHECK();
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
@@ -2845,7 +2854,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                                (const float *)pm->d_thr.p, nrows / nparticles, nrows, (RowRes *)pm->d_rowres.p, (int *)pm->d_survList.p,
                                d_pruned + 1);
             XH_LAUNCH_CHECK();
-            pm->lastPruneRows = nrows;
+            pm->lastPruneRows = d_mask ? listedRows : nrows;
             nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
         }
         grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
@@ -2895,6 +2904,21 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         }
         dense = identity;
     }
+    // A local search (APM:615-631 visits my_neighbors[imgno] only) whose lists are non-empty and ascending -- what the
+    // sampling file holds -- runs over the whole bank on the matrix cores too: the low-frequency contraction of every
+    // (particle, reference) pair costs less than gathering sub-banks, and the branch and bound then drops every reference
+    // that is not on the particle's list before anything else is computed for it (k_pm_prune_plan). Rows, visiting
+    // order and results are those of the list search. Lists in another order keep the gather path below.
+    bool masked = false;
+    if (!dense && pm->use_mask_lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1) {
+        masked = true;
+        for (int p = 0; p < n && masked; ++p) {
+            masked = h_nbr_off[p + 1] > h_nbr_off[p];
+            for (int j = h_nbr_off[p] + 1; j < h_nbr_off[p + 1] && masked; ++j) masked = h_nbr_ids[j] > h_nbr_ids[j - 1];
+        }
+    }
+    const bool lists = !dense && !masked;     // rows = the lists' entries; otherwise rows = particles x bank
+    const int maskW = (pm->nrefs + 31) / 32;
     // 5-D search translations (APM:575-589); none given = the single translation (0,0)
     const int nt = ntrans > 0 ? ntrans : 1;
     const double *d_offs = nullptr;
@@ -2912,7 +2936,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     // chunking: bound the S2->S3 intermediate (rows * nk * 16 B)
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
     // (with the two-level contraction a row only holds the frequencies below K0: far more rows per chunk)
-    const bool willPrune = dense && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1;
+    const bool willPrune = !lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1;
     const size_t rawStride = willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
     size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (rawStride * sizeof(float4)));
     // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
@@ -2926,38 +2950,51 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         int m = 0;
         size_t rows = 0;
         while (p0 + m < n && m < 4096 && (size_t)(m + 1) * nt <= std::max<size_t>(maxSlots, nt)) {
-            const size_t nn = (dense ? (size_t)pm->nrefs : (size_t)(h_nbr_off[p0 + m + 1] - h_nbr_off[p0 + m])) * nt;
+            const size_t nn = (!lists ? (size_t)pm->nrefs : (size_t)(h_nbr_off[p0 + m + 1] - h_nbr_off[p0 + m])) * nt;
             if (m > 0 && rows + nn > maxRows) break;
             rows += nn;
             ++m;
         }
         const int ms = m * nt;                                  // slots of this chunk
-        std::vector<int> poff(ms + 1), rowSlot(dense ? 0 : rows), ids(dense ? 0 : rows);
+        std::vector<int> poff(ms + 1), rowSlot(!lists ? 0 : rows), ids(!lists ? 0 : rows);
         poff[0] = 0;
         for (int i = 0; i < m; ++i) {
-            const int nn = dense ? pm->nrefs : (h_nbr_off[p0 + i + 1] - h_nbr_off[p0 + i]);
+            const int nn = !lists ? pm->nrefs : (h_nbr_off[p0 + i + 1] - h_nbr_off[p0 + i]);
             for (int it = 0; it < nt; ++it) {
                 const int sl = i * nt + it;
                 poff[sl + 1] = poff[sl] + nn;
-                if (!dense)
+                if (lists)
                     for (int j = 0; j < nn; ++j) { rowSlot[poff[sl] + j] = sl; ids[poff[sl] + j] = h_nbr_ids[h_nbr_off[p0 + i] + j]; }
             }
         }
         const int nrows = (int)rows;
         XH_TRY(xh_buf_reserve(ctx, pm->d_poff, sizeof(int) * (ms + 1 + rows)));
-        int *d_poff = (int *)pm->d_poff.p, *d_rowSlot = dense ? nullptr : d_poff + (ms + 1);
+        int *d_poff = (int *)pm->d_poff.p, *d_rowSlot = !lists ? nullptr : d_poff + (ms + 1);
         XH_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int) * (ms + 1), hipMemcpyHostToDevice, ctx->stream));
-        if (!dense && rows) XH_HIP(hipMemcpyAsync(d_rowSlot, rowSlot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
+        if (lists && rows) XH_HIP(hipMemcpyAsync(d_rowSlot, rowSlot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
         const int *d_ids = nullptr;
-        if (!dense && rows) {
+        if (lists && rows) {
             XH_TRY(xh_buf_reserve(ctx, pm->d_nbr, sizeof(int) * rows));
             XH_HIP(hipMemcpyAsync(pm->d_nbr.p, ids.data(), sizeof(int) * rows, hipMemcpyHostToDevice, ctx->stream));
             d_ids = (const int *)pm->d_nbr.p;
         }
+        // the lists of this chunk as one bit per (particle, reference)
+        const unsigned *d_mask = nullptr;
+        int listedRows = 0;
+        std::vector<unsigned> mask;
+        if (masked) {
+            mask.assign((size_t)m * maskW, 0u);
+            for (int i = 0; i < m; ++i)
+                for (int j = h_nbr_off[p0 + i]; j < h_nbr_off[p0 + i + 1]; ++j) mask[(size_t)i * maskW + (h_nbr_ids[j] >> 5)] |= 1u << (h_nbr_ids[j] & 31);
+            listedRows = (h_nbr_off[p0 + m] - h_nbr_off[p0]) * nt;
+            XH_TRY(xh_buf_reserve(ctx, pm->d_listMask, sizeof(unsigned) * mask.size()));
+            XH_HIP(hipMemcpyAsync(pm->d_listMask.p, mask.data(), sizeof(unsigned) * mask.size(), hipMemcpyHostToDevice, ctx->stream));
+            d_mask = (const unsigned *)pm->d_listMask.p;
+        }
         XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
         RowMap M;
-        M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = dense ? pm->nrefs : 0;
-        pm->stat_rows += nrows;
+        M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = !lists ? pm->nrefs : 0;
+        pm->stat_rows += masked ? listedRows : nrows;
         const size_t smem64 = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N) + (n_orient > 1 ? sizeof(double) * 2 * L.N : 0);
         if (n_orient > 1) {
             // exact path: every row in fp64, K largest distinct values per row, then the reference's running top-N
@@ -2999,7 +3036,8 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         XH_TRY(xh_buf_reserve(ctx, pm->d_counters, sizeof(int) * 4));
         XH_HIP(hipMemsetAsync(pm->d_counters.p, 0, sizeof(int) * 4, ctx->stream));
         pm->lastPruneRows = 0;
-        XH_TRY(run_rows(pm, ms, poff, d_ids, dense, pm->nrefs, pm->ev[2], &M, m, 2.f * tauAbs, (int *)pm->d_counters.p + 2));
+        XH_TRY(run_rows(pm, ms, poff, d_ids, !lists, pm->nrefs, pm->ev[2], &M, m, 2.f * tauAbs, (int *)pm->d_counters.p + 2, d_mask, maskW,
+                        listedRows));
         XH_HIP(hipEventRecord(pm->ev[3], ctx->stream));
         // S4
         XH_TRY(xh_buf_reserve(ctx, pm->d_ambList, sizeof(int) * m));
