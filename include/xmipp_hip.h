@@ -319,6 +319,20 @@ int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs /* [ncoef][2] conj'd
 int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32_t precision,
                           double *h_corr2N);
 
+/* ---- 2-D complex FFTs of whole movie frames (FlexAlign) --------------------------------
+ * reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:633-725 plans cuFFT transforms of 4096 x 5760 (K3) frames;
+ * a line of that length does not fit one LDS transform, so it is done in four steps (two strided passes of the line
+ * kernels, a twiddle pass, an untangling transpose). ny x nx complex<float>, row-major, interleaved, in place;
+ * forward un-normalised, inverse divided by ny nx (FFTW / cuFFT conventions of the reference's FourierTransformer:
+ * forward/normalised-inverse pair). Any ny, nx whose prime factors allow a split into two lines of at most 2048 (powers
+ * of two) / 1024 (other lengths, Bluestein) points: up to about a million points per axis. */
+typedef struct xh_fft2d xh_fft2d;
+int xh_fft2d_create(xh_ctx *ctx, int32_t ny, int32_t nx, xh_fft2d **out);
+int xh_fft2d_destroy(xh_fft2d *f);
+/* h_factors[4] = (ny1, ny2, nx1, nx2): the split of either axis (n2 = 1: one LDS transform per line) */
+int xh_fft2d_factors(const xh_fft2d *f, int32_t *h_factors);
+int xh_fft2d_exec(xh_fft2d *f, float *d_data /* [ny][nx][2] */, int32_t inverse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,10 @@ SIGNATURES = {
     "xh_pm_match": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp]),
     "xh_frc_dpr": (C.c_int, [vp, vp, vp, i32, i32, i32, d, i32, i32, d, d, vp, vp, vp, vp, vp, vp]),
     "xh_rf_kernel_ms": (C.c_int, [vp, vp, vp, i32]),
+    "xh_fft2d_create": (C.c_int, [vp, i32, i32, pvp]),
+    "xh_fft2d_destroy": (C.c_int, [vp]),
+    "xh_fft2d_factors": (C.c_int, [vp, vp]),
+    "xh_fft2d_exec": (C.c_int, [vp, vp, i32]),
     "xh_fp_create": (C.c_int, [vp, vp, i32, C.c_double, C.c_double, i32, pvp]),
     "xh_fp_destroy": (C.c_int, [vp]),
     "xh_fp_info": (C.c_int, [vp, vp, vp, vp]),

@@ -327,6 +327,39 @@ def allreduce_reconstruction(rf):
         dist.all_reduce(rf.cropped_view(), op=dist.ReduceOp.SUM)
 
 
+class Fft2D:
+    """In-place complex 2-D FFT of an [ny, nx] complex64 cuda tensor, lines of any factorisable length (xh_fft2d_*: the
+    four-step transform FlexAlign's movie frames need)."""
+
+    def __init__(self, ctx, ny, nx):
+        self.ctx, self.ny, self.nx = ctx, int(ny), int(nx)
+        h = C.c_void_p()
+        check(lib().xh_fft2d_create(ctx.h, self.ny, self.nx, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        f = np.zeros(4, np.int32)
+        check(lib().xh_fft2d_factors(h, _np_ptr(f)))
+        self.factors = tuple(int(v) for v in f)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_fft2d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, data, inverse=False):
+        torch = _torch()
+        assert data.is_cuda and data.dtype == torch.complex64 and data.is_contiguous() and tuple(data.shape) == (self.ny, self.nx)
+        check(lib().xh_fft2d_exec(self.h, C.c_void_p(data.data_ptr()), int(bool(inverse))))
+        return data
+
+
 class FourierProjector:
     """Device side of FourierProjector (data/fourier_projection.cpp): central-slice projections of a
     volume `[z][y][x]` (float32, cuda) with cubic B-spline interpolation in Fourier space."""

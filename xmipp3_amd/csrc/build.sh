@@ -13,6 +13,7 @@ $HIPCC $COMMON -ffp-contract=off -c xh_rf.hip -o build/xh_rf.o & pids+=($!)
 $HIPCC $COMMON -c xh_ctx.hip -o build/xh_ctx.o & pids+=($!)
 if [ -f xh_pm.hip ]; then $HIPCC $COMMON -c xh_pm.hip -o build/xh_pm.o & pids+=($!); fi
 $HIPCC $COMMON -c xh_fp.hip -o build/xh_fp.o & pids+=($!)
+$HIPCC $COMMON -c xh_fft2d.hip -o build/xh_fft2d.o & pids+=($!)
 # shell membership of the FSC is decided in double arithmetic that must round like the scalar code
 $HIPCC $COMMON -ffp-contract=off -c xh_fsc.hip -o build/xh_fsc.o & pids+=($!)
 fail=0

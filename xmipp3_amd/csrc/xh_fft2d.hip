@@ -1,0 +1,251 @@
+// xh_fft2d.hip -- complex 2-D FFTs whose lines do not fit one LDS transform (gfx950).
+//
+// FlexAlign transforms whole movie frames (4096 x 5760 K3 frames, reconstruction_adapt_cuda/
+// movie_alignment_correlation_gpu.cpp:633-725 plans them with cuFFT); the line transforms of xh_plan.h hold a line in
+// LDS and stop at 1024 points (4096 for powers of two). A longer line of N = N1 N2 points is done in four steps
+// (Bailey), every step a pass of kernels that already exist or a plain streaming kernel:
+//     n = N2 n1 + n2,  k = k1 + N1 k2
+//     1. N2 transforms of length N1 over n1 (elements N2 apart)                  xh_k_fft_lines, strided
+//     2. multiply element (k1, n2) by exp(-+2 pi i k1 n2 / N)                    k_fft2d_twiddle
+//     3. N1 transforms of length N2 over n2 (contiguous)                         xh_k_fft_lines
+//     4. X[k1 + N1 k2] sits at N2 k1 + k2: transpose the N1 x N2 matrix          k_fft2d_untangle (out of place)
+// Rows (contiguous lines) and columns (lines nx apart) take the same four steps with different strides. Un-normalised
+// like the line kernels; xh_fft2d_exec divides by ny nx on the inverse.
+#include "xh_common.h"
+#include "xh_fft.h"
+#include "xh_plan.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+typedef xh_c2<float> xh_cf;
+
+namespace {
+
+// one axis: direct (n2 == 1) or four-step
+struct Axis {
+    int n = 0, n1 = 0, n2 = 1;
+    XhPlanBufs<float> p1, p2;        // length n1 (or n when direct), length n2
+    XhBuf tw;                        // exp(-2 pi i j / n), j < n (four-step only)
+};
+
+// largest line xh_k_fft_lines takes in 64 KB of LDS with at least four lines per workgroup
+bool direct_ok(int n)
+{
+    int M = 1;
+    while (M < (xh_is_pow2(n) ? n : 2 * n - 1)) M <<= 1;
+    return M <= 2048;
+}
+
+// n = n1 * n2 with both factors direct_ok, as balanced as possible, powers of two preferred for n1
+bool factorise(int n, int &n1, int &n2)
+{
+    long best = -1;
+    for (int a = 2; (long)a * a <= (long)n * 4 && a <= n / 2; ++a) {
+        if (n % a) continue;
+        const int b = n / a;
+        if (!direct_ok(a) || !direct_ok(b)) continue;
+        // cost: LDS line lengths the two passes run at (Bluestein lines cost their padded length three times)
+        auto cost = [](int m) { int M = 1; while (M < (xh_is_pow2(m) ? m : 2 * m - 1)) M <<= 1; return (long)(xh_is_pow2(m) ? M : 3 * M); };
+        const long c = cost(a) * b + cost(b) * a;
+        if (best < 0 || c < best) { best = c; n1 = a; n2 = b; }
+    }
+    return best >= 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_fft2d_twiddle(xh_cf *__restrict__ data, const xh_cf *__restrict__ tw, size_t total, int n, int n2, size_t inner, size_t outerStride,
+                size_t innerStride, size_t elemStride, int inverse)
+{
+    // element e = N2 k1 + n2 of line l (same line addressing as xh_k_fft_lines); consecutive threads, consecutive lines
+    // of the inner index when the lines are columns, consecutive elements when they are rows
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    size_t l, e;
+    if (elemStride == 1) { l = i / n; e = i - l * n; }
+    else { e = i / inner % n; l = (i / inner / n) * inner + i % inner; }
+    const int k1 = (int)(e / n2), m2 = (int)(e - (size_t)k1 * n2);
+    xh_cf w = tw[(size_t)((long long)k1 * m2 % n)];
+    if (inverse) w.y = -w.y;
+    xh_cf *p = data + (l / inner) * outerStride + (l % inner) * innerStride + e * elemStride;
+    *p = xh_cmul(*p, w);
+}
+
+// out[line][k1 + n1 k2] = in[line][n2 k1 + k2]
+__global__ void __launch_bounds__(256)
+k_fft2d_untangle(const xh_cf *__restrict__ in, xh_cf *__restrict__ out, size_t total, int n, int n1, int n2, size_t inner,
+                 size_t outerStride, size_t innerStride, size_t elemStride, float scale)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    size_t l, k;                                  // k: output element, consecutive threads write consecutive addresses
+    if (elemStride == 1) { l = i / n; k = i - l * n; }
+    else { k = i / inner % n; l = (i / inner / n) * inner + i % inner; }
+    const int k2 = (int)(k / n1), k1 = (int)(k - (size_t)k2 * n1);
+    const size_t base = (l / inner) * outerStride + (l % inner) * innerStride;
+    xh_cf v = in[base + ((size_t)k1 * n2 + k2) * elemStride];
+    v.x *= scale; v.y *= scale;
+    out[base + k * elemStride] = v;
+}
+
+__global__ void __launch_bounds__(256) k_fft2d_scale(xh_cf *__restrict__ d, size_t total, float scale)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { d[i].x *= scale; d[i].y *= scale; }
+}
+
+int axis_create(xh_ctx *ctx, int n, Axis &A)
+{
+    A.n = n;
+    if (direct_ok(n)) {
+        A.n1 = n; A.n2 = 1;
+        return xh_plan_create<float>(ctx, n, A.p1);
+    }
+    XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
+    XH_TRY(xh_plan_create<float>(ctx, A.n1, A.p1));
+    XH_TRY(xh_plan_create<float>(ctx, A.n2, A.p2));
+    const long double PI = 3.14159265358979323846264338327950288L;
+    std::vector<xh_cf> w(n);
+    for (int j = 0; j < n; ++j) {
+        const long double a = -2.0L * PI * j / n;
+        w[j] = xh_cf{(float)cosl(a), (float)sinl(a)};
+    }
+    XH_TRY(xh_buf_alloc(ctx, A.tw, sizeof(xh_cf) * n));
+    XH_HIP(hipMemcpy(A.tw.p, w.data(), A.tw.bytes, hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+void axis_free(Axis &A)
+{
+    xh_plan_free(A.p1);
+    xh_plan_free(A.p2);
+    xh_buf_free(A.tw);
+}
+
+int lines(xh_ctx *ctx, xh_cf *data, const XhPlan<float> &plan, size_t nlines, size_t inner, size_t outerStride, size_t innerStride,
+          size_t elemStride, bool inverse)
+{
+    const int lpb = xh_plan_lpb(plan, 64 * 1024, 16);
+    const size_t smem = ((size_t)lpb * sizeof(xh_cf)) << plan.logM;
+    const unsigned grid = (unsigned)((nlines + lpb - 1) / lpb);
+    if (inverse)
+        hipLaunchKernelGGL((xh_k_fft_lines<float, true>), dim3(grid), dim3(256), smem, ctx->stream, data, plan, nlines, inner, outerStride,
+                           innerStride, elemStride, lpb);
+    else
+        hipLaunchKernelGGL((xh_k_fft_lines<float, false>), dim3(grid), dim3(256), smem, ctx->stream, data, plan, nlines, inner, outerStride,
+                           innerStride, elemStride, lpb);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+// Transforms `count` lines of A.n points: line l starts at (l / inner) * outerStride + (l % inner) * innerStride, elements
+// elemStride apart. Result in `data` (direct) or in `other` (four-step: the untangling pass is out of place); *inData says which.
+int axis_exec(xh_ctx *ctx, const Axis &A, xh_cf *data, xh_cf *other, size_t count, size_t inner, size_t outerStride, size_t innerStride,
+              size_t elemStride, bool inverse, float scale, bool *inData)
+{
+    if (A.n2 == 1) {
+        XH_TRY(lines(ctx, data, A.p1.plan, count, inner, outerStride, innerStride, elemStride, inverse));
+        *inData = true;
+        return XH_OK;
+    }
+    const size_t n1 = A.n1, n2 = A.n2;
+    if (elemStride == 1) {
+        // rows: sub-line (l, n2) starts at base(l) + n2, elements n2 apart; needs inner == count (one row after the other)
+        XH_CHECK(inner == count || innerStride == outerStride / inner, XH_ERR_ARG, "xh_fft2d: rows must be evenly spaced");
+        const size_t rowStride = inner == count ? innerStride : outerStride / inner;
+        XH_TRY(lines(ctx, data, A.p1.plan, count * n2, n2, rowStride, 1, n2, inverse));
+        const size_t total = count * A.n;
+        hipLaunchKernelGGL(k_fft2d_twiddle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, data, (const xh_cf *)A.tw.p, total,
+                           A.n, A.n2, (size_t)1, rowStride, (size_t)0, (size_t)1, inverse ? 1 : 0);
+        XH_LAUNCH_CHECK();
+        XH_TRY(lines(ctx, data, A.p2.plan, count * n1, n1, rowStride, n2, 1, inverse));
+        hipLaunchKernelGGL(k_fft2d_untangle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)data, other, total,
+                           A.n, A.n1, A.n2, (size_t)1, rowStride, (size_t)0, (size_t)1, scale);
+        XH_LAUNCH_CHECK();
+    } else {
+        // columns of a row-major array: count = nx columns, elemStride = nx
+        XH_CHECK(inner == count && innerStride == 1, XH_ERR_ARG, "xh_fft2d: columns must be neighbours");
+        const size_t nx = elemStride;
+        XH_TRY(lines(ctx, data, A.p1.plan, count * n2, count, nx, 1, nx * n2, inverse));            // (x, n2): start n2 nx + x
+        const size_t total = count * A.n;
+        hipLaunchKernelGGL(k_fft2d_twiddle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, data, (const xh_cf *)A.tw.p, total,
+                           A.n, A.n2, count, (size_t)0, (size_t)1, nx, inverse ? 1 : 0);
+        XH_LAUNCH_CHECK();
+        XH_TRY(lines(ctx, data, A.p2.plan, count * n1, count, nx * n2, 1, nx, inverse));            // (x, k1): start k1 n2 nx + x
+        hipLaunchKernelGGL(k_fft2d_untangle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)data, other, total,
+                           A.n, A.n1, A.n2, count, (size_t)0, (size_t)1, nx, scale);
+        XH_LAUNCH_CHECK();
+    }
+    *inData = false;
+    return XH_OK;
+}
+
+}  // namespace
+
+struct xh_fft2d {
+    xh_ctx *ctx;
+    int ny, nx;
+    Axis ax, ay;
+    XhBuf tmp;
+};
+
+extern "C" {
+
+int xh_fft2d_create(xh_ctx *ctx, int32_t ny, int32_t nx, xh_fft2d **out)
+{
+    XH_CHECK(ctx && out && ny >= 1 && nx >= 1, XH_ERR_ARG, "xh_fft2d_create: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    xh_fft2d *f = new xh_fft2d;
+    f->ctx = ctx; f->ny = ny; f->nx = nx;
+    int rc = axis_create(ctx, nx, f->ax);
+    if (rc == XH_OK) rc = axis_create(ctx, ny, f->ay);
+    if (rc == XH_OK && (f->ax.n2 > 1 || f->ay.n2 > 1)) rc = xh_buf_alloc(ctx, f->tmp, sizeof(xh_cf) * (size_t)ny * nx);
+    if (rc != XH_OK) { axis_free(f->ax); axis_free(f->ay); xh_buf_free(f->tmp); delete f; return rc; }
+    *out = f;
+    return XH_OK;
+}
+
+int xh_fft2d_destroy(xh_fft2d *f)
+{
+    if (!f) return XH_OK;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    axis_free(f->ax); axis_free(f->ay); xh_buf_free(f->tmp);
+    delete f;
+    return XH_OK;
+}
+
+int xh_fft2d_factors(const xh_fft2d *f, int32_t *h_factors)
+{
+    XH_CHECK(f && h_factors, XH_ERR_ARG, "xh_fft2d_factors: bad argument");
+    h_factors[0] = f->ay.n1; h_factors[1] = f->ay.n2; h_factors[2] = f->ax.n1; h_factors[3] = f->ax.n2;
+    return XH_OK;
+}
+
+int xh_fft2d_exec(xh_fft2d *f, float *d_data, int32_t inverse)
+{
+    XH_CHECK(f && d_data, XH_ERR_ARG, "xh_fft2d_exec: bad argument");
+    xh_ctx *ctx = f->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t ny = f->ny, nx = f->nx;
+    xh_cf *cur = (xh_cf *)d_data, *oth = (xh_cf *)f->tmp.p;
+    const float scale = inverse ? 1.0f / ((float)ny * (float)nx) : 1.0f;
+    bool scaled = false, inCur = true;
+    // rows: ny lines of nx contiguous points, nx apart
+    XH_TRY(axis_exec(ctx, f->ax, cur, oth, ny, ny, 0, nx, 1, inverse != 0, f->ax.n2 > 1 ? scale : 1.0f, &inCur));
+    if (f->ax.n2 > 1) scaled = true;
+    if (!inCur) std::swap(cur, oth);
+    // columns: nx lines of ny points nx apart
+    const bool scaleHere = !scaled && f->ay.n2 > 1;
+    XH_TRY(axis_exec(ctx, f->ay, cur, oth, nx, nx, 0, 1, nx, inverse != 0, scaleHere ? scale : 1.0f, &inCur));
+    if (scaleHere) scaled = true;
+    if (!inCur) std::swap(cur, oth);
+    if (cur != (xh_cf *)d_data) XH_HIP(hipMemcpyAsync(d_data, cur, sizeof(xh_cf) * ny * nx, hipMemcpyDeviceToDevice, ctx->stream));
+    if (inverse && !scaled) {
+        hipLaunchKernelGGL(k_fft2d_scale, dim3((unsigned)((ny * nx + 255) / 256)), dim3(256), 0, ctx->stream, (xh_cf *)d_data, ny * nx, scale);
+        XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+}
+
+}  // extern "C"
