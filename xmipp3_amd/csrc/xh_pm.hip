@@ -1260,17 +1260,33 @@ __global__ void __launch_bounds__(256)
 k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr, int rowsPerParticle, int nrows,
                RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count)
 {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = row < nrows;
-    const bool keep = valid && !(rowBound[row] < thr[row / rowsPerParticle]);
-    if (valid && !keep) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
-    const unsigned long long kb = __ballot(keep);
-    if (!kb) return;                       // most waves: nothing survives, no atomic
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(kb));
-    base = __shfl(base, 0, 64);
-    if (keep) list[base + __popcll(kb & ((1ull << lane) - 1ull))] = row;
+    // block per particle: its survivors are listed next to each other, so the four waves of a transforming workgroup
+    // (which take four consecutive list entries) mostly work on one particle and share its coefficient rows in the caches
+    // (the frequencies >= K0 of a surviving row are contracted by the wave that transforms it: 205 KB of the particle's and
+    // 205 KB of the reference's coefficients per row)
+    __shared__ int sc[256];
+    __shared__ int sBase;
+    const int p = blockIdx.x, r0 = p * rowsPerParticle;
+    const float t = thr[p];
+    int c = 0;
+    for (int r = r0 + threadIdx.x; r < r0 + rowsPerParticle; r += 256) {
+        const bool keep = !(rowBound[r] < t);
+        if (!keep) { RowRes q; q.best = -3.0e38f; q.idx = 0; q.second = -3.0e38f; q.pad = 0; res[r] = q; }
+        c += keep ? 1 : 0;
+    }
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                    // inclusive scan
+        const int v = (int)threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 255) sBase = sc[255] ? atomicAdd(count, sc[255]) : 0;
+    __syncthreads();
+    int o = sBase + sc[threadIdx.x] - c;
+    for (int r = r0 + threadIdx.x; r < r0 + rowsPerParticle; r += 256)
+        if (!(rowBound[r] < t)) list[o++] = r;
 }
 
 // thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned.
@@ -2850,7 +2866,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             XH_LAUNCH_CHECK();
             // survivors, compacted on the device; d_pruned[1] counts them (the host derives the pruned rows)
             XH_TRY(xh_buf_reserve(ctx, pm->d_survList, sizeof(int) * (size_t)nrows));
-            hipLaunchKernelGGL(k_pm_survivors, dim3((nrows + 255) / 256), dim3(256), 0, ctx->stream, (const float *)pm->d_rowBound.p,
+            hipLaunchKernelGGL(k_pm_survivors, dim3(nparticles), dim3(256), 0, ctx->stream, (const float *)pm->d_rowBound.p,
                                (const float *)pm->d_thr.p, nrows / nparticles, nrows, (RowRes *)pm->d_rowres.p, (int *)pm->d_survList.p,
                                d_pruned + 1);
             XH_LAUNCH_CHECK();
