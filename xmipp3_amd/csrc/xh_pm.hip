@@ -122,6 +122,7 @@ struct xh_pm {
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
+    int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int use_fir64;               // fp64 prefilter as a 65-tap convolution (1) or the recursion (0)
     XhBuf d_firTmp64;
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
@@ -487,6 +488,101 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
         else if (nact == 1) XH_RD_GO(1);
         else XH_RD_GO(0);
 #undef XH_RD_GO
+    }
+}
+
+// ---- the same product in fp64 for the re-scored particles: v_mfma_f64_16x16x4_f64 --------------------------------------
+// The direct kernel (k_pm_ringdft<double>) is bound by its LDS gathers: every lane reads a 16-byte twiddle per 2 FMAs
+// (4 TFLOP/s of the 78 the vector units have). On the matrix cores a wave's 16 slots x 16 frequencies share their
+// operands: per instruction (16 x 16 x 4: 2048 flops) the lanes read one sample and one twiddle each. Same fold of the
+// real samples as above; block = (ring, 16 slots), wave w owns the frequency tiles w, w + 4, ... (up to XH_RD64_NT).
+// Layout of the instruction: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 e][col = lane & 15].
+typedef double xh_f64x4_rd __attribute__((ext_vector_type(4)));
+#define XH_RD64_CH 128
+#define XH_RD64_LD (XH_RD64_CH + 1)
+#define XH_RD64_NT 8
+__global__ void __launch_bounds__(256)
+k_pm_ringdft_mfma64(const double *__restrict__ polar, const double *__restrict__ stat, xh_cd *__restrict__ out,
+                    const xh_cd *__restrict__ tw, const int *__restrict__ nsam, const int *__restrict__ soff,
+                    const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, int nslots, int nrings)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double (*sE)[XH_RD64_LD] = reinterpret_cast<double (*)[XH_RD64_LD]>(smem);
+    double (*sO)[XH_RD64_LD] = sE + 16;
+    xh_cd *sT = reinterpret_cast<xh_cd *>(smem + sizeof(double) * 32 * XH_RD64_LD);        // 32 * 129 * 8 bytes: 16-byte aligned
+    __shared__ double sMean[16];
+    const int r = nrings - 1 - blockIdx.x;        // long rings first
+    const int slot0 = blockIdx.y * 16;
+    const int n = nsam[r], nh = n >> 1, nf = nh + 1, nk = nf, nkt = (nk + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int soffr = soff[r];
+    for (int i = tid; i < n; i += 256) sT[i + (i >> 3)] = tw[soffr + i];    // one pad entry per 8: 16-byte entries, 128-byte rows
+    if (tid < 16) sMean[tid] = stat[2 * min(slot0 + tid, nslots - 1)];
+    for (int kt0 = 0; kt0 < nkt; kt0 += 4 * XH_RD64_NT) {
+        const int left = nkt - kt0 - wv;
+        const int nact = left <= 0 ? 0 : min(XH_RD64_NT, (left + 3) / 4);
+        xh_f64x4_rd accR[XH_RD64_NT], accI[XH_RD64_NT];
+        int j[XH_RD64_NT], dj[XH_RD64_NT], kq[XH_RD64_NT];
+#pragma unroll
+        for (int i = 0; i < XH_RD64_NT; ++i) {
+            accR[i] = (xh_f64x4_rd){0., 0., 0., 0.}; accI[i] = accR[i];
+            kq[i] = ((kt0 + wv + 4 * i) * 16 + li) % n;
+            dj[i] = (4 * kq[i]) % n;
+            j[i] = 0;
+        }
+        for (int sc = 0; sc < nf; sc += XH_RD64_CH) {
+            __syncthreads();                      // previous chunk consumed (sT, sMean visible on the first pass)
+            // fold on the way in: thread <-> (column tid & 127, slots (tid >> 7) + 2 q)
+            {
+                const int col = tid & (XH_RD64_CH - 1), ss = sc + col;
+                const bool inRing = ss < nf, edge = ss == 0 || ss == nh;
+                const int sa = min(ss, nh), sb = sa == 0 ? 0 : n - sa;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int sl = (tid >> 7) + 2 * q;
+                    const double *row = polar + (size_t)min(slot0 + sl, nslots - 1) * nsamples + soffr;
+                    const double xa = row[sa] - sMean[sl], xb = row[sb] - sMean[sl];
+                    sE[sl][col] = inRing ? (edge ? xa : xa + xb) : 0.;
+                    sO[sl][col] = inRing && !edge ? xa - xb : 0.;
+                }
+            }
+            __syncthreads();
+            if (nact > 0) {
+                const int steps = (min(XH_RD64_CH, nf - sc) + 3) >> 2;
+#pragma unroll
+                for (int i = 0; i < XH_RD64_NT; ++i) j[i] = (int)(((long long)(sc + lk) * kq[i]) % n);
+                const double *pe = &sE[li][lk], *po = &sO[li][lk];
+                for (int t = 0; t < steps; ++t) {
+                    const double e = pe[4 * t], o = po[4 * t];
+#pragma unroll
+                    for (int i = 0; i < XH_RD64_NT; ++i) {
+                        if (i < nact) {
+                            const xh_cd w = sT[j[i] + (j[i] >> 3)];
+                            accR[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(e, w.x, accR[i], 0, 0, 0);
+                            accI[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, w.y, accI[i], 0, 0, 0);
+                            j[i] += dj[i];
+                            if (j[i] >= n) j[i] -= n;
+                        }
+                    }
+                }
+            }
+        }
+        const double inv = 1.0 / (double)n;
+#pragma unroll
+        for (int i = 0; i < XH_RD64_NT; ++i) {
+            if (i >= nact) continue;
+            const int k = (kt0 + wv + 4 * i) * 16 + li;
+            if (k >= nk) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int slot = slot0 + lk + 4 * e;
+                if (slot >= nslots) continue;
+                double re = accR[i][e] * inv, im = accI[i][e] * inv;
+                if (conjugate) im = im * (-1.0);
+                out[(size_t)slot * ncoef + coff[r] + k] = xh_cd{re, im};
+            }
+        }
     }
 }
 
@@ -2261,6 +2357,16 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         XH_LAUNCH_CHECK();
         return XH_OK;
     }
+    if (std::is_same<T, double>::value && !d_count && pm->use_mfma64) {
+        // fp64 on the matrix cores (the re-scored particles, the reference bank)
+        const size_t smemD = sizeof(double) * 32 * XH_RD64_LD + sizeof(xh_cd) * (L.N + L.N / 8 + 1);
+        hipLaunchKernelGGL(k_pm_ringdft_mfma64, dim3(L.nrings, (unsigned)((nps + 15) / 16)), dim3(256), smemD, ctx->stream,
+                           (const double *)polarBuf.p, (const double *)statBuf.p, (xh_cd *)outBuf.p, (const xh_cd *)twBuf.p,
+                           (const int *)pm->d_nsam.p, (const int *)pm->d_soff.p, (const int *)pm->d_coff.p, L.nsamples, L.ncoef,
+                           conjugate ? 1 : 0, (int)nps, L.nrings);
+        XH_LAUNCH_CHECK();
+        return XH_OK;
+    }
     const size_t smem2 = sizeof(T) * ((L.N + 3) & ~3) + sizeof(xh_c2<T>) * L.N;
     hipLaunchKernelGGL((k_pm_ringdft<T>), dim3(L.nrings, (unsigned)nps), dim3(256), smem2, ctx->stream, (const T *)polarBuf.p,
                        (const double *)statBuf.p, (xh_c2<T> *)outBuf.p, (const xh_c2<T> *)twBuf.p,
@@ -2366,6 +2472,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tau_rel = 1e-6;
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
+    pm->use_mfma64 = 1;
     pm->use_prune = 1;
     pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
@@ -2689,6 +2796,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "chunk_rows")) pm->chunk_rows = (size_t)value;
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
+    else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
