@@ -123,6 +123,7 @@ struct xh_pm {
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
+    int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
     int use_fir64;               // fp64 prefilter as a 65-tap convolution (1) or the recursion (0)
     XhBuf d_firTmp64;
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
@@ -2171,9 +2172,103 @@ k_pm_tr_cols(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD)
     }
 }
 
+// Two particles per block. The cross-power spectra P_a, P_b are those of real maps, so one complex inverse transform carries
+// both: W = P_a + i P_b  ->  R_a = Re, R_b = Im of its inverse. A block forwards LN/2 columns (LN/4 Hermitian pairs) of either
+// particle, forms the two cross-powers, and inverts LN/2 combined columns into particle a's buffer: the inverse column pass,
+// its stores and the whole inverse row pass (k_pm_tr_irows<.., true>) are halved. Particle b = min(a + 1, m - 1): an odd
+// batch pairs its last particle with itself and the imaginary half is dropped.
 template <int R1, int R2>
 __global__ void __launch_bounds__(256)
-k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_cd *__restrict__ WD, XhTrPart *__restrict__ part)
+k_pm_tr_cols_pair(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD, int m)
+{
+    typedef TrGeom<R1, R2> G;
+    constexpr int D = G::D;
+    constexpr int HL = G::LN / 2;             // lines per particle
+    constexpr int HP = G::LN / 4;             // column pairs per particle and block
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cd *s = reinterpret_cast<xh_cd *>(smem);
+    xh_cd *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int pa = 2 * blockIdx.y, pb = min(pa + 1, m - 1);
+    for (int i = tid; i < D; i += 256) sW[i] = WD[i];
+    // line l: particle l / HL; within a particle, c = l % HL < HP: column P = blockIdx.x*HP + c, c >= HP: its partner D - P
+    auto column = [&](int c) {
+        const int q = c < HP ? c : c - HP;
+        const int P = blockIdx.x * HP + q;
+        if (P == 0) return c < HP ? 0 : D / 2;
+        return c < HP ? P : D - P;
+    };
+    xh_cd v[G::RM];
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;
+        const xh_cd *img = w + (size_t)(cl < HL ? pa : pb) * D * D;
+        const int col = column(cl % HL);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = img[(size_t)(n1 * R2 + n2) * D + col];
+        tr_fwd1<R1, R2>(v, s + cl * G::LS, sW, n2);
+    }
+    __syncthreads();
+    const int cl2 = tid % G::LN, k1 = tid / G::LN;
+    const bool act2 = tid < G::LN * R1;
+    if (act2) tr_fwd2<R1, R2>(v, s + cl2 * G::LS, k1);
+    __syncthreads();
+    if (act2) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[cl2 * G::LS + k1 * G::S1 + k2] = v[k2];
+    }
+    __syncthreads();
+    if (act2) {
+        const int c = cl2 % HL, base = cl2 - c;
+        const int q = c < HP ? c : c - HP;
+        const bool special = (blockIdx.x * HP + q) == 0;
+        const int pc = special ? cl2 : base + (c < HP ? c + HP : c - HP);
+        const double inv = 1.0 / ((double)D * (double)D);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int ky = k1 + R1 * k2;
+            const int nky = (D - ky) & (D - 1);
+            const xh_cd a = v[k2];
+            const xh_cd b = s[pc * G::LS + (nky % R1) * G::S1 + (nky / R1)];
+            const xh_cd f1 = xh_cd{0.5 * (a.x + b.x), 0.5 * (a.y - b.y)};
+            const xh_cd f2 = xh_cd{0.5 * (a.y + b.y), -0.5 * (a.x - b.x)};
+            xh_cd r = xh_cmulc(f1, f2);
+            r.x *= inv;
+            r.y *= inv;
+            v[k2] = r;
+        }
+    }
+    __syncthreads();                          // every partner value has been read
+    if (act2 && cl2 >= HL) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[cl2 * G::LS + k1 * G::S1 + k2] = v[k2];     // P_b to the lines of particle a
+    }
+    __syncthreads();
+    if (act2 && cl2 < HL) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const xh_cd pbv = s[(cl2 + HL) * G::LS + k1 * G::S1 + k2];
+            v[k2] = xh_cd{v[k2].x - pbv.y, v[k2].y + pbv.x};                          // P_a + i P_b
+        }
+    }
+    __syncthreads();
+    if (act2 && cl2 < HL) tr_inv2<R1, R2>(v, s + cl2 * G::LS, sW, k1);
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;
+        if (cl < HL) {
+            tr_inv1<R1, R2>(v, s + cl * G::LS, n2);
+            xh_cd *img = w + (size_t)pa * D * D;
+            const int col = column(cl);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) img[(size_t)(n1 * R2 + n2) * D + col] = v[n1];
+        }
+    }
+}
+
+template <int R1, int R2, bool PAIR = false>
+__global__ void __launch_bounds__(256)
+k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_cd *__restrict__ WD, XhTrPart *__restrict__ part, int m)
 {
     typedef TrGeom<R1, R2> G;
     constexpr int D = G::D;
@@ -2181,7 +2276,8 @@ k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_c
     xh_cd *s = reinterpret_cast<xh_cd *>(smem);
     xh_cd *sW = s + (size_t)G::LN * G::LS;
     const int tid = threadIdx.x;
-    const int p = blockIdx.y, row0 = blockIdx.x * G::LN;
+    // PAIR: the buffer of particle 2 blockIdx.y holds the combined columns of two particles (k_pm_tr_cols_pair)
+    const int p = PAIR ? 2 * blockIdx.y : blockIdx.y, p2 = PAIR ? min(p + 1, m - 1) : p, row0 = blockIdx.x * G::LN;
     for (int i = tid; i < D; i += 256) sW[i] = WD[i];
     __syncthreads();
     xh_cd v[G::RM];
@@ -2199,39 +2295,47 @@ k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_c
         double *dst = Rout + ((size_t)p * D + row0 + l) * D;
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) dst[n1 * R2 + n2] = v[n1].x;
+        if (PAIR && p2 != p) {
+            double *dst2 = Rout + ((size_t)p2 * D + row0 + l) * D;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) dst2[n1 * R2 + n2] = v[n1].y;
+        }
     }
     // What bestShift needs of the whole map before it can look at single elements -- sum and sum of squares
     // (statisticsAdjust) and the first maximum in raster order of the centred map -- leaves with the map: one partial result
     // per block, combined in block order by k_pm_bestshift, which then reads the map once instead of three times.
-    double s1 = 0, s2 = 0, bv = -1.0e300;
-    int bi = 0x7fffffff;
-    if (tid < G::LN * R2) {
-        const int l = tid / R2, n2 = tid - l * R2;
-        const int ci = ((row0 + l + D / 2) % D) * D;          // centred row (CenterFFT(R, true)) of this raw row
-#pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) {
-            const double x = v[n1].x;
-            const int t = ci + (n1 * R2 + n2 + D / 2) % D;
-            s1 += x; s2 += x * x;
-            if (x > bv || (x == bv && t < bi)) { bv = x; bi = t; }
-        }
-    }
-    __syncthreads();                                          // the exchange area is free again
     double *red = reinterpret_cast<double *>(smem);
     int *redi = reinterpret_cast<int *>(red + 3 * 256);
-    red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; redi[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            red[tid] += red[tid + o];
-            red[256 + tid] += red[256 + tid + o];
-            const double ov = red[512 + tid + o];
-            const int oi = redi[tid + o];
-            if (ov > red[512 + tid] || (ov == red[512 + tid] && oi < redi[tid])) { red[512 + tid] = ov; redi[tid] = oi; }
+    for (int h = 0; h < (PAIR ? 2 : 1); ++h) {
+        if (h == 1 && p2 == p) break;
+        double s1 = 0, s2 = 0, bv = -1.0e300;
+        int bi = 0x7fffffff;
+        if (tid < G::LN * R2) {
+            const int l = tid / R2, n2 = tid - l * R2;
+            const int ci = ((row0 + l + D / 2) % D) * D;          // centred row (CenterFFT(R, true)) of this raw row
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const double x = h ? v[n1].y : v[n1].x;
+                const int t = ci + (n1 * R2 + n2 + D / 2) % D;
+                s1 += x; s2 += x * x;
+                if (x > bv || (x == bv && t < bi)) { bv = x; bi = t; }
+            }
         }
+        __syncthreads();                                          // the exchange area (or the previous round) is free
+        red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; redi[tid] = bi;
         __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                red[tid] += red[tid + o];
+                red[256 + tid] += red[256 + tid + o];
+                const double ov = red[512 + tid + o];
+                const int oi = redi[tid + o];
+                if (ov > red[512 + tid] || (ov == red[512 + tid] && oi < redi[tid])) { red[512 + tid] = ov; redi[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
     }
-    if (tid == 0) part[(size_t)p * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
 }
 
 // ---- CTF filtering of the reference gallery (APM:457-481): window to paddim, FFT, multiply the
@@ -2473,6 +2577,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_idft3 = 1;
     pm->use_mfma = 1;
     pm->use_mfma64 = 1;
+    pm->s6_pair = 1;
     pm->use_prune = 1;
     pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
@@ -2797,6 +2902,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_idft3")) pm->use_idft3 = (int)value;
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
+    else if (!strcmp(name, "s6_pair")) pm->s6_pair = (int)value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
@@ -3251,7 +3357,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         if (G::smem > 64 * 1024) {                                                                                          \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_rows<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
-            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
         }                                                                                                                   \
         hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d_psi + p0,                     \
                            (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
@@ -3261,10 +3367,19 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         hipLaunchKernelGGL((k_pm_tr_rows<A_, B_, true>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                \
                            d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0, d_psi + p0,       \
                            d_flip + p0, z, w, (const xh_cd *)pm->d_WD64.p, L.N);                                            \
+        if (pm->s6_pair) {                                                                                                  \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols_pair<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
+            XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
+            hipLaunchKernelGGL((k_pm_tr_cols_pair<A_, B_>), dim3(2 * D / G::LN, (m + 1) / 2), dim3(256), G::smem, ctx->stream, w, \
+                               (const xh_cd *)pm->d_WD64.p, m);                                                             \
+            hipLaunchKernelGGL((k_pm_tr_irows<A_, B_, true>), dim3(D / G::LN, (m + 1) / 2), dim3(256), G::smem, ctx->stream, \
+                               (const xh_cd *)w, R, (const xh_cd *)pm->d_WD64.p, (XhTrPart *)pm->d_trPart.p, m);            \
+        } else {                                                                                                            \
         hipLaunchKernelGGL((k_pm_tr_cols<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, w,                   \
                            (const xh_cd *)pm->d_WD64.p);                                                                    \
-        hipLaunchKernelGGL((k_pm_tr_irows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cd *)w, R, \
-                           (const xh_cd *)pm->d_WD64.p, (XhTrPart *)pm->d_trPart.p);                                        \
+        hipLaunchKernelGGL((k_pm_tr_irows<A_, B_, false>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cd *)w, R, \
+                           (const xh_cd *)pm->d_WD64.p, (XhTrPart *)pm->d_trPart.p, m);                                     \
+        }                                                                                                                   \
         nparts = D / G::LN;                                                                                                 \
     }
             if (D == 64) XH_TR(8, 8)
