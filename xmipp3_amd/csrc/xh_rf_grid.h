@@ -423,7 +423,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 const float oyf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(ciy - H2.w))));
                 const int ox = min(max((int)oxf, -XG_PAD), SX - XG_PAD - XG_PW);       // floats: the conversion then runs on the scalar side
                 const int oy = min(max((int)oyf, -XG_PAD), SY - XG_PAD - XG_PW);
-                if (dbg != 3) {
+                if (dbg != 3 && dbg != 6 && dbg != 7) {
                     // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
                     const unsigned cell = ((unsigned)__float_as_int(R0.w) * (unsigned)SY + (unsigned)(oy + XG_PAD)) * (unsigned)SX + (unsigned)(ox + XG_PAD);
                     xg_dma_patch(pk + cell, dOff, patchBase);
@@ -433,6 +433,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
                 const float ax = R0.x * px + R0.y * py, ay = R1.x * px + R1.y * py, az = R2.x * px + R2.y * py;
                 int qn = 0;
+                if (dbg != 7)
 #pragma unroll
                 for (int zp = 0; zp < 2; ++zp) {
                     const xg_v2f pz2 = zp ? pz23 : pz01;
@@ -470,7 +471,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     const bool a2 = (fabsf(u1 + H0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + H1.w - 0.5f) + et < 0.5f);
                     allHit = __builtin_amdgcn_readfirstlane((int)(a1 || a2)) != 0;
                 }
-                if (dbg != 2) for (int b0 = 0; b0 < qn; b0 += 64) {
+                if (dbg != 2 && dbg != 6 && dbg != 7 && dbg != 8) for (int b0 = 0; b0 < qn; b0 += 64) {
                     if (b0 + lane < qn) {
                         const int id = sQueue[b0 + lane];
                         const float qx = fx0 + (float)(id & 0xff), qy = fy0 + (float)((id >> 8) & 0xff), qz = fz0 + (float)((id >> 16) & 0xff);
