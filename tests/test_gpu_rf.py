@@ -38,9 +38,10 @@ def test_tables_match_oracle(gpu, oracle):
         assert (rf.P, rf.mv) == (o.P, o.mv)
 
 
-@pytest.mark.parametrize("D,maxres", [(32, 0.5), (64, 0.5), (64, 0.3), (50, 0.5), (36, 0.4), (45, 0.5)])
+@pytest.mark.parametrize("D,maxres", [(32, 0.5), (64, 0.5), (64, 0.3), (128, 0.5), (50, 0.5), (36, 0.4), (45, 0.5)])
 def test_prepare_images(gpu, oracle, D, maxres):
-    """D=64 takes the register-blocked FFT, D=32 the radix-2 LDS one, 50/36/45 (padded 100/72/90) Bluestein."""
+    """D=64 and 128 take the register-blocked columns-first / rows-last FFT (radix 16 x 8, 16 x 16; 256 px: 16 x 32, in
+    test_gridding_at_full_size_against_the_oracle), D=32 the radix-2 LDS one, 50/36/45 (padded 100/72/90) Bluestein."""
     xa, ctx, torch = gpu
     rng = np.random.default_rng(D)
     imgs = rng.standard_normal((5, D, D)).astype(np.float32)
