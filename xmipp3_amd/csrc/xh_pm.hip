@@ -209,7 +209,7 @@ k_pm_polar(const T *__restrict__ coefs, T *__restrict__ polar, double *__restric
 // fall into one XH_PC x XH_PC pixel cell of the image (host-built lists, ~1000 samples per cell), stages the cell's
 // (XH_PC + 4)^2 coefficient patch in LDS with the mirror boundary applied, and interpolates from there: same weights, same
 // summation order as d_interp, same bits. Zero offsets only (no 5-D search translation, no wrap): the others keep k_pm_polar.
-#define XH_PC 32
+#define XH_PC 64
 #define XH_PCW (XH_PC + 4)
 template <typename T>
 __global__ void __launch_bounds__(256)

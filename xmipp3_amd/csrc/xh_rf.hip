@@ -1556,9 +1556,14 @@ static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs
                        (const int *)nullptr);
     XH_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rf_shift, dim3((D * ((D + XH_SHIFT_V - 1) / XH_SHIFT_V) + 255) / 256, n), dim3(256), 0, ctx->stream, d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p, d_imgs,
-                       d_shiftXY, d_flip, d_out, D);
-    XH_LAUNCH_CHECK();
+    const float *coefs = d_coefs ? d_coefs : (const float *)rf->d_shiftCoef.p;
+    for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
+        const int m = std::min(65535, n - i0);
+        const size_t o = (size_t)i0 * D * D;
+        hipLaunchKernelGGL(k_rf_shift, dim3((D * ((D + XH_SHIFT_V - 1) / XH_SHIFT_V) + 255) / 256, m), dim3(256), 0, ctx->stream, coefs + o, d_imgs + o,
+                           d_shiftXY + i0, d_flip ? d_flip + i0 : nullptr, d_out + o, D);
+        XH_LAUNCH_CHECK();
+    }
     return XH_OK;
 }
 
