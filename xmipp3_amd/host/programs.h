@@ -729,7 +729,7 @@ public:
         int32_t P, mv, sx, sy;
         xhCheck(xh_rf_sizes(rf, &P, &mv, &sx, &sy));
         const bool hasCTF = useCTF && (SF.containsLabel("ctfModel") || SF.containsLabel("ctfDefocusU"));
-        DeviceBuffer d_img, d_shift, d_fft, d_ctf, d_mod;
+        DeviceBuffer d_img, d_shift;
         std::vector<float> h_img;
         ImageBatchLoader loader;
         loader.dim = imgSize;
@@ -781,16 +781,10 @@ public:
                 xhCheck(xh_rf_shift_images(rf, imgs, sh.data(), fl.data(), (int)n, d_shift.as<float>()));
                 imgs = d_shift.as<float>();
             }
-            d_fft.reserve(ctx, n * (size_t)sx * sy * 8);
-            xhCheck(xh_rf_prepare_images(rf, imgs, (int)n, d_fft.as<float>()));
-            float *ctf = nullptr, *mod = nullptr;
-            if (hasCTF) {
-                d_ctf.reserve(ctx, n * (size_t)sx * sy * 4); d_mod.reserve(ctx, n * (size_t)sx * sy * 4);
-                ctf = d_ctf.as<float>(); mod = d_mod.as<float>();
-                xhCheck(xh_rf_ctf_arrays(rf, ctfs.data(), (int)n, ctf, mod));
-            }
-            xhCheck(xh_rf_insert(rf, d_fft.as<float>(), ctf, mod, ang.data(), do_weights ? w.data() : nullptr, (int)n,
-                                 R_repository.data(), (int)(R_repository.size() / 9)));
+            // processBufferGPU in one call (RFG:417-473): FFT, CTF factor and modulator evaluated while the gridding records
+            // are packed (no CTF planes, same records bit for bit as the three separate steps), insertion
+            xhCheck(xh_rf_insert_images(rf, imgs, hasCTF ? ctfs.data() : nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n,
+                                        R_repository.data(), (int)(R_repository.size() / 9)));
             xhCheck(xh_ctx_sync(ctx));
         }
     }
