@@ -30,7 +30,7 @@
 #ifndef XG_NW
 #define XG_NW 12                // waves per workgroup (= per CU: the LDS budget admits one workgroup)
 #endif
-#define XG_KCAP 256             // surviving projections listed per cull phase
+#define XG_KCAP 64              // surviving projections listed per cull phase, three words each (index + flag, patch cell, patch origin)
 #ifndef XG_PAD
 #define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
 #endif
@@ -40,8 +40,8 @@
 #define XG_LDS_PATCH 0                                   // [XG_NW][XG_PATCH_BYTES]; first, so that LDS-DMA bases stay below 64 KB
 #define XG_LDS_BLOB (XG_NW * XG_PATCH_BYTES)             // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
 #define XG_LDS_ACC (XG_LDS_BLOB + 4 * (XH_BLOB_TABLE + 4))   // [XG_NW][3][256] float
-#define XG_LDS_KEPT (XG_LDS_ACC + XG_NW * 3 * 256 * 4)   // [XG_NW][XG_KCAP] int
-#define XG_LDS_QUEUE (XG_LDS_KEPT + XG_NW * XG_KCAP * 4) // [XG_NW][256] int
+#define XG_LDS_KEPT (XG_LDS_ACC + XG_NW * 3 * 256 * 4)   // [XG_NW][3][XG_KCAP] int
+#define XG_LDS_QUEUE (XG_LDS_KEPT + XG_NW * 3 * XG_KCAP * 4) // [XG_NW][256] int
 #define XG_LDS_RING (XG_LDS_QUEUE + XG_NW * 1024)        // tile ring: int[8] tiles, int[8] ready, ticket, hop
 #define XG_LDS_TOTAL (XG_LDS_RING + 4 * 32)
 
@@ -248,7 +248,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *sBlob = reinterpret_cast<float *>(lds + XG_LDS_BLOB);
     float *sAcc = reinterpret_cast<float *>(lds + XG_LDS_ACC) + wv * 3 * 256;
-    int *sKept = reinterpret_cast<int *>(lds + XG_LDS_KEPT) + wv * XG_KCAP;
+    int *sKept = reinterpret_cast<int *>(lds + XG_LDS_KEPT) + wv * 3 * XG_KCAP;      // [0]: index | allHit << 31, [KCAP]: cell, [2 KCAP]: ox | oy << 16
     int *sQueue = reinterpret_cast<int *>(lds + XG_LDS_QUEUE) + wv * 256;
     int *sTile = reinterpret_cast<int *>(lds + XG_LDS_RING), *sReady = sTile + 8, *sTicket = sTile + 16, *sHop = sTile + 17;
     const unsigned char *sPatch = lds + XG_LDS_PATCH + wv * XG_PATCH_BYTES;
@@ -363,7 +363,30 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     keep = (fabsf(dn) <= frCull + hn) && (dx >= -(frCull + hx)) && (dx <= sizeX + frCull + hx);
                 }
                 const unsigned long long bal = __ballot(keep);
-                if (keep) sKept[nk + __popcll(bal & below)] = sIdx;
+                if (keep) {
+                    // What a visit needs before it can start, found here for 64 projections at a time instead of once per visit
+                    // on the scalar side: where the 16 x 16 patch that covers the unit's footprints begins (the first footprint
+                    // pixel of the corner with the smallest image coordinates; the unit's image extent is < 10.4 pixels,
+                    // H2.zw = extent + r; kept inside the padded record: footprints never leave that, so an origin moved inwards
+                    // still covers them), and whether every row of the unit crosses a face of the slab (u and t of the unit's
+                    // centre row keep their distance from 0 and 1 by more than they vary over the unit: 3.5 rows in y, 1.5 in z).
+                    const float4 r0 = recs[sIdx].r0, r1 = recs[sIdx].r1, h0 = recs[sIdx].h0, h1 = recs[sIdx].h1, h2 = recs[sIdx].h2;
+                    const float cix = r0.x * ucx + r0.y * ucy + r0.z * ucz;
+                    const float ciy = r1.x * ucx + r1.y * ucy + r1.z * ucz + fmvh;
+                    const int ox = min(max((int)ceilf(cix - h2.z), -XG_PAD), SX - XG_PAD - XG_PW);
+                    const int oy = min(max((int)ceilf(ciy - h2.w), -XG_PAD), SY - XG_PAD - XG_PW);
+                    // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
+                    const unsigned cell = ((unsigned)__float_as_int(r0.w) * (unsigned)SY + (unsigned)(oy + XG_PAD)) * (unsigned)SX + (unsigned)(ox + XG_PAD);
+                    const float yc = (float)y0 + 3.5f, zc = (float)z0 + 1.5f;
+                    const float u1 = h0.x * yc + h0.y * zc + h0.z, t1 = h1.x * yc + h1.y * zc + h1.z;
+                    const float eu = 3.5f * fabsf(h0.x) + 1.5f * fabsf(h0.y) + h2.x + 1e-4f, et = 3.5f * fabsf(h1.x) + 1.5f * fabsf(h1.y) + h2.y + 1e-4f;
+                    const bool a1 = (fabsf(u1 - 0.5f) + eu < 0.5f) && (fabsf(t1 - 0.5f) + et < 0.5f);
+                    const bool a2 = (fabsf(u1 + h0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + h1.w - 0.5f) + et < 0.5f);
+                    const int at = nk + __popcll(bal & below);
+                    sKept[at] = sIdx | ((a1 || a2) ? (int)0x80000000 : 0);
+                    sKept[XG_KCAP + at] = (int)cell;
+                    sKept[2 * XG_KCAP + at] = (ox & 0xffff) | (oy << 16);
+                }
                 nk += __popcll(bal);
                 pos += 64;
             }
@@ -372,12 +395,17 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
 
             // ---- visits. Records travel through scalar registers, one visit ahead (unconditional loads: a select would
             // make the compiler wait for them on the spot); the index of the record after that is read from LDS meanwhile
-            int kid = __builtin_amdgcn_readfirstlane(sKept[0]);
-            int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]);
+            int kw = __builtin_amdgcn_readfirstlane(sKept[0]);
+            int kid = kw & 0x7fffffff;
+            int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]) & 0x7fffffff;
             float4 R0 = recs[kid].r0, R1 = recs[kid].r1, R2 = recs[kid].r2, H0 = recs[kid].h0, H1 = recs[kid].h1, H2 = recs[kid].h2;
             for (int k = 0; k < nk; ++k) {
                 const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2, NH0 = recs[kidN].h0, NH1 = recs[kidN].h1, NH2 = recs[kidN].h2;
-                const int kidNN = sKept[min(k + 2, nk - 1)];
+                const int kidNN = sKept[min(k + 2, nk - 1)], kwN = sKept[min(k + 1, nk - 1)];
+                const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane(sKept[XG_KCAP + k]);
+                const int oxy = __builtin_amdgcn_readfirstlane(sKept[2 * XG_KCAP + k]);
+                const int ox = (int)(short)(oxy & 0xffff), oy = oxy >> 16;
+                const bool allHit = kw < 0;
                 if constexpr (FAST) {
                     // processVoxel (RFA:595-625) over the traversal of a zero-thickness slab (RFA:743-761): every row (y, z)
                     // that crosses the image plane gives its voxel nearest to the crossing the nearest pixel. lane <-> row.
@@ -410,24 +438,13 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     }
                     R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
                     kid = kidN;
-                    kidN = __builtin_amdgcn_readfirstlane(kidNN);
+                    kw = __builtin_amdgcn_readfirstlane(kwN);
+                    kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x7fffffff;
                     continue;
                 }
-                // ---- the 16 x 16 patch that covers the unit's footprints: it starts at the first footprint pixel of the
-                // corner with the smallest image coordinates (the unit's image extent is < 10.4 pixels; H2.zw = extent + r).
-                // It stays inside the padded record: footprints never leave that, so an origin moved inwards still
-                // covers them. The patch buffer is free: the previous dense pass has consumed its reads.
-                const float cix = R0.x * ucx + R0.y * ucy + R0.z * ucz;
-                const float ciy = R1.x * ucx + R1.y * ucy + R1.z * ucz + fmvh;
-                const float oxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(cix - H2.z))));
-                const float oyf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ceilf(ciy - H2.w))));
-                const int ox = min(max((int)oxf, -XG_PAD), SX - XG_PAD - XG_PW);       // floats: the conversion then runs on the scalar side
-                const int oy = min(max((int)oyf, -XG_PAD), SY - XG_PAD - XG_PW);
-                if (dbg != 3 && dbg != 6 && dbg != 7) {
-                    // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
-                    const unsigned cell = ((unsigned)__float_as_int(R0.w) * (unsigned)SY + (unsigned)(oy + XG_PAD)) * (unsigned)SX + (unsigned)(ox + XG_PAD);
-                    xg_dma_patch(pk + cell, dOff, patchBase);
-                }
+                // ---- the patch copy (origin found in the cull phase). The patch buffer is free: the previous dense pass has
+                // consumed its reads.
+                if (dbg != 3 && dbg != 6 && dbg != 7) xg_dma_patch(pk + cell, dOff, patchBase);
                 // ---- sparse pass (RFA:631-653 and the reach of the footprint), two z at a time
                 const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
@@ -460,17 +477,6 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 // ---- dense pass
                 const xg_v2f r01x = {R0.x, R1.x}, r01y = {R0.y, R1.y}, r01z = {R0.z, R1.z};
                 const float uLo = 0.5f - H2.x, uHi = 0.5f + H2.x, tLo = 0.5f - H2.y, tHi = 0.5f + H2.y;
-                // every row of the unit crosses a face when u and t of the unit's centre row keep their distance from 0 and 1
-                // by more than they vary over the unit (3.5 rows in y, 1.5 in z): no per-voxel test then
-                bool allHit;
-                {
-                    const float yc = (float)y0 + 3.5f, zc = (float)z0 + 1.5f;
-                    const float u1 = H0.x * yc + H0.y * zc + H0.z, t1 = H1.x * yc + H1.y * zc + H1.z;
-                    const float eu = 3.5f * fabsf(H0.x) + 1.5f * fabsf(H0.y) + H2.x + 1e-4f, et = 3.5f * fabsf(H1.x) + 1.5f * fabsf(H1.y) + H2.y + 1e-4f;
-                    const bool a1 = (fabsf(u1 - 0.5f) + eu < 0.5f) && (fabsf(t1 - 0.5f) + et < 0.5f);
-                    const bool a2 = (fabsf(u1 + H0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + H1.w - 0.5f) + et < 0.5f);
-                    allHit = __builtin_amdgcn_readfirstlane((int)(a1 || a2)) != 0;
-                }
                 if (dbg != 2 && dbg != 6 && dbg != 7 && dbg != 8) for (int b0 = 0; b0 < qn; b0 += 64) {
                     if (b0 + lane < qn) {
                         const int id = sQueue[b0 + lane];
@@ -574,7 +580,8 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 __builtin_amdgcn_wave_barrier();
                 R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
                 kid = kidN;
-                kidN = __builtin_amdgcn_readfirstlane(kidNN);
+                kw = __builtin_amdgcn_readfirstlane(kwN);
+                kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x7fffffff;
             }
         }
         // ---- write-back
