@@ -269,7 +269,9 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     // which pixel of a patch lane l of DMA instruction i fetches: LDS slot s = 64 i + l holds pixel (s / 18, s % 18)
     unsigned dOff[XG_NDMA];
 #pragma unroll
-    for (int i = 0; i < XG_NDMA; ++i) { const int slot = 64 * i + lane, row = slot / XG_PW, col = slot - row * XG_PW; dOff[i] = (unsigned)(row * SX + col) * 16u; }
+    // (footprints reach rows and columns 0..15 of a patch: the two skew columns and the slots behind row 15 re-read pixel
+    // 15 of their row / row 15, which costs no further cache line)
+    for (int i = 0; i < XG_NDMA; ++i) { const int slot = 64 * i + lane, row = slot / XG_PW, col = slot - row * XG_PW; dOff[i] = (unsigned)(min(row, 15) * SX + min(col, 15)) * 16u; }
     // queue word of this lane's voxel zi: x | y << 8 | z << 16 | accumulator index << 24 (bytes feed v_cvt_f32_ubyteN)
     const int qword = lx | (ly << 8) | (lane << 24);
 
