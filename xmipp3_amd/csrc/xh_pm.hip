@@ -354,7 +354,7 @@ k_pm_ringdft(const T *__restrict__ polar, const double *__restrict__ stat, xh_c2
 typedef float xh_f32x16_rd __attribute__((ext_vector_type(16)));
 #define XH_RD_CH 256
 #define XH_RD_LD (XH_RD_CH + 3)      // row stride of the staged samples: odd multiple of banks apart, three zero columns behind a chunk
-#define XH_RD_KT 4
+#define XH_RD_KT 3
 // one round of a block: NA live frequency tiles for this wave (kt0 + wv + 4*i, i < NA). Every wave of
 // the block runs the same number of barriers whatever its NA.
 template <int NA>
@@ -379,7 +379,10 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_LD], float (*sO)[XH_R
     //   Re X[k] = sum_{s=0}^{n/2} E[s] tw[sk].x,   Im X[k] = sum_{s=0}^{n/2} O[s] tw[sk].y
     // -- half the matrix-core work of the plain sum over n samples. The fold happens on the way into LDS.
     const int nh = n >> 1, nf = nh + 1;
-    // chunk c+1 travels from HBM/L2 into registers while the matrix cores work on chunk c
+    // The samples of a chunk pass through registers on their way to LDS. (Fetching chunk c+1 while the matrix cores work on
+    // chunk c needs those 64 registers for the whole chunk and, with four frequency tiles per wave, 454 registers: one wave per
+    // SIMD, matrix cores 32 % busy. Three tiles per wave and no prefetch fit two waves per SIMD -- the other workgroup's matrix
+    // work covers this one's staging: 2.41 -> 1.69 ms per 4096 particles.)
     float preA[32], preB[32];
     auto fetch = [&](int sc) {
         const int ss = min(sc + tid, nh);
@@ -391,8 +394,8 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_LD], float (*sO)[XH_R
             preB[q] = row[sb];
         }
     };
-    fetch(0);
     for (int sc = 0; sc < nf; sc += XH_RD_CH) {
+        fetch(sc);
         __syncthreads();            // previous chunk consumed (and sT / sMean visible on the first pass)
         const int ss = sc + tid;
         const bool inRing = ss < nf, edge = ss == 0 || ss == nh;
@@ -403,7 +406,6 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_LD], float (*sO)[XH_R
             sO[q][tid] = inRing && !edge ? xa - xb : 0.f;
         }
         __syncthreads();
-        if (sc + XH_RD_CH < nf && dbg != 1) fetch(sc + XH_RD_CH);
         if (NA > 0 && dbg != 2) {
             // A step takes two samples (lanes 0-31 the first, 32-63 the second) through 2 NA matrix instructions. Its
             // operands -- the sample pair and NA twiddles -- are read from LDS one whole step ahead, into the other of two
@@ -458,7 +460,7 @@ __device__ __forceinline__ void rd_round(float (*sX)[XH_RD_LD], float (*sO)[XH_R
         }
     }
 }
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ stat, xh_cf *__restrict__ out,
                   const xh_cf *__restrict__ tw, const int *__restrict__ nsam, const int *__restrict__ soff,
                   const int *__restrict__ coff, int nsamples, int ncoef, int conjugate, int nslots, int nrings, int dbg)
@@ -482,7 +484,10 @@ k_pm_ringdft_mfma(const float *__restrict__ polar, const double *__restrict__ st
 #define XH_RD_GO(NA_) rd_round<NA_>(sX, sO, sT, polar, sMean, out, n, nk, kt0, slot0, nslots, nsamples, soff[r], coff[r], ncoef, conjugate, dbg)
 #if XH_RD_KT >= 4
         if (nact == 4) XH_RD_GO(4);
-        else if (nact == 3) XH_RD_GO(3);
+        else
+#endif
+#if XH_RD_KT >= 3
+        if (nact == 3) XH_RD_GO(3);
         else
 #endif
         if (nact == 2) XH_RD_GO(2);
