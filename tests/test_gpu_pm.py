@@ -355,7 +355,7 @@ def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     assert pm.last_stats()["rescored_particles"] == 6
 
 
-@pytest.mark.parametrize("mode", ["dense", "lists"])
+@pytest.mark.parametrize("mode", ["dense", "lists", "ascending_lists"])
 def test_5d_search_indices_bit_identical(gpu, oracle, lib64, mode):
     """--search5d_shift 3 --search5d_step 2 (APM:321-348,575-589,676): 9 extra polar transforms per
     particle, every (reference, translation) pair competes; only (refno, psi, flip) are kept."""
@@ -365,15 +365,17 @@ def test_5d_search_indices_bit_identical(gpu, oracle, lib64, mode):
     assert len(xo) == 9 and (xo[4], yo[4]) == (0, 0)
     n = 21
     off = ids = None
-    if mode == "lists":
+    if mode != "dense":
         rng = np.random.default_rng(5)
         lists = [rng.choice(len(refs), size=int(rng.integers(1, 9)), replace=False) for _ in range(n)]
+        if mode == "ascending_lists":         # the matrix-core path with the off-list references masked
+            lists = [np.sort(l) for l in lists]
         off = np.zeros(n + 1, np.int32)
         off[1:] = np.cumsum([len(l) for l in lists])
         ids = np.concatenate(lists).astype(np.int32)
     pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
-    if mode == "lists":
-        pm.set_option("chunk_rows", 300)
+    if mode != "dense":
+        pm.set_option("chunk_rows", 300 if mode == "lists" else 3 * 9 * len(refs))
     o = oracle.PM(refs)
     refno, psi, flip = pm.match(torch.from_numpy(parts[:n]).cuda(), off, ids, parity=1, shifts5d=(xo, yo))
     er, ep, ef, _ = o.match(parts[:n], off, ids, parity=1, xoff5d=xo, yoff5d=yo)
