@@ -253,6 +253,7 @@ def main():
     if pm is not None and args.tau_rel > 0:
         pm.set_option("tau_rel", args.tau_rel)
     rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
+    s6_rep = [0]            # particles whose translational alignment was repeated in double precision, timed steps only
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     t_grid = ctx.timer()
     grid_ms = []
@@ -270,6 +271,8 @@ def main():
                 st = pm.last_stats()
                 rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
             sx, sy, cc = pm.translate(parts, refno, psi, flip)
+            if record:
+                s6_rep[0] += pm.translate_repeated()
             # the orientations stay on the device: (rot, tilt) of the matched reference, psi from the sample index
             ang = torch.cat([dirs_dev[refno.long()], (psi.double() * (360.0 / pm.N))[:, None]], 1).contiguous()
             shifts = (sx, sy)
@@ -468,6 +471,8 @@ def main():
         # particle's best value are not transformed; the fraction depends on the data
         out["s3_rows_pruned_fraction"] = rows_seen[1] / float(max(1, rows_seen[0]))
         out["s2_two_level_cut"] = dict(zip(("K0", "nk"), pm.two_level_cut()))
+        # S6 runs in fp32 first; particles whose arg-max / window decision is within 2e-5 |max| of flipping are repeated in fp64
+        out["s6_repeated_fraction"] = s6_rep[0] / float(max(1, args.steps * B))
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, host cores of rank 0
     if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N=1 only

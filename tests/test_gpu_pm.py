@@ -504,3 +504,27 @@ def test_errors_are_loud(gpu):
     pm = xa.ProjectionMatcher(ctx, torch.rand((2, 64, 64), device="cuda"))
     with pytest.raises(xa.XhError):
         pm.match(torch.rand((1, 64, 64), device="cuda"), np.array([0, 1], np.int32), np.array([7], np.int32))
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_translation_fp32_pass_with_double_precision_repeats(gpu, oracle, D):
+    """xh_pm_translate runs its chain in fp32 and repeats in double precision every particle whose arg-max or window
+    decision (filters.cpp:1659-1689) comes within 2e-5 |max| of flipping. Against the all-double chain on the same device:
+    no discrete decision differs (shifts within 1e-4 px, far below a window step), maxCC within 1e-6; a sizeable fraction,
+    but not all, of the particles stays fp32."""
+    xa, ctx, torch = gpu
+    nrefs, n = 12, 301
+    refs = _library(D, nrefs, seed=4)
+    rng = np.random.default_rng(D)
+    parts, truth = synth.make_particles(refs, n, rng, snr=0.1, max_shift=3)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    dp = torch.from_numpy(parts).cuda()
+    refno, psi, flip = pm.match(dp)
+    fast = [t.cpu().numpy() for t in pm.translate(dp, refno, psi, flip)]
+    rep = pm.translate_repeated()
+    pm.set_option("s6_fp32", 0)
+    full = [t.cpu().numpy() for t in pm.translate(dp, refno, psi, flip)]
+    assert pm.translate_repeated() == 0
+    assert np.abs(fast[0] - full[0]).max() <= 1e-4 and np.abs(fast[1] - full[1]).max() <= 1e-4
+    assert np.abs(fast[2] - full[2]).max() <= 1e-6
+    assert 0 <= rep < n // 2

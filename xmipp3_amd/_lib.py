@@ -93,6 +93,7 @@ SIGNATURES = {
     "xh_pm_match_ex": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "xh_pm_translate": (C.c_int, [vp, vp, i32, vp, vp, vp, d, vp, vp, vp]),
     "xh_pm_last_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "xh_pm_translate_stats": (C.c_int, [vp, C.POINTER(i64)]),
     "xh_pm_last_coefficients": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]),
     "xh_pm_stage_ms": (C.c_int, [vp, vp, i32]),
     "xh_pm_rows_pruned": (C.c_int, [vp, vp]),

@@ -475,6 +475,12 @@ class ProjectionMatcher:
                                     _ptr(sx), _ptr(sy), _ptr(cc)))
         return sx, sy, cc
 
+    def translate_repeated(self):
+        """Particles the last translate() repeated in double precision (its first pass is fp32)."""
+        r = C.c_int64()
+        check(lib().xh_pm_translate_stats(self.h, C.byref(r)))
+        return r.value
+
     def stage_ms(self, reset=True):
         ms = np.zeros(8, np.float64)
         check(lib().xh_pm_stage_ms(self.h, _np_ptr(ms), int(reset)))

@@ -124,6 +124,10 @@ struct xh_pm {
     int use_idft3, use_mfma, contract_dbg, use_fir;
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
+    int s6_debug;                // profiling: xh_pm_translate returns decision margins instead of shifts
+    int s6_fp32;                 // S6: fp32 pass + double-precision repeat of the ambiguous particles (0: everything in double)
+    double s6_eps;               // ... its ambiguity margin relative to the map's maximum
+    long long s6_flagged;        // particles the last xh_pm_translate repeated in double precision
     int use_fir64;               // fp64 prefilter as a 65-tap convolution (1) or the recursion (0)
     XhBuf d_firTmp64;
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
@@ -135,7 +139,7 @@ struct xh_pm {
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
     XhBuf d_bT, d_aT, d_kboundsLow;
-    XhBuf d_firTmp, d_polarPart, d_trPart, d_listMask;
+    XhBuf d_firTmp, d_polarPart, d_trPart, d_listMask, d_s6Flag, d_s6List, d_s6Parts, d_s6Meta, d_s6Out;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
 };
@@ -1758,10 +1762,12 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
 // bestShift on the centred correlation map (FIL:1593-1719, mask == nullptr, maxShift == -1),
 // max_shift rejection (APM:841-842), translate(LINEAR, wrap) + correlationIndex (APM:850-851).
 // One block per particle. R = real part of the inverse FFT, un-centred (zero lag at index 0).
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__restrict__ zimg, const int *__restrict__ refno,
+k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restrict__ zimg, const int *__restrict__ refno,
                const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
-               double *__restrict__ shiftY, double *__restrict__ maxCC, const XhTrPart *__restrict__ part, int nparts)
+               double *__restrict__ shiftY, double *__restrict__ maxCC, const XhTrPart *__restrict__ part, int nparts, int dbgMargins,
+               unsigned char *__restrict__ flag, double eps)
 {
     __shared__ double red[8];
     __shared__ double sv[256];
@@ -1769,14 +1775,14 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
     __shared__ double sh[2];
     const int p = blockIdx.x;
     if (refno[p] < 0) {
-        if (threadIdx.x == 0) { shiftX[p] = 0; shiftY[p] = 0; maxCC[p] = 0; }
+        if (threadIdx.x == 0) { shiftX[p] = 0; shiftY[p] = 0; maxCC[p] = 0; if (flag) flag[p] = 0; }
         return;
     }
     const int n = D * D, cen = D / 2;
     // rstride 1: real map; 2: real parts of an interleaved complex map
-    const double *R = Rraw + (size_t)p * n * rstride;
+    const T *R = Rraw + (size_t)p * n * rstride;
     // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
-#define RC(i, j) (R[((size_t)(((i) - cen + D) % D) * D + (((j) - cen + D) % D)) * rstride])
+#define RC(i, j) ((double)R[((size_t)(((i) - cen + D) % D) * D + (((j) - cen + D) % D)) * rstride])
     double S1, S2;
     if (part) {
         // sums and the raw maximum came with the map (k_pm_tr_irows), block by block
@@ -1794,7 +1800,7 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
         S1 = red[0]; S2 = red[1];
     } else {
         double s1 = 0, s2 = 0;
-        for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
+        for (int t = threadIdx.x; t < n; t += blockDim.x) { const double v = (double)R[(size_t)t * rstride]; s1 += v; s2 += v * v; }
         S1 = d_block_sum(s1, red); S2 = d_block_sum(s2, red);
     }
     const double avg = S1 / n;
@@ -1841,11 +1847,21 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
             imax = tmax / D + start; jmax = tmax % D + start;
             int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
             int tfirst = tmax;
+            double sec = -1.0e300;                          // largest value beside the maximum (flag != nullptr only)
             for (int t = threadIdx.x; t < n; t += blockDim.x) {
                 const int i = t / D, j = t - i * D;
                 const double v = a * RC(i, j) + b;
                 if (thr > v) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
                 if (v == mx && t < tfirst) tfirst = t;      // an earlier element that rounds onto the maximum (part != nullptr only)
+                if (t != tmax) sec = fmax(sec, v);
+            }
+            if (flag) {
+                __syncthreads();
+                sv[threadIdx.x] = sec;
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sv[threadIdx.x] = fmax(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+                if (threadIdx.x == 0) sh[0] = sv[0];
+                __syncthreads();
             }
             si[threadIdx.x] = nf; si2[threadIdx.x] = tfirst;
             __syncthreads();
@@ -1862,6 +1878,27 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
             __syncthreads();
         }
         int n_max = si[0];
+        if (dbgMargins) {
+            // profiling only: how far the window decision and the arg-max are from flipping (relative to the maximum)
+            __syncthreads();
+            double mg = 1.0e300, sec = -1.0e300;
+            for (int t = threadIdx.x; t < n; t += blockDim.x) {
+                const int i = t / D, j = t - i * D;
+                const double v = a * RC(i, j) + b;
+                if (max(abs(i + start - imax), abs(j + start - jmax)) <= n_max) mg = fmin(mg, fabs(v - thr));
+                if (t != tmax) sec = fmax(sec, v);
+            }
+            sv[threadIdx.x] = mg;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sv[threadIdx.x] = fmin(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+            const double mgAll = sv[0];
+            __syncthreads();
+            sv[threadIdx.x] = sec;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sv[threadIdx.x] = fmax(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+            if (threadIdx.x == 0) { shiftX[p] = mgAll / fabs(mx); shiftY[p] = (mx - sv[0]) / fabs(mx); maxCC[p] = (double)n_max; }
+            return;
+        }
         __syncthreads();
         if (imax - n_max < start) n_max = min(imax - start, n_max);
         if (imax + n_max > fin) n_max = min(fin - imax, n_max);
@@ -1870,6 +1907,8 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
         // centre of mass of the window (FIL:1700-1716)
         double xmax = 0, ymax = 0, sumcorr = 0;
         const int wd = 2 * n_max + 1;
+        double mg = 1.0e300;                                // how close an element of the window comes to the threshold
+        const double secAll = flag ? sh[0] : 0.0;
         for (int t = threadIdx.x; t < wd * wd; t += blockDim.x) {
             const int i = t / wd - n_max, j = t % wd - n_max;
             const int ia = i + imax, ja = j + jmax;
@@ -1877,6 +1916,21 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
             ymax += ia * val;
             xmax += ja * val;
             sumcorr += val;
+            mg = fmin(mg, fabs(val - thr));
+        }
+        if (flag) {
+            // The coarse (fp32) pass of xh_pm_translate: the arg-max and the window are discrete decisions. Where the
+            // runner-up comes within eps |max| of the maximum, or an element of the window within eps |max| of the
+            // threshold, the particle is flagged and repeated in double precision.
+            __syncthreads();
+            sv[threadIdx.x] = mg;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sv[threadIdx.x] = fmin(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+            if (threadIdx.x == 0) {
+                const double lim = eps * fabs(mx);
+                flag[p] = !(sv[0] > lim && mx - secAll > lim && sd != 0) ? 1 : 0;     // NaN-safe: anything unclear is repeated
+            }
+            __syncthreads();
         }
         const double YM = d_block_sum(ymax, red), XM = d_block_sum(xmax, red), SC = d_block_sum(sumcorr, red);
         if (threadIdx.x == 0) {
@@ -1893,7 +1947,7 @@ k_pm_bestshift(const double *__restrict__ Rraw, int rstride, const xh_cd *__rest
     const double ox = sh[0], oy = sh[1];
     // Mtrans = translate(LINEAR, Mimg, (ox,oy), WRAP): out(x,y) samples Mimg at (x-ox, y-oy)
     // correlationIndex(Mref, Mtrans): population statistics
-    const xh_cd *Z = zimg + (size_t)p * n;    // .x = Mref, .y = Mimg
+    const xh_c2<T> *Z = zimg + (size_t)p * n;    // .x = Mref, .y = Mimg
     const double minp = -cen, maxp = D - cen - 1;
     double sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0;
     for (int t = threadIdx.x; t < n; t += blockDim.x) {
@@ -1965,23 +2019,24 @@ __global__ void k_pm_tr_angles(const int *__restrict__ psi, double2 *__restrict_
     const double ang = (double)psi[p] * (360. / (double)N) * 3.14159265358979323846 / 180.0;
     cs[p] = make_double2(cos(ang), sin(ang));
 }
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ refCoef, const int *__restrict__ refno,
-              const double2 *__restrict__ cs, const unsigned char *__restrict__ flip, xh_cd *__restrict__ z, int D)
+              const double2 *__restrict__ cs, const unsigned char *__restrict__ flip, xh_c2<T> *__restrict__ z, int D)
 {
-    __shared__ double sC[XH_TRBW * XH_TRBW];
+    __shared__ T sC[XH_TRBW * XH_TRBW];       // T = double: the reference's arithmetic; float: the coarse pass of xh_pm_translate
     const int tid = threadIdx.x, p = blockIdx.y;
     const int tpr = D / XH_TRB;
     const int ti0 = (blockIdx.x / tpr) * XH_TRB, tj0 = (blockIdx.x % tpr) * XH_TRB;
     const int ref = refno[p];
     const int cen = D / 2;
-    const double c = cs[p].x, sn = cs[p].y;
-    const double minp = -cen, maxp = D - cen - 1;
+    const T c = (T)cs[p].x, sn = (T)cs[p].y;
+    const T minp = -cen, maxp = D - cen - 1;
     // source position of the tile centre and the reach of the rotated tile: first tap column / row of the patch
     const double hc = 0.5 * (XH_TRB - 1);
     const double xc = (tj0 + hc) - cen, yc = (ti0 + hc) - cen;
-    const double xpc = c * xc - sn * yc + cen, ypc = sn * xc + c * yc + cen;      // in index space (x - start)
-    const double ext = hc * (fabs(c) + fabs(sn)) + 1e-6;
+    const double xpc = cs[p].x * xc - cs[p].y * yc + cen, ypc = cs[p].y * xc + cs[p].x * yc + cen;      // in index space (x - start)
+    const double ext = hc * (fabs(cs[p].x) + fabs(cs[p].y)) + 1e-4;
     const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
     if (ref >= 0) {
         const double *coef = refCoef + (size_t)ref * D * D;
@@ -1990,7 +2045,7 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
             // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
             int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
             em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
-            sC[e] = coef[(size_t)em * D + el];
+            sC[e] = (T)coef[(size_t)em * D + el];
         }
     }
     __syncthreads();
@@ -2002,8 +2057,8 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
     bool pixOk = ref >= 0;
     int jsrc = j;
     if (fl) {
-        const double mx = -(double)(j - cen);
-        pixOk = pixOk && !(mx < minp - 1e-6 || mx > maxp + 1e-6);
+        const T mx = -(T)(j - cen);
+        pixOk = pixOk && !(mx < minp - (T)1e-6 || mx > maxp + (T)1e-6);
         jsrc = 2 * cen - j;
     }
 #pragma unroll
@@ -2014,24 +2069,24 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
 #pragma unroll
     for (int k = 0; k < XH_TRB * XH_TRB / 256; ++k) {
         const int i = ti0 + (tid / XH_TRB) + (256 / XH_TRB) * k;
-        xh_cd out = xh_cd{0., (double)pix[k]};
+        xh_c2<T> out = xh_c2<T>{(T)0, (T)pix[k]};
         if (ref >= 0) {
-            const double x = j - cen, y = i - cen;
-            double xp = c * x - sn * y, yp = sn * x + c * y;
-            if (!(xp < minp - 1e-6 || xp > maxp + 1e-6 || yp < minp - 1e-6 || yp > maxp + 1e-6)) {
+            const T x = j - cen, y = i - cen;
+            T xp = c * x - sn * y, yp = sn * x + c * y;
+            if (!(xp < minp - (T)1e-6 || xp > maxp + (T)1e-6 || yp < minp - (T)1e-6 || yp > maxp + (T)1e-6)) {
                 // d_interp<double> on the staged patch
-                xp -= (double)(-cen);
-                yp -= (double)(-cen);
-                const int l1 = (int)ceil(xp - 2.0), m1 = (int)ceil(yp - 2.0);
-                double wx[4], wy[4];
-                d_bspline03_w4<double>(xp, l1, wx);
-                d_bspline03_w4<double>(yp, m1, wy);
-                const double *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
-                double columns = 0;
+                xp -= (T)(-cen);
+                yp -= (T)(-cen);
+                const int l1 = (int)ceil(xp - (T)2), m1 = (int)ceil(yp - (T)2);
+                T wx[4], wy[4];
+                d_bspline03_w4<T>(xp, l1, wx);
+                d_bspline03_w4<T>(yp, m1, wy);
+                const T *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
+                T columns = 0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double *row = base + t * XH_TRBW;
-                    double rows = 0;
+                    const T *row = base + t * XH_TRBW;
+                    T rows = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
                     columns += rows * wy[t];
@@ -2343,6 +2398,203 @@ k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_c
     }
 }
 
+// fp32 pass of S6 (see xh_pm_translate): forward rows of the prebuilt z
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_pm_s6f_rows(const xh_cf *__restrict__ z, xh_cf *__restrict__ w, const xh_cd *__restrict__ WD)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int D = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.y, row0 = blockIdx.x * G::LN;
+    for (int i = tid; i < D; i += 256) sW[i] = xh_cf{(float)WD[i].x, (float)WD[i].y};
+    for (int e = tid; e < G::LN * D; e += 256) {
+        const int l = e / D, j = e - l * D;
+        s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = z[((size_t)p * D + row0 + l) * D + j];
+    }
+    __syncthreads();
+    xh_cf v[G::RM];
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        xh_cf *sl = s + l * G::LS;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = sl[n1 * G::S1 + n2];
+        tr_fwd1<R1, R2>(v, sl, sW, n2);
+    }
+    __syncthreads();
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        tr_fwd2<R1, R2>(v, s + l * G::LS, k1);
+        xh_cf *dst = w + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) dst[k1 + R1 * k2] = v[k2];
+    }
+}
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256)
+k_pm_s6f_cols_pair(xh_cf *__restrict__ w, const xh_cd *__restrict__ WD, int m)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int D = G::D;
+    constexpr int HL = G::LN / 2;             // lines per particle
+    constexpr int HP = G::LN / 4;             // column pairs per particle and block
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    const int pa = 2 * blockIdx.y, pb = min(pa + 1, m - 1);
+    for (int i = tid; i < D; i += 256) sW[i] = xh_cf{(float)WD[i].x, (float)WD[i].y};
+    // line l: particle l / HL; within a particle, c = l % HL < HP: column P = blockIdx.x*HP + c, c >= HP: its partner D - P
+    auto column = [&](int c) {
+        const int q = c < HP ? c : c - HP;
+        const int P = blockIdx.x * HP + q;
+        if (P == 0) return c < HP ? 0 : D / 2;
+        return c < HP ? P : D - P;
+    };
+    xh_cf v[G::RM];
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;
+        const xh_cf *img = w + (size_t)(cl < HL ? pa : pb) * D * D;
+        const int col = column(cl % HL);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = img[(size_t)(n1 * R2 + n2) * D + col];
+        tr_fwd1<R1, R2>(v, s + cl * G::LS, sW, n2);
+    }
+    __syncthreads();
+    const int cl2 = tid % G::LN, k1 = tid / G::LN;
+    const bool act2 = tid < G::LN * R1;
+    if (act2) tr_fwd2<R1, R2>(v, s + cl2 * G::LS, k1);
+    __syncthreads();
+    if (act2) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[cl2 * G::LS + k1 * G::S1 + k2] = v[k2];
+    }
+    __syncthreads();
+    if (act2) {
+        const int c = cl2 % HL, base = cl2 - c;
+        const int q = c < HP ? c : c - HP;
+        const bool special = (blockIdx.x * HP + q) == 0;
+        const int pc = special ? cl2 : base + (c < HP ? c + HP : c - HP);
+        const float inv = 1.0f / ((float)D * (float)D);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int ky = k1 + R1 * k2;
+            const int nky = (D - ky) & (D - 1);
+            const xh_cf a = v[k2];
+            const xh_cf b = s[pc * G::LS + (nky % R1) * G::S1 + (nky / R1)];
+            const xh_cf f1 = xh_cf{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
+            const xh_cf f2 = xh_cf{0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
+            xh_cf r = xh_cmulc(f1, f2);
+            r.x *= inv;
+            r.y *= inv;
+            v[k2] = r;
+        }
+    }
+    __syncthreads();                          // every partner value has been read
+    if (act2 && cl2 >= HL) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) s[cl2 * G::LS + k1 * G::S1 + k2] = v[k2];     // P_b to the lines of particle a
+    }
+    __syncthreads();
+    if (act2 && cl2 < HL) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const xh_cf pbv = s[(cl2 + HL) * G::LS + k1 * G::S1 + k2];
+            v[k2] = xh_cf{v[k2].x - pbv.y, v[k2].y + pbv.x};                          // P_a + i P_b
+        }
+    }
+    __syncthreads();
+    if (act2 && cl2 < HL) tr_inv2<R1, R2>(v, s + cl2 * G::LS, sW, k1);
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int cl = tid % G::LN, n2 = tid / G::LN;
+        if (cl < HL) {
+            tr_inv1<R1, R2>(v, s + cl * G::LS, n2);
+            xh_cf *img = w + (size_t)pa * D * D;
+            const int col = column(cl);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) img[(size_t)(n1 * R2 + n2) * D + col] = v[n1];
+        }
+    }
+}
+
+template <int R1, int R2, bool PAIR = false>
+__global__ void __launch_bounds__(256)
+k_pm_s6f_irows(const xh_cf *__restrict__ w, float *__restrict__ Rout, const xh_cd *__restrict__ WD, XhTrPart *__restrict__ part, int m)
+{
+    typedef TrGeom<R1, R2, float> G;
+    constexpr int D = G::D;
+    extern __shared__ __align__(16) unsigned char smem[];
+    xh_cf *s = reinterpret_cast<xh_cf *>(smem);
+    xh_cf *sW = s + (size_t)G::LN * G::LS;
+    const int tid = threadIdx.x;
+    // PAIR: the buffer of particle 2 blockIdx.y holds the combined columns of two particles (k_pm_tr_cols_pair)
+    const int p = PAIR ? 2 * blockIdx.y : blockIdx.y, p2 = PAIR ? min(p + 1, m - 1) : p, row0 = blockIdx.x * G::LN;
+    for (int i = tid; i < D; i += 256) sW[i] = xh_cf{(float)WD[i].x, (float)WD[i].y};
+    __syncthreads();
+    xh_cf v[G::RM];
+    if (tid < G::LN * R1) {
+        const int l = tid / R1, k1 = tid - l * R1;
+        const xh_cf *src = w + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) v[k2] = src[k1 + R1 * k2];
+        tr_inv2<R1, R2>(v, s + l * G::LS, sW, k1);
+    }
+    __syncthreads();
+    if (tid < G::LN * R2) {
+        const int l = tid / R2, n2 = tid - l * R2;
+        tr_inv1<R1, R2>(v, s + l * G::LS, n2);
+        float *dst = Rout + ((size_t)p * D + row0 + l) * D;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) dst[n1 * R2 + n2] = v[n1].x;
+        if (PAIR && p2 != p) {
+            float *dst2 = Rout + ((size_t)p2 * D + row0 + l) * D;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) dst2[n1 * R2 + n2] = v[n1].y;
+        }
+    }
+    // What bestShift needs of the whole map before it can look at single elements -- sum and sum of squares
+    // (statisticsAdjust) and the first maximum in raster order of the centred map -- leaves with the map: one partial result
+    // per block, combined in block order by k_pm_bestshift, which then reads the map once instead of three times.
+    double *red = reinterpret_cast<double *>(smem);
+    int *redi = reinterpret_cast<int *>(red + 3 * 256);
+    for (int h = 0; h < (PAIR ? 2 : 1); ++h) {
+        if (h == 1 && p2 == p) break;
+        double s1 = 0, s2 = 0, bv = -1.0e300;
+        int bi = 0x7fffffff;
+        if (tid < G::LN * R2) {
+            const int l = tid / R2, n2 = tid - l * R2;
+            const int ci = ((row0 + l + D / 2) % D) * D;          // centred row (CenterFFT(R, true)) of this raw row
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const double x = h ? v[n1].y : v[n1].x;
+                const int t = ci + (n1 * R2 + n2 + D / 2) % D;
+                s1 += x; s2 += x * x;
+                if (x > bv || (x == bv && t < bi)) { bv = x; bi = t; }
+            }
+        }
+        __syncthreads();                                          // the exchange area (or the previous round) is free
+        red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; redi[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                red[tid] += red[tid + o];
+                red[256 + tid] += red[256 + tid + o];
+                const double ov = red[512 + tid + o];
+                const int oi = redi[tid + o];
+                if (ov > red[512 + tid] || (ov == red[512 + tid] && oi < redi[tid])) { red[512 + tid] = ov; redi[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
+    }
+}
+
 // ---- CTF filtering of the reference gallery (APM:457-481): window to paddim, FFT, multiply the
 // spectrum by the real filter Mctf, inverse FFT, window back. fp64, once per library.
 __global__ void k_pm_pad_complex(const float *__restrict__ refs, xh_cd *__restrict__ z, int D, int P)
@@ -2499,7 +2751,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2583,6 +2835,10 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma = 1;
     pm->use_mfma64 = 1;
     pm->s6_pair = 1;
+    pm->s6_debug = 0;
+    pm->s6_fp32 = 1;
+    pm->s6_eps = 2e-5;
+    pm->s6_flagged = 0;
     pm->use_prune = 1;
     pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
@@ -2908,6 +3164,9 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
     else if (!strcmp(name, "s6_pair")) pm->s6_pair = (int)value;
+    else if (!strcmp(name, "s6_debug")) pm->s6_debug = (int)value;
+    else if (!strcmp(name, "s6_fp32")) pm->s6_fp32 = (int)value;
+    else if (!strcmp(name, "s6_eps")) pm->s6_eps = value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
@@ -3327,6 +3586,46 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
     return xh_pm_match_ex(pm, d_particles, n, h_nbr_off, h_nbr_ids, parity, 1, 0, nullptr, nullptr, d_refno, d_psi, d_flip);
 }
 
+// ---- S6 in two precisions. The reference's bestShift is double arithmetic on a 256 x 256 correlation map; its outputs are
+// continuous in the map except for two discrete decisions: which element is the maximum, and how far the window around it
+// grows (the first ring with an element below max / 1.414). The coarse pass runs the whole chain in fp32 (half the bytes,
+// half the LDS per line) and measures how close either decision comes to flipping; a particle whose runner-up lies within
+// eps |max| of the maximum, or which has a window element within eps |max| of the threshold, is repeated in double
+// precision (s6_eps, default 2e-5: twenty times the rounding of the fp32 map; 3 % of the bench's particles). Everyone else
+// keeps shifts that differ from the double-precision ones by the rounding of an fp32 sum (1e-5 px against the tolerance of
+// 1e-3 px the tests hold the fp64 path to).
+__global__ void k_pm_s6_list(const unsigned char *__restrict__ flag, int m, int *__restrict__ list, int *__restrict__ count)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < m && flag[p]) list[atomicAdd(count, 1)] = p;
+}
+__global__ void __launch_bounds__(256)
+k_pm_s6_gather(const float *__restrict__ parts, const int *__restrict__ refno, const int *__restrict__ psi, const unsigned char *__restrict__ flip,
+               const int *__restrict__ list, size_t per, float *__restrict__ oparts, int *__restrict__ oref, int *__restrict__ opsi,
+               unsigned char *__restrict__ oflip)
+{
+    const int q = blockIdx.y, p = list[q];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    if (i + 3 < per) *reinterpret_cast<float4 *>(oparts + (size_t)q * per + i) = *reinterpret_cast<const float4 *>(parts + (size_t)p * per + i);
+    else for (size_t k = i; k < per; ++k) oparts[(size_t)q * per + k] = parts[(size_t)p * per + k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { oref[q] = refno[p]; opsi[q] = psi[p]; oflip[q] = flip[p]; }
+}
+__global__ void k_pm_s6_scatter(const int *__restrict__ list, int cnt, const double *__restrict__ tsx, const double *__restrict__ tsy,
+                                const double *__restrict__ tcc, double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ cc)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= cnt) return;
+    const int p = list[q];
+    sx[p] = tsx[q]; sy[p] = tsy[q]; cc[p] = tcc[q];
+}
+
+int xh_pm_translate_stats(const xh_pm *pm, int64_t *repeated)
+{
+    XH_CHECK(pm && repeated, XH_ERR_ARG, "xh_pm_translate_stats: bad argument");
+    *repeated = pm->s6_flagged;
+    return XH_OK;
+}
+
 int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *d_refno, const int32_t *d_psi,
                     const uint8_t *d_flip, double max_shift, double *d_sx, double *d_sy, double *d_cc)
 {
@@ -3349,11 +3648,12 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
     if (D == 64 || D == 128 || D == 256) {
         // register-blocked three-kernel path
         XH_TRY(xh_buf_reserve(ctx, pm->d_t3, sizeof(double) * per * chunk));
-        for (int p0 = 0; p0 < n; p0 += chunk) {
-            const int m = std::min(chunk, n - p0);
+        XH_TRY(xh_buf_reserve(ctx, pm->d_trAngles, sizeof(double2) * (size_t)chunk));
+        XH_TRY(xh_buf_reserve(ctx, pm->d_trPart, sizeof(XhTrPart) * (size_t)chunk * 64));
+        // the chain in double precision over m particles (the reference's arithmetic)
+        auto chain64 = [&](const float *parts, const int *refno, const int *psi, const unsigned char *flip, int m, double *sx, double *sy,
+                           double *cc) -> int {
             xh_cd *z = (xh_cd *)pm->d_t1.p, *w = (xh_cd *)pm->d_t2.p;
-            XH_TRY(xh_buf_reserve(ctx, pm->d_trAngles, sizeof(double2) * (size_t)chunk));
-            XH_TRY(xh_buf_reserve(ctx, pm->d_trPart, sizeof(XhTrPart) * (size_t)chunk * 64));
             double *R = (double *)pm->d_t3.p;
             int nparts = 0;
 #define XH_TR(A_, B_)                                                                                                       \
@@ -3364,14 +3664,14 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
         }                                                                                                                   \
-        hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, d_psi + p0,                     \
+        hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, psi,                            \
                            (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
-        hipLaunchKernelGGL(k_pm_tr_build, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,                   \
-                           d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0,                   \
-                           (const double2 *)pm->d_trAngles.p, d_flip + p0, z, D);                                           \
+        hipLaunchKernelGGL(k_pm_tr_build<double>, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,           \
+                           parts, (const double *)pm->d_refCoef.p, refno,                                                   \
+                           (const double2 *)pm->d_trAngles.p, flip, z, D);                                                  \
         hipLaunchKernelGGL((k_pm_tr_rows<A_, B_, true>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                \
-                           d_particles + (size_t)p0 * per, (const double *)pm->d_refCoef.p, d_refno + p0, d_psi + p0,       \
-                           d_flip + p0, z, w, (const xh_cd *)pm->d_WD64.p, L.N);                                            \
+                           parts, (const double *)pm->d_refCoef.p, refno, psi,                                              \
+                           flip, z, w, (const xh_cd *)pm->d_WD64.p, L.N);                                                   \
         if (pm->s6_pair) {                                                                                                  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_cols_pair<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));  \
             XH_HIP(hipFuncSetAttribute((const void *)k_pm_tr_irows<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem)); \
@@ -3392,8 +3692,77 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             else XH_TR(16, 16)
 #undef XH_TR
             XH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)R, 1, (const xh_cd *)z, d_refno + p0,
-                               d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0, (const XhTrPart *)pm->d_trPart.p, nparts);
+            hipLaunchKernelGGL(k_pm_bestshift<double>, dim3(m), dim3(256), 0, ctx->stream, (const double *)R, 1, (const xh_cd *)z, refno,
+                               flip, D, max_shift, sx, sy, cc, (const XhTrPart *)pm->d_trPart.p, nparts, pm->s6_debug,
+                               (unsigned char *)nullptr, 0.0);
+            XH_LAUNCH_CHECK();
+            return XH_OK;
+        };
+        // the same chain in fp32 with the ambiguity flags (see above); buffers are the first halves of the double-precision ones
+        auto chain32 = [&](const float *parts, const int *refno, const int *psi, const unsigned char *flip, int m, double *sx, double *sy,
+                           double *cc, unsigned char *flag) -> int {
+            xh_cf *z = (xh_cf *)pm->d_t1.p, *w = (xh_cf *)pm->d_t2.p;
+            float *R = (float *)pm->d_t3.p;
+            int nparts = 0;
+#define XH_TRF(A_, B_)                                                                                                      \
+    {                                                                                                                       \
+        typedef TrGeom<A_, B_, float> G;                                                                                    \
+        hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, psi,                            \
+                           (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
+        hipLaunchKernelGGL(k_pm_tr_build<float>, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,            \
+                           parts, (const double *)pm->d_refCoef.p, refno, (const double2 *)pm->d_trAngles.p, flip, z, D);   \
+        hipLaunchKernelGGL((k_pm_s6f_rows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cf *)z, w, \
+                           (const xh_cd *)pm->d_WD64.p);                                                                    \
+        hipLaunchKernelGGL((k_pm_s6f_cols_pair<A_, B_>), dim3(2 * D / G::LN, (m + 1) / 2), dim3(256), G::smem, ctx->stream, w, \
+                           (const xh_cd *)pm->d_WD64.p, m);                                                                 \
+        hipLaunchKernelGGL((k_pm_s6f_irows<A_, B_, true>), dim3(D / G::LN, (m + 1) / 2), dim3(256), G::smem, ctx->stream,    \
+                           (const xh_cf *)w, R, (const xh_cd *)pm->d_WD64.p, (XhTrPart *)pm->d_trPart.p, m);                \
+        nparts = D / G::LN;                                                                                                 \
+    }
+            if (D == 64) XH_TRF(8, 8)
+            else if (D == 128) XH_TRF(16, 8)
+            else XH_TRF(16, 16)
+#undef XH_TRF
+            XH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_pm_bestshift<float>, dim3(m), dim3(256), 0, ctx->stream, (const float *)R, 1, (const xh_cf *)z, refno,
+                               flip, D, max_shift, sx, sy, cc, (const XhTrPart *)pm->d_trPart.p, nparts, 0, flag, pm->s6_eps);
+            XH_LAUNCH_CHECK();
+            return XH_OK;
+        };
+        pm->s6_flagged = 0;
+        for (int p0 = 0; p0 < n; p0 += chunk) {
+            const int m = std::min(chunk, n - p0);
+            const float *parts = d_particles + (size_t)p0 * per;
+            if (!pm->s6_fp32 || pm->s6_debug) {
+                XH_TRY(chain64(parts, d_refno + p0, d_psi + p0, d_flip + p0, m, d_sx + p0, d_sy + p0, d_cc + p0));
+                continue;
+            }
+            XH_TRY(xh_buf_reserve(ctx, pm->d_s6Flag, (size_t)chunk));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_s6List, sizeof(int) * ((size_t)chunk + 1)));
+            unsigned char *flag = (unsigned char *)pm->d_s6Flag.p;
+            int *list = (int *)pm->d_s6List.p, *count = list + chunk;
+            XH_TRY(chain32(parts, d_refno + p0, d_psi + p0, d_flip + p0, m, d_sx + p0, d_sy + p0, d_cc + p0, flag));
+            XH_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(k_pm_s6_list, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const unsigned char *)flag, m, list, count);
+            XH_LAUNCH_CHECK();
+            int cnt = 0;
+            XH_HIP(hipMemcpyAsync(&cnt, count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            XH_HIP(hipStreamSynchronize(ctx->stream));
+            pm->s6_flagged += cnt;
+            if (cnt == 0) continue;
+            // the flagged particles once more, in double precision, on a compact copy
+            XH_TRY(xh_buf_reserve(ctx, pm->d_s6Parts, sizeof(float) * per * (size_t)cnt));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_s6Meta, (sizeof(int) * 2 + 1) * (size_t)chunk));
+            XH_TRY(xh_buf_reserve(ctx, pm->d_s6Out, sizeof(double) * 3 * (size_t)chunk));
+            int *oref = (int *)pm->d_s6Meta.p, *opsi = oref + chunk;
+            unsigned char *oflip = (unsigned char *)(opsi + chunk);
+            double *tsx = (double *)pm->d_s6Out.p, *tsy = tsx + chunk, *tcc = tsy + chunk;
+            hipLaunchKernelGGL(k_pm_s6_gather, dim3((unsigned)((per + 1023) / 1024), cnt), dim3(256), 0, ctx->stream, parts, d_refno + p0,
+                               d_psi + p0, d_flip + p0, (const int *)list, per, (float *)pm->d_s6Parts.p, oref, opsi, oflip);
+            XH_LAUNCH_CHECK();
+            XH_TRY(chain64((const float *)pm->d_s6Parts.p, oref, opsi, oflip, cnt, tsx, tsy, tcc));
+            hipLaunchKernelGGL(k_pm_s6_scatter, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, (const int *)list, cnt, (const double *)tsx,
+                               (const double *)tsy, (const double *)tcc, d_sx + p0, d_sy + p0, d_cc + p0);
             XH_LAUNCH_CHECK();
         }
         return XH_OK;
@@ -3427,8 +3796,8 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
                            pw, planD, nlines, (size_t)D, per, (size_t)1, (size_t)D, lpb);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pm_bestshift, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,
-                           d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0, (const XhTrPart *)nullptr, 0);
+        hipLaunchKernelGGL(k_pm_bestshift<double>, dim3(m), dim3(256), 0, ctx->stream, (const double *)pw, 2, (const xh_cd *)z, d_refno + p0,
+                           d_flip + p0, D, max_shift, d_sx + p0, d_sy + p0, d_cc + p0, (const XhTrPart *)nullptr, 0, 0, (unsigned char *)nullptr, 0.0);
         XH_LAUNCH_CHECK();
     }
     return XH_OK;
