@@ -98,7 +98,9 @@ template <int R1, int R2, typename T = double> struct TrGeom {
     static constexpr int RM = R1 > R2 ? R1 : R2;
     static constexpr int LN = 256 / RM;
     static constexpr int S1 = R2 + 1;
-    static constexpr int LS = R1 * S1;
+    // one element more than the grid needs: R1 * S1 elements are a multiple of 32 banks for every (R1, R2) in use, and the
+    // column kernels map neighbouring lanes to neighbouring LINES (same element of 8-32 lines: all on one bank without this)
+    static constexpr int LS = R1 * S1 + 1;
     static constexpr size_t smem = sizeof(xh_c2<T>) * ((size_t)LN * LS + D);
 };
 // forward pass 1 on registers v[n1] (thread = (line, n2)): radix R1, twiddle W^(k1*n2), to LDS

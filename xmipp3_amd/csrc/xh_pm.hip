@@ -1779,6 +1779,8 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
         return;
     }
     const int n = D * D, cen = D / 2;
+    const bool pow2 = (D & (D - 1)) == 0;
+    const int lgD = 31 - __clz(D);
     // rstride 1: real map; 2: real parts of an interleaved complex map
     const T *R = Rraw + (size_t)p * n * rstride;
     // centred map value at physical (i,j): raw[(i - cen) mod D][(j - cen) mod D]   (CenterFFT(R,true))
@@ -1848,12 +1850,26 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
             int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
             int tfirst = tmax;
             double sec = -1.0e300;                          // largest value beside the maximum (flag != nullptr only)
-            for (int t = threadIdx.x; t < n; t += blockDim.x) {
-                const int i = t / D, j = t - i * D;
-                const double v = a * RC(i, j) + b;
-                if (thr > v) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
-                if (v == mx && t < tfirst) tfirst = t;      // an earlier element that rounds onto the maximum (part != nullptr only)
-                if (t != tmax) sec = fmax(sec, v);
+            // raw order (coalesced), four independent loads in flight per thread: a block is alone with its map and would
+            // otherwise wait out one memory latency per element
+            for (int t0 = threadIdx.x; t0 < n; t0 += 4 * (int)blockDim.x) {
+                T rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int tr = t0 + u * (int)blockDim.x; rv[u] = tr < n ? R[(size_t)tr * rstride] : (T)0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tr = t0 + u * (int)blockDim.x;
+                    if (tr >= n) break;
+                    const int ri = pow2 ? tr >> lgD : tr / D, rj = tr - ri * D;
+                    int i = ri + cen, j = rj + cen;                          // centred position of raw (ri, rj)
+                    if (i >= D) i -= D;
+                    if (j >= D) j -= D;
+                    const int t = i * D + j;
+                    const double v = a * (double)rv[u] + b;
+                    if (thr > v) nf = min(nf, max(abs(i + start - imax), abs(j + start - jmax)));
+                    if (v == mx && t < tfirst) tfirst = t;      // an earlier element that rounds onto the maximum (part != nullptr only)
+                    if (t != tmax) sec = fmax(sec, v);
+                }
             }
             if (flag) {
                 __syncthreads();
@@ -1950,37 +1966,61 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
     const xh_c2<T> *Z = zimg + (size_t)p * n;    // .x = Mref, .y = Mimg
     const double minp = -cen, maxp = D - cen - 1;
     double sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const int i = t / D, j = t - i * D;
+    const bool ident = ox == 0.0 && oy == 0.0;                   // identity matrix: applyGeometry copies
+    // bilinear taps of the translated particle: the shift is one constant, so the fractional weights are too (except
+    // where the wrap moves a coordinate); the four taps of four pixels are fetched before any of them is used
+    auto taps = [&](int t, int &m1, int &m2, int &n1, int &n2, double &wx, double &wy) {
+        const int i = pow2 ? t >> lgD : t / D, j = t - i * D;
         double xp = (double)(j - cen) - ox, yp = (double)(i - cen) - oy;
-        double val;
-        if (ox == 0.0 && oy == 0.0) val = Z[t].y;      // identity matrix: applyGeometry copies
-        else {
-            if (xp < minp - 1e-6 || xp > maxp + 1e-6) xp = d_realwrap<double>(xp, minp - 0.5, maxp + 0.5);
-            if (yp < minp - 1e-6 || yp > maxp + 1e-6) yp = d_realwrap<double>(yp, minp - 0.5, maxp + 0.5);
-            double wx = xp + cen;
-            const int m1 = (int)wx;
-            wx = wx - m1;
-            int m2 = m1 + 1;
-            double wy = yp + cen;
-            const int n1 = (int)wy;
-            wy = wy - n1;
-            int n2 = n1 + 1;
-            if (m2 >= D) m2 = 0;
-            if (n2 >= D) n2 = 0;
-            const double wx_1 = 1 - wx, wy_1 = 1 - wy;
-            double aux2 = wy_1 * wx_1;
-            double tmp = aux2 * Z[(size_t)n1 * D + m1].y;
-            if (wx != 0 && m2 < D) tmp += (wy_1 - aux2) * Z[(size_t)n1 * D + m2].y;
-            if (wy != 0 && n2 < D) {
-                aux2 = wy * wx_1;
-                tmp += aux2 * Z[(size_t)n2 * D + m1].y;
-                if (wx != 0 && m2 < D) tmp += (wy - aux2) * Z[(size_t)n2 * D + m2].y;
+        if (xp < minp - 1e-6 || xp > maxp + 1e-6) xp = d_realwrap<double>(xp, minp - 0.5, maxp + 0.5);
+        if (yp < minp - 1e-6 || yp > maxp + 1e-6) yp = d_realwrap<double>(yp, minp - 0.5, maxp + 0.5);
+        wx = xp + cen;
+        m1 = (int)wx;
+        wx = wx - m1;
+        m2 = m1 + 1;
+        wy = yp + cen;
+        n1 = (int)wy;
+        wy = wy - n1;
+        n2 = n1 + 1;
+        if (m2 >= D) m2 = 0;
+        if (n2 >= D) n2 = 0;
+    };
+    for (int t0 = threadIdx.x; t0 < n; t0 += 4 * (int)blockDim.x) {
+        T r[4], q00[4], q01[4], q10[4], q11[4];
+        double wxs[4], wys[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + u * (int)blockDim.x, n - 1);
+            const xh_c2<T> zc = Z[t];
+            r[u] = zc.x; q00[u] = zc.y; q01[u] = q10[u] = q11[u] = (T)0; wxs[u] = wys[u] = 0;
+            if (!ident) {
+                int m1, m2, n1, n2;
+                taps(t, m1, m2, n1, n2, wxs[u], wys[u]);
+                q00[u] = Z[(size_t)n1 * D + m1].y; q01[u] = Z[(size_t)n1 * D + m2].y;
+                q10[u] = Z[(size_t)n2 * D + m1].y; q11[u] = Z[(size_t)n2 * D + m2].y;
             }
-            val = tmp;
         }
-        const double r = Z[t].x;
-        sx += r; sxx += r * r; sy += val; syy += val * val; sxy += r * val;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t0 + u * (int)blockDim.x >= n) break;
+            double val;
+            if (ident) val = (double)q00[u];
+            else {
+                const double wx = wxs[u], wy = wys[u];
+                const double wx_1 = 1 - wx, wy_1 = 1 - wy;
+                double aux2 = wy_1 * wx_1;
+                double tmp = aux2 * (double)q00[u];
+                if (wx != 0) tmp += (wy_1 - aux2) * (double)q01[u];
+                if (wy != 0) {
+                    aux2 = wy * wx_1;
+                    tmp += aux2 * (double)q10[u];
+                    if (wx != 0) tmp += (wy - aux2) * (double)q11[u];
+                }
+                val = tmp;
+            }
+            const double rr = (double)r[u];
+            sx += rr; sxx += rr * rr; sy += val; syy += val * val; sxy += rr * val;
+        }
     }
     const double SX = d_block_sum(sx, red), SXX = d_block_sum(sxx, red), SY = d_block_sum(sy, red);
     const double SYY = d_block_sum(syy, red), SXY = d_block_sum(sxy, red);
@@ -2250,11 +2290,15 @@ k_pm_tr_cols_pair(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD, int m)
     xh_cd *sW = s + (size_t)G::LN * G::LS;
     const int tid = threadIdx.x;
     const int pa = 2 * blockIdx.y, pb = min(pa + 1, m - 1);
+    // The blocks of one particle pair that share 128-byte lines of its rows (neighbouring column groups) get block indices
+    // 8 apart: consecutive indices go to consecutive XCDs, so those blocks meet in one L2.
+    const int ngrp = gridDim.x >> 3;
+    const int bx = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * ngrp + (int)(blockIdx.x >> 3);
     for (int i = tid; i < D; i += 256) sW[i] = WD[i];
     // line l: particle l / HL; within a particle, c = l % HL < HP: column P = blockIdx.x*HP + c, c >= HP: its partner D - P
     auto column = [&](int c) {
         const int q = c < HP ? c : c - HP;
-        const int P = blockIdx.x * HP + q;
+        const int P = bx * HP + q;
         if (P == 0) return c < HP ? 0 : D / 2;
         return c < HP ? P : D - P;
     };
@@ -2281,7 +2325,7 @@ k_pm_tr_cols_pair(xh_cd *__restrict__ w, const xh_cd *__restrict__ WD, int m)
     if (act2) {
         const int c = cl2 % HL, base = cl2 - c;
         const int q = c < HP ? c : c - HP;
-        const bool special = (blockIdx.x * HP + q) == 0;
+        const bool special = (bx * HP + q) == 0;
         const int pc = special ? cl2 : base + (c < HP ? c + HP : c - HP);
         const double inv = 1.0 / ((double)D * (double)D);
 #pragma unroll
@@ -2447,11 +2491,15 @@ k_pm_s6f_cols_pair(xh_cf *__restrict__ w, const xh_cd *__restrict__ WD, int m)
     xh_cf *sW = s + (size_t)G::LN * G::LS;
     const int tid = threadIdx.x;
     const int pa = 2 * blockIdx.y, pb = min(pa + 1, m - 1);
+    // The blocks of one particle pair that share 128-byte lines of its rows (neighbouring column groups) get block indices
+    // 8 apart: consecutive indices go to consecutive XCDs, so those blocks meet in one L2.
+    const int ngrp = gridDim.x >> 3;
+    const int bx = (gridDim.x & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * ngrp + (int)(blockIdx.x >> 3);
     for (int i = tid; i < D; i += 256) sW[i] = xh_cf{(float)WD[i].x, (float)WD[i].y};
     // line l: particle l / HL; within a particle, c = l % HL < HP: column P = blockIdx.x*HP + c, c >= HP: its partner D - P
     auto column = [&](int c) {
         const int q = c < HP ? c : c - HP;
-        const int P = blockIdx.x * HP + q;
+        const int P = bx * HP + q;
         if (P == 0) return c < HP ? 0 : D / 2;
         return c < HP ? P : D - P;
     };
@@ -2478,7 +2526,7 @@ k_pm_s6f_cols_pair(xh_cf *__restrict__ w, const xh_cd *__restrict__ WD, int m)
     if (act2) {
         const int c = cl2 % HL, base = cl2 - c;
         const int q = c < HP ? c : c - HP;
-        const bool special = (blockIdx.x * HP + q) == 0;
+        const bool special = (bx * HP + q) == 0;
         const int pc = special ? cl2 : base + (c < HP ? c + HP : c - HP);
         const float inv = 1.0f / ((float)D * (float)D);
 #pragma unroll
