@@ -100,7 +100,7 @@ struct xh_pm {
     // static device data
     XhBuf d_sin, d_cos, d_ringOfSample, d_nsam, d_soff, d_coff, d_rstart, d_ringW;
     XhBuf d_tw32, d_tw64;        // ring DFT twiddles per ring, [nsamples] complex
-    XhBuf d_refs64, d_refsB, d_refSigma, d_refCoef;
+    XhBuf d_refs64, d_refsB, d_refSigma, d_refCoef, d_refCoef32;
     XhBuf d_W32;                 // FFT twiddles for length M (float), M/2 entries (radix-2 kernels)
     XhBuf d_Wfull, d_vperm;      // register-blocked S3: W_M^j, j < M; kernel spectrum in (k1,k2,k3) order
     int R1, R2, R3;              // M = R1*R2*R3 (0 => radix-2 kernel)
@@ -2059,9 +2059,9 @@ __global__ void k_pm_tr_angles(const int *__restrict__ psi, double2 *__restrict_
     const double ang = (double)psi[p] * (360. / (double)N) * 3.14159265358979323846 / 180.0;
     cs[p] = make_double2(cos(ang), sin(ang));
 }
-template <typename T>
+template <typename T, typename TC>
 __global__ void __launch_bounds__(256)
-k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ refCoef, const int *__restrict__ refno,
+k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoef, const int *__restrict__ refno,
               const double2 *__restrict__ cs, const unsigned char *__restrict__ flip, xh_c2<T> *__restrict__ z, int D)
 {
     __shared__ T sC[XH_TRBW * XH_TRBW];       // T = double: the reference's arithmetic; float: the coarse pass of xh_pm_translate
@@ -2079,7 +2079,7 @@ k_pm_tr_build(const float *__restrict__ particles, const double *__restrict__ re
     const double ext = hc * (fabs(cs[p].x) + fabs(cs[p].y)) + 1e-4;
     const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
     if (ref >= 0) {
-        const double *coef = refCoef + (size_t)ref * D * D;
+        const TC *coef = refCoef + (size_t)ref * D * D;
         for (int e = tid; e < XH_TRBW * XH_TRBW; e += 256) {
             const int m = mmin + e / XH_TRBW, l = lmin + e % XH_TRBW;
             // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
@@ -2795,7 +2795,7 @@ template <typename T> static int upload(xh_ctx *ctx, XhBuf &b, const std::vector
 static void free_all(xh_pm *pm)
 {
     XhBuf *bufs[] = {&pm->d_sin, &pm->d_cos, &pm->d_ringOfSample, &pm->d_nsam, &pm->d_soff, &pm->d_coff, &pm->d_rstart, &pm->d_ringW,
-                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack, &pm->d_kbounds,
+                     &pm->d_tw32, &pm->d_tw64, &pm->d_refs64, &pm->d_refsB, &pm->d_refSigma, &pm->d_refCoef, &pm->d_refCoef32, &pm->d_W32, &pm->d_Wfull, &pm->d_vperm, &pm->d_qoff, &pm->d_Bpack, &pm->d_Apack, &pm->d_kbounds,
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
@@ -3714,7 +3714,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         }                                                                                                                   \
         hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, psi,                            \
                            (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
-        hipLaunchKernelGGL(k_pm_tr_build<double>, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,           \
+        hipLaunchKernelGGL((k_pm_tr_build<double, double>), dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream, \
                            parts, (const double *)pm->d_refCoef.p, refno,                                                   \
                            (const double2 *)pm->d_trAngles.p, flip, z, D);                                                  \
         hipLaunchKernelGGL((k_pm_tr_rows<A_, B_, true>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream,                \
@@ -3757,8 +3757,8 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         typedef TrGeom<A_, B_, float> G;                                                                                    \
         hipLaunchKernelGGL(k_pm_tr_angles, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, psi,                            \
                            (double2 *)pm->d_trAngles.p, m, L.N);                                                            \
-        hipLaunchKernelGGL(k_pm_tr_build<float>, dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,            \
-                           parts, (const double *)pm->d_refCoef.p, refno, (const double2 *)pm->d_trAngles.p, flip, z, D);   \
+        hipLaunchKernelGGL((k_pm_tr_build<float, float>), dim3((D / XH_TRB) * (D / XH_TRB), m), dim3(256), 0, ctx->stream,   \
+                           parts, (const float *)pm->d_refCoef32.p, refno, (const double2 *)pm->d_trAngles.p, flip, z, D);  \
         hipLaunchKernelGGL((k_pm_s6f_rows<A_, B_>), dim3(D / G::LN, m), dim3(256), G::smem, ctx->stream, (const xh_cf *)z, w, \
                            (const xh_cd *)pm->d_WD64.p);                                                                    \
         hipLaunchKernelGGL((k_pm_s6f_cols_pair<A_, B_>), dim3(2 * D / G::LN, (m + 1) / 2), dim3(256), G::smem, ctx->stream, w, \
@@ -3778,6 +3778,14 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             return XH_OK;
         };
         pm->s6_flagged = 0;
+        if (pm->s6_fp32 && !pm->s6_debug && !pm->d_refCoef32.p) {
+            // the references' B-spline coefficients once more in fp32 for the coarse pass (half the patch traffic of its build)
+            const size_t tot = (size_t)pm->nrefs * per;
+            XH_TRY(xh_buf_alloc(ctx, pm->d_refCoef32, sizeof(float) * tot));
+            hipLaunchKernelGGL((k_pm_convert<double, float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double *)pm->d_refCoef.p, (float *)pm->d_refCoef32.p, tot);
+            XH_LAUNCH_CHECK();
+        }
         for (int p0 = 0; p0 < n; p0 += chunk) {
             const int m = std::min(chunk, n - p0);
             const float *parts = d_particles + (size_t)p0 * per;
