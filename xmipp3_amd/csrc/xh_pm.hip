@@ -1762,6 +1762,7 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
 // bestShift on the centred correlation map (FIL:1593-1719, mask == nullptr, maxShift == -1),
 // max_shift rejection (APM:841-842), translate(LINEAR, wrap) + correlationIndex (APM:850-851).
 // One block per particle. R = real part of the inverse FFT, un-centred (zero lag at index 0).
+#define XH_BS_U 4            // map elements a thread of k_pm_bestshift has in flight
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restrict__ zimg, const int *__restrict__ refno,
@@ -1850,14 +1851,14 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
             int nf = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
             int tfirst = tmax;
             double sec = -1.0e300;                          // largest value beside the maximum (flag != nullptr only)
-            // raw order (coalesced), four independent loads in flight per thread: a block is alone with its map and would
+            // raw order (coalesced), XH_BS_U independent loads in flight per thread: a block is alone with its map and would
             // otherwise wait out one memory latency per element
-            for (int t0 = threadIdx.x; t0 < n; t0 += 4 * (int)blockDim.x) {
-                T rv[4];
+            for (int t0 = threadIdx.x; t0 < n; t0 += XH_BS_U * (int)blockDim.x) {
+                T rv[XH_BS_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int tr = t0 + u * (int)blockDim.x; rv[u] = tr < n ? R[(size_t)tr * rstride] : (T)0; }
+                for (int u = 0; u < XH_BS_U; ++u) { const int tr = t0 + u * (int)blockDim.x; rv[u] = tr < n ? R[(size_t)tr * rstride] : (T)0; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < XH_BS_U; ++u) {
                     const int tr = t0 + u * (int)blockDim.x;
                     if (tr >= n) break;
                     const int ri = pow2 ? tr >> lgD : tr / D, rj = tr - ri * D;
@@ -1985,11 +1986,11 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
         if (m2 >= D) m2 = 0;
         if (n2 >= D) n2 = 0;
     };
-    for (int t0 = threadIdx.x; t0 < n; t0 += 4 * (int)blockDim.x) {
-        T r[4], q00[4], q01[4], q10[4], q11[4];
-        double wxs[4], wys[4];
+    for (int t0 = threadIdx.x; t0 < n; t0 += XH_BS_U * (int)blockDim.x) {
+        T r[XH_BS_U], q00[XH_BS_U], q01[XH_BS_U], q10[XH_BS_U], q11[XH_BS_U];
+        double wxs[XH_BS_U], wys[XH_BS_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < XH_BS_U; ++u) {
             const int t = min(t0 + u * (int)blockDim.x, n - 1);
             const xh_c2<T> zc = Z[t];
             r[u] = zc.x; q00[u] = zc.y; q01[u] = q10[u] = q11[u] = (T)0; wxs[u] = wys[u] = 0;
@@ -2001,7 +2002,7 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < XH_BS_U; ++u) {
             if (t0 + u * (int)blockDim.x >= n) break;
             double val;
             if (ident) val = (double)q00[u];
