@@ -3640,7 +3640,7 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
 // grows (the first ring with an element below max / 1.414). The coarse pass runs the whole chain in fp32 (half the bytes,
 // half the LDS per line) and measures how close either decision comes to flipping; a particle whose runner-up lies within
 // eps |max| of the maximum, or which has a window element within eps |max| of the threshold, is repeated in double
-// precision (s6_eps, default 2e-5: twenty times the rounding of the fp32 map; 3 % of the bench's particles). Everyone else
+// precision (s6_eps, default 2e-5: twenty times the rounding of the fp32 map; 5 % of the bench's particles). Everyone else
 // keeps shifts that differ from the double-precision ones by the rounding of an fp32 sum (1e-5 px against the tolerance of
 // 1e-3 px the tests hold the fp64 path to).
 __global__ void k_pm_s6_list(const unsigned char *__restrict__ flag, int m, int *__restrict__ list, int *__restrict__ count)
