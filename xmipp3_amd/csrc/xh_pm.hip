@@ -761,28 +761,31 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
             const int k = k0 + kk;
             if (k < kEnd) {
                 const int qb = qoff[k], qe = qoff[k + 1];
-                // software pipeline: the next quad's operands are in flight while this quad's MFMAs issue
-                float4 a[XH_PW2], b = B[(size_t)qb * 64];
+                // software pipeline: the next quad's operands are in flight while this quad's MFMAs issue. Two register sets,
+                // the loop body is two quads (no copies; written out because the compiler turns the one-set form into
+                // load - wait - multiply)
+                float4 a0[XH_PW2], a1[XH_PW2], b0 = B[(size_t)qb * 64], b1 = b0;
 #pragma unroll
-                for (int t = 0; t < XH_PW2; ++t) a[t] = A[t][(size_t)qb * 64];
-                for (int qd = qb; qd < qe; ++qd) {
-                    const int qn = qd < lastQuad ? qd + 1 : qd;
-                    float4 an[XH_PW2];
-                    const float4 bn = B[(size_t)qn * 64];
-#pragma unroll
-                    for (int t = 0; t < XH_PW2; ++t) an[t] = A[t][(size_t)qn * 64];
-#pragma unroll
-                    for (int t = 0; t < XH_PW2; ++t) {
-                        if (dbg == 2) { acc[t][kk][0] += a[t].x * b.x + a[t].w * b.w; continue; }
-                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t][kk], 0, 0, 0);
-                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t][kk], 0, 0, 0);
-                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t][kk], 0, 0, 0);
-                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t][kk], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int t = 0; t < XH_PW2; ++t) a[t] = an[t];
-                    b = bn;
+                for (int t = 0; t < XH_PW2; ++t) { a0[t] = A[t][(size_t)qb * 64]; a1[t] = a0[t]; }
+#define XH_CT_STEP(AC, BC, AN, BN, QN)                                                                        \
+                {                                                                                              \
+                    const int qn_ = (QN) <= lastQuad ? (QN) : lastQuad;                                        \
+                    BN = B[(size_t)qn_ * 64];                                                                  \
+                    _Pragma("unroll") for (int t = 0; t < XH_PW2; ++t) AN[t] = A[t][(size_t)qn_ * 64];         \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
+                    _Pragma("unroll") for (int t = 0; t < XH_PW2; ++t) {                                       \
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[t].x, BC.x, acc[t][kk], 0, 0, 0); \
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[t].y, BC.y, acc[t][kk], 0, 0, 0); \
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[t].z, BC.z, acc[t][kk], 0, 0, 0); \
+                        acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[t].w, BC.w, acc[t][kk], 0, 0, 0); \
+                    }                                                                                          \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
                 }
+                for (int qd = qb; qd < qe; qd += 2) {
+                    XH_CT_STEP(a0, b0, a1, b1, qd + 1)
+                    if (qd + 1 < qe) XH_CT_STEP(a1, b1, a0, b0, qd + 2)
+                }
+#undef XH_CT_STEP
             }
         }
         // lane (j, hi) holds column j = (reference qj, Re|Im) for rows i = (reg&3) + 8*(reg>>2) + 4*hi.
