@@ -228,11 +228,20 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
     if (count && slot >= *count) return;
     const T *c = coefs + (size_t)slot * D * D;
     const int2 org = cellOrg[cell];                      // first tap column / row of the patch, image index space
-    for (int e = threadIdx.x; e < XH_PCW * XH_PCW; e += 256) {
-        const int m = org.y + e / XH_PCW, l = org.x + e % XH_PCW;
-        int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
-        em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
-        sC[e] = c[(size_t)em * D + el];
+    // six loads in flight per thread (the plain loop compiles to load - wait - store)
+    for (int e0 = threadIdx.x; e0 < XH_PCW * XH_PCW; e0 += 6 * 256) {
+        T v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = min(e0 + u * 256, XH_PCW * XH_PCW - 1);
+            const int m = org.y + e / XH_PCW, l = org.x + e % XH_PCW;
+            int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+            em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
+            v[u] = c[(size_t)em * D + el];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (e0 + u * 256 < XH_PCW * XH_PCW) sC[e0 + u * 256] = v[u];
     }
     __syncthreads();
     double sw = 0, swv = 0, swv2 = 0;
@@ -2084,12 +2093,21 @@ k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoe
     const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
     if (ref >= 0) {
         const TC *coef = refCoef + (size_t)ref * D * D;
-        for (int e = tid; e < XH_TRBW * XH_TRBW; e += 256) {
-            const int m = mmin + e / XH_TRBW, l = lmin + e % XH_TRBW;
-            // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
-            int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
-            em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
-            sC[e] = (T)coef[(size_t)em * D + el];
+        // four loads in flight per thread (written out: the plain loop compiles to load - wait - store)
+        for (int e0 = tid; e0 < XH_TRBW * XH_TRBW; e0 += 4 * 256) {
+            TC v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * 256, XH_TRBW * XH_TRBW - 1);
+                const int m = mmin + e / XH_TRBW, l = lmin + e % XH_TRBW;
+                // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
+                int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+                em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
+                v[u] = coef[(size_t)em * D + el];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 256 < XH_TRBW * XH_TRBW) sC[e0 + u * 256] = (T)v[u];
         }
     }
     __syncthreads();
