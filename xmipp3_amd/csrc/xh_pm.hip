@@ -111,7 +111,7 @@ struct xh_pm {
     // per-call scratch
     XhBuf d_coef32, d_polar32, d_A32, d_stat32;     // S1<float>
     XhBuf d_trAngles;                               // S6: cos / sin per particle
-    XhBuf d_cellStart, d_cellSamples, d_cellOrg;    // k_pm_polar_cells: samples per image cell
+    XhBuf d_cellStart, d_cellSamples, d_cellOrg, d_cellData;    // k_pm_polar_cells: samples per image cell
     int ncells, use_cells;
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
     XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
@@ -219,7 +219,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float *__restrict__ sinr, const float *__restrict__ cosr,
                  const short *__restrict__ ringOf, const double *__restrict__ ringW, int D, int nsamples,
-                 const int *__restrict__ cellStart, const int *__restrict__ cellSamples, const int2 *__restrict__ cellOrg,
+                 const int *__restrict__ cellStart, const float4 *__restrict__ cellData, const int2 *__restrict__ cellOrg,
                  int ncells, const int *__restrict__ count, double *__restrict__ partial)
 {
     __shared__ T sC[XH_PCW * XH_PCW];
@@ -246,27 +246,40 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
     __syncthreads();
     double sw = 0, swv = 0, swv2 = 0;
     const T start = (T)(-(D / 2));
-    for (int q = cellStart[cell] + threadIdx.x; q < cellStart[cell + 1]; q += 256) {
-        const int i = cellSamples[q];
-        const T x = (T)sinr[i] - start, y = (T)cosr[i] - start;
-        const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
-        T wx[4], wy[4];
-        d_bspline03_w4<T>(x, l1, wx);
-        d_bspline03_w4<T>(y, m1, wy);
-        const T *base = sC + (m1 - org.y) * XH_PCW + (l1 - org.x);
-        T columns = 0;
+    // four samples per thread and step: their 16-byte records (x, y, sample index, ring) first, then the ring weights,
+    // then the interpolation (the one-sample loop waited out a chain of four dependent loads per sample)
+    const int qEnd = cellStart[cell + 1];
+    for (int q0 = cellStart[cell] + threadIdx.x; q0 < qEnd; q0 += 4 * 256) {
+        float4 rec[4];
+        double wr[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const T *row = base + t * XH_PCW;
-            T rows = 0;
+        for (int u = 0; u < 4; ++u) rec[u] = cellData[min(q0 + u * 256, qEnd - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rows += row[u] * wx[u];
-            columns += rows * wy[t];
+        for (int u = 0; u < 4; ++u) wr[u] = ringW[__float_as_int(rec[u].w)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (q0 + u * 256 >= qEnd) break;
+            const int i = __float_as_int(rec[u].z);
+            const T x = (T)rec[u].x - start, y = (T)rec[u].y - start;
+            const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
+            T wx[4], wy[4];
+            d_bspline03_w4<T>(x, l1, wx);
+            d_bspline03_w4<T>(y, m1, wy);
+            const T *base = sC + (m1 - org.y) * XH_PCW + (l1 - org.x);
+            T columns = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const T *row = base + t * XH_PCW;
+                T rows = 0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rows += row[v] * wx[v];
+                columns += rows * wy[t];
+            }
+            polar[(size_t)slot * nsamples + i] = columns;
+            const double w = wr[u];
+            const double dv = (double)columns;
+            sw += w; swv += w * dv; swv2 += w * dv * dv;
         }
-        polar[(size_t)slot * nsamples + i] = columns;
-        const double w = ringW[ringOf[i]];
-        const double dv = (double)columns;
-        sw += w; swv += w * dv; swv2 += w * dv * dv;
     }
     const double N = d_block_sum(sw, red);
     const double S = d_block_sum(swv, red);
@@ -2756,7 +2769,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         hipLaunchKernelGGL((k_pm_polar_cells<T>), dim3((unsigned)(nps * nc)), dim3(256), 0, ctx->stream, (const T *)coefBuf.p, (T *)polarBuf.p,
                            (const float *)pm->d_sin.p, (const float *)pm->d_cos.p, (const short *)pm->d_ringOfSample.p,
                            (const double *)pm->d_ringW.p, D, L.nsamples, (const int *)pm->d_cellStart.p,
-                           (const int *)pm->d_cellSamples.p, (const int2 *)pm->d_cellOrg.p, nc, d_count, (double *)pm->d_polarPart.p);
+                           (const float4 *)pm->d_cellData.p, (const int2 *)pm->d_cellOrg.p, nc, d_count, (double *)pm->d_polarPart.p);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pm_polar_stats_counted, dim3((unsigned)((nps + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double *)pm->d_polarPart.p, (double *)statBuf.p, (int)nps, nc, d_count);
@@ -2821,7 +2834,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -3030,6 +3043,15 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
             if (rc == XH_OK) rc = upload(ctx, pm->d_cellStart, cstart);
             if (rc == XH_OK) rc = upload(ctx, pm->d_cellSamples, csamp);
             if (rc == XH_OK) rc = upload(ctx, pm->d_cellOrg, corg);
+            // everything a sample needs in list order: (x, y, sample index, ring) in one 16-byte load
+            std::vector<float4> cdata(csamp.size());
+            for (size_t q = 0; q < csamp.size(); ++q) {
+                const int i = csamp[q], ring = ringOf[i];
+                float fi, fr;
+                memcpy(&fi, &i, 4); memcpy(&fr, &ring, 4);
+                cdata[q] = make_float4(sn[i], cs[i], fi, fr);
+            }
+            if (rc == XH_OK) rc = upload(ctx, pm->d_cellData, cdata);
         }
         if (rc == XH_OK) rc = upload(ctx, pm->d_ringOfSample, ringOf);
         if (rc == XH_OK) rc = upload(ctx, pm->d_nsam, L.nsam);
