@@ -2195,12 +2195,19 @@ k_pm_tr_rows(const float *__restrict__ particles, const double *__restrict__ ref
     const double minp = -cen, maxp = D - cen - 1;
     const float *img = particles + (size_t)p * D * D;
     const bool fl = flip[p] != 0;
+    if (PREBUILT) {              // z comes from k_pm_tr_build; all of the thread's elements in flight before the first store
+        constexpr int NE = G::LN * D / 256;
+        xh_cd in[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) in[u] = z[((size_t)p * D + row0) * D + tid + 256 * u];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + 256 * u, l = e / D, j = e - l * D;
+            s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = in[u];
+        }
+    } else
     for (int e = tid; e < G::LN * D; e += 256) {
         const int l = e / D, j = e - l * D, i = row0 + l;
-        if (PREBUILT) {          // z comes from k_pm_tr_build
-            s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = z[((size_t)p * D + i) * D + j];
-            continue;
-        }
         xh_cd out = xh_cd{0., 0.};
         if (ref >= 0) {
             const double x = j - cen, y = i - cen;
@@ -2490,9 +2497,17 @@ k_pm_s6f_rows(const xh_cf *__restrict__ z, xh_cf *__restrict__ w, const xh_cd *_
     const int tid = threadIdx.x;
     const int p = blockIdx.y, row0 = blockIdx.x * G::LN;
     for (int i = tid; i < D; i += 256) sW[i] = xh_cf{(float)WD[i].x, (float)WD[i].y};
-    for (int e = tid; e < G::LN * D; e += 256) {
-        const int l = e / D, j = e - l * D;
-        s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = z[((size_t)p * D + row0 + l) * D + j];
+    {
+        // all of the thread's elements in flight before the first is stored (the plain loop compiles to load - wait - store)
+        constexpr int NE = G::LN * D / 256;
+        xh_cf in[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) in[u] = z[((size_t)p * D + row0) * D + tid + 256 * u];      // LN consecutive rows: one run
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + 256 * u, l = e / D, j = e - l * D;
+            s[l * G::LS + (j / R2) * G::S1 + (j % R2)] = in[u];
+        }
     }
     __syncthreads();
     xh_cf v[G::RM];
