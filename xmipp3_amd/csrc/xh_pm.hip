@@ -1061,7 +1061,16 @@ __global__ void k_pm_tail_norms(const xh_cf *__restrict__ X, float *__restrict__
     if (k >= nk || item >= nitems) return;
     const xh_cf *x = X + (size_t)item * ncoef + k;
     float acc = 0.f;
-    for (int r = rstart[k]; r < nrings; ++r) { const xh_cf v = x[coff[r]]; acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); }
+    // eight rings per step: eight loads in flight (same order of additions as one ring at a time)
+    int r = rstart[k];
+    for (; r + 8 <= nrings; r += 8) {
+        xh_cf v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[coff[r + u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc = fmaf(v[u].x, v[u].x, acc); acc = fmaf(v[u].y, v[u].y, acc); }
+    }
+    for (; r < nrings; ++r) { const xh_cf v = x[coff[r]]; acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); }
     out[(size_t)item * strideItem + (size_t)k * strideK] = sqrtf(acc) * 1.000001f;
 }
 
@@ -1336,7 +1345,24 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
                 ref[j] = rr[j] < s1 ? d_row_ref(M, rr[j], slot) : 0;
                 tail[j] = 0.f;
             }
-            for (int k = 0; k < nhigh; ++k) {
+            // four frequencies per step: sixteen loads in flight (same order of additions)
+            int k = 0;
+            for (; k + 4 <= nhigh; k += 4) {
+                float bv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *bk = bT + (size_t)(K0 + k + u) * nrefs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[u][j] = bk[ref[j]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float av = sA[k + u];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tail[j] = fmaf(av, bv[u][j], tail[j]);
+                }
+            }
+            for (; k < nhigh; ++k) {
                 const float av = sA[k];
                 const float *bk = bT + (size_t)(K0 + k) * nrefs;
 #pragma unroll
