@@ -873,12 +873,15 @@ k_rf_supercull(const float4 *__restrict__ cullN, const float4 *__restrict__ cull
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) sBase = 0;
     __syncthreads();
+    // the next round's vectors travel while this round is counted and written
+    float4 nNext = make_float4(0.f, 0.f, 0.f, 0.f), xNext = nNext;
+    if ((int)threadIdx.x < nspaces) { nNext = cullN[threadIdx.x]; xNext = cullX[threadIdx.x]; }
     for (int s0 = 0; s0 < nspaces; s0 += 256) {
         const int s = s0 + threadIdx.x;
         bool hit = false;
-        float4 n = make_float4(0.f, 0.f, 0.f, 0.f), r0 = n;
+        float4 n = nNext, r0 = xNext;
+        if (s + 256 < nspaces) { nNext = cullN[s + 256]; xNext = cullX[s + 256]; }
         if (s < nspaces) {
-            n = cullN[s]; r0 = cullX[s];
             const float dn = n.x * cx + n.y * cy + n.z * cz;
             const float dx = r0.x * cx + r0.y * cy + r0.z * cz;
             // box bounds (voxel centres within +-XH_SUPERH of the super-tile centre per axis), never wider than the sphere bound
