@@ -278,6 +278,9 @@ int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned);
 int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
+/* current value of "tau_rel" (ambiguity margin of the fp32 coarse search, relative to sum_r 2 pi r) or "s6_eps" (margin of the
+ * fp32 pass of xh_pm_translate, relative to the maximum of the correlation map): the tests hold the measured fp32 errors against them */
+int xh_pm_get_option(const xh_pm *pm, const char *name, double *value);
 
 /* ---- FourierProjector: central-slice projections of a volume ------------------
  * Replaces the class FourierProjector (libraries/data/fourier_projection.h:111-172) behind
@@ -322,6 +325,9 @@ int xh_pm_debug_ref(xh_pm *pm, int32_t ref, double *h_coefs /* [ncoef][2] conj'd
  * computed by the fp32 coarse pass (precision 32) or the fp64 re-scorer (64) */
 int xh_pm_debug_corr_rows(xh_pm *pm, const float *d_particle, int32_t ref, int32_t precision,
                           double *h_corr2N);
+/* the correlation maps (correlation_matrix, FIL:1636) the last chunk of an xh_pm_translate call under
+ * set_option("s6_capture", 32 | 64) left behind, [n][D][D] doubles on the host; 64, 128 and 256 px */
+int xh_pm_debug_s6_maps(xh_pm *pm, int32_t n, double *h_maps);
 
 /* ---- 2-D complex FFTs of whole movie frames (FlexAlign) --------------------------------
  * reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:633-725 plans cuFFT transforms of 4096 x 5760 (K3) frames;

@@ -145,6 +145,50 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
 
 
 @pytest.mark.gpu
+def test_cli_second_iteration_applies_the_previous_shifts(bins, tmp_path, oracle):
+    """A second refinement iteration: the input metadata carries shiftX / shiftY from the first. getCurrentImage
+    (APM:1194-1236) builds the transformation from them, inverts it and applies it with BSPLINE3 + WRAP and IS_INV before
+    anything else; the shifts written out are the newly found ones plus the previous ones (APM:1142-1144). Oracle: the same
+    geometry applied with the oracle's applyGeometry, then its match and translate on the moved images."""
+    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path, D=32, n=9, seed=6)
+    n, nrefs = len(parts), len(refs)
+    rng = np.random.default_rng(12)
+    prev = np.round(rng.uniform(-2.5, 2.5, (n, 2)), 3)
+    prev[0] = (0.0, 0.0)                       # an identity transformation is skipped (APM:1231)
+    prev[1] = (1.0, -2.0)                      # whole pixels
+    xmipp_io.write_xmd(str(tmp_path / "exp2.xmd"), [("noname", ["itemId", "image", "shiftX", "shiftY", "scale"],
+                       [[100 + i, f"{i + 1}@{tmp_path}/parts.stk", f"{prev[i, 0]:.3f}", f"{prev[i, 1]:.3f}", "1.000000"] for i in range(n)])])
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp2.xmd"), "-o", str(tmp_path / "out2.xmd"),
+              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4"])
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out2.xmd"))
+    c = {l: i for i, l in enumerate(labels)}
+    moved = np.empty_like(parts)
+    for i in range(n):
+        T = np.array([[1.0, 0, prev[i, 0]], [0, 1, prev[i, 1]], [0, 0, 1]])
+        moved[i] = parts[i] if not prev[i].any() else oracle.apply_geometry2d(parts[i], np.linalg.inv(T), 3, True, True)
+    assert np.abs(moved[1] - np.roll(parts[1], (-2, 1), (0, 1))).max() < 1e-9 * np.abs(parts[1]).max() + 1e-6     # content moves by +shift
+    pos = {ids[i]: i for i in range(nrefs)}
+    lists = [[pos[int(v)] for v in s.split()] for s in nbrs]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    pm = oracle.PM(refs)
+    er, ep, ef, _ = pm.match(moved, off, np.concatenate(lists).astype(np.int32))
+    ex, ey, ec = pm.translate(moved, er[:, 0], ep[:, 0], ef[:, 0], 6.0)
+    assert len(rows) == n
+    for i, row in enumerate(rows):
+        assert int(row[c["ref"]]) == ids[er[i, 0]] and int(row[c["flip"]]) == ef[i, 0]
+        assert abs(float(row[c["anglePsi"]]) - ep[i, 0] * 360.0 / pm.N) < 1e-5
+        assert abs(float(row[c["shiftX"]]) - (ex[i] + prev[i, 0])) < 1e-3 and abs(float(row[c["shiftY"]]) - (ey[i] + prev[i, 1])) < 1e-3
+        assert abs(float(row[c["maxCC"]]) - ec[i]) < 1e-5
+    # a scaled input row is refused loudly (the reference would resample it, APM:1222-1233)
+    xmipp_io.write_xmd(str(tmp_path / "exp3.xmd"), [("noname", ["itemId", "image", "scale"], [[1, f"1@{tmp_path}/parts.stk", "1.050000"]])])
+    r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp3.xmd"), "-o", str(tmp_path / "out3.xmd"),
+              "--ref", str(tmp_path / "ref.stk")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "scale" in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_several_devices_give_the_single_device_answer(bins, tmp_path):
     """--gpus / --devices: one host thread per device slot, contiguous particle ranges, the visiting-order
     parity carried across the ranges, one tree reduction of the volumes. The box has one GPU, so the slots

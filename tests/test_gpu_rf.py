@@ -123,48 +123,32 @@ def test_ctf_arrays(gpu, oracle, kind):
     assert np.abs(m - me).max() < 1e-6
 
 
-def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=None, **kw):
+def _insert_both(xa, ctx, torch, oracle, D, imgs, ang, **kw):
     rf = xa.RecFourier(ctx, D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order", "blob_radius")})
-    if path not in (None, "grid"):
-        # the earlier forms of the gridding kernel only exist in XH_EXPERIMENTS=1 builds of the library
-        try:
-            rf.set_option("require_experiments", 1)
-        except xa.XhError:
-            pytest.skip("library built without -DXH_EXPERIMENTS")
-        if path == "scatter":
-            rf.set_option("insert_variant", 3)   # atomic scatter kernel
-        else:
-            rf.set_option("tile_min_spaces", 1)   # output-stationary kernels even for one projection
-            # LDS-staged patches | tile kernel with block-level staging | wave-independent sub-cubes
-            rf.set_option("tile_variant", {"tiles": 1, "tiles_queue": 0, "cubes": 2}[path])
+    for k, v in kw.get("options", {}).items():
+        rf.set_option(k, v)
     o = oracle.RF(D, **{k: v for k, v in kw.items() if k in ("fast", "blob_order", "blob_radius")})
     ffts = np.stack([o.prepare_image(im) for im in imgs])
     return rf, o, ffts
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes", "grid"])
-def test_insert_single_projection_bit_exact(gpu, oracle, data32, path):
-    """One projection into an empty volume: the same voxels and, summing taps in the same
-    order with the same float arithmetic, the same bits as processVoxelBlob (RFA:627-700)."""
+def test_insert_single_projection_same_voxels_and_taps(gpu, oracle, data32):
+    """One projection into an empty volume: the same voxels, the same taps and the same table entries as
+    processVoxelBlob (RFA:627-700); sums to float rounding."""
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     for i in (0, 3, 7):
-        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[i:i + 1], ang[i:i + 1], path=path)
+        rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[i:i + 1], ang[i:i + 1])
         o.insert(ffts[0], synth.euler_matrix(*ang[i]).T)
         rf.insert(torch.from_numpy(ffts).cuda(), ang[i:i + 1])
         ev, ew = o.temp()
         gv, gw = rf.temp_spaces()
         gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
         assert (ew > 0).sum() > 1000
-        if path == "grid":
-            # same voxels, same taps, same table entries; the products inside a tap are re-associated (records carry
-            # re*ctf*mod*w) and fused: float rounding
-            assert np.array_equal(gw != 0, ew != 0)
-            assert np.abs(gw - ew).max() <= 1e-6 * np.abs(ew).max()
-            assert np.abs(gv - ev).max() <= 1e-6 * np.abs(ev).max()
-            continue
-        assert np.array_equal(gw, ew)
-        assert np.array_equal(gv, ev)
+        # the products inside a tap are re-associated (records carry re*ctf*mod*w) and fused: float rounding
+        assert np.array_equal(gw != 0, ew != 0)
+        assert np.abs(gw - ew).max() <= 1e-6 * np.abs(ew).max()
+        assert np.abs(gv - ev).max() <= 1e-6 * np.abs(ev).max()
 
 
 def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
@@ -181,15 +165,12 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("path", ["scatter", "tiles", "tiles_queue", "cubes", "grid"])
 @pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
-def test_insert_many(gpu, oracle, data32, mode, path):
+def test_insert_many(gpu, oracle, data32, mode):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     fast = mode.startswith("fast")
-    if fast and path not in ("scatter", "grid"):
-        pytest.skip("--fast: the scatter kernel or the product kernel")
-    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, path=path, fast=fast)
+    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, fast=fast)
     n = len(imgs)
     rng = np.random.default_rng(5)
     weights = None
@@ -216,7 +197,7 @@ def test_insert_many(gpu, oracle, data32, mode, path):
     ev, ew = o.temp()
     gv, gw = rf.temp_spaces()
     gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
-    # identical voxel sets; sums differ only by float summation order (atomics)
+    # identical voxel sets; sums differ only by float summation order
     assert ((ew != 0) == (gw != 0)).all()
     assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
     assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
@@ -418,7 +399,6 @@ def test_linearity_of_insertion(gpu, data32):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
     rf = xa.RecFourier(ctx, D)
-    rf.set_option("tile_min_spaces", 1)
     f = rf.prepare_images(torch.from_numpy(imgs).cuda())
     rf.insert(f, ang)
     v1 = rf.temp.clone()

@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B of gridding-kernel builds on ONE box (box-to-box spread is +-4 %): alternates the given libraries, three rounds.
-#   bash tools/ab_grid.sh xmipp3_amd/libA.so xmipp3_amd/libB.so [bench_grid.py args]
-a=$1; b=$2; shift 2
+# A/B of gridding-kernel configurations on ONE box (box-to-box spread is +-4 %): alternates the given option sets, three rounds.
+#   bash tools/ab_grid.sh "unit_z=4" "unit_z=8" "unit_z=8,grid_waves=8" [-- bench_grid.py args]
+sets=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do sets+=("$1"); shift; done
+[ "$1" == "--" ] && shift
 for r in 1 2 3; do
-  for l in $a $b; do
-    echo -n "$l  "; XMIPP_HIP_LIB=$PWD/$l python3 tools/bench_grid.py "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_launch'])"
+  for o in "${sets[@]}"; do
+    args=(); IFS=',' read -ra kv <<< "$o"; for x in "${kv[@]}"; do args+=(--opt "$x"); done
+    echo -n "$o  "; python3 tools/bench_grid.py "${args[@]}" "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_launch'], d.get('identical_bits',''), d.get('voxel_sets_equal',''))"
   done
 done

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Times the gridding kernel alone (HIP events around the launch, xh_rf_kernel_ms) on random orientations.
 
-    python3 tools/bench_grid.py [--box 256] [--n 4096] [--reps 3] [--variant 3] [--no-ctf] [--check]
+    python3 tools/bench_grid.py [--box 256] [--n 4096] [--reps 3] [--no-ctf] [--opt unit_z=4 --opt grid_waves=12] [--check]
 
 Prints one JSON line: ms per launch, projections/s, fraction of the HBM roofline (B_grid = 4 D^2 + 24 n_vox bytes per
-projection).  --check compares the temp spaces of the chosen variant with those of variant 2
-(the bit-exact wave-per-sub-cube kernel, only in builds with -DXH_EXPERIMENTS).
+projection).  --check compares the temp spaces with those of the other unit depth (the same taps
+summed in the same order: identical bits expected).
 """
 import argparse
 import json
@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--no-ctf", action="store_true")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="name=value options passed to xh_rf_set_option")
@@ -41,13 +40,11 @@ def main():
         c = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda") + 0.5
         m = torch.rand((n, rf.sizeY, rf.sizeX), generator=g, device="cuda")
     ang = synth.random_angles(n, np.random.default_rng(4))
-    rf.set_option("tile_min_spaces", 1)
     for o in args.opt:
         k, v = o.split("=")
         rf.set_option(k, float(v))
 
-    def run(variant, reps):
-        rf.set_option("tile_variant", variant)
+    def run(reps):
         rf.reset()
         rf.insert(f, ang, ctf=c, modulator=m)      # warm-up (allocations, first-touch)
         torch.cuda.synchronize()
@@ -59,24 +56,24 @@ def main():
         ms, launches = rf.kernel_ms(reset=True)
         return ms / max(1, launches)
 
-    ms = run(args.variant, args.reps)
+    ms = run(args.reps)
     mv = rf.mv
     nvox = math.pi * (mv / 2) ** 2 / 2 * 2 * 1.9
     bgrid = 4 * D * D + 24 * nvox
-    out = {"variant": args.variant, "box": D, "n": n, "ctf": not args.no_ctf, "ms_per_launch": round(ms, 3),
+    out = {"opts": args.opt, "box": D, "n": n, "ctf": not args.no_ctf, "ms_per_launch": round(ms, 3),
            "projections_per_s": round(n / ms * 1e3), "B_grid": round(bgrid),
            "roofline_frac": round(n * bgrid / (ms * 1e-3) / 8e12, 4)}
     if args.check:
         got = rf.temp.clone()
-        run(2, 1)
+        rf.set_option("unit_z", 4 if any(o.startswith("unit_z=4") for o in args.opt) is False else 8)
+        rf.set_option("grid_waves", 0)
+        run(1)
         ref = rf.temp
         sc = ref.abs().max().item()
-        out["check_vs_variant2_rel"] = (got / args.reps - ref).abs().max().item() / sc
+        out["check_vs_other_unit_depth_rel"] = (got / args.reps - ref).abs().max().item() / sc
         d = (got != 0) != (ref != 0)
         out["voxel_sets_equal"] = not bool(d.any().item())
-        out["voxel_set_diffs"] = int(d.sum().item())
-        if d.any():
-            out["max_abs_at_diffs"] = [got[d].abs().max().item(), ref[d].abs().max().item()]
+        out["identical_bits"] = bool(args.reps == 1 and (got == ref).all().item())
     print(json.dumps(out))
 
 

@@ -102,6 +102,8 @@ SIGNATURES = {
     "xh_pm_debug_prepare": (C.c_int, [vp, vp, i32, i32, vp, vp]),
     "xh_pm_debug_ref": (C.c_int, [vp, i32, vp, vp]),
     "xh_pm_debug_corr_rows": (C.c_int, [vp, vp, i32, i32, vp]),
+    "xh_pm_debug_s6_maps": (C.c_int, [vp, i32, vp]),
+    "xh_pm_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(d)]),
 }
 
 

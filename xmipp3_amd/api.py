@@ -524,3 +524,14 @@ class ProjectionMatcher:
         out = np.empty(2 * self.N, np.float64)
         check(lib().xh_pm_debug_corr_rows(self.h, _ptr(particle), ref, precision, _np_ptr(out)))
         return out
+
+    def debug_s6_maps(self, n):
+        """correlation maps left by the last translate() under set_option("s6_capture", 32 | 64): [n, D, D] float64"""
+        out = np.empty((n, self.D, self.D), np.float64)
+        check(lib().xh_pm_debug_s6_maps(self.h, n, _np_ptr(out)))
+        return out
+
+    def get_option(self, name):
+        v = C.c_double()
+        check(lib().xh_pm_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value

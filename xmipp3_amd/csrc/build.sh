@@ -4,8 +4,6 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result"
-# XH_EXPERIMENTS=1 bash build.sh  adds the earlier gridding kernels (xh_rf_experiments.h) for A/B measurements
-if [ -n "$XH_EXPERIMENTS" ]; then COMMON="$COMMON -DXH_EXPERIMENTS"; fi
 mkdir -p build
 pids=()
 # geometry of the gridding must round like the reference's scalar code: no FMA contraction

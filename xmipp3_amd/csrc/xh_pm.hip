@@ -125,6 +125,9 @@ struct xh_pm {
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
     int s6_debug;                // profiling: xh_pm_translate returns decision margins instead of shifts
+    int s6_capture;              // test hook: 32 / 64 = xh_pm_translate runs only that chain and leaves the correlation maps for xh_pm_debug_s6_maps
+    int s6_captured;             // ... precision and count of the maps left behind
+    int s6_capturedN;
     int s6_fp32;                 // S6: fp32 pass + double-precision repeat of the ambiguous particles (0: everything in double)
     double s6_eps;               // ... its ambiguity margin relative to the map's maximum
     long long s6_flagged;        // particles the last xh_pm_translate repeated in double precision
@@ -1139,7 +1142,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
     for (int it = blockIdx.x * 4 + wv; it < nrows; it += gridDim.x * 4) {
         const int row = rowList ? rowList[it] : it;
         // branch and bound: the row cannot reach (best of its particle - 2 tau), see k_pm_prune_plan
-        if (rowBound && rowBound[row] < thr[row / rowsPerParticle]) {
+        if (rowBound && (rowBound[row] == -INFINITY || rowBound[row] < thr[row / rowsPerParticle])) {
             if (lane == 0) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
             ++skipped;
             continue;
@@ -1401,8 +1404,14 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            // fewer than XH_PRUNE_T rows (or NaN bounds): repeat the first pick, the list stays valid
-            const int pick = sr[0] >= 0 ? sr[0] : (t > 0 ? chosen[0] : r0);
+            // fewer than XH_PRUNE_T rows (or NaN bounds): repeat the first pick, the list stays valid; with nothing picked at all
+            // the first row that belongs to the search (not an off-list reference of a masked one)
+            int pick = sr[0] >= 0 ? sr[0] : (t > 0 ? chosen[0] : -1);
+            if (pick < 0) {
+                pick = r0;
+                for (int r = r0; r < r1; ++r)
+                    if (rowBound[r] != -INFINITY) { pick = r; break; }
+            }
             chosen[t] = pick;
             topRows[p * XH_PRUNE_T + t] = pick;
         }
@@ -1427,7 +1436,9 @@ k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr
     const float t = thr[p];
     int c = 0;
     for (int r = r0 + threadIdx.x; r < r0 + rowsPerParticle; r += 256) {
-        const bool keep = !(rowBound[r] < t);
+        // (an off-list reference of a masked search carries -inf and is dropped whatever the threshold is: a NaN threshold --
+        // a particle without variance -- prunes nothing else)
+        const bool keep = rowBound[r] != -INFINITY && !(rowBound[r] < t);
         if (!keep) { RowRes q; q.best = -3.0e38f; q.idx = 0; q.second = -3.0e38f; q.pad = 0; res[r] = q; }
         c += keep ? 1 : 0;
     }
@@ -1443,7 +1454,7 @@ k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr
     __syncthreads();
     int o = sBase + sc[threadIdx.x] - c;
     for (int r = r0 + threadIdx.x; r < r0 + rowsPerParticle; r += 256)
-        if (!(rowBound[r] < t)) list[o++] = r;
+        if (rowBound[r] != -INFINITY && !(rowBound[r] < t)) list[o++] = r;
 }
 
 // thr[p] = (best normalised value among the particle's listed rows) - 2 tau; NaN => nothing is pruned.
@@ -2005,6 +2016,9 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
             double ox = 0, oy = 0;
             if (SC != 0) { ox = XM / SC; oy = YM / SC; }
             if (!(maxShift > 0)) ox = oy = 0.;
+            // the rejection of shifts beyond max_shift (APM:841-842) is a discrete decision too: a coarse-pass shift within
+            // 1e-3 px of the limit is repeated in double precision
+            if (flag && maxShift > 0 && fabs(sqrt(ox * ox + oy * oy) - (double)maxShift) < 1e-3) flag[p] = 1;
             if (ox * ox + oy * oy > maxShift * maxShift) ox = oy = 0.;
             sh[0] = ox; sh[1] = oy;
         }
@@ -2960,6 +2974,9 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma64 = 1;
     pm->s6_pair = 1;
     pm->s6_debug = 0;
+    pm->s6_capture = 0;
+    pm->s6_captured = 0;
+    pm->s6_capturedN = 0;
     pm->s6_fp32 = 1;
     pm->s6_eps = 2e-5;
     pm->s6_flagged = 0;
@@ -3298,6 +3315,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
     else if (!strcmp(name, "s6_pair")) pm->s6_pair = (int)value;
     else if (!strcmp(name, "s6_debug")) pm->s6_debug = (int)value;
+    else if (!strcmp(name, "s6_capture")) pm->s6_capture = (int)value;
     else if (!strcmp(name, "s6_fp32")) pm->s6_fp32 = (int)value;
     else if (!strcmp(name, "s6_eps")) pm->s6_eps = value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
@@ -3874,8 +3892,9 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
         for (int p0 = 0; p0 < n; p0 += chunk) {
             const int m = std::min(chunk, n - p0);
             const float *parts = d_particles + (size_t)p0 * per;
-            if (!pm->s6_fp32 || pm->s6_debug) {
+            if (!pm->s6_fp32 || pm->s6_debug || pm->s6_capture == 64) {
                 XH_TRY(chain64(parts, d_refno + p0, d_psi + p0, d_flip + p0, m, d_sx + p0, d_sy + p0, d_cc + p0));
+                if (pm->s6_capture == 64) { pm->s6_captured = 64; pm->s6_capturedN = m; }
                 continue;
             }
             XH_TRY(xh_buf_reserve(ctx, pm->d_s6Flag, (size_t)chunk));
@@ -3883,6 +3902,7 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             unsigned char *flag = (unsigned char *)pm->d_s6Flag.p;
             int *list = (int *)pm->d_s6List.p, *count = list + chunk;
             XH_TRY(chain32(parts, d_refno + p0, d_psi + p0, d_flip + p0, m, d_sx + p0, d_sy + p0, d_cc + p0, flag));
+            if (pm->s6_capture == 32) { pm->s6_captured = 32; pm->s6_capturedN = m; continue; }      // the coarse pass alone, no repeats
             XH_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(k_pm_s6_list, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const unsigned char *)flag, m, list, count);
             XH_LAUNCH_CHECK();
@@ -3945,6 +3965,32 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
 }
 
 // ------------------------------------------------------------------------------ test hooks
+// The correlation maps (correlation_matrix, filters.cpp:1636, before statisticsAdjust) that the last chunk of an xh_pm_translate call
+// under set_option("s6_capture", 32 | 64) left behind: [n][D][D] doubles on the host. 64, 128 and 256 px only (the fp32 chain).
+int xh_pm_debug_s6_maps(xh_pm *pm, int32_t n, double *h_maps)
+{
+    XH_CHECK(pm && h_maps && n > 0, XH_ERR_ARG, "xh_pm_debug_s6_maps: bad argument");
+    XH_CHECK(pm->s6_captured && n <= pm->s6_capturedN, XH_ERR_STATE, "xh_pm_debug_s6_maps: no captured maps (set_option s6_capture, then xh_pm_translate)");
+    XH_HIP(hipSetDevice(pm->ctx->device));
+    const size_t tot = (size_t)n * pm->L.D * pm->L.D;
+    XH_HIP(hipStreamSynchronize(pm->ctx->stream));
+    if (pm->s6_captured == 64) { XH_HIP(hipMemcpy(h_maps, pm->d_t3.p, tot * sizeof(double), hipMemcpyDeviceToHost)); return XH_OK; }
+    std::vector<float> tmp(tot);
+    XH_HIP(hipMemcpy(tmp.data(), pm->d_t3.p, tot * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tot; ++i) h_maps[i] = tmp[i];
+    return XH_OK;
+}
+
+// current value of a tuning knob (the margins the exactness argument rests on: "tau_rel", "s6_eps")
+int xh_pm_get_option(const xh_pm *pm, const char *name, double *value)
+{
+    XH_CHECK(pm && name && value, XH_ERR_ARG, "xh_pm_get_option: null argument");
+    if (!strcmp(name, "tau_rel")) *value = pm->tau_rel;
+    else if (!strcmp(name, "s6_eps")) *value = pm->s6_eps;
+    else { xh_set_error("xh_pm_get_option: unknown option %s", name); return XH_ERR_ARG; }
+    return XH_OK;
+}
+
 int xh_pm_debug_prepare(xh_pm *pm, const float *d_particles, int32_t n, int32_t precision, double *h_coefs, double *h_sigma)
 {
     XH_CHECK(pm && d_particles && h_coefs && h_sigma && n > 0, XH_ERR_ARG, "bad argument");

@@ -233,13 +233,12 @@ struct xh_rf {
     XhBuf own_temp;   // 3*(mv+1)^3 floats when library-owned
     float *d_temp;    // active temp buffer
     XhBuf d_rows;     // intermediate of the 2-D FFT
-    XhBuf d_spaces;
     XhBuf d_ctfp;
     XhBuf d_fin;      // finaliser scratch
     XhBuf d_shiftCoef, d_shiftXY;   // xh_rf_shift_images scratch
-    XhBuf d_tiles, d_tileCounter;   // tile list per z-layer class and class offsets
-    XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec, d_recs, d_dense, d_wimg;
-    XhBuf d_gtiles, d_grecs, d_gweights, d_planes, d_spectra;   // d_planes, d_spectra: scratch of xh_rf_insert_images   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
+    XhBuf d_tileCounter;            // ints [32,41): class offsets of the tile list, [128,384): the stream counters
+    XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec;
+    XhBuf d_gtiles[2], d_grecs, d_gweights, d_planes, d_spectra;   // d_planes, d_spectra: scratch of xh_rf_insert_images   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
     // pinned staging of the small host arrays (records, shifts, CTF parameters): uploads never wait for the stream
     unsigned char *h_stage = nullptr;
     size_t stageCap = 0, stageUsed = 0;
@@ -248,9 +247,7 @@ struct xh_rf {
     XhBuf d_sym, d_angles;          // device-side inputs of k_rf_spaces
     bool packCtf = false;           // xh_rf_insert_images: the pack kernel evaluates the CTF of d_ctfp itself
     const float *packImgs = nullptr; // ... and the records come straight from the images (k_rf_colsA + k_rf_rowsB<PACK>)
-    int use_supercull;    // two-level culling of the tile kernel (k_rf_supercull)
     int tile_max_spaces;
-    int tile_variant;     // 2: wave-independent sub-cubes (product); 1: LDS-staged patches (blob radius < 2); 0: tile kernel
     int fft_variant;      // 0: register-blocked 2-D FFT of the projections where P allows; 1: radix-2 LDS kernels
     // HIP-event bracket of every gridding-kernel launch (bench.py's roofline), drained lazily
     std::vector<hipEvent_t> evPool;
@@ -258,11 +255,9 @@ struct xh_rf {
     double kernelMs;
     int64_t kernelLaunches;
     double meanFactor2;   // cached mean of sinc^2 over the output window (< 0: not computed yet)
-    int ntiles;
     bool cropped;
-    int insert_variant;   // 0 = product path; 1/2 = ablation experiments on the scatter kernel; 3 = force scatter
-    int tile_min_spaces;
-    int tile_dbg;         // ablation switch of the tile kernel (profiling only)
+    int unit_z = 8;       // depth of a gridding unit (8 x 8 x unit_z voxels per wave): 4 or 8
+    int grid_waves = 0;   // waves per CU of the gridding kernel; 0: the default of the unit depth
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
     int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)
 };
@@ -925,9 +920,6 @@ __device__ __forceinline__ bool d_hit(float y, float z, float a1, float a2, floa
 }
 
 #include "xh_rf_grid.h"
-#ifdef XH_EXPERIMENTS
-#include "xh_rf_experiments.h"
-#endif
 
 // ---- finaliser ---------------------------------------------------------------------------
 // mirrorAndCrop RFA:861-887 in gather form. in: (mv+1)^3, out: (mv+1)^2 (half+1)
@@ -1193,12 +1185,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     rf->iDeltaFourier = 1 / deltaFourier;
     rf->d_temp = nullptr;
     rf->cropped = false;
-    rf->insert_variant = 0;
-    rf->tile_min_spaces = 24;
-    rf->tile_dbg = 0;
     rf->tile_max_spaces = 8192;
-    rf->tile_variant = 3;   // 3: k_rf_grid (product); XH_EXPERIMENTS builds: 2 wave-independent sub-cubes, 0 tile kernel, 1 LDS patches
-    rf->use_supercull = 1;
     rf->fft_variant = 0;
     rf->evUsed = 0;
     rf->kernelMs = 0;
@@ -1209,59 +1196,25 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
     if (r == XH_OK) r = make_twiddles(ctx, rf->P, rf->d_twP32, rf->d_twP64);
     if (r == XH_OK) r = xh_plan_create<float>(ctx, rf->P, rf->planP32);
     if (r == XH_OK) r = xh_plan_create<double>(ctx, rf->P, rf->planP64);
-    rf->ntiles = 0;
-    if (r == XH_OK) {
-        // tiles that a projection can reach (sphere of radius sizeX + blob), heaviest (central) first
-        const int tpd = (rf->mv + 1 + XH_TSZ - 1) / XH_TSZ;
-        const double R = rf->sizeX + p->blob_radius + 6.1 + 1.0;
-        // Raster order (z, y, x) cut into 8 contiguous z-slabs of equal estimated work, one per XCD
-        // (block b runs on XCD b%8): a projection's patch is then pulled into one or two L2s instead
-        // of all eight. A tile at distance rho from the centre is crossed by a fraction ~1/rho of all
-        // central planes, so that is its weight.
-        std::vector<unsigned> packed;
-        std::vector<double> wsum;
-        double acc = 0;
-        for (int tz = 0; tz < tpd; ++tz)
-            for (int ty = 0; ty < tpd; ++ty)
-                for (int tx = 0; tx < tpd; ++tx) {
-                    const double cx = tx * XH_TSZ + 3.5 - rf->mv / 2, cy = ty * XH_TSZ + 3.5 - rf->mv / 2, cz = tz * XH_TSZ + 3.5 - rf->mv / 2;
-                    const double d = std::sqrt(cx * cx + cy * cy + cz * cz);
-                    if (d <= R) { packed.push_back((unsigned)(tx | (ty << 8) | (tz << 16))); acc += 1.0 / std::max(d, 6.0); wsum.push_back(acc); }
-                }
-        int classOff[9];
-        classOff[0] = 0;
-        for (int c = 1; c < 8; ++c) {
-            const double target = acc * c / 8.0;
-            classOff[c] = (int)(std::lower_bound(wsum.begin(), wsum.end(), target) - wsum.begin());
-        }
-        classOff[8] = (int)packed.size();
-        {
-            // Morton order inside every class: the waves of the chip work on a narrow band of consecutive tiles, and a
-            // compact band shares more of the projections' patches in the L2 than a row of the raster (38.8 -> 36.9 ms)
-            auto spread = [](unsigned v) { unsigned long long x = v & 0x3ff; x = (x | x << 16) & 0x30000ffULL; x = (x | x << 8) & 0x300f00fULL; x = (x | x << 4) & 0x30c30c3ULL; x = (x | x << 2) & 0x9249249ULL; return x; };
-            auto key = [&](unsigned t) { return spread(t & 0xff) | spread((t >> 8) & 0xff) << 1 | spread((t >> 16) & 0xff) << 2; };
-            for (int c = 0; c < 8; ++c)
-                std::sort(packed.begin() + classOff[c], packed.begin() + classOff[c + 1], [&](unsigned u, unsigned v) { return key(u) < key(v); });
-        }
-        rf->ntiles = (int)packed.size();
-        r = xh_buf_alloc(ctx, rf->d_tiles, sizeof(unsigned) * packed.size());
-        if (r == XH_OK) r = (hipMemcpy(rf->d_tiles.p, packed.data(), rf->d_tiles.bytes, hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
-        // d_tileCounter: ints [0,8) work counters, [16,25) class offsets
-        // (+ [128,384): the stream counters of the wave-independent kernel)
-        if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 512);
-        if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 16, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
-    }
-    if (r == XH_OK) {
-        // k_rf_grid: 16 x 16 x 8 tiles (eight 8 x 8 x 4 units), same ordering rules; class offsets at d_tileCounter + 32
-        const int tpx = (rf->mv + 1 + 15) / 16, tpz = (rf->mv + 1 + 7) / 8;
-        const double R = rf->sizeX + p->blob_radius + 11.2 + 1.0;
+    if (r == XH_OK) r = xh_buf_alloc(ctx, rf->d_tileCounter, sizeof(int) * 512);
+    // k_rf_grid: tiles of 2 x 2 x 2 units (16 x 16 x 8 voxels for units 4 deep, 16^3 for units 8 deep) that a projection can
+    // reach (sphere of radius sizeX + blob), in raster order (z, y, x) cut into 8 contiguous z-slabs of equal estimated work, one
+    // per XCD (block b runs on XCD b % 8: a projection's patch is pulled into one or two L2s instead of all eight). A tile at
+    // distance rho from the centre is crossed by a fraction ~1/rho of all central planes: that is its weight. Inside a class
+    // Morton order (the waves of the chip work on a narrow band of consecutive tiles, and a compact band shares more of the
+    // projections' patches in the L2 than a row of the raster). Class offsets at d_tileCounter + 32 (units 4 deep) and + 48 (8).
+    for (int v = 0; v < 2 && r == XH_OK; ++v) {
+        const int tzs = v ? 16 : 8;                            // voxels per tile in z
+        const int tpx = (rf->mv + 1 + 15) / 16, tpz = (rf->mv + 1 + tzs - 1) / tzs;
+        const double hz = 0.5 * tzs - 0.5;
+        const double R = rf->sizeX + p->blob_radius + std::sqrt(2 * 7.5 * 7.5 + hz * hz) + 1.0;
         std::vector<unsigned> packed;
         std::vector<double> wsum;
         double acc = 0;
         for (int tz = 0; tz < tpz; ++tz)
             for (int ty = 0; ty < tpx; ++ty)
                 for (int tx = 0; tx < tpx; ++tx) {
-                    const double cx = tx * 16 + 7.5 - rf->mv / 2, cy = ty * 16 + 7.5 - rf->mv / 2, cz = tz * 8 + 3.5 - rf->mv / 2;
+                    const double cx = tx * 16 + 7.5 - rf->mv / 2, cy = ty * 16 + 7.5 - rf->mv / 2, cz = tz * tzs + hz - rf->mv / 2;
                     const double d = std::sqrt(cx * cx + cy * cy + cz * cz);
                     if (d <= R) { packed.push_back((unsigned)(tx | (ty << 10) | (tz << 20))); acc += 1.0 / std::max(d, 8.0); wsum.push_back(acc); }
                 }
@@ -1271,13 +1224,16 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
             classOff[c] = (int)(std::lower_bound(wsum.begin(), wsum.end(), acc * c / 8.0) - wsum.begin());
         classOff[8] = (int)packed.size();
         auto spread = [](unsigned v) { unsigned long long x = v & 0x3ff; x = (x | x << 16) & 0x30000ffULL; x = (x | x << 8) & 0x300f00fULL; x = (x | x << 4) & 0x30c30c3ULL; x = (x | x << 2) & 0x9249249ULL; return x; };
-        // Morton order on (x, y, z / 2): tiles are half as tall as wide
-        auto key = [&](unsigned t) { return (spread(t & 0x3ff) | spread((t >> 10) & 0x3ff) << 1 | spread((t >> 21) & 0x1ff) << 2) << 1 | ((t >> 20) & 1); };
+        // Morton order; tiles of 4-deep units are half as tall as wide: on (x, y, z / 2) with the low bit of z last
+        auto key = [&](unsigned t) {
+            if (tzs == 16) return spread(t & 0x3ff) | spread((t >> 10) & 0x3ff) << 1 | spread((t >> 20) & 0x3ff) << 2;
+            return (spread(t & 0x3ff) | spread((t >> 10) & 0x3ff) << 1 | spread((t >> 21) & 0x1ff) << 2) << 1 | ((t >> 20) & 1);
+        };
         for (int c = 0; c < 8; ++c)
-            std::sort(packed.begin() + classOff[c], packed.begin() + classOff[c + 1], [&](unsigned u, unsigned v) { return key(u) < key(v); });
-        r = xh_buf_alloc(ctx, rf->d_gtiles, sizeof(unsigned) * std::max<size_t>(1, packed.size()));
-        if (r == XH_OK) r = (hipMemcpy(rf->d_gtiles.p, packed.data(), sizeof(unsigned) * packed.size(), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
-        if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 32, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+            std::sort(packed.begin() + classOff[c], packed.begin() + classOff[c + 1], [&](unsigned u, unsigned w) { return key(u) < key(w); });
+        r = xh_buf_alloc(ctx, rf->d_gtiles[v], sizeof(unsigned) * std::max<size_t>(1, packed.size()));
+        if (r == XH_OK) r = (hipMemcpy(rf->d_gtiles[v].p, packed.data(), sizeof(unsigned) * packed.size(), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
+        if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 32 + 16 * v, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
     }
     if (r != XH_OK) { xh_rf_destroy(rf); return r; }
     *out = rf;
@@ -1291,15 +1247,15 @@ int xh_rf_destroy(xh_rf *rf)
     (void)hipStreamSynchronize(rf->ctx->stream);
     xh_buf_free(rf->d_blob); xh_buf_free(rf->d_twP32); xh_buf_free(rf->d_twP64);
     xh_plan_free(rf->planP32); xh_plan_free(rf->planP64);
-    xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows); xh_buf_free(rf->d_spaces);
+    xh_buf_free(rf->own_temp); xh_buf_free(rf->d_rows);
     xh_buf_free(rf->d_ctfp); xh_buf_free(rf->d_fin);
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
-    xh_buf_free(rf->d_tiles); xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
-    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec); xh_buf_free(rf->d_recs); xh_buf_free(rf->d_dense); xh_buf_free(rf->d_wimg);
+    xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
+    xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec);
     xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles);
     if (rf->h_stage) (void)hipHostFree(rf->h_stage);
     if (rf->stageEv) (void)hipEventDestroy(rf->stageEv);
-    xh_buf_free(rf->d_gtiles); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
+    xh_buf_free(rf->d_gtiles[0]); xh_buf_free(rf->d_gtiles[1]); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
     return XH_OK;
@@ -1318,21 +1274,15 @@ int xh_rf_kernel_ms(xh_rf *rf, double *h_ms, int64_t *h_launches, int32_t reset)
 int xh_rf_set_option(xh_rf *rf, const char *name, double value)
 {
     XH_CHECK(rf && name, XH_ERR_ARG, "null argument");
-    if (!strcmp(name, "insert_variant")) rf->insert_variant = (int)value;
-    else if (!strcmp(name, "tile_min_spaces")) rf->tile_min_spaces = (int)value;
-    else if (!strcmp(name, "tile_dbg")) rf->tile_dbg = (int)value;
+    if (!strcmp(name, "unit_z")) {
+        XH_CHECK((int)value == 4 || (int)value == 8, XH_ERR_ARG, "xh_rf_set_option: unit_z is 4 or 8");
+        rf->unit_z = (int)value;
+    }
+    else if (!strcmp(name, "grid_waves")) rf->grid_waves = (int)value;
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
-    else if (!strcmp(name, "tile_variant")) rf->tile_variant = (int)value;
-    else if (!strcmp(name, "supercull")) rf->use_supercull = (int)value;
     else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
-    else if (!strcmp(name, "require_experiments")) {
-#ifndef XH_EXPERIMENTS
-        xh_set_error("xh_rf_set_option: this library was built without -DXH_EXPERIMENTS (the earlier gridding kernels)");
-        return XH_ERR_UNSUPPORTED;
-#endif
-    }
     else { xh_set_error("xh_rf_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1681,7 +1631,7 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
         } else
         hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((SXp * SYp + XG_PACK_CELLS - 1) / XG_PACK_CELLS), m), dim3(256), 0, ctx->stream,
                            (const xh_cf *)d_fft + o, d_ctf ? d_ctf + o : nullptr, d_mod ? d_mod + o : nullptr, d_weights ? d_weights + i0 : nullptr,
-                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY, rf->tile_dbg);
+                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
         XH_LAUNCH_CHECK();
     }
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds
@@ -1714,15 +1664,31 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
                            (int *)rf->d_superList.p, (int *)rf->d_superCount.p, superN, superX);
         XH_LAUNCH_CHECK();
         if (ev0 && ev1) XH_HIP(hipEventRecord(ev0, ctx->stream));    // the events bracket the gridding kernel alone
-#define XH_GRID(W_, F_)                                                                                                          \
-    hipLaunchKernelGGL((k_rf_grid<W_, F_>), dim3(8 * std::max(1, ctx->num_cus / 8)), dim3(64 * XG_NW), 0, ctx->stream,           \
+        // unit depth and waves per CU: 8-deep units halve the visits (and the patch bytes they fetch) for the price of a larger
+        // accumulator block per wave, which the LDS holds for nine waves instead of twelve
+        const int uz = rf->unit_z, tl = uz == 8 ? 1 : 0;
+        const int nw = rf->grid_waves ? rf->grid_waves : (uz == 8 ? (br < 2.0 || fast ? 9 : 8) : 12);      // (6 x 6 footprints: larger patches)
+#ifndef XG_ABL
+#define XG_ABL 0
+#endif
+#define XH_GRID(W_, F_, Z_, N_)                                                                                                  \
+    hipLaunchKernelGGL((k_rf_grid<W_, F_, Z_, N_, XG_ABL>), dim3(8 * std::max(1, ctx->num_cus / 8)), dim3(64 * N_), 0, ctx->stream, \
                        (const XgRec *)rf->d_grecs.p + s0, (const float4 *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, \
-                       rf->mv, rf->iDeltaSqrt, br, (const unsigned *)rf->d_gtiles.p, (const int *)rf->d_tileCounter.p + 32,        \
+                       rf->mv, rf->iDeltaSqrt, br, (const unsigned *)rf->d_gtiles[tl].p, (const int *)rf->d_tileCounter.p + 32 + 16 * tl, \
                        (int *)rf->d_tileCounter.p + 128, (const int *)rf->d_superList.p, (const int *)rf->d_superCount.p,         \
-                       superDim, m, (const float4 *)superN, (const float4 *)superX, reach, rf->tile_dbg)
-        if (fast) XH_GRID(4, true);
-        else if (br < 2.0) XH_GRID(4, false);
-        else XH_GRID(6, false);
+                       superDim, m, (const float4 *)superN, (const float4 *)superX, reach)
+#define XH_GRID_WF(W_, F_)                                                                                                       \
+    do {                                                                                                                         \
+        if (uz == 8 && nw == 9 && W_ == 4) XH_GRID(4, F_, 8, 9);                                                                 \
+        else if (uz == 8 && nw == 8) XH_GRID(W_, F_, 8, 8);                                                                      \
+        else if (uz == 4 && nw == 12) XH_GRID(W_, F_, 4, 12);                                                                    \
+        else if (uz == 4 && nw == 16 && W_ == 4) XH_GRID(4, F_, 4, 16);                                                          \
+        else { xh_set_error("xh_rf_insert: no gridding kernel for unit_z %d with %d waves", uz, nw); return XH_ERR_UNSUPPORTED; } \
+    } while (0)
+        if (fast) XH_GRID_WF(4, true);
+        else if (br < 2.0) XH_GRID_WF(4, false);
+        else XH_GRID_WF(6, false);
+#undef XH_GRID_WF
 #undef XH_GRID
         XH_LAUNCH_CHECK();
         if (ev0 && ev1) XH_HIP(hipEventRecord(ev1, ctx->stream));
@@ -1730,186 +1696,6 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     return XH_OK;
 }
 
-#ifdef XH_EXPERIMENTS
-// the launch code of the earlier gridding kernels (xh_rf_experiments.h)
-static int experiments_insert(xh_rf *rf, std::vector<XhSpace> &spaces, const float *d_fft, const float *d_ctf, const float *d_mod, int n)
-{
-    xh_ctx *ctx = rf->ctx;
-    const int ns = (int)spaces.size();
-    XH_TRY(xh_buf_reserve(ctx, rf->d_spaces, sizeof(XhSpace) * ns));
-    XH_HIP(hipMemcpyAsync(rf->d_spaces.p, spaces.data(), sizeof(XhSpace) * ns, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));
-    const size_t d = rf->mv + 1;
-    float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
-    const bool hasCtf = d_ctf != nullptr, fast = rf->p.use_fast != 0;
-    // product path: output-stationary tiles (no atomics). The scatter kernel remains for --fast
-    // (one voxel per row, RFA:595-625) and for launches too small to amortise a volume pass.
-    const bool useTiles = !fast && rf->insert_variant == 0 && ns >= rf->tile_min_spaces && rf->mv / XH_TSZ < 255;
-    if (useTiles) {
-        const int grid = 8 * std::max(1, (ctx->num_cus * 2) / 8);
-        const bool smallBlob = rf->p.blob_radius < 2.0;
-        // cull tables (plane normal / image x axis per space), SoA for coalesced block-level culling
-        std::vector<float> cull((size_t)ns * 8);
-        for (int i = 0; i < ns; ++i) {
-            float *n = &cull[(size_t)i * 4], *x = &cull[(size_t)(ns + i) * 4];
-            // .w: the 1-norm, i.e. the support function of a unit cube: |v . delta| <= h * |v|_1 for |delta_i| <= h
-            n[0] = spaces[i].tInv[6]; n[1] = spaces[i].tInv[7]; n[2] = spaces[i].tInv[8]; n[3] = std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2]);
-            x[0] = spaces[i].tInv[0]; x[1] = spaces[i].tInv[1]; x[2] = spaces[i].tInv[2]; x[3] = std::fabs(x[0]) + std::fabs(x[1]) + std::fabs(x[2]);
-        }
-        XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float) * cull.size()));
-        XH_HIP(hipMemcpyAsync(rf->d_cull.p, cull.data(), sizeof(float) * cull.size(), hipMemcpyHostToDevice, ctx->stream));
-        // compact records of the traverse spaces for the wave-independent kernel (scalar loads)
-        std::vector<XhRec> recs(ns);
-        for (int i = 0; i < ns; ++i) {
-            const XhSpace &S = spaces[i];
-            int im = S.img, yy = S.minY | (S.maxY << 16), zz = S.minZ | (S.maxZ << 16);
-            float fi, fy, fz;
-            memcpy(&fi, &im, 4); memcpy(&fy, &yy, 4); memcpy(&fz, &zz, 4);
-            recs[i].r0 = make_float4(S.tInv[0], S.tInv[1], S.tInv[2], fi);
-            recs[i].r1 = make_float4(S.tInv[3], S.tInv[4], S.tInv[5], fy);
-            recs[i].r2 = make_float4(S.tInv[6], S.tInv[7], S.tInv[8], fz);
-        }
-        XH_TRY(xh_buf_reserve(ctx, rf->d_recs, sizeof(XhRec) * (size_t)ns));
-        XH_HIP(hipMemcpyAsync(rf->d_recs.p, recs.data(), sizeof(XhRec) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-        std::vector<XhDense> dense(ns);
-        std::vector<float2> wimg(ns);
-        for (int i = 0; i < ns; ++i) {
-            const XhSpace &S = spaces[i];
-            dense[i].a = make_float4(S.u[1], S.u[2], S.v[1], S.v[2]);
-            dense[i].b = make_float4(S.p0[1], S.p0[2], S.p4[1], S.p4[2]);
-            int im = S.img;
-            float fi;
-            memcpy(&fi, &im, 4);
-            wimg[i] = make_float2(S.weight, fi);
-        }
-        XH_TRY(xh_buf_reserve(ctx, rf->d_dense, sizeof(XhDense) * (size_t)ns));
-        XH_TRY(xh_buf_reserve(ctx, rf->d_wimg, sizeof(float2) * (size_t)ns));
-        XH_HIP(hipMemcpyAsync(rf->d_dense.p, dense.data(), sizeof(XhDense) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-        XH_HIP(hipMemcpyAsync(rf->d_wimg.p, wimg.data(), sizeof(float2) * (size_t)ns, hipMemcpyHostToDevice, ctx->stream));
-        XH_HIP(hipStreamSynchronize(ctx->stream));
-        {
-            // packed + padded projection records (re, im[, ctf, mod]) for contiguous 4-pixel row fetches
-            const size_t cells = (size_t)n * (rf->sizeX + 2 * XH_PAD) * (rf->sizeY + 2 * XH_PAD);
-            XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * (hasCtf ? sizeof(float4) : sizeof(float2))));
-            if (hasCtf)
-                hipLaunchKernelGGL((k_rf_pack<true>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
-                                   rf->d_pack.p, n, rf->sizeX, rf->sizeY);
-            else
-                hipLaunchKernelGGL((k_rf_pack<false>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft, d_ctf, d_mod,
-                                   rf->d_pack.p, n, rf->sizeX, rf->sizeY);
-            XH_LAUNCH_CHECK();
-        }
-        // the super-tile lists are sized for the worst case (every projection of the launch in every list): bound the
-        // launch so that they stay within 8 GB
-        const int sdim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + (1 << XH_SUPERSHIFT) - 1) >> XH_SUPERSHIFT;
-        const size_t listBytesPerSpace = (size_t)sdim * sdim * sdim * 36;
-        const int maxByLists = (int)std::max<size_t>(256, ((size_t)8 << 30) / listBytesPerSpace);
-        const int maxsp = std::min(std::max(64, rf->tile_max_spaces), rf->use_supercull ? maxByLists : (1 << 30));
-        for (int s0 = 0; s0 < ns; s0 += maxsp) {
-            const int m = std::min(maxsp, ns - s0);
-            XH_HIP(hipMemsetAsync(rf->d_tileCounter.p, 0, sizeof(int) * 8, ctx->stream));
-            XH_HIP(hipMemsetAsync((int *)rf->d_tileCounter.p + 128, 0, sizeof(int) * 256, ctx->stream));
-            if (rf->evUsed >= 256) drain_events(rf);
-            hipEvent_t ev0 = next_event(rf), ev1 = next_event(rf);
-            // super-tile lists of this launch
-            const int superDim = ((rf->mv + 1 + XH_TSZ - 1) / XH_TSZ + (1 << XH_SUPERSHIFT) - 1) >> XH_SUPERSHIFT;
-            const int nsuper = superDim * superDim * superDim;
-            const int *superList = nullptr, *superCount = nullptr;
-            float4 *superN = nullptr, *superX = nullptr;
-            if (rf->use_supercull && m >= 32) {
-                XH_TRY(xh_buf_reserve(ctx, rf->d_superList, sizeof(int) * (size_t)nsuper * m));
-                XH_TRY(xh_buf_reserve(ctx, rf->d_superCount, sizeof(int) * (size_t)nsuper));
-                const bool inlineVecs = rf->tile_variant >= 2;
-                if (inlineVecs) XH_TRY(xh_buf_reserve(ctx, rf->d_superVec, 2 * sizeof(float4) * (size_t)nsuper * m));
-                superN = inlineVecs ? (float4 *)rf->d_superVec.p : nullptr;
-                superX = inlineVecs ? superN + (size_t)nsuper * m : nullptr;
-                hipLaunchKernelGGL(k_rf_supercull, dim3(nsuper), dim3(256), 0, ctx->stream, (const float4 *)rf->d_cull.p + s0,
-                                   (const float4 *)rf->d_cull.p + ns + s0, m, rf->mv, (float)rf->p.blob_radius, superDim, m,
-                                   (int *)rf->d_superList.p, (int *)rf->d_superCount.p, superN, superX);
-                XH_LAUNCH_CHECK();
-                superList = (const int *)rf->d_superList.p;
-                superCount = (const int *)rf->d_superCount.p;
-            }
-            if (ev0 && ev1) XH_HIP(hipEventRecord(ev0, ctx->stream));    // the events bracket the gridding kernel alone
-#define XH_TILES(CTF_, SB_)                                                                                         \
-    hipLaunchKernelGGL((k_rf_insert_tiles<CTF_, SB_>), dim3(grid), dim3(512), 0, ctx->stream,                        \
-                       (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
-                       (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,                        \
-                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,          \
-                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p, rf->tile_dbg, \
-                       superList, superCount, superDim, m)
-            if (smallBlob && rf->tile_variant == 1) {
-                if (hasCtf)
-                    hipLaunchKernelGGL((k_rf_insert_tiles_lds<true>), dim3(grid), dim3(512), 0, ctx->stream, (const XhSpace *)rf->d_spaces.p + s0,
-                                       (const float4 *)rf->d_cull.p + s0, (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,
-                                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
-                                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
-                else
-                    hipLaunchKernelGGL((k_rf_insert_tiles_lds<false>), dim3(grid), dim3(512), 0, ctx->stream, (const XhSpace *)rf->d_spaces.p + s0,
-                                       (const float4 *)rf->d_cull.p + s0, (const float4 *)rf->d_cull.p + ns + s0, m, (const void *)rf->d_pack.p,
-                                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius,
-                                       (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16, (int *)rf->d_tileCounter.p);
-            }
-            else if (rf->tile_variant == 2) {
-                // float thresholds equivalent to the double reach tests of the sparse pass (see the kernel): walk the
-                // floats around the boundary with the very expressions the tests use
-                const double br = rf->p.blob_radius;
-                auto lowest = [&](auto ok, float guess) {      // smallest float f with ok(f); ok is monotone (false.. true)
-                    float f = guess;
-                    while (ok(f)) f = std::nextafterf(f, -INFINITY);
-                    while (!ok(f)) f = std::nextafterf(f, INFINITY);
-                    return f;
-                };
-                auto highest = [&](auto ok, float guess) {     // largest float f with ok(f); ok is monotone (true.. false)
-                    float f = guess;
-                    while (ok(f)) f = std::nextafterf(f, INFINITY);
-                    while (!ok(f)) f = std::nextafterf(f, -INFINITY);
-                    return f;
-                };
-                const int sX = rf->sizeX, sY = rf->sizeY;
-                const float4 reach = make_float4(lowest([&](float f) { return (double)f + br >= 0.0; }, (float)-br),
-                                                 highest([&](float f) { return (double)f - br <= (double)(sX - 1); }, (float)(sX - 1 + br)),
-                                                 lowest([&](float f) { return (double)f + br >= 0.0; }, (float)-br),
-                                                 highest([&](float f) { return (double)f - br <= (double)(sY - 1); }, (float)(sY - 1 + br)));
-#define XH_CUBES(CTF_, SB_)                                                                                         \
-    hipLaunchKernelGGL((k_rf_insert_cubes<CTF_, SB_>), dim3(grid), dim3(64 * XH_CUBE_NW), 0, ctx->stream,                        \
-                       (const XhSpace *)rf->d_spaces.p + s0, (const float4 *)rf->d_cull.p + s0,                      \
-                       (const float4 *)rf->d_cull.p + ns + s0, (const XhRec *)rf->d_recs.p + s0, m,                   \
-                       (const void *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, \
-                       rf->p.blob_radius, (const unsigned *)rf->d_tiles.p, (const int *)rf->d_tileCounter.p + 16,      \
-                       (int *)rf->d_tileCounter.p + 128, rf->tile_dbg, superList, superCount, superDim, m,            \
-                       (const float4 *)superN, (const float4 *)superX, (const XhDense *)rf->d_dense.p + s0,            \
-                       (const float2 *)rf->d_wimg.p + s0, reach)
-                if (hasCtf && smallBlob) XH_CUBES(true, true);
-                else if (hasCtf) XH_CUBES(true, false);
-                else if (smallBlob) XH_CUBES(false, true);
-                else XH_CUBES(false, false);
-#undef XH_CUBES
-            }
-            else if (hasCtf && smallBlob) XH_TILES(true, true);
-            else if (hasCtf) XH_TILES(true, false);
-            else if (smallBlob) XH_TILES(false, true);
-            else XH_TILES(false, false);
-#undef XH_TILES
-            XH_LAUNCH_CHECK();
-            if (ev0 && ev1) XH_HIP(hipEventRecord(ev1, ctx->stream));
-        }
-        return XH_OK;
-    }
-    const int grid = 8 * std::max(1, (ctx->num_cus * 4) / 8);
-#define XH_INSERT(CTF_, FAST_)                                                                              \
-    hipLaunchKernelGGL((k_rf_insert<CTF_, FAST_>), dim3(grid), dim3(256), 0, ctx->stream,                    \
-                       (const XhSpace *)rf->d_spaces.p, ns, (const xh_cf *)d_fft, d_ctf, d_mod,              \
-                       (const float *)rf->d_blob.p, tempV, tempW, rf->mv, rf->iDeltaSqrt, rf->p.blob_radius, rf->insert_variant)
-    if (hasCtf && fast) XH_INSERT(true, true);
-    else if (hasCtf) XH_INSERT(true, false);
-    else if (fast) XH_INSERT(false, true);
-    else XH_INSERT(false, false);
-#undef XH_INSERT
-    XH_LAUNCH_CHECK();
-    return XH_OK;
-}
-#endif
 
 // one traverse space per (projection with non-zero weight, symmetry matrix): RFA:939-966
 static void build_spaces(xh_rf *rf, const double *h_ainv, const float *h_weights, int n, const double *h_sym, int nsym,
@@ -1943,13 +1729,7 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     build_spaces(rf, h_ainv, h_weights, n, h_sym, nsym, spaces);
     const int ns = (int)spaces.size();
     if (ns == 0) return XH_OK;
-    if (rf->tile_variant == 3 && rf->insert_variant == 0) return grid_insert(rf, spaces, d_fft, d_ctf, d_mod, h_weights, n);
-#ifdef XH_EXPERIMENTS
-    return experiments_insert(rf, spaces, d_fft, d_ctf, d_mod, n);
-#else
-    xh_set_error("xh_rf_insert: tile_variant %d / insert_variant %d are earlier forms of the gridding kernel, only in builds with -DXH_EXPERIMENTS", rf->tile_variant, rf->insert_variant);
-    return XH_ERR_UNSUPPORTED;
-#endif
+    return grid_insert(rf, spaces, d_fft, d_ctf, d_mod, h_weights, n);
 }
 
 int xh_rf_insert_matrices(xh_rf *rf, const float *d_fft, const float *d_ctf, const float *d_mod,
@@ -1988,7 +1768,7 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
     xh_ctx *ctx = rf->ctx;
     const size_t plane = (size_t)n * rf->sizeX * rf->sizeY;
     float *d_ctf = nullptr, *d_mod = nullptr;
-    const bool fuse = h_ctf && rf->tile_variant == 3 && rf->insert_variant == 0 && rf->fuse_ctf;
+    const bool fuse = h_ctf && rf->fuse_ctf;
     if (fuse) XH_TRY(ctf_params_upload(rf, h_ctf, n));      // the pack kernel evaluates the CTF: no planes
     else if (h_ctf) {
         XH_TRY(xh_buf_reserve(ctx, rf->d_planes, 2 * plane * sizeof(float)));
@@ -2016,7 +1796,6 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
 {
     XH_CHECK(rf && d_imgs && d_angles && n >= 0, XH_ERR_ARG, "xh_rf_insert_images_dev: bad argument");
     XH_CHECK(!rf->cropped, XH_ERR_STATE, "xh_rf_insert_images_dev: temp spaces already mirrored/cropped; call xh_rf_reset");
-    XH_CHECK(rf->tile_variant == 3 && rf->insert_variant == 0, XH_ERR_UNSUPPORTED, "xh_rf_insert_images_dev: only the gridding kernel of the product path takes device-side orientations");
     XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     XH_TRY(ensure_temp(rf));

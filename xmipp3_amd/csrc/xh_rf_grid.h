@@ -27,23 +27,39 @@
 #ifndef XH_RF_GRID_H
 #define XH_RF_GRID_H
 
-#ifndef XG_NW
-#define XG_NW 12                // waves per workgroup (= per CU: the LDS budget admits one workgroup)
-#endif
-#define XG_KCAP 64              // surviving projections listed per cull phase, three words each (index + flag, patch cell, patch origin)
 #ifndef XG_PAD
 #define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
 #endif
-#define XG_PW 18                // patch row stride in pixels: 16 are needed, 18 skews consecutive rows by two bank groups
-#define XG_NDMA 5               // LDS-DMA instructions per patch: 320 slots = 17.8 rows of 18 pixels
-#define XG_PATCH_BYTES (XG_NDMA * 1024)
-#define XG_LDS_PATCH 0                                   // [XG_NW][XG_PATCH_BYTES]; first, so that LDS-DMA bases stay below 64 KB
-#define XG_LDS_BLOB (XG_NW * XG_PATCH_BYTES)             // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
-#define XG_LDS_ACC (XG_LDS_BLOB + 4 * (XH_BLOB_TABLE + 4))   // [XG_NW][3][256] float
-#define XG_LDS_KEPT (XG_LDS_ACC + XG_NW * 3 * 256 * 4)   // [XG_NW][3][XG_KCAP] int
-#define XG_LDS_QUEUE (XG_LDS_KEPT + XG_NW * 3 * XG_KCAP * 4) // [XG_NW][256] int
-#define XG_LDS_RING (XG_LDS_QUEUE + XG_NW * 1024)        // tile ring: int[8] tiles, int[8] ready, ticket, hop
-#define XG_LDS_TOTAL (XG_LDS_RING + 4 * 32)
+
+// Compile-time shape of a kernel instance. A unit is 8 x 8 x ZD voxels (ZD = 4 or 8); NW waves share a CU.
+//   PN   pixels per patch row / column a footprint can reach: the image extent of a unit is at most its diagonal
+//        (10.4 / 12.2 pixels), so first footprint pixels lie 0..11 / 0..13 behind the patch origin, and a footprint is W wide
+//   PW   patch row stride in pixels: > PN and not a multiple of 16 (64 banks of 4 bytes): consecutive rows are skewed by two or
+//        four bank groups
+//   NDMA LDS-DMA instructions per patch (64 pixels each)
+//   KCAP surviving projections listed per cull phase, three words each (index + flag, patch cell, patch origin)
+// With 14 or more waves the LDS has no room for skew columns or for the slots behind the last row: the patch is PN x PN pixels
+// exactly (an odd row stride: rows are skewed anyway), the last copy instruction runs with the lanes beyond the patch switched
+// off, and the cull phase lists 32 projections at a time.
+template <int W, int ZD, int NW> struct XgCfg {
+    static constexpr int PN = (ZD == 8 ? 14 : 12) + W - 1;
+    static constexpr bool TIGHT = NW >= 14;
+    static constexpr int PW = TIGHT ? PN : (PN <= 17 ? 18 : 20);
+    static constexpr int NDMA = (PN * PW + 63) / 64;
+    static constexpr int PATCH_BYTES = TIGHT ? PN * PW * 16 : NDMA * 1024;
+    static constexpr int KCAP = TIGHT ? 32 : 64;
+    static constexpr int HALVES = TIGHT ? 2 : 1;           // the 4 x 4 footprint in one go or two rows at a time (registers)
+    static constexpr int NVOX = 64 * ZD;
+    static constexpr int LDS_PATCH = 0;                                  // [NW][PATCH_BYTES]; first, so that LDS-DMA bases stay below 64 KB
+    static constexpr int LDS_BLOB = NW * PATCH_BYTES;                    // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
+    static constexpr int LDS_ACC = LDS_BLOB + 4 * (XH_BLOB_TABLE + 4);   // [NW][3][NVOX] float
+    static constexpr int LDS_KEPT = LDS_ACC + NW * 3 * NVOX * 4;         // [NW][3][KCAP] int
+    static constexpr int LDS_QUEUE = LDS_KEPT + NW * 3 * KCAP * 4;       // [NW][NVOX] unsigned short
+    static constexpr int LDS_RING = LDS_QUEUE + NW * NVOX * 2;           // tile ring: int[8] tiles, int[8] ready, ticket, hop
+    static constexpr int LDS_TOTAL = LDS_RING + 4 * 32;
+    static_assert(NW * PATCH_BYTES <= 65536, "LDS-DMA bases must stay below 64 KB");
+    static_assert(LDS_TOTAL <= 163840, "LDS budget of a CU");
+};
 
 // One traverse space (projection x symmetry placement) as the kernel reads it, through scalar loads:
 //   r0, r1, r2  rows of the inverse transform (RFA:643-647); .w: image index, minY | maxY << 16, minZ | maxZ << 16 (AABB rows)
@@ -52,16 +68,19 @@
 //   da, db, dc  getX operands for the exact evaluation (d_hit, d_getX): (u.y, u.z, v.y, v.z), (p0.y, p0.z, p4.y, p4.z), (u.x, v.x, p0.x, 0)
 struct XgRec { float4 r0, r1, r2, h0, h1, h2, da, db, dc; };
 
-// the patch copy: XG_NDMA LDS-DMA instructions, every lane's 16 bytes at base + off[i] land at ldsBase + 1024 i + 16 lane
-// (base, ldsBase wave-uniform). M0 carries the LDS address; the compiler keeps nothing in M0 across a statement.
-__device__ __forceinline__ void xg_dma_patch(const void *base, const unsigned (&off)[5], unsigned ldsBase)
+// the patch copy: NDMA LDS-DMA instructions, every lane's 16 bytes at base + off[i] land at ldsBase + 1024 i + 16 lane
+// (base, ldsBase wave-uniform). M0 carries the LDS address. M0 is a reserved register of the AMDGPU back end: it never holds a
+// value across instructions (the compiler writes it right before every use it generates), and naming it as a clobber is
+// rejected as undefined behaviour (-Winline-asm), so the clobber list names memory and SCC only.
+template <int NDMA, int SLOTS>
+__device__ __forceinline__ void xg_dma_patch(const void *base, const unsigned (&off)[NDMA], unsigned ldsBase, int lane)
 {
-    asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5"
-                 :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(base), "s"(ldsBase) : "memory", "scc");
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        // (SLOTS < 64 NDMA: the lanes of the last instruction that would write behind the patch stay out of it)
+        if (64 * (i + 1) <= SLOTS || 64 * i + lane < SLOTS)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off[i]), "s"(base), "s"(ldsBase + 1024u * i) : "memory");
+    }
 }
 __device__ __forceinline__ void xg_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 typedef float xg_v2f __attribute__((ext_vector_type(2)));
@@ -72,7 +91,7 @@ typedef float xg_v4f __attribute__((ext_vector_type(4)));
 #define XG_PACK_CELLS 1024
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
-               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY, int dbg)
+               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
 {
     const unsigned SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD, cells = SX * SY;
     const unsigned img = blockIdx.y;
@@ -92,7 +111,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
         in[k] = x >= 0 && x < sizeX && y >= 0 && y < sizeY;     // false beyond the last cell too (y >= sizeY)
         const size_t o = src + (size_t)(in[k] ? y * sizeX + x : 0);
         f[k] = xh_cf{0.f, 0.f}; cm[k] = 1.f; cc[k] = 1.f;
-        if (in[k] && dbg != 10) {
+        if (in[k]) {
             f[k] = ffts[o];
             if (ctfs) { cm[k] = mods[o]; cc[k] = ctfs[o]; }
         }
@@ -106,7 +125,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
             if (ctfs) { const float mw = cm[k] * w; v = make_float4(f[k].x * mw * cc[k], f[k].y * mw * cc[k], mw, 0.f); }
             else v = make_float4(f[k].x * w, f[k].y * w, w, 0.f);
         }
-        if (dbg != 11 || v.x == 123.456f) dst[c] = v;
+        dst[c] = v;
     }
 }
 
@@ -235,28 +254,35 @@ __global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ ang
 }
 
 // W: footprint width (4 for a blob radius below 2, 6 below 3). FAST: processVoxel (RFA:595-625), nearest pixel, one voxel per row.
-template <int W, bool FAST>
-__global__ void __launch_bounds__(64 * XG_NW, (XG_NW + 3) / 4)
+// ZD: depth of a unit in z (4 or 8); NW: waves per workgroup (= per CU: the LDS budget admits one workgroup).
+// ABL: ablation switch for profiling builds (tools/ab_grid.sh); 0 in the product: 1 no wait for the patch copy, 2 no dense pass,
+// 3 no patch copy, 5 histogram of items per visit into tempV, 6 = 2 + 3, 7 = 6 without the sparse pass.
+template <int W, bool FAST, int ZD, int NW, int ABL>
+__global__ void __launch_bounds__(64 * NW, (NW + 3) / 4)
 k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const float *__restrict__ blobTable,
           float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
           const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter,
           const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
-          const float4 *__restrict__ superN, const float4 *__restrict__ superX, float4 reach, int dbg)
+          const float4 *__restrict__ superN, const float4 *__restrict__ superX, float4 reach)
 {
-    __shared__ __align__(16) unsigned char lds[XG_LDS_TOTAL];
+    using C = XgCfg<W, ZD, NW>;
+    constexpr int PW = C::PW, PN = C::PN, NDMA = C::NDMA, NVOX = C::NVOX, KCAP = C::KCAP;
+    constexpr float HZ = 0.5f * ZD - 0.5f;                   // half extent of a unit's voxel centres in z
+    constexpr float HSPH = ZD == 8 ? 6.1f : 5.2f;            // ... never wider than the sphere around them
+    __shared__ __align__(16) unsigned char lds[C::LDS_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *sBlob = reinterpret_cast<float *>(lds + XG_LDS_BLOB);
-    float *sAcc = reinterpret_cast<float *>(lds + XG_LDS_ACC) + wv * 3 * 256;
-    int *sKept = reinterpret_cast<int *>(lds + XG_LDS_KEPT) + wv * 3 * XG_KCAP;      // [0]: index | allHit << 31, [KCAP]: cell, [2 KCAP]: ox | oy << 16
-    int *sQueue = reinterpret_cast<int *>(lds + XG_LDS_QUEUE) + wv * 256;
-    int *sTile = reinterpret_cast<int *>(lds + XG_LDS_RING), *sReady = sTile + 8, *sTicket = sTile + 16, *sHop = sTile + 17;
-    const unsigned char *sPatch = lds + XG_LDS_PATCH + wv * XG_PATCH_BYTES;
+    float *sBlob = reinterpret_cast<float *>(lds + C::LDS_BLOB);
+    float *sAcc = reinterpret_cast<float *>(lds + C::LDS_ACC) + wv * 3 * NVOX;
+    int *sKept = reinterpret_cast<int *>(lds + C::LDS_KEPT) + wv * 3 * KCAP;      // [0]: index | allHit << 31, [KCAP]: cell, [2 KCAP]: ox | oy << 16
+    unsigned short *sQueue = reinterpret_cast<unsigned short *>(lds + C::LDS_QUEUE) + wv * NVOX;
+    int *sTile = reinterpret_cast<int *>(lds + C::LDS_RING), *sReady = sTile + 8, *sTicket = sTile + 16, *sHop = sTile + 17;
+    const unsigned char *sPatch = lds + C::LDS_PATCH + wv * C::PATCH_BYTES;
     const unsigned patchBase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)sPatch;
     const int sizeX = mv / 2, sizeY = mv, dim = mv + 1;
     const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
 
-    for (int i = tid; i < XH_BLOB_TABLE + 4; i += 64 * XG_NW) sBlob[i] = i < XH_BLOB_TABLE ? blobTable[i] : 0.f;
+    for (int i = tid; i < XH_BLOB_TABLE + 4; i += 64 * NW) sBlob[i] = i < XH_BLOB_TABLE ? blobTable[i] : 0.f;
     const float fr = FAST ? 0.f : (float)blobRadius;
     const float frCull = FAST ? 0.5f : fr;       // --fast: the voxel nearest to the crossing lies up to half a voxel off the plane
     const float maxDistanceSqr = (sizeX + (FAST ? 0.0 : blobRadius)) * (sizeX + (FAST ? 0.0 : blobRadius));
@@ -266,17 +292,15 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     const xg_v2f idel2 = {iDeltaSqrt, iDeltaSqrt}, half2 = {0.5f, 0.5f};
     const float limf = (float)XH_BLOB_TABLE;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // which pixel of a patch lane l of DMA instruction i fetches: LDS slot s = 64 i + l holds pixel (s / 18, s % 18)
-    unsigned dOff[XG_NDMA];
+    // which pixel of a patch lane l of DMA instruction i fetches: LDS slot s = 64 i + l holds pixel (s / PW, s % PW)
+    // (footprints reach rows and columns 0..PN-1 of a patch: the skew columns and the slots behind the last row re-read the last
+    // pixel of their row / the last row, which costs no further cache line)
+    unsigned dOff[NDMA];
 #pragma unroll
-    // (footprints reach rows and columns 0..15 of a patch: the two skew columns and the slots behind row 15 re-read pixel
-    // 15 of their row / row 15, which costs no further cache line)
-    for (int i = 0; i < XG_NDMA; ++i) { const int slot = 64 * i + lane, row = slot / XG_PW, col = slot - row * XG_PW; dOff[i] = (unsigned)(min(row, 15) * SX + min(col, 15)) * 16u; }
-    // queue word of this lane's voxel zi: x | y << 8 | z << 16 | accumulator index << 24 (bytes feed v_cvt_f32_ubyteN)
-    const int qword = lx | (ly << 8) | (lane << 24);
+    for (int i = 0; i < NDMA; ++i) { const int slot = 64 * i + lane, row = slot / PW, col = slot - row * PW; dOff[i] = (unsigned)(min(row, PN - 1) * SX + min(col, PN - 1)) * 16u; }
 
-    // ---- work distribution: the tile ring of the previous kernel (tiles = 2 x 2 x 2 units, eight XCD classes dealt into
-    // NSUB interleaved streams, one global grab per tile, eight tickets per tile drawn by the waves of the workgroup)
+    // ---- work distribution: a tile ring (tiles = 2 x 2 x 2 units, eight XCD classes dealt into NSUB interleaved streams, one
+    // global grab per tile, eight tickets per tile drawn by the waves of the workgroup)
     constexpr int NSUB = 8, RS = 8;
     const int home = (blockIdx.x & 7) * NSUB + ((blockIdx.x >> 3) & (NSUB - 1));
     auto streamTiles = [&](int st) {
@@ -321,12 +345,12 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
         const unsigned packed = (unsigned)tileP;
         const int sub = t & 7;
         const int tx = packed & 0x3ff, ty = (packed >> 10) & 0x3ff, tz = (packed >> 20) & 0x3ff;
-        const int x0 = tx * 16 + (sub & 1) * 8, y0 = ty * 16 + ((sub >> 1) & 1) * 8, z0 = tz * 8 + (sub >> 2) * 4;
+        const int x0 = tx * 16 + (sub & 1) * 8, y0 = ty * 16 + ((sub >> 1) & 1) * 8, z0 = tz * (2 * ZD) + (sub >> 2) * ZD;
         const int x = x0 + lx, y = y0 + ly;
         const float px = x - mv / 2, py = y - mv / 2;
         int sph = 0;      // bit zi: voxel (x, y, z0 + zi) lies in the volume and inside the sphere the reference keeps (RFA:640)
 #pragma unroll
-        for (int zi = 0; zi < 4; ++zi) {
+        for (int zi = 0; zi < ZD; ++zi) {
             const int z = z0 + zi;
             const float pz = z - mv / 2;
             const bool in = (x <= mv) && (y <= mv) && (z <= mv) && !((px * px + py * py + pz * pz) > maxDistanceSqr);
@@ -334,11 +358,10 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
         }
         if (!__ballot(sph != 0)) continue;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) sAcc[i * 64 + lane] = 0.f;
+        for (int i = 0; i < 3 * ZD; ++i) sAcc[i * 64 + lane] = 0.f;
         const float fx0 = (float)(x0 - mv / 2), fy0 = (float)(y0 - mv / 2), fz0 = (float)(z0 - mv / 2);
-        const xg_v2f pz01 = {fz0, fz0 + 1.f}, pz23 = {fz0 + 2.f, fz0 + 3.f};
-        const float ucx = x0 + 3.5f - mv / 2, ucy = y0 + 3.5f - mv / 2, ucz = z0 + 1.5f - mv / 2;
-        const int sup = ((tz >> 1) * superDim + ty) * superDim + tx;
+        const float ucx = x0 + 3.5f - mv / 2, ucy = y0 + 3.5f - mv / 2, ucz = z0 + HZ - mv / 2;
+        const int sup = ((tz * (2 * ZD) / 16) * superDim + ty) * superDim + tx;
         const int nlist = superCount[sup];
         const int *lst = superList + (size_t)sup * superCap;
         const float4 *lstN = superN + (size_t)sup * superCap, *lstX = superX + (size_t)sup * superCap;
@@ -346,51 +369,54 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
         int pos = 0;
         int sNext = 0;
         float4 nNext = make_float4(0.f, 0.f, 0.f, 0.f), xNext = nNext;
-        if (lane < nlist) { sNext = lst[lane]; nNext = lstN[lane]; xNext = lstX[lane]; }
+        constexpr int CR = KCAP < 64 ? KCAP : 64;      // list entries per cull round: every one of them may survive
+        if (lane < CR && lane < nlist) { sNext = lst[lane]; nNext = lstN[lane]; xNext = lstX[lane]; }
         while (pos < nlist) {
             // ---- cull phase: lane <-> list entry
             int nk = 0;
-            while (pos < nlist && nk <= XG_KCAP - 64) {
+            while (pos < nlist && nk <= KCAP - CR) {
                 const int sIdx = sNext;
                 const float4 n = nNext, xv = xNext;
-                const int e = pos + lane, en = e + 64;
-                if (en < nlist) { sNext = lst[en]; nNext = lstN[en]; xNext = lstX[en]; }
+                const int e = pos + lane, en = e + CR;
+                if (lane < CR && en < nlist) { sNext = lst[en]; nNext = lstN[en]; xNext = lstX[en]; }
                 bool keep = false;
-                if (e < nlist) {
+                if (lane < CR && e < nlist) {
                     const float dn = n.x * ucx + n.y * ucy + n.z * ucz;
                     const float dx = xv.x * ucx + xv.y * ucy + xv.z * ucz;
-                    // support function of the box of voxel centres (half extents 3.5, 3.5, 1.5), never wider than its sphere
-                    const float hn = fminf(5.2f, 3.5f * (fabsf(n.x) + fabsf(n.y)) + 1.5f * fabsf(n.z) + 0.02f);
-                    const float hx = fminf(5.2f, 3.5f * (fabsf(xv.x) + fabsf(xv.y)) + 1.5f * fabsf(xv.z) + 0.02f);
+                    // support function of the box of voxel centres (half extents 3.5, 3.5, HZ), never wider than its sphere
+                    const float hn = fminf(HSPH, 3.5f * (fabsf(n.x) + fabsf(n.y)) + HZ * fabsf(n.z) + 0.02f);
+                    const float hx = fminf(HSPH, 3.5f * (fabsf(xv.x) + fabsf(xv.y)) + HZ * fabsf(xv.z) + 0.02f);
                     keep = (fabsf(dn) <= frCull + hn) && (dx >= -(frCull + hx)) && (dx <= sizeX + frCull + hx);
                 }
                 const unsigned long long bal = __ballot(keep);
                 if (keep) {
                     // What a visit needs before it can start, found here for 64 projections at a time instead of once per visit
-                    // on the scalar side: where the 16 x 16 patch that covers the unit's footprints begins (the first footprint
-                    // pixel of the corner with the smallest image coordinates; the unit's image extent is < 10.4 pixels,
-                    // H2.zw = extent + r; kept inside the padded record: footprints never leave that, so an origin moved inwards
-                    // still covers them), and whether every row of the unit crosses a face of the slab (u and t of the unit's
-                    // centre row keep their distance from 0 and 1 by more than they vary over the unit: 3.5 rows in y, 1.5 in z).
+                    // on the scalar side: where the PN x PN patch that covers the unit's footprints begins (the first footprint
+                    // pixel of the corner with the smallest image coordinates: centre - image extent of the unit - r; kept inside
+                    // the padded record: footprints never leave that, so an origin moved inwards still covers them), and whether
+                    // every row of the unit crosses a face of the slab (u and t of the unit's centre row keep their distance from
+                    // 0 and 1 by more than they vary over the unit: 3.5 rows in y, HZ in z).
                     const float4 r0 = recs[sIdx].r0, r1 = recs[sIdx].r1, h0 = recs[sIdx].h0, h1 = recs[sIdx].h1, h2 = recs[sIdx].h2;
                     const float cix = r0.x * ucx + r0.y * ucy + r0.z * ucz;
                     const float ciy = r1.x * ucx + r1.y * ucy + r1.z * ucz + fmvh;
-                    const int ox = min(max((int)ceilf(cix - h2.z), -XG_PAD), SX - XG_PAD - XG_PW);
-                    const int oy = min(max((int)ceilf(ciy - h2.w), -XG_PAD), SY - XG_PAD - XG_PW);
+                    const float ex = 3.5f * (fabsf(r0.x) + fabsf(r0.y)) + HZ * fabsf(r0.z) + 0.01f + fr;
+                    const float ey = 3.5f * (fabsf(r1.x) + fabsf(r1.y)) + HZ * fabsf(r1.z) + 0.01f + fr;
+                    const int ox = min(max((int)ceilf(cix - ex), -XG_PAD), SX - XG_PAD - PN);
+                    const int oy = min(max((int)ceilf(ciy - ey), -XG_PAD), SY - XG_PAD - PN);
                     // cell index of the patch origin in the packed records (the host keeps a launch below 2^31 cells)
                     const unsigned cell = ((unsigned)__float_as_int(r0.w) * (unsigned)SY + (unsigned)(oy + XG_PAD)) * (unsigned)SX + (unsigned)(ox + XG_PAD);
-                    const float yc = (float)y0 + 3.5f, zc = (float)z0 + 1.5f;
+                    const float yc = (float)y0 + 3.5f, zc = (float)z0 + HZ;
                     const float u1 = h0.x * yc + h0.y * zc + h0.z, t1 = h1.x * yc + h1.y * zc + h1.z;
-                    const float eu = 3.5f * fabsf(h0.x) + 1.5f * fabsf(h0.y) + h2.x + 1e-4f, et = 3.5f * fabsf(h1.x) + 1.5f * fabsf(h1.y) + h2.y + 1e-4f;
+                    const float eu = 3.5f * fabsf(h0.x) + HZ * fabsf(h0.y) + h2.x + 1e-4f, et = 3.5f * fabsf(h1.x) + HZ * fabsf(h1.y) + h2.y + 1e-4f;
                     const bool a1 = (fabsf(u1 - 0.5f) + eu < 0.5f) && (fabsf(t1 - 0.5f) + et < 0.5f);
                     const bool a2 = (fabsf(u1 + h0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + h1.w - 0.5f) + et < 0.5f);
                     const int at = nk + __popcll(bal & below);
                     sKept[at] = sIdx | ((a1 || a2) ? (int)0x80000000 : 0);
-                    sKept[XG_KCAP + at] = (int)cell;
-                    sKept[2 * XG_KCAP + at] = (ox & 0xffff) | (oy << 16);
+                    sKept[KCAP + at] = (int)cell;
+                    sKept[2 * KCAP + at] = (ox & 0xffff) | (oy << 16);
                 }
                 nk += __popcll(bal);
-                pos += 64;
+                pos += CR;
             }
             if (nk == 0) continue;
             __builtin_amdgcn_wave_barrier();
@@ -404,15 +430,15 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
             for (int k = 0; k < nk; ++k) {
                 const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2, NH0 = recs[kidN].h0, NH1 = recs[kidN].h1, NH2 = recs[kidN].h2;
                 const int kidNN = sKept[min(k + 2, nk - 1)], kwN = sKept[min(k + 1, nk - 1)];
-                const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane(sKept[XG_KCAP + k]);
-                const int oxy = __builtin_amdgcn_readfirstlane(sKept[2 * XG_KCAP + k]);
+                const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane(sKept[KCAP + k]);
+                const int oxy = __builtin_amdgcn_readfirstlane(sKept[2 * KCAP + k]);
                 const int ox = (int)(short)(oxy & 0xffff), oy = oxy >> 16;
                 const bool allHit = kw < 0;
                 if constexpr (FAST) {
                     // processVoxel (RFA:595-625) over the traversal of a zero-thickness slab (RFA:743-761): every row (y, z)
                     // that crosses the image plane gives its voxel nearest to the crossing the nearest pixel. lane <-> row.
-                    if (lane < 32) {
-                        const int ry = lane & 7, rz = lane >> 3, vy = y0 + ry, vz = z0 + rz;
+                    for (int rr = lane; rr < 8 * ZD; rr += 64) {
+                        const int ry = rr & 7, rz = rr >> 3, vy = y0 + ry, vz = z0 + rz;
                         const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                         const float4 da = recs[kid].da, db = recs[kid].db, dc = recs[kid].dc;
                         const float ua[3] = {dc.x, da.x, da.y}, va[3] = {dc.y, da.z, da.w}, p0[3] = {dc.z, db.x, db.y};
@@ -433,8 +459,8 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                                 const float4 q = pk[((size_t)__float_as_int(R0.w) * SY + (imgY + XG_PAD)) * SX + (imgX + XG_PAD)];
                                 const int ai = rz * 64 + ry * 8 + (vx - x0);
                                 sAcc[ai] += q.z;
-                                sAcc[256 + ai] += q.x;
-                                sAcc[512 + ai] += q.y;
+                                sAcc[NVOX + ai] += q.x;
+                                sAcc[2 * NVOX + ai] += q.y;
                             }
                         }
                     }
@@ -446,16 +472,16 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 }
                 // ---- the patch copy (origin found in the cull phase). The patch buffer is free: the previous dense pass has
                 // consumed its reads.
-                if (dbg != 3 && dbg != 6 && dbg != 7) xg_dma_patch(pk + cell, dOff, patchBase);
+                if constexpr (ABL != 3 && ABL != 6 && ABL != 7) xg_dma_patch<NDMA, C::PATCH_BYTES / 16>(pk + cell, dOff, patchBase, lane);
                 // ---- sparse pass (RFA:631-653 and the reach of the footprint), two z at a time
                 const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
                 const float ax = R0.x * px + R0.y * py, ay = R1.x * px + R1.y * py, az = R2.x * px + R2.y * py;
                 int qn = 0;
-                if (dbg != 7)
+                if constexpr (ABL != 7)
 #pragma unroll
-                for (int zp = 0; zp < 2; ++zp) {
-                    const xg_v2f pz2 = zp ? pz23 : pz01;
+                for (int zp = 0; zp < ZD / 2; ++zp) {
+                    const xg_v2f pz2 = {fz0 + (float)(2 * zp), fz0 + (float)(2 * zp + 1)};
                     const xg_v2f ix2 = (xg_v2f){ax, ax} + (xg_v2f){R0.z, R0.z} * pz2;
                     xg_v2f iy2 = (xg_v2f){ay, ay} + (xg_v2f){R1.z, R1.z} * pz2;
                     const xg_v2f iz2 = (xg_v2f){az, az} + (xg_v2f){R2.z, R2.z} * pz2;
@@ -469,20 +495,20 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                         const bool pass = ((sph >> zi) & 1) && yok && zok && !(zSqr > radiusSqr) &&
                                           (ix >= reach.x) && (ix <= reach.y) && (iy >= reach.z) && (iy <= reach.w);
                         const unsigned long long pb = __ballot(pass);
-                        if (pass) sQueue[qn + __popcll(pb & below)] = qword + zi * 0x40010000;
+                        if (pass) sQueue[qn + __popcll(pb & below)] = (unsigned short)(lane + 64 * zi);     // the voxel's accumulator: x + 8 y + 64 z
                         qn += __popcll(pb);
                     }
                 }
-                if (dbg == 5 && lane == 0) atomicAdd(reinterpret_cast<int *>(tempV) + min(qn, 256), 1);   // profiling: items per visit
+                if constexpr (ABL == 5) { if (lane == 0) atomicAdd(reinterpret_cast<int *>(tempV) + min(qn, NVOX), 1); }   // profiling: items per visit
                 // ---- the patch of this visit has landed
-                if (dbg != 1) xg_wait_vm0();
+                if constexpr (ABL != 1) xg_wait_vm0();
                 // ---- dense pass
                 const xg_v2f r01x = {R0.x, R1.x}, r01y = {R0.y, R1.y}, r01z = {R0.z, R1.z};
                 const float uLo = 0.5f - H2.x, uHi = 0.5f + H2.x, tLo = 0.5f - H2.y, tHi = 0.5f + H2.y;
-                if (dbg != 2 && dbg != 6 && dbg != 7 && dbg != 8) for (int b0 = 0; b0 < qn; b0 += 64) {
+                if constexpr (ABL != 2 && ABL != 6 && ABL != 7) for (int b0 = 0; b0 < qn; b0 += 64) {
                     if (b0 + lane < qn) {
-                        const int id = sQueue[b0 + lane];
-                        const float qx = fx0 + (float)(id & 0xff), qy = fy0 + (float)((id >> 8) & 0xff), qz = fz0 + (float)((id >> 16) & 0xff);
+                        const int ai = sQueue[b0 + lane];
+                        const float qx = fx0 + (float)(ai & 7), qy = fy0 + (float)((ai >> 3) & 7), qz = fz0 + (float)(ai >> 6);
                         // image coordinates of the voxel, (x, y) packed, with the reference's own operation order (RFA:643-647):
                         // a float coordinate near 256 has an ulp of 3e-5, which d2 * iDelta turns into 0.3 table entries
                         xg_v2f ixy = r01x * (xg_v2f){qx, qx} + r01y * (xg_v2f){qy, qy} + r01z * (xg_v2f){qz, qz};
@@ -508,11 +534,15 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                         }
                         // first pixel of the W x W footprint, ceil(i - r) (RFA:655-658)
                         const float fbx = ceilf(ixy.x - fr), fby = ceilf(ixy.y - fr);
-                        const int ry = (int)fby - oy, cx = (int)fbx - ox;       // 0..12 each
+                        const int ry = (int)fby - oy, cx = (int)fbx - ox;       // 0..PN-W each
                         const __attribute__((address_space(3))) xg_v4f *tap =
-                            (const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)patchBase + (ry * XG_PW + cx);
-                        // (re, im) and (weight, 0) as two packed FMAs per tap; the fourth component is 0 in every record
-                        xg_v2f accRI = {0.f, 0.f}, accWZ = {0.f, 0.f};
+                            (const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)patchBase + (ry * PW + cx);
+                        // (re, im) as one packed FMA per tap, the weight as a plain one; the fourth component of a record only keeps
+                        // the read a ds_read_b128
+                        xg_v2f accRI = {0.f, 0.f};
+                        float accW = 0.f;
+                        // the voxel's sums so far: requested now, needed at the very end
+                        const float oW = sAcc[ai], oR = sAcc[NVOX + ai], oI = sAcc[2 * NVOX + ai];
                         if constexpr (W == 4) {
                             // distances to the footprint's columns and rows as the reference forms them, i - (float)j (RFA:663,673)
                             const xg_v2f ix2 = {ixy.x, ixy.x}, iy2 = {ixy.y, ixy.y}, fbx2 = {fbx, fbx}, fby2 = {fby, fby};
@@ -522,30 +552,41 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                             const xg_v2f z2 = {zSqr, zSqr};
                             const xg_v2f yz01 = ya * ya + z2, yz23 = yb * yb + z2;
                             const float yz[4] = {yz01.x, yz01.y, yz23.x, yz23.y};
-                            // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
-                            int aux[16];
+                            constexpr int NT = 16 / C::HALVES, NR = 4 / C::HALVES;     // taps and footprint rows per go
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const xg_v2f ya2 = {yz[a], yz[a]};
-                                const xg_v2f d01 = xs01 + ya2, d23 = xs23 + ya2;
-                                const xg_v2f t01 = d01 * idel2 + half2, t23 = d23 * idel2 + half2;
-                                aux[a * 4 + 0] = (int)(d01.x > radiusSqr ? limf : t01.x);
-                                aux[a * 4 + 1] = (int)(d01.y > radiusSqr ? limf : t01.y);
-                                aux[a * 4 + 2] = (int)(d23.x > radiusSqr ? limf : t23.x);
-                                aux[a * 4 + 3] = (int)(d23.y > radiusSqr ? limf : t23.y);
-                            }
-                            float wB[16];
-                            xg_v4f q[16];
+                            for (int h = 0; h < C::HALVES; ++h) {
+                                // the records are requested before the index arithmetic of the weights, which they do not depend
+                                // on: their latency passes under it (the scheduler, left alone, clusters them behind the table
+                                // reads and the wave then waits for all of them)
+                                xg_v4f q[NT];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) wB[t] = sBlob[aux[t]];
+                                for (int t = 0; t < NT; ++t)
+                                    q[t] = tap[(h * NR + (t >> 2)) * PW + (t & 3)];
+                                __builtin_amdgcn_sched_barrier(0);
+                                // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
+                                int aux[NT];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t)
-                                q[t] = tap[(t >> 2) * XG_PW + (t & 3)];
+                                for (int a = 0; a < NR; ++a) {
+                                    const xg_v2f ya2 = {yz[h * NR + a], yz[h * NR + a]};
+                                    const xg_v2f d01 = xs01 + ya2, d23 = xs23 + ya2;
+                                    const xg_v2f t01 = d01 * idel2 + half2, t23 = d23 * idel2 + half2;
+                                    aux[a * 4 + 0] = (int)(d01.x > radiusSqr ? limf : t01.x);
+                                    aux[a * 4 + 1] = (int)(d01.y > radiusSqr ? limf : t01.y);
+                                    aux[a * 4 + 2] = (int)(d23.x > radiusSqr ? limf : t23.x);
+                                    aux[a * 4 + 3] = (int)(d23.y > radiusSqr ? limf : t23.y);
+                                }
+                                float wB[NT];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) {
-                                const xg_v2f w2 = {wB[t], wB[t]};
-                                accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[t].x, q[t].y}, accRI);
-                                accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[t].z, q[t].w}, accWZ);
+                                for (int t = 0; t < NT; ++t) wB[t] = sBlob[aux[t]];
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+                                    const xg_v2f w2 = {wB[t], wB[t]};
+                                    accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[t].x, q[t].y}, accRI);
+                                    accW = __builtin_fmaf(wB[t], q[t].z, accW);
+                                    // the unused fourth component stays allocated up to here: handed out again earlier, its
+                                    // register makes the index arithmetic wait for the record reads (write after write)
+                                    asm volatile("" :: "v"(q[t].w));
+                                }
                             }
                         } else {
                             // wider blobs: the same taps row by row
@@ -562,21 +603,19 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                                 for (int b = 0; b < W; ++b) {
                                     const float d2 = xs[b] + yzS;
                                     wB[b] = sBlob[(int)(d2 > radiusSqr ? limf : d2 * iDeltaSqrt + 0.5f)];
-                                    q[b] = tap[a * XG_PW + b];
+                                    q[b] = tap[a * PW + b];
                                 }
 #pragma unroll
                                 for (int b = 0; b < W; ++b) {
                                     const xg_v2f w2 = {wB[b], wB[b]};
                                     accRI = __builtin_elementwise_fma(w2, (xg_v2f){q[b].x, q[b].y}, accRI);
-                                    accWZ = __builtin_elementwise_fma(w2, (xg_v2f){q[b].z, q[b].w}, accWZ);
+                                    accW = __builtin_fmaf(wB[b], q[b].z, accW);
                                 }
                             }
                         }
-                        const float vW = accWZ.x + accWZ.y, vR = accRI.x, vI = accRI.y;
-                        const int ai = (unsigned)id >> 24;
-                        sAcc[ai] += vW;
-                        sAcc[256 + ai] += vR;
-                        sAcc[512 + ai] += vI;
+                        sAcc[ai] = oW + accW;
+                        sAcc[NVOX + ai] = oR + accRI.x;
+                        sAcc[2 * NVOX + ai] = oI + accRI.y;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -588,8 +627,8 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
         }
         // ---- write-back
 #pragma unroll
-        for (int zi = 0; zi < 4; ++zi) {
-            const float aW = sAcc[zi * 64 + lane], aR = sAcc[256 + zi * 64 + lane], aI = sAcc[512 + zi * 64 + lane];
+        for (int zi = 0; zi < ZD; ++zi) {
+            const float aW = sAcc[zi * 64 + lane], aR = sAcc[NVOX + zi * 64 + lane], aI = sAcc[2 * NVOX + zi * 64 + lane];
             if (((sph >> zi) & 1) && (aW != 0.f || aR != 0.f || aI != 0.f)) {
                 const size_t vi = ((size_t)(z0 + zi) * dim + y) * dim + x;
                 float2 *V = reinterpret_cast<float2 *>(tempV) + vi;
