@@ -11,12 +11,16 @@ shard of synthetic 256x256 particles resident in HBM and, per step, pushes one b
 
 and, after the K steps, mirror+crop, ONE all-reduce (RCCL) of [volume | weights] and the
 finaliser (3-D inverse FFT + blob correction) on every rank.  All of it is inside the timed
-region.  Weak scaling: per-GPU work is fixed as N grows.
+region, and so is the traffic SURVEY.md 8d puts inside the metric: every batch comes from page-locked
+host memory (two device buffers; the copy of batch k+1 runs on its own stream under step k, only the
+very first copy precedes the clock) and every step's results (reference, in-plane angle, mirror,
+shifts, maxCC) go back to page-locked host memory.  Four distinct batches are cycled.  Weak scaling:
+per-GPU work is fixed as N grows.
 
 One JSON line on rank 0 (see the driver contract in the task statement), with
   roofline      -- the kernel that dominates the timed region, algorithmic work / HIP-event time
   worst_case    -- the same step with the data-dependent shortcuts of the matcher switched off
-  value_with_h2d -- the same steps with every batch streamed from page-locked host memory
+  value_resident -- the same steps on a batch that already lies in HBM (no host traffic)
   cpu_baseline  -- the CPU oracle ("port" of the reference algorithm; Xmipp itself cannot be
                    built here: xmippCore/FFTW absent) timed on a bounded sample on rank 0.
 
@@ -64,7 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
-    ap.add_argument("--unique-batches", type=int, default=0, help="--mode grid: distinct particle batches cycled (0: 4 = 16384 projections at --batch 4096)")
+    ap.add_argument("--unique-batches", type=int, default=0, help="distinct particle batches cycled from host memory (0: 4 = 16384 particles at --batch 4096)")
     return ap.parse_args(argv)
 
 
@@ -218,11 +222,21 @@ def main():
                                                       align_corners=False)[:, 0]
         return (out + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous(), idx
 
-    # --mode grid is BASELINE config 3: >= 16384 distinct projections cycled, fresh orientations per use
-    nuniq = (args.unique_batches or 4) if args.mode == "grid" else 1
-    made = [make_batch() for _ in range(nuniq)]
-    batches = [b for b, _ in made]
-    particles = batches[0]
+    # >= 16384 distinct particles cycled (BASELINE config 3: fresh orientations per use); they live in page-locked HOST memory and
+    # are streamed through two device buffers inside the timed region; batch 0 also stays on the device for the resident leg,
+    # the CPU sample and the parity checks
+    nuniq = args.unique_batches or 4
+    host, h_truth = [], []
+    particles = None
+    for u in range(nuniq):
+        b_, i_ = make_batch()
+        hb = torch.empty(b_.shape, dtype=b_.dtype, pin_memory=True)
+        hb.copy_(b_)
+        host.append(hb)
+        h_truth.append(i_.cpu().numpy())
+        if u == 0:
+            particles = b_
+        del b_
     # --neighbours K: the K references nearest (angular distance of the projection directions) to the particle's own
     nbr = None
     if args.neighbours > 0 and args.mode != "grid":
@@ -230,8 +244,8 @@ def main():
         rt = np.radians(dirs[:, :2])
         v = np.stack([np.sin(rt[:, 1]) * np.cos(rt[:, 0]), np.sin(rt[:, 1]) * np.sin(rt[:, 0]), np.cos(rt[:, 1])], 1)
         table = np.sort(np.argsort(-(v @ v.T), axis=1, kind="stable")[:, :K], axis=1).astype(np.int32)
-        h_idx = made[0][1].cpu().numpy()
-        nbr = ((np.arange(B + 1) * K).astype(np.int32), np.ascontiguousarray(table[h_idx].ravel()))
+        nbrs = [((np.arange(B + 1) * K).astype(np.int32), np.ascontiguousarray(table[h_truth[u]].ravel())) for u in range(nuniq)]
+        nbr = nbrs[0]
     rng = np.random.default_rng(100 + rank)
     from xmipp3_amd.api import ctf_params
     ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d))
@@ -255,24 +269,45 @@ def main():
     rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
     s6_rep = [0]            # particles whose translational alignment was repeated in double precision, timed steps only
     rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
-    t_grid = ctx.timer()
-    grid_ms = []
-    step_no = [0]
+    # HIP-event pairs on the library's stream around the stages xh_pm_stage_ms does not cover; read after the timed region
+    timers = {"translate_s6": [], "shift_images": [], "gridding_insert_images": []}
 
-    def step(record, parts=None):
+    def timed(name, record, fn):
+        if not record:
+            return fn()
+        t = ctx.timer()
+        t.start()
+        r = fn()
+        t.stop()
+        timers[name].append(t)
+        return r
+
+    # results of a step as a host would receive them: page-locked, copied behind the step's kernels without a sync
+    h_out = None
+    if pm is not None:
+        h_out = [{"refno": torch.empty(B, dtype=torch.int32, pin_memory=True), "psi": torch.empty(B, dtype=torch.int32, pin_memory=True),
+                  "flip": torch.empty(B, dtype=torch.uint8, pin_memory=True), "sx": torch.empty(B, dtype=torch.float64, pin_memory=True),
+                  "sy": torch.empty(B, dtype=torch.float64, pin_memory=True), "cc": torch.empty(B, dtype=torch.float64, pin_memory=True)}
+                 for _ in range(2)]
+
+    def step(record, parts=None, u=0, slot=None):
         ang = flips = None
         if parts is None:
-            parts = batches[step_no[0] % nuniq]
-        step_no[0] += 1
+            parts = particles
         imgs = parts
         if pm is not None:
-            refno, psi, flip = pm.match(parts, *nbr) if nbr is not None else pm.match(parts)
+            nb = nbrs[u] if nbr is not None else None
+            refno, psi, flip = pm.match(parts, *nb) if nb is not None else pm.match(parts)
             if record:
                 st = pm.last_stats()
                 rows_seen[0] += st["rows"]; rows_seen[1] += st["pruned_rows"]
-            sx, sy, cc = pm.translate(parts, refno, psi, flip)
+            sx, sy, cc = timed("translate_s6", record, lambda: pm.translate(parts, refno, psi, flip))
             if record:
                 s6_rep[0] += pm.translate_repeated()
+            if slot is not None:
+                ho = h_out[slot]
+                for k_, t_ in (("refno", refno), ("psi", psi), ("flip", flip), ("sx", sx), ("sy", sy), ("cc", cc)):
+                    ho[k_].copy_(t_, non_blocking=True)
             # the orientations stay on the device: (rot, tilt) of the matched reference, psi from the sample index
             ang = torch.cat([dirs_dev[refno.long()], (psi.double() * (360.0 / pm.N))[:, None]], 1).contiguous()
             shifts = (sx, sy)
@@ -282,13 +317,8 @@ def main():
             shifts = rng.uniform(-3, 3, (B, 2))
         if rf is not None:
             # the matcher has just computed the particles' B-spline coefficients: the shift reuses them
-            imgs = rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B) if pm is not None else None)
-            if record:
-                t_grid.start()
-            rf.insert_images(imgs, ang, ctf_array=ctf_arr)      # CTF planes + FFT + records + gridding
-            if record:
-                t_grid.stop()
-                grid_ms.append(t_grid.elapsed_ms())
+            imgs = timed("shift_images", record, lambda: rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B) if pm is not None else None))
+            timed("gridding_insert_images", record, lambda: rf.insert_images(imgs, ang, ctf_array=ctf_arr))      # CTF planes + FFT + records + gridding
 
     def finish():
         if rf is None:
@@ -312,14 +342,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    t_fin0 = time.perf_counter()
-    finish()
-    barrier()
-    t1 = time.perf_counter()
+    # ---- the timed region: batches streamed from page-locked host memory through two device buffers
+    dbuf = [torch.empty_like(particles), torch.empty_like(particles)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def fetch(k):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[k & 1])          # the step that last used this buffer has finished
+            dbuf[k & 1].copy_(host[k % nuniq], non_blocking=True)
+            ready[k & 1].record(copy_stream)
+
+    def streamed_steps(nsteps, record):
+        for e in done:
+            e.record()
+        fetch(0)                                          # the prologue copy: before the clock starts
+        barrier()
+        ta = time.perf_counter()
+        for k in range(nsteps):
+            if k + 1 < nsteps:
+                fetch(k + 1)                              # flies under step k
+            torch.cuda.current_stream().wait_event(ready[k & 1])
+            step(record, dbuf[k & 1], k % nuniq, k & 1)
+            done[k & 1].record()
+        tb = time.perf_counter()
+        finish()
+        barrier()
+        return ta, tb, time.perf_counter()
+
+    t0, t_fin0, t1 = streamed_steps(args.steps, True)
     elapsed = t1 - t0
     finish_s = t1 - t_fin0
     if world > 1:
@@ -333,43 +385,21 @@ def main():
     # ---- extra legs, outside the timed region (every rank runs them: same collectives, same barriers)
     extra = {}
     if not args.no_extra_legs:
-        # (1) every batch streamed from page-locked host memory: two device buffers, the copy of batch k+1 on its own
-        # stream while batch k is worked on
-        nh = max(2, min(args.steps, 4))
-        host = [b.cpu().pin_memory() for b in batches[:2]] if nuniq > 1 else [particles.cpu().pin_memory()]
-        dbuf = [torch.empty_like(particles), torch.empty_like(particles)]
-        copy_stream = torch.cuda.Stream(device=dev)
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        done = [torch.cuda.Event(), torch.cuda.Event()]
-
-        def fetch(k):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(done[k & 1])
-                dbuf[k & 1].copy_(host[k % len(host)], non_blocking=True)
-                ready[k & 1].record(copy_stream)
-        for e in done:
-            e.record()
+        # (1) the same steps on a batch that already lies in HBM: what the host traffic costs is value_resident - value
+        nres = max(2, min(args.steps, 4))
         barrier()
         th0 = time.perf_counter()
-        fetch(0)
-        for k in range(nh):
-            if k + 1 < nh:
-                fetch(k + 1)
-            torch.cuda.current_stream().wait_event(ready[k & 1])
-            step(False, dbuf[k & 1])
-            done[k & 1].record()
+        for _ in range(nres):
+            step(False)
         finish()
         barrier()
-        th1 = time.perf_counter()
-        el = th1 - th0
+        el = time.perf_counter() - th0
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
-        extra["value_with_h2d"] = nh * B * world / el
-        extra["h2d_leg"] = {"steps": nh, "bytes_per_step_per_gpu": B * D * D * 4,
-                            "what": "same steps + finish, every batch copied from page-locked host memory on a second stream"}
-        del host, dbuf
+        extra["value_resident"] = nres * B * world / el
+        extra["resident_leg"] = {"steps": nres, "what": "same steps + finish on a batch resident in HBM, no host traffic"}
         # (2) the matcher without its data-dependent shortcuts: every correlation row contracted over all frequencies and
         # transformed (S3 branch and bound off, two-level cut off)
         if pm is not None and not args.no_prune:
@@ -402,7 +432,9 @@ def main():
 
     total_particles = args.steps * B * world
     value = total_particles / elapsed
-    stage["gridding_insert_images"] = float(sum(grid_ms))   # CTF planes + FFT + records + spaces upload + kernel
+    for name, ts in timers.items():                         # translate (S6), shift, insert_images = CTF + FFT + records + spaces + kernel
+        if ts:
+            stage[name] = float(sum(t.elapsed_ms() for t in ts))
     stage["k_rf_grid"] = k_ms                                # HIP events around the kernel launches only
     # ---- roofline of the dominant kernel (per launch = per chunk; reported per particle-second)
     N = pm.N if pm is not None else 2 * int(math.pi * (D // 2 - 1))
@@ -420,7 +452,7 @@ def main():
         surv = rows - rows_seen[1]
         frac_low = min(1.0, K0 / float(nk))
         fl = surv * (5.0 * N * math.log2(N) + 8.0 * ncoef * (1.0 - frac_low))
-        cand["k_pm_idft_max"] = ("mfma", fl / (stage["idft_max"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["idft_max"],
+        cand["k_pm_idft_max"] = ("valu", fl / (stage["idft_max"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["idft_max"],
                                  f"{surv} of {rows} rows transformed (the rest pruned by the branch and bound)")
         fl2 = rows * 8.0 * ncoef * frac_low
         cand["k_pm_contract"] = ("mfma", fl2 / (stage["contract"] * 1e-3) / 1e12, 157.3, "TFLOP/s", stage["contract"],
@@ -460,6 +492,7 @@ def main():
                    "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "neighbours": args.neighbours or None,
                    "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
+                   "host_traffic": "every batch H2D from page-locked memory (double-buffered, second stream), results D2H, inside the timed region",
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
         "stage_ms": stage, "finish_and_allreduce_s": finish_s,

@@ -343,6 +343,22 @@ int xh_fft2d_destroy(xh_fft2d *f);
 int xh_fft2d_factors(const xh_fft2d *f, int32_t *h_factors);
 int xh_fft2d_exec(xh_fft2d *f, float *d_data /* [ny][nx][2] */, int32_t inverse);
 
+/* ---- CTF pre-steps -------------------------------------------------------------------
+ * xmipp_ctf_phase_flip: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) -- the coefficients of a micrograph where
+ * the undamped CTF (getValuePureWithoutDampingAt, data/ctf.h:541-570) is negative change sign.
+ * xmipp_ctf_correct_wiener2d: Wiener2D::wienerFilter + applyWienerFilter (data/wiener2d.cpp:29-141) -- every particle is
+ * padded about the Xmipp origin, multiplied in Fourier space by CTF / (CTF^2 + wc) (wc < 0: 0.1 mean CTF^2) and cropped back.
+ * A handle serves images of one size: ydim x xdim floats on the device, in place; pad = 1 for phase flipping. CTF
+ * descriptions on the host (phase_shift in degrees, as the metadata holds it); sampling_rate = Tm the CTF is evaluated at.
+ * is_isotropic is accepted and, as in the reference (which averages the defoci after produceSideInfo has used them), has no
+ * effect. CTF in double precision, transforms in fp32. */
+typedef struct xh_ctfop xh_ctfop;
+int xh_ctfop_create(xh_ctx *ctx, int32_t ydim, int32_t xdim, double pad, xh_ctfop **out);
+int xh_ctfop_destroy(xh_ctfop *h);
+int xh_ctfop_phase_flip(xh_ctfop *h, float *d_img, const xh_ctf_params *ctf, double sampling_rate);
+int xh_ctfop_wiener2d(xh_ctfop *h, float *d_imgs /* [n][ydim][xdim] */, int32_t n, const xh_ctf_params *ctfs, double sampling_rate,
+                      int32_t phase_flipped, int32_t is_isotropic, double wiener_constant, int32_t correct_envelope);
+
 #ifdef __cplusplus
 }
 #endif

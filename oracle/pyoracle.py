@@ -93,6 +93,8 @@ def lib():
         "xo_ctf_defaults": (None, [C.POINTER(CtfParams)]),
         "xo_ctf_value_pure_nok": (d, [C.POINTER(CtfParams), d, d]),
         "xo_ctf_lambda": (d, [C.POINTER(CtfParams)]),
+        "xo_ctf_phase_flip": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), C.c_int]),
+        "xo_ctf_wiener2d": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), d, d, C.c_int, C.c_int, d, C.c_int]),
         "xo_rf_create": (vp, [C.POINTER(RfParams)]),
         "xo_rf_destroy": (None, [vp]),
         "xo_rf_blob_table_sqrt": (c_float_p, [vp]),
@@ -367,6 +369,21 @@ class PM:
 
 
 # ---------------------------------------------------------------- reconstruction
+def ctf_phase_flip(img, ctf, with_damping=False):
+    """actualPhaseFlip (ctf_phase_flip.cpp:88-117); ctf.Tm = sampling rate of the image. with_damping: CTFDescription::correctPhase."""
+    out = f64(img).copy()
+    lib().xo_ctf_phase_flip(_dp(out), out.shape[0], out.shape[1], C.byref(ctf), int(with_damping))
+    return out
+
+
+def ctf_wiener2d(img, ctf, sampling_rate=1.0, pad=2.0, phase_flipped=False, is_isotropic=False, wiener_constant=-1.0, correct_envelope=False):
+    """Wiener2D::applyWienerFilter (data/wiener2d.cpp:101-141) on one image"""
+    out = f64(img).copy()
+    lib().xo_ctf_wiener2d(_dp(out), out.shape[0], out.shape[1], C.byref(ctf), sampling_rate, pad, int(phase_flipped), int(is_isotropic),
+                          wiener_constant, int(correct_envelope))
+    return out
+
+
 def ctf_params(**kw):
     p = CtfParams()
     lib().xo_ctf_defaults(C.byref(p))

@@ -129,6 +129,12 @@ void xo_ctf_defaults(xo_ctf_params *p);
 /* getValuePureNoKAt at continuous frequency (X,Y) [1/A] */
 double xo_ctf_value_pure_nok(const xo_ctf_params *p, double X, double Y);
 double xo_ctf_lambda(const xo_ctf_params *p);
+/* actualPhaseFlip (ctf_phase_flip.cpp:88-117; with_damping = 1: CTFDescription::correctPhase, ctf.cpp:1553-1582), in place;
+ * ctf->Tm = sampling rate of the image, ctf->phase_shift in degrees */
+void xo_ctf_phase_flip(double *img, int ydim, int xdim, const xo_ctf_params *ctf, int with_damping);
+/* Wiener2D::applyWienerFilter (data/wiener2d.cpp:29-141) on one image, in place */
+void xo_ctf_wiener2d(double *img, int ydim, int xdim, const xo_ctf_params *ctf, double sampling_rate, double pad,
+                     int phase_flipped, int is_isotropic, double wiener_constant, int correct_envelope);
 
 /* ---- Fourier reconstruction (RFA) ---------------------------------------- */
 typedef struct {

@@ -88,8 +88,9 @@ def test_fp32_error_distribution_at_full_size_against_the_margin(gpu, kind):
     """The ambiguity margin tau_rel is not a worst-case bound (one for 127 rings x 400 frequencies x a 2048-point transform is
     two orders above what happens) but a multiple of the MEASURED error of the coarse pass, so the measurement is a test: at
     256 px, coarse (fp32) against re-score (fp64, equal to the oracle to 1e-10 S: test above) rows of 24 particles x 8
-    references, 3e5 samples per gallery kind: the largest error stays below tau_rel / 8 and the standard deviation below
-    tau_rel / 40 (the errors are sums of ~1e5 independent roundings: a 20-sigma margin on either side of a comparison)."""
+    references, 3e5 samples per gallery kind: the largest error stays below tau_rel / 4 -- half of the tau / 2 the argument
+    needs -- and the standard deviation below tau_rel / 20 (the errors are sums of ~1e5 roundings: tau / 2 is ten of these
+    bounds away)."""
     xa, ctx, torch = gpu
     D, nrefs, n = 256, 8, 24
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -113,8 +114,8 @@ def test_fp32_error_distribution_at_full_size_against_the_margin(gpu, kind):
     e = np.concatenate(errs) / scale
     tau = pm.get_option("tau_rel")
     print(kind, "fp32 - fp64 over", e.size, "samples: max", np.abs(e).max(), "std", e.std(), "tau_rel", tau)
-    assert np.abs(e).max() <= tau / 8
-    assert e.std() <= tau / 40
+    assert np.abs(e).max() <= tau / 4
+    assert e.std() <= tau / 20
 
 
 @pytest.mark.parametrize("parity", [0, 1])

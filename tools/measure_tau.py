@@ -25,14 +25,12 @@ parts = torch.nn.functional.grid_sample(refs[idx][:, None], grid, mode="bilinear
 parts = (parts + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
 pm = xa.ProjectionMatcher(ctx, refs)
 S = 2 * math.pi * sum(range(1, D // 2))
-_, sig_p = pm.debug_prepare(parts, 64)
 errs = []
 rng = np.random.default_rng(0)
 for i in range(B):
     for r in (int(idx[i]), int(rng.integers(nrefs))):
         a = pm.debug_corr_rows(parts[i], r, 32); b = pm.debug_corr_rows(parts[i], r, 64)
-        _, sr = pm.debug_ref(r)
-        errs.append((a - b) / (sig_p[i] * sr) / S)
+        errs.append((a - b) / S)          # debug_corr_rows returns rows already divided by sigma_ref sigma_img
 e = np.concatenate(errs)
 print("samples", e.size, "rms", np.sqrt((e**2).mean()), "max", np.abs(e).max(), "max/rms", np.abs(e).max()/np.sqrt((e**2).mean()))
 for q in (0.999, 0.99999, 0.9999999): print(q, np.quantile(np.abs(e), q))

@@ -75,6 +75,10 @@ SIGNATURES = {
     "xh_rf_cropped_import": (C.c_int, [vp, vp, i32]),
     "xh_rf_reduce": (C.c_int, [pvp, i32]),
     "xh_rf_finish": (C.c_int, [vp, vp]),
+    "xh_ctfop_create": (C.c_int, [vp, i32, i32, d, pvp]),
+    "xh_ctfop_destroy": (C.c_int, [vp]),
+    "xh_ctfop_phase_flip": (C.c_int, [vp, vp, C.POINTER(CtfParams), d]),
+    "xh_ctfop_wiener2d": (C.c_int, [vp, vp, i32, vp, d, i32, i32, d, i32]),
     "xh_pm_create": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, i32, pvp]),
     "xh_pm_destroy": (C.c_int, [vp]),
     "xh_pm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

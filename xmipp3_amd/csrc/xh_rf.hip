@@ -256,7 +256,7 @@ struct xh_rf {
     int64_t kernelLaunches;
     double meanFactor2;   // cached mean of sinc^2 over the output window (< 0: not computed yet)
     bool cropped;
-    int unit_z = 8;       // depth of a gridding unit (8 x 8 x unit_z voxels per wave): 4 or 8
+    int unit_z = 4;       // depth of a gridding unit (8 x 8 x unit_z voxels per wave): 4 or 8
     int grid_waves = 0;   // waves per CU of the gridding kernel; 0: the default of the unit depth
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
     int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)

@@ -34,8 +34,7 @@
 // Compile-time shape of a kernel instance. A unit is 8 x 8 x ZD voxels (ZD = 4 or 8); NW waves share a CU.
 //   PN   pixels per patch row / column a footprint can reach: the image extent of a unit is at most its diagonal
 //        (10.4 / 12.2 pixels), so first footprint pixels lie 0..11 / 0..13 behind the patch origin, and a footprint is W wide
-//   PW   patch row stride in pixels: > PN and not a multiple of 16 (64 banks of 4 bytes): consecutive rows are skewed by two or
-//        four bank groups
+//   PW   patch row stride in pixels: > PN and not a multiple of 16 (64 banks of 4 bytes): consecutive rows are skewed
 //   NDMA LDS-DMA instructions per patch (64 pixels each)
 //   KCAP surviving projections listed per cull phase, three words each (index + flag, patch cell, patch origin)
 // With 14 or more waves the LDS has no room for skew columns or for the slots behind the last row: the patch is PN x PN pixels
@@ -44,7 +43,14 @@
 template <int W, int ZD, int NW> struct XgCfg {
     static constexpr int PN = (ZD == 8 ? 14 : 12) + W - 1;
     static constexpr bool TIGHT = NW >= 14;
-    static constexpr int PW = TIGHT ? PN : (PN <= 17 ? 18 : 20);
+#ifdef XG_PW_OVERRIDE
+    static constexpr int PW = (W == 4 && ZD == 4 && NW == 12) ? XG_PW_OVERRIDE : (TIGHT ? PN : (PN <= 17 ? 18 : 20));      // A/B builds (tools/build_variant.sh)
+#else
+    // (15 rows of 21 pixels fill the five copy instructions of the 4 x 4 footprint's patch; a record is four banks wide, so the
+    // sixteen lanes a ds_read_b128 serves per cycle collide when their (row, column) differ by a multiple of sixteen in
+    // 21 row + column -- (1, -5), (3, 1), (2, 6) ... -- where a stride of 18 had (1, -2): measured 3 % of the kernel)
+    static constexpr int PW = TIGHT ? PN : (PN == 15 ? 21 : (PN <= 17 ? 18 : 20));
+#endif
     static constexpr int NDMA = (PN * PW + 63) / 64;
     static constexpr int PATCH_BYTES = TIGHT ? PN * PW * 16 : NDMA * 1024;
     static constexpr int KCAP = TIGHT ? 32 : 64;
