@@ -25,7 +25,7 @@ def _run(args, **kw):
 
 def test_help_and_argument_errors(bins):
     for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier",
-                 "xmipp_angular_project_library", "xmipp_resolution_fsc"):
+                 "xmipp_angular_project_library", "xmipp_resolution_fsc", "xmipp_ctf_phase_flip", "xmipp_ctf_correct_wiener2d"):
         r = _run([os.path.join(bins, prog), "--help"])
         assert r.returncode == 0 and "USAGE" in r.stderr
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-o", "x.xmd"])
@@ -434,3 +434,49 @@ def test_cli_gallery_then_matching(bins, tmp_path, oracle):
             d = abs(float(rw[oc["anglePsi"]]) - psi) % 360
             assert min(d, 360 - d) <= 360.0 / 90 + 1e-6      # within one step of the in-plane angular grid
         assert float(rw[oc["maxCC"]]) > 0.98
+
+
+_CTF_COLS = ["ctfSamplingRate", "ctfVoltage", "ctfDefocusU", "ctfDefocusV", "ctfDefocusAngle", "ctfSphericalAberration", "ctfQ0", "ctfK"]
+
+
+@pytest.mark.gpu
+def test_cli_ctf_phase_flip_and_wiener2d(bins, tmp_path, oracle):
+    """xmipp_ctf_phase_flip (ctf_phase_flip.cpp:29-86) and xmipp_ctf_correct_wiener2d (ctf_correct_wiener2d.cpp:30-105) with the
+    reference's flags, against the oracle on the same files' contents."""
+    rng = np.random.default_rng(21)
+    mic = rng.standard_normal((96, 128)).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "mic.stk"), mic[None])
+    vals = [2.0, 300.0, 21000.0, 19500.0, 25.0, 2.7, 0.07, 1.0]
+    xmipp_io.write_xmd(str(tmp_path / "mic.ctfparam"), [("noname", _CTF_COLS, [[f"{v:.6f}" for v in vals]])])
+    r = _run([os.path.join(bins, "xmipp_ctf_phase_flip"), "-i", f"1@{tmp_path}/mic.stk", "-o", str(tmp_path / "flipped.spi"),
+              "--ctf", str(tmp_path / "mic.ctfparam"), "--downsampling", "1.5"])
+    assert r.returncode == 0, r.stderr
+    got = xmipp_io.read_volume(str(tmp_path / "flipped.spi"))
+    got = got.reshape(got.shape[-2:])
+    kw = dict(zip(("Tm", "kV", "DeltafU", "DeltafV", "azimuthal_angle", "Cs", "Q0", "K"), vals))
+    kw["Tm"] = 2.0 * 1.5                  # no --sampling: the ctfparam's rate times the downsampling (ctf_phase_flip.cpp:75-79)
+    exp = oracle.ctf_phase_flip(mic, oracle.ctf_params(**kw))
+    assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max()
+    r = _run([os.path.join(bins, "xmipp_ctf_phase_flip"), "-i", f"1@{tmp_path}/mic.stk", "-o", str(tmp_path / "x.spi")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "--ctf" in r.stderr
+    # Wiener correction of a particle stack, one CTF per row
+    n, D = 7, 40
+    parts = rng.standard_normal((n, D, D)).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "parts.stk"), parts)
+    rows = []
+    for i in range(n):
+        rows.append([f"{i + 1}@{tmp_path}/parts.stk"] + [f"{v:.6f}" for v in (1.0, 300.0, 15000.0 + 900.0 * i, 15400.0 + 900.0 * i, 10.0 * i, 2.7, 0.07, 1.0)] + [f"{0.5 * i:.6f}"])
+    xmipp_io.write_xmd(str(tmp_path / "parts.xmd"), [("noname", ["image"] + _CTF_COLS + ["shiftX"], rows)])
+    r = _run([os.path.join(bins, "xmipp_ctf_correct_wiener2d"), "-i", str(tmp_path / "parts.xmd"), "-o", str(tmp_path / "corrected.stk"),
+              "--sampling_rate", "1.2", "--pad", "2", "--phase_flipped", "--batch", "3"])
+    assert r.returncode == 0, r.stderr
+    got = xmipp_io.read_stack(str(tmp_path / "corrected.stk"))
+    assert got.shape == parts.shape
+    for i in range(n):
+        c = oracle.ctf_params(Tm=1.0, kV=300.0, DeltafU=15000.0 + 900.0 * i, DeltafV=15400.0 + 900.0 * i, azimuthal_angle=10.0 * i, Cs=2.7, Q0=0.07, K=1.0)
+        exp = oracle.ctf_wiener2d(parts[i], c, sampling_rate=1.2, pad=2.0, phase_flipped=True)
+        assert np.abs(got[i] - exp).max() <= 1e-5 * np.abs(exp).max()
+    labels, orows = xmipp_io.read_xmd(str(tmp_path / "corrected.xmd"))
+    # postProcess (ctf_correct_wiener2d.cpp:58-93): the defoci and K are gone, the image column names the new stack
+    assert "ctfDefocusU" not in labels and "ctfK" not in labels and "shiftX" in labels and "ctfVoltage" in labels
+    assert len(orows) == n and orows[2][labels.index("image")] == f"3@{tmp_path}/corrected.stk"

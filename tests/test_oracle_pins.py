@@ -109,6 +109,21 @@ def test_ctf_wavelength_and_first_zero_pin(oracle):
     assert abs(val - 7.6852355) < 2e-6
 
 
+def test_ctf_phase_flip_pin(oracle):
+    """test_ctf_main.cpp:126-149: a centred delta in a 256 x 256 image, phase flipped (CTFDescription::correctPhase, the
+    variant with the damping envelope; without envelope parameters it flips the same coefficients as actualPhaseFlip, the
+    restatement the programs use): standard deviation 0.003906, maximum 0.017565, EXPECT_NEAR 1e-4."""
+    c = oracle.ctf_params(Tm=1.0, kV=300.0, DeltafU=20000.0, DeltafV=20000.0, Cs=2.0, Q0=0.1, K=1.0)
+    delta = np.zeros((256, 256))
+    delta[128, 128] = 1.0
+    for damping in (True, False):
+        f = oracle.ctf_phase_flip(delta, c, with_damping=damping)
+        assert abs(f.std() - 0.003906) < 1e-4
+        assert abs(f.max() - 0.017565) < 1e-4
+    # and it is a sign pattern: every coefficient keeps its modulus
+    assert np.allclose(np.abs(np.fft.rfft2(f)), np.abs(np.fft.rfft2(delta)), atol=1e-12)
+
+
 def test_prefilter_inverts_bspline_sampling(oracle):
     # coefficients c reproduce the samples: s[k] = (c[k-1] + 4 c[k] + c[k+1]) / 6 with
     # half-sample mirror (c[-1] = c[0], c[n] = c[n-1])  (SURVEY.md Appendix B)

@@ -360,6 +360,47 @@ class Fft2D:
         return data
 
 
+class CtfOps:
+    """CTF pre-steps on the device: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) and
+    Wiener2D::applyWienerFilter (data/wiener2d.cpp:101-141) for images of one size."""
+
+    def __init__(self, ctx, ydim, xdim, pad=1.0):
+        self.ctx, self.ydim, self.xdim = ctx, int(ydim), int(xdim)
+        h = C.c_void_p()
+        check(lib().xh_ctfop_create(ctx.h, self.ydim, self.xdim, float(pad), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_ctfop_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def phase_flip(self, img, ctf, sampling_rate):
+        """img: [ydim, xdim] float32 on the device, flipped in place"""
+        torch = _torch()
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and tuple(img.shape) == (self.ydim, self.xdim)
+        check(lib().xh_ctfop_phase_flip(self.h, _ptr(img), C.byref(ctf), float(sampling_rate)))
+        return img
+
+    def wiener2d(self, imgs, ctfs, sampling_rate=1.0, phase_flipped=False, is_isotropic=False, wiener_constant=-1.0, correct_envelope=False):
+        """imgs: [n, ydim, xdim] float32 on the device, corrected in place; ctfs: list of CtfParams or ctf_param_array"""
+        torch = _torch()
+        n = imgs.shape[0]
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous() and tuple(imgs.shape[1:]) == (self.ydim, self.xdim)
+        arr = ctfs if isinstance(ctfs, C.Array) else (CtfParams * n)(*ctfs)
+        check(lib().xh_ctfop_wiener2d(self.h, _ptr(imgs), n, arr, float(sampling_rate), int(phase_flipped), int(is_isotropic),
+                                      float(wiener_constant), int(correct_envelope)))
+        return imgs
+
+
 class FourierProjector:
     """Device side of FourierProjector (data/fourier_projection.cpp): central-slice projections of a
     volume `[z][y][x]` (float32, cuda) with cubic B-spline interpolation in Fourier space."""

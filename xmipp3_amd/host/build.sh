@@ -10,6 +10,8 @@ $CXX $FLAGS angular_projection_matching_main.cpp -o ../bin/xmipp_angular_project
 $CXX $FLAGS reconstruct_fourier_accel_main.cpp -o ../bin/xmipp_reconstruct_fourier_accel $LINK &
 $CXX $FLAGS angular_project_library_main.cpp -o ../bin/xmipp_angular_project_library $LINK &
 $CXX $FLAGS resolution_fsc_main.cpp -o ../bin/xmipp_resolution_fsc $LINK &
+$CXX $FLAGS ctf_phase_flip_main.cpp -o ../bin/xmipp_ctf_phase_flip $LINK &
+$CXX $FLAGS ctf_correct_wiener2d_main.cpp -o ../bin/xmipp_ctf_correct_wiener2d $LINK &
 wait
 cp -f ../bin/xmipp_reconstruct_fourier_accel ../bin/xmipp_reconstruct_fourier
-echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library,resolution_fsc}"
+echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library,resolution_fsc,ctf_phase_flip,ctf_correct_wiener2d}"
