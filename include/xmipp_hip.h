@@ -359,6 +359,24 @@ int xh_ctfop_phase_flip(xh_ctfop *h, float *d_img, const xh_ctf_params *ctf, dou
 int xh_ctfop_wiener2d(xh_ctfop *h, float *d_imgs /* [n][ydim][xdim] */, int32_t n, const xh_ctf_params *ctfs, double sampling_rate,
                       int32_t phase_flipped, int32_t is_isotropic, double wiener_constant, int32_t correct_envelope);
 
+/* ---- FlexAlign: global alignment of a movie (BASELINE config 5, first slice) -----------
+ * ProgMovieAlignmentCorrelationGPU<T>::computeGlobalAlignment (reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:
+ * 633-725) with the arithmetic of the CPU program (reconstruction/movie_alignment_correlation.cpp:45-157, _base.cpp:152-320,
+ * 399-418, eq_system_solver.cpp:35-106): dark / gain correction, Fourier-space reduction of every frame to the size the
+ * maximal resolution needs, Gaussian low-pass, correlation of all frame pairs, bestShift within max_shift, least squares over
+ * the pair shifts with outlier rejection, reference frame, shift of every frame from it.
+ *   create: frames of Y x X pixels at sampling_rate A/px, --maxResForCorrelation A; fails when the scale factor is >= 1.
+ *   global_alignment: d_frames [N][Y][X] float on the device, d_dark / d_gain [Y][X] or null, max_shift_px = --maxShift /
+ *   sampling rate. Host outputs: pair shifts h_bX / h_bY [N (N-1)/2] (nullable; movie pixels, order (0,1), (0,2) ...),
+ *   h_shiftX / h_shiftY [N] from the reference frame h_ref (what storeGlobalShifts negates into the metadata).
+ * The patch (local) alignment has no CPU counterpart in the reference and is not part of this entry. */
+typedef struct xh_fa xh_fa;
+int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float max_res_for_correlation, xh_fa **out);
+int xh_fa_destroy(xh_fa *h);
+int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor);
+int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, float max_shift_px,
+                           double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,9 @@ def lib():
         "xo_ctf_defaults": (None, [C.POINTER(CtfParams)]),
         "xo_ctf_value_pure_nok": (d, [C.POINTER(CtfParams), d, d]),
         "xo_ctf_lambda": (d, [C.POINTER(CtfParams)]),
+        "xo_fa_global_alignment": (C.c_int, [c_double_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, C.c_float, C.c_float, C.c_float,
+                                             c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "xo_fa_solve": (None, [c_double_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]),
         "xo_ctf_phase_flip": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), C.c_int]),
         "xo_ctf_wiener2d": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), d, d, C.c_int, C.c_int, d, C.c_int]),
         "xo_rf_create": (vp, [C.POINTER(RfParams)]),
@@ -369,6 +372,31 @@ class PM:
 
 
 # ---------------------------------------------------------------- reconstruction
+def fa_global_alignment(frames, Ts=1.0, max_shift_px=50.0, max_res=30.0, dark=None, igain=None):
+    """ProgMovieAlignmentCorrelation<double>::computeGlobalAlignment on frames [N, Y, X]: dict with the pair shifts, the
+    frame shifts from the reference frame (movie pixels), the reference frame and the size of the reduced frames."""
+    fr = f64(frames)
+    N, Y, X = fr.shape
+    rows = N * (N - 1) // 2
+    bx, by, sx, sy = np.empty(rows), np.empty(rows), np.empty(N), np.empty(N)
+    ref, nd = C.c_int(0), (C.c_int * 2)()
+    dk = None if dark is None else f64(dark)
+    ig = None if igain is None else f64(igain)
+    rc = lib().xo_fa_global_alignment(_dp(fr), N, Y, X, None if dk is None else _dp(dk), None if ig is None else _dp(ig), Ts, max_shift_px,
+                                      max_res, _dp(bx), _dp(by), _dp(sx), _dp(sy), C.byref(ref), nd)
+    if rc != 0:
+        raise ValueError("the correlation scale factor is >= 1 (checkSettings)")
+    return {"bX": bx, "bY": by, "shiftX": sx, "shiftY": sy, "ref": ref.value, "new_dims": (nd[0], nd[1])}
+
+
+def fa_solve(bX, bY, N, iterations=2):
+    bx, by = f64(bX), f64(bY)
+    sx, sy = np.empty(N), np.empty(N)
+    ref = C.c_int(0)
+    lib().xo_fa_solve(_dp(bx), _dp(by), N, iterations, _dp(sx), _dp(sy), C.byref(ref))
+    return sx, sy, ref.value
+
+
 def ctf_phase_flip(img, ctf, with_damping=False):
     """actualPhaseFlip (ctf_phase_flip.cpp:88-117); ctf.Tm = sampling rate of the image. with_damping: CTFDescription::correctPhase."""
     out = f64(img).copy()

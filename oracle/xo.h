@@ -136,6 +136,12 @@ void xo_ctf_phase_flip(double *img, int ydim, int xdim, const xo_ctf_params *ctf
 void xo_ctf_wiener2d(double *img, int ydim, int xdim, const xo_ctf_params *ctf, double sampling_rate, double pad,
                      int phase_flipped, int is_isotropic, double wiener_constant, int correct_envelope);
 
+/* ---- FlexAlign, global alignment (reconstruction/movie_alignment_correlation.cpp:45-157 + _base.cpp + eq_system_solver.cpp) -- */
+int xo_fa_global_alignment(const double *frames, int N, int Y, int X, const double *dark, const double *igain, float Ts,
+                           float maxShift, float maxRes, double *bX, double *bY, double *shiftX, double *shiftY, int *refFrame,
+                           int *newDims);
+void xo_fa_solve(const double *bX, const double *bY, int N, int iterations, double *shiftX, double *shiftY, int *refFrame);
+
 /* ---- Fourier reconstruction (RFA) ---------------------------------------- */
 typedef struct {
     int imgSize;              /* D */

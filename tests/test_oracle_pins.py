@@ -124,6 +124,39 @@ def test_ctf_phase_flip_pin(oracle):
     assert np.allclose(np.abs(np.fft.rfft2(f)), np.abs(np.fft.rfft2(delta)), atol=1e-12)
 
 
+def test_flexalign_global_alignment_recovers_a_known_drift(oracle):
+    """The reference holds no known answer for the movie alignment that runs without CUDA (PARITY UNPINNED, oracle/xo_flexalign.cpp);
+    the restatement is checked on physics: a synthetic movie with a known drift. The shifts it reports are the negatives of
+    the frames' displacements from the reference frame (storeGlobalShifts negates them once more into "the shift to apply"),
+    pair shifts are consistent, and the solver alone reproduces exact shifts from exact pair shifts, outlier included."""
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    Y, X, N = 240, 320, 6
+    base = ndimage.gaussian_filter(rng.standard_normal((Y + 64, X + 64)), 3.0) * 10
+    drift = np.cumsum(rng.uniform(-1.5, 1.5, (N, 2)), 0)
+    drift -= drift[0]
+    frames = np.stack([ndimage.shift(base, (-drift[i, 1], -drift[i, 0]), order=3, mode="wrap")[32:32 + Y, 32:32 + X]
+                       + 0.5 * rng.standard_normal((Y, X)) for i in range(N)])
+    r = oracle.fa_global_alignment(frames, Ts=1.0, max_shift_px=20.0, max_res=8.0)
+    assert r["new_dims"] == (int(Y * 0.8493218 * 8 / 8.0), int(X * 0.8493218 * 8 / 8.0))
+    t = drift - drift[r["ref"]]
+    assert np.abs(r["shiftX"] + t[:, 0]).max() < 0.6 and np.abs(r["shiftY"] + t[:, 1]).max() < 0.6
+    assert np.corrcoef(r["shiftX"], -t[:, 0])[0, 1] > 0.95
+    # the solver: exact pair shifts (one of them corrupted) give back the exact frame-to-frame shifts
+    s = rng.uniform(-2, 2, (7, 2))                         # shifts between successive frames of an 8-frame movie
+    bx, by = [], []
+    for i in range(7):
+        for j in range(i + 1, 8):
+            bx.append(s[i:j, 0].sum()); by.append(s[i:j, 1].sum())
+    bx, by = np.array(bx), np.array(by)
+    bx[5] += 40.0                                          # an outlier: rejected by the 3-sigma round
+    sx, sy, ref = oracle.fa_solve(bx, by, 8)
+    for j in range(8):
+        tx = -s[ref:j, 0].sum() if ref < j else s[j:ref, 0].sum()
+        assert abs(sx[j] - tx) < 1e-9
+    assert ref == int(np.argmin([max(abs(-s[i:j, 0].sum() if i < j else s[j:i, 0].sum()) for j in range(8)) for i in range(8)]))
+
+
 def test_prefilter_inverts_bspline_sampling(oracle):
     # coefficients c reproduce the samples: s[k] = (c[k-1] + 4 c[k] + c[k+1]) / 6 with
     # half-sample mirror (c[-1] = c[0], c[n] = c[n-1])  (SURVEY.md Appendix B)

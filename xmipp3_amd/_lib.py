@@ -75,6 +75,10 @@ SIGNATURES = {
     "xh_rf_cropped_import": (C.c_int, [vp, vp, i32]),
     "xh_rf_reduce": (C.c_int, [pvp, i32]),
     "xh_rf_finish": (C.c_int, [vp, vp]),
+    "xh_fa_create": (C.c_int, [vp, i32, i32, C.c_float, C.c_float, pvp]),
+    "xh_fa_destroy": (C.c_int, [vp]),
+    "xh_fa_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(d)]),
+    "xh_fa_global_alignment": (C.c_int, [vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, C.POINTER(i32)]),
     "xh_ctfop_create": (C.c_int, [vp, i32, i32, d, pvp]),
     "xh_ctfop_destroy": (C.c_int, [vp]),
     "xh_ctfop_phase_flip": (C.c_int, [vp, vp, C.POINTER(CtfParams), d]),

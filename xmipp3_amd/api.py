@@ -360,6 +360,44 @@ class Fft2D:
         return data
 
 
+class FlexAlign:
+    """Global alignment of a movie (ProgMovieAlignmentCorrelation*::computeGlobalAlignment) for frames of one size."""
+
+    def __init__(self, ctx, Y, X, sampling_rate=1.0, max_res=30.0):
+        self.ctx, self.Y, self.X = ctx, int(Y), int(X)
+        h = C.c_void_p()
+        check(lib().xh_fa_create(ctx.h, self.Y, self.X, float(sampling_rate), float(max_res), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        a, b, f = C.c_int32(), C.c_int32(), C.c_double()
+        check(lib().xh_fa_info(h, C.byref(a), C.byref(b), C.byref(f)))
+        self.new_dims, self.size_factor = (a.value, b.value), f.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_fa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def global_alignment(self, frames, max_shift_px, dark=None, gain=None):
+        """frames [N, Y, X] float32 on the device -> dict(bX, bY, shiftX, shiftY, ref)"""
+        torch = _torch()
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape[1:]) == (self.Y, self.X)
+        N = frames.shape[0]
+        rows = N * (N - 1) // 2
+        bx, by, sx, sy = np.empty(rows), np.empty(rows), np.empty(N), np.empty(N)
+        ref = C.c_int32(0)
+        check(lib().xh_fa_global_alignment(self.h, _ptr(frames), N, _ptr(dark, torch.float32), _ptr(gain, torch.float32), float(max_shift_px),
+                                           _np_ptr(bx), _np_ptr(by), _np_ptr(sx), _np_ptr(sy), C.byref(ref)))
+        return {"bX": bx, "bY": by, "shiftX": sx, "shiftY": sy, "ref": ref.value}
+
+
 class CtfOps:
     """CTF pre-steps on the device: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) and
     Wiener2D::applyWienerFilter (data/wiener2d.cpp:101-141) for images of one size."""

@@ -1094,8 +1094,10 @@ k_rf_c2r_window(const xh_cd *__restrict__ F, XhPlan<double> plan, double *__rest
         const double xs = radius / (2 * D);
         const double sinc = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
         const double factor2 = sinc * sinc;
-        val /= (ipad_relation * factor2 * factor);
-        vol[((size_t)k * D + ii) * D + j] = val * meanFactor2;
+        // meanFactor2 < 0: xmipp_reconstruct_fourier --iter 0 divides by the blob transform only (RF:1160-1166)
+        if (meanFactor2 < 0) val /= (ipad_relation * factor);
+        else val = val / (ipad_relation * factor2 * factor) * meanFactor2;
+        vol[((size_t)k * D + ii) * D + j] = val;
     }
 }
 
@@ -1135,6 +1137,67 @@ static int make_twiddles(xh_ctx *ctx, int n, XhBuf &b32, XhBuf &b64)
     XH_TRY(xh_buf_alloc(ctx, b64, sizeof(xh_cd) * (n / 2)));
     XH_HIP(hipMemcpy(b32.p, w32.data(), b32.bytes, hipMemcpyHostToDevice));
     XH_HIP(hipMemcpy(b64.p, w64.data(), b64.bytes, hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+// Tail of finishComputations (RFA:1017-1054 / RF:1127-1178) shared by the two programs: the expanded spectrum (P x P x (P/2+1) complex
+// doubles, FFTW layout) -> inverse transform, CenterFFT, window to D^3, blob (and sinc^2) correction -> host volume.
+static int finish_from_spectrum(xh_ctx *ctx, const XhPlan<double> &plan, xh_cd *specp, double *volp, const double *fbtp, int D, double iDeltaFourier,
+                                double padding_proj, double padding_vol, double &meanFactor2Cache, bool sincCorrection, double *h_volume)
+{
+    const int P = plan.n, xh = P / 2 + 1;
+    struct { void *p; } spec{specp}, vol{volp}, fbt{(void *)fbtp};
+    const size_t volBytes = sizeof(double) * (size_t)D * D * D;
+#define XH_HIP_C(call) XH_HIP(call)
+    const int lpb = xh_plan_lpb(plan, 64 * 1024, 8);
+    const size_t smem = ((size_t)lpb * sizeof(xh_cd)) << plan.logM;
+    // inverse along z: lines (y,x), element stride P*xh
+    {
+        const size_t nlines = (size_t)P * xh;
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           (xh_cd *)spec.p, plan, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
+        XH_HIP_C(hipGetLastError());
+    }
+    // inverse along y: lines (z,x): offset z*P*xh + x, element stride xh
+    {
+        const size_t nlines = (size_t)P * xh;
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                           (xh_cd *)spec.p, plan, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
+        XH_HIP_C(hipGetLastError());
+    }
+    // meanFactor2 = mean over the D^3 window of sinc^2(radius/(2D)) (RFA:1040-1050). It depends on D only:
+    // computed once, grouped by the integer squared radius (the grouping changes the sum by ~1e-15 relative).
+    if (meanFactor2Cache < 0) {
+        const int s0 = -(D / 2), s1 = s0 + D - 1;
+        const int maxr2 = 3 * std::max(s0 * s0, s1 * s1);
+        std::vector<long long> cnt((size_t)maxr2 + 1, 0);
+        std::vector<int> c1(D);
+        for (int i = 0; i < D; ++i) c1[i] = (i + s0) * (i + s0);
+        for (int k = 0; k < D; ++k)
+            for (int i = 0; i < D; ++i) {
+                const int b = c1[k] + c1[i];
+                for (int j = 0; j < D; ++j) ++cnt[b + c1[j]];
+            }
+        double acc = 0;
+        for (int r2 = 0; r2 <= maxr2; ++r2)
+            if (cnt[r2]) {
+                const double radius = std::sqrt((double)r2);
+                const double xs = radius / (2 * D);
+                const double sinc = (xs == 0) ? 1.0 : std::sin(kPI * xs) / (kPI * xs);
+                acc += (double)cnt[r2] * std::pow(sinc, 2);
+            }
+        meanFactor2Cache = acc / ((double)D * D * D);
+    }
+    const double meanFactor2 = sincCorrection ? meanFactor2Cache : -1.0;
+    const double pr0 = padding_proj / padding_vol;
+    const double ipad_relation = 1.0 / (pr0 * pr0 * pr0);
+    hipLaunchKernelGGL(k_rf_c2r_window, dim3((unsigned)(((size_t)D * D + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
+                       (const xh_cd *)spec.p, plan, (double *)vol.p, (const double *)fbt.p, D,
+                       iDeltaFourier, ipad_relation, meanFactor2, lpb);
+    XH_HIP_C(hipGetLastError());
+    XH_HIP_C(hipMemcpyAsync(h_volume, vol.p, volBytes, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP_C(hipStreamSynchronize(ctx->stream));
+#undef XH_HIP_C
     return XH_OK;
 }
 
@@ -2071,55 +2134,11 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     XH_HIP_C(hipMemcpyAsync(fbt.p, rf->fourierBlobTable.data(), fbt.bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_rf_expand, dim3((unsigned)((specElems + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)V, (xh_cd *)spec.p, mv, P);
     XH_HIP_C(hipGetLastError());
-    const XhPlan<double> &plan = rf->planP64.plan;
-    const int lpb = xh_plan_lpb(plan, 64 * 1024, 8);
-    const size_t smem = ((size_t)lpb * sizeof(xh_cd)) << plan.logM;
-    // inverse along z: lines (y,x), element stride P*xh
     {
-        const size_t nlines = (size_t)P * xh;
-        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           (xh_cd *)spec.p, plan, nlines, nlines, (size_t)0, (size_t)1, (size_t)P * xh, lpb);
-        XH_HIP_C(hipGetLastError());
+        const int rc = finish_from_spectrum(ctx, rf->planP64.plan, (xh_cd *)spec.p, (double *)vol.p, (const double *)fbt.p, D, (double)rf->iDeltaFourier,
+                                            rf->p.padding_proj, rf->p.padding_vol, rf->meanFactor2, true, h_volume);
+        if (rc != XH_OK) { cleanup(); return rc; }
     }
-    // inverse along y: lines (z,x): offset z*P*xh + x, element stride xh
-    {
-        const size_t nlines = (size_t)P * xh;
-        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                           (xh_cd *)spec.p, plan, nlines, (size_t)xh, (size_t)P * xh, (size_t)1, (size_t)xh, lpb);
-        XH_HIP_C(hipGetLastError());
-    }
-    // meanFactor2 = mean over the D^3 window of sinc^2(radius/(2D)) (RFA:1040-1050). It depends on D only:
-    // computed once, grouped by the integer squared radius (the grouping changes the sum by ~1e-15 relative).
-    if (rf->meanFactor2 < 0) {
-        const int s0 = -(D / 2), s1 = s0 + D - 1;
-        const int maxr2 = 3 * std::max(s0 * s0, s1 * s1);
-        std::vector<long long> cnt((size_t)maxr2 + 1, 0);
-        std::vector<int> c1(D);
-        for (int i = 0; i < D; ++i) c1[i] = (i + s0) * (i + s0);
-        for (int k = 0; k < D; ++k)
-            for (int i = 0; i < D; ++i) {
-                const int b = c1[k] + c1[i];
-                for (int j = 0; j < D; ++j) ++cnt[b + c1[j]];
-            }
-        double acc = 0;
-        for (int r2 = 0; r2 <= maxr2; ++r2)
-            if (cnt[r2]) {
-                const double radius = std::sqrt((double)r2);
-                const double xs = radius / (2 * D);
-                const double sinc = (xs == 0) ? 1.0 : std::sin(kPI * xs) / (kPI * xs);
-                acc += (double)cnt[r2] * std::pow(sinc, 2);
-            }
-        rf->meanFactor2 = acc / ((double)D * D * D);
-    }
-    const double meanFactor2 = rf->meanFactor2;
-    const double pr0 = rf->p.padding_proj / rf->p.padding_vol;
-    const double ipad_relation = 1.0 / (pr0 * pr0 * pr0);
-    hipLaunchKernelGGL(k_rf_c2r_window, dim3((unsigned)(((size_t)D * D + lpb - 1) / lpb)), dim3(256), smem, ctx->stream,
-                       (const xh_cd *)spec.p, plan, (double *)vol.p, (const double *)fbt.p, D,
-                       (double)rf->iDeltaFourier, ipad_relation, meanFactor2, lpb);
-    XH_HIP_C(hipGetLastError());
-    XH_HIP_C(hipMemcpyAsync(h_volume, vol.p, vol.bytes, hipMemcpyDeviceToHost, ctx->stream));
-    XH_HIP_C(hipStreamSynchronize(ctx->stream));
 #undef XH_HIP_C
     cleanup();
     return XH_OK;
