@@ -343,6 +343,31 @@ int xh_fft2d_destroy(xh_fft2d *f);
 int xh_fft2d_factors(const xh_fft2d *f, int32_t *h_factors);
 int xh_fft2d_exec(xh_fft2d *f, float *d_data /* [ny][nx][2] */, int32_t inverse);
 
+/* ---- ProgRecFourier's own arithmetic: the program behind xmipp_reconstruct_fourier ----------
+ * reconstruction/reconstruct_fourier.cpp: double accumulators, image-driven scatter into the FFTW-layout Fourier volume with
+ * wrap and, beyond the half, the point-mirrored conjugated slot (RF:571-793), correctWeight with its re-processing passes
+ * (RF:1056-1101), enforceHermitianSymmetry + PROCESS_WEIGHTS + inverse transform + corrections (RF:451-480,1103-1178).
+ *   create   == produceSideInfo (RF:184-287); niter_weight = --iter (0: weights set to one).
+ *   insert   == processImages over n projections (shifts already applied, D x D floats on the device): their transform in
+ *               double, then the scatter with double-precision atomics; h_ctf nullable (--useCTF, RF:600-625), h_angles
+ *               (rot, tilt, psi), h_weights nullable, h_sym nsym x 9 nullable. reprocess != 0: the weight re-processing pass
+ *               (images ignored).
+ *   weights_step == correctWeight: 0 begin; per further iteration { 1; replay every projection with reprocess = 1; 2 }; 3 end.
+ *   finish   == finishComputations -> D^3 doubles on the host; the Fourier volume and weights stay (state_export / import
+ *               [F (2 nF) | W (nF)] doubles keep the halves of --prepare_fsc, RF:991-1045).
+ * Built for exactness (BASELINE config 1's plumbing path); the accel program is the fast one. */
+typedef struct xh_rf2 xh_rf2;
+int xh_rf2_create(xh_ctx *ctx, const xh_rf_params *p, int32_t niter_weight, xh_rf2 **out);
+int xh_rf2_destroy(xh_rf2 *h);
+int xh_rf2_reset(xh_rf2 *h);
+int xh_rf2_insert(xh_rf2 *h, const float *d_imgs, const xh_ctf_params *h_ctf, const double *h_angles, const float *h_weights, int32_t n,
+                  const double *h_sym, int32_t nsym, int32_t reprocess);
+int xh_rf2_weights_step(xh_rf2 *h, int32_t step);
+size_t xh_rf2_state_doubles(const xh_rf2 *h);
+int xh_rf2_state_export(xh_rf2 *h, double *d_dst);
+int xh_rf2_state_import(xh_rf2 *h, const double *d_src, int32_t add);
+int xh_rf2_finish(xh_rf2 *h, double *h_volume);
+
 /* ---- CTF pre-steps -------------------------------------------------------------------
  * xmipp_ctf_phase_flip: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) -- the coefficients of a micrograph where
  * the undamped CTF (getValuePureWithoutDampingAt, data/ctf.h:541-570) is negative change sign.

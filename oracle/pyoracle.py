@@ -572,25 +572,30 @@ class RF2:
         except Exception:
             pass
 
-    def _insert(self, img, A, R, weight, reprocess):
-        lib().xo_rf2_insert(self.h, _dp(img), _dp(A), _dp(R), float(weight), None, 1.0, 0.01, 0, int(reprocess))
+    def _insert(self, img, A, R, weight, reprocess, ctf=None):
+        lib().xo_rf2_insert(self.h, _dp(img), _dp(A), _dp(R), float(weight), None if ctf is None else C.byref(ctf), 1.0 / self.sampling,
+                            self.min_ctf, int(self.phase_flipped), int(reprocess))
 
-    def insert(self, img, euler_T, R=None, weight=1.0):
+    sampling, min_ctf, phase_flipped = 1.0, 0.01, False      # --sampling, --minCTF, --phaseFlipped (RF:48-56)
+
+    def insert(self, img, euler_T, R=None, weight=1.0, ctf=None):
         img = f64(img)
         A = f64(euler_T)
         R = f64(np.eye(3) if R is None else R)
         self.images.append((img, A, R, weight))
-        self._insert(img, A, R, weight, 0)
+        self._insert(img, A, R, weight, 0, ctf)
 
-    def finish(self):
+    def finish(self, correct_weight=True):
+        """correct_weight=False: finishComputations as --prepare_fsc calls it for the two halves (RF:991-1045), before correctWeight"""
         L = lib()
-        L.xo_rf2_weights_begin(self.h)                      # correctWeight, RF:1056-1101
-        for _ in range(1, self.niter):
-            L.xo_rf2_weights_iter_begin(self.h)
-            for img, A, R, w in self.images:
-                self._insert(img, A, R, w, 1)
-            L.xo_rf2_weights_iter_end(self.h)
-        L.xo_rf2_weights_end(self.h)
+        if correct_weight:
+            L.xo_rf2_weights_begin(self.h)                      # correctWeight, RF:1056-1101
+            for _ in range(1, self.niter):
+                L.xo_rf2_weights_iter_begin(self.h)
+                for img, A, R, w in self.images:
+                    self._insert(img, A, R, w, 1)
+                L.xo_rf2_weights_iter_end(self.h)
+            L.xo_rf2_weights_end(self.h)
         out = np.empty((self.D,) * 3, np.float64)
         L.xo_rf2_finish(self.h, _dp(out))
         return out

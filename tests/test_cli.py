@@ -25,7 +25,7 @@ def _run(args, **kw):
 
 def test_help_and_argument_errors(bins):
     for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier",
-                 "xmipp_angular_project_library", "xmipp_resolution_fsc", "xmipp_ctf_phase_flip", "xmipp_ctf_correct_wiener2d"):
+                 "xmipp_angular_project_library", "xmipp_resolution_fsc", "xmipp_ctf_phase_flip", "xmipp_ctf_correct_wiener2d", "xmipp_movie_alignment_correlation"):
         r = _run([os.path.join(bins, prog), "--help"])
         assert r.returncode == 0 and "USAGE" in r.stderr
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-o", "x.xmd"])
@@ -220,7 +220,7 @@ def test_cli_several_devices_give_the_single_device_answer(bins, tmp_path):
 
 @pytest.mark.gpu
 def test_cli_prepare_fsc_writes_the_two_half_set_volumes(bins, tmp_path):
-    """xmipp_reconstruct_fourier --prepare_fsc <root> (RF:846,991-1045): images 0..(n-1)/2 -> <root>_1_recons.vol,
+    """xmipp_reconstruct_fourier_accel --prepare_fsc <root> (the bookkeeping of RF:846,991-1045 on the accel arithmetic): images 0..(n-1)/2 -> <root>_1_recons.vol,
     the rest -> <root>_2_recons.vol, output volume = reconstruction from the summed halves."""
     D, n = 32, 9
     vol = synth.phantom(D, seed=8, nblobs=10)
@@ -235,7 +235,7 @@ def test_cli_prepare_fsc_writes_the_two_half_set_volumes(bins, tmp_path):
     split = (n - 1) // 2          # FSCIndex, included in half 1
     write("h1.xmd", range(0, split + 1))
     write("h2.xmd", range(split + 1, n))
-    rf = os.path.join(bins, "xmipp_reconstruct_fourier")
+    rf = os.path.join(bins, "xmipp_reconstruct_fourier_accel")
     r = _run([rf, "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "all.vol"), "--prepare_fsc", str(tmp_path / "fsc"), "--devices", "0,0"])
     assert r.returncode == 0, r.stderr
     for name in ("plain", "h1", "h2"):
@@ -262,7 +262,7 @@ def test_cli_half_sets_then_resolution_fsc(bins, tmp_path, oracle):
     xmipp_io.write_stack(str(tmp_path / "p.stk"), imgs)
     xmipp_io.write_xmd(str(tmp_path / "all.xmd"), [("noname", ["image", "angleRot", "angleTilt", "anglePsi"],
                        [[f"{i + 1}@{tmp_path}/p.stk"] + [f"{v:.6f}" for v in ang[i]] for i in range(n)])])
-    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier"), "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "all.vol"),
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "all.vol"),
               "--prepare_fsc", str(tmp_path / "fsc")])
     assert r.returncode == 0, r.stderr
     fsc = os.path.join(bins, "xmipp_resolution_fsc")
@@ -480,3 +480,94 @@ def test_cli_ctf_phase_flip_and_wiener2d(bins, tmp_path, oracle):
     # postProcess (ctf_correct_wiener2d.cpp:58-93): the defoci and K are gone, the image column names the new stack
     assert "ctfDefocusU" not in labels and "ctfK" not in labels and "shiftX" in labels and "ctfVoltage" in labels
     assert len(orows) == n and orows[2][labels.index("image")] == f"3@{tmp_path}/corrected.stk"
+
+
+@pytest.mark.gpu
+def test_cli_reconstruct_fourier_is_the_double_precision_program(bins, tmp_path, oracle):
+    """BASELINE config 1's binary: xmipp_reconstruct_fourier = ProgRecFourier (reconstruction/reconstruct_fourier.cpp) with its own
+    arithmetic on the device. Against oracle.RF2 on the same files' contents: --iter 1 (default), --iter 0 (weights set to one,
+    RF:1058-1064), --iter 3 (re-processing passes), symmetry and --weight; 1e-6 of the peak (the file holds floats).
+    --prepare_fsc: the halves are finished as the reference finishes them (no correctWeight, RF:991-1045), the final volume
+    is the plain one; several device slots sum to the same volume."""
+    D, n = 32, 30
+    vol = synth.phantom(D, seed=8, nblobs=10)
+    rng = np.random.default_rng(5)
+    ang = synth.random_angles(n, rng)
+    imgs = np.stack([synth.project(vol, *a) for a in ang]).astype(np.float32)
+    w = np.round(rng.uniform(0.2, 2.0, n), 3)
+    xmipp_io.write_stack(str(tmp_path / "p.stk"), imgs)
+    xmipp_io.write_xmd(str(tmp_path / "all.xmd"), [("noname", ["image", "angleRot", "angleTilt", "anglePsi", "weight"],
+                       [[f"{i + 1}@{tmp_path}/p.stk"] + [f"{v:.6f}" for v in ang[i]] + [f"{w[i]:.6f}"] for i in range(n)])])
+    rf = os.path.join(bins, "xmipp_reconstruct_fourier")
+    h_ang = np.round(ang, 6)
+    c2 = np.diag([-1.0, -1.0, 1.0])
+
+    def expected(niter, use_w, sym):
+        o = oracle.RF2(D, niter_weight=niter)
+        for i in range(n):
+            for R in sym:
+                o.insert(imgs[i], synth.euler_matrix(*h_ang[i]).T, R=R, weight=float(w[i]) if use_w else 1.0)
+        return o.finish()
+
+    cases = [([], 1, False, [np.eye(3)]), (["--iter", "0"], 0, False, [np.eye(3)]), (["--iter", "3", "--weight", "--sym", "c2", "--batch", "7"], 3, True, [np.eye(3), c2])]
+    for k, (flags, niter, use_w, sym) in enumerate(cases):
+        r = _run([rf, "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / f"v{k}.vol")] + flags)
+        assert r.returncode == 0, r.stderr
+        got = xmipp_io.read_volume(str(tmp_path / f"v{k}.vol"))
+        exp = expected(niter, use_w, sym)
+        assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max(), (flags, np.abs(got - exp).max() / np.abs(exp).max())
+    plain = xmipp_io.read_volume(str(tmp_path / "v0.vol"))
+    r = _run([rf, "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "f.vol"), "--prepare_fsc", str(tmp_path / "fsc"), "--devices", "0,0"])
+    assert r.returncode == 0, r.stderr
+    assert np.abs(xmipp_io.read_volume(str(tmp_path / "f.vol")) - plain).max() <= 1e-6 * np.abs(plain).max()
+    split = (n - 1) // 2
+    for name, idx in (("fsc_1_recons.vol", range(0, split + 1)), ("fsc_2_recons.vol", range(split + 1, n))):
+        o = oracle.RF2(D, niter_weight=1)
+        for i in idx:
+            o.insert(imgs[i], synth.euler_matrix(*h_ang[i]).T)
+        exp = o.finish(correct_weight=False)
+        got = xmipp_io.read_volume(str(tmp_path / name))
+        assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max()
+    # the accel program refuses nothing it used to accept; --fast belongs to it alone
+    r = _run([rf, "-i", str(tmp_path / "all.xmd"), "-o", str(tmp_path / "x.vol"), "--fast"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_movie_global_alignment(bins, tmp_path, oracle):
+    """xmipp_movie_alignment_correlation --skipLocalAlignment (movie_alignment_correlation_base.cpp:36-68,364-396,560-600): the
+    shifts written to frameShifts@out.xmd are the negatives of the oracle's estimated shifts (storeGlobalShifts), the frames
+    outside --frameRange are disabled, referenceFrame@out.xmd names the reference frame; dark and gain are applied."""
+    from tests.test_gpu_flexalign import synthetic_movie
+    N, Y, X = 7, 200, 260
+    frames, drift = synthetic_movie(N, Y, X, seed=11)
+    rng = np.random.default_rng(2)
+    dark = (0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    gain = (1.0 + 0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    xmipp_io.write_stack(str(tmp_path / "dark.stk"), dark[None])
+    xmipp_io.write_stack(str(tmp_path / "gain.stk"), gain[None])
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "out.xmd"), "--sampling", "1.25", "--maxShift", "25",
+              "--maxResForCorrelation", "10", "--frameRange", "1", "5", "--dark", f"1@{tmp_path}/dark.stk", "--gain", f"1@{tmp_path}/gain.stk",
+              "--skipLocalAlignment", "--oavgInitial", str(tmp_path / "initial.spi")])
+    assert r.returncode == 0, r.stderr
+    exp = oracle.fa_global_alignment(frames[1:6], Ts=1.25, max_shift_px=25.0 / 1.25, max_res=10.0, dark=dark, igain=gain)
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"), block="frameShifts")
+    c = {l: i for i, l in enumerate(labels)}
+    assert len(rows) == N
+    for n, row in enumerate(rows):
+        if 1 <= n <= 5:
+            assert int(float(row[c["enabled"]])) == 1
+            assert abs(float(row[c["shiftX"]]) + exp["shiftX"][n - 1]) < 3e-3 and abs(float(row[c["shiftY"]]) + exp["shiftY"][n - 1]) < 3e-3
+        else:
+            assert int(float(row[c["enabled"]])) == -1 and float(row[c["shiftX"]]) == 0.0
+    _, ref_rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"), block="referenceFrame")
+    assert int(float(ref_rows[0][0])) == 1 + exp["ref"]
+    ini = xmipp_io.read_volume(str(tmp_path / "initial.spi"))[0]
+    assert np.abs(ini - ((frames[1:6] - dark) * gain).mean(0)).max() < 1e-4
+    # the local alignment and the aligned outputs are refused loudly, as is a scale factor >= 1
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.xmd")])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "--skipLocalAlignment" in r.stderr
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.xmd"), "--skipLocalAlignment", "--sampling", "5", "--maxResForCorrelation", "10"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "scale factor" in r.stderr

@@ -75,6 +75,15 @@ SIGNATURES = {
     "xh_rf_cropped_import": (C.c_int, [vp, vp, i32]),
     "xh_rf_reduce": (C.c_int, [pvp, i32]),
     "xh_rf_finish": (C.c_int, [vp, vp]),
+    "xh_rf2_create": (C.c_int, [vp, C.POINTER(RfParams), i32, pvp]),
+    "xh_rf2_destroy": (C.c_int, [vp]),
+    "xh_rf2_reset": (C.c_int, [vp]),
+    "xh_rf2_insert": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32, i32]),
+    "xh_rf2_weights_step": (C.c_int, [vp, i32]),
+    "xh_rf2_state_doubles": (sz, [vp]),
+    "xh_rf2_state_export": (C.c_int, [vp, vp]),
+    "xh_rf2_state_import": (C.c_int, [vp, vp, i32]),
+    "xh_rf2_finish": (C.c_int, [vp, vp]),
     "xh_fa_create": (C.c_int, [vp, i32, i32, C.c_float, C.c_float, pvp]),
     "xh_fa_destroy": (C.c_int, [vp]),
     "xh_fa_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(d)]),

@@ -295,6 +295,60 @@ class RecFourier:
         return out
 
 
+class RecFourier2:
+    """Device side of ProgRecFourier (reconstruction/reconstruct_fourier.cpp), the double-precision program behind the name
+    xmipp_reconstruct_fourier. Keeps what it inserted so that finish() can replay it for --iter > 1 (correctWeight)."""
+
+    def __init__(self, ctx, imgSize, padding_proj=2.0, padding_vol=2.0, max_resolution=0.5, blob_radius=1.9, blob_order=0, blob_alpha=15.0,
+                 niter_weight=1, phase_flipped=False, min_ctf=0.01, sampling=1.0):
+        self.ctx, self.D, self.niter = ctx, int(imgSize), int(niter_weight)
+        p = RfParams(self.D, padding_proj, padding_vol, max_resolution, blob_radius, int(blob_order), blob_alpha, 0, int(phase_flipped), min_ctf, sampling)
+        h = C.c_void_p()
+        check(lib().xh_rf2_create(ctx.h, C.byref(p), self.niter, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        self._calls = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_rf2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _insert(self, imgs, ctfs, ang, w, s, reprocess):
+        n = ang.shape[0]
+        arr = None if ctfs is None else (ctfs if isinstance(ctfs, C.Array) else (CtfParams * n)(*ctfs))
+        check(lib().xh_rf2_insert(self.h, _ptr(imgs), arr, _np_ptr(ang), _np_ptr(w), n, _np_ptr(s), 0 if s is None else s.shape[0], int(reprocess)))
+
+    def insert(self, imgs, angles, weights=None, sym=None, ctfs=None):
+        torch = _torch()
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
+        ang = np.ascontiguousarray(angles, np.float64).reshape(-1, 3)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        s = None if sym is None else np.ascontiguousarray(sym, np.float64).reshape(-1, 9)
+        self._insert(imgs, ctfs, ang, w, s, 0)
+        self._calls.append((ang, w, s))
+
+    def finish(self):
+        L = lib()
+        check(L.xh_rf2_weights_step(self.h, 0))
+        for _ in range(1, self.niter):
+            check(L.xh_rf2_weights_step(self.h, 1))
+            for ang, w, s in self._calls:
+                self._insert(None, None, ang, w, s, 1)
+            check(L.xh_rf2_weights_step(self.h, 2))
+        check(L.xh_rf2_weights_step(self.h, 3))
+        out = np.empty((self.D,) * 3, np.float64)
+        check(L.xh_rf2_finish(self.h, _np_ptr(out)))
+        return out
+
+
 def reduce_reconstructions(rfs):
     """Sum the cropped spaces of several handles of this process (one per device) into rfs[0]:
     the thread-per-device counterpart of allreduce_reconstruction (xh_rf_reduce)."""

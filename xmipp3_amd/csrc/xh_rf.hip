@@ -1140,6 +1140,17 @@ static int make_twiddles(xh_ctx *ctx, int n, XhBuf &b32, XhBuf &b64)
     return XH_OK;
 }
 
+__global__ void __launch_bounds__(256) k_rf_scale_cd(xh_cd *__restrict__ v, size_t n, double f)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) { v[t].x *= f; v[t].y *= f; }
+}
+__global__ void __launch_bounds__(256) k_rf_add_d(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) dst[t] += src[t];
+}
+
 // Tail of finishComputations (RFA:1017-1054 / RF:1127-1178) shared by the two programs: the expanded spectrum (P x P x (P/2+1) complex
 // doubles, FFTW layout) -> inverse transform, CenterFFT, window to D^3, blob (and sinc^2) correction -> host volume.
 static int finish_from_spectrum(xh_ctx *ctx, const XhPlan<double> &plan, xh_cd *specp, double *volp, const double *fbtp, int D, double iDeltaFourier,
@@ -2142,6 +2153,410 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
 #undef XH_HIP_C
     cleanup();
     return XH_OK;
+}
+
+
+}  // extern "C"
+
+// =====================================================================================================================
+// ProgRecFourier's own arithmetic (reconstruction/reconstruct_fourier.cpp, "RF"): the program behind the name
+// xmipp_reconstruct_fourier. Everything in double: the padded projection's transform (RF:386-404), the image-driven scatter
+// of every Fourier pixel within --max_resolution into the FFTW-layout volume with wrap and, beyond the half, the point-mirrored
+// conjugated slot (RF:571-793), correctWeight with its re-processing passes (RF:1056-1101, forceWeightSymmetry RF:1186-1221),
+// enforceHermitianSymmetry + PROCESS_WEIGHTS (RF:451-480,1103-1126) and the shared finaliser tail. The scatter adds with
+// double-precision atomics: the sums differ from the reference's sequential ones by their order only (1e-16 relative). This is
+// BASELINE config 1's plumbing path: sized for exactness, not for throughput (the accel program is the fast one).
+namespace {
+__device__ __forceinline__ int d_wrap(int x, int n) { int r = x % n; return r < 0 ? r + n : r; }       // intWRAP(x, 0, n - 1)
+
+// zero-pad about the Xmipp origin + CenterFFT(true) (RF:386-401): image pixel (i, j) lands at ((i + off + P/2) % P, ...)
+__global__ void __launch_bounds__(256) k_rf2_pad(const float *__restrict__ imgs, int D, xh_cd *__restrict__ out, int P, int n)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)n * D * D) return;
+    const int img = (int)(t / ((size_t)D * D)), r = (int)(t - (size_t)img * D * D), i = r / D, j = r - i * D;
+    const int off = -(D / 2) + P / 2, sh = P / 2;
+    out[((size_t)img * P + (i + off + sh) % P) * P + (j + off + sh) % P] = xh_cd{(double)imgs[t], 0.0};
+}
+
+// CTF value of RF:600-625 (getValuePureNoKAt at the double digital frequency / Ts)
+__device__ __forceinline__ double d_rf2_ctf(const XhCtfDev &c, double X, double Y)
+{
+    const double u2 = X * X + Y * Y, u = sqrt(u2), u4 = u2 * u2;
+    double deltaf;
+    if (fabs(X) < 1e-6 && fabs(Y) < 1e-6) deltaf = 0;
+    else deltaf = c.defocus_average + c.defocus_deviation * cos(2 * (atan2(Y, X) - c.rad_azimuth));
+    double VPP = 0.0;
+    if (round(c.VPP_radius * 1000) != 0) VPP = -c.phase_shift * (1 - exp(-u2 / (2 * c.VPP_radius * c.VPP_radius)));
+    const double argument = VPP + c.K1 * deltaf * u2 + c.K2 * u4;
+    double sine_part, cosine_part;
+    sincos(argument, &sine_part, &cosine_part);
+    const double Eespr = exp(-c.K3 * u4);
+    const double EdeltaF = d_bessj0(c.K5 * u2);
+    const double xs = u * c.DeltaR;
+    const double EdeltaR = (xs == 0) ? 1.0 : sin(3.14159265358979323846 * xs) / (3.14159265358979323846 * xs);
+    const double aux = (c.K7 * u2 * u + deltaf * u);
+    const double Ealpha = exp(-c.K6 * aux * aux);
+    double E = Eespr * EdeltaF * EdeltaR * Ealpha + c.envR0 + c.envR1 * u + c.envR2 * u2;
+    if (E < 0) E = 0;
+    return c.K * (-c.K * (c.Ksin * sine_part - c.Kcos * cosine_part) * E);
+}
+
+// one thread per (projection x symmetry matrix, Fourier pixel of the half spectrum)
+__global__ void __launch_bounds__(256)
+k_rf2_scatter(const xh_cd *__restrict__ spectra, const double *__restrict__ A_SL, const float *__restrict__ weights, const int *__restrict__ imgOf,
+              const XhCtfDev *__restrict__ ctf, int nspaces, int P, int V, double maxRes2, double radius, double iDeltaSqrt,
+              const double *__restrict__ table, xh_cd *__restrict__ F, double *__restrict__ W, double iTs, double minCTF, int phaseFlipped,
+              int reprocess)
+{
+    const int pxh = P / 2 + 1, xh = V / 2 + 1;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)nspaces * P * pxh) return;
+    const int sp = (int)(t / ((size_t)P * pxh)), r = (int)(t - (size_t)sp * P * pxh), i = r / pxh, j = r - i * pxh;
+    const int img = imgOf[sp];
+    const double weight = weights ? (double)weights[img] : 1.0;
+    if (weight == 0.0) return;
+    const double fx = (j <= (P >> 1)) ? (double)j / P : (double)(j - P) / P, fy = (i <= (P >> 1)) ? (double)i / P : (double)(i - P) / P;
+    if (fx * fx + fy * fy > maxRes2) return;
+    double wCTF = 1, wMod = 1;
+    if (ctf && !reprocess) {
+        wCTF = d_rf2_ctf(ctf[img], fx * iTs, fy * iTs);
+        if (isnan(wCTF)) { if (i == 0 && j == 0) wMod = wCTF = 1.0; else wMod = wCTF = 0.0; }
+        if (fabs(wCTF) < minCTF) { wMod = fabs(wCTF); wCTF = (wCTF >= 0) ? 1.0 : -1.0; }
+        else wCTF = 1.0 / wCTF;
+        if (phaseFlipped) wCTF = fabs(wCTF);
+    }
+    const double *A = A_SL + 9 * (size_t)sp;
+    const double rx = (A[0] * fx + A[1] * fy) * V, ry = (A[3] * fx + A[4] * fy) * V, rz = (A[6] * fx + A[7] * fy) * V;
+    const int x1 = (int)ceil(rx - radius), x2 = (int)floor(rx + radius);
+    const int y1 = (int)ceil(ry - radius), y2 = (int)floor(ry + radius);
+    const int z1 = (int)ceil(rz - radius), z2 = (int)floor(rz + radius);
+    const double r2 = radius * radius;
+    const xh_cd in = reprocess ? xh_cd{0., 0.} : spectra[((size_t)img * P + i) * P + j];
+    const int xsize_1 = xh - 1;
+    for (int iz = z1; iz <= z2; ++iz) {
+        const double dz = iz - rz, z2v = dz * dz;
+        const int kz = d_wrap(iz, V), kzn = d_wrap(-kz, V);
+        for (int iy = y1; iy <= y2; ++iy) {
+            const double dy = iy - ry, y2z2 = dy * dy + z2v;
+            if (y2z2 > r2) continue;
+            const int ky = d_wrap(iy, V), kyn = d_wrap(-ky, V);
+            for (int ix = x1; ix <= x2; ++ix) {
+                const double dx = ix - rx, d2 = dx * dx + y2z2;
+                if (d2 > r2) continue;
+                const double w = table[(int)(d2 * iDeltaSqrt + 0.5)] * weight * wMod;
+                const int kx = d_wrap(ix, V);
+                bool cj = false;
+                int pz = kz, py = ky, px = kx;
+                if (kx > xsize_1) { pz = kzn; py = kyn; px = d_wrap(-kx, V); cj = true; }
+                const size_t o = ((size_t)pz * V + py) * xh + px;
+                if (reprocess) atomicAdd(&W[o], w * F[o].x);            // RF:770-775: F holds the current 1 / w estimate
+                else {
+                    const double we = w * wCTF;
+                    atomicAdd(&F[o].x, we * in.x);
+                    atomicAdd(&F[o].y, cj ? -we * in.y : we * in.y);
+                    atomicAdd(&W[o], w);
+                }
+            }
+        }
+    }
+}
+
+// forceWeightSymmetry (RF:1186-1221) / enforceHermitianSymmetry (xmippCore xmipp_fftw.cpp, 3-D) on the x = 0 plane:
+// mode 0 averages the weights of (k, i, 0) and (-k, -i, 0), mode 1 the coefficients with their conjugated point mirror
+__global__ void __launch_bounds__(256) k_rf2_plane_symmetry(xh_cd *__restrict__ F, double *__restrict__ W, int V, int mode)
+{
+    const int xh = V / 2 + 1;
+    int half = V / 2; if (V % 2 == 0) half--;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    // threads [0, V * half): rows i = 1 .. half of every k; then [V * half, V * half + half): the column i = 0, k = 1 .. half
+    int k, i;
+    if (t < V * half) { k = t / half; i = t - k * half + 1; }
+    else if (t < V * half + half) { k = t - V * half + 1; i = 0; }
+    else return;
+    const int ks = d_wrap(-k, V), is = d_wrap(-i, V);
+    const size_t a = ((size_t)k * V + i) * xh, b = ((size_t)ks * V + is) * xh;
+    if (mode == 0) { const double m = 0.5 * (W[a] + W[b]); W[a] = W[b] = m; }
+    else { const xh_cd m = xh_cd{0.5 * (F[a].x + F[b].x), 0.5 * (F[a].y - F[b].y)}; F[a] = m; F[b] = xh_cd{m.x, -m.y}; }
+}
+
+// the element-wise steps of correctWeight (RF:1056-1101): 0 weights = 1; 1 F.re = 1 / w where |w| > 1e-3; 2 F.re /= w where |w| > 1e-3;
+// 3 w = F.re
+__global__ void __launch_bounds__(256) k_rf2_weight_step(xh_cd *__restrict__ F, double *__restrict__ W, size_t n, int step)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    if (step == 0) W[t] = 1;
+    else if (step == 1) { if (fabs(W[t]) > 1e-3) F[t].x = 1.0 / W[t]; }
+    else if (step == 2) { if (fabs(W[t]) > 1e-3) F[t].x = F[t].x / W[t]; }
+    else W[t] = F[t].x;
+}
+
+// PROCESS_WEIGHTS (RF:451-480)
+__global__ void __launch_bounds__(256) k_rf2_process_weights(const xh_cd *__restrict__ F, const double *__restrict__ W, xh_cd *__restrict__ out, size_t n,
+                                                             double corr2D_3D, int niter)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    xh_cd v = F[t];
+    if (niter == 0) { v.x *= corr2D_3D; v.y *= corr2D_3D; }
+    else {
+        const double w = W[t];
+        if (1.0 / w > 1e-6) { v.x *= corr2D_3D * w; v.y *= corr2D_3D * w; }
+        else v = xh_cd{0., 0.};
+    }
+    out[t] = v;
+}
+}  // namespace
+
+struct xh_rf2 {
+    xh_ctx *ctx;
+    xh_rf_params p;
+    int D, P, V, xh, niter;
+    double iDeltaSqrt, iDeltaFourier, meanFactor2;
+    std::vector<double> table, ftable;
+    XhPlanBufs<double> planP, planV;
+    XhBuf d_F, d_W, d_Fsave, d_table, d_spec, d_A, d_img, d_w, d_ctf, d_imgOf;
+    size_t nF;
+};
+
+extern "C" {
+
+int xh_rf2_destroy(xh_rf2 *h)
+{
+    if (!h) return XH_OK;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    xh_plan_free(h->planP); xh_plan_free(h->planV);
+    xh_buf_free(h->d_F); xh_buf_free(h->d_W); xh_buf_free(h->d_Fsave); xh_buf_free(h->d_table); xh_buf_free(h->d_spec); xh_buf_free(h->d_A);
+    xh_buf_free(h->d_img); xh_buf_free(h->d_w); xh_buf_free(h->d_ctf); xh_buf_free(h->d_imgOf);
+    delete h;
+    return XH_OK;
+}
+
+int xh_rf2_reset(xh_rf2 *h)
+{
+    XH_CHECK(h, XH_ERR_ARG, "xh_rf2_reset: null handle");
+    XH_HIP(hipSetDevice(h->ctx->device));
+    XH_HIP(hipMemsetAsync(h->d_F.p, 0, h->d_F.bytes, h->ctx->stream));
+    XH_HIP(hipMemsetAsync(h->d_W.p, 0, h->d_W.bytes, h->ctx->stream));
+    return XH_OK;
+}
+
+int xh_rf2_create(xh_ctx *ctx, const xh_rf_params *p, int32_t niter_weight, xh_rf2 **out)
+{
+    XH_CHECK(ctx && p && out && niter_weight >= 0, XH_ERR_ARG, "xh_rf2_create: bad argument");
+    XH_CHECK(p->imgSize >= 4 && (p->blob_order == 0 || p->blob_order == 2), XH_ERR_ARG, "xh_rf2_create: bad image size or blob order");
+    XH_CHECK(!p->use_fast, XH_ERR_UNSUPPORTED, "xh_rf2_create: ProgRecFourier has no --fast");
+    XH_HIP(hipSetDevice(ctx->device));
+    xh_rf2 *h = new xh_rf2;
+    h->ctx = ctx; h->p = *p; h->D = p->imgSize; h->niter = niter_weight;
+    h->P = (int)(h->D * p->padding_proj);            // RF:229-231
+    h->V = (int)(h->D * p->padding_vol);
+    h->xh = h->V / 2 + 1;
+    h->meanFactor2 = -1;
+    h->nF = (size_t)h->V * h->V * h->xh;
+    // tables, RF:222-269 (the same as RFA's, kept in double)
+    const int Xdim = h->D;
+    h->table.resize(XH_BLOB_TABLE); h->ftable.resize(XH_BLOB_TABLE);
+    const double rFourier = p->blob_radius / (p->padding_vol * Xdim), rNorm = p->blob_radius / (p->padding_proj / p->padding_vol);
+    const double deltaSqrt = (p->blob_radius * p->blob_radius) / (XH_BLOB_TABLE - 1), deltaFourier = (std::sqrt(3.) * Xdim / 2.) / (XH_BLOB_TABLE - 1);
+    const double iw0 = 1.0 / h_kaiser_fourier(0.0, rNorm, p->blob_alpha, p->blob_order);
+    double pad3 = p->padding_vol * Xdim;
+    pad3 = pad3 * pad3 * pad3;
+    const double tsz = p->blob_radius * std::sqrt(1. / (XH_BLOB_TABLE - 1));
+    for (int i = 0; i < XH_BLOB_TABLE; ++i) {
+        h->table[i] = h_kaiser_value(tsz * std::sqrt((double)i), p->blob_radius, p->blob_alpha, p->blob_order) * iw0;
+        h->ftable[i] = h_kaiser_fourier(deltaFourier * i, rFourier, p->blob_alpha, p->blob_order) * pad3 * iw0;
+    }
+    h->iDeltaSqrt = 1 / deltaSqrt; h->iDeltaFourier = 1 / deltaFourier;
+    int rc = (h->P <= 2048 && h->V <= 2048) ? XH_OK : XH_ERR_UNSUPPORTED;
+    if (rc != XH_OK) xh_set_error("xh_rf2_create: padded sizes %d / %d exceed 2048", h->P, h->V);
+    if (rc == XH_OK) rc = xh_plan_create<double>(ctx, h->P, h->planP);
+    if (rc == XH_OK) rc = xh_plan_create<double>(ctx, h->V, h->planV);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->d_F, sizeof(xh_cd) * h->nF);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->d_W, sizeof(double) * h->nF);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->d_table, sizeof(double) * 2 * XH_BLOB_TABLE);
+    if (rc == XH_OK && hipMemcpy(h->d_table.p, h->table.data(), sizeof(double) * XH_BLOB_TABLE, hipMemcpyHostToDevice) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipMemcpy((double *)h->d_table.p + XH_BLOB_TABLE, h->ftable.data(), sizeof(double) * XH_BLOB_TABLE, hipMemcpyHostToDevice) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK) rc = xh_rf2_reset(h);
+    if (rc != XH_OK) { xh_rf2_destroy(h); return rc; }
+    *out = h;
+    return XH_OK;
+}
+
+// n projections (shifts already applied), their CTFs (nullable), orientations (rot, tilt, psi), weights (nullable), symmetry
+// matrices (nullable = identity). reprocess != 0: the weight re-processing pass of correctWeight (images ignored).
+int xh_rf2_insert(xh_rf2 *h, const float *d_imgs, const xh_ctf_params *h_ctf, const double *h_angles, const float *h_weights, int32_t n,
+                  const double *h_sym, int32_t nsym, int32_t reprocess)
+{
+    XH_CHECK(h && h_angles && n >= 0 && (reprocess || d_imgs), XH_ERR_ARG, "xh_rf2_insert: bad argument");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return XH_OK;
+    static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!h_sym) { h_sym = ident; nsym = 1; }
+    const int P = h->P, D = h->D, pxh = P / 2 + 1;
+    // A_SL = R * localAInv per (projection, symmetry matrix), RF:560-566
+    std::vector<double> A((size_t)n * nsym * 9);
+    std::vector<int> imgOf((size_t)n * nsym);
+    for (int i = 0; i < n; ++i) {
+        double E[9], T[9];
+        h_euler(h_angles[3 * i], h_angles[3 * i + 1], h_angles[3 * i + 2], E);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) T[r * 3 + c] = E[c * 3 + r];
+        for (int s_ = 0; s_ < nsym; ++s_) {
+            double *o = &A[((size_t)i * nsym + s_) * 9];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < 3; ++k) acc += h_sym[9 * s_ + r * 3 + k] * T[k * 3 + c];
+                    o[r * 3 + c] = acc;
+                }
+            imgOf[(size_t)i * nsym + s_] = i;
+        }
+    }
+    XH_TRY(xh_buf_reserve(ctx, h->d_A, sizeof(double) * A.size()));
+    XH_TRY(xh_buf_reserve(ctx, h->d_imgOf, sizeof(int) * imgOf.size()));
+    XH_HIP(hipMemcpyAsync(h->d_A.p, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipMemcpyAsync(h->d_imgOf.p, imgOf.data(), sizeof(int) * imgOf.size(), hipMemcpyHostToDevice, ctx->stream));
+    const float *d_w = nullptr;
+    if (h_weights) {
+        XH_TRY(xh_buf_reserve(ctx, h->d_w, sizeof(float) * (size_t)n));
+        XH_HIP(hipMemcpyAsync(h->d_w.p, h_weights, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        d_w = (const float *)h->d_w.p;
+    }
+    const XhCtfDev *d_c = nullptr;
+    std::vector<XhCtfDev> hc;
+    if (h_ctf && !reprocess) {
+        hc.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const xh_ctf_params &c = h_ctf[i];
+            const double local_Cs = c.Cs * 1e7, local_Ca = c.Ca * 1e7, local_kV = c.kV * 1e3, local_ispr = c.ispr * 1e6;
+            const double lambda = 12.2643247 / std::sqrt(local_kV * (1. + 0.978466e-6 * local_kV));
+            XhCtfDev &d = hc[i];
+            d.K1 = kPI * lambda; d.K2 = kPI / 2 * local_Cs * lambda * lambda * lambda;
+            d.K3 = std::pow(0.25 * kPI * local_Ca * lambda * (c.espr / c.kV + 2 * local_ispr), 2) / std::log(2.0);
+            d.K5 = kPI * c.DeltaF * lambda; d.K6 = kPI * kPI * c.alpha * c.alpha; d.K7 = local_Cs * lambda * lambda;
+            d.Ksin = std::sqrt(1 - c.Q0 * c.Q0); d.Kcos = c.Q0; d.rad_azimuth = c.azimuthal_angle * kPI / 180.;
+            d.defocus_average = -(c.DeltafU + c.DeltafV) * 0.5; d.defocus_deviation = -(c.DeltafU - c.DeltafV) * 0.5;
+            d.DeltaR = c.DeltaR; d.K = c.K; d.envR0 = c.envR0; d.envR1 = c.envR1; d.envR2 = c.envR2;
+            d.phase_shift = c.phase_shift; d.VPP_radius = c.VPP_radius;
+        }
+        XH_TRY(xh_buf_reserve(ctx, h->d_ctf, sizeof(XhCtfDev) * (size_t)n));
+        XH_HIP(hipMemcpyAsync(h->d_ctf.p, hc.data(), sizeof(XhCtfDev) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        d_c = (const XhCtfDev *)h->d_ctf.p;
+    }
+    if (!reprocess) {
+        // RF:386-404: pad, centre, transform (normalised by 1 / P^2)
+        const size_t tot = (size_t)n * P * P;
+        XH_TRY(xh_buf_reserve(ctx, h->d_spec, sizeof(xh_cd) * tot));
+        XH_HIP(hipMemsetAsync(h->d_spec.p, 0, sizeof(xh_cd) * tot, ctx->stream));
+        hipLaunchKernelGGL(k_rf2_pad, dim3((unsigned)(((size_t)n * D * D + 255) / 256)), dim3(256), 0, ctx->stream, d_imgs, D, (xh_cd *)h->d_spec.p, P, n);
+        XH_LAUNCH_CHECK();
+        const XhPlan<double> &plan = h->planP.plan;
+        const int lpb = xh_plan_lpb(plan, 64 * 1024, 16);
+        const size_t smem = ((size_t)lpb * sizeof(xh_cd)) << plan.logM;
+        const size_t nlines = (size_t)n * P;
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream, (xh_cd *)h->d_spec.p, plan,
+                           nlines, (size_t)1, (size_t)P, (size_t)0, (size_t)1, lpb);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((nlines + lpb - 1) / lpb)), dim3(256), smem, ctx->stream, (xh_cd *)h->d_spec.p, plan,
+                           nlines, (size_t)P, (size_t)P * P, (size_t)1, (size_t)P, lpb);
+        XH_LAUNCH_CHECK();
+        const double inv = 1.0 / ((double)P * P);
+        hipLaunchKernelGGL(k_rf_scale_cd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (xh_cd *)h->d_spec.p, tot, inv);
+        XH_LAUNCH_CHECK();
+    }
+    const size_t threads = (size_t)n * nsym * P * pxh;
+    hipLaunchKernelGGL(k_rf2_scatter, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cd *)h->d_spec.p, (const double *)h->d_A.p,
+                       d_w, (const int *)h->d_imgOf.p, d_c, n * nsym, P, h->V, h->p.max_resolution * h->p.max_resolution, h->p.blob_radius, h->iDeltaSqrt,
+                       (const double *)h->d_table.p, (xh_cd *)h->d_F.p, (double *)h->d_W.p, 1.0 / h->p.sampling, h->p.min_ctf, h->p.phase_flipped, reprocess);
+    XH_LAUNCH_CHECK();
+    XH_HIP(hipStreamSynchronize(ctx->stream));          // the host arrays of this call go out of scope
+    return XH_OK;
+}
+
+// correctWeight, split so that the caller replays the projections (xh_rf2_insert with reprocess = 1) between the steps:
+//   step 0 begin;  niter - 1 times { step 1 iteration begin; replay; step 2 iteration end };  step 3 end
+int xh_rf2_weights_step(xh_rf2 *h, int32_t step)
+{
+    XH_CHECK(h && step >= 0 && step <= 3, XH_ERR_ARG, "xh_rf2_weights_step: bad argument");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const int V = h->V;
+    int half = V / 2; if (V % 2 == 0) half--;
+    const unsigned nbSym = (unsigned)((V * half + half + 255) / 256), nbAll = (unsigned)((h->nF + 255) / 256);
+    auto sym = [&]() { hipLaunchKernelGGL(k_rf2_plane_symmetry, dim3(nbSym), dim3(256), 0, ctx->stream, (xh_cd *)h->d_F.p, (double *)h->d_W.p, V, 0); };
+    auto el = [&](int s_) { hipLaunchKernelGGL(k_rf2_weight_step, dim3(nbAll), dim3(256), 0, ctx->stream, (xh_cd *)h->d_F.p, (double *)h->d_W.p, h->nF, s_); };
+    if (step == 0) {
+        sym();
+        if (h->niter == 0) { el(0); XH_LAUNCH_CHECK(); return XH_OK; }
+        XH_TRY(xh_buf_reserve(ctx, h->d_Fsave, sizeof(xh_cd) * h->nF));
+        XH_HIP(hipMemcpyAsync(h->d_Fsave.p, h->d_F.p, sizeof(xh_cd) * h->nF, hipMemcpyDeviceToDevice, ctx->stream));
+        sym();
+        el(1);
+    } else if (step == 1) XH_HIP(hipMemsetAsync(h->d_W.p, 0, sizeof(double) * h->nF, ctx->stream));
+    else if (step == 2) { sym(); el(2); }
+    else if (h->niter != 0) {
+        el(3);
+        XH_HIP(hipMemcpyAsync(h->d_F.p, h->d_Fsave.p, sizeof(xh_cd) * h->nF, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+size_t xh_rf2_state_doubles(const xh_rf2 *h) { return h ? 3 * h->nF : 0; }
+// the Fourier volume and its weights [F (2 nF) | W (nF)] to / from a device buffer of the caller (--prepare_fsc keeps the halves)
+int xh_rf2_state_export(xh_rf2 *h, double *d_dst)
+{
+    XH_CHECK(h && d_dst, XH_ERR_ARG, "xh_rf2_state_export: bad argument");
+    XH_HIP(hipSetDevice(h->ctx->device));
+    XH_HIP(hipMemcpyAsync(d_dst, h->d_F.p, sizeof(xh_cd) * h->nF, hipMemcpyDeviceToDevice, h->ctx->stream));
+    XH_HIP(hipMemcpyAsync(d_dst + 2 * h->nF, h->d_W.p, sizeof(double) * h->nF, hipMemcpyDeviceToDevice, h->ctx->stream));
+    return XH_OK;
+}
+int xh_rf2_state_import(xh_rf2 *h, const double *d_src, int32_t add)
+{
+    XH_CHECK(h && d_src, XH_ERR_ARG, "xh_rf2_state_import: bad argument");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    if (!add) {
+        XH_HIP(hipMemcpyAsync(h->d_F.p, d_src, sizeof(xh_cd) * h->nF, hipMemcpyDeviceToDevice, ctx->stream));
+        XH_HIP(hipMemcpyAsync(h->d_W.p, d_src + 2 * h->nF, sizeof(double) * h->nF, hipMemcpyDeviceToDevice, ctx->stream));
+        return XH_OK;
+    }
+    hipLaunchKernelGGL(k_rf_add_d, dim3((unsigned)((2 * h->nF + 255) / 256)), dim3(256), 0, ctx->stream, (double *)h->d_F.p, d_src, 2 * h->nF);
+    hipLaunchKernelGGL(k_rf_add_d, dim3((unsigned)((h->nF + 255) / 256)), dim3(256), 0, ctx->stream, (double *)h->d_W.p, d_src + 2 * h->nF, h->nF);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+// finishComputations (RF:1103-1178): enforceHermitianSymmetry, PROCESS_WEIGHTS, inverse transform, window, corrections.
+// The Fourier volume and the weights stay as they are (the program keeps them for --prepare_fsc).
+int xh_rf2_finish(xh_rf2 *h, double *h_volume)
+{
+    XH_CHECK(h && h_volume, XH_ERR_ARG, "xh_rf2_finish: bad argument");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const int V = h->V, D = h->D;
+    int half = V / 2; if (V % 2 == 0) half--;
+    XhBuf spec, vol;
+    int rc = xh_buf_alloc(ctx, spec, sizeof(xh_cd) * h->nF);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, vol, sizeof(double) * (size_t)D * D * D);
+    if (rc == XH_OK) {
+        // on a copy: the symmetrised coefficients are what the reference transforms, and it transforms in place
+        hipLaunchKernelGGL(k_rf2_plane_symmetry, dim3((unsigned)((V * half + half + 255) / 256)), dim3(256), 0, ctx->stream, (xh_cd *)h->d_F.p, (double *)h->d_W.p, V, 1);
+        const double corr2D_3D = std::pow(h->p.padding_proj, 2.) / (D * std::pow(h->p.padding_vol, 3.));
+        hipLaunchKernelGGL(k_rf2_process_weights, dim3((unsigned)((h->nF + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cd *)h->d_F.p, (const double *)h->d_W.p,
+                           (xh_cd *)spec.p, h->nF, corr2D_3D, h->niter);
+        if (hipGetLastError() != hipSuccess) { xh_set_error("xh_rf2_finish: kernel launch failed"); rc = XH_ERR_HIP; }
+    }
+    if (rc == XH_OK)
+        rc = finish_from_spectrum(ctx, h->planV.plan, (xh_cd *)spec.p, (double *)vol.p, (const double *)h->d_table.p + XH_BLOB_TABLE, D, h->iDeltaFourier,
+                                  h->p.padding_proj, h->p.padding_vol, h->meanFactor2, h->niter != 0, h_volume);
+    xh_buf_free(spec); xh_buf_free(vol);
+    return rc;
 }
 
 }  // extern "C"

@@ -567,12 +567,17 @@ public:
     size_t imgSize = 0;
     std::vector<double> R_repository;   // nsym x 9
     // one slot per device: its own context (stream), gridding handle and temp spaces; slot 0 finishes
-    struct Slot { int device = 0; xh_ctx *ctx = nullptr; xh_rf *rf = nullptr; };
+    struct Slot { int device = 0; xh_ctx *ctx = nullptr; xh_rf *rf = nullptr; xh_rf2 *rf2 = nullptr; };
     std::vector<Slot> slots;
+    // xmipp_reconstruct_fourier (ProgRecFourier, reconstruction/reconstruct_fourier.cpp): its own double-precision arithmetic on the
+    // device (xh_rf2_*); NiterWeight = --iter (RF:44,96)
+    bool rfArithmetic = false;
+    int NiterWeight = 1;
 
     ~ProgRecFourierAccel() override
     {
         for (Slot &s : slots) {
+            if (s.rf2) xh_rf2_destroy(s.rf2);
             if (s.rf) xh_rf_destroy(s.rf);
             if (s.ctx) xh_ctx_destroy(s.ctx);
         }
@@ -602,7 +607,7 @@ public:
         addParamsLine("                                 : CTF values (in absolute value) below this one will not be corrected");
         addParamsLine("  [--bufferSize <size=25>]        : Number of projection loaded in memory (will be actually 2x as much.");
         addParamsLine("  [--thr <threads=1> <rows=1>]   : Accepted for compatibility with xmipp_reconstruct_fourier (RF:50); unused");
-        addParamsLine("  [--iter <iterations=1>]        : xmipp_reconstruct_fourier weight-correction iterations (RF:44); >= 1");
+        addParamsLine("  [--iter <iterations=1>]        : xmipp_reconstruct_fourier: number of iterations for weight correction (RF:44)");
         addParamsLine("  [--prepare_fsc <fscfile>]      : Filename root for FSC files (RF:47): <root>_1_recons.vol, <root>_2_recons.vol");
         addParamsLine("  [--device <id=0>]              : first HIP device");
         addParamsLine("  [--gpus <n=1>]                 : number of consecutive HIP devices, one host thread each");
@@ -635,10 +640,10 @@ public:
         deviceList = getParam("--devices");
         batch = std::max(1, (int)getIntParam("--batch"));
         if (checkParam("--prepare_fsc")) fn_fsc = getParam("--prepare_fsc");
-        // correctWeight (RF:1056-1101): the re-processing pass adds w * X into the weight of the same voxel, X being the current
-        // 1 / W estimate, so X <- X / (X W) returns X wherever W > 1e-3: any --iter >= 1 gives the volume of --iter 1 (measured on
-        // a CPU restatement of RF: 4e-16). --iter 0 (no weight normalisation at all) is not built.
-        if (getIntParam("--iter") < 1) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--iter 0 (weights set to one, RF:1058-1064) is not available on the device path");
+        NiterWeight = (int)getIntParam("--iter");
+        if (NiterWeight < 0) REPORT_ERROR(ERR_ARG_INCORRECT, "--iter must not be negative");
+        if (rfArithmetic && useFast) REPORT_ERROR(ERR_ARG_INCORRECT, "--fast belongs to xmipp_reconstruct_fourier_accel");
+        // the accel program has no weight iterations (RFA:61-79): under its own name --iter is accepted and ignored
     }
 
     void show()
@@ -690,8 +695,9 @@ public:
             Slot &s = slots.back();
             s.device = d;
             xhCheck(xh_ctx_create_private(d, &s.ctx));
-            xhCheck(xh_rf_create(s.ctx, &p, &s.rf));
-            xhCheck(xh_rf_reset(s.rf));
+            xhCheck(xh_rf_create(s.ctx, &p, &s.rf));       // (the double-precision program uses it for the shifts of readApplyGeo only)
+            if (rfArithmetic) xhCheck(xh_rf2_create(s.ctx, &p, NiterWeight, &s.rf2));
+            else xhCheck(xh_rf_reset(s.rf));
         }
     }
 
@@ -783,6 +789,10 @@ public:
             }
             // processBufferGPU in one call (RFG:417-473): FFT, CTF factor and modulator evaluated while the gridding records
             // are packed (no CTF planes, same records bit for bit as the three separate steps), insertion
+            if (rfArithmetic)
+                xhCheck(xh_rf2_insert(slot.rf2, imgs, hasCTF ? ctfs.data() : nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n,
+                                      R_repository.data(), (int)(R_repository.size() / 9), 0));
+            else
             xhCheck(xh_rf_insert_images(rf, imgs, hasCTF ? ctfs.data() : nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n,
                                         R_repository.data(), (int)(R_repository.size() / 9)));
             xhCheck(xh_ctx_sync(ctx));
@@ -796,11 +806,89 @@ public:
         writeVolume(out_name, vol.data(), imgSize, imgSize, imgSize);
     }
 
+    // ---- xmipp_reconstruct_fourier (RF:124-180): every device's Fourier volume and weights summed into slot 0 through host memory
+    void gatherDouble()
+    {
+        if (slots.size() < 2) return;
+        const size_t nd = xh_rf2_state_doubles(slots[0].rf2);
+        std::vector<double> host(nd);
+        DeviceBuffer d0;
+        d0.reserve(slots[0].ctx, nd * sizeof(double));
+        for (size_t g = 1; g < slots.size(); ++g) {
+            DeviceBuffer dg;
+            dg.reserve(slots[g].ctx, nd * sizeof(double));
+            xhCheck(xh_rf2_state_export(slots[g].rf2, dg.as<double>()));
+            xhCheck(xh_memcpy_d2h(slots[g].ctx, host.data(), dg.p, nd * sizeof(double)));
+            xhCheck(xh_memcpy_h2d(slots[0].ctx, d0.p, host.data(), nd * sizeof(double)));
+            xhCheck(xh_rf2_state_import(slots[0].rf2, d0.as<double>(), 1));
+            xhCheck(xh_ctx_sync(slots[0].ctx));
+            xhCheck(xh_rf2_reset(slots[g].rf2));
+        }
+    }
+
+    // correctWeight (RF:836-990,1056-1101): the re-processing passes replay orientations, weights and symmetry only
+    void correctWeightDouble()
+    {
+        xh_rf2 *h = slots[0].rf2;
+        xhCheck(xh_rf2_weights_step(h, 0));
+        for (int it = 1; it < NiterWeight; ++it) {
+            xhCheck(xh_rf2_weights_step(h, 1));
+            for (size_t b0 = 0; b0 < SF.size(); b0 += (size_t)batch) {
+                const size_t n = std::min((size_t)batch, SF.size() - b0);
+                std::vector<double> ang(3 * n);
+                std::vector<float> w(n, 1.f);
+                for (size_t k = 0; k < n; ++k) {
+                    const size_t id = b0 + k;
+                    ang[3 * k] = SF.getDouble("angleRot", id, 0); ang[3 * k + 1] = SF.getDouble("angleTilt", id, 0); ang[3 * k + 2] = SF.getDouble("anglePsi", id, 0);
+                    if (do_weights) w[k] = (float)SF.getDouble("weight", id, 1.0);
+                }
+                xhCheck(xh_rf2_insert(h, nullptr, nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n, R_repository.data(), (int)(R_repository.size() / 9), 1));
+            }
+            xhCheck(xh_rf2_weights_step(h, 2));
+        }
+        xhCheck(xh_rf2_weights_step(h, 3));
+    }
+
+    void finishDouble(const std::string &out_name)
+    {
+        std::vector<double> vol(imgSize * imgSize * imgSize);
+        xhCheck(xh_rf2_finish(slots[0].rf2, vol.data()));
+        writeVolume(out_name, vol.data(), imgSize, imgSize, imgSize);
+    }
+
+    void runDouble()
+    {
+        const size_t last = SF.size() - 1;
+        xh_rf2 *h = slots[0].rf2;
+        if (fn_fsc.empty()) {
+            processImages(0, last);
+            gatherDouble();
+        } else {
+            // RF:991-1045: the halves are finished as they stand -- finishComputations without correctWeight, i.e. PROCESS_WEIGHTS
+            // multiplies by the raw weights; kept -- and their Fourier volumes and weights summed for the final volume
+            const size_t FSCIndex = last / 2, nd = xh_rf2_state_doubles(h);
+            DeviceBuffer half1;
+            half1.reserve(slots[0].ctx, nd * sizeof(double));
+            processImages(0, FSCIndex);
+            gatherDouble();
+            xhCheck(xh_rf2_state_export(h, half1.as<double>()));
+            finishDouble(fn_fsc + "_1_recons.vol");
+            xhCheck(xh_rf2_reset(h));
+            if (FSCIndex + 1 <= last) processImages(FSCIndex + 1, last);
+            gatherDouble();
+            finishDouble(fn_fsc + "_2_recons.vol");
+            xhCheck(xh_rf2_state_import(h, half1.as<double>(), 1));
+        }
+        correctWeightDouble();
+        finishDouble(fn_out);
+    }
+
     void run() override
     {
         // RFA:139-156
         show();
         produceSideinfo();
+        if (rfArithmetic) { runDouble(); return; }
         const size_t last = SF.size() - 1;
         if (fn_fsc.empty()) {
             processImages(0, last);

@@ -1,4 +1,4 @@
-// xmipp_reconstruct_fourier_accel (also installed as xmipp_reconstruct_fourier) -- same main as the
+// xmipp_reconstruct_fourier_accel -- same main as the
 // reference's applications/programs/reconstruct_fourier_accel/reconstruct_fourier_accel_main.cpp
 #include "programs.h"
 int main(int argc, char **argv)
