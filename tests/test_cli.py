@@ -549,7 +549,7 @@ def test_cli_movie_global_alignment(bins, tmp_path, oracle):
     xmipp_io.write_stack(str(tmp_path / "gain.stk"), gain[None])
     prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
     r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "out.xmd"), "--sampling", "1.25", "--maxShift", "25",
-              "--maxResForCorrelation", "10", "--frameRange", "1", "5", "--dark", f"1@{tmp_path}/dark.stk", "--gain", f"1@{tmp_path}/gain.stk",
+              "--maxResForCorrelation", "10", "--frameRange", "1", "5", "--frameRangeSum", "1", "5", "--dark", f"1@{tmp_path}/dark.stk", "--gain", f"1@{tmp_path}/gain.stk",
               "--skipLocalAlignment", "--oavgInitial", str(tmp_path / "initial.spi")])
     assert r.returncode == 0, r.stderr
     exp = oracle.fa_global_alignment(frames[1:6], Ts=1.25, max_shift_px=25.0 / 1.25, max_res=10.0, dark=dark, igain=gain)
