@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
+    ap.add_argument("--sdma", type=int, default=-1, help="1 / 0: HSA_ENABLE_SDMA for this process (copy engines or shader copies for the host traffic); -1: leave the environment alone")
     ap.add_argument("--unique-batches", type=int, default=0, help="distinct particle batches cycled from host memory (0: 4 = 16384 particles at --batch 4096)")
     return ap.parse_args(argv)
 
@@ -161,6 +162,8 @@ def main():
         if rc != 0:
             sys.exit(rc)
         sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.sdma >= 0:
+        os.environ["HSA_ENABLE_SDMA"] = str(args.sdma)          # read when the runtime starts: before torch is imported
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge

@@ -416,8 +416,18 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     const float eu = 3.5f * fabsf(h0.x) + HZ * fabsf(h0.y) + h2.x + 1e-4f, et = 3.5f * fabsf(h1.x) + HZ * fabsf(h1.y) + h2.y + 1e-4f;
                     const bool a1 = (fabsf(u1 - 0.5f) + eu < 0.5f) && (fabsf(t1 - 0.5f) + et < 0.5f);
                     const bool a2 = (fabsf(u1 + h0.w - 0.5f) + eu < 0.5f) && (fabsf(t1 + h1.w - 0.5f) + et < 0.5f);
+                    // ... and whether the sparse pass can skip its bounds: every voxel of the unit inside the rows the traversal visits
+                    // (AABB, RFA:724-741) and every image coordinate within reach of the image (the unit's image extent without the blob)
+                    const int yy = __float_as_int(r1.w), zz = __float_as_int(recs[sIdx].r2.w);
+                    const bool inBox = y0 >= (yy & 0xffff) && y0 + 7 <= (yy >> 16) && z0 >= (zz & 0xffff) && z0 + ZD - 1 <= (zz >> 16);
+                    const float ex0 = ex - fr, ey0 = ey - fr;
+                    const bool inReach = (cix - ex0 >= reach.x) && (cix + ex0 <= reach.y) && (ciy - ey0 >= reach.z) && (ciy + ey0 <= reach.w);
                     const int at = nk + __popcll(bal & below);
-                    sKept[at] = sIdx | ((a1 || a2) ? (int)0x80000000 : 0);
+#ifdef XG_NO_INTERIOR
+                    sKept[at] = sIdx | ((a1 || a2) ? (int)0x80000000 : 0) | ((inBox && inReach && mv < 0) ? 0x40000000 : 0);      // A/B builds
+#else
+                    sKept[at] = sIdx | ((a1 || a2) ? (int)0x80000000 : 0) | ((inBox && inReach) ? 0x40000000 : 0);
+#endif
                     sKept[KCAP + at] = (int)cell;
                     sKept[2 * KCAP + at] = (ox & 0xffff) | (oy << 16);
                 }
@@ -430,16 +440,19 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
             // ---- visits. Records travel through scalar registers, one visit ahead (unconditional loads: a select would
             // make the compiler wait for them on the spot); the index of the record after that is read from LDS meanwhile
             int kw = __builtin_amdgcn_readfirstlane(sKept[0]);
-            int kid = kw & 0x7fffffff;
-            int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]) & 0x7fffffff;
-            float4 R0 = recs[kid].r0, R1 = recs[kid].r1, R2 = recs[kid].r2, H0 = recs[kid].h0, H1 = recs[kid].h1, H2 = recs[kid].h2;
+            int kid = kw & 0x3fffffff;
+            int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]) & 0x3fffffff;
+            float4 R0 = recs[kid].r0, R1 = recs[kid].r1, R2 = recs[kid].r2;
             for (int k = 0; k < nk; ++k) {
-                const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2, NH0 = recs[kidN].h0, NH1 = recs[kidN].h1, NH2 = recs[kidN].h2;
+                const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2;
                 const int kidNN = sKept[min(k + 2, nk - 1)], kwN = sKept[min(k + 1, nk - 1)];
                 const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane(sKept[KCAP + k]);
                 const int oxy = __builtin_amdgcn_readfirstlane(sKept[2 * KCAP + k]);
                 const int ox = (int)(short)(oxy & 0xffff), oy = oxy >> 16;
-                const bool allHit = kw < 0;
+                const bool allHit = kw < 0, interior = (kw & 0x40000000) != 0;
+                // the row-visit test's forms are only read where some row of the unit may miss (15 % of the visits)
+                float4 H0 = make_float4(0.f, 0.f, 0.f, 0.f), H1 = H0, H2 = H0;
+                if (!allHit) { H0 = recs[kid].h0; H1 = recs[kid].h1; H2 = recs[kid].h2; }
                 if constexpr (FAST) {
                     // processVoxel (RFA:595-625) over the traversal of a zero-thickness slab (RFA:743-761): every row (y, z)
                     // that crosses the image plane gives its voxel nearest to the crossing the nearest pixel. lane <-> row.
@@ -470,10 +483,10 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                             }
                         }
                     }
-                    R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
+                    R0 = N0; R1 = N1; R2 = N2;
                     kid = kidN;
                     kw = __builtin_amdgcn_readfirstlane(kwN);
-                    kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x7fffffff;
+                    kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x3fffffff;
                     continue;
                 }
                 // ---- the patch copy (origin found in the cull phase). The patch buffer is free: the previous dense pass has
@@ -484,7 +497,24 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
                 const float ax = R0.x * px + R0.y * py, ay = R1.x * px + R1.y * py, az = R2.x * px + R2.y * py;
                 int qn = 0;
-                if constexpr (ABL != 7)
+                if constexpr (ABL != 7) {
+                if (interior) {
+                    // the slab test alone (the sphere bit stays: the unit may straddle the sphere the reference keeps)
+#pragma unroll
+                    for (int zp = 0; zp < ZD / 2; ++zp) {
+                        const xg_v2f pz2 = {fz0 + (float)(2 * zp), fz0 + (float)(2 * zp + 1)};
+                        const xg_v2f iz2 = (xg_v2f){az, az} + (xg_v2f){R2.z, R2.z} * pz2;
+                        const xg_v2f zs2 = iz2 * iz2;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int zi = 2 * zp + h;
+                            const bool pass = ((sph >> zi) & 1) && !((h ? zs2.y : zs2.x) > radiusSqr);
+                            const unsigned long long pb = __ballot(pass);
+                            if (pass) sQueue[qn + __popcll(pb & below)] = (unsigned short)(lane + 64 * zi);
+                            qn += __popcll(pb);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int zp = 0; zp < ZD / 2; ++zp) {
                     const xg_v2f pz2 = {fz0 + (float)(2 * zp), fz0 + (float)(2 * zp + 1)};
@@ -504,6 +534,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                         if (pass) sQueue[qn + __popcll(pb & below)] = (unsigned short)(lane + 64 * zi);     // the voxel's accumulator: x + 8 y + 64 z
                         qn += __popcll(pb);
                     }
+                }
                 }
                 if constexpr (ABL == 5) { if (lane == 0) atomicAdd(reinterpret_cast<int *>(tempV) + min(qn, NVOX), 1); }   // profiling: items per visit
                 // ---- the patch of this visit has landed
@@ -625,10 +656,10 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                R0 = N0; R1 = N1; R2 = N2; H0 = NH0; H1 = NH1; H2 = NH2;
+                R0 = N0; R1 = N1; R2 = N2;
                 kid = kidN;
                 kw = __builtin_amdgcn_readfirstlane(kwN);
-                kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x7fffffff;
+                kidN = __builtin_amdgcn_readfirstlane(kidNN) & 0x3fffffff;
             }
         }
         // ---- write-back
