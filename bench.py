@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
+    ap.add_argument("--stream-test", type=int, default=0, help="diagnosis of the host-traffic cost: 1 no result copies, 2 batches copied device to device, 3 host copies in 16 chunks")
     ap.add_argument("--sdma", type=int, default=-1, help="1 / 0: HSA_ENABLE_SDMA for this process (copy engines or shader copies for the host traffic); -1: leave the environment alone")
     ap.add_argument("--unique-batches", type=int, default=0, help="distinct particle batches cycled from host memory (0: 4 = 16384 particles at --batch 4096)")
     return ap.parse_args(argv)
@@ -307,7 +308,7 @@ def main():
             sx, sy, cc = timed("translate_s6", record, lambda: pm.translate(parts, refno, psi, flip))
             if record:
                 s6_rep[0] += pm.translate_repeated()
-            if slot is not None:
+            if slot is not None and args.stream_test != 1:
                 ho = h_out[slot]
                 for k_, t_ in (("refno", refno), ("psi", psi), ("flip", flip), ("sx", sx), ("sy", sy), ("cc", cc)):
                     ho[k_].copy_(t_, non_blocking=True)
@@ -354,7 +355,13 @@ def main():
     def fetch(k):
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(done[k & 1])          # the step that last used this buffer has finished
-            dbuf[k & 1].copy_(host[k % nuniq], non_blocking=True)
+            if args.stream_test == 2:
+                dbuf[k & 1].copy_(particles, non_blocking=True)
+            elif args.stream_test == 3:
+                for c0 in range(0, B, B // 16):
+                    dbuf[k & 1][c0:c0 + B // 16].copy_(host[k % nuniq][c0:c0 + B // 16], non_blocking=True)
+            else:
+                dbuf[k & 1].copy_(host[k % nuniq], non_blocking=True)
             ready[k & 1].record(copy_stream)
 
     def streamed_steps(nsteps, record):

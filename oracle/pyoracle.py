@@ -95,6 +95,11 @@ def lib():
         "xo_ctf_lambda": (d, [C.POINTER(CtfParams)]),
         "xo_fa_global_alignment": (C.c_int, [c_double_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, C.c_float, C.c_float, C.c_float,
                                              c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "xo_fa_local_alignment": (C.c_int, [c_double_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                            c_double_p, C.POINTER(C.c_int)]),
+        "xo_fa_bspline_shift": (None, [c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
+        "xo_fa_apply_bspline": (None, [c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p]),
         "xo_fa_solve": (None, [c_double_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]),
         "xo_ctf_phase_flip": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), C.c_int]),
         "xo_ctf_wiener2d": (None, [c_double_p, C.c_int, C.c_int, C.POINTER(CtfParams), d, d, C.c_int, C.c_int, d, C.c_int]),
@@ -387,6 +392,39 @@ def fa_global_alignment(frames, Ts=1.0, max_shift_px=50.0, max_res=30.0, dark=No
     if rc != 0:
         raise ValueError("the correlation scale factor is >= 1 (checkSettings)")
     return {"bX": bx, "bY": by, "shiftX": sx, "shiftY": sy, "ref": ref.value, "new_dims": (nd[0], nd[1])}
+
+
+def fa_local_alignment(frames, g_shift_x, g_shift_y, ref, Ts=1.0, max_shift_px=50.0, max_res=30.0, patches=(7, 7), patch_size=(500, 500),
+                       patches_avg=3, control_points=(6, 6, 5)):
+    """computeLocalAlignment of the CUDA program (movie_alignment_correlation_gpu.cpp:288-430) on corrected frames [N, Y, X]."""
+    fr = f64(frames)
+    N, Y, X = fr.shape
+    px, py = patches
+    lX, lY, lT = control_points
+    shifts, centers = np.empty((py, px, N, 2)), np.empty((py, px, 2))
+    cx, cy = np.empty(lX * lY * lT), np.empty(lX * lY * lT)
+    dims = (C.c_int * 4)()
+    gx, gy = f64(g_shift_x), f64(g_shift_y)
+    rc = lib().xo_fa_local_alignment(_dp(fr), N, Y, X, _dp(gx), _dp(gy), int(ref), Ts, max_shift_px, max_res, px, py, patch_size[0], patch_size[1],
+                                     patches_avg, lX, lY, lT, _dp(shifts), _dp(centers), _dp(cx), _dp(cy), dims)
+    if rc != 0:
+        raise ValueError("Movie is too small for local alignment.")
+    return {"patch_shifts": shifts, "centers": centers, "coeffsX": cx, "coeffsY": cy, "dims": tuple(dims)}
+
+
+def fa_bspline_shift(coeffsX, coeffsY, control_points, X, Y, N, x, y, n):
+    sx, sy = C.c_double(), C.c_double()
+    cx, cy = f64(coeffsX), f64(coeffsY)
+    lib().xo_fa_bspline_shift(_dp(cx), _dp(cy), control_points[0], control_points[1], control_points[2], X, Y, N, int(x), int(y), int(n), C.byref(sx), C.byref(sy))
+    return sx.value, sy.value
+
+
+def fa_apply_bspline(frame, coeffsX, coeffsY, control_points, N, n):
+    fr = f64(frame)
+    out = np.empty_like(fr)
+    cx, cy = f64(coeffsX), f64(coeffsY)
+    lib().xo_fa_apply_bspline(_dp(fr), fr.shape[0], fr.shape[1], _dp(cx), _dp(cy), control_points[0], control_points[1], control_points[2], N, int(n), _dp(out))
+    return out
 
 
 def fa_solve(bX, bY, N, iterations=2):

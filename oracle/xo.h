@@ -141,6 +141,16 @@ int xo_fa_global_alignment(const double *frames, int N, int Y, int X, const doub
                            float maxShift, float maxRes, double *bX, double *bY, double *shiftX, double *shiftY, int *refFrame,
                            int *newDims);
 void xo_fa_solve(const double *bX, const double *bY, int N, int iterations, double *shiftX, double *shiftY, int *refFrame);
+/* local (patch) alignment as the CUDA program does it (movie_alignment_correlation_gpu.cpp:140-222,288-430), in double; see the
+ * source for what is and what is not taken from the reference */
+int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+                          float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
+                          int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
+                          double *coeffsY, int *dims);
+void xo_fa_bspline_shift(const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int X, int Y, int N, int x, int y, int n,
+                         double *shiftX, double *shiftY);
+void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int N, int n,
+                         double *out);
 
 /* ---- Fourier reconstruction (RFA) ---------------------------------------- */
 typedef struct {

@@ -128,21 +128,13 @@ void weighted_least_squares(std::vector<double> &A, int rows, int cols, const st
 }
 }  // namespace
 
-extern "C" {
-
-// EquationSystemSolver::solve + computeAlignment (movie_alignment_correlation_base.cpp:399-418): the N-1 shifts between successive
-// frames from the N(N-1)/2 pair shifts, one round of 3-sigma outlier rejection (solverIterations = 2), the reference frame as
-// the minimax of the X shifts (findReferenceImage looks at X only, L258-261), the total shift of every frame from it.
-void xo_fa_solve(const double *bX, const double *bY, int N, int iterations, double *shiftX, double *shiftY, int *refFrame)
+namespace {
+// EquationSystemSolver::solve (eq_system_solver.cpp:35-106) for any observation matrix A (rows x cols, row-major): weighted least
+// squares for both right-hand sides, residuals against the row-weighted A, 3-sigma outliers get weight 0, `iterations` rounds
+void solve_system(const std::vector<double> &A0, int rows, int cols, const std::vector<double> &bx, const std::vector<double> &by,
+                  int iterations, std::vector<double> &sx, std::vector<double> &sy)
 {
-    const int rows = N * (N - 1) / 2, cols = N - 1;
-    std::vector<double> A0((size_t)rows * cols, 0.0), bx(bX, bX + rows), by(bY, bY + rows), w(rows, 1.0), sx, sy;
-    int idx = 0;
-    for (int i = 0; i < N - 1; ++i)
-        for (int j = i + 1; j < N; ++j) {
-            for (int ij = i; ij < j; ++ij) A0[(size_t)idx * cols + ij] = 1;
-            ++idx;
-        }
+    std::vector<double> w(rows, 1.0);
     int it = 0;
     do {
         std::vector<double> A = A0;
@@ -156,33 +148,67 @@ void xo_fa_solve(const double *bX, const double *bY, int N, int iterations, doub
         double mean, sdx, sdy;
         mean_stddev(ex, mean, sdx);
         mean_stddev(ey, mean, sdy);
-        double oldSum = 0, newSum = 0;
-        for (double v : w) oldSum += v;
         for (int r = 0; r < rows; ++r)
             if (std::fabs(ex[r]) > 3 * sdx || std::fabs(ey[r]) > 3 * sdy) w[r] = 0.0;
-        for (double v : w) newSum += v;
-        (void)oldSum; (void)newSum;          // (the early exit on "no outlier" only happens at verbosity > 1, L88-91)
-        ++it;
+        ++it;          // (the early exit on "no outlier" only happens at verbosity > 1, L88-91)
     } while (it < iterations);
+}
+
+// computeAlignment (movie_alignment_correlation_base.cpp:399-418) from the pair shifts; refFrame < 0: findReferenceImage
+void alignment_from_pairs(const std::vector<double> &bx, const std::vector<double> &by, int N, int iterations, int refIn, double *shiftX,
+                          double *shiftY, int *refFrame)
+{
+    const int rows = N * (N - 1) / 2, cols = N - 1;
+    std::vector<double> A0((size_t)rows * cols, 0.0), sx, sy;
+    int idx = 0;
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j, ++idx)
+            for (int ij = i; ij < j; ++ij) A0[(size_t)idx * cols + ij] = 1;
+    solve_system(A0, rows, cols, bx, by, iterations, sx, sy);
     // computeTotalShift (L229-244)
     auto total = [&](int iref, int j, double &tx, double &ty) {
         tx = ty = 0;
         if (iref < j) for (int jj = j - 1; jj >= iref; --jj) { tx -= sx[jj]; ty -= sy[jj]; }
         else if (iref > j) for (int jj = j; jj <= iref - 1; ++jj) { tx += sx[jj]; ty += sy[jj]; }
     };
-    int best = -1;
-    double worstEver = 1.79769313486231570815e+308;
-    for (int iref = 0; iref < N; ++iref) {
-        double worst = -1;
-        for (int j = 0; j < N; ++j) {
-            double tx, ty;
-            total(iref, j, tx, ty);
-            if (std::fabs(tx) > worst) worst = std::fabs(tx);
+    int best = refIn;
+    if (best < 0) {
+        // findReferenceImage (L246-266): minimax of the X shifts only
+        double worstEver = 1.79769313486231570815e+308;
+        for (int iref = 0; iref < N; ++iref) {
+            double worst = -1;
+            for (int j = 0; j < N; ++j) {
+                double tx, ty;
+                total(iref, j, tx, ty);
+                if (std::fabs(tx) > worst) worst = std::fabs(tx);
+            }
+            if (worst < worstEver) { worstEver = worst; best = iref; }
         }
-        if (worst < worstEver) { worstEver = worst; best = iref; }
     }
     *refFrame = best;
     for (int i = 0; i < N; ++i) total(best, i, shiftX[i], shiftY[i]);
+}
+
+// Bspline03 (xmippCore numerical tools): the cubic B-spline
+double bspline03(double x)
+{
+    x = std::fabs(x);
+    if (x < 1) return (x * x * (x - 2) * 3 + 4) * (1.0 / 6.0);
+    if (x < 2) { x -= 2; return x * x * x * (-1.0 / 6.0); }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+// EquationSystemSolver::solve + computeAlignment (movie_alignment_correlation_base.cpp:399-418): the N-1 shifts between successive
+// frames from the N(N-1)/2 pair shifts, one round of 3-sigma outlier rejection (solverIterations = 2), the reference frame as
+// the minimax of the X shifts (findReferenceImage looks at X only, L258-261), the total shift of every frame from it.
+void xo_fa_solve(const double *bX, const double *bY, int N, int iterations, double *shiftX, double *shiftY, int *refFrame)
+{
+    const int rows = N * (N - 1) / 2;
+    std::vector<double> bx(bX, bX + rows), by(bY, bY + rows);
+    alignment_from_pairs(bx, by, N, iterations, -1, shiftX, shiftY, refFrame);
 }
 
 // Returns 0, or 1 when the correlation scale factor is >= 1 (checkSettings, L74-79). frames: [N][Y][X]; dark / igain: [Y][X] or
@@ -244,6 +270,201 @@ int xo_fa_global_alignment(const double *frames, int N, int Y, int X, const doub
     if (bY) std::memcpy(bY, by.data(), sizeof(double) * rows);
     xo_fa_solve(bx.data(), by.data(), N, 2, shiftX, shiftY, refFrame);
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Local (patch) alignment. The reference has it on CUDA only (reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:
+// 140-222,288-430; kernels reconstruction_cuda/cuda_scaleFFT_kernels.cu:44-81, cuda_gpu_movie_alignment_correlation_kernels.cu:
+// 134-183, cuda_single_extrema_finder.cu:131-187,255-311; BSplineHelper, reconstruction/bspline_helper.cpp:34-148; warp
+// reconstruction_cuda/cuda_gpu_geo_transformer.cu:96-131 + cuda_gpu_multidim_array.cu:160-235): restated here from those
+// sources in double. What is NOT taken from the reference: the patch and correlation sizes, which it picks by benchmarking
+// cuFFT (findGoodPatchSize / findGoodCorrelationSize) -- here the requested patch size rounded down to even and the correlation
+// hint (getCorrelationHint) as they are. PARITY UNPINNED (no CPU form, CUDA-only tests): checked on synthetic movies.
+//
+// frames: corrected (dark / gain applied) [N][Y][X]; global shifts and reference frame from the global alignment.
+// Outputs: patchShifts [py][px][N][2] = round(global) + local (x, y); centers [py][px][2]; B-spline coefficients
+// coeffsX / coeffsY [lT][lY][lX] (computeBSplineCoeffs: they describe the OPPOSITE transformation, used to compensate).
+// dims[4] = (patch size x, y, correlation size x, y). Returns 0, or 2 when the movie is too small for the patches.
+int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+                          float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
+                          int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
+                          double *coeffsY, int *dims)
+{
+    const float c = std::sqrt(-1.f / (2.f * std::log(0.5f)));
+    const float reqScale = Ts / (maxRes / (8.f * c));                       // getScaleFactor
+    const int PX = patchSizeX & ~1, PY = patchSizeY & ~1;
+    if (X < PX || Y < PY || PX < 8 || PY < 8) return 2;
+    auto nearestEven = [](int v, float minScale) { int size = 2; while ((size / (float)v) < minScale) size += 2; return size; };   // getCorrelationHint
+    const int CX = nearestEven(PX, reqScale), CY = nearestEven(PY, reqScale);
+    if (dims) { dims[0] = PX; dims[1] = PY; dims[2] = CX; dims[3] = CY; }
+    const float actualScale = (float)CX / (float)PX;
+    // getMovieBorders (:204-222)
+    double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
+    for (int i = 0; i < N; ++i) {
+        minX = std::min(std::floor(gShiftX[i]), minX); maxX = std::max(std::ceil(gShiftX[i]), maxX);
+        minY = std::min(std::floor(gShiftY[i]), minY); maxY = std::max(std::ceil(gShiftY[i]), maxY);
+    }
+    const double bordX = std::fabs(maxX - minX), bordY = std::fabs(maxY - minY);
+    // getPatchesLocation (:139-164)
+    const double windowX = X - 2 * bordX, windowY = Y - 2 * bordY;
+    const double corrX = std::ceil(((patchesX * PX) - windowX) / (double)(patchesX - 1)), corrY = std::ceil(((patchesY * PY) - windowY) / (double)(patchesY - 1));
+    const double stepX = PX - corrX, stepY = PY - corrY;
+    // low-pass of the correlation size (setFilter, :265-271)
+    std::vector<double> filter;
+    create_lpf((double)(Ts / actualScale), maxRes, CX, CY, filter);
+    const int pxh = PX / 2 + 1, cxh = CX / 2 + 1;
+    const double norm = 1.0 / ((double)PX * PY);
+    const int maxDist = (int)(maxShift * actualScale);            // context.maxShift -> size_t in sFindMax2DAroundCenter
+    const int rows = N * (N - 1) / 2;
+    std::vector<double> patch((size_t)PY * PX), F((size_t)PY * pxh * 2), prod((size_t)CY * cxh * 2), corr((size_t)CY * CX);
+    std::vector<std::vector<double>> S(N, std::vector<double>((size_t)CY * cxh * 2));
+    for (int py = 0; py < patchesY; ++py)
+        for (int px = 0; px < patchesX; ++px) {
+            const double tlx = bordX + px * stepX, tly = bordY + py * stepY;
+            const double brx = tlx + PX - 1, bry = tly + PY - 1;
+            // Rectangle::getCenter: (tl + br) / 2 ... of the point type T (float): the centre may be fractional
+            const double cx = (tlx + brx) / 2, cy = (tly + bry) / 2;
+            centers[((size_t)py * patchesX + px) * 2] = cx; centers[((size_t)py * patchesX + px) * 2 + 1] = cy;
+            for (int t = 0; t < N; ++t) {
+                // getPatchData (:166-202): the frames t - (avg-1)/2 .. t + avg/2 at their rounded global shift, summed
+                std::fill(patch.begin(), patch.end(), 0.0);
+                for (int f = std::max(0, t - ((patchesAvg - 1) / 2)); f <= std::min(N - 1, t + (patchesAvg / 2)); ++f) {
+                    const int xs = (int)std::round(gShiftX[f]), ys = (int)std::round(gShiftY[f]);
+                    const double *fr = frames + (size_t)f * Y * X;
+                    for (int y = 0; y < PY; ++y) {
+                        const int srcY = (int)tly + y + ys, srcX = (int)tlx + xs;
+                        for (int x = 0; x < PX; ++x) patch[(size_t)y * PX + x] += fr[(size_t)srcY * X + srcX + x];
+                    }
+                }
+                // runFFTScale (cuda_flexalign_scale.cpp:58-77): un-normalised forward transform, rows 0 .. C/2 from the top and the
+                // C/2 - 1 last ones from the bottom, filter, 1 / (P P)
+                xo_fft2d_r2c(patch.data(), PY, PX, F.data());          // (normalised by norm already)
+                const cd *B = reinterpret_cast<const cd *>(F.data());
+                cd *O = reinterpret_cast<cd *>(S[t].data());
+                const int yhalf = CY / 2;
+                for (int iy = 0; iy < CY; ++iy) {
+                    const int origY = (iy <= yhalf) ? iy : (PY - (CY - iy));
+                    for (int ix = 0; ix < cxh; ++ix) O[(size_t)iy * cxh + ix] = B[(size_t)origY * pxh + ix] * filter[(size_t)iy * cxh + ix];
+                }
+            }
+            (void)norm;
+            std::vector<double> bx(rows), by(rows);
+            int idx = 0;
+            for (int i = 0; i < N - 1; ++i)
+                for (int j = i + 1; j < N; ++j, ++idx) {
+                    const cd *F1 = reinterpret_cast<const cd *>(S[i].data()), *F2 = reinterpret_cast<const cd *>(S[j].data());
+                    cd *P = reinterpret_cast<cd *>(prod.data());
+                    for (int iy = 0; iy < CY; ++iy)
+                        for (int ix = 0; ix < cxh; ++ix) {
+                            const double a = 1 - 2 * ((ix + iy) & 1);          // centres the correlation (even sizes)
+                            P[(size_t)iy * cxh + ix] = F1[(size_t)iy * cxh + ix] * std::conj(F2[(size_t)iy * cxh + ix]) * a;
+                        }
+                    xo_fft2d_c2r(prod.data(), CY, CX, corr.data());
+                    // sFindMax2DAroundCenter: first maximum in raster order within maxDist of (C/2, C/2)
+                    const int xHalf = CX / 2, yHalf = CY / 2;
+                    double best = -1.79769313486231570815e+308;
+                    int pos = -1;
+                    for (int y = std::max(0, yHalf - maxDist); y <= std::min(CY - 1, yHalf + maxDist); ++y)
+                        for (int x = std::max(0, xHalf - maxDist); x <= std::min(CX - 1, xHalf + maxDist); ++x) {
+                            const int ly = y - yHalf, lx = x - xHalf;
+                            if (ly * ly + lx * lx > maxDist * maxDist) continue;
+                            if (corr[(size_t)y * CX + x] > best) { best = corr[(size_t)y * CX + x]; pos = y * CX + x; }
+                        }
+                    // refineLocation<3>: centre of mass of the 3 x 3 window, values relative to the maximum
+                    double posX = 0, posY = 0;
+                    if (pos >= 0) {
+                        const int refY = pos / CX, refX = pos % CX;
+                        double refVal = corr[pos];
+                        refVal = (refVal == 0) ? 0 : 1.0 / refVal;
+                        double sw = 0, slx = 0, sly = 0;
+                        for (int y = std::max(0, refY - 1); y <= std::min(CY - 1, refY + 1); ++y)
+                            for (int x = std::max(0, refX - 1); x <= std::min(CX - 1, refX + 1); ++x) {
+                                const double rel = corr[(size_t)y * CX + x] * refVal;
+                                sw += rel; slx += x * rel; sly += y * rel;
+                            }
+                        sw = (sw == 0) ? 0 : 1.0 / sw;
+                        posX = slx * sw; posY = sly * sw;
+                    }
+                    // computeAlignment (:776-797): deduct the centre, scale to the patch's pixels
+                    bx[idx] = (posX - CX / 2.0) * ((double)PX / CX);
+                    by[idx] = (posY - CY / 2.0) * ((double)PY / CY);
+                }
+            std::vector<double> lsx(N), lsy(N);
+            int ref = refFrame;
+            alignment_from_pairs(bx, by, N, 2, refFrame, lsx.data(), lsy.data(), &ref);
+            for (int t = 0; t < N; ++t) {
+                double *o = patchShifts + (((size_t)py * patchesX + px) * N + t) * 2;
+                o[0] = std::round(gShiftX[t]) + lsx[t];
+                o[1] = std::round(gShiftY[t]) + lsy[t];
+            }
+        }
+    // BSplineHelper::computeBSplineCoeffs (bspline_helper.cpp:34-87)
+    const int nP = patchesX * patchesY, R = nP * N, Cc = lX * lY * lT;
+    std::vector<double> A((size_t)R * Cc, 0.0), bX(R), bY(R), cX, cY;
+    const double hX = (lX == 3) ? X : (X / (double)(lX - 3)), hY = (lY == 3) ? Y : (Y / (double)(lY - 3)), hT = (lT == 3) ? N : (N / (double)(lT - 3));
+    for (int py = 0; py < patchesY; ++py)
+        for (int px = 0; px < patchesX; ++px)
+            for (int t = 0; t < N; ++t) {
+                const int i = py * patchesX + px, row = t * nP + i;
+                const int tcx = (int)centers[(size_t)i * 2], tcy = (int)centers[(size_t)i * 2 + 1];        // int tileCenterX = meta.rec.getCenter().x
+                for (int ct = -1; ct < lT - 1; ++ct) {
+                    const double tT = bspline03((t / hT) - ct);
+                    if (tT == 0) continue;
+                    for (int cy = -1; cy < lY - 1; ++cy) {
+                        const double tY = bspline03((tcy / hY) - cy);
+                        if (tY == 0) continue;
+                        for (int cx = -1; cx < lX - 1; ++cx) {
+                            const double tX = bspline03((tcx / hX) - cx);
+                            A[(size_t)row * Cc + ((ct + 1) * lX * lY) + ((cy + 1) * lX) + (cx + 1)] = tT * tY * tX;
+                        }
+                    }
+                }
+                const double *sh = patchShifts + ((size_t)i * N + t) * 2;
+                bX[row] = -sh[0]; bY[row] = -sh[1];
+            }
+    solve_system(A, R, Cc, bX, bY, 2, cX, cY);
+    for (int k = 0; k < Cc; ++k) { coeffsX[k] = cX[k]; coeffsY[k] = cY[k]; }
+    return 0;
+}
+
+// BSplineHelper::getShift (bspline_helper.cpp:104-148) at pixel (x, y) of frame n
+void xo_fa_bspline_shift(const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int X, int Y, int N, int x, int y, int n,
+                         double *shiftX, double *shiftY)
+{
+    const double delta = 0.0001;
+    const double hX = (lX == 3) ? X : (X / (double)(lX - 3)), hY = (lY == 3) ? Y : (Y / (double)(lY - 3)), hT = (lT == 3) ? N : (N / (double)(lT - 3));
+    const double xPos = x / hX, yPos = y / hY, tPos = n / hT;
+    double sx = 0, sy = 0;
+    for (int it = std::max(-1, (int)tPos - 1); it <= std::min((int)tPos + 2, lT - 2); ++it) {
+        const double tT = bspline03(tPos - it);
+        for (int iy = std::max(-1, (int)yPos - 1); iy <= std::min((int)yPos + 2, lY - 2); ++iy) {
+            const double tY = bspline03(yPos - iy);
+            for (int ix = std::max(-1, (int)xPos - 1); ix <= std::min((int)xPos + 2, lX - 2); ++ix) {
+                const double tmp = bspline03(xPos - ix) * tY * tT;
+                if (std::fabs((float)tmp) > delta) {
+                    const size_t o = (size_t)(it + 1) * (lX * lY) + (size_t)(iy + 1) * lX + (ix + 1);
+                    sx += coeffsX[o] * tmp; sy += coeffsY[o] * tmp;
+                }
+            }
+        }
+    }
+    *shiftX = sx; *shiftY = sy;
+}
+
+// applyBSplineTransform(3, out, frame, coeffs, n) (cuda_gpu_geo_transformer.cpp:155-184, kernel cuda_gpu_geo_transformer.cu:96-131):
+// cubic B-spline coefficients of the frame, every output pixel sampled at (x - shiftX, y - shiftY), mirror boundaries
+void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int N, int n,
+                         double *out)
+{
+    std::vector<double> coef((size_t)Y * X);
+    xo::prefilter2d(frame, Y, X, coef.data());
+    for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x) {
+            double sx, sy;
+            xo_fa_bspline_shift(coeffsX, coeffsY, lX, lY, lT, X, Y, N, x, y, n, &sx, &sy);
+            out[(size_t)y * X + x] = xo::interp2d(coef.data(), Y, X, 0, 0, x - sx, y - sy);
+        }
 }
 
 }  // extern "C"

@@ -75,3 +75,31 @@ def make_particles(refs, n, rng, snr=0.1, max_shift=3):
         out[i] = img
         truth.append((k, ang, fl, int(sh[1]), int(sh[0])))
     return out, truth
+
+
+def movie(N, Y, X, seed, max_step=1.5, noise=0.5, smooth=3.0, local=0.0):
+    """A smooth random field drifting under the frame window plus white noise per frame. local > 0 adds a drift that grows
+    with time and differs over the field (a dilation about the centre plus a shear, `local` px at the corners of the last frame):
+    returns frames [N, Y, X] (float32), the global drift [N, 2] (x, y) and a function field(n, x, y) -> (dx, dy), the
+    displacement of the content of frame n at movie position (x, y)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    base = ndimage.gaussian_filter(rng.standard_normal((Y + 64, X + 64)), smooth) * 10
+    drift = np.cumsum(rng.uniform(-max_step, max_step, (N, 2)), 0)
+    drift -= drift[0]
+
+    def field(n, x, y):
+        u, v = (np.asarray(x, float) / X - 0.5) * 2, (np.asarray(y, float) / Y - 0.5) * 2
+        a = local * n / max(N - 1, 1)
+        return drift[n, 0] + a * (0.7 * u + 0.3 * v), drift[n, 1] + a * (0.8 * v - 0.2 * u)
+
+    yy, xx = np.mgrid[0:Y, 0:X].astype(float)
+    frames = []
+    for n in range(N):
+        if local == 0.0:
+            f = ndimage.shift(base, (-drift[n, 1], -drift[n, 0]), order=3, mode="wrap")[32:32 + Y, 32:32 + X]
+        else:
+            dx, dy = field(n, xx, yy)
+            f = ndimage.map_coordinates(base, [yy + 32 + dy, xx + 32 + dx], order=3, mode="wrap")
+        frames.append(f + noise * rng.standard_normal((Y, X)))
+    return np.stack(frames).astype(np.float32), drift, field

@@ -14,15 +14,9 @@ def gpu():
 
 
 def synthetic_movie(N, Y, X, seed, max_step=1.5, noise=0.5, smooth=3.0):
-    """A smooth random field drifting under the frame window, plus white noise per frame."""
-    from scipy import ndimage
-    rng = np.random.default_rng(seed)
-    base = ndimage.gaussian_filter(rng.standard_normal((Y + 64, X + 64)), smooth) * 10
-    drift = np.cumsum(rng.uniform(-max_step, max_step, (N, 2)), 0)
-    drift -= drift[0]
-    frames = np.stack([ndimage.shift(base, (-drift[i, 1], -drift[i, 0]), order=3, mode="wrap")[32:32 + Y, 32:32 + X]
-                       + noise * rng.standard_normal((Y, X)) for i in range(N)])
-    return frames.astype(np.float32), drift
+    from tests import synth
+    frames, drift, _ = synth.movie(N, Y, X, seed, max_step, noise, smooth)
+    return frames, drift
 
 
 @pytest.mark.parametrize("N,Y,X,ts,res", [(8, 512, 512, 1.0, 8.0), (6, 240, 320, 1.0, 8.0), (5, 384, 300, 1.4, 12.0)])

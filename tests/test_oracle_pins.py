@@ -274,3 +274,48 @@ def test_the_two_reference_reconstruction_programs_agree_to_float_level():
     assert np.corrcoef(va.ravel(), vb.ravel())[0, 1] > 0.99999
     assert np.abs(vb3 - vb).max() <= 1e-12 * peak
     assert np.corrcoef(vb.ravel(), vol.ravel())[0, 1] > 0.999
+
+
+def test_flexalign_local_alignment_recovers_a_known_field(oracle):
+    """The patch alignment of the CUDA program (computeLocalAlignment) has no known answer in the reference either (its tests need
+    a CUDA device): physics again. A movie whose drift differs over the field: the patch shifts follow the local drift at the
+    patch centres, the B-spline of BSplineHelper gives -(patch shift) back at the centres (the rows of the fit), its value
+    anywhere in the field is the local displacement from the reference frame, and warping a frame by it (applyShiftTransform's
+    arithmetic) brings it onto the reference frame."""
+    from tests import synth
+    N, Y, X = 8, 384, 384
+    frames, drift, field = synth.movie(N, Y, X, seed=3, local=4.0)
+    g = oracle.fa_global_alignment(frames, max_shift_px=30.0, max_res=8.0)
+    ref, cp, pt = g["ref"], (3, 3, 3), (5, 5)
+    loc = oracle.fa_local_alignment(frames, g["shiftX"], g["shiftY"], ref, max_shift_px=30.0, max_res=8.0, patches=pt, patch_size=(128, 128),
+                                    control_points=cp)
+    assert loc["dims"] == (128, 128, 110, 110)        # getCorrelationHint: the smallest even size with size / 128 >= 0.8493
+    ps, cen = loc["patch_shifts"], loc["centers"]
+    e_patch, e_fit = [], []
+    for j in range(pt[1]):
+        for i in range(pt[0]):
+            for n in range(N):
+                dx, dy = field(n, cen[j, i, 0], cen[j, i, 1])
+                d0x, d0y = field(ref, cen[j, i, 0], cen[j, i, 1])
+                e_patch.append((ps[j, i, n, 0] + dx - d0x, ps[j, i, n, 1] + dy - d0y))
+                sx, sy = oracle.fa_bspline_shift(loc["coeffsX"], loc["coeffsY"], cp, X, Y, N, int(cen[j, i, 0]), int(cen[j, i, 1]), n)
+                e_fit.append((sx + ps[j, i, n, 0], sy + ps[j, i, n, 1]))
+    e_patch, e_fit = np.array(e_patch), np.array(e_fit)
+    assert np.sqrt((e_patch ** 2).mean()) < 0.6 and np.abs(e_patch).max() < 1.5
+    assert np.sqrt((e_fit ** 2).mean()) < 0.8          # 27 coefficients for 200 rows, and getShift drops terms below 1e-4
+    e_field, raw = [], []
+    for n in range(N):
+        for y in range(64, Y - 63, 64):
+            for x in range(64, X - 63, 64):
+                sx, sy = oracle.fa_bspline_shift(loc["coeffsX"], loc["coeffsY"], cp, X, Y, N, x, y, n)
+                dx, dy = field(n, x, y)
+                d0x, d0y = field(ref, x, y)
+                e_field.append((sx - (dx - d0x), sy - (dy - d0y)))
+                raw.append((dx - d0x, dy - d0y))
+    e_field, raw = np.array(e_field), np.array(raw)
+    assert np.sqrt((e_field ** 2).mean()) < 0.7 < 1.2 < np.sqrt((raw ** 2).mean())
+    n = N - 1 if ref < N // 2 else 0
+    w = oracle.fa_apply_bspline(frames[n], loc["coeffsX"], loc["coeffsY"], cp, N, n)
+    w0 = oracle.fa_apply_bspline(frames[ref], loc["coeffsX"], loc["coeffsY"], cp, N, ref)
+    c = lambda a, b: np.corrcoef(a[40:-40, 40:-40].ravel(), b[40:-40, 40:-40].ravel())[0, 1]
+    assert c(frames[n], frames[ref]) < 0.75 < 0.8 < c(w, w0)
