@@ -394,13 +394,37 @@ int xh_ctfop_wiener2d(xh_ctfop *h, float *d_imgs /* [n][ydim][xdim] */, int32_t 
  *   global_alignment: d_frames [N][Y][X] float on the device, d_dark / d_gain [Y][X] or null, max_shift_px = --maxShift /
  *   sampling rate. Host outputs: pair shifts h_bX / h_bY [N (N-1)/2] (nullable; movie pixels, order (0,1), (0,2) ...),
  *   h_shiftX / h_shiftY [N] from the reference frame h_ref (what storeGlobalShifts negates into the metadata).
- * The patch (local) alignment has no CPU counterpart in the reference and is not part of this entry. */
+ *
+ * Local (patch) alignment, ProgMovieAlignmentCorrelationGPU<T>::computeLocalAlignment (movie_alignment_correlation_gpu.cpp:
+ * 288-430; the reference has it for CUDA only) and the output of the aligned movie (applyShiftsComputeAverage, :479-570):
+ *   local_alignment: patches_x x patches_y patches of patch_size pixels (made even) laid out by getPatchesLocation over what
+ *   the global shifts h_gShiftX/Y [N] leave of the frame; per patch the sum of patches_avg frames at their rounded global
+ *   shift, reduced in Fourier space to the correlation size (getCorrelationHint: the smallest even size keeping the scale
+ *   factor; the reference may pick a larger one after benchmarking cuFFT on the installed GPU), low-passed, all frame pairs
+ *   correlated, first maximum within max_shift of the centre, 3 x 3 centre of mass, least squares per patch from frame
+ *   ref_frame. Host outputs: h_patchShifts [patches_y][patches_x][N][2] (x, y; rounded global + local), h_centers
+ *   [patches_y][patches_x][2], the B-spline coefficients h_coeffsX/Y [lT][lY][lX] of BSplineHelper::computeBSplineCoeffs
+ *   (nullable), h_dims[4] = patch size x, y, correlation size x, y (nullable).
+ *   local_from_global: localFromGlobal (:432-456), the B-spline of a movie aligned globally only.
+ *   apply_bspline: frame n of N (d_frame [Y][X], dark / gain applied on the way) warped by the B-spline like
+ *   GeoTransformer::applyBSplineTransform(3, ...) (cuda_gpu_geo_transformer.cpp:186-239): d_out = the aligned frame (nullable),
+ *   d_sum += it (nullable), d_initial_sum += the corrected, unaligned frame (nullable). */
 typedef struct xh_fa xh_fa;
 int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float max_res_for_correlation, xh_fa **out);
 int xh_fa_destroy(xh_fa *h);
 int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor);
 int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, float max_shift_px,
                            double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref);
+int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, const double *h_gShiftX,
+                          const double *h_gShiftY, int32_t ref_frame, float max_shift_px, int32_t patches_x, int32_t patches_y,
+                          int32_t patch_size_x, int32_t patch_size_y, int32_t patches_avg, int32_t lX, int32_t lY, int32_t lT,
+                          double *h_patchShifts, double *h_centers, double *h_coeffsX, double *h_coeffsY, int32_t *h_dims);
+int xh_fa_local_from_global(xh_fa *h, int32_t N, const double *h_gShiftX, const double *h_gShiftY, int32_t patches_x, int32_t patches_y,
+                            int32_t patch_size_x, int32_t patch_size_y, int32_t lX, int32_t lY, int32_t lT, double *h_centers,
+                            double *h_coeffsX, double *h_coeffsY);
+int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, const float *d_gain, const double *h_coeffsX,
+                        const double *h_coeffsY, int32_t lX, int32_t lY, int32_t lT, int32_t N, int32_t n, float *d_out, float *d_sum,
+                        float *d_initial_sum);
 
 #ifdef __cplusplus
 }

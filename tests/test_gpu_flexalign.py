@@ -75,3 +75,109 @@ def test_errors_are_loud(gpu):
     fa = xa.FlexAlign(ctx, 256, 256, 1.0, 8.0)
     with pytest.raises(xa.XhError):
         fa.global_alignment(torch.zeros((3, 256, 256), device="cuda"), 500.0)       # --maxShift beyond the reduced frame
+
+
+@pytest.mark.parametrize("N,Y,X,patches,psize,cp,avg", [(8, 384, 384, (5, 5), (128, 128), (3, 3, 3), 3), (6, 300, 420, (4, 5), (100, 90), (3, 4, 3), 1)])
+def test_local_alignment_against_the_oracle(gpu, oracle, N, Y, X, patches, psize, cp, avg):
+    """computeLocalAlignment of the CUDA program: patch layout, patch shifts (pruned fp32 transforms against the oracle's double
+    FFTs: 5e-3 px) and the B-spline fitted to them, evaluated over the field (the coefficients themselves are badly conditioned
+    -- end control points barely touch the patch centres -- their spline is not)."""
+    from tests import synth
+    xa, ctx, torch = gpu
+    frames, drift, field = synth.movie(N, Y, X, seed=N + X, local=4.0)
+    max_shift, res = 25.0, 8.0
+    g = oracle.fa_global_alignment(frames, max_shift_px=max_shift, max_res=res)
+    exp = oracle.fa_local_alignment(frames, g["shiftX"], g["shiftY"], g["ref"], max_shift_px=max_shift, max_res=res, patches=patches, patch_size=psize,
+                                    patches_avg=avg, control_points=cp)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, res)
+    got = fa.local_alignment(torch.from_numpy(frames).cuda(), g["shiftX"], g["shiftY"], g["ref"], max_shift, patches, psize, avg, cp)
+    assert got["dims"] == exp["dims"]
+    assert np.array_equal(got["centers"], exp["centers"])
+    d = np.abs(got["patch_shifts"] - exp["patch_shifts"])
+    print("patch shifts: max difference", d.max())
+    assert d.max() <= 5e-3
+    worst = 0.0
+    for n in range(N):
+        for y in range(0, Y, 37):
+            for x in range(0, X, 41):
+                a = oracle.fa_bspline_shift(got["coeffsX"], got["coeffsY"], cp, X, Y, N, x, y, n)
+                b = oracle.fa_bspline_shift(exp["coeffsX"], exp["coeffsY"], cp, X, Y, N, x, y, n)
+                worst = max(worst, abs(a[0] - b[0]), abs(a[1] - b[1]))
+    print("spline: max difference over the field", worst)
+    assert worst <= 0.05
+
+
+def test_bspline_warp_against_the_oracle(gpu, oracle):
+    """applyBSplineTransform: prefilter (33-tap fp32 convolution against the double recursion), the shift of every pixel from the
+    control points with the reference's 1e-4 cut, cubic interpolation with mirrored borders; dark and gain on the way; the two
+    sums. Coefficients from a real fit and, second case, random ones of a few pixels (shifts that leave the frame)."""
+    from tests import synth
+    xa, ctx, torch = gpu
+    N, Y, X = 6, 200, 264
+    frames, drift, field = synth.movie(N, Y, X, seed=9, local=3.0)
+    rng = np.random.default_rng(2)
+    dark = (0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    gain = (1.0 + 0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+    g = oracle.fa_global_alignment(frames, max_shift_px=20.0, max_res=8.0)
+    cp = (4, 3, 5)
+    cx, cy = fa.local_from_global(g["shiftX"], g["shiftY"], patches=(5, 4), patch_size=(64, 64), control_points=cp)
+    # localFromGlobal: the spline follows the negative of the frames' global shifts (loosely: five control points in time for six
+    # frames, weakly determined end points and the 1e-4 cut of getShift; the fit itself is checked against the oracle above)
+    for n in range(N):
+        sx, sy = oracle.fa_bspline_shift(cx, cy, cp, X, Y, N, X // 3, Y // 2, n)
+        assert abs(sx + g["shiftX"][n]) < 1.0 and abs(sy + g["shiftY"][n]) < 1.0
+    cases = [(cx, cy), (rng.uniform(-6, 6, cx.size), rng.uniform(-6, 6, cx.size))]
+    for cxx, cyy in cases:
+        total = torch.zeros((Y, X), device="cuda")
+        initial = torch.zeros((Y, X), device="cuda")
+        exp_total = np.zeros((Y, X))
+        for n in range(N):
+            out = torch.empty((Y, X), device="cuda")
+            fa.apply_bspline(torch.from_numpy(frames[n]).cuda(), cxx, cyy, cp, N, n, torch.from_numpy(dark).cuda(), torch.from_numpy(gain).cuda(), out, total, initial)
+            corrected = (frames[n].astype(np.float64) - dark) * gain
+            exp = oracle.fa_apply_bspline(corrected, cxx.astype(np.float32), cyy.astype(np.float32), cp, N, n)
+            exp_total += exp
+            err = np.abs(out.cpu().numpy() - exp).max()
+            assert err <= 2e-4 * np.abs(exp).max(), (n, err)
+        assert np.abs(total.cpu().numpy() - exp_total).max() <= 3e-4 * np.abs(exp_total).max()
+        assert np.abs(initial.cpu().numpy() - ((frames.astype(np.float64) - dark) * gain).sum(0)).max() <= 1e-4 * np.abs(exp_total).max()
+
+
+def test_local_alignment_improves_a_movie_with_a_drift_field(gpu):
+    """End to end on the device at a size no oracle run fits in a test (12 frames of 1536 x 1536, 7 x 7 patches of 300 px,
+    5 x 5 x 4 control points): global alignment, local alignment, warp; the aligned sum correlates with the clean field
+    better than the sum aligned globally only."""
+    from scipy import ndimage
+    xa, ctx, torch = gpu
+    N, Y, X = 12, 1536, 1536
+    rng = np.random.default_rng(4)
+    base = ndimage.gaussian_filter(rng.standard_normal((Y + 64, X + 64)), 2.0) * 10
+    drift = np.cumsum(rng.uniform(-1.5, 1.5, (N, 2)), 0)
+    drift -= drift[0]
+    yy, xx = np.mgrid[0:Y, 0:X].astype(np.float64)
+    u, v = (xx / X - 0.5) * 2, (yy / Y - 0.5) * 2
+    frames = np.empty((N, Y, X), np.float32)
+    for n in range(N):
+        a = 5.0 * n / (N - 1)
+        dx, dy = drift[n, 0] + a * (0.7 * u + 0.3 * v), drift[n, 1] + a * (0.8 * v - 0.2 * u)
+        frames[n] = ndimage.map_coordinates(base, [yy + 32 + dy, xx + 32 + dx], order=1, mode="wrap") + 0.5 * rng.standard_normal((Y, X))
+    d_frames = torch.from_numpy(frames).cuda()
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 10.0)
+    g = fa.global_alignment(d_frames, 40.0)
+    patches, psize, cp = (7, 7), (300, 300), (5, 5, 4)
+    loc = fa.local_alignment(d_frames, g["shiftX"], g["shiftY"], g["ref"], 40.0, patches, psize, 3, cp)
+    gcx, gcy = fa.local_from_global(g["shiftX"], g["shiftY"], patches, psize, cp)
+    sums = {}
+    for name, (cx, cy) in {"global": (gcx, gcy), "local": (loc["coeffsX"], loc["coeffsY"])}.items():
+        total = torch.zeros((Y, X), device="cuda")
+        for n in range(N):
+            fa.apply_bspline(d_frames[n], cx, cy, cp, N, n, total=total)
+        sums[name] = total.cpu().numpy()
+    # the clean field as the reference frame saw it
+    a = 5.0 * g["ref"] / (N - 1)
+    dx, dy = drift[g["ref"], 0] + a * (0.7 * u + 0.3 * v), drift[g["ref"], 1] + a * (0.8 * v - 0.2 * u)
+    clean = ndimage.map_coordinates(base, [yy + 32 + dy, xx + 32 + dx], order=1, mode="wrap")
+    c = {k: np.corrcoef(s[64:-64, 64:-64].ravel(), clean[64:-64, 64:-64].ravel())[0, 1] for k, s in sums.items()}
+    print("correlation of the aligned sum with the clean field:", c)
+    assert c["local"] > 0.99 and (1 - c["local"]) < 0.5 * (1 - c["global"])

@@ -451,6 +451,50 @@ class FlexAlign:
                                            _np_ptr(bx), _np_ptr(by), _np_ptr(sx), _np_ptr(sy), C.byref(ref)))
         return {"bX": bx, "bY": by, "shiftX": sx, "shiftY": sy, "ref": ref.value}
 
+    def local_alignment(self, frames, g_shift_x, g_shift_y, ref, max_shift_px, patches=(7, 7), patch_size=(500, 500), patches_avg=3,
+                        control_points=(6, 6, 5), dark=None, gain=None):
+        """computeLocalAlignment of the CUDA program: dict(patch_shifts [py, px, N, 2], centers [py, px, 2], coeffsX, coeffsY, dims)"""
+        torch = _torch()
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape[1:]) == (self.Y, self.X)
+        N = frames.shape[0]
+        px, py = patches
+        lX, lY, lT = control_points
+        gx, gy = np.ascontiguousarray(g_shift_x, np.float64), np.ascontiguousarray(g_shift_y, np.float64)
+        assert gx.shape == (N,) and gy.shape == (N,)
+        shifts, centers = np.empty((py, px, N, 2)), np.empty((py, px, 2))
+        cx, cy = np.empty(lX * lY * lT), np.empty(lX * lY * lT)
+        dims = np.zeros(4, np.int32)
+        check(lib().xh_fa_local_alignment(self.h, _ptr(frames), N, _ptr(dark, torch.float32), _ptr(gain, torch.float32), _np_ptr(gx), _np_ptr(gy), int(ref),
+                                          float(max_shift_px), px, py, int(patch_size[0]), int(patch_size[1]), int(patches_avg), lX, lY, lT,
+                                          _np_ptr(shifts), _np_ptr(centers), _np_ptr(cx), _np_ptr(cy), _np_ptr(dims)))
+        return {"patch_shifts": shifts, "centers": centers, "coeffsX": cx, "coeffsY": cy, "dims": tuple(int(v) for v in dims)}
+
+    def local_from_global(self, g_shift_x, g_shift_y, patches=(7, 7), patch_size=(500, 500), control_points=(6, 6, 5)):
+        """localFromGlobal: the B-spline of a movie aligned globally only -> (coeffsX, coeffsY)"""
+        gx, gy = np.ascontiguousarray(g_shift_x, np.float64), np.ascontiguousarray(g_shift_y, np.float64)
+        N = gx.shape[0]
+        px, py = patches
+        lX, lY, lT = control_points
+        centers = np.empty((py, px, 2))
+        cx, cy = np.empty(lX * lY * lT), np.empty(lX * lY * lT)
+        check(lib().xh_fa_local_from_global(self.h, N, _np_ptr(gx), _np_ptr(gy), px, py, int(patch_size[0]), int(patch_size[1]), lX, lY, lT, _np_ptr(centers),
+                                            _np_ptr(cx), _np_ptr(cy)))
+        return cx, cy
+
+    def apply_bspline(self, frame, coeffsX, coeffsY, control_points, N, n, dark=None, gain=None, out=None, total=None, initial=None):
+        """Frame n of N ([Y, X] float32 on the device) warped by the B-spline (applyBSplineTransform): out = aligned frame,
+        total += it, initial += the corrected unaligned frame (each optional)."""
+        torch = _torch()
+        assert frame.is_cuda and frame.dtype == torch.float32 and frame.is_contiguous() and tuple(frame.shape) == (self.Y, self.X)
+        for t in (out, total, initial):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.Y, self.X))
+        lX, lY, lT = control_points
+        cx, cy = np.ascontiguousarray(coeffsX, np.float64), np.ascontiguousarray(coeffsY, np.float64)
+        assert cx.size == lX * lY * lT and cy.size == lX * lY * lT
+        check(lib().xh_fa_apply_bspline(self.h, _ptr(frame), _ptr(dark, torch.float32), _ptr(gain, torch.float32), _np_ptr(cx), _np_ptr(cy), lX, lY, lT, int(N), int(n),
+                                        _ptr(out), _ptr(total), _ptr(initial)))
+        return out
+
 
 class CtfOps:
     """CTF pre-steps on the device: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) and

@@ -27,6 +27,7 @@
 #include <limits>
 
 #include "xh_common.h"
+#include "xh_bspline.h"
 
 namespace {
 typedef float2 fa_cf;
@@ -170,6 +171,294 @@ __global__ void __launch_bounds__(256) k_fa_bestshift(const fa_cf *__restrict__ 
     out[0] = shiftX; out[1] = shiftY; out[2] = mx;
 }
 
+// ---- local (patch) alignment: computeLocalAlignment, movie_alignment_correlation_gpu.cpp:288-430 ------------------------------
+// One patch position at a time, all N frames of it:
+//   k_fa_gather      the patch window of every frame at the frame's rounded global shift, dark / gain applied (getPatchData, :166-202)
+//   k_fa_gemm        the part of the patch spectrum the correlation keeps, as two pruned DFTs written as matrix products:
+//                    along x for the cxh = C/2+1 kept columns, along y for the C kept rows (performFFTAndScale /
+//                    scaleFFT2DKernel, cuda_flexalign_scale.cpp:58-77 + cuda_gpu_movie_alignment_correlation_kernels.cu, take an
+//                    FFT of P x P and drop all but C x cxh values: 58 x 114 of 251 x 500 at the defaults)
+//   k_fa_patch_sum   the patchesAvg frames around t summed (the transform is linear: getPatchData sums the pixels), low-pass
+//   k_fa_patch_corr  per frame pair: S_a conj(S_b) (-1)^(x+y), inverse transform of the window the maximum is searched in only
+//                    (2 maxDist + 3 rows and columns about the centre, not all C x C), first maximum within maxDist, centre of
+//                    mass of the 3 x 3 values around it (computeCorrelations / sFindMax2DAroundCenter / refineLocation)
+__global__ void __launch_bounds__(256) k_fa_gather(const float *__restrict__ frames, const float *__restrict__ dark, const float *__restrict__ gain,
+                                                   const int *__restrict__ offs, float *__restrict__ out, int N, int Y, int X, int PY, int PX)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)N * PY * PX) return;
+    const int x = (int)(t % PX), y = (int)((t / PX) % PY), f = (int)(t / ((size_t)PX * PY));
+    const size_t src = (size_t)(offs[2 * f + 1] + y) * X + offs[2 * f] + x;
+    float v = frames[(size_t)f * Y * X + src];
+    if (dark) v -= dark[src];
+    if (gain) v *= gain[src];
+    out[t] = v;
+}
+
+// C[b][m][n] = sum_k A[b][m][k] B[b][k][n], B and C complex, A real or complex; 64 x 32 tiles of C per block, 4 x 2 per thread
+template <bool ACPLX>
+__global__ void __launch_bounds__(256) k_fa_gemm(const float *__restrict__ A, size_t lda, size_t sA, const fa_cf *__restrict__ B, size_t ldb, size_t sB,
+                                                 fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K)
+{
+    constexpr int TM = 64, TN = 32, TK = 16;
+    __shared__ fa_cf As[TK][TM + 1];
+    __shared__ fa_cf Bs[TK][TN];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    A += sA * blockIdx.z; B += sB * blockIdx.z; C += sC * blockIdx.z;
+    fa_cf acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = fa_cf{0.f, 0.f}; acc[i][1] = fa_cf{0.f, 0.f}; }
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        {
+            const int r = t >> 2, kc = (t & 3) * 4, m = m0 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + kc + q;
+                fa_cf v = fa_cf{0.f, 0.f};
+                if (m < M && k < K) {
+                    if (ACPLX) v = reinterpret_cast<const fa_cf *>(A)[(size_t)m * lda + k];
+                    else v.x = A[(size_t)m * lda + k];
+                }
+                As[kc + q][r] = v;
+            }
+            const int kb = t >> 4, nb = (t & 15) * 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = k0 + kb, n = n0 + nb + q;
+                Bs[kb][nb + q] = (k < K && n < Nc) ? B[(size_t)k * ldb + n] : fa_cf{0.f, 0.f};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            const fa_cf b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const fa_cf a = As[kk][ty * 4 + i];
+                acc[i][0].x += a.x * b0.x; acc[i][0].y += a.x * b0.y;
+                acc[i][1].x += a.x * b1.x; acc[i][1].y += a.x * b1.y;
+                if (ACPLX) {
+                    acc[i][0].x -= a.y * b0.y; acc[i][0].y += a.y * b0.x;
+                    acc[i][1].x -= a.y * b1.y; acc[i][1].y += a.y * b1.x;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = n0 + tx * 2 + q;
+            if (n < Nc) C[(size_t)m * ldc + n] = acc[i][q];
+        }
+    }
+}
+
+// S[t] = filter * sum of the single-frame spectra of the frames t - (avg-1)/2 .. t + avg/2
+__global__ void __launch_bounds__(256) k_fa_patch_sum(const fa_cf *__restrict__ single, fa_cf *__restrict__ S, const float *__restrict__ filter, int N, size_t E, int avg)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (size_t)N * E) return;
+    const int t = (int)(g / E);
+    const size_t e = g - (size_t)t * E;
+    float re = 0.f, im = 0.f;
+    for (int f = max(0, t - ((avg - 1) / 2)); f <= min(N - 1, t + (avg / 2)); ++f) { const fa_cf v = single[(size_t)f * E + e]; re += v.x; im += v.y; }
+    const float w = filter[e];
+    S[g] = fa_cf{re * w, im * w};
+}
+
+// One block per frame pair (a, b), a < b in the order (0,1), (0,2) ...: the correlation map in rows y0 .. y0+wy-1, columns
+// x0 .. x0+wx-1 (U, W: scratch of the block), its first maximum within maxDist of the centre and the 3 x 3 centre of mass.
+// out[pair] = (posX, posY) in pixels of the correlation map.
+__global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__ S, int N, int CY, int CX, const fa_cf *__restrict__ tabY, const fa_cf *__restrict__ tabX,
+                                                       int y0, int wy, int x0, int wx, int maxDist, fa_cf *__restrict__ Uall, float *__restrict__ Wall,
+                                                       double *__restrict__ out)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int cxh = CX / 2 + 1;
+    // pair index -> (a, b)
+    int a = 0, rem = blockIdx.x;
+    while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
+    const int b = a + 1 + rem;
+    const fa_cf *Sa = S + (size_t)a * CY * cxh, *Sb = S + (size_t)b * CY * cxh;
+    fa_cf *U = Uall + (size_t)blockIdx.x * wy * cxh;
+    float *W = Wall + (size_t)blockIdx.x * wy * wx;
+    // along y: U[yy][kx] = sum_ky P[ky][kx] e^{2 pi i ky y / CY}
+    for (int o = threadIdx.x; o < wy * cxh; o += 256) {
+        const int yy = o / cxh, kx = o - yy * cxh, y = y0 + yy;
+        float re = 0.f, im = 0.f;
+        int m = 0;
+        for (int ky = 0; ky < CY; ++ky) {
+            const fa_cf p = Sa[(size_t)ky * cxh + kx], q = Sb[(size_t)ky * cxh + kx];
+            const float sgn = ((kx + ky) & 1) ? -1.f : 1.f;                      // centres the correlation
+            const float pr = (p.x * q.x + p.y * q.y) * sgn, pi = (p.y * q.x - p.x * q.y) * sgn;
+            const fa_cf w = tabY[m];
+            re += pr * w.x - pi * w.y; im += pr * w.y + pi * w.x;
+            m += y; if (m >= CY) m -= CY;
+        }
+        U[o] = fa_cf{re, im};
+    }
+    __syncthreads();
+    // along x, real part: what a complex-to-real transform of the half spectrum returns
+    for (int o = threadIdx.x; o < wy * wx; o += 256) {
+        const int yy = o / wx, xx = o - yy * wx, x = x0 + xx;
+        const fa_cf *u = U + (size_t)yy * cxh;
+        float acc = 0.f;
+        int m = 0;
+        for (int kx = 0; kx < cxh; ++kx) {
+            const fa_cf w = tabX[m], v = u[kx];
+            const float r = v.x * w.x - v.y * w.y;
+            acc += (kx == 0 || 2 * kx == CX) ? r : 2.f * r;
+            m += x; if (m >= CX) m -= CX;
+        }
+        W[o] = acc;
+    }
+    __syncthreads();
+    const int xHalf = CX / 2, yHalf = CY / 2;
+    float best = -3.402823466e+38f;
+    int bestIdx = 0x7fffffff;
+    for (int o = threadIdx.x; o < wy * wx; o += 256) {
+        const int yy = o / wx, xx = o - yy * wx;
+        const int ly = y0 + yy - yHalf, lx = x0 + xx - xHalf;
+        if (ly * ly + lx * lx > maxDist * maxDist) continue;
+        const float v = W[o];
+        if (v > best) { best = v; bestIdx = o; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bestIdx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v = sv[threadIdx.x + o];
+            const int k = si[threadIdx.x + o];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && k < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = k; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double posX = 0, posY = 0;
+    if (si[0] != 0x7fffffff) {
+        const int refY = y0 + si[0] / wx, refX = x0 + si[0] % wx;
+        double refVal = (double)sv[0];
+        refVal = (refVal == 0) ? 0 : 1.0 / refVal;
+        double sw = 0, slx = 0, sly = 0;
+        for (int y = max(0, refY - 1); y <= min(CY - 1, refY + 1); ++y)
+            for (int x = max(0, refX - 1); x <= min(CX - 1, refX + 1); ++x) {
+                const double rel = (double)W[(size_t)(y - y0) * wx + (x - x0)] * refVal;
+                sw += rel; slx += x * rel; sly += y * rel;
+            }
+        sw = (sw == 0) ? 0 : 1.0 / sw;
+        posX = slx * sw; posY = sly * sw;
+    }
+    out[2 * blockIdx.x] = posX; out[2 * blockIdx.x + 1] = posY;
+}
+
+// ---- B-spline warp: applyBSplineTransform(3, ...) (cuda_gpu_geo_transformer.cpp:186-239) ---------------------------------------
+// cubic B-spline prefilter of the (dark / gain corrected) frame as a convolution (xh_bspline.h: exactly the recursion with the
+// half-sample mirror, 33 taps in fp32), columns then rows; COLS: `in` is the raw frame and the correction is applied on the way
+template <bool COLS>
+__global__ void __launch_bounds__(256) k_fa_fir(const float *__restrict__ in, const float *__restrict__ dark, const float *__restrict__ gain, float *__restrict__ out,
+                                                float *__restrict__ plain, int Y, int X, XhFir F)
+{
+    const unsigned segs = COLS ? (Y + XH_FIR_V - 1) / XH_FIR_V : (X + XH_FIR_V - 1) / XH_FIR_V;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)segs * (COLS ? X : Y)) return;
+    int x0, y0;
+    if (COLS) { const unsigned q = (unsigned)(t / X); x0 = (int)(t - (size_t)q * X); y0 = q * XH_FIR_V; }
+    else { const unsigned q = (unsigned)(t / segs); x0 = (int)(t - (size_t)q * segs) * XH_FIR_V; y0 = q; }
+    const int n = COLS ? Y : X;
+    float w[XH_FIR_V + 2 * XH_FIR_K];
+#pragma unroll
+    for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
+        int p = (COLS ? y0 : x0) + i - XH_FIR_K;
+        while (p < 0 || p >= n) p = p < 0 ? -1 - p : 2 * n - 1 - p;
+        const size_t src = COLS ? (size_t)p * X + x0 : (size_t)y0 * X + p;
+        float v = in[src];
+        if (COLS) {
+            if (dark) v -= dark[src];
+            if (gain) v *= gain[src];
+        }
+        w[i] = v;
+    }
+#pragma unroll
+    for (int o = 0; o < XH_FIR_V; ++o) {
+        const int q = (COLS ? y0 : x0) + o;
+        if (q >= n) break;
+        float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+        const size_t dst = COLS ? (size_t)q * X + x0 : (size_t)y0 * X + q;
+        out[dst] = acc;
+        if (COLS && plain) plain[dst] += w[o + XH_FIR_K];          // the sum of the unaligned frames (initialMic)
+    }
+}
+
+__device__ __forceinline__ float d_fa_b3(float x)
+{
+    // bspline03, reconstruction_cuda/cuda_gpu_bilib.cu:16-25
+    float a = fabsf(x);
+    if (a < 1.f) return a * a * (a - 2.f) * 0.5f + (2.f / 3.f);
+    if (a < 2.f) { a -= 2.f; return a * a * a * (-1.f / 6.f); }
+    return 0.f;
+}
+
+// applyLocalShiftGeometryKernelMorePixels<T, 3> (cuda_gpu_geo_transformer.cu:193-254): the shift of every pixel from the control
+// points (getShiftMorePixels: terms of weight <= 1e-4 are dropped), the frame sampled at (x - shiftX, y - shiftY) with mirrored
+// borders (interpolatedElementBSpline2D_Degree3MorePixelsEdge, cuda_gpu_multidim_array.cu:277-334)
+__global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef, const float *__restrict__ cX, const float *__restrict__ cY, int lX, int lY, int lT,
+                                                 float hX, float hY, float tPos, int Y, int X, float *__restrict__ out, float *__restrict__ sum)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= X || y >= Y) return;
+    const float delta = 0.0001f;
+    const float xPos = x / hX, yPos = y / hY;
+    float sx = 0.f, sy = 0.f;
+    const int tEnd = min((int)tPos + 2, lT - 2), xEnd = min((int)xPos + 2, lX - 2), yEnd = min((int)yPos + 2, lY - 2);
+    for (int it = (int)tPos - 1; it <= tEnd; ++it) {
+        const float tT = d_fa_b3(tPos - it);
+        for (int ix = (int)xPos - 1; ix <= xEnd; ++ix) {
+            const float tX = d_fa_b3(xPos - ix) * tT;
+            for (int iy = (int)yPos - 1; iy <= yEnd; ++iy) {
+                const float tmp = d_fa_b3(yPos - iy) * tX;
+                if (tmp > delta) {
+                    const int o = (it + 1) * lX * lY + (iy + 1) * lX + (ix + 1);
+                    sx += cX[o] * tmp; sy += cY[o] * tmp;
+                }
+            }
+        }
+    }
+    const int xc = (int)ceilf(-sx), yc = (int)ceilf(-sy);
+    const float xd = 2.f - (sx + xc), yd = 2.f - (sy + yc);
+    const int l1 = x + xc - 2, m1 = y + yc - 2;
+    float wx[4];
+    int lx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int l = l1 + i;
+        wx[i] = d_fa_b3(xd - i);
+        while (l < 0 || l >= X) l = l < 0 ? -l - 1 : 2 * X - l - 1;
+        lx[i] = l;
+    }
+    float columns = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m1 + i;
+        while (m < 0 || m >= Y) m = m < 0 ? -m - 1 : 2 * Y - m - 1;
+        const float *ref = coef + (size_t)m * X;
+        float rows = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rows += ref[lx[j]] * wx[j];
+        columns += rows * d_fa_b3(yd - i);
+    }
+    const size_t o = (size_t)y * X + x;
+    if (out) out[o] = columns;
+    if (sum) sum[o] += columns;
+}
+
 // ---- host: EquationSystemSolver::solve + computeAlignment ------------------------------------------------------------------
 void mean_stddev(const std::vector<double> &v, double &mean, double &sd)
 {
@@ -222,14 +511,11 @@ void weighted_least_squares(std::vector<double> &A, int rows, int cols, const st
     }
 }
 
-void fa_solve(const std::vector<double> &bx, const std::vector<double> &by, int N, int iterations, double *shiftX, double *shiftY, int *refFrame)
+// EquationSystemSolver::solve (eq_system_solver.cpp:35-106) for an observation matrix A0 [rows][cols]
+void fa_solve_system(const std::vector<double> &A0, int rows, int cols, const std::vector<double> &bx, const std::vector<double> &by, int iterations,
+                     std::vector<double> &sx, std::vector<double> &sy)
 {
-    const int rows = N * (N - 1) / 2, cols = N - 1;
-    std::vector<double> A0((size_t)rows * cols, 0.0), w(rows, 1.0), sx, sy;
-    int idx = 0;
-    for (int i = 0; i < N - 1; ++i)
-        for (int j = i + 1; j < N; ++j, ++idx)
-            for (int ij = i; ij < j; ++ij) A0[(size_t)idx * cols + ij] = 1;
+    std::vector<double> w(rows, 1.0);
     int it = 0;
     do {
         std::vector<double> A = A0;
@@ -247,24 +533,61 @@ void fa_solve(const std::vector<double> &bx, const std::vector<double> &by, int 
             if (std::fabs(ex[r]) > 3 * sdx || std::fabs(ey[r]) > 3 * sdy) w[r] = 0.0;
         ++it;
     } while (it < iterations);
+}
+
+// computeAlignment (movie_alignment_correlation_base.cpp:399-418): refIn < 0 looks for the reference frame (global alignment),
+// otherwise the shifts are taken from frame refIn (patches of the local alignment keep the global reference frame)
+void fa_solve(const std::vector<double> &bx, const std::vector<double> &by, int N, int iterations, int refIn, double *shiftX, double *shiftY, int *refFrame)
+{
+    const int rows = N * (N - 1) / 2, cols = N - 1;
+    std::vector<double> A0((size_t)rows * cols, 0.0), sx, sy;
+    int idx = 0;
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j, ++idx)
+            for (int ij = i; ij < j; ++ij) A0[(size_t)idx * cols + ij] = 1;
+    fa_solve_system(A0, rows, cols, bx, by, iterations, sx, sy);
     auto total = [&](int iref, int j, double &tx, double &ty) {
         tx = ty = 0;
         if (iref < j) for (int jj = j - 1; jj >= iref; --jj) { tx -= sx[jj]; ty -= sy[jj]; }
         else if (iref > j) for (int jj = j; jj <= iref - 1; ++jj) { tx += sx[jj]; ty += sy[jj]; }
     };
-    int best = -1;
-    double worstEver = std::numeric_limits<double>::max();
-    for (int iref = 0; iref < N; ++iref) {
-        double worst = -1;
-        for (int j = 0; j < N; ++j) {
-            double tx, ty;
-            total(iref, j, tx, ty);
-            if (std::fabs(tx) > worst) worst = std::fabs(tx);         // X only: movie_alignment_correlation_base.cpp:258-261
+    int best = refIn;
+    if (best < 0) {
+        double worstEver = std::numeric_limits<double>::max();
+        for (int iref = 0; iref < N; ++iref) {
+            double worst = -1;
+            for (int j = 0; j < N; ++j) {
+                double tx, ty;
+                total(iref, j, tx, ty);
+                if (std::fabs(tx) > worst) worst = std::fabs(tx);         // X only: movie_alignment_correlation_base.cpp:258-261
+            }
+            if (worst < worstEver) { worstEver = worst; best = iref; }
         }
-        if (worst < worstEver) { worstEver = worst; best = iref; }
     }
     *refFrame = best;
     for (int i = 0; i < N; ++i) total(best, i, shiftX[i], shiftY[i]);
+}
+
+// createLPF + scaleLPF (movie_alignment_correlation_base.cpp:184-227): a 1-D Gaussian profile of nX samples, looked up by
+// |w| nX with linear interpolation, for the half spectrum [nY][nX/2+1] of images sampled at Tsp A/px
+std::vector<float> fa_make_lpf(double Tsp, float maxRes, int nX, int nY, double scale)
+{
+    const float c = std::sqrt(-1.f / (2.f * std::log(0.5f)));
+    const int nxh = nX / 2 + 1;
+    std::vector<double> prof(nX);
+    const double iX = 1 / (double)nX, sigma = (Tsp * c) / maxRes;
+    for (int x = 0; x < nX; ++x) { const double w = x * iX; prof[x] = std::exp(-0.5 * (w * w) / (sigma * sigma)); }
+    std::vector<float> lpf((size_t)nY * nxh);
+    for (int i = 0; i < nY; ++i)
+        for (int j = 0; j < nxh; ++j) {
+            const double wy = nY <= 1 ? 0.0 : (double)(i <= nY / 2 ? i : i - nY) / nY, wx = (double)(j <= nX / 2 ? j : j - nX) / nX;
+            const double x = std::sqrt(wx * wx + wy * wy) * nX;
+            const int x0 = (int)std::floor(x), x1 = x0 + 1;
+            const double fx = x - x0;
+            const double d0 = (x0 < 0 || x0 >= nX) ? 0.0 : prof[x0], d1 = (x1 < 0 || x1 >= nX) ? 0.0 : prof[x1];
+            lpf[(size_t)i * nxh + j] = (float)(((1 - fx) * d0 + fx * d1) * scale);
+        }
+    return lpf;
 }
 }  // namespace
 
@@ -274,7 +597,7 @@ struct xh_fa {
     float Ts, maxRes;
     double sizeFactor;
     xh_fft2d *big, *small;
-    XhBuf work, spectra, lpf, pair, part, res;
+    XhBuf work, spectra, lpf, pair, part, res, warpC;
     int capFrames;
 };
 
@@ -287,7 +610,7 @@ int xh_fa_destroy(xh_fa *h)
     (void)hipStreamSynchronize(h->ctx->stream);
     if (h->big) xh_fft2d_destroy(h->big);
     if (h->small) xh_fft2d_destroy(h->small);
-    xh_buf_free(h->work); xh_buf_free(h->spectra); xh_buf_free(h->lpf); xh_buf_free(h->pair); xh_buf_free(h->part); xh_buf_free(h->res);
+    xh_buf_free(h->work); xh_buf_free(h->spectra); xh_buf_free(h->lpf); xh_buf_free(h->pair); xh_buf_free(h->part); xh_buf_free(h->res); xh_buf_free(h->warpC);
     delete h;
     return XH_OK;
 }
@@ -317,22 +640,8 @@ int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float m
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->part, sizeof(double) * 2 * 256);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->res, sizeof(double) * 4);
     if (rc == XH_OK) {
-        // createLPF + scaleLPF (:184-227): a 1-D Gaussian profile of nX samples, looked up by |w| nX with linear interpolation
-        const int nX = h->nX, nY = h->nY, nxh = nX / 2 + 1;
         const double Tsp = (double)(sampling_rate / (float)h->sizeFactor);       // getPixelResolution (float)
-        std::vector<double> prof(nX);
-        const double iX = 1 / (double)nX, sigma = (Tsp * c) / max_res_for_correlation;
-        for (int x = 0; x < nX; ++x) { const double w = x * iX; prof[x] = std::exp(-0.5 * (w * w) / (sigma * sigma)); }
-        std::vector<float> lpf((size_t)nY * nxh);
-        for (int i = 0; i < nY; ++i)
-            for (int j = 0; j < nxh; ++j) {
-                const double wy = nY <= 1 ? 0.0 : (double)(i <= nY / 2 ? i : i - nY) / nY, wx = (double)(j <= nX / 2 ? j : j - nX) / nX;
-                const double x = std::sqrt(wx * wx + wy * wy) * nX;
-                const int x0 = (int)std::floor(x), x1 = x0 + 1;
-                const double fx = x - x0;
-                const double d0 = (x0 < 0 || x0 >= nX) ? 0.0 : prof[x0], d1 = (x1 < 0 || x1 >= nX) ? 0.0 : prof[x1];
-                lpf[(size_t)i * nxh + j] = (float)((1 - fx) * d0 + fx * d1);
-            }
+        const std::vector<float> lpf = fa_make_lpf(Tsp, max_res_for_correlation, h->nX, h->nY, 1.0);
         rc = xh_buf_alloc(ctx, h->lpf, sizeof(float) * lpf.size());
         if (rc == XH_OK && hipMemcpy(h->lpf.p, lpf.data(), sizeof(float) * lpf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = XH_ERR_HIP;
     }
@@ -399,8 +708,234 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     if (h_bX) std::memcpy(h_bX, bx.data(), sizeof(double) * rows);
     if (h_bY) std::memcpy(h_bY, by.data(), sizeof(double) * rows);
     int ref = 0;
-    fa_solve(bx, by, N, 2, h_shiftX, h_shiftY, &ref);          // solverIterations = 2 (movie_alignment_correlation_base.h:332)
+    fa_solve(bx, by, N, 2, -1, h_shiftX, h_shiftY, &ref);          // solverIterations = 2 (movie_alignment_correlation_base.h:332)
     *h_ref = ref;
+    return XH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+double fa_b3(double x)
+{
+    x = std::fabs(x);
+    if (x < 1) return (x * x * (x - 2) * 3 + 4) * (1.0 / 6.0);
+    if (x < 2) { x -= 2; return x * x * x * (-1.0 / 6.0); }
+    return 0;
+}
+
+// getMovieBorders + getPatchesLocation (movie_alignment_correlation_gpu.cpp:204-222, 139-164): top-left corner [p][2] and centre
+// [p][2] of every patch, p = py patchesX + px
+void fa_patch_layout(int N, int Y, int X, const double *gx, const double *gy, int patchesX, int patchesY, int PX, int PY, std::vector<double> &tl,
+                     double *centers)
+{
+    double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
+    for (int i = 0; i < N; ++i) {
+        minX = std::min(std::floor(gx[i]), minX); maxX = std::max(std::ceil(gx[i]), maxX);
+        minY = std::min(std::floor(gy[i]), minY); maxY = std::max(std::ceil(gy[i]), maxY);
+    }
+    const double bordX = std::fabs(maxX - minX), bordY = std::fabs(maxY - minY);
+    const double windowX = X - 2 * bordX, windowY = Y - 2 * bordY;
+    const double corrX = std::ceil(((patchesX * PX) - windowX) / (double)(patchesX - 1)), corrY = std::ceil(((patchesY * PY) - windowY) / (double)(patchesY - 1));
+    const double stepX = PX - corrX, stepY = PY - corrY;
+    tl.resize((size_t)patchesX * patchesY * 2);
+    for (int py = 0; py < patchesY; ++py)
+        for (int px = 0; px < patchesX; ++px) {
+            const size_t p = (size_t)py * patchesX + px;
+            const double tlx = bordX + px * stepX, tly = bordY + py * stepY;
+            tl[2 * p] = tlx; tl[2 * p + 1] = tly;
+            centers[2 * p] = (tlx + (tlx + PX - 1)) / 2; centers[2 * p + 1] = (tly + (tly + PY - 1)) / 2;        // Rectangle::getCenter
+        }
+}
+
+// BSplineHelper::computeBSplineCoeffs (bspline_helper.cpp:34-87): the spline of lX x lY x lT control points whose value at
+// (patch centre, frame) is minus the patch's shift, least squares with one round of outlier rejection
+void fa_fit_bspline(int N, int Y, int X, int nP, const double *centers, const double *patchShifts, int lX, int lY, int lT, double *coeffsX, double *coeffsY)
+{
+    const int R = nP * N, Cc = lX * lY * lT;
+    std::vector<double> A((size_t)R * Cc, 0.0), bX(R), bY(R), cX, cY;
+    const double hX = (lX == 3) ? X : (X / (double)(lX - 3)), hY = (lY == 3) ? Y : (Y / (double)(lY - 3)), hT = (lT == 3) ? N : (N / (double)(lT - 3));
+    for (int i = 0; i < nP; ++i)
+        for (int t = 0; t < N; ++t) {
+            const int row = t * nP + i;
+            const int tcx = (int)centers[(size_t)i * 2], tcy = (int)centers[(size_t)i * 2 + 1];
+            for (int ct = -1; ct < lT - 1; ++ct) {
+                const double tT = fa_b3((t / hT) - ct);
+                if (tT == 0) continue;
+                for (int cy = -1; cy < lY - 1; ++cy) {
+                    const double tY = fa_b3((tcy / hY) - cy);
+                    if (tY == 0) continue;
+                    for (int cx = -1; cx < lX - 1; ++cx)
+                        A[(size_t)row * Cc + ((ct + 1) * lX * lY) + ((cy + 1) * lX) + (cx + 1)] = tT * tY * fa_b3((tcx / hX) - cx);
+                }
+            }
+            bX[row] = -patchShifts[((size_t)i * N + t) * 2];
+            bY[row] = -patchShifts[((size_t)i * N + t) * 2 + 1];
+        }
+    fa_solve_system(A, R, Cc, bX, bY, 2, cX, cY);
+    for (int k = 0; k < Cc; ++k) { coeffsX[k] = cX[k]; coeffsY[k] = cY[k]; }
+}
+
+int fa_upload(const void *src, XhBuf &b, size_t bytes, xh_ctx *ctx)
+{
+    XH_TRY(xh_buf_alloc(ctx, b, bytes));
+    XH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));          // the source is a host temporary
+    return XH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, const double *h_gShiftX,
+                          const double *h_gShiftY, int32_t ref_frame, float max_shift_px, int32_t patchesX, int32_t patchesY, int32_t patchSizeX,
+                          int32_t patchSizeY, int32_t patchesAvg, int32_t lX, int32_t lY, int32_t lT, double *h_patchShifts, double *h_centers,
+                          double *h_coeffsX, double *h_coeffsY, int32_t *h_dims)
+{
+    XH_CHECK(h && d_frames && N >= 2 && h_gShiftX && h_gShiftY && ref_frame >= 0 && ref_frame < N && h_patchShifts && h_centers, XH_ERR_ARG,
+             "xh_fa_local_alignment: bad argument");
+    XH_CHECK(patchesX >= 2 && patchesY >= 2 && patchesAvg >= 1 && lX >= 3 && lY >= 3 && lT >= 3, XH_ERR_ARG,
+             "xh_fa_local_alignment: at least 2 x 2 patches, 1 frame per patch and 3 control points per axis");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const int Y = h->Y, X = h->X;
+    const int PX = patchSizeX & ~1, PY = patchSizeY & ~1;
+    XH_CHECK(PX >= 8 && PY >= 8 && PX <= X && PY <= Y, XH_ERR_ARG, "xh_fa_local_alignment: patches of %d x %d pixels in frames of %d x %d (Movie is too small for local alignment.)",
+             PX, PY, X, Y);
+    // getCorrelationHint (movie_alignment_correlation_gpu.cpp:124-137): the smallest even size that keeps the requested scale
+    const float reqScale = (float)h->sizeFactor;
+    auto nearestEven = [](int v, float minScale) { int size = 2; while ((size / (float)v) < minScale) size += 2; return size; };
+    const int CX = nearestEven(PX, reqScale), CY = nearestEven(PY, reqScale), cxh = CX / 2 + 1;
+    if (h_dims) { h_dims[0] = PX; h_dims[1] = PY; h_dims[2] = CX; h_dims[3] = CY; }
+    const float actualScale = (float)CX / (float)PX;
+    const int maxDist = (int)(max_shift_px * actualScale);
+    XH_CHECK(maxDist >= 0, XH_ERR_ARG, "xh_fa_local_alignment: negative --maxShift");
+    const int nP = patchesX * patchesY, rows = N * (N - 1) / 2;
+    std::vector<double> tl;
+    fa_patch_layout(N, Y, X, h_gShiftX, h_gShiftY, patchesX, patchesY, PX, PY, tl, h_centers);
+    // the window of every frame of every patch lies inside the frame (getPatchData reads without a check)
+    std::vector<int> offs((size_t)nP * N * 2);
+    for (int p = 0; p < nP; ++p)
+        for (int f = 0; f < N; ++f) {
+            const int sx = (int)tl[2 * p] + (int)std::round(h_gShiftX[f]), sy = (int)tl[2 * p + 1] + (int)std::round(h_gShiftY[f]);
+            XH_CHECK(sx >= 0 && sy >= 0 && sx + PX <= X && sy + PY <= Y, XH_ERR_ARG,
+                     "xh_fa_local_alignment: patch %d of frame %d reaches outside the frame (x %d..%d, y %d..%d): fewer or smaller patches", p, f, sx, sx + PX - 1, sy,
+                     sy + PY - 1);
+            offs[((size_t)p * N + f) * 2] = sx; offs[((size_t)p * N + f) * 2 + 1] = sy;
+        }
+    // tables: pruned forward transforms, low-pass of the correlation size with the 1 / (PX PY) of the transform, inverse twiddles
+    std::vector<fa_cf> Wx((size_t)PX * cxh), Wy((size_t)CY * PY), tabY(CY), tabX(CX);
+    const double twoPi = 6.283185307179586476925286766559;
+    for (int x = 0; x < PX; ++x)
+        for (int k = 0; k < cxh; ++k) { const double a = -twoPi * (double)(((long long)x * k) % PX) / PX; Wx[(size_t)x * cxh + k] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    for (int iy = 0; iy < CY; ++iy) {
+        const int origY = (iy <= CY / 2) ? iy : (PY - (CY - iy));          // rows 0 .. C/2 from the top, the others from the bottom (scaleFFT2DKernel)
+        for (int y = 0; y < PY; ++y) { const double a = -twoPi * (double)(((long long)origY * y) % PY) / PY; Wy[(size_t)iy * PY + y] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    }
+    for (int k = 0; k < CY; ++k) tabY[k] = fa_cf{(float)std::cos(twoPi * k / CY), (float)std::sin(twoPi * k / CY)};
+    for (int k = 0; k < CX; ++k) tabX[k] = fa_cf{(float)std::cos(twoPi * k / CX), (float)std::sin(twoPi * k / CX)};
+    const std::vector<float> filter = fa_make_lpf((double)(h->Ts / actualScale), h->maxRes, CX, CY, 1.0 / ((double)PX * PY));
+    const int yHalf = CY / 2, xHalf = CX / 2;
+    const int y0 = std::max(0, yHalf - maxDist - 1), y1 = std::min(CY - 1, yHalf + maxDist + 1), wy = y1 - y0 + 1;
+    const int x0 = std::max(0, xHalf - maxDist - 1), x1 = std::min(CX - 1, xHalf + maxDist + 1), wx = x1 - x0 + 1;
+
+    XhBuf bOffs, bWx, bWy, bTabY, bTabX, bFilter, bPatch, bT, bSingle, bS, bU, bW, bRes;
+    auto freeAll = [&]() { XhBuf *all[] = {&bOffs, &bWx, &bWy, &bTabY, &bTabX, &bFilter, &bPatch, &bT, &bSingle, &bS, &bU, &bW, &bRes}; for (XhBuf *q : all) xh_buf_free(*q); };
+    const size_t E = (size_t)CY * cxh;
+    int rc = fa_upload(offs.data(), bOffs, sizeof(int) * offs.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(Wx.data(), bWx, sizeof(fa_cf) * Wx.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(Wy.data(), bWy, sizeof(fa_cf) * Wy.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(tabY.data(), bTabY, sizeof(fa_cf) * tabY.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(tabX.data(), bTabX, sizeof(fa_cf) * tabX.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(filter.data(), bFilter, sizeof(float) * filter.size(), ctx);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPatch, sizeof(float) * (size_t)N * PY * PX);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bT, sizeof(fa_cf) * (size_t)N * PY * cxh);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bSingle, sizeof(fa_cf) * (size_t)N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bS, sizeof(fa_cf) * (size_t)N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * cxh);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRes, sizeof(double) * 2 * (size_t)rows * nP);
+    for (int p = 0; p < nP && rc == XH_OK; ++p) {
+        const size_t tot = (size_t)N * PY * PX;
+        hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p * N * 2,
+                           (float *)bPatch.p, N, Y, X, PY, PX);
+        // along x, all frames at once: [N PY][PX] x [PX][cxh]
+        hipLaunchKernelGGL((k_fa_gemm<false>), dim3((cxh + 31) / 32, (unsigned)(((size_t)N * PY + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p, (size_t)PX,
+                           (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, N * PY, cxh, PX);
+        // along y, frame by frame: [CY][PY] x [PY][cxh]
+        hipLaunchKernelGGL((k_fa_gemm<true>), dim3((cxh + 31) / 32, (CY + 63) / 64, N), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
+                           (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
+        hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)N * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
+                           (const float *)bFilter.p, N, E, patchesAvg);
+        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows), dim3(256), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p, (const fa_cf *)bTabX.p, y0, wy,
+                           x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p + 2 * (size_t)rows * p);
+        if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_local_alignment: kernel launch failed"); rc = XH_ERR_HIP; }
+    }
+    std::vector<double> res(2 * (size_t)rows * nP);
+    if (rc == XH_OK && hipMemcpyAsync(res.data(), bRes.p, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    freeAll();
+    if (rc != XH_OK) { if (rc == XH_ERR_HIP) xh_set_error("xh_fa_local_alignment: device error"); return rc; }
+    // computeAlignment (:776-797) per patch: deduct the centre, scale to the movie's pixels, solve, add the rounded global shift
+    std::vector<double> bx(rows), by(rows), lsx(N), lsy(N);
+    for (int p = 0; p < nP; ++p) {
+        for (int r = 0; r < rows; ++r) {
+            bx[r] = (res[2 * ((size_t)rows * p + r)] - CX / 2.0) * ((double)PX / CX);
+            by[r] = (res[2 * ((size_t)rows * p + r) + 1] - CY / 2.0) * ((double)PY / CY);
+        }
+        int ref = ref_frame;
+        fa_solve(bx, by, N, 2, ref_frame, lsx.data(), lsy.data(), &ref);
+        for (int t = 0; t < N; ++t) {
+            h_patchShifts[((size_t)p * N + t) * 2] = std::round(h_gShiftX[t]) + lsx[t];
+            h_patchShifts[((size_t)p * N + t) * 2 + 1] = std::round(h_gShiftY[t]) + lsy[t];
+        }
+    }
+    if (h_coeffsX && h_coeffsY) fa_fit_bspline(N, Y, X, nP, h_centers, h_patchShifts, lX, lY, lT, h_coeffsX, h_coeffsY);
+    return XH_OK;
+}
+
+// localFromGlobal (movie_alignment_correlation_gpu.cpp:432-456): the B-spline of a movie aligned globally only -- every patch
+// carries the global shift of its frame
+int xh_fa_local_from_global(xh_fa *h, int32_t N, const double *h_gShiftX, const double *h_gShiftY, int32_t patchesX, int32_t patchesY, int32_t patchSizeX,
+                            int32_t patchSizeY, int32_t lX, int32_t lY, int32_t lT, double *h_centers, double *h_coeffsX, double *h_coeffsY)
+{
+    XH_CHECK(h && N >= 1 && h_gShiftX && h_gShiftY && h_centers && h_coeffsX && h_coeffsY && patchesX >= 2 && patchesY >= 2 && lX >= 3 && lY >= 3 && lT >= 3, XH_ERR_ARG,
+             "xh_fa_local_from_global: bad argument");
+    const int PX = patchSizeX & ~1, PY = patchSizeY & ~1, nP = patchesX * patchesY;
+    std::vector<double> tl, shifts((size_t)nP * N * 2);
+    fa_patch_layout(N, h->Y, h->X, h_gShiftX, h_gShiftY, patchesX, patchesY, PX, PY, tl, h_centers);
+    for (int p = 0; p < nP; ++p)
+        for (int t = 0; t < N; ++t) { shifts[((size_t)p * N + t) * 2] = h_gShiftX[t]; shifts[((size_t)p * N + t) * 2 + 1] = h_gShiftY[t]; }
+    fa_fit_bspline(N, h->Y, h->X, nP, h_centers, shifts.data(), lX, lY, lT, h_coeffsX, h_coeffsY);
+    return XH_OK;
+}
+
+int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, const float *d_gain, const double *h_coeffsX, const double *h_coeffsY, int32_t lX,
+                        int32_t lY, int32_t lT, int32_t N, int32_t n, float *d_out, float *d_sum, float *d_initial_sum)
+{
+    XH_CHECK(h && d_frame && h_coeffsX && h_coeffsY && lX >= 3 && lY >= 3 && lT >= 3 && N >= 1 && n >= 0 && n < N, XH_ERR_ARG, "xh_fa_apply_bspline: bad argument");
+    xh_ctx *ctx = h->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const int Y = h->Y, X = h->X, Cc = lX * lY * lT;
+    std::vector<float> c(2 * (size_t)Cc);                                   // the reference's coefficients are Matrix1D<float>
+    for (int k = 0; k < Cc; ++k) { c[k] = (float)h_coeffsX[k]; c[Cc + k] = (float)h_coeffsY[k]; }
+    XH_TRY(xh_buf_reserve(ctx, h->warpC, sizeof(float) * c.size()));
+    XH_HIP(hipMemcpyAsync(h->warpC.p, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    float *coef = (float *)h->work.p, *tmp = coef + (size_t)Y * X;          // the two planes of the transform buffer
+    const XhFir F = xh_fir_taps();
+    const size_t nc = (size_t)X * ((Y + XH_FIR_V - 1) / XH_FIR_V), nr = (size_t)Y * ((X + XH_FIR_V - 1) / XH_FIR_V);
+    hipLaunchKernelGGL((k_fa_fir<true>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, tmp, d_initial_sum, Y, X, F);
+    hipLaunchKernelGGL((k_fa_fir<false>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)tmp, (const float *)nullptr, (const float *)nullptr, coef,
+                       (float *)nullptr, Y, X, F);
+    if (d_out || d_sum) {
+        // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
+        const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
+        const float tPos = n / hT;
+        hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), 0, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
+                           (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
+    }
+    XH_LAUNCH_CHECK();
     return XH_OK;
 }
 

@@ -1798,7 +1798,6 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     XH_HIP(hipSetDevice(rf->ctx->device));
     if (n == 0) return XH_OK;
     XH_TRY(ensure_temp(rf));
-    xh_ctx *ctx = rf->ctx;
     std::vector<XhSpace> spaces;
     build_spaces(rf, h_ainv, h_weights, n, h_sym, nsym, spaces);
     const int ns = (int)spaces.size();
