@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: the reconstruction half (shift, CTF, FFT, gridding) of batch k runs on a second "
+                    "stream beside the matching of batch k+1")
     ap.add_argument("--stream-test", type=int, default=0, help="diagnosis of the host-traffic cost: 1 no result copies, 2 batches copied device to device, 3 host copies in 16 chunks")
     ap.add_argument("--sdma", type=int, default=-1, help="1 / 0: HSA_ENABLE_SDMA for this process (copy engines or shader copies for the host traffic); -1: leave the environment alone")
     ap.add_argument("--unique-batches", type=int, default=0, help="distinct particle batches cycled from host memory (0: 4 = 16384 particles at --batch 4096)")
@@ -272,14 +274,26 @@ def main():
         pm.set_option("tau_rel", args.tau_rel)
     rows_seen = [0, 0]      # correlation rows searched / skipped by the S3 branch and bound, timed steps only
     s6_rep = [0]            # particles whose translational alignment was repeated in double precision, timed steps only
-    rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
+    # --pipeline: the reconstructor lives on a second stream (its own library context), so that the gridding of batch k
+    # (LDS / VALU bound) runs beside the matching of batch k+1 (mostly HBM bound)
+    import contextlib
+    pipelined = bool(args.pipeline) and args.mode == "full"
+    side = torch.cuda.Stream(device=dev) if pipelined else None
+    ctx_rf = ctx
+    if pipelined:
+        with torch.cuda.stream(side):
+            ctx_rf = xa.Context(local)
+
+    def on_rf_stream():
+        return torch.cuda.stream(side) if pipelined else contextlib.nullcontext()
+    rf = xa.RecFourier(ctx_rf, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
     # HIP-event pairs on the library's stream around the stages xh_pm_stage_ms does not cover; read after the timed region
     timers = {"translate_s6": [], "shift_images": [], "gridding_insert_images": []}
 
-    def timed(name, record, fn):
+    def timed(name, record, fn, c=None):
         if not record:
             return fn()
-        t = ctx.timer()
+        t = (c or ctx).timer()
         t.start()
         r = fn()
         t.stop()
@@ -294,7 +308,7 @@ def main():
                   "sy": torch.empty(B, dtype=torch.float64, pin_memory=True), "cc": torch.empty(B, dtype=torch.float64, pin_memory=True)}
                  for _ in range(2)]
 
-    def step(record, parts=None, u=0, slot=None):
+    def step(record, parts=None, u=0, slot=None, pipe=True):
         ang = flips = None
         if parts is None:
             parts = particles
@@ -319,7 +333,24 @@ def main():
         else:
             ang = synth.random_angles(B, rng)
             shifts = rng.uniform(-3, 3, (B, 2))
-        if rf is not None:
+        if rf is not None and pipelined:
+            matched = torch.cuda.Event()
+            matched.record()
+            shifted = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                side.wait_event(matched)
+                for t_ in (parts, sx, sy, flip, ang):
+                    t_.record_stream(side)
+                imgs = timed("shift_images", record, lambda: rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B)), ctx_rf)
+                shifted.record(side)
+                timed("gridding_insert_images", record, lambda: rf.insert_images(imgs, ang, ctf_array=ctf_arr), ctx_rf)
+            # the next match overwrites the coefficients (and the copy stream the batch) the shift has just read
+            torch.cuda.current_stream().wait_event(shifted)
+            if not pipe:                                    # one-stream leg: the matching waits for the gridding too
+                gridded = torch.cuda.Event()
+                gridded.record(side)
+                torch.cuda.current_stream().wait_event(gridded)
+        elif rf is not None:
             # the matcher has just computed the particles' B-spline coefficients: the shift reuses them
             imgs = timed("shift_images", record, lambda: rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B) if pm is not None else None))
             timed("gridding_insert_images", record, lambda: rf.insert_images(imgs, ang, ctf_array=ctf_arr))      # CTF planes + FFT + records + gridding
@@ -327,10 +358,11 @@ def main():
     def finish():
         if rf is None:
             return
-        rf.mirror_and_crop()
-        xa.allreduce_reconstruction(rf)
-        rf.finish()
-        rf.reset()
+        with on_rf_stream():
+            rf.mirror_and_crop()
+            xa.allreduce_reconstruction(rf)
+            rf.finish()
+            rf.reset()
 
     for _ in range(args.warmup):
         step(False)
@@ -410,6 +442,25 @@ def main():
             el = t.item()
         extra["value_resident"] = nres * B * world / el
         extra["resident_leg"] = {"steps": nres, "what": "same steps + finish on a batch resident in HBM, no host traffic"}
+        if pipelined:
+            # (1b) the same without the second stream: every stage of a step behind the one before it
+            if rf is not None:
+                rf.kernel_ms(reset=True)
+            barrier()
+            ts0 = time.perf_counter()
+            for _ in range(nres):
+                step(False, pipe=False)
+            finish()
+            barrier()
+            el = time.perf_counter() - ts0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            k1, n1 = rf.kernel_ms(reset=False)
+            extra["one_stream_leg"] = {"value": nres * B * world / el, "steps": nres, "k_rf_grid_avg_launch_ms": k1 / max(1, n1),
+                                       "what": "resident batch, reconstruction half behind the matching on the same timeline: what the second stream buys, "
+                                               "and the gridding kernel's duration without the other stream's kernels beside it"}
         # (2) the matcher without its data-dependent shortcuts: every correlation row contracted over all frequencies and
         # transformed (S3 branch and bound off, two-level cut off)
         if pm is not None and not args.no_prune:
@@ -503,6 +554,7 @@ def main():
                    "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
                    "host_traffic": "every batch H2D from page-locked memory (double-buffered, second stream), results D2H, inside the timed region",
+                   "pipeline": ("reconstruction half of batch k on a second stream beside the matching of batch k+1" if pipelined else "one stream"),
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
         "stage_ms": stage, "finish_and_allreduce_s": finish_s,
@@ -578,17 +630,20 @@ def main():
                 c, m = chk.ctf_arrays(cpar)
                 chk.insert(chk.prepare_image(img), synth.euler_matrix(*oang[i]).T, ctf=c, modulator=m)
             ev, ew = chk.temp()
-            rf.reset()
-            simg = rf.shift_images(particles[:nv].contiguous(), np.stack([ex[:nv], ey[:nv]], 1))
-            c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs[:nv]))
-            rf.insert(rf.prepare_images(simg), oang[:nv], ctf=c, modulator=m)
-            gv, gw = rf.temp_spaces()
-            gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+            torch.cuda.synchronize()
+            with on_rf_stream():
+                rf.reset()
+                simg = rf.shift_images(particles[:nv].contiguous(), np.stack([ex[:nv], ey[:nv]], 1))
+                c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs[:nv]))
+                rf.insert(rf.prepare_images(simg), oang[:nv], ctf=c, modulator=m)
+                gv, gw = rf.temp_spaces()
+                gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
             out["parity_volume_rel_err"] = float(np.abs(gv - ev).max() / np.abs(ev).max())
             out["parity_weights_rel_err"] = float(np.abs(gw - ew).max() / np.abs(ew).max())
             out["parity_volume_voxel_sets_equal"] = bool(((gw != 0) == (ew != 0)).all())
             out["parity_volume_particles"] = nv
-            rf.reset()
+            with on_rf_stream():
+                rf.reset()
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -566,8 +566,64 @@ def test_cli_movie_global_alignment(bins, tmp_path, oracle):
     assert int(float(ref_rows[0][0])) == 1 + exp["ref"]
     ini = xmipp_io.read_volume(str(tmp_path / "initial.spi"))[0]
     assert np.abs(ini - ((frames[1:6] - dark) * gain).mean(0)).max() < 1e-4
-    # the local alignment and the aligned outputs are refused loudly, as is a scale factor >= 1
-    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.xmd")])
-    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "--skipLocalAlignment" in r.stderr
+    # a movie too small for the default patches (500 A) and a scale factor >= 1 are refused loudly
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.xmd"), "--sampling", "1.25", "--maxResForCorrelation", "10"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "control points" in r.stderr
     r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.xmd"), "--skipLocalAlignment", "--sampling", "5", "--maxResForCorrelation", "10"])
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "scale factor" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_movie_local_alignment(bins, tmp_path, oracle):
+    """xmipp_movie_alignment_correlation with the local alignment (run(), movie_alignment_correlation_base.cpp:531-586, steps of the
+    CUDA program): localAlignment@out.xmd carries patches, control points and the spline coefficients; the aligned frames
+    (--oaligned) and their average (--oavg) are the oracle's warp of the corrected frames by the oracle's spline; with
+    --skipLocalAlignment the spline of localFromGlobal moves every frame by its global shift."""
+    from tests import synth
+    N, Y, X = 8, 384, 384
+    frames, drift, field = synth.movie(N, Y, X, seed=3, local=4.0)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    common = ["-i", str(tmp_path / "movie.stk"), "--maxShift", "30", "--maxResForCorrelation", "8", "--patches", "5", "5", "--minLocalRes", "128",
+              "--controlPoints", "3", "3", "3"]
+    r = _run([prog] + common + ["-o", str(tmp_path / "out.xmd"), "--oavg", str(tmp_path / "avg.spi"), "--oaligned", str(tmp_path / "aligned.stk"),
+                                "--oavgInitial", str(tmp_path / "initial.spi")])
+    assert r.returncode == 0, r.stderr
+    g = oracle.fa_global_alignment(frames, max_shift_px=30.0, max_res=8.0)
+    cp = (3, 3, 3)
+    loc = oracle.fa_local_alignment(frames, g["shiftX"], g["shiftY"], g["ref"], max_shift_px=30.0, max_res=8.0, patches=(5, 5), patch_size=(128, 128), control_points=cp)
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"), block="localAlignment")
+    c = {l: i for i, l in enumerate(labels)}
+    vec = lambda t: np.array([float(v) for v in t.strip("'[] ").split()])
+    assert list(vec(rows[0][c["localAlignmentPatches"]])) == [5, 5] and list(vec(rows[0][c["localAlignmentControlPoints"]])) == [3, 3, 3]
+    cx, cy = vec(rows[0][c["localAlignmentCoeffsX"]]), vec(rows[0][c["localAlignmentCoeffsY"]])
+    assert cx.size == 27 and cy.size == 27
+    # the spline of the written coefficients against the oracle's over the field (the coefficients themselves are ill-conditioned)
+    worst = 0.0
+    for n in range(N):
+        for y in range(0, Y, 48):
+            for x in range(0, X, 48):
+                a, b = oracle.fa_bspline_shift(cx, cy, cp, X, Y, N, x, y, n), oracle.fa_bspline_shift(loc["coeffsX"], loc["coeffsY"], cp, X, Y, N, x, y, n)
+                worst = max(worst, abs(a[0] - b[0]), abs(a[1] - b[1]))
+    assert worst < 0.02, worst
+    assert 0 <= float(rows[0][c["localAlignmentConf2_5Perc"]]) <= float(rows[0][c["localAlignmentConf97_5Perc"]]) < 10
+    aligned = xmipp_io.read_stack(str(tmp_path / "aligned.stk"))
+    assert aligned.shape == (N, Y, X)
+    exp = np.stack([oracle.fa_apply_bspline(frames[n], loc["coeffsX"].astype(np.float32), loc["coeffsY"].astype(np.float32), cp, N, n) for n in range(N)])
+    scale = np.abs(exp).max()
+    assert np.abs(aligned - exp).max() < 2e-3 * scale
+    avg = xmipp_io.read_volume(str(tmp_path / "avg.spi"))[0]
+    assert np.abs(avg - exp.mean(0)).max() < 2e-3 * scale
+    ini = xmipp_io.read_volume(str(tmp_path / "initial.spi"))[0]
+    assert np.abs(ini - frames.mean(0)).max() < 1e-4
+    # global only: every frame moved by its global shift (order-3 interpolation of the prefiltered frame), sums of frames 2..6 only
+    r = _run([prog] + common + ["-o", str(tmp_path / "out2.xmd"), "--skipLocalAlignment", "--oavg", str(tmp_path / "avg2.spi"), "--frameRangeSum", "2", "6"])
+    assert r.returncode == 0, r.stderr
+    avg2 = xmipp_io.read_volume(str(tmp_path / "avg2.spi"))[0]
+    clean = synth.movie(N, Y, X, seed=3, local=4.0, noise=0.0)[0]
+    inner = (slice(40, -40), slice(40, -40))
+    cc = lambda a: np.corrcoef(a[inner].ravel(), clean[g["ref"]][inner].ravel())[0, 1]
+    print("correlation with the clean reference frame: aligned", cc(avg2), "unaligned", cc(frames[2:7].mean(0)), "locally aligned", cc(avg))
+    assert cc(avg2) > cc(frames[2:7].mean(0)) + 0.01 and cc(avg) > cc(avg2) - 0.01
+    labels2, _ = xmipp_io.read_xmd(str(tmp_path / "out2.xmd"), block="frameShifts")
+    assert "shiftX" in labels2

@@ -31,7 +31,7 @@ namespace mc {
 // ------------------------------------------------------------------ errors
 enum ErrorType { ERR_ARG_INCORRECT = 2, ERR_ARG_MISSING = 3, ERR_IO_NOTEXIST = 20, ERR_IO_NOREAD = 21,
                  ERR_MD_NOOBJ = 30, ERR_MD_BADLABEL = 31, ERR_MULTIDIM_SIZE = 40, ERR_VALUE_INCORRECT = 50,
-                 ERR_GPU = 60, ERR_NOT_IMPLEMENTED = 61 };
+                 ERR_GPU = 60, ERR_NOT_IMPLEMENTED = 61, ERR_LOGIC_ERROR = 62 };
 struct XmippError : public std::runtime_error {
     int code;
     XmippError(int c, const std::string &m) : std::runtime_error(m), code(c) {}

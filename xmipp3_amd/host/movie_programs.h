@@ -1,6 +1,9 @@
-// movie_programs.h -- host side of FlexAlign's global alignment: ProgMovieAlignmentCorrelation's command
-// line (reconstruction/movie_alignment_correlation_base.cpp:36-150,560-620) over xh_fa_*. The local (patch) alignment and the
-// aligned outputs (--oavg, --oaligned: translate(BSPLINE3, DONT_WRAP) per frame) are not on the device path yet and fail loudly.
+// movie_programs.h -- host side of FlexAlign: the command line and the run() of AProgMovieAlignmentCorrelation
+// (reconstruction/movie_alignment_correlation_base.cpp:36-150,519-586) over xh_fa_*, with the steps of the CUDA program
+// (reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp): global alignment, local (patch) alignment unless
+// --skipLocalAlignment, the B-spline warp of every summed frame (localFromGlobal when only the global alignment ran), the sums
+// and the metadata blocks referenceFrame / localAlignment / frameShifts. Not here: --bin other than 1 and the reference's search
+// for FFT-friendly patch and correlation sizes (it benchmarks cuFFT on the installed GPU; the requested sizes are used).
 #ifndef XMIPP3_AMD_MOVIE_PROGRAMS_H
 #define XMIPP3_AMD_MOVIE_PROGRAMS_H
 #include "ctf_programs.h"
@@ -12,7 +15,26 @@ public:
     std::string fnMovie, fnOut, fnInitialAvg, fnDark, fnGain, fnAligned, fnAvg;
     float binning = 1, Ts = 1, maxShift = 50, maxResForCorrelation = 30;
     int nfirst = -1, nlast = -1, nfirstSum = -1, nlastSum = -1, device = 0;
+    int cpX = 6, cpY = 6, cpT = 5, patchesX = 0, patchesY = 0, patchesAvg = 3, minLocalRes = 500;
     bool skipLocalAlignment = false;
+
+    // BSplineHelper::getShift (bspline_helper.cpp:104-148)
+    void splineShift(const std::vector<double> &cX, const std::vector<double> &cY, int X, int Y, int N, int x, int y, int n, double &sx, double &sy) const
+    {
+        auto b3 = [](double v) { v = std::fabs(v); if (v < 1) return (v * v * (v - 2) * 3 + 4) / 6; if (v < 2) { v -= 2; return v * v * v / -6; } return 0.0; };
+        const double hX = cpX == 3 ? X : X / (double)(cpX - 3), hY = cpY == 3 ? Y : Y / (double)(cpY - 3), hT = cpT == 3 ? N : N / (double)(cpT - 3);
+        const double xPos = x / hX, yPos = y / hY, tPos = n / hT;
+        sx = sy = 0;
+        for (int it = std::max(-1, (int)tPos - 1); it <= std::min((int)tPos + 2, cpT - 2); ++it)
+            for (int iy = std::max(-1, (int)yPos - 1); iy <= std::min((int)yPos + 2, cpY - 2); ++iy)
+                for (int ix = std::max(-1, (int)xPos - 1); ix <= std::min((int)xPos + 2, cpX - 2); ++ix) {
+                    const double tmp = b3(xPos - ix) * b3(yPos - iy) * b3(tPos - it);
+                    if (std::fabs((float)tmp) > 0.0001) {
+                        const size_t o = (size_t)(it + 1) * (cpX * cpY) + (size_t)(iy + 1) * cpX + (ix + 1);
+                        sx += cX[o] * tmp; sy += cY[o] * tmp;
+                    }
+                }
+    }
 
     void defineParams() override
     {
@@ -37,6 +59,7 @@ public:
         addParamsLine("  [--controlPoints <x=6> <y=6> <t=5>]: Number of control points (including end points) used for defining the BSpline");
         addParamsLine("  [--patches <x=7> <y=7>]: Number of patches used for local alignment");
         addParamsLine("  [--minLocalRes <R=500>]      : Minimal resolution (in A) of patches during local alignment");
+        addParamsLine("  [--patchesAvg <avg=3>]       : Number of near frames used for averaging a single patch");
         addParamsLine("  [--device <id=0>]            : HIP device");
         addExampleLine("xmipp_movie_alignment_correlation -i movie.xmd --oaligned alignedMovie.stk --oavg alignedMicrograph.mrc");
     }
@@ -64,12 +87,14 @@ public:
         nlastSum = (int)getIntParam("--frameRangeSum", 1);
         skipLocalAlignment = checkParam("--skipLocalAlignment");
         device = (int)getIntParam("--device");
-        if (!skipLocalAlignment)
-            REPORT_ERROR(ERR_NOT_IMPLEMENTED, "the local (patch) alignment is not available on the device path: give --skipLocalAlignment "
-                         "(the reference's CPU program has none either, movie_alignment_correlation.cpp:63-76)");
-        if (!fnAligned.empty() || !fnAvg.empty())
-            REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--oaligned / --oavg (translate with BSPLINE3 and DONT_WRAP per frame) are not available on the device path yet; "
-                         "the shifts are written to -o");
+        minLocalRes = (int)getIntParam("--minLocalRes");
+        cpX = (int)getIntParam("--controlPoints", 0);
+        cpY = (int)getIntParam("--controlPoints", 1);
+        cpT = (int)getIntParam("--controlPoints", 2);
+        if (cpX < 3 || cpY < 3 || cpT < 3) REPORT_ERROR(ERR_ARG_INCORRECT, "All control points has to be bigger than 2");
+        if (checkParam("--patches")) { patchesX = (int)getIntParam("--patches", 0); patchesY = (int)getIntParam("--patches", 1); }
+        patchesAvg = (int)getIntParam("--patchesAvg");
+        if (patchesAvg < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "Patch averaging has to be at least 1 (one).");
     }
 
     void run() override
@@ -110,18 +135,28 @@ public:
         const size_t per = I.x * I.y;
         if (!dark.empty() && (Id.x != I.x || Id.y != I.y)) REPORT_ERROR(ERR_ARG_INCORRECT, "The dark image size does not match the movie frame size.");
         if (!gain.empty() && (Ig.x != I.x || Ig.y != I.y)) REPORT_ERROR(ERR_ARG_INCORRECT, "The gain image size does not match the movie frame size.");
+        // setNoOfPatches (:516-528), getRequestedPatchSize (base.h:217-219), checkSettings (:80-86)
+        const size_t reqPatch = (size_t)(minLocalRes / Ts);
+        if (patchesX <= 0 || patchesY <= 0) {
+            patchesX = (int)std::ceil((float)I.x / (float)reqPatch);
+            patchesY = (int)std::ceil((float)I.y / (float)reqPatch);
+        }
+        if (!skipLocalAlignment && (patchesX <= cpX || patchesY <= cpY))
+            REPORT_ERROR(ERR_LOGIC_ERROR, "More control points than patches. Decrease the number of control points.");
         if (verbose) std::cout << "Computing global alignment ...\n";
         CtxGuard g;
         xhCheck(xh_ctx_create_private(device, &g.c));
-        std::vector<double> sx(N), sy(N), initial;
-        int ref = 0;
+        std::vector<double> sx(N), sy(N), initial, average;
+        const int nC = cpX * cpY * cpT;
+        std::vector<double> coeffsX(nC), coeffsY(nC), centers, patchShifts;
+        std::vector<float> aligned;
+        int ref = 0, Nsum = 0;
         {
             xh_fa *fa = nullptr;
             xhCheck(xh_fa_create(g.c, (int)I.y, (int)I.x, Ts, maxResForCorrelation, &fa));
             struct FaGuard { xh_fa *f; ~FaGuard() { xh_fa_destroy(f); } } fg{fa};
-            DeviceBuffer d_frames, d_dark, d_gain;
+            DeviceBuffer d_frames, d_dark, d_gain, d_out, d_sum, d_initial;
             d_frames.reserve(g.c, (size_t)N * per * sizeof(float));
-            if (!fnInitialAvg.empty()) initial.assign(per, 0.0);
             for (int n = 0; n < N; ++n) {
                 std::string fn;
                 movie.getValue("image", fn, (size_t)(nfirst + n));
@@ -129,13 +164,48 @@ public:
                 readImage(fn, frame, In);
                 if (In.x != I.x || In.y != I.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnMovie);
                 xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), frame.data(), per * sizeof(float)));
-                if (!initial.empty() && nfirst + n >= nfirstSum && nfirst + n <= nlastSum)
-                    for (size_t k = 0; k < per; ++k) initial[k] += ((double)frame[k] - (dark.empty() ? 0.0 : dark[k])) * (gain.empty() ? 1.0 : gain[k]);
             }
             if (!dark.empty()) { d_dark.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), per * sizeof(float))); }
             if (!gain.empty()) { d_gain.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), per * sizeof(float))); }
-            xhCheck(xh_fa_global_alignment(fa, d_frames.as<float>(), N, dark.empty() ? nullptr : d_dark.as<float>(), gain.empty() ? nullptr : d_gain.as<float>(),
-                                           maxShift, nullptr, nullptr, sx.data(), sy.data(), &ref));
+            const float *pd = dark.empty() ? nullptr : d_dark.as<float>(), *pg = gain.empty() ? nullptr : d_gain.as<float>();
+            xhCheck(xh_fa_global_alignment(fa, d_frames.as<float>(), N, pd, pg, maxShift, nullptr, nullptr, sx.data(), sy.data(), &ref));
+            centers.resize((size_t)patchesX * patchesY * 2);
+            const bool wantAligned = !fnAligned.empty(), wantAvg = !fnAvg.empty(), wantInitial = !fnInitialAvg.empty();
+            if ((patchesX < 2 || patchesY < 2) && (!skipLocalAlignment || wantAligned || wantAvg))
+                REPORT_ERROR(ERR_LOGIC_ERROR, "The movie is too small for patches of " + std::to_string(reqPatch) + " px: give --patches and --minLocalRes");
+            if (skipLocalAlignment && !(wantAligned || wantAvg)) {
+                // only the shifts (and the plain sum) are asked for: no spline needed
+            } else if (skipLocalAlignment) {
+                // applyShiftsComputeAverage(globAlignment) -> localFromGlobal (movie_alignment_correlation_gpu.cpp:432-465)
+                xhCheck(xh_fa_local_from_global(fa, N, sx.data(), sy.data(), patchesX, patchesY, (int)reqPatch, (int)reqPatch, cpX, cpY, cpT, centers.data(), coeffsX.data(),
+                                                coeffsY.data()));
+            } else {
+                if (verbose) std::cout << "Computing local alignment ...\n";
+                patchShifts.resize((size_t)patchesX * patchesY * N * 2);
+                int dims[4];
+                xhCheck(xh_fa_local_alignment(fa, d_frames.as<float>(), N, pd, pg, sx.data(), sy.data(), ref, maxShift, patchesX, patchesY, (int)reqPatch, (int)reqPatch,
+                                              patchesAvg, cpX, cpY, cpT, patchShifts.data(), centers.data(), coeffsX.data(), coeffsY.data(), dims));
+                if (verbose) std::cout << "Patches: " << patchesX << " x " << patchesY << " of " << dims[0] << " x " << dims[1] << " px, correlated at " << dims[2] << " x " << dims[3] << "\n";
+            }
+            // applyShiftsComputeAverage (:479-570): every summed frame warped by the B-spline, the sums kept on the device
+            if (wantAligned || wantAvg || wantInitial) {
+                if (wantAligned) d_out.reserve(g.c, per * sizeof(float));
+                std::vector<float> host(per, 0.f);
+                if (wantAvg) { d_sum.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_sum.p, host.data(), per * sizeof(float))); }
+                if (wantInitial) { d_initial.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_initial.p, host.data(), per * sizeof(float))); }
+                for (int fi = nfirstSum; fi <= nlastSum; ++fi) {
+                    const int off = fi - nfirst;
+                    xhCheck(xh_fa_apply_bspline(fa, d_frames.as<float>() + (size_t)off * per, pd, pg, coeffsX.data(), coeffsY.data(), cpX, cpY, cpT, N, off,
+                                                wantAligned ? d_out.as<float>() : nullptr, wantAvg ? d_sum.as<float>() : nullptr, wantInitial ? d_initial.as<float>() : nullptr));
+                    if (wantAligned) {
+                        xhCheck(xh_memcpy_d2h(g.c, host.data(), d_out.p, per * sizeof(float)));
+                        aligned.insert(aligned.end(), host.begin(), host.end());
+                    }
+                    ++Nsum;
+                }
+                if (wantAvg) { xhCheck(xh_memcpy_d2h(g.c, host.data(), d_sum.p, per * sizeof(float))); average.assign(host.begin(), host.end()); }
+                if (wantInitial) { xhCheck(xh_memcpy_d2h(g.c, host.data(), d_initial.p, per * sizeof(float))); initial.assign(host.begin(), host.end()); }
+            }
         }
         // storeGlobalShifts (:364-396): the shift that should be applied is the negative of the estimated one
         for (size_t id = 0; id < movie.size(); ++id) {
@@ -156,15 +226,47 @@ public:
             for (int n = 0; n < N; ++n) printf("X: %07.4f Y: %07.4f\n", sx[n] * binning, sy[n] * binning);
             std::cout << std::endl;
         }
-        if (!fnInitialAvg.empty()) {     // storeResults (:421-426)
-            const int Ninitial = std::min(nlastSum, nlast) - std::max(nfirstSum, nfirst) + 1;
-            for (double &v : initial) v /= Ninitial;
-            writeVolume(fnInitialAvg, initial.data(), I.x, I.y, 1);
-        }
         const std::string out = fnOut.empty() ? fnMovie : fnOut;
         MetaDataVec mdIref;
         mdIref.setValue("ref", (long)(nfirst + ref), mdIref.addObject());
         mdIref.write("referenceFrame@" + out, false);
+        if (!skipLocalAlignment) {
+            // storeResults(localAlignment) (:460-514): how far the spline moves the patch centres from the global shift (2.5 % and
+            // 97.5 % of the sorted distances), patches, coefficients, control points
+            std::vector<double> dist;
+            const int nP = patchesX * patchesY;
+            for (int p = 0; p < nP; ++p)
+                for (int t = 0; t < N; ++t) {
+                    double bx, by;
+                    splineShift(coeffsX, coeffsY, (int)I.x, (int)I.y, N, (int)centers[2 * p], (int)centers[2 * p + 1], t, bx, by);
+                    dist.push_back(std::hypot(bx - sx[t], by - sy[t]));
+                }
+            std::sort(dist.begin(), dist.end());
+            MetaDataVec md;
+            const size_t id = md.addObject();
+            md.setValue("localAlignmentConf2_5Perc", dist.at((size_t)(dist.size() * 0.025)), id);
+            md.setValue("localAlignmentConf97_5Perc", dist.at((size_t)(dist.size() * 0.975)), id);
+            md.setValue("localAlignmentPatches", "[ " + std::to_string(patchesX) + " " + std::to_string(patchesY) + " ]", id);
+            auto vec = [](const std::vector<double> &v) { std::string s = "[ "; char b[64]; for (double x : v) { snprintf(b, sizeof(b), "%.6f ", x); s += b; } return s + "]"; };
+            md.setValue("localAlignmentCoeffsX", vec(coeffsX), id);
+            md.setValue("localAlignmentCoeffsY", vec(coeffsY), id);
+            md.setValue("localAlignmentControlPoints", "[ " + std::to_string(cpX) + " " + std::to_string(cpY) + " " + std::to_string(cpT) + " ]", id);
+            md.write("localAlignment@" + out, true);
+        }
+        // storeResults (:421-433)
+        if (!fnInitialAvg.empty()) {
+            for (double &v : initial) v /= Nsum;
+            writeVolume(fnInitialAvg, initial.data(), I.x, I.y, 1);
+        }
+        if (!fnAvg.empty()) {
+            for (double &v : average) v /= Nsum;
+            writeVolume(fnAvg, average.data(), I.x, I.y, 1);
+        }
+        if (!fnAligned.empty()) {
+            FileName fa(fnAligned);
+            if (isMrcExt(fa.extension())) { std::vector<double> d(aligned.begin(), aligned.end()); writeVolume(fnAligned, d.data(), I.x, I.y, (size_t)Nsum); }
+            else writeStack(fa.path, aligned.data(), I.x, I.y, (size_t)Nsum);
+        }
         movie.write("frameShifts@" + out, true);
     }
 };
