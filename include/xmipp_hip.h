@@ -342,6 +342,7 @@ int xh_fft2d_destroy(xh_fft2d *f);
 /* h_factors[4] = (ny1, ny2, nx1, nx2): the split of either axis (n2 = 1: one LDS transform per line) */
 int xh_fft2d_factors(const xh_fft2d *f, int32_t *h_factors);
 int xh_fft2d_exec(xh_fft2d *f, float *d_data /* [ny][nx][2] */, int32_t inverse);
+int xh_fft2d_exec_axis(xh_fft2d *f, float *d_data, int32_t inverse, int32_t axis /* 0: rows only, 1: columns only; un-normalised */);
 
 /* ---- ProgRecFourier's own arithmetic: the program behind xmipp_reconstruct_fourier ----------
  * reconstruction/reconstruct_fourier.cpp: double accumulators, image-driven scatter into the FFTW-layout Fourier volume with
@@ -413,6 +414,8 @@ typedef struct xh_fa xh_fa;
 int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float max_res_for_correlation, xh_fa **out);
 int xh_fa_destroy(xh_fa *h);
 int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor);
+int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: every pair correlation through the full inverse transform (A/B) */
+int xh_fa_last_full_pairs(const xh_fa *h);                        /* pairs of the last global alignment that needed the full transform */
 int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, float max_shift_px,
                            double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref);
 int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, const double *h_gShiftX,

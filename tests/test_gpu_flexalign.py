@@ -37,6 +37,13 @@ def test_global_alignment_against_the_oracle(gpu, oracle, N, Y, X, ts, res):
     assert np.abs(got["bX"] - exp["bX"]).max() <= 2e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 2e-3
     assert got["ref"] == exp["ref"]
     assert np.abs(got["shiftX"] - exp["shiftX"]).max() <= 2e-3 and np.abs(got["shiftY"] - exp["shiftY"]).max() <= 2e-3
+    # the pair correlations were taken inside the search window (pruned transforms); every pair through the full inverse transform
+    # gives the same shifts
+    assert fa.last_full_pairs() < len(exp["bX"]) // 4
+    fa.set_option("window", 0)
+    full = fa.global_alignment(torch.from_numpy(frames).cuda(), max_shift, torch.from_numpy(dark).cuda(), torch.from_numpy(gain).cuda())
+    assert fa.last_full_pairs() == len(exp["bX"])
+    assert np.abs(full["bX"] - got["bX"]).max() <= 1e-3 and np.abs(full["bY"] - got["bY"]).max() <= 1e-3 and full["ref"] == got["ref"]
     # and the drift that was put in comes out (the stored shift is the negative of the frame's displacement)
     t = drift - drift[exp["ref"]]
     assert np.abs(got["shiftX"] + t[:, 0]).max() < 0.6 and np.abs(got["shiftY"] + t[:, 1]).max() < 0.6

@@ -87,6 +87,8 @@ SIGNATURES = {
     "xh_fa_create": (C.c_int, [vp, i32, i32, C.c_float, C.c_float, pvp]),
     "xh_fa_destroy": (C.c_int, [vp]),
     "xh_fa_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(d)]),
+    "xh_fa_set_option": (C.c_int, [vp, C.c_char_p, d]),
+    "xh_fa_last_full_pairs": (C.c_int, [vp]),
     "xh_fa_global_alignment": (C.c_int, [vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, C.POINTER(i32)]),
     "xh_fa_local_alignment": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "xh_fa_local_from_global": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "xh_fft2d_destroy": (C.c_int, [vp]),
     "xh_fft2d_factors": (C.c_int, [vp, vp]),
     "xh_fft2d_exec": (C.c_int, [vp, vp, i32]),
+    "xh_fft2d_exec_axis": (C.c_int, [vp, vp, i32, i32]),
     "xh_fp_create": (C.c_int, [vp, vp, i32, C.c_double, C.c_double, i32, pvp]),
     "xh_fp_destroy": (C.c_int, [vp]),
     "xh_fp_info": (C.c_int, [vp, vp, vp, vp]),

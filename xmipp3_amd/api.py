@@ -439,6 +439,12 @@ class FlexAlign:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        check(lib().xh_fa_set_option(self.h, name.encode(), float(value)))
+
+    def last_full_pairs(self):
+        return lib().xh_fa_last_full_pairs(self.h)
+
     def global_alignment(self, frames, max_shift_px, dark=None, gain=None):
         """frames [N, Y, X] float32 on the device -> dict(bX, bY, shiftX, shiftY, ref)"""
         torch = _torch()

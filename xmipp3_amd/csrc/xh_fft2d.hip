@@ -248,4 +248,21 @@ int xh_fft2d_exec(xh_fft2d *f, float *d_data, int32_t inverse)
     return XH_OK;
 }
 
+// One axis only, un-normalised in both directions: axis 0 = the ny rows, axis 1 = the nx columns. FlexAlign's frame transform
+// packs two real rows into one complex row, transforms the rows, keeps the columns the reduced frame needs and transforms
+// those down the other axis on a narrower array (xh_flexalign.hip).
+int xh_fft2d_exec_axis(xh_fft2d *f, float *d_data, int32_t inverse, int32_t axis)
+{
+    XH_CHECK(f && d_data && (axis == 0 || axis == 1), XH_ERR_ARG, "xh_fft2d_exec_axis: bad argument");
+    xh_ctx *ctx = f->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t ny = f->ny, nx = f->nx;
+    xh_cf *cur = (xh_cf *)d_data, *oth = (xh_cf *)f->tmp.p;
+    bool inCur = true;
+    if (axis == 0) XH_TRY(axis_exec(ctx, f->ax, cur, oth, ny, ny, 0, nx, 1, inverse != 0, 1.0f, &inCur));
+    else XH_TRY(axis_exec(ctx, f->ay, cur, oth, nx, nx, 0, 1, nx, inverse != 0, 1.0f, &inCur));
+    if (!inCur) XH_HIP(hipMemcpyAsync(d_data, oth, sizeof(xh_cf) * ny * nx, hipMemcpyDeviceToDevice, ctx->stream));
+    return XH_OK;
+}
+
 }  // extern "C"

@@ -88,6 +88,90 @@ __global__ void __launch_bounds__(256) k_fa_pair(const fa_cf *__restrict__ A, co
     P[t] = fa_cf{(a.x * b.x + a.y * b.y) * scale, (a.y * b.x - a.x * b.y) * scale};
 }
 
+// Two real rows per complex row: row 2r in the real part, row 2r+1 in the imaginary part (one transform along x for both)
+__global__ void __launch_bounds__(256) k_fa_load2(const float *__restrict__ frame, const float *__restrict__ dark, const float *__restrict__ gain,
+                                                  fa_cf *__restrict__ out, int Y, int X)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int Yh = (Y + 1) / 2;
+    if (t >= (size_t)Yh * X) return;
+    const int r = (int)(t / X), x = (int)(t - (size_t)r * X);
+    const size_t s0 = (size_t)(2 * r) * X + x, s1 = s0 + X;
+    float v0 = frame[s0], v1 = 0.f;
+    if (dark) v0 -= dark[s0];
+    if (gain) v0 *= gain[s0];
+    if (2 * r + 1 < Y) {
+        v1 = frame[s1];
+        if (dark) v1 -= dark[s1];
+        if (gain) v1 *= gain[s1];
+    }
+    out[t] = fa_cf{v0, v1};
+}
+
+// ... and apart again for the nc columns the reduced frame keeps: with Z = F(a + i b), F(a)[k] = (Z[k] + conj Z[-k]) / 2,
+// F(b)[k] = (Z[k] - conj Z[-k]) / 2i. C: [Y][nc]
+__global__ void __launch_bounds__(256) k_fa_unpack(const fa_cf *__restrict__ Z, fa_cf *__restrict__ C, int Y, int X, int nc)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int Yh = (Y + 1) / 2;
+    if (t >= (size_t)Yh * nc) return;
+    const int r = (int)(t / nc), k = (int)(t - (size_t)r * nc);
+    const fa_cf zk = Z[(size_t)r * X + k], zm = Z[(size_t)r * X + (k ? X - k : 0)];
+    C[(size_t)(2 * r) * nc + k] = fa_cf{0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+    if (2 * r + 1 < Y) C[(size_t)(2 * r + 1) * nc + k] = fa_cf{0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+}
+
+// Pair correlation inside the window the shift is looked for in only. With c = S_a conj(S_b) the map the full path returns is
+// M = dSize sum_k c_k e^{2 pi i k x}; its mean is dSize c_0 and its variance dSize^2 sum_{k != 0} |c_k|^2 (Parseval), so
+// statisticsAdjust needs no map, and bestShift looks at the disc of radius maxShift and at the square it grows around the
+// maximum: rows / columns -h .. h of the centred map, transformed as two pruned DFTs. First along y:
+// U[pair][yy][kx] = sum_ky c[ky][kx] twY[ky][yy], kx <= nX/2; RW rows per thread.
+template <int RW>
+__global__ void __launch_bounds__(256) k_fa_pairwin_a(const fa_cf *__restrict__ S, int N, int nY, int nX, const fa_cf *__restrict__ twY, int wy,
+                                                      fa_cf *__restrict__ U, double *__restrict__ stat)
+{
+    __shared__ float red[256];
+    const int nxh = nX / 2 + 1;
+    const int kx = blockIdx.x * 256 + threadIdx.x;
+    int a = 0, rem = blockIdx.y;
+    while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
+    const int b = a + 1 + rem;
+    const size_t small = (size_t)nY * nX;
+    const fa_cf *Sa = S + (size_t)a * small, *Sb = S + (size_t)b * small;
+    const int yy0 = blockIdx.z * RW;
+    const bool first = blockIdx.z == 0;
+    fa_cf acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = fa_cf{0.f, 0.f};
+    float ss = 0.f, c0 = 0.f;
+    if (kx < nxh) {
+        const float wgt = (kx == 0 || 2 * kx == nX) ? 1.f : 2.f;
+        for (int ky = 0; ky < nY; ++ky) {
+            const fa_cf p = Sa[(size_t)ky * nX + kx], q = Sb[(size_t)ky * nX + kx];
+            const float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
+            if (first) {
+                if (ky == 0 && kx == 0) c0 = pr;
+                else ss += wgt * (pr * pr + pi * pi);
+            }
+            const fa_cf *w = twY + (size_t)ky * wy + yy0;
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                if (yy0 + r < wy) { const fa_cf t = w[r]; acc[r].x += pr * t.x - pi * t.y; acc[r].y += pr * t.y + pi * t.x; }
+        }
+        fa_cf *u = U + ((size_t)blockIdx.y * wy + yy0) * nxh + kx;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (yy0 + r < wy) u[(size_t)r * nxh] = acc[r];
+    }
+    if (first) {
+        red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) atomicAdd(&stat[2 * blockIdx.y + 1], (double)red[0]);
+        if (kx == 0) stat[2 * blockIdx.y] = (double)c0;
+    }
+}
+
 // sum and sum of squares of the correlation map (real part of the inverse transform), one partial per block
 __global__ void __launch_bounds__(256) k_fa_stats(const fa_cf *__restrict__ M, size_t tot, double *__restrict__ part)
 {
@@ -169,6 +253,95 @@ __global__ void __launch_bounds__(256) k_fa_bestshift(const fa_cf *__restrict__ 
         }
     if (sc != 0) { shiftX = xs / sc; shiftY = ys / sc; }
     out[0] = shiftX; out[1] = shiftY; out[2] = mx;
+}
+
+// ... then along x (real part: the spectra are Hermitian) into the block's window W[wy][wx], and bestShift as k_fa_bestshift does
+// it on the full map. out[pair] = (shiftX, shiftY, max, overflow): overflow = 1 when the square grown around the maximum reaches
+// beyond the window; the host repeats such a pair through the full transform.
+__global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ Uall, const fa_cf *__restrict__ twX, const double *__restrict__ stat, int nY, int nX,
+                                                      int hy, int hx, int maxShift, float *__restrict__ Wall, double *__restrict__ out)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int nxh = nX / 2 + 1, wy = 2 * hy + 1, wx = 2 * hx + 1;
+    const fa_cf *U = Uall + (size_t)blockIdx.x * wy * nxh;
+    float *W = Wall + (size_t)blockIdx.x * wy * wx;
+    const double dSize = (double)nY * (double)nX;
+    for (int o = threadIdx.x; o < wy * wx; o += 256) {
+        const int yy = o / wx, xx = o - yy * wx;
+        const fa_cf *u = U + (size_t)yy * nxh;
+        const fa_cf *w = twX + xx;
+        float acc = 0.f;
+        for (int kx = 0; kx < nxh; ++kx) {
+            const fa_cf t = w[(size_t)kx * wx], v = u[kx];
+            const float r = v.x * t.x - v.y * t.y;
+            acc += (kx == 0 || 2 * kx == nX) ? r : 2.f * r;
+        }
+        W[o] = acc * (float)dSize;
+    }
+    __syncthreads();
+    const double avg = dSize * stat[2 * blockIdx.x];
+    const double sd = dSize * sqrt(stat[2 * blockIdx.x + 1]);
+    double a = 0, b = 0;
+    if (sd != 0) { a = 1.0 / sd; b = -avg * a; }
+    const int starty = -(nY / 2), startx = -(nX / 2), finy = starty + nY - 1, finx = startx + nX - 1;
+    auto val = [&](int i, int j) { return a * (double)W[(size_t)(i + hy) * wx + (j + hx)] + b; };
+    const int w = 2 * maxShift + 1;
+    double best = -1.79769313486231570815e+308;
+    int bestIdx = 0x7fffffff;
+    for (int t = threadIdx.x; t < w * w; t += 256) {
+        const int i = t / w - maxShift, j = t % w - maxShift;
+        if (i * i + j * j > maxShift * maxShift) continue;
+        const double v = val(i, j);
+        if (v > best) { best = v; bestIdx = t; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bestIdx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v = sv[threadIdx.x + o];
+            const int k = si[threadIdx.x + o];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && k < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = k; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double *o4 = out + 4 * (size_t)blockIdx.x;
+    if (si[0] == 0x7fffffff) { o4[0] = 0; o4[1] = 0; o4[2] = -1; o4[3] = 0; return; }
+    const int imax = si[0] / w - maxShift, jmax = si[0] % w - maxShift;
+    const double mx = sv[0];
+    bool overflow = false;
+    auto inwin = [&](int i, int j) { return i >= -hy && i <= hy && j >= -hx && j <= hx; };
+    int n_max = -1;
+    bool neighbourhood = true;
+    while (neighbourhood) {
+        n_max++;
+        for (int i = -n_max; i <= n_max && neighbourhood; i++) {
+            const int ia = i + imax;
+            if (ia < starty || ia > finy) { neighbourhood = false; break; }
+            for (int j = -n_max; j <= n_max && neighbourhood; j++) {
+                const int ja = j + jmax;
+                if (ja < startx || ja > finx) { neighbourhood = false; break; }
+                if (!inwin(ia, ja)) { overflow = true; neighbourhood = false; break; }
+                if (mx / 1.414 > val(ia, ja)) { neighbourhood = false; break; }
+            }
+        }
+    }
+    if (imax - n_max < starty) n_max = min(imax - starty, n_max);
+    if (imax + n_max > finy) n_max = min(finy - imax, n_max);
+    if (jmax - n_max < starty) n_max = min(jmax - startx, n_max);
+    if (jmax + n_max > finy) n_max = min(finx - jmax, n_max);
+    double xs = 0, ys = 0, sc = 0;
+    for (int i = -n_max; i <= n_max && !overflow; i++)
+        for (int j = -n_max; j <= n_max; j++) {
+            const int ia = i + imax, ja = j + jmax;
+            if (!inwin(ia, ja)) { overflow = true; break; }
+            const double v = val(ia, ja);
+            ys += ia * v; xs += ja * v; sc += v;
+        }
+    double shiftX = 0, shiftY = 0;
+    if (sc != 0) { shiftX = xs / sc; shiftY = ys / sc; }
+    o4[0] = shiftX; o4[1] = shiftY; o4[2] = mx; o4[3] = overflow ? 1.0 : 0.0;
 }
 
 // ---- local (patch) alignment: computeLocalAlignment, movie_alignment_correlation_gpu.cpp:288-430 ------------------------------
@@ -589,6 +762,13 @@ std::vector<float> fa_make_lpf(double Tsp, float maxRes, int nX, int nY, double 
         }
     return lpf;
 }
+int fa_upload(const void *src, XhBuf &b, size_t bytes, xh_ctx *ctx)
+{
+    XH_TRY(xh_buf_alloc(ctx, b, bytes));
+    XH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));          // the source is a host temporary
+    return XH_OK;
+}
 }  // namespace
 
 struct xh_fa {
@@ -596,7 +776,10 @@ struct xh_fa {
     int Y, X, nY, nX;
     float Ts, maxRes;
     double sizeFactor;
-    xh_fft2d *big, *small;
+    xh_fft2d *rows, *cols, *small;        // rows: (Y+1)/2 packed rows of X points; cols: the nc kept columns of Y points; small: a pair map
+    int nc;                               // columns of the frame transform the reduced frame keeps (nX/2 + 1)
+    int lastFull = 0;                     // pairs of the last global alignment that went through the full transform
+    int use_window = 1;                   // pair correlations inside the search window only (0: every pair through the full transform)
     XhBuf work, spectra, lpf, pair, part, res, warpC;
     int capFrames;
 };
@@ -608,7 +791,8 @@ int xh_fa_destroy(xh_fa *h)
     if (!h) return XH_OK;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    if (h->big) xh_fft2d_destroy(h->big);
+    if (h->rows) xh_fft2d_destroy(h->rows);
+    if (h->cols) xh_fft2d_destroy(h->cols);
     if (h->small) xh_fft2d_destroy(h->small);
     xh_buf_free(h->work); xh_buf_free(h->spectra); xh_buf_free(h->lpf); xh_buf_free(h->pair); xh_buf_free(h->part); xh_buf_free(h->res); xh_buf_free(h->warpC);
     delete h;
@@ -629,11 +813,13 @@ int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float m
     h->ctx = ctx; h->Y = Y; h->X = X; h->Ts = sampling_rate; h->maxRes = max_res_for_correlation;
     h->sizeFactor = scale;
     h->nX = (int)(X * h->sizeFactor); h->nY = (int)(Y * h->sizeFactor);       // loadData, movie_alignment_correlation.cpp:101-102
-    h->big = h->small = nullptr;
+    h->rows = h->cols = h->small = nullptr;
     h->capFrames = 0;
+    h->nc = h->nX / 2 + 1;
     int rc = (h->nX >= 4 && h->nY >= 4) ? XH_OK : XH_ERR_ARG;
     if (rc != XH_OK) xh_set_error("xh_fa_create: reduced frames of %d x %d pixels", h->nY, h->nX);
-    if (rc == XH_OK) rc = xh_fft2d_create(ctx, Y, X, &h->big);
+    if (rc == XH_OK) rc = xh_fft2d_create(ctx, (Y + 1) / 2, X, &h->rows);
+    if (rc == XH_OK) rc = xh_fft2d_create(ctx, Y, h->nc, &h->cols);
     if (rc == XH_OK) rc = xh_fft2d_create(ctx, h->nY, h->nX, &h->small);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->work, sizeof(fa_cf) * (size_t)Y * X);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->pair, sizeof(fa_cf) * (size_t)h->nY * h->nX);
@@ -649,6 +835,16 @@ int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float m
     *out = h;
     return XH_OK;
 }
+
+int xh_fa_set_option(xh_fa *h, const char *name, double value)
+{
+    XH_CHECK(h && name, XH_ERR_ARG, "xh_fa_set_option: bad argument");
+    if (!strcmp(name, "window")) h->use_window = value != 0;
+    else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
+    return XH_OK;
+}
+
+int xh_fa_last_full_pairs(const xh_fa *h) { return h ? h->lastFull : -1; }
 
 int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor)
 {
@@ -672,11 +868,20 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     XH_TRY(xh_buf_reserve(ctx, h->spectra, sizeof(fa_cf) * small * (size_t)N));
     fa_cf *S = (fa_cf *)h->spectra.p, *wk = (fa_cf *)h->work.p, *P = (fa_cf *)h->pair.p;
     const float inorm = (float)(1.0 / ((double)h->Y * (double)h->X));
+    // frame transform: two rows per complex row along x, the nc kept columns apart again and down y on their own
+    // ((Y+1)/2 X + Y nc complex values: both fit the Y X of `work` because nc <= X / 2)
+    const int Yh = (h->Y + 1) / 2, nc = h->nc;
+    XH_CHECK((size_t)Yh * h->X + (size_t)h->Y * nc <= big, XH_ERR_ARG, "xh_fa_global_alignment: frames of %d x %d are too small", h->Y, h->X);
+    fa_cf *Cc = wk + (size_t)Yh * h->X;
     for (int n = 0; n < N; ++n) {
-        hipLaunchKernelGGL(k_fa_load, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, big);
+        const size_t tz = (size_t)Yh * h->X, tc = (size_t)Yh * nc;
+        hipLaunchKernelGGL(k_fa_load2, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, h->Y, h->X);
         XH_LAUNCH_CHECK();
-        XH_TRY(xh_fft2d_exec(h->big, (float *)wk, 0));
-        hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, h->Y, h->X, S + (size_t)n * small, nY, nX,
+        XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
+        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cc, h->Y, h->X, nc);
+        XH_LAUNCH_CHECK();
+        XH_TRY(xh_fft2d_exec_axis(h->cols, (float *)Cc, 0, 1));
+        hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)Cc, h->Y, nc, S + (size_t)n * small, nY, nX,
                            (const float *)h->lpf.p, inorm);
         XH_LAUNCH_CHECK();
     }
@@ -686,22 +891,81 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     XH_TRY(xh_buf_alloc(ctx, resAll, sizeof(double) * 3 * (size_t)rows));
     const double dSize = (double)small;
     const int nparts = 256;
-    int idx = 0, rc = XH_OK;
-    for (int i = 0; i < N - 1 && rc == XH_OK; ++i)
-        for (int j = i + 1; j < N && rc == XH_OK; ++j, ++idx) {
-            // FFT1 conj(FFT2) dSize through an un-normalised inverse (correlation_matrix); ours divides by dSize
-            hipLaunchKernelGGL(k_fa_pair, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)(S + (size_t)i * small),
-                               (const fa_cf *)(S + (size_t)j * small), P, small, (float)(dSize * dSize));
-            rc = xh_fft2d_exec(h->small, (float *)P, 1);
-            if (rc != XH_OK) break;
-            hipLaunchKernelGGL(k_fa_stats, dim3(nparts), dim3(256), 0, ctx->stream, (const fa_cf *)P, small, (double *)h->part.p);
-            hipLaunchKernelGGL(k_fa_bestshift, dim3(1), dim3(256), 0, ctx->stream, (const fa_cf *)P, nY, nX, ms, (const double *)h->part.p, nparts,
-                               (double *)resAll.p + 3 * (size_t)idx);
-            if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_global_alignment: kernel launch failed"); rc = XH_ERR_HIP; }
-        }
+    int rc = XH_OK;
+    // the full path of one pair: FFT1 conj(FFT2) dSize through an un-normalised inverse (correlation_matrix); ours divides by dSize
+    auto pairFull = [&](int i, int j, int idx) {
+        hipLaunchKernelGGL(k_fa_pair, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)(S + (size_t)i * small),
+                           (const fa_cf *)(S + (size_t)j * small), P, small, (float)(dSize * dSize));
+        int r2 = xh_fft2d_exec(h->small, (float *)P, 1);
+        if (r2 != XH_OK) return r2;
+        hipLaunchKernelGGL(k_fa_stats, dim3(nparts), dim3(256), 0, ctx->stream, (const fa_cf *)P, small, (double *)h->part.p);
+        hipLaunchKernelGGL(k_fa_bestshift, dim3(1), dim3(256), 0, ctx->stream, (const fa_cf *)P, nY, nX, ms, (const double *)h->part.p, nparts,
+                           (double *)resAll.p + 3 * (size_t)idx);
+        if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_global_alignment: kernel launch failed"); return (int)XH_ERR_HIP; }
+        return (int)XH_OK;
+    };
     std::vector<double> res(3 * (size_t)rows);
-    if (rc == XH_OK && hipMemcpyAsync(res.data(), resAll.p, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
-    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    const int G = 8;                                  // rows / columns beyond the search disc for the square bestShift grows
+    const int hy = ms + G, hx = ms + G;
+    const bool windowed = h->use_window && hy < nY / 2 - 1 && hx < nX / 2 - 1;
+    if (windowed) {
+        const int wy = 2 * hy + 1, wx = 2 * hx + 1, nxh = nX / 2 + 1;
+        std::vector<fa_cf> twY((size_t)nY * wy), twX((size_t)nxh * wx);
+        const double twoPi = 6.283185307179586476925286766559;
+        for (int ky = 0; ky < nY; ++ky)
+            for (int yy = 0; yy < wy; ++yy) {
+                const long long m = (((long long)ky * (yy - hy)) % nY + nY) % nY;
+                twY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(twoPi * m / nY), (float)std::sin(twoPi * m / nY)};
+            }
+        for (int kx = 0; kx < nxh; ++kx)
+            for (int xx = 0; xx < wx; ++xx) {
+                const long long m = (((long long)kx * (xx - hx)) % nX + nX) % nX;
+                twX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(twoPi * m / nX), (float)std::sin(twoPi * m / nX)};
+            }
+        XhBuf bTwY, bTwX, bU, bW, bStat, bOut;
+        auto freeWin = [&]() { XhBuf *all[] = {&bTwY, &bTwX, &bU, &bW, &bStat, &bOut}; for (XhBuf *q : all) xh_buf_free(*q); };
+        rc = fa_upload(twY.data(), bTwY, sizeof(fa_cf) * twY.size(), ctx);
+        if (rc == XH_OK) rc = fa_upload(twX.data(), bTwX, sizeof(fa_cf) * twX.size(), ctx);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * nxh);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bStat, sizeof(double) * 2 * (size_t)rows);
+        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bOut, sizeof(double) * 4 * (size_t)rows);
+        if (rc == XH_OK && hipMemsetAsync(bStat.p, 0, sizeof(double) * 2 * (size_t)rows, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+        std::vector<double> out4(4 * (size_t)rows);
+        if (rc == XH_OK) {
+            constexpr int RW = 16;
+            hipLaunchKernelGGL((k_fa_pairwin_a<RW>), dim3((nxh + 255) / 256, rows, (wy + RW - 1) / RW), dim3(256), 0, ctx->stream, (const fa_cf *)S, N, nY, nX,
+                               (const fa_cf *)bTwY.p, wy, (fa_cf *)bU.p, (double *)bStat.p);
+            hipLaunchKernelGGL(k_fa_pairwin_b, dim3(rows), dim3(256), 0, ctx->stream, (const fa_cf *)bU.p, (const fa_cf *)bTwX.p, (const double *)bStat.p, nY, nX, hy, hx, ms,
+                               (float *)bW.p, (double *)bOut.p);
+            if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
+        }
+        if (rc == XH_OK && hipMemcpyAsync(out4.data(), bOut.p, sizeof(double) * out4.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+        if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+        freeWin();
+        // pairs whose maximum is so wide that the square grown around it leaves the window: through the full transform
+        std::vector<int> redo;
+        int idx = 0;
+        for (int i = 0; i < N - 1 && rc == XH_OK; ++i)
+            for (int j = i + 1; j < N && rc == XH_OK; ++j, ++idx) {
+                if (out4[4 * (size_t)idx + 3] != 0) { redo.push_back(idx); rc = pairFull(i, j, idx); }
+                else for (int c = 0; c < 3; ++c) res[3 * (size_t)idx + c] = out4[4 * (size_t)idx + c];
+            }
+        h->lastFull = (int)redo.size();
+        if (rc == XH_OK && !redo.empty()) {
+            std::vector<double> full(3 * (size_t)rows);
+            if (hipMemcpyAsync(full.data(), resAll.p, sizeof(double) * full.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+            if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+            for (int q : redo) for (int c = 0; c < 3; ++c) res[3 * (size_t)q + c] = full[3 * (size_t)q + c];
+        }
+    } else {
+        int idx = 0;
+        for (int i = 0; i < N - 1 && rc == XH_OK; ++i)
+            for (int j = i + 1; j < N && rc == XH_OK; ++j, ++idx) rc = pairFull(i, j, idx);
+        h->lastFull = rows;
+        if (rc == XH_OK && hipMemcpyAsync(res.data(), resAll.p, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+        if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    }
     xh_buf_free(resAll);
     if (rc != XH_OK) { if (rc == XH_ERR_HIP) xh_set_error("xh_fa_global_alignment: device error"); return rc; }
     for (int r = 0; r < rows; ++r) { bx[r] = res[3 * r] / h->sizeFactor; by[r] = res[3 * r + 1] / h->sizeFactor; }       // scale to the movie's pixels
@@ -776,13 +1040,6 @@ void fa_fit_bspline(int N, int Y, int X, int nP, const double *centers, const do
     for (int k = 0; k < Cc; ++k) { coeffsX[k] = cX[k]; coeffsY[k] = cY[k]; }
 }
 
-int fa_upload(const void *src, XhBuf &b, size_t bytes, xh_ctx *ctx)
-{
-    XH_TRY(xh_buf_alloc(ctx, b, bytes));
-    XH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));          // the source is a host temporary
-    return XH_OK;
-}
 }  // namespace
 
 extern "C" {
