@@ -22,9 +22,13 @@
 // The patch (local) alignment of movie_alignment_correlation_gpu.cpp:289-430 is not here: the reference has no CPU form of it
 // to compare with (movie_alignment_correlation.cpp:63-76 throw "Not implemented").
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "xh_common.h"
 #include "xh_bspline.h"
@@ -446,14 +450,17 @@ __global__ void __launch_bounds__(256) k_fa_patch_sum(const fa_cf *__restrict__ 
 
 // One block per frame pair (a, b), a < b in the order (0,1), (0,2) ...: the correlation map in rows y0 .. y0+wy-1, columns
 // x0 .. x0+wx-1 (U, W: scratch of the block), its first maximum within maxDist of the centre and the 3 x 3 centre of mass.
-// out[pair] = (posX, posY) in pixels of the correlation map.
-__global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__ S, int N, int CY, int CX, const fa_cf *__restrict__ tabY, const fa_cf *__restrict__ tabX,
+// blockDim = the kept columns rounded up to whole waves (at most 256): a thread owns a column kx of the product spectrum and
+// eight rows of the window at a time, so the product of a (ky, kx) is formed once per eight outputs and the twiddles
+// twY[ky][yy] are the same for the whole wave. out[pair] = (posX, posY) in pixels of the correlation map.
+__global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__ S, int N, int CY, int CX, const fa_cf *__restrict__ twY, const fa_cf *__restrict__ twX,
                                                        int y0, int wy, int x0, int wx, int maxDist, fa_cf *__restrict__ Uall, float *__restrict__ Wall,
                                                        double *__restrict__ out)
 {
+    constexpr int RW = 8;
     __shared__ float sv[256];
     __shared__ int si[256];
-    const int cxh = CX / 2 + 1;
+    const int cxh = CX / 2 + 1, nt = blockDim.x;
     // pair index -> (a, b)
     int a = 0, rem = blockIdx.x;
     while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
@@ -462,32 +469,35 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
     fa_cf *U = Uall + (size_t)blockIdx.x * wy * cxh;
     float *W = Wall + (size_t)blockIdx.x * wy * wx;
     // along y: U[yy][kx] = sum_ky P[ky][kx] e^{2 pi i ky y / CY}
-    for (int o = threadIdx.x; o < wy * cxh; o += 256) {
-        const int yy = o / cxh, kx = o - yy * cxh, y = y0 + yy;
-        float re = 0.f, im = 0.f;
-        int m = 0;
-        for (int ky = 0; ky < CY; ++ky) {
-            const fa_cf p = Sa[(size_t)ky * cxh + kx], q = Sb[(size_t)ky * cxh + kx];
-            const float sgn = ((kx + ky) & 1) ? -1.f : 1.f;                      // centres the correlation
-            const float pr = (p.x * q.x + p.y * q.y) * sgn, pi = (p.y * q.x - p.x * q.y) * sgn;
-            const fa_cf w = tabY[m];
-            re += pr * w.x - pi * w.y; im += pr * w.y + pi * w.x;
-            m += y; if (m >= CY) m -= CY;
+    for (int kx = threadIdx.x; kx < cxh; kx += nt)
+        for (int g = 0; g < wy; g += RW) {
+            fa_cf acc[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = fa_cf{0.f, 0.f};
+            for (int ky = 0; ky < CY; ++ky) {
+                const fa_cf p = Sa[(size_t)ky * cxh + kx], q = Sb[(size_t)ky * cxh + kx];
+                const float sgn = ((kx + ky) & 1) ? -1.f : 1.f;                      // centres the correlation
+                const float pr = (p.x * q.x + p.y * q.y) * sgn, pi = (p.y * q.x - p.x * q.y) * sgn;
+                const fa_cf *w = twY + (size_t)ky * wy + g;
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (g + r < wy) { const fa_cf t = w[r]; acc[r].x += pr * t.x - pi * t.y; acc[r].y += pr * t.y + pi * t.x; }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                if (g + r < wy) U[(size_t)(g + r) * cxh + kx] = acc[r];
         }
-        U[o] = fa_cf{re, im};
-    }
     __syncthreads();
     // along x, real part: what a complex-to-real transform of the half spectrum returns
-    for (int o = threadIdx.x; o < wy * wx; o += 256) {
-        const int yy = o / wx, xx = o - yy * wx, x = x0 + xx;
+    for (int o = threadIdx.x; o < wy * wx; o += nt) {
+        const int yy = o / wx, xx = o - yy * wx;
         const fa_cf *u = U + (size_t)yy * cxh;
+        const fa_cf *w = twX + xx;
         float acc = 0.f;
-        int m = 0;
         for (int kx = 0; kx < cxh; ++kx) {
-            const fa_cf w = tabX[m], v = u[kx];
-            const float r = v.x * w.x - v.y * w.y;
+            const fa_cf t = w[(size_t)kx * wx], v = u[kx];
+            const float r = v.x * t.x - v.y * t.y;
             acc += (kx == 0 || 2 * kx == CX) ? r : 2.f * r;
-            m += x; if (m >= CX) m -= CX;
         }
         W[o] = acc;
     }
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
     const int xHalf = CX / 2, yHalf = CY / 2;
     float best = -3.402823466e+38f;
     int bestIdx = 0x7fffffff;
-    for (int o = threadIdx.x; o < wy * wx; o += 256) {
+    for (int o = threadIdx.x; o < wy * wx; o += nt) {
         const int yy = o / wx, xx = o - yy * wx;
         const int ly = y0 + yy - yHalf, lx = x0 + xx - xHalf;
         if (ly * ly + lx * lx > maxDist * maxDist) continue;
@@ -503,12 +513,13 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
         if (v > best) { best = v; bestIdx = o; }
     }
     sv[threadIdx.x] = best; si[threadIdx.x] = bestIdx;
+    for (int o = nt + threadIdx.x; o < 256; o += nt) { sv[o] = -3.402823466e+38f; si[o] = 0x7fffffff; }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const float v = sv[threadIdx.x + o];
-            const int k = si[threadIdx.x + o];
-            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && k < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = k; }
+        for (int t = threadIdx.x; t < o; t += nt) {
+            const float v = sv[t + o];
+            const int k = si[t + o];
+            if (v > sv[t] || (v == sv[t] && k < si[t])) { sv[t] = v; si[t] = k; }
         }
         __syncthreads();
     }
@@ -532,41 +543,60 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
 
 // ---- B-spline warp: applyBSplineTransform(3, ...) (cuda_gpu_geo_transformer.cpp:186-239) ---------------------------------------
 // cubic B-spline prefilter of the (dark / gain corrected) frame as a convolution (xh_bspline.h: exactly the recursion with the
-// half-sample mirror, 33 taps in fp32), columns then rows; COLS: `in` is the raw frame and the correction is applied on the way
-template <bool COLS>
-__global__ void __launch_bounds__(256) k_fa_fir(const float *__restrict__ in, const float *__restrict__ dark, const float *__restrict__ gain, float *__restrict__ out,
-                                                float *__restrict__ plain, int Y, int X, XhFir F)
+// half-sample mirror, 33 taps in fp32), both passes in one kernel like k_pm_prefilter_fir2d, for frames that are not square:
+// a block owns XH_FIR_V rows x 256 columns, filters down the columns (thread <-> column, the 16 either side too, the correction
+// applied as the samples are read) into an LDS tile and along the rows out of it. plain += the corrected samples (initialMic).
+__global__ void __launch_bounds__(256) k_fa_prefilter(const float *__restrict__ in, const float *__restrict__ dark, const float *__restrict__ gain,
+                                                      float *__restrict__ out, float *__restrict__ plain, int Y, int X, int tilesX, XhFir F)
 {
-    const unsigned segs = COLS ? (Y + XH_FIR_V - 1) / XH_FIR_V : (X + XH_FIR_V - 1) / XH_FIR_V;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)segs * (COLS ? X : Y)) return;
-    int x0, y0;
-    if (COLS) { const unsigned q = (unsigned)(t / X); x0 = (int)(t - (size_t)q * X); y0 = q * XH_FIR_V; }
-    else { const unsigned q = (unsigned)(t / segs); x0 = (int)(t - (size_t)q * segs) * XH_FIR_V; y0 = q; }
-    const int n = COLS ? Y : X;
-    float w[XH_FIR_V + 2 * XH_FIR_K];
+    constexpr int TW = 256;
+    __shared__ __align__(16) float tile[XH_FIR_V][TW + 2 * XH_FIR_K];
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x0 = tx * TW, y0 = ty * XH_FIR_V;
+    for (int xx = threadIdx.x; xx < TW + 2 * XH_FIR_K; xx += 256) {
+        const int pu = x0 + xx - XH_FIR_K;
+        if (pu >= X + XH_FIR_K) break;                   // beyond the halo of the last, partial tile
+        int p = pu;
+        while (p < 0 || p >= X) p = p < 0 ? -1 - p : 2 * X - 1 - p;
+        float w[XH_FIR_V + 2 * XH_FIR_K];
 #pragma unroll
-    for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
-        int p = (COLS ? y0 : x0) + i - XH_FIR_K;
-        while (p < 0 || p >= n) p = p < 0 ? -1 - p : 2 * n - 1 - p;
-        const size_t src = COLS ? (size_t)p * X + x0 : (size_t)y0 * X + p;
-        float v = in[src];
-        if (COLS) {
+        for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
+            int q = y0 + i - XH_FIR_K;
+            while (q < 0 || q >= Y) q = q < 0 ? -1 - q : 2 * Y - 1 - q;
+            const size_t src = (size_t)q * X + p;
+            float v = in[src];
             if (dark) v -= dark[src];
             if (gain) v *= gain[src];
+            w[i] = v;
         }
-        w[i] = v;
-    }
+        const bool own = plain && pu >= x0 && pu < x0 + TW && pu < X;
 #pragma unroll
-    for (int o = 0; o < XH_FIR_V; ++o) {
-        const int q = (COLS ? y0 : x0) + o;
-        if (q >= n) break;
+        for (int o = 0; o < XH_FIR_V; ++o) {
+            float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+            for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+            tile[o][xx] = acc;
+            if (own && y0 + o < Y) plain[(size_t)(y0 + o) * X + pu] += w[o + XH_FIR_K];
+        }
+    }
+    __syncthreads();
+    const int r = threadIdx.x / (TW / 8), seg = threadIdx.x - r * (TW / 8);
+    const int xo = x0 + seg * 8, y = y0 + r;
+    if (y >= Y || xo >= X) return;
+    float w[8 + 2 * XH_FIR_K];
+    const float4 *t4 = reinterpret_cast<const float4 *>(&tile[r][seg * 8]);
+#pragma unroll
+    for (int i = 0; i < (8 + 2 * XH_FIR_K) / 4; ++i) {
+        const float4 q = t4[i];
+        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+    float *dst = out + (size_t)y * X + xo;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
         float acc = F.h[0] * w[o + XH_FIR_K];
 #pragma unroll
         for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
-        const size_t dst = COLS ? (size_t)q * X + x0 : (size_t)y0 * X + q;
-        out[dst] = acc;
-        if (COLS && plain) plain[dst] += w[o + XH_FIR_K];          // the sum of the unaligned frames (initialMic)
+        if (xo + o < X) dst[o] = acc;
     }
 }
 
@@ -585,6 +615,12 @@ __device__ __forceinline__ float d_fa_b3(float x)
 __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef, const float *__restrict__ cX, const float *__restrict__ cY, int lX, int lY, int lT,
                                                  float hX, float hY, float tPos, int Y, int X, float *__restrict__ out, float *__restrict__ sum)
 {
+    // the control points of the frames around tPos (at most four layers of lX lY values) in LDS
+    extern __shared__ float sc[];
+    const int nl = lX * lY, t0 = max((int)tPos - 1, -1), t1 = min((int)tPos + 2, lT - 2), nlay = t1 - t0 + 1;
+    float *scX = sc, *scY = sc + nlay * nl;
+    for (int i = threadIdx.x; i < nlay * nl; i += 256) { scX[i] = cX[(t0 + 1) * nl + i]; scY[i] = cY[(t0 + 1) * nl + i]; }
+    __syncthreads();
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= X || y >= Y) return;
     const float delta = 0.0001f;
@@ -598,8 +634,8 @@ __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef,
             for (int iy = (int)yPos - 1; iy <= yEnd; ++iy) {
                 const float tmp = d_fa_b3(yPos - iy) * tX;
                 if (tmp > delta) {
-                    const int o = (it + 1) * lX * lY + (iy + 1) * lX + (ix + 1);
-                    sx += cX[o] * tmp; sy += cY[o] * tmp;
+                    const int o = (it - t0) * nl + (iy + 1) * lX + (ix + 1);
+                    sx += scX[o] * tmp; sy += scY[o] * tmp;
                 }
             }
         }
@@ -655,15 +691,23 @@ void weighted_least_squares(std::vector<double> &A, int rows, int cols, const st
     }
     const int W = cols + 2;
     std::vector<double> M((size_t)cols * W, 0.0);
+    std::vector<int> nz(cols);
     for (int i = 0; i < rows; ++i) {
+        // the rows are sparse (a run of ones in the alignment, 64 spline weights in the fit): the non-zero columns only, upper triangle
         const double *r = &A[(size_t)i * cols];
-        for (int p = 0; p < cols; ++p) {
-            if (r[p] == 0) continue;
-            for (int q = 0; q < cols; ++q) M[(size_t)p * W + q] += r[p] * r[q];
-            M[(size_t)p * W + cols] += r[p] * wbx[i];
-            M[(size_t)p * W + cols + 1] += r[p] * wby[i];
+        int m = 0;
+        for (int p = 0; p < cols; ++p) if (r[p] != 0) nz[m++] = p;
+        for (int a = 0; a < m; ++a) {
+            const int p = nz[a];
+            const double rp = r[p];
+            double *Mp = &M[(size_t)p * W];
+            for (int b = a; b < m; ++b) Mp[nz[b]] += rp * r[nz[b]];
+            Mp[cols] += rp * wbx[i];
+            Mp[cols + 1] += rp * wby[i];
         }
     }
+    for (int p = 0; p < cols; ++p)
+        for (int q = 0; q < p; ++q) M[(size_t)p * W + q] = M[(size_t)q * W + p];
     for (int k = 0; k < cols; ++k) {
         int piv = k;
         for (int r = k + 1; r < cols; ++r) if (std::fabs(M[(size_t)r * W + k]) > std::fabs(M[(size_t)piv * W + k])) piv = r;
@@ -1067,6 +1111,9 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     const float actualScale = (float)CX / (float)PX;
     const int maxDist = (int)(max_shift_px * actualScale);
     XH_CHECK(maxDist >= 0, XH_ERR_ARG, "xh_fa_local_alignment: negative --maxShift");
+    const bool timing = getenv("XH_FA_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tA = now();
     const int nP = patchesX * patchesY, rows = N * (N - 1) / 2;
     std::vector<double> tl;
     fa_patch_layout(N, Y, X, h_gShiftX, h_gShiftY, patchesX, patchesY, PX, PY, tl, h_centers);
@@ -1081,7 +1128,7 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
             offs[((size_t)p * N + f) * 2] = sx; offs[((size_t)p * N + f) * 2 + 1] = sy;
         }
     // tables: pruned forward transforms, low-pass of the correlation size with the 1 / (PX PY) of the transform, inverse twiddles
-    std::vector<fa_cf> Wx((size_t)PX * cxh), Wy((size_t)CY * PY), tabY(CY), tabX(CX);
+    std::vector<fa_cf> Wx((size_t)PX * cxh), Wy((size_t)CY * PY);
     const double twoPi = 6.283185307179586476925286766559;
     for (int x = 0; x < PX; ++x)
         for (int k = 0; k < cxh; ++k) { const double a = -twoPi * (double)(((long long)x * k) % PX) / PX; Wx[(size_t)x * cxh + k] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
@@ -1089,13 +1136,17 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
         const int origY = (iy <= CY / 2) ? iy : (PY - (CY - iy));          // rows 0 .. C/2 from the top, the others from the bottom (scaleFFT2DKernel)
         for (int y = 0; y < PY; ++y) { const double a = -twoPi * (double)(((long long)origY * y) % PY) / PY; Wy[(size_t)iy * PY + y] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
     }
-    for (int k = 0; k < CY; ++k) tabY[k] = fa_cf{(float)std::cos(twoPi * k / CY), (float)std::sin(twoPi * k / CY)};
-    for (int k = 0; k < CX; ++k) tabX[k] = fa_cf{(float)std::cos(twoPi * k / CX), (float)std::sin(twoPi * k / CX)};
     const std::vector<float> filter = fa_make_lpf((double)(h->Ts / actualScale), h->maxRes, CX, CY, 1.0 / ((double)PX * PY));
     const int yHalf = CY / 2, xHalf = CX / 2;
     const int y0 = std::max(0, yHalf - maxDist - 1), y1 = std::min(CY - 1, yHalf + maxDist + 1), wy = y1 - y0 + 1;
     const int x0 = std::max(0, xHalf - maxDist - 1), x1 = std::min(CX - 1, xHalf + maxDist + 1), wx = x1 - x0 + 1;
+    std::vector<fa_cf> tabY((size_t)CY * wy), tabX((size_t)cxh * wx);           // e^{2 pi i ky y / CY}, e^{2 pi i kx x / CX} of the window
+    for (int ky = 0; ky < CY; ++ky)
+        for (int yy = 0; yy < wy; ++yy) { const double a = twoPi * (double)(((long long)ky * (y0 + yy)) % CY) / CY; tabY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    for (int kx = 0; kx < cxh; ++kx)
+        for (int xx = 0; xx < wx; ++xx) { const double a = twoPi * (double)(((long long)kx * (x0 + xx)) % CX) / CX; tabX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
 
+    const double tB = now();
     XhBuf bOffs, bWx, bWy, bTabY, bTabX, bFilter, bPatch, bT, bSingle, bS, bU, bW, bRes;
     auto freeAll = [&]() { XhBuf *all[] = {&bOffs, &bWx, &bWy, &bTabY, &bTabX, &bFilter, &bPatch, &bT, &bSingle, &bS, &bU, &bW, &bRes}; for (XhBuf *q : all) xh_buf_free(*q); };
     const size_t E = (size_t)CY * cxh;
@@ -1112,6 +1163,7 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * cxh);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRes, sizeof(double) * 2 * (size_t)rows * nP);
+    const double tC = now();
     for (int p = 0; p < nP && rc == XH_OK; ++p) {
         const size_t tot = (size_t)N * PY * PX;
         hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p * N * 2,
@@ -1124,30 +1176,45 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
                            (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
         hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)N * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
                            (const float *)bFilter.p, N, E, patchesAvg);
-        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows), dim3(256), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p, (const fa_cf *)bTabX.p, y0, wy,
+        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows), dim3(std::min(256, 64 * ((cxh + 63) / 64))), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p, (const fa_cf *)bTabX.p, y0, wy,
                            x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p + 2 * (size_t)rows * p);
         if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_local_alignment: kernel launch failed"); rc = XH_ERR_HIP; }
     }
     std::vector<double> res(2 * (size_t)rows * nP);
     if (rc == XH_OK && hipMemcpyAsync(res.data(), bRes.p, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
     if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    const double tD = now();
     freeAll();
+    const double tE = now();
     if (rc != XH_OK) { if (rc == XH_ERR_HIP) xh_set_error("xh_fa_local_alignment: device error"); return rc; }
     // computeAlignment (:776-797) per patch: deduct the centre, scale to the movie's pixels, solve, add the rounded global shift
-    std::vector<double> bx(rows), by(rows), lsx(N), lsy(N);
-    for (int p = 0; p < nP; ++p) {
-        for (int r = 0; r < rows; ++r) {
-            bx[r] = (res[2 * ((size_t)rows * p + r)] - CX / 2.0) * ((double)PX / CX);
-            by[r] = (res[2 * ((size_t)rows * p + r) + 1] - CY / 2.0) * ((double)PY / CY);
+    auto solvePatches = [&](int pBegin, int pEnd) {
+        std::vector<double> bx(rows), by(rows), lsx(N), lsy(N);
+        for (int p = pBegin; p < pEnd; ++p) {
+            for (int r = 0; r < rows; ++r) {
+                bx[r] = (res[2 * ((size_t)rows * p + r)] - CX / 2.0) * ((double)PX / CX);
+                by[r] = (res[2 * ((size_t)rows * p + r) + 1] - CY / 2.0) * ((double)PY / CY);
+            }
+            int ref = ref_frame;
+            fa_solve(bx, by, N, 2, ref_frame, lsx.data(), lsy.data(), &ref);
+            for (int t = 0; t < N; ++t) {
+                h_patchShifts[((size_t)p * N + t) * 2] = std::round(h_gShiftX[t]) + lsx[t];
+                h_patchShifts[((size_t)p * N + t) * 2 + 1] = std::round(h_gShiftY[t]) + lsy[t];
+            }
         }
-        int ref = ref_frame;
-        fa_solve(bx, by, N, 2, ref_frame, lsx.data(), lsy.data(), &ref);
-        for (int t = 0; t < N; ++t) {
-            h_patchShifts[((size_t)p * N + t) * 2] = std::round(h_gShiftX[t]) + lsx[t];
-            h_patchShifts[((size_t)p * N + t) * 2 + 1] = std::round(h_gShiftY[t]) + lsy[t];
-        }
+    };
+    {
+        // the patches are independent: a few host threads
+        const int nthr = std::max(1, std::min({nP, 16, (int)std::thread::hardware_concurrency()}));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t) pool.emplace_back(solvePatches, (int)((long long)nP * t / nthr), (int)((long long)nP * (t + 1) / nthr));
+        for (auto &th : pool) th.join();
     }
+    const double tF = now();
     if (h_coeffsX && h_coeffsY) fa_fit_bspline(N, Y, X, nP, h_centers, h_patchShifts, lX, lY, lT, h_coeffsX, h_coeffsY);
+    if (timing)
+        fprintf(stderr, "xh_fa_local_alignment: tables %.1f ms, buffers %.1f ms, device %.1f ms, free %.1f ms, patch solves %.1f ms, spline fit %.1f ms\n", 1e3 * (tB - tA),
+                1e3 * (tC - tB), 1e3 * (tD - tC), 1e3 * (tE - tD), 1e3 * (tF - tE), 1e3 * (now() - tF));
     return XH_OK;
 }
 
@@ -1179,17 +1246,15 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
     XH_TRY(xh_buf_reserve(ctx, h->warpC, sizeof(float) * c.size()));
     XH_HIP(hipMemcpyAsync(h->warpC.p, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(hipStreamSynchronize(ctx->stream));
-    float *coef = (float *)h->work.p, *tmp = coef + (size_t)Y * X;          // the two planes of the transform buffer
+    float *coef = (float *)h->work.p;
     const XhFir F = xh_fir_taps();
-    const size_t nc = (size_t)X * ((Y + XH_FIR_V - 1) / XH_FIR_V), nr = (size_t)Y * ((X + XH_FIR_V - 1) / XH_FIR_V);
-    hipLaunchKernelGGL((k_fa_fir<true>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, tmp, d_initial_sum, Y, X, F);
-    hipLaunchKernelGGL((k_fa_fir<false>), dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)tmp, (const float *)nullptr, (const float *)nullptr, coef,
-                       (float *)nullptr, Y, X, F);
+    const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
+    hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, coef, d_initial_sum, Y, X, tilesX, F);
     if (d_out || d_sum) {
         // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
         const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
         const float tPos = n / hT;
-        hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), 0, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
+        hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), sizeof(float) * 2 * 4 * lX * lY, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
                            (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
     }
     XH_LAUNCH_CHECK();
