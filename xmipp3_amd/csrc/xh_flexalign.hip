@@ -360,13 +360,13 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ 
 //                    (2 maxDist + 3 rows and columns about the centre, not all C x C), first maximum within maxDist, centre of
 //                    mass of the 3 x 3 values around it (computeCorrelations / sFindMax2DAroundCenter / refineLocation)
 __global__ void __launch_bounds__(256) k_fa_gather(const float *__restrict__ frames, const float *__restrict__ dark, const float *__restrict__ gain,
-                                                   const int *__restrict__ offs, float *__restrict__ out, int N, int Y, int X, int PY, int PX)
+                                                   const int *__restrict__ offs, float *__restrict__ out, int N, int nFrames, int Y, int X, int PY, int PX)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)N * PY * PX) return;
-    const int x = (int)(t % PX), y = (int)((t / PX) % PY), f = (int)(t / ((size_t)PX * PY));
+    const int x = (int)(t % PX), y = (int)((t / PX) % PY), f = (int)(t / ((size_t)PX * PY));          // f: (patch of the batch, frame)
     const size_t src = (size_t)(offs[2 * f + 1] + y) * X + offs[2 * f] + x;
-    float v = frames[(size_t)f * Y * X + src];
+    float v = frames[(size_t)(f % nFrames) * Y * X + src];
     if (dark) v -= dark[src];
     if (gain) v *= gain[src];
     out[t] = v;
@@ -436,14 +436,15 @@ __global__ void __launch_bounds__(256) k_fa_gemm(const float *__restrict__ A, si
 }
 
 // S[t] = filter * sum of the single-frame spectra of the frames t - (avg-1)/2 .. t + avg/2
-__global__ void __launch_bounds__(256) k_fa_patch_sum(const fa_cf *__restrict__ single, fa_cf *__restrict__ S, const float *__restrict__ filter, int N, size_t E, int avg)
+__global__ void __launch_bounds__(256) k_fa_patch_sum(const fa_cf *__restrict__ single, fa_cf *__restrict__ S, const float *__restrict__ filter, int N, int nFrames, size_t E, int avg)
 {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= (size_t)N * E) return;
-    const int t = (int)(g / E);
-    const size_t e = g - (size_t)t * E;
+    const int pt = (int)(g / E), t = pt % nFrames;                      // (patch of the batch, frame)
+    const size_t e = g - (size_t)pt * E;
+    const fa_cf *sp = single + (size_t)(pt - t) * E;
     float re = 0.f, im = 0.f;
-    for (int f = max(0, t - ((avg - 1) / 2)); f <= min(N - 1, t + (avg / 2)); ++f) { const fa_cf v = single[(size_t)f * E + e]; re += v.x; im += v.y; }
+    for (int f = max(0, t - ((avg - 1) / 2)); f <= min(nFrames - 1, t + (avg / 2)); ++f) { const fa_cf v = sp[(size_t)f * E + e]; re += v.x; im += v.y; }
     const float w = filter[e];
     S[g] = fa_cf{re * w, im * w};
 }
@@ -465,15 +466,18 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
     int a = 0, rem = blockIdx.x;
     while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
     const int b = a + 1 + rem;
-    const fa_cf *Sa = S + (size_t)a * CY * cxh, *Sb = S + (size_t)b * CY * cxh;
-    fa_cf *U = Uall + (size_t)blockIdx.x * wy * cxh;
-    float *W = Wall + (size_t)blockIdx.x * wy * wx;
+    const size_t pairIdx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;                // blockIdx.y: patch of the batch
+    const fa_cf *Sp = S + (size_t)blockIdx.y * N * CY * cxh;
+    const fa_cf *Sa = Sp + (size_t)a * CY * cxh, *Sb = Sp + (size_t)b * CY * cxh;
+    fa_cf *U = Uall + pairIdx * wy * cxh;
+    float *W = Wall + pairIdx * wy * wx;
     // along y: U[yy][kx] = sum_ky P[ky][kx] e^{2 pi i ky y / CY}
     for (int kx = threadIdx.x; kx < cxh; kx += nt)
         for (int g = 0; g < wy; g += RW) {
             fa_cf acc[RW];
 #pragma unroll
             for (int r = 0; r < RW; ++r) acc[r] = fa_cf{0.f, 0.f};
+#pragma unroll 4
             for (int ky = 0; ky < CY; ++ky) {
                 const fa_cf p = Sa[(size_t)ky * cxh + kx], q = Sb[(size_t)ky * cxh + kx];
                 const float sgn = ((kx + ky) & 1) ? -1.f : 1.f;                      // centres the correlation
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
         sw = (sw == 0) ? 0 : 1.0 / sw;
         posX = slx * sw; posY = sly * sw;
     }
-    out[2 * blockIdx.x] = posX; out[2 * blockIdx.x + 1] = posY;
+    out[2 * pairIdx] = posX; out[2 * pairIdx + 1] = posY;
 }
 
 // ---- B-spline warp: applyBSplineTransform(3, ...) (cuda_gpu_geo_transformer.cpp:186-239) ---------------------------------------
@@ -1156,28 +1160,32 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     if (rc == XH_OK) rc = fa_upload(tabY.data(), bTabY, sizeof(fa_cf) * tabY.size(), ctx);
     if (rc == XH_OK) rc = fa_upload(tabX.data(), bTabX, sizeof(fa_cf) * tabX.size(), ctx);
     if (rc == XH_OK) rc = fa_upload(filter.data(), bFilter, sizeof(float) * filter.size(), ctx);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPatch, sizeof(float) * (size_t)N * PY * PX);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bT, sizeof(fa_cf) * (size_t)N * PY * cxh);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bSingle, sizeof(fa_cf) * (size_t)N * E);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bS, sizeof(fa_cf) * (size_t)N * E);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * cxh);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
+    // PB patches at a time: the pair kernel has one wave per frame pair, and a single patch (780 waves for 40 frames) leaves
+    // most of the device idle
+    const int PB = std::min(nP, 16);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPatch, sizeof(float) * (size_t)PB * N * PY * PX);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bT, sizeof(fa_cf) * (size_t)PB * N * PY * cxh);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bSingle, sizeof(fa_cf) * (size_t)PB * N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bS, sizeof(fa_cf) * (size_t)PB * N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)PB * rows * wy * cxh);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)PB * rows * wy * wx);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRes, sizeof(double) * 2 * (size_t)rows * nP);
     const double tC = now();
-    for (int p = 0; p < nP && rc == XH_OK; ++p) {
-        const size_t tot = (size_t)N * PY * PX;
-        hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p * N * 2,
-                           (float *)bPatch.p, N, Y, X, PY, PX);
-        // along x, all frames at once: [N PY][PX] x [PX][cxh]
-        hipLaunchKernelGGL((k_fa_gemm<false>), dim3((cxh + 31) / 32, (unsigned)(((size_t)N * PY + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p, (size_t)PX,
-                           (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, N * PY, cxh, PX);
+    for (int p0 = 0; p0 < nP && rc == XH_OK; p0 += PB) {
+        const int pb = std::min(PB, nP - p0), nf = pb * N;
+        const size_t tot = (size_t)nf * PY * PX;
+        hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2,
+                           (float *)bPatch.p, nf, N, Y, X, PY, PX);
+        // along x, all frames of all patches of the batch at once: [pb N PY][PX] x [PX][cxh]
+        hipLaunchKernelGGL((k_fa_gemm<false>), dim3((cxh + 31) / 32, (unsigned)(((size_t)nf * PY + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p, (size_t)PX,
+                           (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX);
         // along y, frame by frame: [CY][PY] x [PY][cxh]
-        hipLaunchKernelGGL((k_fa_gemm<true>), dim3((cxh + 31) / 32, (CY + 63) / 64, N), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
+        hipLaunchKernelGGL((k_fa_gemm<true>), dim3((cxh + 31) / 32, (CY + 63) / 64, nf), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
                            (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
-        hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)N * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
-                           (const float *)bFilter.p, N, E, patchesAvg);
-        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows), dim3(std::min(256, 64 * ((cxh + 63) / 64))), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p, (const fa_cf *)bTabX.p, y0, wy,
-                           x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p + 2 * (size_t)rows * p);
+        hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)nf * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
+                           (const float *)bFilter.p, nf, N, E, patchesAvg);
+        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows, pb), dim3(std::min(256, 64 * ((cxh + 63) / 64))), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p,
+                           (const fa_cf *)bTabX.p, y0, wy, x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p + 2 * (size_t)rows * p0);
         if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_local_alignment: kernel launch failed"); rc = XH_ERR_HIP; }
     }
     std::vector<double> res(2 * (size_t)rows * nP);
