@@ -422,6 +422,9 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
                           const double *h_gShiftY, int32_t ref_frame, float max_shift_px, int32_t patches_x, int32_t patches_y,
                           int32_t patch_size_x, int32_t patch_size_y, int32_t patches_avg, int32_t lX, int32_t lY, int32_t lT,
                           double *h_patchShifts, double *h_centers, double *h_coeffsX, double *h_coeffsY, int32_t *h_dims);
+/* CUDAFlexAlignCorrelate<T>::run (reconstruction_cuda/cuda_flexalign_correlate.cpp:95-140): d_frames [N][Y][X] (even sizes) -> h_pos
+ * [N (N-1)/2][2] = (x, y) of the correlation maximum of every pair i < j within max_dist of the centre (X/2, Y/2), refined over 3 x 3 */
+int xh_fa_correlate(xh_ctx *ctx, const float *d_frames, int32_t N, int32_t Y, int32_t X, float max_dist, double *h_pos);
 int xh_fa_local_from_global(xh_fa *h, int32_t N, const double *h_gShiftX, const double *h_gShiftY, int32_t patches_x, int32_t patches_y,
                             int32_t patch_size_x, int32_t patch_size_y, int32_t lX, int32_t lY, int32_t lT, double *h_centers,
                             double *h_coeffsX, double *h_coeffsY);

@@ -427,6 +427,15 @@ def fa_apply_bspline(frame, coeffsX, coeffsY, control_points, N, n):
     return out
 
 
+def fa_correlate(frames, max_dist):
+    """CUDAFlexAlignCorrelate::run on real frames [N, Y, X]: positions (x, y) of the correlation maxima of all pairs i < j."""
+    fr = f64(frames)
+    N, Y, X = fr.shape
+    pos = np.empty((N * (N - 1) // 2, 2))
+    lib().xo_fa_correlate(_dp(fr), N, Y, X, C.c_double(max_dist), _dp(pos))
+    return pos
+
+
 def fa_solve(bX, bY, N, iterations=2):
     bx, by = f64(bX), f64(bY)
     sx, sy = np.empty(N), np.empty(N)

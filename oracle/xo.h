@@ -151,6 +151,7 @@ void xo_fa_bspline_shift(const double *coeffsX, const double *coeffsY, int lX, i
                          double *shiftX, double *shiftY);
 void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int N, int n,
                          double *out);
+void xo_fa_correlate(const double *frames, int N, int Y, int X, double maxDist, double *pos);
 
 /* ---- Fourier reconstruction (RFA) ---------------------------------------- */
 typedef struct {

@@ -1,4 +1,5 @@
-// oracle/xo_flexalign.cpp -- CPU restatement of FlexAlign's GLOBAL alignment. TEST INFRASTRUCTURE ONLY.
+// oracle/xo_flexalign.cpp -- CPU restatement of FlexAlign: the global alignment of the CPU program, the
+// local (patch) alignment, the B-spline fit and the B-spline warp of the CUDA program. TEST INFRASTRUCTURE ONLY.
 //
 //   ProgMovieAlignmentCorrelation<double>::computeGlobalAlignment / loadData / computeShifts
 //       reconstruction/movie_alignment_correlation.cpp:45-157
@@ -6,15 +7,26 @@
 //   findReferenceImage, computeAlignment      reconstruction/movie_alignment_correlation_base.cpp:152-320,399-418
 //   EquationSystemSolver::solve                reconstruction/eq_system_solver.cpp:35-106
 //   bestShift on the correlation matrix        data/filters.cpp:1593-1719 (xo::best_shift_mcorr)
+//   ProgMovieAlignmentCorrelationGPU<T>::computeLocalAlignment, getPatchesLocation, getPatchData, getMovieBorders,
+//   getCorrelationHint, localFromGlobal        reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:124-222,288-456
+//   performFFTAndScale / scaleFFT2DKernel, computeCorrelations, sFindMax2DAroundCenter, refineLocation
+//       reconstruction_cuda/cuda_flexalign_scale.cpp:58-77, cuda_flexalign_correlate.cpp:95-140
+//   BSplineHelper::computeBSplineCoeffs / getShift   reconstruction/bspline_helper.cpp:34-148
+//   GeoTransformer::applyBSplineTransform, applyLocalShiftGeometryKernelMorePixels, interpolatedElementBSpline2D_Degree3*
+//       reconstruction_cuda/cuda_gpu_geo_transformer.cpp:186-239, .cu:140-254, cuda_gpu_multidim_array.cu:236-334
 //
 // Out of the tree (I2PC/xmippCore @ v4, restated from its published source): scaleToSizeFourier (xmipp_fftw.cpp: forward r2c,
 // copy of the rows 0 .. ihalf-1 and of the ihalf-2 last rows, columns 0 .. xsize-1, inverse c2r at the new size),
 // correlation_matrix on two spectra (xmipp_filters: FFT1 conj(FFT2) dSize, inverse, CenterFFT), interpolatedElement1D
 // (linear, 0 outside), weightedLeastSquares (rows scaled by sqrt(w), normal equations), Matrix1D::computeMeanAndStddev
-// (sample standard deviation). PARITY UNPINNED: the reference holds no known answer for this path that runs without CUDA
-// (test_cuda_flexalign_correlate.cpp, test_movie_filter_dose.cpp need a device); the restatement follows the source text and is
-// checked on physics (synthetic movies with known drifts, tests/test_oracle_pins.py).
-// The patch (local) alignment has no CPU form at all in the reference: movie_alignment_correlation.cpp:63-76 throw.
+// (sample standard deviation).
+// PINNED: the pair-correlation stage of the local alignment (xo_fa_correlate) on the known answers of the reference's
+// FlexAlignCorrelateTest (test_cuda_flexalign_correlate.cpp: sizes, maximal distance and 1e-4 tolerance of that test), the warp on
+// the identities GeoTransformerApplyBSplineTransformTest asserts (zero coefficients = identity, zero image stays zero);
+// tests/test_oracle_pins.py. PARITY UNPINNED for the rest: the reference holds no known answer for the global alignment of the
+// CPU program, the patch layout, the Fourier-space reduction or the spline fit (its program tests need a CUDA device and
+// compare against files that are not in the tree); those follow the source text and are checked on physics (synthetic movies
+// with known drift fields).
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -189,6 +201,45 @@ void alignment_from_pairs(const std::vector<double> &bx, const std::vector<doubl
     for (int i = 0; i < N; ++i) total(best, i, shiftX[i], shiftY[i]);
 }
 
+// One frame pair of computeCorrelations (cuda_flexalign_correlate.cpp:95-140; kernels correlate, cuda_gpu_movie_alignment_correlation_kernels.cu;
+// sFindMax2DAroundCenter and refineLocation<3>, cuda_find_extrema.cu / find_extrema.h): F1 conj(F2) (-1)^(x+y) on the half spectra
+// [CY][CX/2+1] (even sizes: the factor centres the correlation), c2r, first maximum in raster order within maxDist of
+// (CX/2, CY/2), centre of mass of the 3 x 3 window with values relative to the maximum. Position in pixels of the map.
+void correlate_pair(const cd *F1, const cd *F2, int CY, int CX, int maxDist, std::vector<double> &prod, std::vector<double> &corr, double &posX, double &posY)
+{
+    const int cxh = CX / 2 + 1;
+    cd *P = reinterpret_cast<cd *>(prod.data());
+    for (int iy = 0; iy < CY; ++iy)
+        for (int ix = 0; ix < cxh; ++ix) {
+            const double a = 1 - 2 * ((ix + iy) & 1);
+            P[(size_t)iy * cxh + ix] = F1[(size_t)iy * cxh + ix] * std::conj(F2[(size_t)iy * cxh + ix]) * a;
+        }
+    xo_fft2d_c2r(prod.data(), CY, CX, corr.data());
+    const int xHalf = CX / 2, yHalf = CY / 2;
+    double best = -1.79769313486231570815e+308;
+    int pos = -1;
+    for (int y = std::max(0, yHalf - maxDist); y <= std::min(CY - 1, yHalf + maxDist); ++y)
+        for (int x = std::max(0, xHalf - maxDist); x <= std::min(CX - 1, xHalf + maxDist); ++x) {
+            const int ly = y - yHalf, lx = x - xHalf;
+            if (ly * ly + lx * lx > maxDist * maxDist) continue;
+            if (corr[(size_t)y * CX + x] > best) { best = corr[(size_t)y * CX + x]; pos = y * CX + x; }
+        }
+    posX = posY = 0;
+    if (pos >= 0) {
+        const int refY = pos / CX, refX = pos % CX;
+        double refVal = corr[pos];
+        refVal = (refVal == 0) ? 0 : 1.0 / refVal;
+        double sw = 0, slx = 0, sly = 0;
+        for (int y = std::max(0, refY - 1); y <= std::min(CY - 1, refY + 1); ++y)
+            for (int x = std::max(0, refX - 1); x <= std::min(CX - 1, refX + 1); ++x) {
+                const double rel = corr[(size_t)y * CX + x] * refVal;
+                sw += rel; slx += x * rel; sly += y * rel;
+            }
+        sw = (sw == 0) ? 0 : 1.0 / sw;
+        posX = slx * sw; posY = sly * sw;
+    }
+}
+
 // Bspline03 (xmippCore numerical tools): the cubic B-spline
 double bspline03(double x)
 {
@@ -353,39 +404,8 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
             int idx = 0;
             for (int i = 0; i < N - 1; ++i)
                 for (int j = i + 1; j < N; ++j, ++idx) {
-                    const cd *F1 = reinterpret_cast<const cd *>(S[i].data()), *F2 = reinterpret_cast<const cd *>(S[j].data());
-                    cd *P = reinterpret_cast<cd *>(prod.data());
-                    for (int iy = 0; iy < CY; ++iy)
-                        for (int ix = 0; ix < cxh; ++ix) {
-                            const double a = 1 - 2 * ((ix + iy) & 1);          // centres the correlation (even sizes)
-                            P[(size_t)iy * cxh + ix] = F1[(size_t)iy * cxh + ix] * std::conj(F2[(size_t)iy * cxh + ix]) * a;
-                        }
-                    xo_fft2d_c2r(prod.data(), CY, CX, corr.data());
-                    // sFindMax2DAroundCenter: first maximum in raster order within maxDist of (C/2, C/2)
-                    const int xHalf = CX / 2, yHalf = CY / 2;
-                    double best = -1.79769313486231570815e+308;
-                    int pos = -1;
-                    for (int y = std::max(0, yHalf - maxDist); y <= std::min(CY - 1, yHalf + maxDist); ++y)
-                        for (int x = std::max(0, xHalf - maxDist); x <= std::min(CX - 1, xHalf + maxDist); ++x) {
-                            const int ly = y - yHalf, lx = x - xHalf;
-                            if (ly * ly + lx * lx > maxDist * maxDist) continue;
-                            if (corr[(size_t)y * CX + x] > best) { best = corr[(size_t)y * CX + x]; pos = y * CX + x; }
-                        }
-                    // refineLocation<3>: centre of mass of the 3 x 3 window, values relative to the maximum
-                    double posX = 0, posY = 0;
-                    if (pos >= 0) {
-                        const int refY = pos / CX, refX = pos % CX;
-                        double refVal = corr[pos];
-                        refVal = (refVal == 0) ? 0 : 1.0 / refVal;
-                        double sw = 0, slx = 0, sly = 0;
-                        for (int y = std::max(0, refY - 1); y <= std::min(CY - 1, refY + 1); ++y)
-                            for (int x = std::max(0, refX - 1); x <= std::min(CX - 1, refX + 1); ++x) {
-                                const double rel = corr[(size_t)y * CX + x] * refVal;
-                                sw += rel; slx += x * rel; sly += y * rel;
-                            }
-                        sw = (sw == 0) ? 0 : 1.0 / sw;
-                        posX = slx * sw; posY = sly * sw;
-                    }
+                    double posX, posY;
+                    correlate_pair(reinterpret_cast<const cd *>(S[i].data()), reinterpret_cast<const cd *>(S[j].data()), CY, CX, maxDist, prod, corr, posX, posY);
                     // computeAlignment (:776-797): deduct the centre, scale to the patch's pixels
                     bx[idx] = (posX - CX / 2.0) * ((double)PX / CX);
                     by[idx] = (posY - CY / 2.0) * ((double)PY / CY);
@@ -465,6 +485,21 @@ void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffs
             xo_fa_bspline_shift(coeffsX, coeffsY, lX, lY, lT, X, Y, N, x, y, n, &sx, &sy);
             out[(size_t)y * X + x] = xo::interp2d(coef.data(), Y, X, 0, 0, x - sx, y - sy);
         }
+}
+
+// CUDAFlexAlignCorrelate<T>::run (cuda_flexalign_correlate.cpp:95-140) on N real frames [N][Y][X] (even sizes): the position of
+// the correlation maximum of every pair (i, j), i < j, in pixels of the map -- pos [N(N-1)/2][2] = (x, y). Known answers:
+// FlexAlignCorrelateTest (applications/tests/function_tests/test_cuda_flexalign_correlate.cpp:23-70).
+void xo_fa_correlate(const double *frames, int N, int Y, int X, double maxDist, double *pos)
+{
+    const int xh = X / 2 + 1;
+    std::vector<std::vector<double>> F(N, std::vector<double>((size_t)Y * xh * 2));
+    for (int n = 0; n < N; ++n) xo_fft2d_r2c(frames + (size_t)n * Y * X, Y, X, F[n].data());
+    std::vector<double> prod((size_t)Y * xh * 2), corr((size_t)Y * X);
+    int idx = 0;
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j, ++idx)
+            correlate_pair(reinterpret_cast<const cd *>(F[i].data()), reinterpret_cast<const cd *>(F[j].data()), Y, X, (int)maxDist, prod, corr, pos[2 * idx], pos[2 * idx + 1]);
 }
 
 }  // extern "C"

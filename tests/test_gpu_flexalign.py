@@ -188,3 +188,44 @@ def test_local_alignment_improves_a_movie_with_a_drift_field(gpu):
     c = {k: np.corrcoef(s[64:-64, 64:-64].ravel(), clean[64:-64, 64:-64].ravel())[0, 1] for k, s in sums.items()}
     print("correlation of the aligned sum with the clean field:", c)
     assert c["local"] > 0.99 and (1 - c["local"]) < 0.5 * (1 - c["global"])
+
+
+@pytest.mark.parametrize("x,y,n", [(42, 24, 10), (24, 42, 10), (36, 86, 17)])
+def test_correlate_known_answers_of_the_reference(gpu, oracle, x, y, n):
+    """FlexAlignCorrelateTest of the reference (test_cuda_flexalign_correlate.cpp): frame k = one point at (x/2 + k, y/2 + k); pair
+    (i, j) correlates at (i - j, i - j) from the centre to 1e-4 -- the reference's sizes, its maximal distance, its tolerance --
+    and the device agrees with the oracle on random frames."""
+    xa, ctx, torch = gpu
+    fr = np.zeros((n, y, x), np.float32)
+    for k in range(n):
+        fr[k, k + y // 2, x // 2 + k] = 1
+    pos = xa.fa_correlate(ctx, torch.from_numpy(fr).cuda(), np.sqrt(2.0 * n * n))
+    idx = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert abs(pos[idx, 0] - x / 2 - (i - j)) <= 1e-4 and abs(pos[idx, 1] - y / 2 - (i - j)) <= 1e-4
+            idx += 1
+    rng = np.random.default_rng(x)
+    from scipy import ndimage
+    fr = np.stack([ndimage.shift(ndimage.gaussian_filter(rng.standard_normal((y, x)), 1.5), (0.3 * k, -0.4 * k), mode="wrap") for k in range(6)]).astype(np.float32)
+    got = xa.fa_correlate(ctx, torch.from_numpy(fr).cuda(), 8.0)
+    exp = oracle.fa_correlate(fr, 8.0)
+    assert np.abs(got - exp).max() <= 1e-3
+
+
+def test_bspline_warp_identities_of_the_reference(gpu):
+    """GeoTransformerApplyBSplineTransformTest (test_cuda_geo_transformer_apply_bspline_transform.cpp:107-147): zero coefficients
+    leave a random 259 x 311 image unchanged (to the reference's 1e-5 for float), a zero image stays zero under random
+    coefficients."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(13)
+    img = torch.from_numpy(rng.uniform(-1, 1, (311, 259)).astype(np.float32)).cuda()
+    fa = xa.FlexAlign(ctx, 311, 259, 1.0, 8.0)
+    out = torch.empty_like(img)
+    fa.apply_bspline(img, np.zeros(27), np.zeros(27), (3, 3, 3), 1, 0, out=out)
+    assert (out - img).abs().max().item() <= 1e-5
+    fa2 = xa.FlexAlign(ctx, 148, 148, 1.0, 8.0)
+    z = torch.zeros((148, 148), device="cuda")
+    out2 = torch.ones_like(z)
+    fa2.apply_bspline(z, rng.uniform(-10, 10, 120), rng.uniform(-10, 10, 120), (6, 5, 4), 4, 0, out=out2)
+    assert out2.abs().max().item() == 0

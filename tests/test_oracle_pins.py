@@ -319,3 +319,33 @@ def test_flexalign_local_alignment_recovers_a_known_field(oracle):
     w0 = oracle.fa_apply_bspline(frames[ref], loc["coeffsX"], loc["coeffsY"], cp, N, ref)
     c = lambda a, b: np.corrcoef(a[40:-40, 40:-40].ravel(), b[40:-40, 40:-40].ravel())[0, 1]
     assert c(frames[n], frames[ref]) < 0.75 < 0.8 < c(w, w0)
+
+
+@pytest.mark.parametrize("x,y,n", [(42, 24, 10), (24, 42, 10), (36, 86, 17)])
+def test_flexalign_correlate_known_answers(oracle, x, y, n):
+    """PINNED: FlexAlignCorrelateTest (applications/tests/function_tests/test_cuda_flexalign_correlate.cpp:17-70,118-140): frame k
+    holds one point at (x/2 + k, y/2 + k); the correlation maximum of the pair (i, j) lies at (i - j, i - j) from the centre,
+    to 1e-4, for the reference's three sizes (Dimensions(42, 24, 1, 10), (24, 42, 1, 10), (36, 86, 1, 17)) and its maximal
+    distance sqrt(2 n^2). This fixes the sign of the pair shifts, the centring by (-1)^(x+y) and the 3 x 3 refinement of the
+    stage the local alignment is built on."""
+    fr = np.zeros((n, y, x))
+    for k in range(n):
+        fr[k, k + y // 2, x // 2 + k] = 1
+    pos = oracle.fa_correlate(fr, np.sqrt(2.0 * n * n))
+    idx = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert abs(pos[idx, 0] - x / 2 - (i - j)) <= 1e-4 and abs(pos[idx, 1] - y / 2 - (i - j)) <= 1e-4
+            idx += 1
+
+
+def test_bspline_warp_identities(oracle):
+    """PINNED on the properties GeoTransformerApplyBSplineTransformTest asserts (test_cuda_geo_transformer_apply_bspline_transform.cpp:
+    107-147): zero coefficients leave a random image of 259 x 311 unchanged (prefilter, then interpolation at the pixel itself),
+    and a zero image stays zero under random coefficients of (6, 5, 4) control points."""
+    rng = np.random.default_rng(13)
+    img = rng.uniform(-1, 1, (311, 259))
+    out = oracle.fa_apply_bspline(img, np.zeros(27), np.zeros(27), (3, 3, 3), 1, 0)
+    assert np.abs(out - img).max() <= 1e-12
+    z = oracle.fa_apply_bspline(np.zeros((147, 147)), rng.uniform(-10, 10, 120), rng.uniform(-10, 10, 120), (6, 5, 4), 4, 0)
+    assert np.abs(z).max() == 0

@@ -502,6 +502,17 @@ class FlexAlign:
         return out
 
 
+def fa_correlate(ctx, frames, max_dist):
+    """CUDAFlexAlignCorrelate::run: frames [N, Y, X] float32 on the device (even sizes) -> positions [N (N-1)/2, 2] (x, y) of the
+    correlation maxima of all pairs i < j."""
+    torch = _torch()
+    assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and frames.dim() == 3
+    N, Y, X = frames.shape
+    pos = np.empty((N * (N - 1) // 2, 2))
+    check(lib().xh_fa_correlate(ctx.h, _ptr(frames), N, Y, X, float(max_dist), _np_ptr(pos)))
+    return pos
+
+
 class CtfOps:
     """CTF pre-steps on the device: actualPhaseFlip (reconstruction/ctf_phase_flip.cpp:88-117) and
     Wiener2D::applyWienerFilter (data/wiener2d.cpp:101-141) for images of one size."""

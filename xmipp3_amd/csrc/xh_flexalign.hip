@@ -1226,6 +1226,58 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     return XH_OK;
 }
 
+// CUDAFlexAlignCorrelate<T>::run (reconstruction_cuda/cuda_flexalign_correlate.cpp:95-140) on its own: N real frames [N][Y][X]
+// (even sizes) -> the position of the correlation maximum of every pair i < j in pixels of the map (centre = (X/2, Y/2)), the
+// stage of the local alignment between the patch spectra and the solver, without crop and filter. The reference tests this
+// stage alone (test_cuda_flexalign_correlate.cpp), so it is callable alone here too.
+int xh_fa_correlate(xh_ctx *ctx, const float *d_frames, int32_t N, int32_t Y, int32_t X, float max_dist, double *h_pos)
+{
+    XH_CHECK(ctx && d_frames && h_pos && N >= 2 && Y >= 4 && X >= 4 && (Y & 1) == 0 && (X & 1) == 0 && max_dist >= 0, XH_ERR_ARG,
+             "xh_fa_correlate: bad argument (even frame sizes, at least two frames)");
+    XH_HIP(hipSetDevice(ctx->device));
+    const int xh = X / 2 + 1, rows = N * (N - 1) / 2, maxDist = (int)max_dist;
+    const double twoPi = 6.283185307179586476925286766559;
+    std::vector<fa_cf> Wx((size_t)X * xh), Wy((size_t)Y * Y);
+    for (int x = 0; x < X; ++x)
+        for (int k = 0; k < xh; ++k) { const double a = -twoPi * (double)(((long long)x * k) % X) / X; Wx[(size_t)x * xh + k] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    for (int k = 0; k < Y; ++k)
+        for (int y = 0; y < Y; ++y) { const double a = -twoPi * (double)(((long long)k * y) % Y) / Y; Wy[(size_t)k * Y + y] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    const int yHalf = Y / 2, xHalf = X / 2;
+    const int y0 = std::max(0, yHalf - maxDist - 1), y1 = std::min(Y - 1, yHalf + maxDist + 1), wy = y1 - y0 + 1;
+    const int x0 = std::max(0, xHalf - maxDist - 1), x1 = std::min(X - 1, xHalf + maxDist + 1), wx = x1 - x0 + 1;
+    std::vector<fa_cf> tabY((size_t)Y * wy), tabX((size_t)xh * wx);
+    for (int ky = 0; ky < Y; ++ky)
+        for (int yy = 0; yy < wy; ++yy) { const double a = twoPi * (double)(((long long)ky * (y0 + yy)) % Y) / Y; tabY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    for (int kx = 0; kx < xh; ++kx)
+        for (int xx = 0; xx < wx; ++xx) { const double a = twoPi * (double)(((long long)kx * (x0 + xx)) % X) / X; tabX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+    XhBuf bWx, bWy, bTabY, bTabX, bT, bS, bU, bW, bRes;
+    auto freeAll = [&]() { XhBuf *all[] = {&bWx, &bWy, &bTabY, &bTabX, &bT, &bS, &bU, &bW, &bRes}; for (XhBuf *q : all) xh_buf_free(*q); };
+    const size_t E = (size_t)Y * xh;
+    int rc = fa_upload(Wx.data(), bWx, sizeof(fa_cf) * Wx.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(Wy.data(), bWy, sizeof(fa_cf) * Wy.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(tabY.data(), bTabY, sizeof(fa_cf) * tabY.size(), ctx);
+    if (rc == XH_OK) rc = fa_upload(tabX.data(), bTabX, sizeof(fa_cf) * tabX.size(), ctx);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bT, sizeof(fa_cf) * (size_t)N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bS, sizeof(fa_cf) * (size_t)N * E);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * xh);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRes, sizeof(double) * 2 * (size_t)rows);
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL((k_fa_gemm<false>), dim3((xh + 31) / 32, (unsigned)(((size_t)N * Y + 63) / 64), 1), dim3(256), 0, ctx->stream, d_frames, (size_t)X, (size_t)0,
+                           (const fa_cf *)bWx.p, (size_t)xh, (size_t)0, (fa_cf *)bT.p, (size_t)xh, (size_t)0, N * Y, xh, X);
+        hipLaunchKernelGGL((k_fa_gemm<true>), dim3((xh + 31) / 32, (Y + 63) / 64, N), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)Y, (size_t)0, (const fa_cf *)bT.p,
+                           (size_t)xh, E, (fa_cf *)bS.p, (size_t)xh, E, Y, xh, Y);
+        hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows, 1), dim3(std::min(256, 64 * ((xh + 63) / 64))), 0, ctx->stream, (const fa_cf *)bS.p, N, Y, X, (const fa_cf *)bTabY.p,
+                           (const fa_cf *)bTabX.p, y0, wy, x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p);
+        if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
+    }
+    if (rc == XH_OK && hipMemcpyAsync(h_pos, bRes.p, sizeof(double) * 2 * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    freeAll();
+    if (rc == XH_ERR_HIP) xh_set_error("xh_fa_correlate: device error");
+    return rc;
+}
+
 // localFromGlobal (movie_alignment_correlation_gpu.cpp:432-456): the B-spline of a movie aligned globally only -- every patch
 // carries the global shift of its frame
 int xh_fa_local_from_global(xh_fa *h, int32_t N, const double *h_gShiftX, const double *h_gShiftY, int32_t patchesX, int32_t patchesY, int32_t patchSizeX,
