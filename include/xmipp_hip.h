@@ -432,6 +432,12 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
                         const double *h_coeffsY, int32_t lX, int32_t lY, int32_t lT, int32_t N, int32_t n, float *d_out, float *d_sum,
                         float *d_initial_sum);
 
+/* ProgMovieFilterDose::applyDoseFilterToImage between the two transforms of a frame (reconstruction/movie_filter_dose.cpp:85-170,
+ * 283-287): d_frame [Y][X] in place; plan = xh_fft2d_create(ctx, Y, X); acc_voltage 200 or 300 kV (anything else is refused like
+ * initVoltage does); dose_start / dose_finish = n / (n + 1) x dosePerFrame + preExposure of frame n. */
+int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y, int32_t X, double pixel_size, double acc_voltage,
+                         double dose_start, double dose_finish);
+
 #ifdef __cplusplus
 }
 #endif

@@ -427,6 +427,26 @@ def fa_apply_bspline(frame, coeffsX, coeffsY, control_points, N, n):
     return out
 
 
+def dose_filter_frame(frame, pixel_size, acc_voltage, dose_start, dose_finish):
+    """One frame through ProgMovieFilterDose's filter."""
+    L = lib()
+    L.xo_dose_voltage_scaling.restype = C.c_double
+    vs = L.xo_dose_voltage_scaling(C.c_double(acc_voltage))
+    if vs < 0:
+        raise ValueError("Bad acceleration voltage (must be 200 or 300 kV")
+    out = f64(frame).copy()
+    L.xo_dose_filter_frame(_dp(out), out.shape[0], out.shape[1], C.c_double(pixel_size), C.c_double(vs), C.c_double(dose_start), C.c_double(dose_finish))
+    return out
+
+
+def dose_scalars():
+    L = lib()
+    for n in ("xo_dose_voltage_scaling", "xo_dose_filter", "xo_dose_critical", "xo_dose_optimal"):
+        getattr(L, n).restype = C.c_double
+    return (lambda v: L.xo_dose_voltage_scaling(C.c_double(v)), lambda d, c: L.xo_dose_filter(C.c_double(d), C.c_double(c)),
+            lambda f, s: L.xo_dose_critical(C.c_double(f), C.c_double(s)), lambda c: L.xo_dose_optimal(C.c_double(c)))
+
+
 def fa_correlate(frames, max_dist):
     """CUDAFlexAlignCorrelate::run on real frames [N, Y, X]: positions (x, y) of the correlation maxima of all pairs i < j."""
     fr = f64(frames)

@@ -151,6 +151,11 @@ void xo_fa_bspline_shift(const double *coeffsX, const double *coeffsY, int lX, i
                          double *shiftX, double *shiftY);
 void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int N, int n,
                          double *out);
+double xo_dose_voltage_scaling(double accelerationVoltage);
+double xo_dose_filter(double dose_at_end_of_frame, double critical_dose);
+double xo_dose_critical(double spatial_frequency, double voltage_scaling_factor);
+double xo_dose_optimal(double critical_dose);
+void xo_dose_filter_frame(double *frame, int Y, int X, double pixel_size, double voltage_scaling_factor, double dose_start, double dose_finish);
 void xo_fa_correlate(const double *frames, int N, int Y, int X, double maxDist, double *pos);
 
 /* ---- Fourier reconstruction (RFA) ---------------------------------------- */

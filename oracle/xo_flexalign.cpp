@@ -502,4 +502,40 @@ void xo_fa_correlate(const double *frames, int N, int Y, int X, double maxDist, 
             correlate_pair(reinterpret_cast<const cd *>(F[i].data()), reinterpret_cast<const cd *>(F[j].data()), Y, X, (int)maxDist, prod, corr, pos[2 * idx], pos[2 * idx + 1]);
 }
 
+// ProgMovieFilterDose (reconstruction/movie_filter_dose.cpp:85-170; the critical-dose curve of summovie): scalar pieces and one
+// frame. PINNED on MovieFilterDoseTest (applications/tests/function_tests/test_movie_filter_dose.cpp:15-90).
+double xo_dose_voltage_scaling(double accelerationVoltage)
+{
+    if (accelerationVoltage < 301 && accelerationVoltage > 299.) return 1.0;
+    if (accelerationVoltage < 201.0 && accelerationVoltage > 199.0) return 0.8;
+    return -1.0;                                   // "Bad acceleration voltage (must be 200 or 300 kV"
+}
+double xo_dose_filter(double dose_at_end_of_frame, double critical_dose) { return std::exp((-0.5 * dose_at_end_of_frame) / critical_dose); }
+double xo_dose_critical(double spatial_frequency, double voltage_scaling_factor)
+{
+    return ((0.24499 * std::pow(spatial_frequency, -1.6649)) + 2.8141) * voltage_scaling_factor;
+}
+double xo_dose_optimal(double critical_dose) { return 2.51284 * critical_dose; }
+
+// applyDoseFilterToImage (:115-170) between FourierTransform and inverseFourierTransform of one frame [Y][X]
+void xo_dose_filter_frame(double *frame, int Y, int X, double pixel_size, double voltage_scaling_factor, double dose_start, double dose_finish)
+{
+    const int xh = X / 2 + 1;
+    std::vector<double> F((size_t)Y * xh * 2);
+    xo_fft2d_r2c(frame, Y, X, F.data());
+    cd *P = reinterpret_cast<cd *>(F.data());
+    const double dc = 1.79769313486231570815e+308 * 0.001;
+    for (int i = 0; i < Y; ++i) {
+        const double y = xo_fft_idx2digfreq(i, Y), yy = y * y;
+        for (int j = 0; j < xh; ++j) {
+            const double x = xo_fft_idx2digfreq(j, X);
+            const double crit = (i == 0 && j == 0) ? dc : xo_dose_critical(std::sqrt(x * x + yy) / pixel_size, voltage_scaling_factor);
+            const double opt = xo_dose_optimal(crit);
+            if (std::fabs(dose_finish - opt) < std::fabs(dose_start - opt)) P[(size_t)i * xh + j] *= xo_dose_filter(dose_finish, crit);
+            else P[(size_t)i * xh + j] = cd(0, 0);
+        }
+    }
+    xo_fft2d_c2r(F.data(), Y, X, frame);               // (xo_fft2d_r2c divides by Y X like FourierTransform, the inverse does not)
+}
+
 }  // extern "C"

@@ -25,7 +25,7 @@ def _run(args, **kw):
 
 def test_help_and_argument_errors(bins):
     for prog in ("xmipp_angular_projection_matching", "xmipp_reconstruct_fourier_accel", "xmipp_reconstruct_fourier",
-                 "xmipp_angular_project_library", "xmipp_resolution_fsc", "xmipp_ctf_phase_flip", "xmipp_ctf_correct_wiener2d", "xmipp_movie_alignment_correlation"):
+                 "xmipp_angular_project_library", "xmipp_resolution_fsc", "xmipp_ctf_phase_flip", "xmipp_ctf_correct_wiener2d", "xmipp_movie_alignment_correlation", "xmipp_movie_filter_dose"):
         r = _run([os.path.join(bins, prog), "--help"])
         assert r.returncode == 0 and "USAGE" in r.stderr
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-o", "x.xmd"])
@@ -627,3 +627,26 @@ def test_cli_movie_local_alignment(bins, tmp_path, oracle):
     assert cc(avg2) > cc(frames[2:7].mean(0)) + 0.01 and cc(avg) > cc(avg2) - 0.01
     labels2, _ = xmipp_io.read_xmd(str(tmp_path / "out2.xmd"), block="frameShifts")
     assert "shiftX" in labels2
+
+
+@pytest.mark.gpu
+def test_cli_movie_filter_dose(bins, tmp_path, oracle):
+    """xmipp_movie_filter_dose (reconstruction/movie_filter_dose.cpp:36-290): every frame of the range filtered with the doses of its
+    place in the movie (frame n: n x dose + pre-exposure .. (n + 1) x dose + pre-exposure), written at its place in the output stack;
+    the oracle's frames to 1e-5 of the frame's range (fp32 transforms); a voltage other than 200 / 300 kV is refused."""
+    rng = np.random.default_rng(4)
+    N, Y, X = 5, 96, 120
+    frames = rng.standard_normal((N, Y, X)).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    prog = os.path.join(bins, "xmipp_movie_filter_dose")
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "out.stk"), "--sampling", "1.3", "--dosePerFrame", "3.5", "--accVoltage", "200",
+              "--preExposure", "1", "--frameRange", "1", "3"])
+    assert r.returncode == 0, r.stderr
+    out = xmipp_io.read_stack(str(tmp_path / "out.stk"))
+    assert out.shape == (4, Y, X) and np.abs(out[0]).max() == 0
+    for n in (1, 2, 3):
+        exp = oracle.dose_filter_frame(frames[n], 1.3, 200, n * 3.5 + 1, (n + 1) * 3.5 + 1)
+        assert np.abs(out[n] - exp).max() <= 1e-5 * np.abs(exp).max() + 1e-6
+        assert np.abs(exp - frames[n]).max() > 0.1                    # the filter does something
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.stk"), "--accVoltage", "250"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "acceleration voltage" in r.stderr

@@ -229,3 +229,19 @@ def test_bspline_warp_identities_of_the_reference(gpu):
     out2 = torch.ones_like(z)
     fa2.apply_bspline(z, rng.uniform(-10, 10, 120), rng.uniform(-10, 10, 120), (6, 5, 4), 4, 0, out=out2)
     assert out2.abs().max().item() == 0
+
+
+@pytest.mark.parametrize("Y,X", [(128, 160), (90, 150)])
+def test_dose_filter_against_the_oracle(gpu, oracle, Y, X):
+    """ProgMovieFilterDose on one frame: fp32 transforms against the oracle's double ones, 1e-5 of the frame's range; late frames lose
+    their high frequencies altogether (the branch that zeroes a coefficient)."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(Y)
+    fr = rng.standard_normal((Y, X)).astype(np.float32)
+    fft = xa.Fft2D(ctx, Y, X)
+    for n, dose in ((0, 2.0), (7, 2.0), (30, 1.5)):
+        got = xa.movie_dose_filter(fft, torch.from_numpy(fr).cuda(), 1.1, 300, n * dose + 0.5, (n + 1) * dose + 0.5).cpu().numpy()
+        exp = oracle.dose_filter_frame(fr, 1.1, 300, n * dose + 0.5, (n + 1) * dose + 0.5)
+        assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max() + 1e-6
+    with pytest.raises(xa.XhError):
+        xa.movie_dose_filter(fft, torch.from_numpy(fr).cuda(), 1.1, 120, 0.0, 2.0)

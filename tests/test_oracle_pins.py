@@ -349,3 +349,21 @@ def test_bspline_warp_identities(oracle):
     assert np.abs(out - img).max() <= 1e-12
     z = oracle.fa_apply_bspline(np.zeros((147, 147)), rng.uniform(-10, 10, 120), rng.uniform(-10, 10, 120), (6, 5, 4), 4, 0)
     assert np.abs(z).max() == 0
+
+
+def test_movie_filter_dose_known_answers(oracle):
+    """PINNED: MovieFilterDoseTest (applications/tests/function_tests/test_movie_filter_dose.cpp:15-90), every value of it:
+    doseFilter, the voltage scaling factors, criticalDose, optimalDoseGivenCriticalDose (EXPECT_FLOAT_EQ = 4 float ulps)."""
+    vs, dose_filter, critical, optimal = oracle.dose_scalars()
+    feq = lambda a, b: abs(np.float32(a) - np.float32(b)) <= 4 * np.spacing(np.float32(b))
+    assert feq(dose_filter(4.0, 412084.3), 0.9999952) and feq(dose_filter(4.0, 12.82717), 0.8556285)
+    assert vs(300) == 1.0 and vs(200) == 0.8 and vs(250) < 0
+    assert int(critical(1.8219448E-04, 1.0)) == int(412084.3) and feq(critical(0.3587903, 1.0), 4.163977)
+    assert feq(optimal(38.49693), 96.73663)
+    # and the frame filter: linear, removes the mean (the "infinite" critical dose at the origin makes both distances to the optimal
+    # dose equal, so the origin is zeroed: "It forces the origin to 0", movie_filter_dose.cpp:152-156) and damps the rest
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal((40, 56)), rng.standard_normal((40, 56))
+    f = lambda v: oracle.dose_filter_frame(v, 1.0, 300, 2.0, 4.0)
+    assert np.abs(f(a + 2 * b) - f(a) - 2 * f(b)).max() < 1e-12
+    assert abs(f(a).mean()) < 1e-12 and f(a).std() < a.std()

@@ -91,6 +91,7 @@ SIGNATURES = {
     "xh_fa_last_full_pairs": (C.c_int, [vp]),
     "xh_fa_global_alignment": (C.c_int, [vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, C.POINTER(i32)]),
     "xh_fa_local_alignment": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "xh_movie_dose_filter": (C.c_int, [vp, vp, vp, i32, i32, d, d, d, d]),
     "xh_fa_correlate": (C.c_int, [vp, vp, i32, i32, i32, C.c_float, vp]),
     "xh_fa_local_from_global": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "xh_fa_apply_bspline": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -502,6 +502,14 @@ class FlexAlign:
         return out
 
 
+def movie_dose_filter(fft, frame, pixel_size, acc_voltage, dose_start, dose_finish):
+    """ProgMovieFilterDose on one frame ([Y, X] float32 on the device, in place); fft = Fft2D(ctx, Y, X)."""
+    torch = _torch()
+    assert frame.is_cuda and frame.dtype == torch.float32 and frame.is_contiguous() and tuple(frame.shape) == (fft.ny, fft.nx)
+    check(lib().xh_movie_dose_filter(fft.ctx.h, fft.h, _ptr(frame), fft.ny, fft.nx, float(pixel_size), float(acc_voltage), float(dose_start), float(dose_finish)))
+    return frame
+
+
 def fa_correlate(ctx, frames, max_dist):
     """CUDAFlexAlignCorrelate::run: frames [N, Y, X] float32 on the device (even sizes) -> positions [N (N-1)/2, 2] (x, y) of the
     correlation maxima of all pairs i < j."""

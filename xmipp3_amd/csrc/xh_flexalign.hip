@@ -1321,4 +1321,66 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
     return XH_OK;
 }
 
+// ---- dose weighting of movie frames: ProgMovieFilterDose (reconstruction/movie_filter_dose.cpp:85-170, 283) -----------------------
+}  // extern "C"
+
+namespace {
+// applyDoseFilterToImage on the full spectrum of a real frame (the filter depends on the squared frequencies only): critical
+// dose of the spatial frequency (summovie's curve), the frame contributes where its final dose is nearer the optimal dose than
+// its initial dose, attenuated by exp(-dose / (2 critical dose))
+__global__ void __launch_bounds__(256) k_dose_apply(fa_cf *__restrict__ F, int Y, int X, double pixel_size, double vscale, double dose_start, double dose_finish)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)Y * X) return;
+    const int i = (int)(t / X), j = (int)(t - (size_t)i * X);
+    const double y = (i <= Y / 2 ? (double)i : (double)(i - Y)) * (1.0 / Y), x = (j <= X / 2 ? (double)j : (double)(j - X)) * (1.0 / X);
+    double crit;
+    if (i == 0 && j == 0) crit = 1.79769313486231570815e+308 * 0.001;
+    else crit = ((0.24499 * pow(sqrt(x * x + y * y) / pixel_size, -1.6649)) + 2.8141) * vscale;
+    const double opt = 2.51284 * crit;
+    fa_cf v = F[t];
+    if (fabs(dose_finish - opt) < fabs(dose_start - opt)) {
+        const double f = exp((-0.5 * dose_finish) / crit);
+        v = fa_cf{(float)(v.x * f), (float)(v.y * f)};
+    } else v = fa_cf{0.f, 0.f};
+    F[t] = v;
+}
+
+__global__ void __launch_bounds__(256) k_dose_store(const fa_cf *__restrict__ F, float *__restrict__ out, size_t tot)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < tot) out[t] = F[t].x;
+}
+}  // namespace
+
+extern "C" {
+
+int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y, int32_t X, double pixel_size, double acc_voltage, double dose_start,
+                         double dose_finish)
+{
+    XH_CHECK(ctx && plan && d_frame && Y >= 2 && X >= 2 && pixel_size > 0, XH_ERR_ARG, "xh_movie_dose_filter: bad argument");
+    double vscale;
+    if (acc_voltage < 301 && acc_voltage > 299.) vscale = 1.0;
+    else if (acc_voltage < 201.0 && acc_voltage > 199.0) vscale = 0.8;
+    else { xh_set_error("xh_movie_dose_filter: Bad acceleration voltage (must be 200 or 300 kV"); return XH_ERR_ARG; }     // initVoltage, :112-124
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t tot = (size_t)Y * X;
+    XhBuf work;
+    XH_TRY(xh_buf_alloc(ctx, work, sizeof(fa_cf) * tot));
+    fa_cf *F = (fa_cf *)work.p;
+    const unsigned grid = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_fa_load, dim3(grid), dim3(256), 0, ctx->stream, (const float *)d_frame, (const float *)nullptr, (const float *)nullptr, F, tot);
+    int rc = xh_fft2d_exec(plan, (float *)F, 0);
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL(k_dose_apply, dim3(grid), dim3(256), 0, ctx->stream, F, Y, X, pixel_size, vscale, dose_start, dose_finish);
+        rc = xh_fft2d_exec(plan, (float *)F, 1);
+    }
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL(k_dose_store, dim3(grid), dim3(256), 0, ctx->stream, (const fa_cf *)F, d_frame, tot);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_movie_dose_filter: device error"); rc = XH_ERR_HIP; }
+    }
+    xh_buf_free(work);
+    return rc;
+}
+
 }  // extern "C"

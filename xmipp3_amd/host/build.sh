@@ -14,5 +14,6 @@ $CXX $FLAGS resolution_fsc_main.cpp -o ../bin/xmipp_resolution_fsc $LINK &
 $CXX $FLAGS ctf_phase_flip_main.cpp -o ../bin/xmipp_ctf_phase_flip $LINK &
 $CXX $FLAGS ctf_correct_wiener2d_main.cpp -o ../bin/xmipp_ctf_correct_wiener2d $LINK &
 $CXX $FLAGS movie_alignment_correlation_main.cpp -o ../bin/xmipp_movie_alignment_correlation $LINK &
+$CXX $FLAGS movie_filter_dose_main.cpp -o ../bin/xmipp_movie_filter_dose $LINK &
 wait
-echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library,resolution_fsc,ctf_phase_flip,ctf_correct_wiener2d,movie_alignment_correlation}"
+echo "built $(cd ../bin && pwd)/xmipp_{angular_projection_matching,reconstruct_fourier_accel,reconstruct_fourier,angular_project_library,resolution_fsc,ctf_phase_flip,ctf_correct_wiener2d,movie_alignment_correlation,movie_filter_dose}"

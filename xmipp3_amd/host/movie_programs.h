@@ -271,5 +271,87 @@ public:
     }
 };
 
+// xmipp_movie_filter_dose: ProgMovieFilterDose (reconstruction/movie_filter_dose.cpp:36-290) over xh_movie_dose_filter
+class ProgMovieFilterDose : public XmippProgram {
+public:
+    std::string fnIn, fnOut;
+    int first = -1, last = -1, device = 0;
+    double pixel_size = 1, dose_per_frame = 2, acceleration_voltage = 300, pre_exposure_amount = 0;
+
+    void defineParams() override
+    {
+        // movie_filter_dose.cpp:68-83, verbatim parameter lines
+        addUsageLine("Align a set of frames by cross-correlation of the frames");
+        addParamsLine("   -i <movie>                  : input movie");
+        addParamsLine("  [-o <fn=\"out.mrcs\">]        : output filtered movie.");
+        addParamsLine("  [--frameRange <n0=-1> <nF=-1>]  : First and last frame to align, frame numbers start at 0");
+        addParamsLine("  [--sampling <Ts=1>]          : Sampling rate (A/pixel)");
+        addParamsLine("  [--dosePerFrame <dose=2>]    : Dose per frame (e/A^2)");
+        addParamsLine("  [--accVoltage <voltage=300>] : Acceleration voltage (kV) min_value=200.0e0,max_value=300.0e0)");
+        addParamsLine("  [--preExposure <preExp=0>]   : P (e/A^2)");
+        addParamsLine("  [--device <id=0>]            : HIP device");
+    }
+
+    void readParams() override
+    {
+        if (!checkParam("-i")) REPORT_ERROR(ERR_ARG_MISSING, "-i is mandatory");
+        fnIn = getParam("-i");
+        fnOut = getParam("-o");
+        first = (int)getIntParam("--frameRange", 0);
+        last = (int)getIntParam("--frameRange", 1);
+        pixel_size = getDoubleParam("--sampling");
+        dose_per_frame = getDoubleParam("--dosePerFrame");
+        acceleration_voltage = getDoubleParam("--accVoltage");
+        if (!((acceleration_voltage < 301 && acceleration_voltage > 299.) || (acceleration_voltage < 201.0 && acceleration_voltage > 199.0)))
+            REPORT_ERROR(ERR_ARG_INCORRECT, "Bad acceleration voltage (must be 200 or 300 kV");          // initVoltage
+        pre_exposure_amount = getDoubleParam("--preExposure");
+        device = (int)getIntParam("--device");
+    }
+
+    void run() override
+    {
+        MetaDataVec movie;
+        const std::string ext = FileName(fnIn).extension();
+        if (ext == "xmd" || ext == "sel" || ext == "doc") movie.read(fnIn);
+        else {
+            const ImageInfo I = readInfo(fnIn);
+            size_t nd = I.isStack ? I.n : 1;
+            if (ext == "mrc" && nd == 1) nd = I.z;
+            for (size_t i = 0; i < nd; ++i) movie.setValue("image", std::to_string(i + 1) + "@" + fnIn, movie.addObject());
+        }
+        if (first < 0) first = 0;
+        if (last < 0) last = (int)movie.size() - 1;
+        if (last >= (int)movie.size() || last < first) REPORT_ERROR(ERR_ARG_INCORRECT, "--frameRange outside the movie");
+        CtxGuard g;
+        xhCheck(xh_ctx_create_private(device, &g.c));
+        std::vector<float> frame, all;
+        ImageInfo I0;
+        xh_fft2d *plan = nullptr;
+        struct PlanGuard { xh_fft2d **p; ~PlanGuard() { if (*p) xh_fft2d_destroy(*p); } } pg{&plan};
+        DeviceBuffer d_frame;
+        for (int n = 0; n <= last; ++n) {
+            if (n < first) continue;
+            std::string fn;
+            movie.getValue("image", fn, (size_t)n);
+            ImageInfo I;
+            readImage(fn, frame, I);
+            if (!plan) {
+                I0 = I;
+                xhCheck(xh_fft2d_create(g.c, (int)I.y, (int)I.x, &plan));
+                d_frame.reserve(g.c, I.x * I.y * sizeof(float));
+                all.assign((size_t)(last + 1) * I.x * I.y, 0.f);          // the frames keep their place in the stack (frame.write(fn, n + 1, ...))
+            } else if (I.x != I0.x || I.y != I0.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnIn);
+            const size_t per = I.x * I.y;
+            xhCheck(xh_memcpy_h2d(g.c, d_frame.p, frame.data(), per * sizeof(float)));
+            xhCheck(xh_movie_dose_filter(g.c, plan, d_frame.as<float>(), (int)I.y, (int)I.x, pixel_size, acceleration_voltage, (n * dose_per_frame) + pre_exposure_amount,
+                                         ((n + 1) * dose_per_frame) + pre_exposure_amount));
+            xhCheck(xh_memcpy_d2h(g.c, all.data() + (size_t)n * per, d_frame.p, per * sizeof(float)));
+        }
+        FileName fo(fnOut);
+        if (isMrcExt(fo.extension())) { std::vector<double> d(all.begin(), all.end()); writeVolume(fnOut, d.data(), I0.x, I0.y, (size_t)(last + 1)); }
+        else writeStack(fo.path, all.data(), I0.x, I0.y, (size_t)(last + 1));
+    }
+};
+
 }  // namespace mc
 #endif
