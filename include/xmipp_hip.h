@@ -112,7 +112,10 @@ typedef struct xh_rf xh_rf;
 
 int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out);
 int xh_rf_destroy(xh_rf *rf);
-/* profiling knobs ("insert_variant": 0 product path, 1 no atomics, 2 atomics only) */
+/* profiling / A-B knobs of the reconstruction handle (defaults are the product path): "unit_z" 4 | 8 (depth of a wave's voxel unit in
+ * k_rf_grid), "grid_waves" 0 (= the configuration's default) | 8 | 9 | 12 | 16, "fuse_ctf" 1 | 0 (CTF evaluated while the records
+ * are packed, or through planes), "records_from_images" 0 | 1 (records written by the FFT's row pass), "tile_max_spaces",
+ * "fft_variant" 1 | 2 (columns-first / rows-first projection FFT). Unknown names fail with XH_ERR_ARG. */
 int xh_rf_set_option(xh_rf *rf, const char *name, double value);
 /* derived sizes (RFA:196-199): paddedImgSize P, maxVolumeIndexYZ mv, fft crop sizeX=mv/2, sizeY=mv */
 int xh_rf_sizes(const xh_rf *rf, int32_t *paddedImgSize, int32_t *maxVolumeIndex,
@@ -165,8 +168,9 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
                         const float *h_weights, int32_t n, const double *h_sym, int32_t nsym);
 /* xh_rf_insert_images with the orientations where the matcher left them: d_angles [n][3] doubles (rot, tilt, psi in
  * degrees) and d_weights [n] floats (or NULL) in device memory. The traverse spaces (RFA:939-966, 430-522) are built
- * by a kernel from the functions the host path uses, so the two forms give the same temp spaces; a weight of 0 drops
- * the projection (RFA:327-329). The call enqueues and returns: it never waits for the stream. */
+ * by a kernel from the functions the host path uses (double arithmetic on both sides, the device's fused multiply-adds
+ * may round the last bit of a matrix element differently), so the two forms give the same temp spaces to float rounding
+ * (test_device_side_orientations_give_the_host_forms_temp_spaces: 1e-6); a weight of 0 drops the projection (RFA:327-329). The call enqueues and returns: it never waits for the stream. */
 int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_ctf, const double *d_angles,
                             const float *d_weights, int32_t n, const double *h_sym, int32_t nsym);
 /* same but taking the 3x3 "localAInv" (= Euler^T) matrices directly, h_ainv [n][9] */
