@@ -442,6 +442,24 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
 int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y, int32_t X, double pixel_size, double acc_voltage,
                          double dose_start, double dose_finish);
 
+/* ---- batched estimator API, first slice ------------------------------------------------------
+ * ExtremaFinder::SingleExtremaFinder<T> (reconstruction/single_extrema_finder.cpp:146-300): n signals [n][z][y][x] on the device;
+ * search_type 0 Max, 1 Lowest (first of equals, like std::max_element / min_element), 2 MaxAroundCenter, 3 LowestAroundCenter (2-D
+ * only: within max_dist of (x/2, y/2), first in raster order); h_positions [n] element offsets as floats (-1: nothing searched),
+ * h_values [n]; either may be NULL. */
+int xh_extrema_find(xh_ctx *ctx, const float *d_data, int32_t n, int32_t zdim, int32_t ydim, int32_t xdim, int32_t search_type, float max_dist,
+                    float *h_positions, float *h_values);
+/* Alignment::ShiftCorrEstimator<T>, AlignType::OneToN (reconstruction/shift_corr_estimator.cpp:33-300): create = init2D (even sizes,
+ * 0 < max_shift < size / 2); load_reference = load2DReferenceOneToN(const T *); correlate = the static
+ * computeCorrelations2DOneToN (d_inout [n][fy][fx] complex spectra <- ref conj(inout), times (-1)^(x+y) when center);
+ * compute_shifts = computeShift2DOneToN + getShifts2D: h_shifts [n][2] = (x, y) as the reference returns them. */
+typedef struct xh_shiftcorr xh_shiftcorr;
+int xh_shiftcorr_create(xh_ctx *ctx, int32_t xdim, int32_t ydim, int32_t max_shift, xh_shiftcorr **out);
+int xh_shiftcorr_destroy(xh_shiftcorr *h);
+int xh_shiftcorr_load_reference(xh_shiftcorr *h, const float *d_ref);
+int xh_shiftcorr_correlate(xh_ctx *ctx, float *d_inout, const float *d_ref, int32_t n, int32_t fy, int32_t fx, int32_t center);
+int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t n, float *h_shifts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""GPU tests of the estimator API's first slice, written after the reference's typed tests
+(applications/tests/function_tests/asingle_extrema_finder_tests.h, ashift_corr_estimator_tests.h, ashift_estimator_tests.h):
+those check against brute force and against answers known by construction, and so do these."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import xmipp3_amd as xa
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return xa, xa.Context(0), torch
+
+
+@pytest.mark.parametrize("shape", [(7, 1000), (3, 1), (5, 31, 17), (4, 64, 64), (2, 5, 6, 7), (1, 300, 301)])
+def test_extrema_max_and_lowest(gpu, shape):
+    """SingleExtremaFinder Max / Lowest (asingle_extrema_finder_tests.h:88-121): position and value of every signal equal the scan's;
+    equal extrema: the first one (std::max_element)."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(sum(shape))
+    data = rng.standard_normal(shape).astype(np.float32)
+    flat = data.reshape(shape[0], -1)
+    flat[0, -1] = flat[0].max()                    # a tie: the earlier element wins
+    flat[-1, 0] = flat[-1].min()
+    d = torch.from_numpy(data).cuda()
+    pos, val = xa.extrema_find(ctx, d, xa.api.EXTREMA_MAX)
+    assert np.array_equal(pos, flat.argmax(1).astype(np.float32)) and np.array_equal(val, flat.max(1))
+    pos, val = xa.extrema_find(ctx, d, xa.api.EXTREMA_LOWEST)
+    assert np.array_equal(pos, flat.argmin(1).astype(np.float32)) and np.array_equal(val, flat.min(1))
+
+
+@pytest.mark.parametrize("n,y,x,dist", [(6, 32, 32, 5), (3, 20, 50, 9), (4, 51, 33, 15), (2, 64, 48, 1), (2, 10, 10, 7)])
+def test_extrema_around_center(gpu, n, y, x, dist):
+    """MaxAroundCenter / LowestAroundCenter (single_extrema_finder.cpp:226-300): within `dist` of (x/2, y/2), first in raster order; a
+    distance beyond the centre's coordinate searches nothing (the reference's unsigned bounds wrap): position -1, the start value."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(n * y + x)
+    data = rng.standard_normal((n, y, x)).astype(np.float32)
+    d = torch.from_numpy(data).cuda()
+    for st, better, start in ((xa.api.EXTREMA_MAX_AROUND_CENTER, np.greater, np.finfo(np.float32).min), (xa.api.EXTREMA_LOWEST_AROUND_CENTER, np.less, np.finfo(np.float32).max)):
+        pos, val = xa.extrema_find(ctx, d, st, dist)
+        for s in range(n):
+            ev, ep = start, -1.0
+            if dist <= x // 2 and dist <= y // 2:
+                for yy in range(max(0, y // 2 - dist), min(y - 1, y // 2 + dist) + 1):
+                    for xx in range(max(0, x // 2 - dist), min(x - 1, x // 2 + dist) + 1):
+                        if (yy - y // 2) ** 2 + (xx - x // 2) ** 2 > dist * dist:
+                            continue
+                        if better(data[s, yy, xx], ev):
+                            ev, ep = data[s, yy, xx], float(yy * x + xx)
+            assert pos[s] == ep and val[s] == np.float32(ev)
+    with pytest.raises(xa.XhError):
+        xa.extrema_find(ctx, torch.zeros((2, 3, 4, 5), device="cuda"), xa.api.EXTREMA_MAX_AROUND_CENTER, 2)      # 3-D: "Not implemented"
+
+
+@pytest.mark.parametrize("n", [1, 5, 6])
+def test_correlate_one_to_n_known_answer(gpu, n):
+    """AShiftCorrEstimator_Test::correlate2DNoCenter (ashift_corr_estimator_tests.h:22-66): spectra of FFTSettings(30, 14): 14 rows of 16
+    coefficients, inOut[n](y, x) = (x + n, y + n), the reference = signal 0: the result is (x, y) conj(x + n, y + n) to 1e-4."""
+    xa, ctx, torch = gpu
+    fy, fx = 14, 16
+    yy, xx = np.mgrid[0:fy, 0:fx]
+    inout = np.stack([(xx + k) + 1j * (yy + k) for k in range(n)]).astype(np.complex64)
+    ref = inout[0].copy()
+    d = torch.from_numpy(inout).cuda()
+    xa.ShiftCorrEstimator.correlate(ctx, d, torch.from_numpy(ref).cuda(), False)
+    got = d.cpu().numpy()
+    for k in range(n):
+        exp = (xx + 1j * yy) * np.conj((xx + k) + 1j * (yy + k))
+        assert np.abs(got[k] - exp).max() <= 1e-4
+    # centred: every other coefficient changes sign
+    d = torch.from_numpy(inout).cuda()
+    xa.ShiftCorrEstimator.correlate(ctx, d, torch.from_numpy(ref).cuda(), True)
+    assert np.abs(d.cpu().numpy()[n - 1] - (xx + 1j * yy) * np.conj((xx + n - 1) + 1j * (yy + n - 1)) * (1 - 2 * ((xx + yy) & 1))).max() <= 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_shift_estimation_of_crosses(gpu, n):
+    """AShiftEstimator_Test::shift2D (ashift_estimator_tests.h:25-86): a cross through the centre, n copies shifted by whole pixels
+    within the maximal shift (the test's generator: x in 0..max, y below sqrt(max^2 - x^2)); sizes even, x == y, x > y, x < y drawn
+    like the test draws them; the estimator returns exactly the negative of every shift."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(42 + n)
+    even = lambda lo, hi: max(8, (int(rng.integers(lo, hi + 1)) // 2) * 2)
+    a, b, c, d_, e = even(0, 368), even(0, 368), even(369, 768), even(0, 368), even(369, 768)
+    for x, y in ((a, a), (c, b), (d_, e)):
+        max_shift = min(x // 2, y // 2) - 1
+        shifts = []
+        for _ in range(n):
+            sx = int(rng.integers(0, max_shift + 1))
+            my = int(np.floor(np.sqrt(max_shift * max_shift - sx * sx)))
+            sy = 0 if my == 0 else int(rng.integers(0, max_shift + 1)) % my
+            shifts.append((sx, sy))
+
+        def cross(cx, cy):
+            img = np.zeros((y, x), np.float32)
+            img[:, cx] = 1
+            img[cy, :] = 1
+            return img
+        ref = cross(x // 2, y // 2)
+        others = np.stack([cross(x // 2 + sx, y // 2 + sy) for sx, sy in shifts])
+        est = xa.ShiftCorrEstimator(ctx, x, y, max_shift)
+        est.load_reference(torch.from_numpy(ref).cuda())
+        got = est.compute_shifts(torch.from_numpy(others).cuda())
+        assert np.array_equal(-got, np.array(shifts, np.float32)), (x, y, shifts, got)
+        est.close()
+    with pytest.raises(xa.XhError):
+        xa.ShiftCorrEstimator(ctx, 31, 32, 4)                      # only even sizes
+    with pytest.raises(xa.XhError):
+        xa.ShiftCorrEstimator(ctx, 32, 32, 16)                     # the maximal shift must be below half of the size
+    est = xa.ShiftCorrEstimator(ctx, 32, 32, 4)
+    with pytest.raises(xa.XhError):
+        est.compute_shifts(torch.zeros((1, 32, 32), device="cuda"))        # no reference loaded

@@ -91,6 +91,12 @@ SIGNATURES = {
     "xh_fa_last_full_pairs": (C.c_int, [vp]),
     "xh_fa_global_alignment": (C.c_int, [vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, C.POINTER(i32)]),
     "xh_fa_local_alignment": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "xh_extrema_find": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp]),
+    "xh_shiftcorr_create": (C.c_int, [vp, i32, i32, i32, pvp]),
+    "xh_shiftcorr_destroy": (C.c_int, [vp]),
+    "xh_shiftcorr_load_reference": (C.c_int, [vp, vp]),
+    "xh_shiftcorr_correlate": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
+    "xh_shiftcorr_compute_shifts": (C.c_int, [vp, vp, i32, vp]),
     "xh_movie_dose_filter": (C.c_int, [vp, vp, vp, i32, i32, d, d, d, d]),
     "xh_fa_correlate": (C.c_int, [vp, vp, i32, i32, i32, C.c_float, vp]),
     "xh_fa_local_from_global": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -502,6 +502,64 @@ class FlexAlign:
         return out
 
 
+EXTREMA_MAX, EXTREMA_LOWEST, EXTREMA_MAX_AROUND_CENTER, EXTREMA_LOWEST_AROUND_CENTER = 0, 1, 2, 3
+
+
+def extrema_find(ctx, data, search_type, max_dist=0.0):
+    """SingleExtremaFinder on signals [n, (z,) (y,) x] float32 on the device -> (positions float32 [n], values float32 [n])"""
+    torch = _torch()
+    assert data.is_cuda and data.dtype == torch.float32 and data.is_contiguous() and 2 <= data.dim() <= 4
+    shp = (data.shape[0],) + (1,) * (4 - data.dim()) + tuple(data.shape[1:])
+    pos, val = np.empty(shp[0], np.float32), np.empty(shp[0], np.float32)
+    check(lib().xh_extrema_find(ctx.h, _ptr(data), shp[0], shp[1], shp[2], shp[3], int(search_type), float(max_dist), _np_ptr(pos), _np_ptr(val)))
+    return pos, val
+
+
+class ShiftCorrEstimator:
+    """Alignment::ShiftCorrEstimator<float>, AlignType::OneToN, for images of x by y pixels (even)."""
+
+    def __init__(self, ctx, x, y, max_shift):
+        self.ctx, self.x, self.y = ctx, int(x), int(y)
+        h = C.c_void_p()
+        check(lib().xh_shiftcorr_create(ctx.h, self.x, self.y, int(max_shift), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                lib().xh_shiftcorr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_reference(self, ref):
+        torch = _torch()
+        assert ref.is_cuda and ref.dtype == torch.float32 and ref.is_contiguous() and tuple(ref.shape) == (self.y, self.x)
+        check(lib().xh_shiftcorr_load_reference(self.h, _ptr(ref)))
+
+    def compute_shifts(self, others):
+        """others [n, y, x] -> shifts [n, 2] (x, y) as getShifts2D returns them (the image's shift is the negative)"""
+        torch = _torch()
+        assert others.is_cuda and others.dtype == torch.float32 and others.is_contiguous() and tuple(others.shape[1:]) == (self.y, self.x)
+        out = np.empty((others.shape[0], 2), np.float32)
+        check(lib().xh_shiftcorr_compute_shifts(self.h, _ptr(others), others.shape[0], _np_ptr(out)))
+        return out
+
+    @staticmethod
+    def correlate(ctx, inout, ref, center):
+        """computeCorrelations2DOneToN: inout [n, fy, fx] complex64 <- ref conj(inout) (times (-1)^(x+y) when center), in place"""
+        torch = _torch()
+        assert inout.is_cuda and inout.dtype == torch.complex64 and inout.is_contiguous() and ref.dtype == torch.complex64 and ref.is_contiguous()
+        assert tuple(ref.shape) == tuple(inout.shape[1:])
+        check(lib().xh_shiftcorr_correlate(ctx.h, C.c_void_p(inout.data_ptr()), C.c_void_p(ref.data_ptr()), inout.shape[0], inout.shape[1], inout.shape[2], int(bool(center))))
+        return inout
+
+
 def movie_dose_filter(fft, frame, pixel_size, acc_voltage, dose_start, dose_finish):
     """ProgMovieFilterDose on one frame ([Y, X] float32 on the device, in place); fft = Fft2D(ctx, Y, X)."""
     torch = _torch()
