@@ -65,6 +65,7 @@ def parse(argv=None):
                     help="local search (APM:615-631): every particle is matched against the K references nearest to its true "
                          "direction only (ascending lists, as a sampling file holds them); 0: the whole bank")
     ap.add_argument("--pm-opt", action="append", default=[], help="name=value passed to xh_pm_set_option (A/B runs)")
+    ap.add_argument("--rf-opt", action="append", default=[], help="name=value passed to xh_rf_set_option (A/B runs)")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
@@ -287,6 +288,9 @@ def main():
     def on_rf_stream():
         return torch.cuda.stream(side) if pipelined else contextlib.nullcontext()
     rf = xa.RecFourier(ctx_rf, D, min_ctf=0.01, sampling=1.0) if args.mode != "match" else None
+    for o_ in (args.rf_opt if rf is not None else []):
+        k_, v_ = o_.split("=")
+        rf.set_option(k_, float(v_))
     # HIP-event pairs on the library's stream around the stages xh_pm_stage_ms does not cover; read after the timed region
     timers = {"translate_s6": [], "shift_images": [], "gridding_insert_images": []}
 

@@ -1757,6 +1757,7 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
         else if (uz == 8 && nw == 8) XH_GRID(W_, F_, 8, 8);                                                                      \
         else if (uz == 4 && nw == 12) XH_GRID(W_, F_, 4, 12);                                                                    \
         else if (uz == 4 && nw == 16 && W_ == 4) XH_GRID(4, F_, 4, 16);                                                          \
+        else if (uz == 4 && nw == 8) XH_GRID(W_, F_, 4, 8);                                                                      \
         else { xh_set_error("xh_rf_insert: no gridding kernel for unit_z %d with %d waves", uz, nw); return XH_ERR_UNSUPPORTED; } \
     } while (0)
         if (fast) XH_GRID_WF(4, true);
