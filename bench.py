@@ -65,6 +65,8 @@ def parse(argv=None):
                     help="local search (APM:615-631): every particle is matched against the K references nearest to its true "
                          "direction only (ascending lists, as a sampling file holds them); 0: the whole bank")
     ap.add_argument("--pm-opt", action="append", default=[], help="name=value passed to xh_pm_set_option (A/B runs)")
+    ap.add_argument("--cu-split", type=int, default=0, help="experiment: q of every 4 CU groups to the matcher's stream, the others to the "
+                    "reconstruction stream (hipExtStreamCreateWithCUMask); 0: no masks")
     ap.add_argument("--rf-opt", action="append", default=[], help="name=value passed to xh_rf_set_option (A/B runs)")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
@@ -193,6 +195,23 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    masked_side = None
+    if args.cu_split > 0:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+
+        def masked_stream(pred):
+            mask = (ctypes.c_uint32 * 8)()
+            for i in range(256):
+                if pred(i):
+                    mask[i // 32] |= 1 << (i % 32)
+            sp = ctypes.c_void_p()
+            rc_ = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, mask)
+            assert rc_ == 0, rc_
+            return torch.cuda.ExternalStream(sp.value, device=dev)
+        q_ = args.cu_split
+        torch.cuda.set_stream(masked_stream(lambda i: (i // 8) % 4 < q_))
+        masked_side = masked_stream(lambda i: (i // 8) % 4 >= q_)
     ctx = xa.Context(local)
     D, nrefs, B = args.box, args.nrefs, args.batch
     gen = torch.Generator(device=dev)
@@ -279,7 +298,7 @@ def main():
     # (LDS / VALU bound) runs beside the matching of batch k+1 (mostly HBM bound)
     import contextlib
     pipelined = bool(args.pipeline) and args.mode == "full"
-    side = torch.cuda.Stream(device=dev) if pipelined else None
+    side = (masked_side or torch.cuda.Stream(device=dev)) if pipelined else None
     ctx_rf = ctx
     if pipelined:
         with torch.cuda.stream(side):
