@@ -1317,7 +1317,9 @@ __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { r
 // every row whose bound lies more than 2 tau below it (tau: the ambiguity margin of S4, so a skipped row can
 // be neither the winner nor a candidate for the fp64 re-score). The result is identical with or without
 // pruning; what is saved depends on the data (rows whose bound stays above the best are still transformed).
+#ifndef XH_PRUNE_T
 #define XH_PRUNE_T 4
+#endif
 __global__ void __launch_bounds__(256)
 k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
                 const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows,
