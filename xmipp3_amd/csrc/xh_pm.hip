@@ -1826,7 +1826,9 @@ __global__ void k_pm_crosspower(const xh_cd *__restrict__ Z, xh_cd *__restrict__
 // bestShift on the centred correlation map (FIL:1593-1719, mask == nullptr, maxShift == -1),
 // max_shift rejection (APM:841-842), translate(LINEAR, wrap) + correlationIndex (APM:850-851).
 // One block per particle. R = real part of the inverse FFT, un-centred (zero lag at index 0).
+#ifndef XH_BS_U
 #define XH_BS_U 4            // map elements a thread of k_pm_bestshift has in flight
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restrict__ zimg, const int *__restrict__ refno,
