@@ -136,7 +136,8 @@ struct xh_pm {
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     int use_mask_lists;          // neighbour-list searches over the whole bank with the off-list references masked (0: gather path)
-    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList;
+    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList, d_rowLow;
+    int use_early_exit;          // surviving rows are dropped while their high frequencies are computed, once the bound allows it
     int64_t stat_pruned;
     int lastPruneRows;           // rows of the last chunk that went through k_pm_survivors (0: none)
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
@@ -1083,6 +1084,10 @@ struct XhHigh {          // what S3 needs to finish a row the contraction left a
     int nrings, ncoef, K0, nq;
     int zeroHigh;        // 1: leave them zero (lower bounds from the low part alone, see k_pm_prune_thr)
     int rawStride;       // float4 per row of the S2 -> S3 intermediate: K0 with the two-level contraction, else nk
+    // bound of a surviving row while its high frequencies are computed (early exit, see k_pm_idft_max3); null: off
+    const float4 *rowLow;        // per row: moduli sums below K0 (straight, mirror), 2 x Cauchy-Schwarz tail, normalisation
+    const float *aT, *bT;        // the per-frequency norms behind that tail: [slot][nk], [nk][nrefs]
+    int nk, nrefs;
 };
 // the four real sums (ac, ad, bc, bd) of frequency k for (slot, ref), ring order ascending like k_pm_contract
 __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref, int k)
@@ -1153,6 +1158,42 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
             for (int k = lane; k < nk; k += 64) sraw[k] = rr[k];
         } else {
             const int slot = row / H.nq, ref = row - slot * H.nq;
+            if (H.rowLow && !H.zeroHigh) {
+                // The row survived on a bound whose high-frequency part is Cauchy-Schwarz per frequency. As the wave computes
+                // those frequencies (64 at a time, a lane each) it replaces their share of the bound by the moduli it now
+                // knows; once the bound falls below the particle's threshold the row is dropped like a pruned one -- same
+                // criterion, same slack (1.0001 covers the rounding of these fp32 sums as it does in k_pm_prune_plan).
+                const float4 lo = H.rowLow[row];
+                float bS = lo.x + lo.z, bM = lo.y + lo.z;
+                const float th = thr[row / rowsPerParticle], scl = 1.0001f / lo.w;
+                bool dead = false;
+                for (int k0 = 0; k0 < nk; k0 += 64) {
+                    const int k = k0 + lane;
+                    float dS = 0.f, dM = 0.f;
+                    if (k < nk) {
+                        if (k < H.K0) sraw[k] = rr[k];
+                        else {
+                            const float4 o = d_row_high(H, slot, ref, k);
+                            sraw[k] = o;
+                            const float fsr = o.x - o.w, fsi = o.y + o.z, fmr = o.x + o.w, fmi = o.y - o.z;
+                            const float cs = 2.f * H.aT[(size_t)slot * H.nk + k] * H.bT[(size_t)k * H.nrefs + ref];
+                            if (k == nk - 1) { dS = fabsf(fsr) - cs; dM = fabsf(fmr) - cs; }       // c2r drops its imaginary part
+                            else { dS = 2.f * sqrtf(fsr * fsr + fsi * fsi) - cs; dM = 2.f * sqrtf(fmr * fmr + fmi * fmi) - cs; }
+                        }
+                    }
+                    if (k0 + 63 >= H.K0) {
+                        for (int o = 32; o > 0; o >>= 1) { dS += __shfl_xor(dS, o, 64); dM += __shfl_xor(dM, o, 64); }
+                        bS += dS; bM += dM;
+                        if (fmaxf(bS, bM) * scl < th) { dead = true; break; }
+                    }
+                }
+                if (dead) {
+                    if (lane == 0) { RowRes r; r.best = -3.0e38f; r.idx = 0; r.second = -3.0e38f; r.pad = 0; res[row] = r; }
+                    ++skipped;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+            } else
             for (int k = lane; k < nk; k += 64)
                 sraw[k] = k < H.K0 ? rr[k] : (H.zeroHigh ? make_float4(0.f, 0.f, 0.f, 0.f) : d_row_high(H, slot, ref, k));
         }
@@ -1324,7 +1365,7 @@ __global__ void __launch_bounds__(256)
 k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
                 const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows,
                 const float *__restrict__ aT, const float *__restrict__ bT, int K0, int nk, int nrefs, float *__restrict__ rowTail,
-                const unsigned *__restrict__ mask, int maskW)
+                const unsigned *__restrict__ mask, int maskW, float4 *__restrict__ rowLow)
 {
     __shared__ float sv[256];
     __shared__ int sr[256];
@@ -1383,6 +1424,7 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
                 // 1e-4: rounding of the fp32 sums, of sqrtf and of the fp32 transform itself (all ~1e-6 relative)
                 rowBound[r] = (fmaxf(bs, bm) + 2.f * tail[j]) * 1.0001f / den;
                 rowTail[r] = 2.f * tail[j] * 1.0001f / den;
+                if (rowLow) rowLow[r] = make_float4(bs, bm, 2.f * tail[j], den);
                 // a neighbour-list search run over the whole bank (xh_pm_match_ex): a reference that is not on the particle's
                 // list can never be picked, listed first or survive -- it is not a row of the search
                 if (mask && !((mask[(size_t)p * maskW + (ref[j] >> 5)] >> (ref[j] & 31)) & 1u)) { rowBound[r] = -INFINITY; rowTail[r] = 0.f; }
@@ -2893,7 +2935,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -2989,6 +3031,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->s6_eps = 2e-5;
     pm->s6_flagged = 0;
     pm->use_prune = 1;
+    pm->use_early_exit = 0;      // measured without gain on the bench gallery (profiles/README.md, round 3): the survivors stay above the threshold to the end
     pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
     pm->stat_pruned = 0;
@@ -3327,6 +3370,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "s6_fp32")) pm->s6_fp32 = (int)value;
     else if (!strcmp(name, "s6_eps")) pm->s6_eps = value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
+    else if (!strcmp(name, "early_exit")) pm->use_early_exit = value != 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
     else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
@@ -3430,6 +3474,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     XhHigh H;
     H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
     H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
+    H.rowLow = nullptr; H.aT = H.bT = nullptr; H.nk = L.nk; H.nrefs = pm->nrefs;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
@@ -3479,6 +3524,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             XH_TRY(xh_buf_reserve(ctx, pm->d_topRows, sizeof(int) * (size_t)nparticles * XH_PRUNE_T));
             XH_TRY(xh_buf_reserve(ctx, pm->d_thr, sizeof(float) * (size_t)nparticles));
             XH_TRY(xh_buf_reserve(ctx, pm->d_aT, sizeof(float) * (size_t)m * L.nk));
+            const bool earlyExit = pm->use_early_exit && K0 < L.nk && !d_mask;
+            if (earlyExit) XH_TRY(xh_buf_reserve(ctx, pm->d_rowLow, sizeof(float4) * (size_t)nrows));
             if (K0 < L.nk) {
                 hipLaunchKernelGGL(k_pm_tail_norms, dim3((L.nk - K0 + 63) / 64, m), dim3(64), 0, ctx->stream, (const xh_cf *)pm->d_A32.p,
                                    (float *)pm->d_aT.p, (const int *)pm->d_coff.p, (const int *)pm->d_rstart.p, L.nrings, L.ncoef, L.nk, K0,
@@ -3488,7 +3535,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             hipLaunchKernelGGL(k_pm_prune_plan, dim3(nparticles), dim3(256), 0, ctx->stream, (const float2 *)pm->d_bpart.p, XH_KSPLIT,
                                (size_t)nrows, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
                                (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p, (const float *)pm->d_aT.p, (const float *)pm->d_bT.p,
-                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p, d_mask, maskW);
+                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p, d_mask, maskW, earlyExit ? (float4 *)pm->d_rowLow.p : (float4 *)nullptr);
             XH_LAUNCH_CHECK();
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
@@ -3509,6 +3556,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             XH_LAUNCH_CHECK();
             pm->lastPruneRows = d_mask ? listedRows : nrows;
             nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
+            if (earlyExit) { thr = (const float *)pm->d_thr.p; rowsPer = nrows / nparticles; H.rowLow = (const float4 *)pm->d_rowLow.p; H.aT = (const float *)pm->d_aT.p; H.bT = (const float *)pm->d_bT.p; H.nk = L.nk; H.nrefs = pm->nrefs; }
         }
         grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
         XH_IDFT3_ANY();
