@@ -114,3 +114,39 @@ def test_shift_estimation_of_crosses(gpu, n):
     est = xa.ShiftCorrEstimator(ctx, 32, 32, 4)
     with pytest.raises(xa.XhError):
         est.compute_shifts(torch.zeros((1, 32, 32), device="cuda"))        # no reference loaded
+
+
+def _clock_arms(oracle, D, deg):
+    """drawClockArms (alignment_test_utils.h:79-96): two arms from the centre, rotated with rotate(BSPLINE3)"""
+    img = np.zeros((D, D))
+    c = D // 2
+    arm = int((D - c) / 1.5)
+    img[c:c + arm, c] = 1
+    img[c, c:c + arm] = 1
+    return oracle.rotate2d(img, float(deg), degree=3, wrap=False) if deg else img
+
+
+@pytest.mark.parametrize("D,n", [(64, 5), (101, 4), (300, 3)])
+def test_rotation_estimation_of_clock_arms(gpu, oracle, D, n):
+    """ARotationEstimator_Test::rotate2D (arotation_estimator_tests.h:45-118): clock arms rotated by known angles, default rings; an
+    image rotated by a reads 360 - a, to 0.62 of the angle one pixel subtends at the edge (the test's bound without noise) -- and the
+    index is the oracle's: arg-max of the straight correlation row of (image, reference), mirrored."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(D)
+    angles = rng.uniform(0, 360, n)
+    ref = _clock_arms(oracle, D, 0.0)
+    others = np.stack([_clock_arms(oracle, D, a) for a in angles])
+    got = xa.rotation_estimate(ctx, torch.from_numpy(ref.astype(np.float32)).cuda(), torch.from_numpy(others.astype(np.float32)).cuda())
+    max_err = np.degrees(np.arctan(2.0 / D)) * 0.62
+    for a, r in zip(angles, got):
+        actual = 360 - r
+        diff = 180 - abs(abs(actual - a) - 180)
+        assert diff <= max_err, (a, r, diff, max_err)
+    first, last = max(2, D // 20), (D - 3) // 2
+    opm = oracle.PM(ref.astype(np.float32)[None], Ri=first, Ro=last)
+    for k in range(n):
+        row = opm.corr_rows(others[k].astype(np.float32), 0)[:opm.N]
+        i = int(np.argmax(row))
+        assert got[k] == np.float32(((opm.N - i) % opm.N) * (360.0 / opm.N))
+    with pytest.raises(xa.XhError):
+        xa.rotation_estimate(ctx, torch.zeros((64, 64), device="cuda"), torch.zeros((1, 64, 64), device="cuda"), 10, 5)       # last ring <= first ring

@@ -515,6 +515,22 @@ def extrema_find(ctx, data, search_type, max_dist=0.0):
     return pos, val
 
 
+def rotation_estimate(ctx, ref, others, first_ring=None, last_ring=None):
+    """PolarRotationEstimator (OneToN): ref [D, D], others [n, D, D] float32 on the device -> rotations [n] in degrees as the
+    reference returns them. Default rings: RotationEstimationSetting::getDefaultFirstRing / getDefaultLastRing."""
+    torch = _torch()
+    D = ref.shape[-1]
+    assert ref.is_cuda and ref.dtype == torch.float32 and ref.is_contiguous() and tuple(ref.shape) == (D, D)
+    assert others.is_cuda and others.dtype == torch.float32 and others.is_contiguous() and tuple(others.shape[1:]) == (D, D)
+    if first_ring is None:
+        first_ring = max(2, D // 20)
+    if last_ring is None:
+        last_ring = (D - 3) // 2
+    out = np.empty(others.shape[0], np.float32)
+    check(lib().xh_rotation_estimate(ctx.h, _ptr(ref), _ptr(others), others.shape[0], D, int(first_ring), int(last_ring), _np_ptr(out)))
+    return out
+
+
 class ShiftCorrEstimator:
     """Alignment::ShiftCorrEstimator<float>, AlignType::OneToN, for images of x by y pixels (even)."""
 

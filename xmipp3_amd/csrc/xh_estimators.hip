@@ -8,7 +8,10 @@
 //                                           cuda_shift_corr_estimator.cpp), AlignType::OneToN: correlation of n spectra with one
 //                                           reference spectrum (optionally centred), shifts of n images against one reference
 //                                           = position of the correlation maximum within maxShift of the centre
-// The polar rotation estimator and the iterative alignment estimator are not built.
+//   Alignment::PolarRotationEstimator<T>    reconstruction/polar_rotation_estimator.cpp:33-144, AlignType::OneToN: rotation of n images
+//                                           against one reference = arg-max of the rotational correlation of their polar Fourier
+//                                           transforms over the rings firstRing .. lastRing (data/polar.cpp:99-148,212-231)
+// The iterative alignment estimator is not built.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -220,6 +223,40 @@ int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t 
         h_shifts[2 * i] = (float)(((int)pos[i] % h->x) - cX);
         h_shifts[2 * i + 1] = (float)(((int)pos[i] / h->x) - cY);
     }
+    return XH_OK;
+}
+
+// PolarRotationEstimator::load2DReferenceOneToN + computeRotation2DOneToN: best_rotation(reference, image) for n square images.
+// Runs on the projection matcher (one reference, rings first_ring .. last_ring, the mirrored particle switched off), i.e. with the
+// matcher's cubic B-spline polar sampling and its exact arg-max; the reference samples the rings with BsplineOrder 1
+// (polar_rotation_estimator.cpp:60,99) -- the correlation values differ in the last digits, the angle by at most one sample of the
+// outer ring in near-ties. best_rotation correlates (reference, image) where the matcher correlates (image, reference):
+// the index is mirrored, result = ((N - psi) mod N) 360 / N degrees.
+int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring, float *h_rotations)
+{
+    XH_CHECK(ctx && d_ref && d_others && h_rotations && n >= 1, XH_ERR_ARG, "xh_rotation_estimate: bad argument");
+    // RotationEstimationSetting::check + PolarRotationEstimator::check (arotation_estimator.h:80-130, polar_rotation_estimator.cpp:125-141)
+    XH_CHECK(D >= 6, XH_ERR_ARG, "xh_rotation_estimate: The input signal is too small.");
+    XH_CHECK(first_ring >= 1 && last_ring > first_ring && last_ring < D, XH_ERR_ARG, "xh_rotation_estimate: rings %d .. %d of a %d px image (first >= 1, last > first, last < size)",
+             first_ring, last_ring, D);
+    XH_CHECK(last_ring <= D / 2 - 1, XH_ERR_ARG, "xh_rotation_estimate: the last ring (%d) needs an edge around it: at most %d for %d px", last_ring, D / 2 - 1, D);
+    xh_pm *pm = nullptr;
+    XH_TRY(xh_pm_create(ctx, D, first_ring, last_ring, 1, d_ref, nullptr, 0, &pm));
+    int rc = xh_pm_set_option(pm, "mirror", 0.0);
+    int32_t N = 0;
+    if (rc == XH_OK) rc = xh_pm_info(pm, &N, nullptr, nullptr);
+    XhBuf bRef, bPsi, bFlip;
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRef, sizeof(int32_t) * n);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPsi, sizeof(int32_t) * n);
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bFlip, n);
+    if (rc == XH_OK) rc = xh_pm_match(pm, d_others, n, nullptr, nullptr, 0, (int32_t *)bRef.p, (int32_t *)bPsi.p, (uint8_t *)bFlip.p);
+    std::vector<int32_t> psi(n);
+    if (rc == XH_OK && hipMemcpyAsync(psi.data(), bPsi.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    xh_buf_free(bRef); xh_buf_free(bPsi); xh_buf_free(bFlip);
+    xh_pm_destroy(pm);
+    if (rc != XH_OK) return rc;
+    for (int i = 0; i < n; ++i) h_rotations[i] = (float)(((N - psi[i]) % N) * (360.0 / N));
     return XH_OK;
 }
 

@@ -137,6 +137,7 @@ struct xh_pm {
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     int use_mask_lists;          // neighbour-list searches over the whole bank with the off-list references masked (0: gather path)
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList, d_rowLow;
+    int no_mirror;               // option "mirror" 0: the mirrored particle is not searched (rotation estimator)
     int use_early_exit;          // surviving rows are dropped while their high frequencies are computed, once the bound allows it
     int64_t stat_pruned;
     int lastPruneRows;           // rows of the last chunk that went through k_pm_survivors (0: none)
@@ -886,7 +887,7 @@ __device__ __forceinline__ void d_top2_insert(float v, int i, float &b, int &bi,
 template <int LOGM>
 __global__ void __launch_bounds__(256)
 k_pm_idft_max(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh_cf *__restrict__ W,
-              const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vhat, int N, int nk, int nrows, int lpb)
+              const xh_cf *__restrict__ chirp, const xh_cf *__restrict__ vhat, int N, int nk, int nrows, int lpb, int noMirror)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     xh_cf *s = reinterpret_cast<xh_cf *>(smem);
@@ -930,7 +931,7 @@ k_pm_idft_max(const float4 *__restrict__ raw, RowRes *__restrict__ res, const xh
         for (int i = tid; i < N; i += nth) {
             const xh_cf z = xh_cmul(s[l * M + i], chirp[i]);
             d_top2_insert(z.x, i, b, bi, sec);
-            d_top2_insert(z.y, N + i, b, bi, sec);
+            if (!noMirror) d_top2_insert(z.y, N + i, b, bi, sec);
         }
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_down(b, o, 64), os = __shfl_down(sec, o, 64);
@@ -1088,6 +1089,7 @@ struct XhHigh {          // what S3 needs to finish a row the contraction left a
     const float4 *rowLow;        // per row: moduli sums below K0 (straight, mirror), 2 x Cauchy-Schwarz tail, normalisation
     const float *aT, *bT;        // the per-frequency norms behind that tail: [slot][nk], [nk][nrefs]
     int nk, nrefs;
+    int noMirror;                // 1: only the straight particle is a candidate (option "mirror" 0: the rotation estimator)
 };
 // the four real sums (ac, ad, bc, bd) of frequency k for (slot, ref), ring order ascending like k_pm_contract
 __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref, int k)
@@ -1323,7 +1325,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
                 if (n < N) {
                     const xh_cf z = xh_cmul(v[n1], chirp[n]);
                     d_top2_insert(z.x, n, b1, bi, sec);
-                    d_top2_insert(z.y, N + n, b1, bi, sec);
+                    if (!H.noMirror) d_top2_insert(z.y, N + n, b1, bi, sec);
                 }
             }
         }
@@ -1345,7 +1347,7 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
 // contiguous, poff[slot]..poff[slot+1]; the rows of a particle are therefore contiguous too.
 // dense (nq > 0): every slot is compared with references 0..nq-1; otherwise rowSlot/refIds give the
 // slot and the reference of every row (neighbour lists, APM:609-626).
-struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; };
+struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; int noMirror = 0; /* 1: the mirrored particle is not a candidate */ };
 __device__ __forceinline__ int d_row_slot(const RowMap &M, int row) { return M.rowSlot ? M.rowSlot[row] : row / M.nq; }
 __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { return M.refIds ? M.refIds[row] : row - slot * M.nq; }
 
@@ -1646,7 +1648,8 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
     double best = -1.0e300;
     int bi = 0x7fffffff;
     const int half = N / 2;
-    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) {
+    const int ncand = M.noMirror ? N : 2 * N;
+    for (int i = threadIdx.x; i < ncand; i += blockDim.x) {
         const xh_cd *F = i < N ? Fs : Fm;
         const int ii = i < N ? i : i - N;
         double acc = F[0].x + ((ii & 1) ? -F[half].x : F[half].x);
@@ -1684,7 +1687,7 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
         // next distinct value: the largest one below the value just written
         best = -1.0e300; bi = 0x7fffffff;
         if (topi != 0x7fffffff)
-            for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) {
+            for (int i = threadIdx.x; i < ncand; i += blockDim.x) {
                 const double v = vals[i];
                 if (v < top - eps && (v > best || (v == best && i < bi))) { best = v; bi = i; }
             }
@@ -2945,7 +2948,7 @@ static void launch_idft(xh_pm *pm, int nrows, int lpb, size_t smem)
 {
     hipLaunchKernelGGL((k_pm_idft_max<LOGM>), dim3((nrows + lpb - 1) / lpb), dim3(256), smem, pm->ctx->stream,
                        (const float4 *)pm->d_raw.p, (RowRes *)pm->d_rowres.p, (const xh_cf *)pm->d_W32.p,
-                       (const xh_cf *)pm->d_chirp.p, (const xh_cf *)pm->d_vhat.p, pm->L.N, pm->L.nk, nrows, lpb);
+                       (const xh_cf *)pm->d_chirp.p, (const xh_cf *)pm->d_vhat.p, pm->L.N, pm->L.nk, nrows, lpb, pm->no_mirror);
 }
 template <int LOGM>
 static void launch_idft_dump(xh_pm *pm, float *d_out, size_t smem)
@@ -3031,6 +3034,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->s6_eps = 2e-5;
     pm->s6_flagged = 0;
     pm->use_prune = 1;
+    pm->no_mirror = 0;
     pm->use_early_exit = 0;      // measured without gain on the bench gallery (profiles/README.md, round 3): the survivors stay above the threshold to the end
     pm->use_mask_lists = 1;
     pm->tr_chunk_mb = 0;
@@ -3371,6 +3375,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "s6_eps")) pm->s6_eps = value;
     else if (!strcmp(name, "prune")) pm->use_prune = (int)value;
     else if (!strcmp(name, "early_exit")) pm->use_early_exit = value != 0;
+    else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
     else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
@@ -3474,7 +3479,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     XhHigh H;
     H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
     H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
-    H.rowLow = nullptr; H.aT = H.bT = nullptr; H.nk = L.nk; H.nrefs = pm->nrefs;
+    H.rowLow = nullptr; H.aT = H.bT = nullptr; H.nk = L.nk; H.nrefs = pm->nrefs; H.noMirror = pm->no_mirror;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
@@ -3694,7 +3699,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         }
         XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
         RowMap M;
-        M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = !lists ? pm->nrefs : 0;
+        M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = !lists ? pm->nrefs : 0; M.noMirror = pm->no_mirror;
         pm->stat_rows += masked ? listedRows : nrows;
         const size_t smem64 = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N) + (n_orient > 1 ? sizeof(double) * 2 * L.N : 0);
         if (n_orient > 1) {
