@@ -464,6 +464,16 @@ int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t 
  * matcher with the mirror search off (xh_pm_set_option "mirror" 0): cubic instead of linear polar sampling, see xh_estimators.hip. */
 int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring,
                          float *h_rotations);
+/* BSplineGeoTransformer<T>::interpolate (reconstruction/bspline_geo_transformer.cpp:103-137): d_dst[i] = applyGeometry(LINEAR, d_src[i],
+ * h_matrices[i] (3 x 3 row major), IS_INV, DONT_WRAP), outside value 0; d_src and d_dst [n][ydim][xdim], not aliased */
+int xh_apply_geometry2d(xh_ctx *ctx, const float *d_src, int32_t n, int32_t ydim, int32_t xdim, const float *h_matrices, float *d_dst);
+/* CorrelationComputer<T>, OneToN, normalised (reconstruction/correlation_computer.cpp:30-56): h_merit[i] = correlationIndex(ref, others[i]) */
+int xh_correlation_merit(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t ydim, int32_t xdim, float *h_merit);
+/* Alignment::IterativeAlignmentEstimator<T>::compute(others, iters) (reconstruction/iterative_alignment_estimator.cpp:96-176) over the three
+ * estimators above: rotation -> shift and shift -> rotation, `iters` rounds each, the images re-interpolated from the originals by the
+ * inverse pose after every step; per image the order with the better merit. h_poses [n][9], h_merit [n]. */
+int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t max_shift, int32_t first_ring,
+                           int32_t last_ring, int32_t iters, float *h_poses, float *h_merit);
 
 #ifdef __cplusplus
 }

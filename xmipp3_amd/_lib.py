@@ -97,6 +97,9 @@ SIGNATURES = {
     "xh_shiftcorr_load_reference": (C.c_int, [vp, vp]),
     "xh_shiftcorr_correlate": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
     "xh_shiftcorr_compute_shifts": (C.c_int, [vp, vp, i32, vp]),
+    "xh_apply_geometry2d": (C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
+    "xh_correlation_merit": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "xh_iterative_alignment": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "xh_rotation_estimate": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "xh_movie_dose_filter": (C.c_int, [vp, vp, vp, i32, i32, d, d, d, d]),
     "xh_fa_correlate": (C.c_int, [vp, vp, i32, i32, i32, C.c_float, vp]),

@@ -531,6 +531,41 @@ def rotation_estimate(ctx, ref, others, first_ring=None, last_ring=None):
     return out
 
 
+def apply_geometry2d(ctx, src, matrices):
+    """BSplineGeoTransformer::interpolate: src [n, y, x] float32 on the device, matrices [n, 3, 3] (applyGeometry LINEAR, IS_INV, DONT_WRAP)"""
+    torch = _torch()
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3
+    m = np.ascontiguousarray(matrices, np.float32).reshape(src.shape[0], 9)
+    out = torch.empty_like(src)
+    check(lib().xh_apply_geometry2d(ctx.h, _ptr(src), src.shape[0], src.shape[1], src.shape[2], _np_ptr(m), _ptr(out)))
+    return out
+
+
+def correlation_merit(ctx, ref, others):
+    """CorrelationComputer (OneToN, normalised): correlationIndex(ref, others[i]) -> float32 [n]"""
+    torch = _torch()
+    assert ref.is_cuda and others.is_cuda and ref.dtype == others.dtype == torch.float32 and ref.is_contiguous() and others.is_contiguous()
+    out = np.empty(others.shape[0], np.float32)
+    check(lib().xh_correlation_merit(ctx.h, _ptr(ref), _ptr(others), others.shape[0], others.shape[1], others.shape[2], _np_ptr(out)))
+    return out
+
+
+def iterative_alignment(ctx, ref, others, max_shift, iters=3, first_ring=None, last_ring=None):
+    """IterativeAlignmentEstimator::compute: ref [D, D], others [n, D, D] -> (poses [n, 3, 3] float32, merit [n])"""
+    torch = _torch()
+    D = ref.shape[-1]
+    assert ref.is_cuda and ref.dtype == torch.float32 and ref.is_contiguous() and tuple(ref.shape) == (D, D)
+    assert others.is_cuda and others.dtype == torch.float32 and others.is_contiguous() and tuple(others.shape[1:]) == (D, D)
+    if first_ring is None:
+        first_ring = max(2, D // 20)
+    if last_ring is None:
+        last_ring = (D - 3) // 2
+    n = others.shape[0]
+    poses, merit = np.empty((n, 9), np.float32), np.empty(n, np.float32)
+    check(lib().xh_iterative_alignment(ctx.h, _ptr(ref), _ptr(others), n, D, int(max_shift), int(first_ring), int(last_ring), int(iters), _np_ptr(poses), _np_ptr(merit)))
+    return poses.reshape(n, 3, 3), merit
+
+
 class ShiftCorrEstimator:
     """Alignment::ShiftCorrEstimator<float>, AlignType::OneToN, for images of x by y pixels (even)."""
 

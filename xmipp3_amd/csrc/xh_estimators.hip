@@ -11,7 +11,11 @@
 //   Alignment::PolarRotationEstimator<T>    reconstruction/polar_rotation_estimator.cpp:33-144, AlignType::OneToN: rotation of n images
 //                                           against one reference = arg-max of the rotational correlation of their polar Fourier
 //                                           transforms over the rings firstRing .. lastRing (data/polar.cpp:99-148,212-231)
-// The iterative alignment estimator is not built.
+//   Alignment::IterativeAlignmentEstimator<T>  reconstruction/iterative_alignment_estimator.cpp:33-176: rotation and shift estimated in turn,
+//                                           the images re-interpolated from the originals by the inverse pose after every step
+//                                           (BSplineGeoTransformer::interpolate, bspline_geo_transformer.cpp:103-137: applyGeometry
+//                                           LINEAR, IS_INV, DONT_WRAP), both orders tried, the better correlationIndex
+//                                           (CorrelationComputer, correlation_computer.cpp:30-56) kept per image
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -91,6 +95,68 @@ __global__ void __launch_bounds__(256) k_es_real(const es_cf *__restrict__ in, f
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t < tot) out[t] = in[t].x;
+}
+
+// applyGeometry(LINEAR, out, in, A, IS_INV, DONT_WRAP) of xmippCore's 2-D branch, outside value 0: out(x, y) = in at A (x, y, 1) in
+// logical (Xmipp origin) coordinates, bilinear, pixels that map outside the image stay 0. A: [n][9] doubles, one matrix per image.
+__global__ void __launch_bounds__(256) k_es_apply_geometry(const float *__restrict__ in, const double *__restrict__ A9, float *__restrict__ out, int ydim, int xdim)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)ydim * xdim) return;
+    const int i = (int)(t / xdim), j = (int)(t - (size_t)i * xdim);
+    const double *A = A9 + 9 * (size_t)blockIdx.y;
+    const float *V1 = in + (size_t)blockIdx.y * ydim * xdim;
+    const int cen_y = ydim / 2, cen_x = xdim / 2;
+    const double eps = 1e-6;                                   // XMIPP_EQUAL_ACCURACY
+    const double minxp = -cen_x, minyp = -cen_y, maxxp = xdim - cen_x - 1, maxyp = ydim - cen_y - 1;
+    const double x = j - cen_x, y = i - cen_y;
+    const double xp = x * A[0] + y * A[1] + A[2], yp = x * A[3] + y * A[4] + A[5];
+    double val = 0.0;
+    if (!(xp < minxp - eps || xp > maxxp + eps || yp < minyp - eps || yp > maxyp + eps)) {
+        double wx = xp + cen_x;
+        const int m1 = (int)wx;
+        wx = wx - m1;
+        const int m2 = m1 + 1;
+        double wy = yp + cen_y;
+        const int n1 = (int)wy;
+        wy = wy - n1;
+        const int n2 = n1 + 1;
+        const double wx_1 = 1 - wx, wy_1 = 1 - wy;
+        double aux2 = wy_1 * wx_1;
+        double tmp = aux2 * (double)V1[(size_t)n1 * xdim + m1];
+        if (wx != 0 && m2 < xdim) tmp += (wy_1 - aux2) * (double)V1[(size_t)n1 * xdim + m2];
+        if (wy != 0 && n2 < ydim) {
+            aux2 = wy * wx_1;
+            tmp += aux2 * (double)V1[(size_t)n2 * xdim + m1];
+            if (wx != 0 && m2 < xdim) tmp += (wy - aux2) * (double)V1[(size_t)n2 * xdim + m2];
+        }
+        val = tmp;
+    }
+    out[(size_t)blockIdx.y * ydim * xdim + t] = (float)val;
+}
+
+// correlationIndex(ref, other) of xmippCore without a mask (population statistics: its N / (N - 1) is an integer division); block per image
+__global__ void __launch_bounds__(256) k_es_corr_index(const float *__restrict__ ref, const float *__restrict__ others, size_t N, float *__restrict__ merit)
+{
+    __shared__ double red[5][256];
+    const float *y = others + (size_t)blockIdx.x * N;
+    double mx = 0, my = 0, sx = 0, sy = 0, sxy = 0;
+    for (size_t i = threadIdx.x; i < N; i += 256) { const double a = ref[i], b = y[i]; mx += a; my += b; sx += a * a; sy += b * b; sxy += a * b; }
+    red[0][threadIdx.x] = mx; red[1][threadIdx.x] = my; red[2][threadIdx.x] = sx; red[3][threadIdx.x] = sy; red[4][threadIdx.x] = sxy;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double n = (double)N;
+    mx = red[0][0] / n; my = red[1][0] / n;
+    const double f = N > 1 ? (double)(N / (N - 1)) : 0.0;
+    sx = sqrt(fabs((red[2][0] / n - mx * mx) * f)); sy = sqrt(fabs((red[3][0] / n - my * my) * f));
+    double r = 0;
+    if (!(fabs(sx) < 1e-6 || fabs(sy) < 1e-6)) r = (red[4][0] - n * mx * my) / ((sx * sy) * n);          // sum (x - mx)(y - my) = sum xy - n mx my
+    merit[blockIdx.x] = (float)r;
 }
 }  // namespace
 
@@ -258,6 +324,121 @@ int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others,
     if (rc != XH_OK) return rc;
     for (int i = 0; i < n; ++i) h_rotations[i] = (float)(((N - psi[i]) % N) * (360.0 / N));
     return XH_OK;
+}
+
+// BSplineGeoTransformer<T>::interpolate (bspline_geo_transformer.cpp:103-137): image i of d_src through matrix h_matrices[i] (3 x 3, row
+// major, as applyGeometry(LINEAR, out, in, M, IS_INV, DONT_WRAP) takes it: out(p) = in(M p))
+int xh_apply_geometry2d(xh_ctx *ctx, const float *d_src, int32_t n, int32_t ydim, int32_t xdim, const float *h_matrices, float *d_dst)
+{
+    XH_CHECK(ctx && d_src && d_dst && h_matrices && n >= 1 && ydim >= 1 && xdim >= 1 && d_src != d_dst, XH_ERR_ARG, "xh_apply_geometry2d: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    std::vector<double> A(9 * (size_t)n);
+    for (size_t i = 0; i < A.size(); ++i) A[i] = (double)h_matrices[i];
+    XhBuf bA;
+    XH_TRY(xh_buf_alloc(ctx, bA, sizeof(double) * A.size()));
+    int rc = XH_OK;
+    if (hipMemcpyAsync(bA.p, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK) {
+        const size_t per = (size_t)ydim * xdim;
+        hipLaunchKernelGGL(k_es_apply_geometry, dim3((unsigned)((per + 255) / 256), n), dim3(256), 0, ctx->stream, d_src, (const double *)bA.p, d_dst, ydim, xdim);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    }
+    xh_buf_free(bA);
+    if (rc == XH_ERR_HIP) xh_set_error("xh_apply_geometry2d: device error");
+    return rc;
+}
+
+// CorrelationComputer<T>::compute, MeritType::OneToN, normalizeResult (correlation_computer.cpp:30-56): correlationIndex(ref, other)
+int xh_correlation_merit(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t ydim, int32_t xdim, float *h_merit)
+{
+    XH_CHECK(ctx && d_ref && d_others && h_merit && n >= 1 && ydim >= 1 && xdim >= 1, XH_ERR_ARG, "xh_correlation_merit: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    XhBuf b;
+    XH_TRY(xh_buf_alloc(ctx, b, sizeof(float) * n));
+    int rc = XH_OK;
+    hipLaunchKernelGGL(k_es_corr_index, dim3(n), dim3(256), 0, ctx->stream, d_ref, d_others, (size_t)ydim * xdim, (float *)b.p);
+    if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipMemcpyAsync(h_merit, b.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+    xh_buf_free(b);
+    if (rc == XH_ERR_HIP) xh_set_error("xh_correlation_merit: device error");
+    return rc;
+}
+
+// IterativeAlignmentEstimator<T>::compute(others, iters) (iterative_alignment_estimator.cpp:96-176) for n square images of D pixels (even)
+// against one reference: h_poses [n][9] (3 x 3 float, row major) and h_merit [n]. The estimators underneath are the three above.
+int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t max_shift, int32_t first_ring, int32_t last_ring,
+                           int32_t iters, float *h_poses, float *h_merit)
+{
+    XH_CHECK(ctx && d_ref && d_others && h_poses && h_merit && n >= 1 && iters >= 1, XH_ERR_ARG, "xh_iterative_alignment: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    xh_shiftcorr *sc = nullptr;
+    XH_TRY(xh_shiftcorr_create(ctx, D, D, max_shift, &sc));
+    const size_t per = (size_t)D * D;
+    XhBuf bDest;
+    int rc = xh_buf_alloc(ctx, bDest, sizeof(float) * per * (size_t)n);
+    if (rc == XH_OK) rc = xh_shiftcorr_load_reference(sc, d_ref);
+    float *dest = (float *)bDest.p;
+    std::vector<float> rot(n), sh(2 * (size_t)n), inv(9 * (size_t)n);
+    auto applyTransform = [&](const std::vector<float> &poses) {
+        // M3x3_INV of every pose (float), then the transformer interpolates the ORIGINAL images with it
+        for (int j = 0; j < n; ++j) {
+            const float *m = &poses[9 * (size_t)j];
+            float *o = &inv[9 * (size_t)j];
+            o[0] = m[8] * m[4] - m[7] * m[5]; o[1] = -(m[8] * m[1] - m[7] * m[2]); o[2] = m[5] * m[1] - m[4] * m[2];
+            o[3] = -(m[8] * m[3] - m[6] * m[5]); o[4] = m[8] * m[0] - m[6] * m[2]; o[5] = -(m[5] * m[0] - m[3] * m[2]);
+            o[6] = m[7] * m[3] - m[6] * m[4]; o[7] = -(m[7] * m[0] - m[6] * m[1]); o[8] = m[4] * m[0] - m[3] * m[1];
+            const float det = m[0] * o[0] + m[3] * o[1] + m[6] * o[2];
+            for (int q = 0; q < 9; ++q) o[q] /= det;
+        }
+        return xh_apply_geometry2d(ctx, d_others, n, D, D, inv.data(), dest);
+    };
+    auto pass = [&](bool rotationFirst, std::vector<float> &poses, std::vector<float> &merit) {
+        poses.assign(9 * (size_t)n, 0.f);
+        for (int j = 0; j < n; ++j) poses[9 * (size_t)j] = poses[9 * (size_t)j + 4] = poses[9 * (size_t)j + 8] = 1.f;
+        int r2 = hipMemcpyAsync(dest, d_others, sizeof(float) * per * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? XH_OK : XH_ERR_HIP;   // copySrcToDest
+        auto stepRotation = [&]() {
+            int r3 = xh_rotation_estimate(ctx, d_ref, dest, n, D, first_ring, last_ring, rot.data());
+            if (r3 != XH_OK) return r3;
+            for (int j = 0; j < n; ++j) {
+                // rotation2DMatrix(angle, r); lhs = r * lhs
+                const double a = (double)rot[j] * 3.14159265358979323846 / 180.0;
+                const float c = (float)std::cos(a), s = (float)std::sin(a);
+                float *m = &poses[9 * (size_t)j];
+                const float r[9] = {c, s, 0.f, -s, c, 0.f, 0.f, 0.f, 1.f};
+                float o[9];
+                for (int p = 0; p < 3; ++p)
+                    for (int q = 0; q < 3; ++q) o[3 * p + q] = r[3 * p] * m[q] + r[3 * p + 1] * m[3 + q] + r[3 * p + 2] * m[6 + q];
+                for (int q = 0; q < 9; ++q) m[q] = o[q];
+            }
+            return applyTransform(poses);
+        };
+        auto stepShift = [&]() {
+            int r3 = xh_shiftcorr_compute_shifts(sc, dest, n, sh.data());
+            if (r3 != XH_OK) return r3;
+            for (int j = 0; j < n; ++j) { poses[9 * (size_t)j + 2] += sh[2 * j]; poses[9 * (size_t)j + 5] += sh[2 * j + 1]; }
+            return applyTransform(poses);
+        };
+        for (int i = 0; i < iters && r2 == XH_OK; ++i) {
+            if (rotationFirst) { r2 = stepRotation(); if (r2 == XH_OK) r2 = stepShift(); }
+            else { r2 = stepShift(); if (r2 == XH_OK) r2 = stepRotation(); }
+        }
+        merit.assign(n, 0.f);
+        if (r2 == XH_OK) r2 = xh_correlation_merit(ctx, d_ref, dest, n, D, D, merit.data());
+        return r2;
+    };
+    std::vector<float> pRS, mRS, pSR, mSR;
+    if (rc == XH_OK) rc = pass(true, pRS, mRS);
+    if (rc == XH_OK) rc = pass(false, pSR, mSR);
+    if (rc == XH_OK)
+        for (int j = 0; j < n; ++j) {
+            const bool sr = mRS[j] < mSR[j];
+            h_merit[j] = sr ? mSR[j] : mRS[j];
+            std::memcpy(h_poses + 9 * (size_t)j, (sr ? pSR : pRS).data() + 9 * (size_t)j, 9 * sizeof(float));
+        }
+    xh_buf_free(bDest);
+    xh_shiftcorr_destroy(sc);
+    return rc;
 }
 
 }  // extern "C"
