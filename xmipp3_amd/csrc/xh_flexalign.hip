@@ -630,15 +630,27 @@ __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef,
     const float delta = 0.0001f;
     const float xPos = x / hX, yPos = y / hY;
     float sx = 0.f, sy = 0.f;
-    const int tEnd = min((int)tPos + 2, lT - 2), xEnd = min((int)xPos + 2, lX - 2), yEnd = min((int)yPos + 2, lY - 2);
-    for (int it = (int)tPos - 1; it <= tEnd; ++it) {
-        const float tT = d_fa_b3(tPos - it);
-        for (int ix = (int)xPos - 1; ix <= xEnd; ++ix) {
-            const float tX = d_fa_b3(xPos - ix) * tT;
-            for (int iy = (int)yPos - 1; iy <= yEnd; ++iy) {
-                const float tmp = d_fa_b3(yPos - iy) * tX;
+    // the spline weights of the (at most) four control points per axis, evaluated once (the reference's loops evaluate them inside
+    // one another: same values, same products bY (bX bT), same cut)
+    const int tB = (int)tPos - 1, xB = (int)xPos - 1, yB = (int)yPos - 1;
+    const int nT = min((int)tPos + 2, lT - 2) - tB + 1, nX = min((int)xPos + 2, lX - 2) - xB + 1, nY = min((int)yPos + 2, lY - 2) - yB + 1;
+    float bT[4], bX[4], bY[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bT[i] = d_fa_b3(tPos - (tB + i)); bX[i] = d_fa_b3(xPos - (xB + i)); bY[i] = d_fa_b3(yPos - (yB + i)); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (a >= nT) break;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= nX) break;
+            const float tX = bX[b] * bT[a];
+            const int ob = (tB + a - t0) * nl + (xB + b + 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= nY) break;
+                const float tmp = bY[c] * tX;
                 if (tmp > delta) {
-                    const int o = (it - t0) * nl + (iy + 1) * lX + (ix + 1);
+                    const int o = ob + (yB + c + 1) * lX;
                     sx += scX[o] * tmp; sy += scY[o] * tmp;
                 }
             }
