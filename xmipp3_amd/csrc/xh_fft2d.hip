@@ -9,6 +9,8 @@
 //     2. multiply element (k1, n2) by exp(-+2 pi i k1 n2 / N)                    k_fft2d_twiddle
 //     3. N1 transforms of length N2 over n2 (contiguous)                         xh_k_fft_lines
 //     4. X[k1 + N1 k2] sits at N2 k1 + k2: transpose the N1 x N2 matrix          k_fft2d_untangle (out of place)
+// When N = (odd factor <= 64) x (power of two), step 1 is a direct DFT of the odd length instead (k_fft2d_small: 45 points cost 45
+// multiply-adds per output, against three 128-point transforms of the chirp-z form): 5760 = 45 x 128, the K3 frame's long side.
 // Rows (contiguous lines) and columns (lines nx apart) take the same four steps with different strides. Un-normalised
 // like the line kernels; xh_fft2d_exec divides by ny nx on the inverse.
 #include "xh_common.h"
@@ -16,6 +18,7 @@
 #include "xh_plan.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 typedef xh_c2<float> xh_cf;
@@ -27,6 +30,8 @@ struct Axis {
     int n = 0, n1 = 0, n2 = 1;
     XhPlanBufs<float> p1, p2;        // length n1 (or n when direct), length n2
     XhBuf tw;                        // exp(-2 pi i j / n), j < n (four-step only)
+    bool small1 = false;             // step 1 as a direct DFT of n1 <= 64 points (k_fft2d_small)
+    XhBuf tw1;                       // exp(-2 pi i j / n1), j < n1
 };
 
 // largest line xh_k_fft_lines takes in 64 KB of LDS with at least four lines per workgroup
@@ -94,6 +99,52 @@ __global__ void __launch_bounds__(256) k_fft2d_scale(xh_cf *__restrict__ d, size
     if (i < total) { d[i].x *= scale; d[i].y *= scale; }
 }
 
+// Direct DFT of short lines (n <= 64 points, elemStride apart; consecutive lines are innerStride apart, `inner` of them per outer
+// step, like xh_k_fft_lines). A block stages 128 lines in LDS ([n][128]: a wave reads 64 neighbouring lines of one element, no
+// conflicts) and its two halves share the outputs of a line (k = half, half + 2, ...); the twiddle of a (j, k) is the same for the
+// whole wave. In place.
+template <bool INV>
+__global__ void __launch_bounds__(256) k_fft2d_small(xh_cf *__restrict__ data, const xh_cf *__restrict__ tw, int n, size_t nlines, size_t inner, size_t outerStride,
+                                                     size_t innerStride, size_t elemStride)
+{
+    extern __shared__ xh_cf ssm[];            // [n][128] samples, then [n] twiddles
+    xh_cf *sx = ssm, *sw = ssm + (size_t)n * 128;
+    const size_t l0 = (size_t)blockIdx.x * 128;
+    for (int j = threadIdx.x; j < n; j += 256) { xh_cf w = tw[j]; if (INV) w.y = -w.y; sw[j] = w; }
+    for (int i = threadIdx.x; i < n * 128; i += 256) {
+        const int j = i >> 7, ll = i & 127;
+        const size_t l = l0 + ll;
+        sx[i] = l < nlines ? data[(l / inner) * outerStride + (l % inner) * innerStride + (size_t)j * elemStride] : xh_cf{0.f, 0.f};
+    }
+    __syncthreads();
+    const int ll = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const size_t l = l0 + ll;
+    if (l >= nlines) return;
+    xh_cf *dst = data + (l / inner) * outerStride + (l % inner) * innerStride;
+    for (int k = half; k < n; k += 2) {
+        float re = 0.f, im = 0.f;
+        int m = 0;
+        for (int j = 0; j < n; ++j) {
+            const xh_cf x = sx[(j << 7) + ll], w = sw[m];
+            re += x.x * w.x - x.y * w.y; im += x.x * w.y + x.y * w.x;
+            m += k; if (m >= n) m -= n;
+        }
+        dst[(size_t)k * elemStride] = xh_cf{re, im};
+    }
+}
+
+int small_lines(xh_ctx *ctx, xh_cf *data, const Axis &A, size_t nlines, size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, bool inverse)
+{
+    const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
+    const unsigned grid = (unsigned)((nlines + 127) / 128);
+    if (inverse)
+        hipLaunchKernelGGL((k_fft2d_small<true>), dim3(grid), dim3(256), smem, ctx->stream, data, (const xh_cf *)A.tw1.p, A.n1, nlines, inner, outerStride, innerStride, elemStride);
+    else
+        hipLaunchKernelGGL((k_fft2d_small<false>), dim3(grid), dim3(256), smem, ctx->stream, data, (const xh_cf *)A.tw1.p, A.n1, nlines, inner, outerStride, innerStride, elemStride);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
 int axis_create(xh_ctx *ctx, int n, Axis &A)
 {
     A.n = n;
@@ -101,8 +152,18 @@ int axis_create(xh_ctx *ctx, int n, Axis &A)
         A.n1 = n; A.n2 = 1;
         return xh_plan_create<float>(ctx, n, A.p1);
     }
-    XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
-    XH_TRY(xh_plan_create<float>(ctx, A.n1, A.p1));
+    // an odd factor of at most 64 points times a power of two: the odd part directly, the rest by the radix kernels
+    int odd = n, p2 = 1;
+    while ((odd & 1) == 0) { odd >>= 1; p2 <<= 1; }
+    if (odd > 1 && odd <= 64 && p2 >= 2 && direct_ok(p2) && !getenv("XH_FFT2D_NO_SMALL")) { A.n1 = odd; A.n2 = p2; A.small1 = true; }
+    else XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
+    if (A.small1) {
+        const long double PI1 = 3.14159265358979323846264338327950288L;
+        std::vector<xh_cf> w1(A.n1);
+        for (int j = 0; j < A.n1; ++j) { const long double a = -2.0L * PI1 * j / A.n1; w1[j] = xh_cf{(float)cosl(a), (float)sinl(a)}; }
+        XH_TRY(xh_buf_alloc(ctx, A.tw1, sizeof(xh_cf) * A.n1));
+        XH_HIP(hipMemcpy(A.tw1.p, w1.data(), A.tw1.bytes, hipMemcpyHostToDevice));
+    } else XH_TRY(xh_plan_create<float>(ctx, A.n1, A.p1));
     XH_TRY(xh_plan_create<float>(ctx, A.n2, A.p2));
     const long double PI = 3.14159265358979323846264338327950288L;
     std::vector<xh_cf> w(n);
@@ -120,6 +181,7 @@ void axis_free(Axis &A)
     xh_plan_free(A.p1);
     xh_plan_free(A.p2);
     xh_buf_free(A.tw);
+    xh_buf_free(A.tw1);
 }
 
 int lines(xh_ctx *ctx, xh_cf *data, const XhPlan<float> &plan, size_t nlines, size_t inner, size_t outerStride, size_t innerStride,
@@ -153,7 +215,8 @@ int axis_exec(xh_ctx *ctx, const Axis &A, xh_cf *data, xh_cf *other, size_t coun
         // rows: sub-line (l, n2) starts at base(l) + n2, elements n2 apart; needs inner == count (one row after the other)
         XH_CHECK(inner == count || innerStride == outerStride / inner, XH_ERR_ARG, "xh_fft2d: rows must be evenly spaced");
         const size_t rowStride = inner == count ? innerStride : outerStride / inner;
-        XH_TRY(lines(ctx, data, A.p1.plan, count * n2, n2, rowStride, 1, n2, inverse));
+        if (A.small1) XH_TRY(small_lines(ctx, data, A, count * n2, n2, rowStride, 1, n2, inverse));
+        else XH_TRY(lines(ctx, data, A.p1.plan, count * n2, n2, rowStride, 1, n2, inverse));
         const size_t total = count * A.n;
         hipLaunchKernelGGL(k_fft2d_twiddle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, data, (const xh_cf *)A.tw.p, total,
                            A.n, A.n2, (size_t)1, rowStride, (size_t)0, (size_t)1, inverse ? 1 : 0);
@@ -166,7 +229,8 @@ int axis_exec(xh_ctx *ctx, const Axis &A, xh_cf *data, xh_cf *other, size_t coun
         // columns of a row-major array: count = nx columns, elemStride = nx
         XH_CHECK(inner == count && innerStride == 1, XH_ERR_ARG, "xh_fft2d: columns must be neighbours");
         const size_t nx = elemStride;
-        XH_TRY(lines(ctx, data, A.p1.plan, count * n2, count, nx, 1, nx * n2, inverse));            // (x, n2): start n2 nx + x
+        if (A.small1) XH_TRY(small_lines(ctx, data, A, count * n2, count, nx, 1, nx * n2, inverse));
+        else XH_TRY(lines(ctx, data, A.p1.plan, count * n2, count, nx, 1, nx * n2, inverse));            // (x, n2): start n2 nx + x
         const size_t total = count * A.n;
         hipLaunchKernelGGL(k_fft2d_twiddle, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, data, (const xh_cf *)A.tw.p, total,
                            A.n, A.n2, count, (size_t)0, (size_t)1, nx, inverse ? 1 : 0);
