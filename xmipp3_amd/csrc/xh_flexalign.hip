@@ -435,6 +435,91 @@ __global__ void __launch_bounds__(256) k_fa_gemm(const float *__restrict__ A, si
     }
 }
 
+// The same products on the matrix cores (v_mfma_f32_32x32x2_f32, fp32 in, fp32 accumulate): a complex B [K][Nc] is a real matrix of
+// 2 Nc columns as it lies in memory, so real A x complex B is one real product; a complex A splits into Ar B + Ai (i B), i.e. a
+// real product over 2 K with the rows of i B = (-Bi, Br) formed while B is staged. Block = 128 x 128 of the real C, four waves of
+// 64 x 64 (2 x 2 MFMA tiles), K in steps of 16 through LDS.
+typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
+template <bool ACPLX>
+__global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ A, size_t lda, size_t sA, const fa_cf *__restrict__ B, size_t ldb, size_t sB,
+                                                      fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K)
+{
+    constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
+    __shared__ float As[BK][LD], Bs[BK][LD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w & 1, wn = w >> 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;          // n0: real column
+    const int N2 = 2 * Nc, K2 = ACPLX ? 2 * K : K;
+    A += sA * blockIdx.z * (ACPLX ? 2 : 1);
+    const float *Bf = reinterpret_cast<const float *>(B + sB * blockIdx.z);
+    float *Cf = reinterpret_cast<float *>(C + sC * blockIdx.z);
+    fa_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int arow = t >> 1, akseg = (t & 1) * 8;                  // A tile: 128 rows x 16 k, eight consecutive k per thread
+    const int bk = t >> 4, bcseg = (t & 15) * 8;                   // B tile: 16 k x 128 real columns, eight consecutive columns per thread
+    for (int k0 = 0; k0 < K2; k0 += BK) {
+        float av[8], bv[8];
+        {
+            const int m = m0 + arow;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kk = k0 + akseg + q;
+                float v = 0.f;
+                if (m < M && kk < K2) {
+                    if (!ACPLX) v = A[(size_t)m * lda + kk];
+                    else v = kk < K ? A[((size_t)m * lda + kk) * 2] : A[((size_t)m * lda + (kk - K)) * 2 + 1];
+                }
+                av[q] = v;
+            }
+            const int kk = k0 + bk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = n0 + bcseg + q;
+                float v = 0.f;
+                if (kk < K2 && c < N2) {
+                    if (!ACPLX || kk < K) v = Bf[(size_t)kk * 2 * ldb + c];
+                    else {
+                        const float *br = Bf + (size_t)(kk - K) * 2 * ldb;        // row of i B: (-Bi, Br)
+                        v = (c & 1) ? br[c - 1] : -br[c + 1];
+                    }
+                }
+                bv[q] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { As[akseg + q][arow] = av[q]; Bs[bk][bcseg + q] = bv[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5), l31 = lane & 31;
+            const float a0 = As[kr][wm * 64 + l31], a1 = As[kr][wm * 64 + 32 + l31];
+            const float b0 = Bs[kr][wn * 64 + l31], b1 = Bs[kr][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D[row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][col = lane & 31]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (c >= N2) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m < M) Cf[(size_t)m * 2 * ldc + c] = acc[i][j][e];
+            }
+        }
+}
+
 // S[t] = filter * sum of the single-frame spectra of the frames t - (avg-1)/2 .. t + avg/2
 __global__ void __launch_bounds__(256) k_fa_patch_sum(const fa_cf *__restrict__ single, fa_cf *__restrict__ S, const float *__restrict__ filter, int N, int nFrames, size_t E, int avg)
 {
@@ -839,6 +924,7 @@ struct xh_fa {
     xh_fft2d *rows, *cols, *small;        // rows: (Y+1)/2 packed rows of X points; cols: the nc kept columns of Y points; small: a pair map
     int nc;                               // columns of the frame transform the reduced frame keeps (nX/2 + 1)
     int lastFull = 0;                     // pairs of the last global alignment that went through the full transform
+    int use_mfma = 1;                     // the pruned-DFT products of the local alignment on the matrix cores (0: the vector-ALU kernel)
     int use_window = 1;                   // pair correlations inside the search window only (0: every pair through the full transform)
     XhBuf work, spectra, lpf, pair, part, res, warpC;
     int capFrames;
@@ -900,6 +986,7 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value)
 {
     XH_CHECK(h && name, XH_ERR_ARG, "xh_fa_set_option: bad argument");
     if (!strcmp(name, "window")) h->use_window = value != 0;
+    else if (!strcmp(name, "mfma")) h->use_mfma = value != 0;
     else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1189,9 +1276,17 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
         hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2,
                            (float *)bPatch.p, nf, N, Y, X, PY, PX);
         // along x, all frames of all patches of the batch at once: [pb N PY][PX] x [PX][cxh]
+        if (h->use_mfma)
+            hipLaunchKernelGGL((k_fa_gemm_mfma<false>), dim3((2 * cxh + 127) / 128, (unsigned)(((size_t)nf * PY + 127) / 128), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p,
+                               (size_t)PX, (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX);
+        else
         hipLaunchKernelGGL((k_fa_gemm<false>), dim3((cxh + 31) / 32, (unsigned)(((size_t)nf * PY + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p, (size_t)PX,
                            (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX);
         // along y, frame by frame: [CY][PY] x [PY][cxh]
+        if (h->use_mfma)
+            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * cxh + 127) / 128, (CY + 127) / 128, nf), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
+                               (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
+        else
         hipLaunchKernelGGL((k_fa_gemm<true>), dim3((cxh + 31) / 32, (CY + 63) / 64, nf), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
                            (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
         hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)nf * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
