@@ -780,69 +780,65 @@ void mean_stddev(const std::vector<double> &v, double &mean, double &sd)
     if (n > 1) sd = std::sqrt(std::fabs((s2 / n - mean * mean) * ((double)n / (n - 1))));
 }
 
-// normal equations of the row-weighted system for both right-hand sides, Gauss-Jordan with partial pivoting
-void weighted_least_squares(std::vector<double> &A, int rows, int cols, const std::vector<double> &w, const std::vector<double> &bx,
-                            const std::vector<double> &by, std::vector<double> &sx, std::vector<double> &sy)
-{
-    std::vector<double> wbx(rows), wby(rows);
-    for (int i = 0; i < rows; ++i) {
-        const double q = std::sqrt(w[i]);
-        wbx[i] = bx[i] * q; wby[i] = by[i] * q;
-        for (int j = 0; j < cols; ++j) A[(size_t)i * cols + j] *= q;
-    }
-    const int W = cols + 2;
-    std::vector<double> M((size_t)cols * W, 0.0);
-    std::vector<int> nz(cols);
-    for (int i = 0; i < rows; ++i) {
-        // the rows are sparse (a run of ones in the alignment, 64 spline weights in the fit): the non-zero columns only, upper triangle
-        const double *r = &A[(size_t)i * cols];
-        int m = 0;
-        for (int p = 0; p < cols; ++p) if (r[p] != 0) nz[m++] = p;
-        for (int a = 0; a < m; ++a) {
-            const int p = nz[a];
-            const double rp = r[p];
-            double *Mp = &M[(size_t)p * W];
-            for (int b = a; b < m; ++b) Mp[nz[b]] += rp * r[nz[b]];
-            Mp[cols] += rp * wbx[i];
-            Mp[cols + 1] += rp * wby[i];
-        }
-    }
-    for (int p = 0; p < cols; ++p)
-        for (int q = 0; q < p; ++q) M[(size_t)p * W + q] = M[(size_t)q * W + p];
-    for (int k = 0; k < cols; ++k) {
-        int piv = k;
-        for (int r = k + 1; r < cols; ++r) if (std::fabs(M[(size_t)r * W + k]) > std::fabs(M[(size_t)piv * W + k])) piv = r;
-        if (piv != k) for (int c = 0; c < W; ++c) std::swap(M[(size_t)k * W + c], M[(size_t)piv * W + c]);
-        const double d = M[(size_t)k * W + k];
-        if (d == 0) continue;
-        for (int r = 0; r < cols; ++r) {
-            if (r == k) continue;
-            const double f = M[(size_t)r * W + k] / d;
-            if (f == 0) continue;
-            for (int c = k; c < W; ++c) M[(size_t)r * W + c] -= f * M[(size_t)k * W + c];
-        }
-    }
-    sx.assign(cols, 0.0); sy.assign(cols, 0.0);
-    for (int k = 0; k < cols; ++k) {
-        const double d = M[(size_t)k * W + k];
-        if (d != 0) { sx[k] = M[(size_t)k * W + cols] / d; sy[k] = M[(size_t)k * W + cols + 1] / d; }
-    }
-}
-
-// EquationSystemSolver::solve (eq_system_solver.cpp:35-106) for an observation matrix A0 [rows][cols]
+// EquationSystemSolver::solve (eq_system_solver.cpp:35-106) for an observation matrix A0 [rows][cols]: weighted least squares for
+// both right-hand sides (normal equations, Gauss-Jordan with partial pivoting), residuals against the row-weighted matrix, rows
+// beyond 3 sigma get weight 0, `iterations` rounds. The weights are 0 or 1 and the rows sparse (a run of ones in the alignment,
+// 64 spline weights in the fit): the rows are kept in compressed form, the normal equations of ALL rows are formed once, and a
+// round subtracts the rejected rows from them.
 void fa_solve_system(const std::vector<double> &A0, int rows, int cols, const std::vector<double> &bx, const std::vector<double> &by, int iterations,
                      std::vector<double> &sx, std::vector<double> &sy)
 {
-    std::vector<double> w(rows, 1.0);
+    std::vector<int> start(rows + 1, 0), idx;
+    std::vector<double> val;
+    for (int r = 0; r < rows; ++r) {
+        const double *a = &A0[(size_t)r * cols];
+        for (int c = 0; c < cols; ++c)
+            if (a[c] != 0) { idx.push_back(c); val.push_back(a[c]); }
+        start[r + 1] = (int)idx.size();
+    }
+    const int W = cols + 2;
+    auto addRow = [&](std::vector<double> &M, int r, double sign) {
+        for (int a = start[r]; a < start[r + 1]; ++a) {
+            const double rp = sign * val[a];
+            double *Mp = &M[(size_t)idx[a] * W];
+            for (int b = a; b < start[r + 1]; ++b) Mp[idx[b]] += rp * val[b];          // upper triangle
+            Mp[cols] += rp * bx[r];
+            Mp[cols + 1] += rp * by[r];
+        }
+    };
+    std::vector<double> Mall((size_t)cols * W, 0.0), w(rows, 1.0);
+    for (int r = 0; r < rows; ++r) addRow(Mall, r, 1.0);
     int it = 0;
     do {
-        std::vector<double> A = A0;
-        weighted_least_squares(A, rows, cols, w, bx, by, sx, sy);
+        std::vector<double> M = Mall;
+        for (int r = 0; r < rows; ++r)
+            if (w[r] == 0.0) addRow(M, r, -1.0);
+        for (int p = 0; p < cols; ++p)
+            for (int q = 0; q < p; ++q) M[(size_t)p * W + q] = M[(size_t)q * W + p];
+        for (int k = 0; k < cols; ++k) {
+            int piv = k;
+            for (int r = k + 1; r < cols; ++r) if (std::fabs(M[(size_t)r * W + k]) > std::fabs(M[(size_t)piv * W + k])) piv = r;
+            if (piv != k) for (int c = 0; c < W; ++c) std::swap(M[(size_t)k * W + c], M[(size_t)piv * W + c]);
+            const double d = M[(size_t)k * W + k];
+            if (d == 0) continue;
+            for (int r = 0; r < cols; ++r) {
+                if (r == k) continue;
+                const double f = M[(size_t)r * W + k] / d;
+                if (f == 0) continue;
+                for (int c = k; c < W; ++c) M[(size_t)r * W + c] -= f * M[(size_t)k * W + c];
+            }
+        }
+        sx.assign(cols, 0.0); sy.assign(cols, 0.0);
+        for (int k = 0; k < cols; ++k) {
+            const double d = M[(size_t)k * W + k];
+            if (d != 0) { sx[k] = M[(size_t)k * W + cols] / d; sy[k] = M[(size_t)k * W + cols + 1] / d; }
+        }
         std::vector<double> ex(rows), ey(rows);
         for (int r = 0; r < rows; ++r) {
             double px = 0, py = 0;
-            for (int c = 0; c < cols; ++c) { px += A[(size_t)r * cols + c] * sx[c]; py += A[(size_t)r * cols + c] * sy[c]; }
-            ex[r] = bx[r] - px; ey[r] = by[r] - py;       // (rows already rejected carry a zeroed A: their residual is b itself)
+            if (w[r] != 0.0)                                  // (rows already rejected carry a zeroed A: their residual is b itself)
+                for (int a = start[r]; a < start[r + 1]; ++a) { px += val[a] * sx[idx[a]]; py += val[a] * sy[idx[a]]; }
+            ex[r] = bx[r] - px; ey[r] = by[r] - py;
         }
         double mean, sdx, sdy;
         mean_stddev(ex, mean, sdx);
