@@ -19,7 +19,7 @@ def synthetic_movie(N, Y, X, seed, max_step=1.5, noise=0.5, smooth=3.0):
     return frames, drift
 
 
-@pytest.mark.parametrize("N,Y,X,ts,res", [(8, 512, 512, 1.0, 8.0), (6, 240, 320, 1.0, 8.0), (5, 384, 300, 1.4, 12.0)])
+@pytest.mark.parametrize("N,Y,X,ts,res", [(8, 512, 512, 1.0, 8.0), (6, 240, 320, 1.0, 8.0), (5, 384, 300, 1.4, 12.0), (5, 241, 321, 1.0, 8.0), (4, 180, 720, 1.0, 8.0)])
 def test_global_alignment_against_the_oracle(gpu, oracle, N, Y, X, ts, res):
     """Pair shifts and frame shifts of the device against ProgMovieAlignmentCorrelation<double>'s arithmetic (oracle): square
     power-of-two frames, non-square ones whose reduced size is not a power of two (Bluestein lines), another sampling rate.
@@ -84,7 +84,8 @@ def test_errors_are_loud(gpu):
         fa.global_alignment(torch.zeros((3, 256, 256), device="cuda"), 500.0)       # --maxShift beyond the reduced frame
 
 
-@pytest.mark.parametrize("N,Y,X,patches,psize,cp,avg", [(8, 384, 384, (5, 5), (128, 128), (3, 3, 3), 3), (6, 300, 420, (4, 5), (100, 90), (3, 4, 3), 1)])
+@pytest.mark.parametrize("N,Y,X,patches,psize,cp,avg", [(8, 384, 384, (5, 5), (128, 128), (3, 3, 3), 3), (6, 300, 420, (4, 5), (100, 90), (3, 4, 3), 1),
+                                                        (5, 301, 423, (4, 4), (91, 120), (3, 3, 3), 2)])
 def test_local_alignment_against_the_oracle(gpu, oracle, N, Y, X, patches, psize, cp, avg):
     """computeLocalAlignment of the CUDA program: patch layout, patch shifts (pruned fp32 transforms against the oracle's double
     FFTs: 5e-3 px) and the B-spline fitted to them, evaluated over the field (the coefficients themselves are badly conditioned
