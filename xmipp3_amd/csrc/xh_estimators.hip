@@ -298,9 +298,8 @@ int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t 
 // (polar_rotation_estimator.cpp:60,99) -- the correlation values differ in the last digits, the angle by at most one sample of the
 // outer ring in near-ties. best_rotation correlates (reference, image) where the matcher correlates (image, reference):
 // the index is mirrored, result = ((N - psi) mod N) 360 / N degrees.
-int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring, float *h_rotations)
+static int es_rotation_create(xh_ctx *ctx, const float *d_ref, int32_t D, int32_t first_ring, int32_t last_ring, xh_pm **out, int32_t *N)
 {
-    XH_CHECK(ctx && d_ref && d_others && h_rotations && n >= 1, XH_ERR_ARG, "xh_rotation_estimate: bad argument");
     // RotationEstimationSetting::check + PolarRotationEstimator::check (arotation_estimator.h:80-130, polar_rotation_estimator.cpp:125-141)
     XH_CHECK(D >= 6, XH_ERR_ARG, "xh_rotation_estimate: The input signal is too small.");
     XH_CHECK(first_ring >= 1 && last_ring > first_ring && last_ring < D, XH_ERR_ARG, "xh_rotation_estimate: rings %d .. %d of a %d px image (first >= 1, last > first, last < size)",
@@ -309,10 +308,16 @@ int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others,
     xh_pm *pm = nullptr;
     XH_TRY(xh_pm_create(ctx, D, first_ring, last_ring, 1, d_ref, nullptr, 0, &pm));
     int rc = xh_pm_set_option(pm, "mirror", 0.0);
-    int32_t N = 0;
-    if (rc == XH_OK) rc = xh_pm_info(pm, &N, nullptr, nullptr);
+    if (rc == XH_OK) rc = xh_pm_info(pm, N, nullptr, nullptr);
+    if (rc != XH_OK) { xh_pm_destroy(pm); return rc; }
+    *out = pm;
+    return XH_OK;
+}
+
+static int es_rotation_run(xh_ctx *ctx, xh_pm *pm, int32_t N, const float *d_others, int32_t n, float *h_rotations)
+{
     XhBuf bRef, bPsi, bFlip;
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRef, sizeof(int32_t) * n);
+    int rc = xh_buf_alloc(ctx, bRef, sizeof(int32_t) * n);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPsi, sizeof(int32_t) * n);
     if (rc == XH_OK) rc = xh_buf_alloc(ctx, bFlip, n);
     if (rc == XH_OK) rc = xh_pm_match(pm, d_others, n, nullptr, nullptr, 0, (int32_t *)bRef.p, (int32_t *)bPsi.p, (uint8_t *)bFlip.p);
@@ -320,10 +325,20 @@ int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others,
     if (rc == XH_OK && hipMemcpyAsync(psi.data(), bPsi.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
     if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
     xh_buf_free(bRef); xh_buf_free(bPsi); xh_buf_free(bFlip);
-    xh_pm_destroy(pm);
     if (rc != XH_OK) return rc;
     for (int i = 0; i < n; ++i) h_rotations[i] = (float)(((N - psi[i]) % N) * (360.0 / N));
     return XH_OK;
+}
+
+int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring, float *h_rotations)
+{
+    XH_CHECK(ctx && d_ref && d_others && h_rotations && n >= 1, XH_ERR_ARG, "xh_rotation_estimate: bad argument");
+    xh_pm *pm = nullptr;
+    int32_t N = 0;
+    XH_TRY(es_rotation_create(ctx, d_ref, D, first_ring, last_ring, &pm, &N));
+    const int rc = es_rotation_run(ctx, pm, N, d_others, n, h_rotations);
+    xh_pm_destroy(pm);
+    return rc;
 }
 
 // BSplineGeoTransformer<T>::interpolate (bspline_geo_transformer.cpp:103-137): image i of d_src through matrix h_matrices[i] (3 x 3, row
@@ -374,6 +389,12 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
     XH_HIP(hipSetDevice(ctx->device));
     xh_shiftcorr *sc = nullptr;
     XH_TRY(xh_shiftcorr_create(ctx, D, D, max_shift, &sc));
+    xh_pm *pm = nullptr;                 // the rotation estimator: one matcher over the one reference for all rounds
+    int32_t Npsi = 0;
+    {
+        const int r0 = es_rotation_create(ctx, d_ref, D, first_ring, last_ring, &pm, &Npsi);
+        if (r0 != XH_OK) { xh_shiftcorr_destroy(sc); return r0; }
+    }
     const size_t per = (size_t)D * D;
     XhBuf bDest;
     int rc = xh_buf_alloc(ctx, bDest, sizeof(float) * per * (size_t)n);
@@ -398,7 +419,7 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
         for (int j = 0; j < n; ++j) poses[9 * (size_t)j] = poses[9 * (size_t)j + 4] = poses[9 * (size_t)j + 8] = 1.f;
         int r2 = hipMemcpyAsync(dest, d_others, sizeof(float) * per * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? XH_OK : XH_ERR_HIP;   // copySrcToDest
         auto stepRotation = [&]() {
-            int r3 = xh_rotation_estimate(ctx, d_ref, dest, n, D, first_ring, last_ring, rot.data());
+            int r3 = es_rotation_run(ctx, pm, Npsi, dest, n, rot.data());
             if (r3 != XH_OK) return r3;
             for (int j = 0; j < n; ++j) {
                 // rotation2DMatrix(angle, r); lhs = r * lhs
@@ -438,6 +459,7 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
         }
     xh_buf_free(bDest);
     xh_shiftcorr_destroy(sc);
+    xh_pm_destroy(pm);
     return rc;
 }
 
