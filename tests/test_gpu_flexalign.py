@@ -246,3 +246,19 @@ def test_dose_filter_against_the_oracle(gpu, oracle, Y, X):
         assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max() + 1e-6
     with pytest.raises(xa.XhError):
         xa.movie_dose_filter(fft, torch.from_numpy(fr).cuda(), 1.1, 120, 0.0, 2.0)
+
+
+def test_wide_correlation_maxima_take_the_full_transform(gpu, oracle):
+    """A very smooth movie: the maximum of a pair correlation is so wide that the square bestShift grows around it leaves the window
+    the pruned transforms cover (maxShift + 8); such pairs are flagged on the device and repeated through the full inverse transform,
+    and the shifts still equal the oracle's."""
+    from tests import synth
+    xa, ctx, torch = gpu
+    N, Y, X = 5, 256, 320
+    frames, drift, _ = synth.movie(N, Y, X, seed=21, smooth=30.0, noise=0.02)
+    exp = oracle.fa_global_alignment(frames, max_shift_px=6.0, max_res=8.0)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+    got = fa.global_alignment(torch.from_numpy(frames).cuda(), 6.0)
+    print("pairs through the full transform:", fa.last_full_pairs(), "of", len(exp["bX"]))
+    assert fa.last_full_pairs() > 0
+    assert np.abs(got["bX"] - exp["bX"]).max() <= 5e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 5e-3 and got["ref"] == exp["ref"]
