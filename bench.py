@@ -656,9 +656,12 @@ def main():
             torch.cuda.synchronize()
             with on_rf_stream():
                 rf.reset()
-                simg = rf.shift_images(particles[:nv].contiguous(), np.stack([ex[:nv], ey[:nv]], 1))
-                c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs[:nv]))
-                rf.insert(rf.prepare_images(simg), oang[:nv], ctf=c, modulator=m)
+                # through the calls the timed region makes: shifts and orientations as device arrays, CTF + FFT + records + gridding in one call
+                sx_t = torch.from_numpy(np.ascontiguousarray(ex[:nv], np.float64)).to(dev)
+                sy_t = torch.from_numpy(np.ascontiguousarray(ey[:nv], np.float64)).to(dev)
+                simg = rf.shift_images(particles[:nv].contiguous(), (sx_t, sy_t))
+                ang_t = torch.from_numpy(np.ascontiguousarray(oang[:nv], np.float64)).to(dev)
+                rf.insert_images(simg, ang_t, ctf_array=xa.RecFourier.ctf_param_array(ctfs[:nv]))
                 gv, gw = rf.temp_spaces()
                 gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
             out["parity_volume_rel_err"] = float(np.abs(gv - ev).max() / np.abs(ev).max())
