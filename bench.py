@@ -65,6 +65,7 @@ def parse(argv=None):
                     help="local search (APM:615-631): every particle is matched against the K references nearest to its true "
                          "direction only (ascending lists, as a sampling file holds them); 0: the whole bank")
     ap.add_argument("--pm-opt", action="append", default=[], help="name=value passed to xh_pm_set_option (A/B runs)")
+    ap.add_argument("--side-priority", type=int, default=0, help="experiment: priority of the reconstruction stream (-1 high, 0 default)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: q of every 4 CU groups to the matcher's stream, the others to the "
                     "reconstruction stream (hipExtStreamCreateWithCUMask); 0: no masks")
     ap.add_argument("--rf-opt", action="append", default=[], help="name=value passed to xh_rf_set_option (A/B runs)")
@@ -298,7 +299,7 @@ def main():
     # (LDS / VALU bound) runs beside the matching of batch k+1 (mostly HBM bound)
     import contextlib
     pipelined = bool(args.pipeline) and args.mode == "full"
-    side = (masked_side or torch.cuda.Stream(device=dev)) if pipelined else None
+    side = (masked_side or torch.cuda.Stream(device=dev, priority=args.side_priority)) if pipelined else None
     ctx_rf = ctx
     if pipelined:
         with torch.cuda.stream(side):
