@@ -47,7 +47,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    L = C.CDLL(build())
+    L = C.CDLL(os.environ.get("XO_ORACLE_LIB") or build())          # XO_ORACLE_LIB: another build of the same sources (sanitizer runs)
     vp = C.c_void_p
     i, d = C.c_int, C.c_double
     sig = {
