@@ -460,8 +460,9 @@ int xh_shiftcorr_load_reference(xh_shiftcorr *h, const float *d_ref);
 int xh_shiftcorr_correlate(xh_ctx *ctx, float *d_inout, const float *d_ref, int32_t n, int32_t fy, int32_t fx, int32_t center);
 int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t n, float *h_shifts);
 /* Alignment::PolarRotationEstimator<T>, AlignType::OneToN (reconstruction/polar_rotation_estimator.cpp:33-144): d_ref [D][D], d_others
- * [n][D][D] -> h_rotations [n] degrees as getRotations2D returns them (an image rotated by a reads 360 - a). Built on the projection
- * matcher with the mirror search off (xh_pm_set_option "mirror" 0): cubic instead of linear polar sampling, see xh_estimators.hip. */
+ * [n][D][D] -> h_rotations [n] degrees as getRotations2D returns them (an image rotated by a reads 360 - a). The reference's own
+ * arithmetic: rings sampled with BsplineOrder 1 (bilinear, zero outside), not normalised, correlation over 2 N - 1 angles
+ * (polar_rotation_estimator.cpp:58-60,94-99), double precision, the first maximum (data/polar.cpp:212-233). */
 int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring,
                          float *h_rotations);
 /* BSplineGeoTransformer<T>::interpolate (reconstruction/bspline_geo_transformer.cpp:103-137): d_dst[i] = applyGeometry(LINEAR, d_src[i],

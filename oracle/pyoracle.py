@@ -137,6 +137,15 @@ def lib():
         "xo_fp_project": (None, [vp, d, d, d, c_double_p, c_double_p]),
         "xo_frc_dpr": (i, [c_double_p, c_double_p, i, i, i, d, i, i, d, d, c_double_p, c_double_p, c_double_p,
                            c_double_p, c_double_p, c_double_p]),
+        "xo_es_rotation_corr_len": (i, [i, i]),
+        "xo_es_polar_rotation": (None, [c_double_p, c_double_p, i, i, i, i, c_double_p, c_double_p]),
+        "xo_es_shifts": (None, [c_float_p, c_float_p, i, i, i, i, c_float_p]),
+        "xo_es_rotations": (None, [c_float_p, c_float_p, i, i, i, i, c_float_p]),
+        "xo_es_iterative_pass": (None, [c_float_p, c_float_p, i, i, i, i, i, i, i, c_float_p, c_float_p]),
+        "xo_es_iterative_alignment": (None, [c_float_p, c_float_p, i, i, i, i, i, i, c_float_p, c_float_p]),
+        "xo_es_test_population": (i, [i, i, c_float_p, c_float_p]),
+        "xo_es_test_add_noise": (None, [c_float_p, C.c_size_t]),
+        "xo_es_test_make_others": (None, [c_float_p, i, i, c_float_p, c_float_p, c_float_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -666,3 +675,70 @@ class RF2:
         out = np.empty((self.D,) * 3, np.float64)
         L.xo_rf2_finish(self.h, _dp(out))
         return out
+
+
+# ---------------------------------------------------------------- estimator chain (xo_estimators.cpp, xo_polar.cpp)
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def es_default_rings(D):
+    """RotationEstimationSetting::getDefaultFirstRing / getDefaultLastRing (arotation_estimator.h:58-64)"""
+    return max(2, D // 20), (D - 3) // 2
+
+
+def es_polar_rotation(ref, others, first_ring=None, last_ring=None, with_corr=False):
+    """PolarRotationEstimator OneToN (polar_rotation_estimator.cpp:49-99): degrees per image; optionally the 2N - 1 correlation rows"""
+    ref, others = f64(ref), f64(others)
+    n, D = others.shape[0], ref.shape[0]
+    a, b = es_default_rings(D)
+    first_ring, last_ring = first_ring or a, last_ring or b
+    rot = np.empty(n)
+    corr = np.empty((n, lib().xo_es_rotation_corr_len(first_ring, last_ring))) if with_corr else None
+    lib().xo_es_polar_rotation(_dp(ref), _dp(others), n, D, first_ring, last_ring, _dp(rot), _dp(corr))
+    return (rot, corr) if with_corr else rot
+
+
+def es_shifts(ref, others, max_shift):
+    """ShiftCorrEstimator::computeShift2DOneToN (shift_corr_estimator.cpp:201-283): [n][2] = (x, y) of the correlation maximum"""
+    ref, others = _f32(ref), _f32(others)
+    n, Y, X = others.shape
+    out = np.empty((n, 2), np.float32)
+    lib().xo_es_shifts(_fp(ref), _fp(others), n, Y, X, int(max_shift), _fp(out))
+    return out
+
+
+def es_iterative_alignment(ref, others, max_shift, iters=3, first_ring=None, last_ring=None, order=None):
+    """IterativeAlignmentEstimator::compute(others, iters) (iterative_alignment_estimator.cpp:96-169); order = "RS" / "SR" runs one
+    half only.  Returns poses [n][3][3] (float) and merits [n]."""
+    ref, others = _f32(ref), _f32(others)
+    n, D = others.shape[0], ref.shape[0]
+    a, b = es_default_rings(D)
+    first_ring, last_ring = first_ring or a, last_ring or b
+    poses, merit = np.empty((n, 3, 3), np.float32), np.empty(n, np.float32)
+    if order is None:
+        lib().xo_es_iterative_alignment(_fp(ref), _fp(others), n, D, int(max_shift), first_ring, last_ring, int(iters), _fp(poses), _fp(merit))
+    else:
+        lib().xo_es_iterative_pass(_fp(ref), _fp(others), n, D, int(max_shift), first_ring, last_ring, int(iters), int(order == "RS"), _fp(poses), _fp(merit))
+    return poses, merit
+
+
+def es_test_population(draw, n):
+    """Size, shifts and rotations of draw `draw` of IterativeAlignmentEstimator_Test's engine (aiterative_alignment_tests.h:107-121)"""
+    sh, rot = np.empty((n, 2), np.float32), np.empty(n, np.float32)
+    size = lib().xo_es_test_population(int(draw), int(n), _fp(sh), _fp(rot))
+    return size, sh, rot
+
+
+def es_test_make_others(ref, shifts, rotations):
+    ref, shifts, rotations = _f32(ref), _f32(shifts), _f32(rotations)
+    n, D = rotations.shape[0], ref.shape[0]
+    out = np.empty((n, D, D), np.float32)
+    lib().xo_es_test_make_others(_fp(ref), D, n, _fp(shifts), _fp(rotations), _fp(out))
+    return out
+
+
+def es_test_add_noise(data):
+    data = _f32(data).copy()
+    lib().xo_es_test_add_noise(_fp(data), data.size)
+    return data

@@ -452,3 +452,119 @@ int xo_num_threads(void)
 #endif
 }
 }
+
+/* ---- PolarRotationEstimator (reconstruction/polar_rotation_estimator.cpp:49-99) -------------
+ * load2DReferenceOneToN: polarFourierTransform<false>(ref, ..., conjugated = false, firstRing, lastRing, plans, BsplineOrder = 1)
+ * computeRotation2DOneToN: the same with conjugated = true per image, then best_rotation (polar.cpp:212-233) over a correlation
+ * array of 2 * getSampleNoOuterRing() - 1 entries (:58).  BsplineOrder 1 = interpolatedElement2DOutsideZero (xmippCore
+ * multidim_array.h: bilinear, samples outside the image are 0; LIN_INTERP(a, l, h) = l + (h - l) * a), no normalisation. */
+static double es_interp_outside_zero(const double *img, int ydim, int xdim, double x, double y)
+{
+    const int x0 = (int)std::floor(x);
+    const double fx = x - x0;
+    const int x1 = x0 + 1;
+    const int y0 = (int)std::floor(y);
+    const double fy = y - y0;
+    const int y1 = y0 + 1;
+    const int i0 = xo::first_xmipp_index(ydim), j0 = xo::first_xmipp_index(xdim);
+    const int iF = i0 + ydim - 1, jF = j0 + xdim - 1;
+    auto at = [&](int i, int j) -> double {
+        if (j < j0 || j > jF || i < i0 || i > iF) return 0.0;
+        return img[(size_t)(i - i0) * xdim + (j - j0)];
+    };
+    const double d00 = at(y0, x0), d01 = at(y0, x1), d10 = at(y1, x0), d11 = at(y1, x1);
+    const double d0 = d00 + (d01 - d00) * fx;
+    const double d1 = d10 + (d11 - d10) * fx;
+    return d0 + (d1 - d0) * fy;
+}
+
+static void es_polar_linear(const Layout &L, const double *img, int D, double *rings)
+{
+    // polar.h:625-703 with BsplineOrder == 1
+    const double minp = xo::first_xmipp_index(D), maxp = xo::last_xmipp_index(D);
+    const double min_e = minp - XO_EQUAL_ACCURACY, max_e = maxp + XO_EQUAL_ACCURACY;
+    for (int r = 0; r < L.nrings; ++r)
+        for (int s = 0; s < L.nsam[r]; ++s) {
+            double xp = L.sinr[L.soff[r] + s], yp = L.cosr[L.soff[r] + s];
+            if (xp < min_e || xp > max_e) xp = xo::realWRAP(xp, minp - 0.5, maxp + 0.5);
+            if (yp < min_e || yp > max_e) yp = xo::realWRAP(yp, minp - 0.5, maxp + 0.5);
+            rings[L.soff[r] + s] = es_interp_outside_zero(img, D, D, xp, yp);
+        }
+}
+
+// rotationalCorrelation (polar.cpp:99-148) into a correlation array of `len` entries (Fsum has len / 2 + 1 of them, every ring
+// adds its nsam / 2 + 1 coefficients), inverse transform un-normalised
+static void es_rot_corr(const Layout &L, const cd *M1, const cd *M2, int len, double *corr)
+{
+    const int nh = len / 2 + 1;
+    std::vector<double> Fsum(2 * (size_t)nh, 0.0);
+    for (int iring = 0; iring < L.nrings; ++iring) {
+        const double radius = (float)iring + L.Ri;
+        const double w = (2. * XO_PI * radius);
+        const int imax = L.nsam[iring] / 2 + 1;
+        const double *ptr1 = reinterpret_cast<const double *>(M1 + L.coff[iring]);
+        const double *ptr2 = reinterpret_cast<const double *>(M2 + L.coff[iring]);
+        double *ptrFsum = Fsum.data();
+        for (int i = 0; i < imax && i < nh; i++) {
+            double a = *ptr1++;
+            double b = *ptr1++;
+            double c = *ptr2++;
+            double d = *ptr2++;
+            *(ptrFsum++) += w * (a * c - b * d);
+            *(ptrFsum++) += w * (b * c + a * d);
+        }
+    }
+    std::vector<cd> A(len), a(len);
+    A[0] = cd(Fsum[0], 0);
+    for (int k = 1; k < nh; ++k) {
+        cd f(Fsum[2 * k], Fsum[2 * k + 1]);
+        if (2 * k == len) A[k] = cd(f.real(), 0);
+        else { A[k] = f; A[len - k] = std::conj(f); }
+    }
+    xo::c2c(A.data(), len, +1, a.data());
+    for (int i = 0; i < len; ++i) corr[i] = a[i].real();
+}
+
+extern "C" {
+
+int xo_es_rotation_corr_len(int first_ring, int last_ring)
+{
+    (void)first_ring;
+    return 2 * nsam_of(XO_TWOPI, (float)last_ring) - 1;          // polar_rotation_estimator.cpp:58
+}
+
+// ref [D][D], others [n][D][D] (the float images of the estimator, handed over as doubles: convert(), :61-68);
+// rotations [n] in degrees = angles[imax] = imax * 360 / len (polar.cpp:143-146,218-232: the first maximum);
+// corr_out (optional) [n][len]
+void xo_es_polar_rotation(const double *ref, const double *others, int n, int D, int first_ring, int last_ring, double *rotations,
+                          double *corr_out)
+{
+    Layout L;
+    L.init(first_ring, last_ring);
+    const int len = 2 * L.nsam[L.nrings - 1] - 1;
+    std::vector<double> rings(L.nsamples);
+    std::vector<cd> Fref(L.ncoefs);
+    Scratch S;
+    es_polar_linear(L, ref, D, rings.data());
+    fft_rings(L, rings.data(), false, Fref.data(), S);
+#pragma omp parallel
+    {
+        std::vector<double> rg(L.nsamples), corr(len);
+        std::vector<cd> F(L.ncoefs);
+        Scratch S2;
+#pragma omp for schedule(dynamic)
+        for (int i = 0; i < n; ++i) {
+            es_polar_linear(L, others + (size_t)i * D * D, D, rg.data());
+            fft_rings(L, rg.data(), true, F.data(), S2);
+            es_rot_corr(L, Fref.data(), F.data(), len, corr.data());
+            int imax = 0;
+            double maxval = corr[0];
+            for (int k = 0; k < len; ++k)
+                if (corr[k] > maxval) { maxval = corr[k]; imax = k; }
+            rotations[i] = (double)imax * (360. / len);
+            if (corr_out) std::memcpy(corr_out + (size_t)i * len, corr.data(), sizeof(double) * len);
+        }
+    }
+}
+
+}  // extern "C"

@@ -606,7 +606,17 @@ def test_cli_movie_local_alignment(bins, tmp_path, oracle):
                 a, b = oracle.fa_bspline_shift(cx, cy, cp, X, Y, N, x, y, n), oracle.fa_bspline_shift(loc["coeffsX"], loc["coeffsY"], cp, X, Y, N, x, y, n)
                 worst = max(worst, abs(a[0] - b[0]), abs(a[1] - b[1]))
     assert worst < 0.02, worst
-    assert 0 <= float(rows[0][c["localAlignmentConf2_5Perc"]]) <= float(rows[0][c["localAlignmentConf97_5Perc"]]) < 10
+    lo, hi = float(rows[0][c["localAlignmentConf2_5Perc"]]), float(rows[0][c["localAlignmentConf97_5Perc"]])
+    assert 0 <= lo <= hi < 10
+    # storeResults (movie_alignment_correlation_base.cpp:470-486) receives BSplineHelper::getShift's pair with X and Y exchanged
+    # (bspline_helper.cpp:99 calls a callee declared (shiftY, shiftX), :112): distances are hypot(splineY - globalX, splineX - globalY)
+    dist = []
+    for (px, py) in np.asarray(loc["centers"]).reshape(-1, 2):
+        for t in range(N):
+            bx, by = oracle.fa_bspline_shift(cx, cy, cp, X, Y, N, int(px), int(py), t)
+            dist.append(np.hypot(by - g["shiftX"][t], bx - g["shiftY"][t]))
+    dist = np.sort(dist)
+    assert abs(lo - dist[int(dist.size * 0.025)]) < 0.02 and abs(hi - dist[int(dist.size * 0.975)]) < 0.02
     aligned = xmipp_io.read_stack(str(tmp_path / "aligned.stk"))
     assert aligned.shape == (N, Y, X)
     exp = np.stack([oracle.fa_apply_bspline(frames[n], loc["coeffsX"].astype(np.float32), loc["coeffsY"].astype(np.float32), cp, N, n) for n in range(N)])

@@ -126,28 +126,35 @@ def _clock_arms(oracle, D, deg):
     return oracle.rotate2d(img, float(deg), degree=3, wrap=False) if deg else img
 
 
-@pytest.mark.parametrize("D,n", [(64, 5), (101, 4), (300, 3)])
-def test_rotation_estimation_of_clock_arms(gpu, oracle, D, n):
-    """ARotationEstimator_Test::rotate2D (arotation_estimator_tests.h:45-118): clock arms rotated by known angles, default rings; an
-    image rotated by a reads 360 - a, to 0.62 of the angle one pixel subtends at the edge (the test's bound without noise) -- and the
-    index is the oracle's: arg-max of the straight correlation row of (image, reference), mirrored."""
+@pytest.mark.parametrize("D,n", [(13, 3), (64, 5), (101, 4), (300, 3), (517, 2), (768, 2)])
+@pytest.mark.parametrize("noise", [False, True])
+def test_rotation_estimation_of_clock_arms(gpu, oracle, D, n, noise):
+    """ARotationEstimator_Test::rotate2D (arotation_estimator_tests.h:45-118): clock arms rotated by known angles, default rings, sizes
+    from the test's range (13 ... 768, odd ones too), with and without its noise (N(0, 0.5), alignment_test_utils.h:66-71); an image
+    rotated by a reads 360 - a to 0.62 (0.81 with noise) of the angle one pixel subtends at the edge -- the test's own bounds -- and the
+    angle IS the oracle's (restatement of polar_rotation_estimator.cpp:49-99: linear sampling, no normalisation, 2 N - 1 angles)."""
     xa, ctx, torch = gpu
+    if noise and D < 20:
+        pytest.skip("below 20 px the test's noise bound depends on the noise drawn")
     rng = np.random.default_rng(D)
     angles = rng.uniform(0, 360, n)
-    ref = _clock_arms(oracle, D, 0.0)
-    others = np.stack([_clock_arms(oracle, D, a) for a in angles])
-    got = xa.rotation_estimate(ctx, torch.from_numpy(ref.astype(np.float32)).cuda(), torch.from_numpy(others.astype(np.float32)).cuda())
-    max_err = np.degrees(np.arctan(2.0 / D)) * 0.62
+    ref = _clock_arms(oracle, D, 0.0).astype(np.float32)
+    others = np.stack([_clock_arms(oracle, D, a) for a in angles]).astype(np.float32)
+    if noise:
+        others = oracle.es_test_add_noise(others)
+    got = xa.rotation_estimate(ctx, torch.from_numpy(ref).cuda(), torch.from_numpy(others).cuda())
+    max_err = np.degrees(np.arctan(2.0 / D)) * (0.81 if noise else 0.62)
     for a, r in zip(angles, got):
         actual = 360 - r
         diff = 180 - abs(abs(actual - a) - 180)
         assert diff <= max_err, (a, r, diff, max_err)
-    first, last = max(2, D // 20), (D - 3) // 2
-    opm = oracle.PM(ref.astype(np.float32)[None], Ri=first, Ro=last)
+    exp, corr = oracle.es_polar_rotation(ref, others, with_corr=True)
+    step = 360.0 / corr.shape[1]
     for k in range(n):
-        row = opm.corr_rows(others[k].astype(np.float32), 0)[:opm.N]
-        i = int(np.argmax(row))
-        assert got[k] == np.float32(((opm.N - i) % opm.N) * (360.0 / opm.N))
+        if got[k] != np.float32(exp[k]):
+            # two angles of the correlation row may tie to the last bits of a double: then both are maxima of the oracle's row
+            i = int(round(got[k] / step))
+            assert corr[k, i] >= corr[k].max() * (1 - 1e-12), (k, got[k], exp[k])
     with pytest.raises(xa.XhError):
         xa.rotation_estimate(ctx, torch.zeros((64, 64), device="cuda"), torch.zeros((1, 64, 64), device="cuda"), 10, 5)       # last ring <= first ring
 
@@ -176,42 +183,87 @@ def test_geometry_transformer_and_merit_against_the_oracle(gpu, oracle):
         assert abs(m[k] - oracle.correlation_index(ref, others[k])) <= 1e-5
 
 
-@pytest.mark.parametrize("D,n", [(128, 24), (260, 12)])
-def test_iterative_alignment_of_clock_arms(gpu, oracle, D, n):
-    """IterativeAlignmentEstimator_Test::testStatistics without noise (aiterative_alignment_tests.h:148-205, 237-255): clock arms moved
-    by known shifts (up to 20 px) and rotations; the estimated pose gives the shift as -(m02, m12) and the rotation as atan2(m10, m00).
-    Pure shifts come back exactly and pure rotations within a quarter of a degree after one round; both together converge round by
-    round (the first rotation estimate is taken about the wrong centre). The reference asks, after three rounds and on a large
-    population, for 80 % of the shifts within a pixel, 90 % within 1.8, 90 % of the rotations within twice the angle a pixel subtends
-    (its CPU figures); this implementation needs six rounds for: 70 % within a pixel, 90 % within 2.5, 70 % of the rotations within twice and 90 %
-    within four times that angle -- stated as measured, not as the reference's bar."""
+def _es_population(oracle, draw, n, noise):
+    D, sh, rot = oracle.es_test_population(draw, n)
+    c = D // 2
+    arm = int((D - c) / 1.5)
+    ref = np.zeros((D, D), np.float32)
+    ref[c:c + arm, c] = 1
+    ref[c, c:c + arm] = 1
+    others = oracle.es_test_make_others(ref, sh, rot)
+    if noise:
+        others = oracle.es_test_add_noise(others)
+    return D, sh, rot, ref, others
+
+
+def _es_errors(poses, sh, rot):
+    """saveResults (aiterative_alignment_tests.h:237-255)"""
+    sa = -poses[:, :2, 2]
+    ra = np.fmod(360 + np.degrees(np.arctan2(poses[:, 1, 0], poses[:, 0, 0])), 360)
+    return np.abs(sa[:, 0] - sh[:, 0]), np.abs(sa[:, 1] - sh[:, 1]), 180 - np.abs(np.abs(ra - rot) - 180)
+
+
+def _pct(v, p, count=None):
+    v = np.sort(np.asarray(v))
+    return v[int(np.floor(((len(v) if count is None else count) - 1) * p))]
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_iterative_alignment_on_the_reference_tests_population(gpu, oracle, noise):
+    """IterativeAlignmentEstimator_Test (aiterative_alignment_tests.h): the test's own population -- sizes drawn from its mt19937(42)
+    (138, 686 with one image; 350, 442, 270, 680, 220, 606 with a hundred; with noise the next eight draws), shifts up to 20 px and
+    rotations from copies of the engine, every image the clock-arm reference moved by applyGeometry(LINEAR) -- aligned with
+    compute(others, 3), THREE rounds as the reference's test (:205), and its CPU acceptance (:61-87): without noise 80 % of the
+    shifts within 1 px and 90 % within 1.8 / 1.86; with noise 41 % within 1 px, 51 / 53 % within 2 px.  The rotation criterion is
+    applied as the test applies it (it indexes the sorted rotation errors with the number of SIZES) and, stricter, as it reads:
+    90 % (67 % with noise) of the rotations within 2 x (10 x) the angle a pixel subtends.  Against the oracle's restatement of the
+    chain: the same pose for at least 97 % of the images of every size (what is left are arg-max ties between the fp32 FFT
+    correlation of the device's shift estimator and the oracle's double one)."""
     xa, ctx, torch = gpu
-    rng = np.random.default_rng(D + n)
+    dX, dY, dR, eR = [], [], [], []
+    for k in range(8):
+        n = 1 if k < 2 else 100
+        D, sh, rot, ref, others = _es_population(oracle, k + (8 if noise else 0), n, noise)
+        if D < 14:
+            continue
+        max_shift = min(20, D // 2 - 1)
+        poses, merit = xa.iterative_alignment(ctx, torch.from_numpy(ref).cuda(), torch.from_numpy(others).cuda(), max_shift, 3)
+        dx, dy, dr = _es_errors(poses, sh, rot)
+        dX += list(dx); dY += list(dy); dR += list(dr); eR.append(np.degrees(np.arctan(2.0 / D)))
+        if D <= 360:           # the oracle on the smaller sizes (seconds); the large ones are covered by the statistics
+            m = min(n, 40)
+            eposes, emerit = oracle.es_iterative_alignment(ref, others[:m], max_shift, 3)
+            same = np.array([np.allclose(poses[i], eposes[i], rtol=0, atol=1e-5) for i in range(m)])
+            assert same.mean() >= 0.97, (D, same.mean())
+            assert np.abs(merit[:m][same] - emerit[same]).max() <= 1e-4
+    if not noise:
+        refR = _pct(eR, 0.9)
+        assert _pct(dR, 0.9, len(eR)) <= 2 * refR                      # :75, as written
+        assert _pct(dR, 0.9) <= 2 * refR                               # as meant
+        assert _pct(dX, 0.8) <= 1 and _pct(dX, 0.9) <= 1.8 and _pct(dY, 0.8) <= 1 and _pct(dY, 0.9) <= 1.86
+    else:
+        refR = _pct(eR, 0.67)
+        assert _pct(dR, 0.67, len(eR)) <= 10 * refR                    # :67, as written (the reference's own chain does not meet it as meant)
+        assert _pct(dX, 0.41) <= 1 and _pct(dX, 0.51) <= 2 and _pct(dY, 0.41) <= 1 and _pct(dY, 0.53) <= 2
+
+
+def test_iterative_alignment_step_by_step_against_the_oracle(gpu, oracle):
+    """The chain bisected: the rotation estimator, the shift estimator and one half-pass (rotation first / shift first, one and
+    two rounds) against the oracle's on the reference test's 220-px population; pure shifts come back exactly."""
+    xa, ctx, torch = gpu
+    D, sh, rot, ref, others = _es_population(oracle, 6, 24, False)
     max_shift = min(20, D // 2 - 1)
-    ref = _clock_arms(oracle, D, 0.0)
-    shifts, rots, others = [], [], []
-    for _ in range(n):
-        sx = int(rng.integers(0, max_shift + 1))
-        my = int(np.floor(np.sqrt(max_shift * max_shift - sx * sx)))
-        sy = 0 if my == 0 else int(rng.integers(0, max_shift + 1)) % my
-        a = float(rng.uniform(0, 360))
-        m = np.eye(3)
-        m[0, 2] += sx
-        m[1, 2] += sy
-        ar = np.radians(a)
-        r = np.array([[np.cos(ar), np.sin(ar), 0], [-np.sin(ar), np.cos(ar), 0], [0, 0, 1]])
-        others.append(oracle.apply_geometry2d(ref, r @ m, 1, False, False))             # sApplyTransform: LINEAR, IS_NOT_INV, DONT_WRAP
-        shifts.append((sx, sy)); rots.append(a)
-    poses, merit = xa.iterative_alignment(ctx, torch.from_numpy(ref.astype(np.float32)).cuda(), torch.from_numpy(np.stack(others).astype(np.float32)).cuda(), max_shift, 6)
-    dx = np.array([abs(-poses[i][0, 2] - shifts[i][0]) for i in range(n)])
-    dy = np.array([abs(-poses[i][1, 2] - shifts[i][1]) for i in range(n)])
-    ra = np.array([(360 + np.degrees(np.arctan2(poses[i][1, 0], poses[i][0, 0]))) % 360 for i in range(n)])
-    dr = 180 - np.abs(np.abs(ra - np.array(rots)) - 180)
-    ref_r = np.degrees(np.arctan(2.0 / D))
-    print("shift errors", np.sort(dx)[-4:], np.sort(dy)[-4:], "rotation errors", np.sort(dr)[-4:], "bound", 2 * ref_r, "merit", merit.min())
-    assert (dx <= 1).mean() >= 0.7 and (dy <= 1).mean() >= 0.7 and (dx <= 2.5).mean() >= 0.9 and (dy <= 2.5).mean() >= 0.9 and (dr <= 2 * ref_r).mean() >= 0.7 and (dr <= 4 * ref_r).mean() >= 0.9
-    assert (merit > 0.3).mean() >= 0.8
-    # the two halves alone: shifts exactly, rotations within the rotation estimator's resolution
-    sh = np.stack([oracle.apply_geometry2d(ref, np.array([[1, 0, s[0]], [0, 1, s[1]], [0, 0, 1.0]]), 1, False, False) for s in shifts[:4]])
-    poses, merit = xa.iterative_alignment(ctx, torch.from_numpy(ref.astype(np.float32)).cuda(), torch.from_numpy(sh.astype(np.float32)).cuda(), max_shift, 1)
-    assert all(-poses[i][0, 2] == shifts[i][0] and -poses[i][1, 2] == shifts[i][1] for i in range(4)) and merit.min() > 0.999
+    dref, doth = torch.from_numpy(ref).cuda(), torch.from_numpy(others).cuda()
+    assert np.array_equal(xa.rotation_estimate(ctx, dref, doth), oracle.es_polar_rotation(ref, others).astype(np.float32))
+    est = xa.ShiftCorrEstimator(ctx, D, D, max_shift)
+    est.load_reference(dref)
+    assert np.array_equal(est.compute_shifts(doth), oracle.es_shifts(ref, others, max_shift))
+    est.close()
+    for iters in (1, 2):
+        poses, merit = xa.iterative_alignment(ctx, dref, doth, max_shift, iters)
+        eposes, emerit = oracle.es_iterative_alignment(ref, others, max_shift, iters)
+        same = np.array([np.allclose(poses[i], eposes[i], rtol=0, atol=1e-5) for i in range(len(others))])
+        assert same.mean() >= 0.95, (iters, same.mean())
+    pure = np.stack([oracle.apply_geometry2d(ref.astype(np.float64), np.array([[1, 0, s[0]], [0, 1, s[1]], [0, 0, 1.0]]), 1, False, False) for s in sh[:4]]).astype(np.float32)
+    poses, merit = xa.iterative_alignment(ctx, dref, torch.from_numpy(pure).cuda(), max_shift, 1)
+    assert all(-poses[i][0, 2] == sh[i][0] and -poses[i][1, 2] == sh[i][1] for i in range(4)) and merit.min() > 0.999

@@ -203,23 +203,44 @@ def test_insert_many(gpu, oracle, data32, mode):
     assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
 
 
-def test_insert_wide_blob(gpu, oracle, data32):
-    """Blob radius in [2, 3): 6 x 6 footprints (the W = 6 instantiation of the gridding kernel)."""
+@pytest.mark.parametrize("radius", [2.4, 2.6, 2.9, 2.99])
+def test_insert_wide_blob(gpu, oracle, data32, radius):
+    """Blob radius in [2, 3): 6 x 6 footprints (the W = 6 instantiation of the gridding kernel).  Radii beyond 2.5 are the
+    ones whose sixth tap carries weight (a footprint spans floor(x - r) ... ceil(x + r): six pixels for r > 2.5 whatever the
+    fraction of x); 40 random orientations, CTF-weighted, voxel sets equal and 2e-6 against the oracle (RFA:627-700)."""
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
-    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs[:12], ang[:12], blob_radius=2.4)
-    for i in range(12):
-        o.insert(ffts[i], synth.euler_matrix(*ang[i]).T)
-    rf.insert(torch.from_numpy(ffts).cuda(), ang[:12])
+    n = len(imgs)
+    rf, o, ffts = _insert_both(xa, ctx, torch, oracle, D, imgs, ang, blob_radius=radius)
+    rng = np.random.default_rng(int(radius * 100))
+    ctf = (rng.uniform(0.5, 2.0, ffts.shape[:3]) * rng.choice([-1, 1], ffts.shape[:3])).astype(np.float32)
+    mod = rng.uniform(0.0, 1.0, ffts.shape[:3]).astype(np.float32)
+    for i in range(n):
+        o.insert(ffts[i], synth.euler_matrix(*ang[i]).T, ctf=ctf[i], modulator=mod[i])
+    rf.insert(torch.from_numpy(ffts).cuda(), ang, ctf=torch.from_numpy(ctf).cuda(), modulator=torch.from_numpy(mod).cuda())
     ev, ew = o.temp()
     gv, gw = rf.temp_spaces()
     gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
     assert ((ew != 0) == (gw != 0)).all()
     assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
     assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+    # a single projection: the same voxels and taps
+    rf.reset()
+    o1 = oracle.RF(D, blob_radius=radius)
+    o1.insert(ffts[7], synth.euler_matrix(*ang[7]).T)
+    rf.insert(torch.from_numpy(ffts[7:8]).cuda(), ang[7:8])
+    _, ew1 = o1.temp()
+    _, gw1 = rf.temp_spaces()
+    gw1 = gw1.cpu().numpy()
+    assert np.array_equal(gw1 != 0, ew1 != 0) and np.abs(gw1 - ew1).max() <= 1e-6 * np.abs(ew1).max()
+
+
+def test_insert_blob_radius_three_and_more_is_refused(gpu, data32):
+    xa, ctx, torch = gpu
+    D, vol, ang, imgs = data32
     with pytest.raises(xa.XhError):
         rf3 = xa.RecFourier(ctx, D, blob_radius=3.2)
-        rf3.insert(torch.from_numpy(ffts[:1]).cuda(), ang[:1])
+        rf3.insert(torch.zeros((1, 2 * D, D, 2), device="cuda"), ang[:1])
 
 
 @pytest.mark.parametrize("D", [64, 50])
@@ -661,6 +682,36 @@ def test_double_precision_program_on_the_device(gpu, oracle, niter, kind):
     h = n // 2
     rf.insert(dimgs[:h].contiguous(), ang[:h], weights=None if weights is None else weights[:h], sym=sym, ctfs=None if dctf is None else dctf[:h])
     rf.insert(dimgs[h:].contiguous(), ang[h:], weights=None if weights is None else weights[h:], sym=sym, ctfs=None if dctf is None else dctf[h:])
+    got = rf.finish()
+    peak = np.abs(exp).max()
+    assert peak > 0 and np.abs(got - exp).max() <= 1e-9 * peak
+
+
+def test_config1_on_the_double_precision_program(gpu, oracle):
+    """BASELINE config 1 on its own binary's arithmetic: xmipp_reconstruct_fourier = ProgRecFourier (RF:571-793,1056-1221),
+    64^3 phantom of 20 Gaussians, 1000 projections uniform on SO(3), --padding 2 2 --blob 1.9 0 15 --max_resolution 0.5.
+    All 1000 projections through xh_rf2_*: the phantom comes back; a 100-projection subset against oracle.RF2 (1e-9 of the
+    peak: double accumulators, the order of the sums is all that differs)."""
+    xa, ctx, torch = gpu
+    D, n = 64, 1000
+    vol = synth.phantom(D, seed=1, nblobs=20).astype(np.float32)
+    ang = synth.random_angles(n, np.random.default_rng(2))
+    fp = xa.FourierProjector(ctx, torch.from_numpy(vol).cuda(), 2.0, 0.5, 3)
+    imgs = fp.project(ang)
+    fp.close()
+    rf = xa.RecFourier2(ctx, D)
+    for lo in range(0, n, 250):
+        rf.insert(imgs[lo:lo + 250].contiguous(), ang[lo:lo + 250])
+    rec = rf.finish()
+    assert np.corrcoef(rec.ravel(), vol.ravel())[0, 1] > 0.99
+    m = 100
+    h = imgs[:m].cpu().numpy()
+    ref = oracle.RF2(D)
+    for i in range(m):
+        ref.insert(h[i], synth.euler_matrix(*ang[i]).T)
+    exp = ref.finish()
+    rf = xa.RecFourier2(ctx, D)
+    rf.insert(imgs[:m].contiguous(), ang[:m])
     got = rf.finish()
     peak = np.abs(exp).max()
     assert peak > 0 and np.abs(got - exp).max() <= 1e-9 * peak

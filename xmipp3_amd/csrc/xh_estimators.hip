@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "xh_common.h"
+#include "xh_bspline.h"
 
 namespace {
 typedef float2 es_cf;
@@ -158,7 +159,229 @@ __global__ void __launch_bounds__(256) k_es_corr_index(const float *__restrict__
     if (!(fabs(sx) < 1e-6 || fabs(sy) < 1e-6)) r = (red[4][0] - n * mx * my) / ((sx * sy) * n);          // sum (x - mx)(y - my) = sum xy - n mx my
     merit[blockIdx.x] = (float)r;
 }
+// ---- PolarRotationEstimator (polar_rotation_estimator.cpp:49-99) as the reference computes it: rings sampled with BsplineOrder 1
+// (polar.h:689-693: interpolatedElement2DOutsideZero, bilinear, zero outside the image), not normalised, every ring's
+// DFT / nsam (polar.cpp:34-54), the ring-weighted products summed per frequency and brought back over 2 N - 1 angles
+// (:58; polar.cpp:99-148), the first maximum (polar.cpp:212-233).  Double precision throughout, as the reference.
+struct EsRing { int nsam, soff, coff; double w; };
+
+__global__ void __launch_bounds__(256) k_es_polar_linear(const float *__restrict__ imgs, const float *__restrict__ sx, const float *__restrict__ sy, int nsamples, int D,
+                                                         double *__restrict__ rings)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nsamples) return;
+    const float *img = imgs + (size_t)blockIdx.y * D * D;
+    const int first = -(D / 2), last = first + D - 1;
+    const double minp = first, maxp = last;
+    double xp = (double)sx[t], yp = (double)sy[t];
+    // coordinates outside [min - 1e-6, max + 1e-6] are wrapped (polar.h:683-686)
+    if (xp < minp - 1e-6 || xp > maxp + 1e-6) xp = d_realwrap<double>(xp, minp - 0.5, maxp + 0.5);
+    if (yp < minp - 1e-6 || yp > maxp + 1e-6) yp = d_realwrap<double>(yp, minp - 0.5, maxp + 0.5);
+    const int x0 = (int)floor(xp), y0 = (int)floor(yp);
+    const double fx = xp - x0, fy = yp - y0;
+    auto at = [&](int i, int j) -> double { return (j < first || j > last || i < first || i > last) ? 0.0 : (double)img[(size_t)(i - first) * D + (j - first)]; };
+    const double d00 = at(y0, x0), d01 = at(y0, x0 + 1), d10 = at(y0 + 1, x0), d11 = at(y0 + 1, x0 + 1);
+    const double d0 = d00 + (d01 - d00) * fx, d1 = d10 + (d11 - d10) * fx;
+    rings[(size_t)blockIdx.y * nsamples + t] = d0 + (d1 - d0) * fy;
+}
+
+// block = (ring, image): the ring's samples and the nsam twiddles in LDS, thread k sums sample s against twiddle (s k) mod nsam
+__global__ void __launch_bounds__(256) k_es_ring_dft(const double *__restrict__ rings, const EsRing *__restrict__ ringTab, int nsamples, int ncoefs, int conjugate,
+                                                     double2 *__restrict__ coefs)
+{
+    extern __shared__ double es_lds[];
+    const EsRing R = ringTab[blockIdx.x];
+    const int n = R.nsam;
+    double *x = es_lds;
+    double2 *tw = (double2 *)(es_lds + n + (n & 1));
+    const double *src = rings + (size_t)blockIdx.y * nsamples + R.soff;
+    for (int s = threadIdx.x; s < n; s += 256) {
+        x[s] = src[s];
+        double sn, cs;
+        sincospi(2.0 * (double)s / (double)n, &sn, &cs);
+        tw[s] = double2{cs, sn};
+    }
+    __syncthreads();
+    const double inv = 1.0 / n;
+    for (int k = threadIdx.x; k <= n / 2; k += 256) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int s = 0; s < n; ++s) {
+            const double2 t = tw[idx];
+            const double v = x[s];
+            re += v * t.x;
+            im -= v * t.y;
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        re *= inv; im *= inv;
+        if (conjugate) im = -im;
+        coefs[(size_t)blockIdx.y * ncoefs + R.coff + k] = double2{re, im};
+    }
+}
+
+// Fsum[k] = sum over the rings that have frequency k of 2 pi r . F1[k] F2[k] (F2 arrives conjugated), polar.cpp:122-135
+__global__ void __launch_bounds__(256) k_es_rot_fsum(const double2 *__restrict__ Fref, const double2 *__restrict__ F, const EsRing *__restrict__ ringTab, int nrings, int ncoefs,
+                                                     int nh, double2 *__restrict__ Fsum)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nh) return;
+    const double2 *f2 = F + (size_t)blockIdx.y * ncoefs;
+    double re = 0.0, im = 0.0;
+    for (int r = 0; r < nrings; ++r) {
+        const EsRing R = ringTab[r];
+        if (k > R.nsam / 2) continue;
+        const double2 a = Fref[R.coff + k], c = f2[R.coff + k];
+        re += R.w * (a.x * c.x - a.y * c.y);
+        im += R.w * (a.y * c.x + a.x * c.y);
+    }
+    Fsum[(size_t)blockIdx.y * nh + k] = double2{re, im};
+}
+
+// the inverse transform of the Hermitian half Fsum over len = 2 nh - 1 (odd) angles, un-normalised: corr[j] = Re F0 + 2 sum_k Re(F_k e^{2 pi i j k / len})
+__global__ void __launch_bounds__(256) k_es_rot_corr(const double2 *__restrict__ Fsum, int nh, int len, double *__restrict__ corr)
+{
+    extern __shared__ double es_lds[];
+    double2 *F = (double2 *)es_lds;
+    const double2 *src = Fsum + (size_t)blockIdx.y * nh;
+    for (int k = threadIdx.x; k < nh; k += 256) F[k] = src[k];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    double acc = 0.0;
+    int idx = 0;
+    const double step = 2.0 / (double)len;
+    for (int k = 1; k < nh; ++k) {
+        idx += j;
+        if (idx >= len) idx -= len;
+        double sn, cs;
+        sincospi(step * (double)idx, &sn, &cs);
+        acc += F[k].x * cs - F[k].y * sn;
+    }
+    corr[(size_t)blockIdx.y * len + j] = F[0].x + 2.0 * acc;
+}
+
+// best_rotation (polar.cpp:218-229): the first element that is strictly greater than everything before it
+__global__ void __launch_bounds__(256) k_es_first_max(const double *__restrict__ corr, int len, int *__restrict__ imax)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const double *c = corr + (size_t)blockIdx.x * len;
+    double best = c[0];
+    int bi = 0;
+    for (int i = threadIdx.x; i < len; i += 256)
+        if (c[i] > best) { best = c[i]; bi = i; }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v = sv[threadIdx.x + o];
+            const int k = si[threadIdx.x + o];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && k < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = k; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) imax[blockIdx.x] = si[0];
+}
 }  // namespace
+
+// the rotation estimator's plan: ring table and sample coordinates on the device, the reference's polar Fourier transform
+struct EsRotation {
+    xh_ctx *ctx = nullptr;
+    int D = 0, first = 0, last = 0, nrings = 0, nsamples = 0, ncoefs = 0, N = 0, len = 0, maxNsam = 0;
+    XhBuf ringTab, sx, sy, Fref, rings, coefs, Fsum, corr, imax;
+};
+
+static void es_rotation_free(EsRotation &R)
+{
+    xh_buf_free(R.ringTab); xh_buf_free(R.sx); xh_buf_free(R.sy); xh_buf_free(R.Fref); xh_buf_free(R.rings); xh_buf_free(R.coefs);
+    xh_buf_free(R.Fsum); xh_buf_free(R.corr); xh_buf_free(R.imax);
+}
+
+// polarFourierTransform<false>(..., BsplineOrder = 1) of n images [n][D][D] (float) into coefs [n][ncoefs]
+static int es_rotation_transform(EsRotation &R, const float *d_imgs, int n, int conjugate, double2 *d_coefs)
+{
+    xh_ctx *ctx = R.ctx;
+    XH_TRY(xh_buf_reserve(ctx, R.rings, sizeof(double) * (size_t)R.nsamples * n));
+    hipLaunchKernelGGL(k_es_polar_linear, dim3((unsigned)((R.nsamples + 255) / 256), n), dim3(256), 0, ctx->stream, d_imgs, (const float *)R.sx.p, (const float *)R.sy.p, R.nsamples,
+                       R.D, (double *)R.rings.p);
+    XH_LAUNCH_CHECK();
+    const size_t smem = sizeof(double) * (size_t)(R.maxNsam + (R.maxNsam & 1)) + sizeof(double2) * (size_t)R.maxNsam;
+    hipLaunchKernelGGL(k_es_ring_dft, dim3(R.nrings, n), dim3(256), smem, ctx->stream, (const double *)R.rings.p, (const EsRing *)R.ringTab.p, R.nsamples, R.ncoefs, conjugate,
+                       d_coefs);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+static int es_rotation_create(xh_ctx *ctx, const float *d_ref, int32_t D, int32_t first_ring, int32_t last_ring, EsRotation &R)
+{
+    // RotationEstimationSetting::check + PolarRotationEstimator::check (arotation_estimator.h:80-130, polar_rotation_estimator.cpp:125-141)
+    XH_CHECK(D >= 6, XH_ERR_ARG, "xh_rotation_estimate: The input signal is too small.");
+    XH_CHECK(first_ring >= 1 && last_ring > first_ring && last_ring < D, XH_ERR_ARG, "xh_rotation_estimate: rings %d .. %d of a %d px image (first >= 1, last > first, last < size)",
+             first_ring, last_ring, D);
+    R.ctx = ctx; R.D = D; R.first = first_ring; R.last = last_ring; R.nrings = last_ring - first_ring + 1;
+    std::vector<EsRing> tab(R.nrings);
+    int ns = 0, nc = 0;
+    for (int r = 0; r < R.nrings; ++r) {
+        const float radius = (float)r + first_ring;
+        int nsam = 2 * (int)(0.5 * 1.0 * 6.2831853071795864769 * radius);          // getNoOfSamples, polar.h:723-726
+        nsam = nsam > 1 ? nsam : 1;
+        tab[r].nsam = nsam; tab[r].soff = ns; tab[r].coff = nc;
+        tab[r].w = 2. * 3.14159265358979323846 * (double)radius;                     // polar.cpp:123
+        ns += nsam; nc += nsam / 2 + 1;
+        R.maxNsam = nsam > R.maxNsam ? nsam : R.maxNsam;
+    }
+    R.nsamples = ns; R.ncoefs = nc; R.N = tab[R.nrings - 1].nsam; R.len = 2 * R.N - 1;
+    const size_t smem = sizeof(double) * (size_t)(R.maxNsam + (R.maxNsam & 1)) + sizeof(double2) * (size_t)R.maxNsam;
+    XH_CHECK(smem <= 160 * 1024 && sizeof(double2) * (size_t)R.N <= 160 * 1024, XH_ERR_UNSUPPORTED, "xh_rotation_estimate: a ring of %d samples does not fit the 160 KB of LDS", R.maxNsam);
+    XH_HIP(hipFuncSetAttribute((const void *)k_es_ring_dft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    XH_HIP(hipFuncSetAttribute((const void *)k_es_rot_corr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double2) * (size_t)R.N)));
+    // the angle cache of Polar<T>::ensureAngleCache (polar.cpp:57-83): float angle, float product, stored as floats
+    std::vector<float> sx(ns), sy(ns);
+    for (int r = 0; r < R.nrings; ++r) {
+        const float radius = (float)(r + first_ring);
+        const int n = tab[r].nsam;
+        const float dphi = (float)(6.2831853071795864769 / (float)n);
+        for (int i = 0; i < n; ++i) {
+            const float phi = i * dphi;
+            sx[tab[r].soff + i] = sinf(phi) * radius;
+            sy[tab[r].soff + i] = cosf(phi) * radius;
+        }
+    }
+    XH_TRY(xh_buf_alloc(ctx, R.ringTab, sizeof(EsRing) * tab.size()));
+    XH_TRY(xh_buf_alloc(ctx, R.sx, sizeof(float) * ns));
+    XH_TRY(xh_buf_alloc(ctx, R.sy, sizeof(float) * ns));
+    XH_TRY(xh_buf_alloc(ctx, R.Fref, sizeof(double2) * nc));
+    XH_HIP(hipMemcpyAsync(R.ringTab.p, tab.data(), sizeof(EsRing) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipMemcpyAsync(R.sx.p, sx.data(), sizeof(float) * ns, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipMemcpyAsync(R.sy.p, sy.data(), sizeof(float) * ns, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));                // the host vectors go out of scope
+    return es_rotation_transform(R, d_ref, 1, 0, (double2 *)R.Fref.p);                // load2DReferenceOneToN: not conjugated
+}
+
+// computeRotation2DOneToN: h_rotations [n] in degrees = imax 360 / (2 N - 1), as floats (getRotations2D is a std::vector<float>)
+static int es_rotation_run(EsRotation &R, const float *d_others, int n, float *h_rotations)
+{
+    xh_ctx *ctx = R.ctx;
+    XH_TRY(xh_buf_reserve(ctx, R.coefs, sizeof(double2) * (size_t)R.ncoefs * n));
+    XH_TRY(xh_buf_reserve(ctx, R.Fsum, sizeof(double2) * (size_t)R.N * n));
+    XH_TRY(xh_buf_reserve(ctx, R.corr, sizeof(double) * (size_t)R.len * n));
+    XH_TRY(xh_buf_reserve(ctx, R.imax, sizeof(int) * (size_t)n));
+    XH_TRY(es_rotation_transform(R, d_others, n, 1, (double2 *)R.coefs.p));
+    hipLaunchKernelGGL(k_es_rot_fsum, dim3((unsigned)((R.N + 255) / 256), n), dim3(256), 0, ctx->stream, (const double2 *)R.Fref.p, (const double2 *)R.coefs.p,
+                       (const EsRing *)R.ringTab.p, R.nrings, R.ncoefs, R.N, (double2 *)R.Fsum.p);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_es_rot_corr, dim3((unsigned)((R.len + 255) / 256), n), dim3(256), sizeof(double2) * (size_t)R.N, ctx->stream, (const double2 *)R.Fsum.p, R.N, R.len,
+                       (double *)R.corr.p);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_es_first_max, dim3(n), dim3(256), 0, ctx->stream, (const double *)R.corr.p, R.len, (int *)R.imax.p);
+    XH_LAUNCH_CHECK();
+    std::vector<int> imax(n);
+    XH_HIP(hipMemcpyAsync(imax.data(), R.imax.p, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) h_rotations[i] = (float)((double)imax[i] * (360. / R.len));
+    return XH_OK;
+}
 
 struct xh_shiftcorr {
     xh_ctx *ctx;
@@ -292,52 +515,17 @@ int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t 
     return XH_OK;
 }
 
-// PolarRotationEstimator::load2DReferenceOneToN + computeRotation2DOneToN: best_rotation(reference, image) for n square images.
-// Runs on the projection matcher (one reference, rings first_ring .. last_ring, the mirrored particle switched off), i.e. with the
-// matcher's cubic B-spline polar sampling and its exact arg-max; the reference samples the rings with BsplineOrder 1
-// (polar_rotation_estimator.cpp:60,99) -- the correlation values differ in the last digits, the angle by at most one sample of the
-// outer ring in near-ties. best_rotation correlates (reference, image) where the matcher correlates (image, reference):
-// the index is mirrored, result = ((N - psi) mod N) 360 / N degrees.
-static int es_rotation_create(xh_ctx *ctx, const float *d_ref, int32_t D, int32_t first_ring, int32_t last_ring, xh_pm **out, int32_t *N)
-{
-    // RotationEstimationSetting::check + PolarRotationEstimator::check (arotation_estimator.h:80-130, polar_rotation_estimator.cpp:125-141)
-    XH_CHECK(D >= 6, XH_ERR_ARG, "xh_rotation_estimate: The input signal is too small.");
-    XH_CHECK(first_ring >= 1 && last_ring > first_ring && last_ring < D, XH_ERR_ARG, "xh_rotation_estimate: rings %d .. %d of a %d px image (first >= 1, last > first, last < size)",
-             first_ring, last_ring, D);
-    XH_CHECK(last_ring <= D / 2 - 1, XH_ERR_ARG, "xh_rotation_estimate: the last ring (%d) needs an edge around it: at most %d for %d px", last_ring, D / 2 - 1, D);
-    xh_pm *pm = nullptr;
-    XH_TRY(xh_pm_create(ctx, D, first_ring, last_ring, 1, d_ref, nullptr, 0, &pm));
-    int rc = xh_pm_set_option(pm, "mirror", 0.0);
-    if (rc == XH_OK) rc = xh_pm_info(pm, N, nullptr, nullptr);
-    if (rc != XH_OK) { xh_pm_destroy(pm); return rc; }
-    *out = pm;
-    return XH_OK;
-}
-
-static int es_rotation_run(xh_ctx *ctx, xh_pm *pm, int32_t N, const float *d_others, int32_t n, float *h_rotations)
-{
-    XhBuf bRef, bPsi, bFlip;
-    int rc = xh_buf_alloc(ctx, bRef, sizeof(int32_t) * n);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPsi, sizeof(int32_t) * n);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bFlip, n);
-    if (rc == XH_OK) rc = xh_pm_match(pm, d_others, n, nullptr, nullptr, 0, (int32_t *)bRef.p, (int32_t *)bPsi.p, (uint8_t *)bFlip.p);
-    std::vector<int32_t> psi(n);
-    if (rc == XH_OK && hipMemcpyAsync(psi.data(), bPsi.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
-    if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
-    xh_buf_free(bRef); xh_buf_free(bPsi); xh_buf_free(bFlip);
-    if (rc != XH_OK) return rc;
-    for (int i = 0; i < n; ++i) h_rotations[i] = (float)(((N - psi[i]) % N) * (360.0 / N));
-    return XH_OK;
-}
-
+// PolarRotationEstimator::load2DReferenceOneToN + computeRotation2DOneToN: best_rotation(reference, image) for n square images, the
+// reference's arithmetic (kernels above); h_corr (optional, [n][2 N - 1] doubles) receives the correlation rows
 int xh_rotation_estimate(xh_ctx *ctx, const float *d_ref, const float *d_others, int32_t n, int32_t D, int32_t first_ring, int32_t last_ring, float *h_rotations)
 {
     XH_CHECK(ctx && d_ref && d_others && h_rotations && n >= 1, XH_ERR_ARG, "xh_rotation_estimate: bad argument");
-    xh_pm *pm = nullptr;
-    int32_t N = 0;
-    XH_TRY(es_rotation_create(ctx, d_ref, D, first_ring, last_ring, &pm, &N));
-    const int rc = es_rotation_run(ctx, pm, N, d_others, n, h_rotations);
-    xh_pm_destroy(pm);
+    XH_HIP(hipSetDevice(ctx->device));
+    EsRotation R;
+    int rc = es_rotation_create(ctx, d_ref, D, first_ring, last_ring, R);
+    if (rc == XH_OK) rc = es_rotation_run(R, d_others, n, h_rotations);
+    (void)hipStreamSynchronize(ctx->stream);
+    es_rotation_free(R);
     return rc;
 }
 
@@ -389,11 +577,10 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
     XH_HIP(hipSetDevice(ctx->device));
     xh_shiftcorr *sc = nullptr;
     XH_TRY(xh_shiftcorr_create(ctx, D, D, max_shift, &sc));
-    xh_pm *pm = nullptr;                 // the rotation estimator: one matcher over the one reference for all rounds
-    int32_t Npsi = 0;
+    EsRotation rotEst;                   // the rotation estimator: the reference's polar transform once for all rounds
     {
-        const int r0 = es_rotation_create(ctx, d_ref, D, first_ring, last_ring, &pm, &Npsi);
-        if (r0 != XH_OK) { xh_shiftcorr_destroy(sc); return r0; }
+        const int r0 = es_rotation_create(ctx, d_ref, D, first_ring, last_ring, rotEst);
+        if (r0 != XH_OK) { es_rotation_free(rotEst); xh_shiftcorr_destroy(sc); return r0; }
     }
     const size_t per = (size_t)D * D;
     XhBuf bDest;
@@ -409,8 +596,9 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
             o[0] = m[8] * m[4] - m[7] * m[5]; o[1] = -(m[8] * m[1] - m[7] * m[2]); o[2] = m[5] * m[1] - m[4] * m[2];
             o[3] = -(m[8] * m[3] - m[6] * m[5]); o[4] = m[8] * m[0] - m[6] * m[2]; o[5] = -(m[5] * m[0] - m[3] * m[2]);
             o[6] = m[7] * m[3] - m[6] * m[4]; o[7] = -(m[7] * m[0] - m[6] * m[1]); o[8] = m[4] * m[0] - m[3] * m[1];
-            const float det = m[0] * o[0] + m[3] * o[1] + m[6] * o[2];
-            for (int q = 0; q < 9; ++q) o[q] /= det;
+            // M3x3_INV: "spduptmp0 = 1.0 / (...)" is a double (SPEED_UP_temps0), the matrix is scaled by it and stored as floats
+            const double t = 1.0 / (double)(m[0] * o[0] + m[3] * o[1] + m[6] * o[2]);
+            for (int q = 0; q < 9; ++q) o[q] = (float)(o[q] * t);
         }
         return xh_apply_geometry2d(ctx, d_others, n, D, D, inv.data(), dest);
     };
@@ -419,7 +607,7 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
         for (int j = 0; j < n; ++j) poses[9 * (size_t)j] = poses[9 * (size_t)j + 4] = poses[9 * (size_t)j + 8] = 1.f;
         int r2 = hipMemcpyAsync(dest, d_others, sizeof(float) * per * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? XH_OK : XH_ERR_HIP;   // copySrcToDest
         auto stepRotation = [&]() {
-            int r3 = es_rotation_run(ctx, pm, Npsi, dest, n, rot.data());
+            int r3 = es_rotation_run(rotEst, dest, n, rot.data());
             if (r3 != XH_OK) return r3;
             for (int j = 0; j < n; ++j) {
                 // rotation2DMatrix(angle, r); lhs = r * lhs
@@ -459,7 +647,8 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
         }
     xh_buf_free(bDest);
     xh_shiftcorr_destroy(sc);
-    xh_pm_destroy(pm);
+    (void)hipStreamSynchronize(ctx->stream);
+    es_rotation_free(rotEst);
     return rc;
 }
 

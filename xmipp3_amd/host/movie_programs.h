@@ -239,7 +239,10 @@ public:
                 for (int t = 0; t < N; ++t) {
                     double bx, by;
                     splineShift(coeffsX, coeffsY, (int)I.x, (int)I.y, N, (int)centers[2 * p], (int)centers[2 * p + 1], t, bx, by);
-                    dist.push_back(std::hypot(bx - sx[t], by - sy[t]));
+                    // BSplineHelper::getShift(grid, ...) hands (shiftX, shiftY) to a callee declared (T &shiftY, T &shiftX, ...)
+                    // (bspline_helper.cpp:99 against :112), so the pair storeResults receives is (Y, X): the reference's two
+                    // confidence scalars are hypot(splineY - globalX, splineX - globalY).  Reproduced: same outputs.
+                    dist.push_back(std::hypot(by - sx[t], bx - sy[t]));
                 }
             std::sort(dist.begin(), dist.end());
             MetaDataVec md;
