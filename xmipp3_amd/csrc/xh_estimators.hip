@@ -16,12 +16,14 @@
 //                                           (BSplineGeoTransformer::interpolate, bspline_geo_transformer.cpp:103-137: applyGeometry
 //                                           LINEAR, IS_INV, DONT_WRAP), both orders tried, the better correlationIndex
 //                                           (CorrelationComputer, correlation_computer.cpp:30-56) kept per image
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "xh_common.h"
 #include "xh_bspline.h"
+#include "xh_plan.h"
 
 namespace {
 typedef float2 es_cf;
@@ -84,6 +86,31 @@ __global__ void __launch_bounds__(256) k_es_correlate(es_cf *__restrict__ inOut,
     es_cf v = es_cf{r.x * o.x + r.y * o.y, r.y * o.x - r.x * o.y};
     if (center && ((x + y) & 1)) { v.x = -v.x; v.y = -v.y; }
     inOut[t] = v;
+}
+
+// the shift estimator's own transforms are double precision (below): image -> complex, ref conj(other) (-1)^(x+y), real part -> float
+__global__ void __launch_bounds__(256) k_es_to_complex64(const float *__restrict__ in, xh_cd *__restrict__ out, size_t tot)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < tot) out[t] = xh_cd{(double)in[t], 0.0};
+}
+
+__global__ void __launch_bounds__(256) k_es_correlate64(xh_cd *__restrict__ inOut, const xh_cd *__restrict__ ref, size_t per, int xdim, size_t total)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const size_t e = t % per;
+    const int y = (int)(e / xdim), x = (int)(e - (size_t)y * xdim);
+    const xh_cd r = ref[e], o = inOut[t];
+    xh_cd v = xh_cd{r.x * o.x + r.y * o.y, r.y * o.x - r.x * o.y};
+    if ((x + y) & 1) { v.x = -v.x; v.y = -v.y; }
+    inOut[t] = v;
+}
+
+__global__ void __launch_bounds__(256) k_es_real64(const xh_cd *__restrict__ in, float *__restrict__ out, size_t tot)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < tot) out[t] = (float)in[t].x;
 }
 
 __global__ void __launch_bounds__(256) k_es_to_complex(const float *__restrict__ in, es_cf *__restrict__ out, size_t tot)
@@ -386,10 +413,29 @@ static int es_rotation_run(EsRotation &R, const float *d_others, int n, float *h
 struct xh_shiftcorr {
     xh_ctx *ctx;
     int x, y, maxShift;
-    xh_fft2d *plan;
+    XhPlanBufs<double> planX, planY;      // line transforms of any length (xh_plan.h), double precision
     XhBuf ref, work, map, pos;
     bool refLoaded;
 };
+
+// 2-D complex transform of n images [n][y][x] (double) in place, un-normalised: rows then columns
+static int es_fft2d64(xh_shiftcorr *h, xh_cd *d, int n, bool inverse)
+{
+    xh_ctx *ctx = h->ctx;
+    const size_t budget = 64 * 1024;
+    const int lx = xh_plan_lpb(h->planX.plan, budget, 16), ly = xh_plan_lpb(h->planY.plan, budget, 16);
+    const size_t rows = (size_t)n * h->y, cols = (size_t)n * h->x;
+    const size_t smx = ((size_t)lx * sizeof(xh_cd)) << h->planX.plan.logM, smy = ((size_t)ly * sizeof(xh_cd)) << h->planY.plan.logM;
+    if (!inverse) {
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((rows + lx - 1) / lx)), dim3(256), smx, ctx->stream, d, h->planX.plan, rows, rows, (size_t)0, (size_t)h->x, (size_t)1, lx);
+        hipLaunchKernelGGL((xh_k_fft_lines<double, false>), dim3((unsigned)((cols + ly - 1) / ly)), dim3(256), smy, ctx->stream, d, h->planY.plan, cols, (size_t)h->x, (size_t)h->x * h->y, (size_t)1, (size_t)h->x, ly);
+    } else {
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((cols + ly - 1) / ly)), dim3(256), smy, ctx->stream, d, h->planY.plan, cols, (size_t)h->x, (size_t)h->x * h->y, (size_t)1, (size_t)h->x, ly);
+        hipLaunchKernelGGL((xh_k_fft_lines<double, true>), dim3((unsigned)((rows + lx - 1) / lx)), dim3(256), smx, ctx->stream, d, h->planX.plan, rows, rows, (size_t)0, (size_t)h->x, (size_t)1, lx);
+    }
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
 
 extern "C" {
 
@@ -431,7 +477,7 @@ int xh_shiftcorr_destroy(xh_shiftcorr *h)
     if (!h) return XH_OK;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    if (h->plan) xh_fft2d_destroy(h->plan);
+    xh_plan_free(h->planX); xh_plan_free(h->planY);
     xh_buf_free(h->ref); xh_buf_free(h->work); xh_buf_free(h->map); xh_buf_free(h->pos);
     delete h;
     return XH_OK;
@@ -446,10 +492,17 @@ int xh_shiftcorr_create(xh_ctx *ctx, int32_t xdim, int32_t ydim, int32_t max_shi
     XH_CHECK(max_shift > 0 && max_shift < xdim / 2 && max_shift < ydim / 2, XH_ERR_ARG, "xh_shiftcorr_create: the maximal shift must be positive and sharply less than half of the size");
     XH_HIP(hipSetDevice(ctx->device));
     xh_shiftcorr *h = new xh_shiftcorr;
-    h->ctx = ctx; h->x = xdim; h->y = ydim; h->maxShift = max_shift; h->plan = nullptr; h->refLoaded = false;
-    int rc = xh_fft2d_create(ctx, ydim, xdim, &h->plan);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->ref, sizeof(es_cf) * (size_t)xdim * ydim);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->work, sizeof(es_cf) * (size_t)xdim * ydim);
+    h->ctx = ctx; h->x = xdim; h->y = ydim; h->maxShift = max_shift; h->refLoaded = false;
+    // The reference's ShiftCorrEstimator<float> transforms with fftwf; its test images (one-pixel lines) give correlation maps full of
+    // exact ties, which single-precision rounding breaks at random.  The device transforms in double and compares the map as floats,
+    // so that the first maximum in raster order is the one exact arithmetic has (and the oracle's).
+    int rc = xh_plan_create<double>(ctx, xdim, h->planX);
+    if (rc == XH_OK) rc = xh_plan_create<double>(ctx, ydim, h->planY);
+    if (rc == XH_OK && ((sizeof(xh_cd) << h->planX.plan.logM) > 64 * 1024 || (sizeof(xh_cd) << h->planY.plan.logM) > 64 * 1024)) {
+        xh_set_error("xh_shiftcorr_create: a line of %d x %d does not fit the LDS of the double-precision transform", xdim, ydim);
+        rc = XH_ERR_UNSUPPORTED;
+    }
+    if (rc == XH_OK) rc = xh_buf_alloc(ctx, h->ref, sizeof(xh_cd) * (size_t)xdim * ydim);
     if (rc != XH_OK) { xh_shiftcorr_destroy(h); return rc; }
     *out = h;
     return XH_OK;
@@ -462,9 +515,9 @@ int xh_shiftcorr_load_reference(xh_shiftcorr *h, const float *d_ref)
     xh_ctx *ctx = h->ctx;
     XH_HIP(hipSetDevice(ctx->device));
     const size_t tot = (size_t)h->x * h->y;
-    hipLaunchKernelGGL(k_es_to_complex, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_ref, (es_cf *)h->ref.p, tot);
+    hipLaunchKernelGGL(k_es_to_complex64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_ref, (xh_cd *)h->ref.p, tot);
     XH_LAUNCH_CHECK();
-    XH_TRY(xh_fft2d_exec(h->plan, (float *)h->ref.p, 0));
+    XH_TRY(es_fft2d64(h, (xh_cd *)h->ref.p, 1, false));
     h->refLoaded = true;
     return XH_OK;
 }
@@ -492,14 +545,18 @@ int xh_shiftcorr_compute_shifts(xh_shiftcorr *h, const float *d_others, int32_t 
     const size_t tot = (size_t)h->x * h->y;
     XH_TRY(xh_buf_reserve(ctx, h->map, sizeof(float) * tot * (size_t)n));
     XH_TRY(xh_buf_reserve(ctx, h->pos, sizeof(float) * (size_t)n));
-    const unsigned grid = (unsigned)((tot + 255) / 256);
-    for (int i = 0; i < n; ++i) {
-        es_cf *w = (es_cf *)h->work.p;
-        hipLaunchKernelGGL(k_es_to_complex, dim3(grid), dim3(256), 0, ctx->stream, d_others + (size_t)i * tot, w, tot);
-        XH_TRY(xh_fft2d_exec(h->plan, (float *)w, 0));
-        hipLaunchKernelGGL(k_es_correlate, dim3(grid), dim3(256), 0, ctx->stream, w, (const es_cf *)h->ref.p, tot, h->x, tot, 1);
-        XH_TRY(xh_fft2d_exec(h->plan, (float *)w, 1));
-        hipLaunchKernelGGL(k_es_real, dim3(grid), dim3(256), 0, ctx->stream, (const es_cf *)w, (float *)h->map.p + (size_t)i * tot, tot);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / (sizeof(xh_cd) * tot)));      // at most 1 GiB of work space
+    XH_TRY(xh_buf_reserve(ctx, h->work, sizeof(xh_cd) * tot * (size_t)chunk));
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        const size_t total = tot * (size_t)m;
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        xh_cd *w = (xh_cd *)h->work.p;
+        hipLaunchKernelGGL(k_es_to_complex64, dim3(grid), dim3(256), 0, ctx->stream, d_others + (size_t)i0 * tot, w, total);
+        XH_TRY(es_fft2d64(h, w, m, false));
+        hipLaunchKernelGGL(k_es_correlate64, dim3(grid), dim3(256), 0, ctx->stream, w, (const xh_cd *)h->ref.p, tot, h->x, total);
+        XH_TRY(es_fft2d64(h, w, m, true));
+        hipLaunchKernelGGL(k_es_real64, dim3(grid), dim3(256), 0, ctx->stream, (const xh_cd *)w, (float *)h->map.p + (size_t)i0 * tot, total);
         XH_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((k_es_extrema<false>), dim3(n), dim3(256), 0, ctx->stream, (const float *)h->map.p, tot, h->y, h->x, 1, h->maxShift, 0, (float *)h->pos.p, (float *)nullptr);
