@@ -137,6 +137,8 @@ def lib():
         "xo_fp_project": (None, [vp, d, d, d, c_double_p, c_double_p]),
         "xo_frc_dpr": (i, [c_double_p, c_double_p, i, i, i, d, i, i, d, d, c_double_p, c_double_p, c_double_p,
                            c_double_p, c_double_p, c_double_p]),
+        "xo_fa_local_patch_shifts_f32": (i, [c_float_p, i, i, i, c_double_p, c_double_p, i, C.c_float, C.c_float, C.c_float, i, i, i, i, i, c_uint8_p,
+                                             c_double_p, c_double_p, c_int32_p]),
         "xo_es_rotation_corr_len": (i, [i, i]),
         "xo_es_polar_rotation": (None, [c_double_p, c_double_p, i, i, i, i, c_double_p, c_double_p]),
         "xo_es_shifts": (None, [c_float_p, c_float_p, i, i, i, i, c_float_p]),
@@ -419,6 +421,24 @@ def fa_local_alignment(frames, g_shift_x, g_shift_y, ref, Ts=1.0, max_shift_px=5
     if rc != 0:
         raise ValueError("Movie is too small for local alignment.")
     return {"patch_shifts": shifts, "centers": centers, "coeffsX": cx, "coeffsY": cy, "dims": tuple(dims)}
+
+
+def fa_local_patch_shifts(frames, g_shift_x, g_shift_y, ref, mask, Ts=1.0, max_shift_px=50.0, max_res=30.0, patches=(7, 7), patch_size=(500, 500), patches_avg=3):
+    """xo_fa_local_alignment on float32 frames for the patches mask [py, px] marks: (patch_shifts [py, px, N, 2] -- NaN where
+    not computed --, centers [py, px, 2], dims)"""
+    fr = np.ascontiguousarray(frames, dtype=np.float32)
+    N, Y, X = fr.shape
+    px, py = patches
+    gx, gy = f64(g_shift_x), f64(g_shift_y)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    assert m.shape == (py, px)
+    shifts, centers = np.full((py, px, N, 2), np.nan), np.empty((py, px, 2))
+    dims = np.zeros(4, np.int32)
+    rc = lib().xo_fa_local_patch_shifts_f32(_fp(fr), N, Y, X, _dp(gx), _dp(gy), int(ref), Ts, max_shift_px, max_res, px, py, int(patch_size[0]), int(patch_size[1]),
+                                            int(patches_avg), m.ctypes.data_as(c_uint8_p), _dp(shifts), _dp(centers), _ip(dims))
+    if rc != 0:
+        raise ValueError("movie too small for the patches")
+    return shifts, centers, tuple(int(v) for v in dims)
 
 
 def fa_bspline_shift(coeffsX, coeffsY, control_points, X, Y, N, x, y, n):

@@ -147,6 +147,10 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
                           float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
                           int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
                           double *coeffsY, int *dims);
+/* the same on float frames for the patches patchMask [py][px] marks (full-size tests): centres of all, shifts of the marked ones, no fit */
+int xo_fa_local_patch_shifts_f32(const float *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+                                 float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
+                                 int patchesAvg, const uint8_t *patchMask, double *patchShifts, double *centers, int *dims);
 void xo_fa_bspline_shift(const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int X, int Y, int N, int x, int y, int n,
                          double *shiftX, double *shiftY);
 void xo_fa_apply_bspline(const double *frame, int Y, int X, const double *coeffsX, const double *coeffsY, int lX, int lY, int lT, int N, int n,

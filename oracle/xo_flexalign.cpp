@@ -337,10 +337,13 @@ int xo_fa_global_alignment(const double *frames, int N, int Y, int X, const doub
 // Outputs: patchShifts [py][px][N][2] = round(global) + local (x, y); centers [py][px][2]; B-spline coefficients
 // coeffsX / coeffsY [lT][lY][lX] (computeBSplineCoeffs: they describe the OPPOSITE transformation, used to compensate).
 // dims[4] = (patch size x, y, correlation size x, y). Returns 0, or 2 when the movie is too small for the patches.
-int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+}  // extern "C"
+
+template <typename FT>
+static int local_alignment_impl(const FT *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
                           float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
                           int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
-                          double *coeffsY, int *dims)
+                          double *coeffsY, int *dims, const uint8_t *patchMask)
 {
     const float c = std::sqrt(-1.f / (2.f * std::log(0.5f)));
     const float reqScale = Ts / (maxRes / (8.f * c));                       // getScaleFactor
@@ -377,12 +380,13 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
             // Rectangle::getCenter: (tl + br) / 2 ... of the point type T (float): the centre may be fractional
             const double cx = (tlx + brx) / 2, cy = (tly + bry) / 2;
             centers[((size_t)py * patchesX + px) * 2] = cx; centers[((size_t)py * patchesX + px) * 2 + 1] = cy;
+            if (patchMask && !patchMask[(size_t)py * patchesX + px]) continue;          // a subset of the patches (full-size tests): their shifts only
             for (int t = 0; t < N; ++t) {
                 // getPatchData (:166-202): the frames t - (avg-1)/2 .. t + avg/2 at their rounded global shift, summed
                 std::fill(patch.begin(), patch.end(), 0.0);
                 for (int f = std::max(0, t - ((patchesAvg - 1) / 2)); f <= std::min(N - 1, t + (patchesAvg / 2)); ++f) {
                     const int xs = (int)std::round(gShiftX[f]), ys = (int)std::round(gShiftY[f]);
-                    const double *fr = frames + (size_t)f * Y * X;
+                    const FT *fr = frames + (size_t)f * Y * X;
                     for (int y = 0; y < PY; ++y) {
                         const int srcY = (int)tly + y + ys, srcX = (int)tlx + xs;
                         for (int x = 0; x < PX; ++x) patch[(size_t)y * PX + x] += fr[(size_t)srcY * X + srcX + x];
@@ -419,6 +423,7 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
                 o[1] = std::round(gShiftY[t]) + lsy[t];
             }
         }
+    if (patchMask) return 0;               // no fit over a subset
     // BSplineHelper::computeBSplineCoeffs (bspline_helper.cpp:34-87)
     const int nP = patchesX * patchesY, R = nP * N, Cc = lX * lY * lT;
     std::vector<double> A((size_t)R * Cc, 0.0), bX(R), bY(R), cX, cY;
@@ -446,6 +451,27 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
     solve_system(A, R, Cc, bX, bY, 2, cX, cY);
     for (int k = 0; k < Cc; ++k) { coeffsX[k] = cX[k]; coeffsY[k] = cY[k]; }
     return 0;
+}
+
+extern "C" {
+
+int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+                          float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
+                          int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
+                          double *coeffsY, int *dims)
+{
+    return local_alignment_impl<double>(frames, N, Y, X, gShiftX, gShiftY, refFrame, Ts, maxShift, maxRes, patchesX, patchesY, patchSizeX, patchSizeY,
+                                        patchesAvg, lX, lY, lT, patchShifts, centers, coeffsX, coeffsY, dims, nullptr);
+}
+
+// The same on float frames (a K3 movie is 3.8 GB as floats) and for the patches patchMask [py][px] marks: centres of every patch,
+// shifts of the marked ones, no spline fit.
+int xo_fa_local_patch_shifts_f32(const float *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
+                                 float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
+                                 int patchesAvg, const uint8_t *patchMask, double *patchShifts, double *centers, int *dims)
+{
+    return local_alignment_impl<float>(frames, N, Y, X, gShiftX, gShiftY, refFrame, Ts, maxShift, maxRes, patchesX, patchesY, patchSizeX, patchSizeY,
+                                       patchesAvg, 3, 3, 3, patchShifts, centers, nullptr, nullptr, dims, patchMask);
 }
 
 // BSplineHelper::getShift (bspline_helper.cpp:104-148) at pixel (x, y) of frame n
