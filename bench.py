@@ -55,7 +55,10 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=4096, help="particles per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU sample (0 = auto)")
-    ap.add_argument("--mode", default="full", choices=["full", "match", "grid"])
+    ap.add_argument("--mode", default="full", choices=["full", "match", "grid", "flexalign"],
+                    help="full / match / grid: the refine iteration or one half of it; flexalign: BASELINE config 5, one K3 movie per step "
+                         "(global + local alignment, warp + sum), movies streamed from page-locked host memory")
+    ap.add_argument("--movie", default="40x4092x5760", help="flexalign mode: frames x rows x columns of a movie")
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
     ap.add_argument("--tr-chunk-mb", type=int, default=0, help="S6 scratch per pass in MB (0: library default)")
@@ -161,6 +164,210 @@ def cpu_model():
     return "unknown"
 
 
+
+def main_flexalign(args):
+    """BASELINE config 5: FlexAlign on K3 movies (40 frames of 4092 x 5760), one movie per step and rank.  Inside the timed region, per movie: the
+    movie's 3.8 GB come from page-locked host memory (two device buffers: the copy of movie k+1 flies on its own stream under the
+    alignment of movie k; only the first copy precedes the clock), global alignment (movie_alignment_correlation_gpu.cpp:633-725), local
+    alignment with the program's defaults (12 x 9 patches of 500 px, three frames per patch, 6 x 6 x 5 control points; :288-430), B-spline
+    warp of every frame into the aligned sum (:460-560), and the sum's copy back to page-locked host memory.  N ranks = N movies at a
+    time, no exchange ("replicas only")."""
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if local == 0:
+            ge.build()
+        dist.barrier()
+    else:
+        ge.build()
+    import xmipp3_amd as xa
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    ctx = xa.Context(local)
+    N, Y, X = (int(v) for v in args.movie.lower().split("x"))
+    Ts, max_res, max_shift = 1.0, 30.0, 50.0
+    req = int(500 / Ts)
+    patches, psize, cp = (int(math.ceil(X / req)), int(math.ceil(Y / req))), (req, req), (6, 6, 5)
+
+    # ---- two synthetic movies: a smooth random field under a global drift (fast at first, settling) plus a dilation / shear that grows
+    # with time, white noise per frame; generated on the device, kept in page-locked host memory
+    def make_movie(seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        base = torch.randn((Y + 128, X + 128), generator=g, device=dev)
+        k = torch.fft.rfft2(base)
+        fy = torch.fft.fftfreq(Y + 128, device=dev)[:, None]
+        fx = torch.fft.rfftfreq(X + 128, device=dev)[None, :]
+        base = torch.fft.irfft2(k * torch.exp(-2 * (math.pi * 4.0) ** 2 * (fx * fx + fy * fy)), s=base.shape) * 30
+        del k
+        t = np.arange(N, dtype=np.float64)
+        sgn = 1.0 if seed % 2 else -1.0
+        drift = np.stack([sgn * 14.0 * (1 - np.exp(-t / 9.0)) + 0.04 * t, -9.0 * (1 - np.exp(-t / 14.0)) + 0.06 * t], 1)
+        H, W = base.shape
+        ys = torch.arange(Y, device=dev, dtype=torch.float32)[:, None]
+        xs = torch.arange(X, device=dev, dtype=torch.float32)[None, :]
+        u, v = (xs / X - 0.5) * 2, (ys / Y - 0.5) * 2
+        mv = torch.empty((N, Y, X), device=dev)
+        for n in range(N):
+            a = 6.0 * n / max(1, N - 1)
+            sx = xs + 64 + float(drift[n, 0]) + a * (0.7 * u + 0.3 * v)
+            sy = ys + 64 + float(drift[n, 1]) + a * (0.8 * v - 0.2 * u)
+            grid = torch.stack(((sx + 0.5) * (2.0 / W) - 1, (sy + 0.5) * (2.0 / H) - 1), -1)[None]
+            mv[n] = torch.nn.functional.grid_sample(base[None, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
+            mv[n] += 0.5 * torch.randn((Y, X), generator=g, device=dev)
+            del grid, sx, sy
+        hb = torch.empty(mv.shape, dtype=mv.dtype, pin_memory=True)
+        hb.copy_(mv)
+        del mv, base
+        return hb, drift
+    nuniq = 2
+    host, drifts = zip(*[make_movie(11 + 2 * rank + u) for u in range(nuniq)])
+    torch.cuda.empty_cache()
+    fa = xa.FlexAlign(ctx, Y, X, Ts, max_res)
+    dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
+    total = torch.zeros((Y, X), device=dev)
+    h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    timers = {"global_alignment": [], "local_alignment": [], "warp_and_sum": []}
+    results = []
+
+    def timed(name, record, fn):
+        if not record:
+            return fn()
+        t = ctx.timer()
+        t.start()
+        r = fn()
+        t.stop()
+        timers[name].append(t)
+        return r
+
+    def fetch(k):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[k & 1])
+            dbuf[k & 1].copy_(host[k % nuniq], non_blocking=True)
+            ready[k & 1].record(copy_stream)
+
+    def align(frames, record, slot):
+        gl = timed("global_alignment", record, lambda: fa.global_alignment(frames, max_shift))
+        loc = timed("local_alignment", record, lambda: fa.local_alignment(frames, gl["shiftX"], gl["shiftY"], gl["ref"], max_shift, patches, psize, 3, cp))
+
+        def warp():
+            total.zero_()
+            for n in range(N):
+                fa.apply_bspline(frames[n], loc["coeffsX"], loc["coeffsY"], cp, N, n, total=total)
+        timed("warp_and_sum", record, warp)
+        h_avg[slot].copy_(total, non_blocking=True)              # the aligned micrograph goes back to the host
+        return gl, loc
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def streamed(nsteps, record):
+        for e in done:
+            e.record()
+        fetch(0)
+        barrier()
+        ta = time.perf_counter()
+        for k in range(nsteps):
+            if k + 1 < nsteps:
+                fetch(k + 1)
+            torch.cuda.current_stream().wait_event(ready[k & 1])
+            r = align(dbuf[k & 1], record, k & 1)
+            done[k & 1].record()
+            if record:
+                results.append((k % nuniq, r[0]))
+        barrier()
+        return time.perf_counter() - ta
+
+    if args.warmup:
+        streamed(args.warmup, False)
+    elapsed = streamed(args.steps, True)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    # the same movies resident in HBM (what the host traffic costs)
+    barrier()
+    tr0 = time.perf_counter()
+    nres = max(2, min(args.steps, 3))
+    for k in range(nres):
+        align(dbuf[k & 1], False, k & 1)
+    barrier()
+    resident = nres * world / (time.perf_counter() - tr0)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    stage = {k_: float(sum(t.elapsed_ms() for t in ts)) for k_, ts in timers.items()}
+    # algorithmic bytes per movie of each stage: the global alignment reads every frame once and keeps the low-frequency columns of its
+    # transform (complex, nY x (nX / 2 + 1)); the local alignment reads every patch of every frame and of the two frames averaged with it;
+    # the warp reads a frame and writes (accumulates) a frame per frame
+    nY, nX = fa.new_dims
+    by = {"global_alignment": N * (Y * X * 4 + nY * (nX // 2 + 1) * 8),
+          "local_alignment": patches[0] * patches[1] * psize[0] * psize[1] * N * 3 * 4,
+          "warp_and_sum": N * Y * X * 8}
+    kern = {"global_alignment": "k_fft2d rows/columns of the frame transforms + pair correlations (xh_fa_global_alignment)",
+            "local_alignment": "k_fa_gather + k_fa_gemm_mfma + pair windows (xh_fa_local_alignment)",
+            "warp_and_sum": "k_fa_prefilter + k_fa_warp (xh_fa_apply_bspline, 40 frames)"}
+    dom = max(stage, key=lambda k_: stage[k_])
+    mk = lambda k_: {"kernel": kern[k_], "bound": "hbm", "achieved": args.steps * by[k_] / (stage[k_] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": args.steps * by[k_] / (stage[k_] * 1e-3) / 1e9 / 8000.0, "traffic": None, "ms_in_timed_region": stage[k_],
+                     "avg_ms_per_movie": stage[k_] / args.steps, "algorithmic_bytes_per_movie": by[k_]}
+    # physics check of the timed movies: the drift that was put in comes out of the global alignment
+    err = 0.0
+    for u, gl in results:
+        tt = drifts[u] - drifts[u][gl["ref"]]
+        err = max(err, float(np.abs(gl["shiftX"] + tt[:, 0]).max()), float(np.abs(gl["shiftY"] + tt[:, 1]).max()))
+    out = {"metric": f"movies/s FlexAlign (global + local alignment, B-spline warp + sum), {X}x{Y}x{N} frames", "value": args.steps * world / elapsed,
+           "unit": "movies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (transforms, correlations, warp) + f64 (shift solves, spline fit on the host)",
+           "data": "synthetic",
+           "config": {"workload": f"FlexAlign movie alignment, {N} frames of {Y}x{X} (BASELINE config 5), patch cross-correlation path: {patches[0]}x{patches[1]} patches of "
+                                  f"{req} px, control points {cp}, {max_res} A at {Ts} A/px", "mode": "flexalign", "movies_total": args.steps * world,
+                      "unique_movies_per_gpu": nuniq,
+                      "host_traffic": f"every movie ({N * Y * X * 4 / 1e9:.2f} GB of float32 frames) H2D from page-locked memory inside the timed region (two device buffers, "
+                                      "copy stream), the aligned sum D2H", "parallelism": f"movie replicas x{world}, no exchange"},
+           "roofline": mk(dom), "roofline_other_kernels": {k_: mk(k_) for k_ in stage if k_ != dom},
+           "stage_ms": stage, "value_resident": resident, "global_shift_error_px": err}
+    if not args.no_cpu_baseline and world == 1:
+        # the oracle's global alignment (ProgMovieAlignmentCorrelation<double>'s arithmetic, one thread) on the first 2 and the first 3 frames
+        # of movie 0 at full size: T(n) = n t_frame + n (n - 1) / 2 t_pair, extrapolated to the movie's frames.  The local alignment and
+        # the warp are NOT in it (the reference has no CPU form of the patch path): a lower bound of the CPU cost of a movie.
+        from oracle import pyoracle as o
+        f3 = host[0][:3].numpy()
+        tb = []
+        for n in (2, 3):
+            t0 = time.perf_counter()
+            og = o.fa_global_alignment(f3[:n], Ts=Ts, max_shift_px=max_shift, max_res=max_res)
+            tb.append(time.perf_counter() - t0)
+        # T(2) = 2 f + p, T(3) = 3 f + 3 p  =>  p = (2 T(3) - 3 T(2)) / 3, f = (T(2) - p) / 2
+        pp = max(0.0, (2 * tb[1] - 3 * tb[0]) / 3.0)
+        ff = (tb[0] - pp) / 2.0
+        movie_s = N * ff + N * (N - 1) / 2 * pp
+        dg = fa.global_alignment(torch.from_numpy(f3).to(dev), max_shift)
+        out["cpu_baseline"] = {"value": 1.0 / movie_s, "unit": "movies/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                               "frame_s": ff, "pair_s": pp,
+                               "sample": f"oracle global alignment of the first 2 ({tb[0]:.1f} s) and 3 ({tb[1]:.1f} s) frames of movie 0 at full size, one thread, "
+                                         f"extrapolated to {N} frames and {N * (N - 1) // 2} pairs; local alignment and warp not included"}
+        out["parity_sample"] = {"what": "pair shifts of the device against the oracle on those 3 frames (px)",
+                                "max_abs_diff": float(max(np.abs(dg["bX"] - og["bX"]).max(), np.abs(dg["bY"] - og["bY"]).max()))}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -171,6 +378,8 @@ def main():
         sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.sdma >= 0:
         os.environ["HSA_ENABLE_SDMA"] = str(args.sdma)          # read when the runtime starts: before torch is imported
+    if args.mode == "flexalign":
+        return main_flexalign(args)
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -232,7 +441,7 @@ def main():
         refs = ((refs - refs.mean()) / refs.std()).contiguous()
     else:
         refs = smooth_noise(torch, nrefs, D, genr, dev)
-    def make_batch():
+    def make_batch(refs=refs):
         """particle = reference, random in-plane rotation, mirror with p = 0.5, shift U{-3..3}^2, white noise at SNR 0.1"""
         idx = torch.randint(0, nrefs, (B,), generator=gen, device=dev)
         th = torch.rand((B,), generator=gen, device=dev) * (2 * math.pi)
@@ -332,7 +541,7 @@ def main():
                   "sy": torch.empty(B, dtype=torch.float64, pin_memory=True), "cc": torch.empty(B, dtype=torch.float64, pin_memory=True)}
                  for _ in range(2)]
 
-    def step(record, parts=None, u=0, slot=None, pipe=True):
+    def step(record, parts=None, u=0, slot=None, pipe=True, pm=pm):
         ang = flips = None
         if parts is None:
             parts = particles
@@ -445,6 +654,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     stage = pm.stage_ms(reset=False) if pm is not None else {}
+    stage = dict(stage)
     k_ms, k_launches = rf.kernel_ms(reset=False) if rf is not None else (0.0, 0)
     stats_timed = pm.last_stats() if pm is not None else None
 
@@ -470,6 +680,7 @@ def main():
             # (1b) the same without the second stream: every stage of a step behind the one before it
             if rf is not None:
                 rf.kernel_ms(reset=True)
+            stage_timed = pm.stage_ms(reset=True) if pm is not None else {}       # (the timed region's, kept; the timers restart)
             barrier()
             ts0 = time.perf_counter()
             for _ in range(nres):
@@ -482,7 +693,9 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = t.item()
             k1, n1 = rf.kernel_ms(reset=False)
+            st1 = pm.stage_ms(reset=True) if pm is not None else {}
             extra["one_stream_leg"] = {"value": nres * B * world / el, "steps": nres, "k_rf_grid_avg_launch_ms": k1 / max(1, n1),
+                                       "matcher_stage_ms_per_step": {k_: v_ / nres for k_, v_ in st1.items()},
                                        "what": "resident batch, reconstruction half behind the matching on the same timeline: what the second stream buys, "
                                                "and the gridding kernel's duration without the other stream's kernels beside it"}
         # (2) the matcher without its data-dependent shortcuts: every correlation row contracted over all frequencies and
@@ -509,6 +722,31 @@ def main():
                                            "what a gallery and particles with flat correlation peaks would cost"}
             pm.set_option("prune", 1)
             pm.set_option("k0", 0 if args.k0 < 0 else args.k0)
+        # (3) the other end of the data dependence: a gallery of unrelated band-limited noise images (sharp correlation peaks, no band
+        # limit for the two-level cut to use) -- the same step on a resident batch made from that gallery
+        if pm is not None and args.refs == "phantom" and args.neighbours == 0:
+            refs_n = smooth_noise(torch, nrefs, D, genr, dev)
+            pm_n = xa.ProjectionMatcher(ctx, refs_n)
+            parts_n, _ = make_batch(refs_n)
+            step(False, parts_n, pm=pm_n)
+            finish()
+            barrier()
+            tn0 = time.perf_counter()
+            nn = 2
+            for _ in range(nn):
+                step(False, parts_n, pm=pm_n)
+            finish()
+            barrier()
+            el = time.perf_counter() - tn0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            extra["noise_gallery"] = {"value": nn * B * world / el, "unit": "particles/s", "steps": nn,
+                                      "what": "the same step (resident batch) with 1000 unrelated band-limited noise images as references and "
+                                              "particles made from them: the value of `--refs noise`; with worst_case the honest range of the headline"}
+            pm_n.close()
+            del pm_n, refs_n, parts_n
 
     if rank != 0:
         if world > 1:
@@ -573,7 +811,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (coarse search, gridding) + f64 (exact re-score, shifts, finaliser)",
         "data": "synthetic",
-        "config": {"workload": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references",
+        "config": {"workload": {"full": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references (BASELINE config 4 per GPU)",
+                                "match": f"projection matching only (rotational + translational), {D}x{D} particles vs {nrefs} references (BASELINE config 2 shape)",
+                                "grid": f"Fourier gridding only (shift + CTF + FFT + insertion + finish), {D}x{D} projections into a {D}^3 volume (BASELINE config 3 shape)"}[args.mode],
                    "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "neighbours": args.neighbours or None,
                    "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
@@ -582,7 +822,15 @@ def main():
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
         "stage_ms": stage, "finish_and_allreduce_s": finish_s,
+        # the step rate without the once-per-run tail (mirror/crop + all-reduce + finaliser): config 4 is 1 M particles = 30.5 steps of
+        # 4096 per GPU on 8 GPUs, so a run of fewer steps over-weights the tail in `value` -- run --steps 31 for that comparison
+        "value_steps_only": total_particles / max(1e-9, elapsed - finish_s),
+        "steps_for_config4_per_gpu": int(math.ceil(1e6 / 8 / B)),
     }
+    if pipelined:
+        out["stage_ms_note"] = ("HIP-event times of the matcher's stages (prep32 ... translate_s6) and of gridding_insert_images are taken on two streams that "
+                                "share the device: they include WAITING for the other stream's kernels (k_rf_grid holds every CU), not work alone; "
+                                "one_stream_leg.matcher_stage_ms_per_step and one_stream_leg.k_rf_grid_avg_launch_ms are the same stages without a neighbour")
     out.update(extra)
     if pm is not None:
         out["rescored_fraction"] = stats_timed["rescored_particles"] / float(B)

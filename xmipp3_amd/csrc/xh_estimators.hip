@@ -495,7 +495,7 @@ int xh_shiftcorr_create(xh_ctx *ctx, int32_t xdim, int32_t ydim, int32_t max_shi
     h->ctx = ctx; h->x = xdim; h->y = ydim; h->maxShift = max_shift; h->refLoaded = false;
     // The reference's ShiftCorrEstimator<float> transforms with fftwf; its test images (one-pixel lines) give correlation maps full of
     // exact ties, which single-precision rounding breaks at random.  The device transforms in double and compares the map as floats,
-    // so that the first maximum in raster order is the one exact arithmetic has (and the oracle's).
+    // so that the first maximum in raster order is the one exact arithmetic has.
     int rc = xh_plan_create<double>(ctx, xdim, h->planX);
     if (rc == XH_OK) rc = xh_plan_create<double>(ctx, ydim, h->planY);
     if (rc == XH_OK && ((sizeof(xh_cd) << h->planX.plan.logM) > 64 * 1024 || (sizeof(xh_cd) << h->planY.plan.logM) > 64 * 1024)) {

@@ -923,6 +923,7 @@ struct xh_fa {
     int use_mfma = 1;                     // the pruned-DFT products of the local alignment on the matrix cores (0: the vector-ALU kernel)
     int use_window = 1;                   // pair correlations inside the search window only (0: every pair through the full transform)
     XhBuf work, spectra, lpf, pair, part, res, warpC;
+    std::vector<float> warpCHost;         // the spline coefficients the device holds (uploaded once per set, not once per frame)
     int capFrames;
 };
 
@@ -1406,9 +1407,15 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
     const int Y = h->Y, X = h->X, Cc = lX * lY * lT;
     std::vector<float> c(2 * (size_t)Cc);                                   // the reference's coefficients are Matrix1D<float>
     for (int k = 0; k < Cc; ++k) { c[k] = (float)h_coeffsX[k]; c[Cc + k] = (float)h_coeffsY[k]; }
-    XH_TRY(xh_buf_reserve(ctx, h->warpC, sizeof(float) * c.size()));
-    XH_HIP(hipMemcpyAsync(h->warpC.p, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(hipStreamSynchronize(ctx->stream));
+    if (c != h->warpCHost) {
+        // a new set of coefficients: wait for the frames still being warped with the old one, then upload (the forty frames of a
+        // movie share one set: one upload and one synchronisation per movie)
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+        XH_TRY(xh_buf_reserve(ctx, h->warpC, sizeof(float) * c.size()));
+        h->warpCHost = c;
+        XH_HIP(hipMemcpyAsync(h->warpC.p, h->warpCHost.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(hipStreamSynchronize(ctx->stream));
+    }
     float *coef = (float *)h->work.p;
     const XhFir F = xh_fir_taps();
     const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
