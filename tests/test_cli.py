@@ -574,6 +574,36 @@ def test_cli_movie_global_alignment(bins, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_movie_sum_range_inside_the_alignment_range(bins, tmp_path, oracle):
+    """--frameRangeSum inside --frameRange (movie_alignment_correlation_gpu.cpp:519-541): frame fi of the aligned movie lands in slot
+    fi - nfirst + 1 of --oaligned, the stack is nlastSum - nfirst + 1 images long and the slots before the first summed frame stay
+    empty; the metadata blocks are appended (MD_APPEND, movie_alignment_correlation_base.cpp:396,433): a block that is already in
+    the -o file from an earlier run is replaced, other blocks stay."""
+    from tests.test_gpu_flexalign import synthetic_movie
+    N, Y, X = 7, 200, 260
+    frames, drift = synthetic_movie(N, Y, X, seed=13)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    out = tmp_path / "out.xmd"
+    out.write_text("# XMIPP_STAR_1 * \n# \ndata_other\nloop_\n _ref\n 7 \ndata_referenceFrame\nloop_\n _ref\n 99 \n")
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(out), "--maxShift", "25", "--maxResForCorrelation", "8", "--frameRange", "1", "5",
+              "--frameRangeSum", "3", "4", "--skipLocalAlignment", "--patches", "4", "4", "--minLocalRes", "60", "--controlPoints", "3", "3", "3",
+              "--oaligned", str(tmp_path / "aligned.stk"), "--oavg", str(tmp_path / "avg.spi")])
+    assert r.returncode == 0, r.stderr
+    aligned = xmipp_io.read_stack(str(tmp_path / "aligned.stk"))
+    assert aligned.shape == (4, Y, X)                          # slots for frames 1..4, frames 3 and 4 written
+    assert not aligned[0].any() and not aligned[1].any() and aligned[2].any() and aligned[3].any()
+    avg = xmipp_io.read_volume(str(tmp_path / "avg.spi"))[0]
+    assert np.abs(avg - (aligned[2] + aligned[3]) / 2).max() < 1e-4 * np.abs(avg).max()
+    exp = oracle.fa_global_alignment(frames[1:6], max_shift_px=25.0, max_res=8.0)
+    _, ref_rows = xmipp_io.read_xmd(str(out), block="referenceFrame")
+    assert len(ref_rows) == 1 and int(float(ref_rows[0][0])) == 1 + exp["ref"]
+    _, other = xmipp_io.read_xmd(str(out), block="other")
+    assert int(float(other[0][0])) == 7
+    assert out.read_text().count("data_referenceFrame") == 1
+
+
+@pytest.mark.gpu
 def test_cli_movie_local_alignment(bins, tmp_path, oracle):
     """xmipp_movie_alignment_correlation with the local alignment (run(), movie_alignment_correlation_base.cpp:531-586, steps of the
     CUDA program): localAlignment@out.xmd carries patches, control points and the spline coefficients; the aligned frames

@@ -160,7 +160,10 @@ public:
         xh_ctfop *op = nullptr;
         xhCheck(xh_ctfop_create(g.c, (int)I0.y, (int)I0.x, pad, &op));
         struct OpGuard { xh_ctfop *o; ~OpGuard() { xh_ctfop_destroy(o); } } og{op};
-        std::vector<float> all(n * per), one;
+        // one device batch on the host at a time: every corrected batch goes into its slots of the output stack as soon as it is back
+        // (the reference reads, filters and writes image by image; a set of 1e6 particles does not fit a host buffer)
+        std::vector<float> hb((size_t)batch * per), one;
+        StackWriter stack(fn_out, I0.x, I0.y, n);
         DeviceBuffer d;
         d.reserve(g.c, (size_t)batch * per * sizeof(float));
         for (size_t b0 = 0; b0 < n; b0 += (size_t)batch) {
@@ -172,14 +175,15 @@ public:
                 ImageInfo I;
                 readImage(fn, one, I);
                 if (I.x != I0.x || I.y != I0.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "images of different sizes in " + fn_in);
-                std::copy(one.begin(), one.end(), all.begin() + (b0 + k) * per);
+                std::copy(one.begin(), one.end(), hb.begin() + k * per);
                 readCtfRow(md, b0 + k, ctfs[k]);        // ctf.readFromMdRow(rowIn), wiener2d.cpp:148
             }
-            xhCheck(xh_memcpy_h2d(g.c, d.p, all.data() + b0 * per, m * per * sizeof(float)));
+            xhCheck(xh_memcpy_h2d(g.c, d.p, hb.data(), m * per * sizeof(float)));
             xhCheck(xh_ctfop_wiener2d(op, d.as<float>(), (int)m, ctfs.data(), sampling_rate, phase_flipped, isIsotropic, wiener_constant, correct_envelope));
-            xhCheck(xh_memcpy_d2h(g.c, all.data() + b0 * per, d.p, m * per * sizeof(float)));
+            xhCheck(xh_memcpy_d2h(g.c, hb.data(), d.p, m * per * sizeof(float)));
+            for (size_t k = 0; k < m; ++k) stack.write(b0 + k, hb.data() + k * per);
         }
-        writeStack(fn_out, all.data(), I0.x, I0.y, n);
+        stack.finish();
         // postProcess (ctf_correct_wiener2d.cpp:58-93): the image column points at the corrected stack, the CTF columns go
         MetaDataVec out;
         const char *drop[] = {"ctfDefocusA", "ctfDefocusU", "ctfDefocusAngle", "ctfDefocusV", "ctfBgBaseline", "ctfBgGaussian2Angle",

@@ -154,6 +154,18 @@ public:
         FileName fn(fnFull);
         const std::string block = (fn.prefix.empty() || fn.hasNumber()) ? "noname" : fn.prefix;
         const bool exists = fileExists(fn.path);
+        if (append && exists) {
+            // MD_APPEND: a block of this name already in the file is replaced, the other blocks stay
+            std::ifstream in(fn.path);
+            std::string line, kept;
+            bool skipping = false, dropped = false;
+            while (std::getline(in, line)) {
+                if (line.compare(0, 5, "data_") == 0) { skipping = (line.substr(5) == block); dropped = dropped || skipping; }
+                if (!skipping) kept += line + "\n";
+            }
+            in.close();
+            if (dropped) { std::ofstream o(fn.path, std::ios::trunc); o << kept; }
+        }
         std::ofstream f(fn.path, append ? std::ios::app : std::ios::trunc);
         if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "MetaData::write: cannot write " + fn.path);
         if (!(append && exists)) f << "# XMIPP_STAR_1 * \n# \n";
@@ -287,6 +299,62 @@ inline void writeStack(const std::string &path, const float *data, size_t x, siz
         f.write((char *)(data + i * x * y), x * y * 4);
     }
 }
+
+// A stack written image by image (Image::write(..., index, true, WRITE_REPLACE) of the reference, e.g. ctf_correct_wiener2d.cpp's
+// XmippMetadataProgram loop and movie_alignment_correlation_gpu.cpp:537-541): the file is created with room for n images, every
+// write() puts one image into its slot, slots never written stay zero images.  Spider stack, or an MRC stack by extension.
+class StackWriter {
+    std::fstream f;
+    size_t x = 0, y = 0, n = 0, hdr = 0, perHdr = 0;
+    bool mrc = false;
+    std::vector<bool> written;
+    std::vector<float> h;
+
+public:
+    StackWriter(const std::string &path, size_t x_, size_t y_, size_t n_) : x(x_), y(y_), n(n_), written(n_, false)
+    {
+        FileName fn(path);
+        mrc = isMrcExt(fn.extension());
+        { std::ofstream c(fn.path, std::ios::binary | std::ios::trunc); if (!c.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: cannot write " + fn.path); }
+        f.open(fn.path, std::ios::binary | std::ios::in | std::ios::out);
+        if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: cannot write " + fn.path);
+        if (mrc) {
+            int32_t m[256];
+            memset(m, 0, sizeof(m));
+            m[0] = (int32_t)x; m[1] = (int32_t)y; m[2] = (int32_t)n; m[3] = 2; m[7] = (int32_t)x; m[8] = (int32_t)y; m[9] = (int32_t)n;
+            float *hf = (float *)m;
+            hf[10] = (float)x; hf[11] = (float)y; hf[12] = (float)n; hf[13] = hf[14] = hf[15] = 90.f;
+            m[16] = 1; m[17] = 2; m[18] = 3;
+            memcpy(&m[52], "MAP ", 4);
+            unsigned char stamp[4] = {0x44, 0x44, 0, 0};
+            memcpy(&m[53], stamp, 4);
+            f.write((char *)m, 1024);
+            hdr = 1024; perHdr = 0;
+        } else {
+            spiderHeader(h, x, y, 1, 1, 2, n, 0);
+            f.write((char *)h.data(), h.size() * 4);
+            hdr = perHdr = h.size() * 4;
+        }
+    }
+    // image i (0-based) of the stack
+    void write(size_t i, const float *data)
+    {
+        if (i >= n) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: image " + std::to_string(i + 1) + " beyond the stack");
+        f.seekp((std::streamoff)(hdr + i * (perHdr + x * y * 4)));
+        if (!mrc) { spiderHeader(h, x, y, 1, 1, 0, 0, i + 1); f.write((char *)h.data(), h.size() * 4); }
+        f.write((const char *)data, x * y * 4);
+        if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::write: short write");
+        written[i] = true;
+    }
+    // zero images into the slots nobody wrote
+    void finish()
+    {
+        std::vector<float> zero;
+        for (size_t i = 0; i < n; ++i)
+            if (!written[i]) { if (zero.empty()) zero.assign(x * y, 0.f); write(i, zero.data()); }
+        f.flush();
+    }
+};
 
 // ------------------------------------------------------------------ symmetries (cyclic groups)
 class SymList {

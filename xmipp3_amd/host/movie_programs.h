@@ -7,6 +7,9 @@
 #ifndef XMIPP3_AMD_MOVIE_PROGRAMS_H
 #define XMIPP3_AMD_MOVIE_PROGRAMS_H
 #include "ctf_programs.h"
+#include <deque>
+#include <future>
+#include <memory>
 
 namespace mc {
 
@@ -149,7 +152,7 @@ public:
         std::vector<double> sx(N), sy(N), initial, average;
         const int nC = cpX * cpY * cpT;
         std::vector<double> coeffsX(nC), coeffsY(nC), centers, patchShifts;
-        std::vector<float> aligned;
+        std::unique_ptr<StackWriter> alignedStack;
         int ref = 0, Nsum = 0;
         {
             xh_fa *fa = nullptr;
@@ -157,13 +160,25 @@ public:
             struct FaGuard { xh_fa *f; ~FaGuard() { xh_fa_destroy(f); } } fg{fa};
             DeviceBuffer d_frames, d_dark, d_gain, d_out, d_sum, d_initial;
             d_frames.reserve(g.c, (size_t)N * per * sizeof(float));
-            for (int n = 0; n < N; ++n) {
+            // the frames are read a few ahead by their own threads while the one before them goes to the device (the reference loads
+            // with a thread pool beside its two GPU streams, movie_alignment_correlation_gpu.cpp:667-691)
+            auto readFrame = [&](int n) {
                 std::string fn;
                 movie.getValue("image", fn, (size_t)(nfirst + n));
+                std::vector<float> f;
                 ImageInfo In;
-                readImage(fn, frame, In);
+                readImage(fn, f, In);
                 if (In.x != I.x || In.y != I.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnMovie);
-                xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), frame.data(), per * sizeof(float)));
+                return f;
+            };
+            const int ahead = 4;
+            std::deque<std::future<std::vector<float>>> inFlight;
+            for (int n = 0; n < std::min(ahead, N); ++n) inFlight.push_back(std::async(std::launch::async, readFrame, n));
+            for (int n = 0; n < N; ++n) {
+                std::vector<float> cur = inFlight.front().get();          // re-throws what the reader threw
+                inFlight.pop_front();
+                if (n + ahead < N) inFlight.push_back(std::async(std::launch::async, readFrame, n + ahead));
+                xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), cur.data(), per * sizeof(float)));
             }
             if (!dark.empty()) { d_dark.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), per * sizeof(float))); }
             if (!gain.empty()) { d_gain.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), per * sizeof(float))); }
@@ -189,7 +204,12 @@ public:
             }
             // applyShiftsComputeAverage (:479-570): every summed frame warped by the B-spline, the sums kept on the device
             if (wantAligned || wantAvg || wantInitial) {
-                if (wantAligned) d_out.reserve(g.c, per * sizeof(float));
+                if (wantAligned) {
+                    d_out.reserve(g.c, per * sizeof(float));
+                    // frame fi goes to slot fi - nfirst of the stack (tmp.write(fnAligned, frameOffset + 1, true, WRITE_REPLACE),
+                    // movie_alignment_correlation_gpu.cpp:528,540): with --frameRangeSum inside --frameRange the leading slots stay empty
+                    alignedStack.reset(new StackWriter(fnAligned, I.x, I.y, (size_t)(nlastSum - nfirst + 1)));
+                }
                 std::vector<float> host(per, 0.f);
                 if (wantAvg) { d_sum.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_sum.p, host.data(), per * sizeof(float))); }
                 if (wantInitial) { d_initial.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_initial.p, host.data(), per * sizeof(float))); }
@@ -199,10 +219,11 @@ public:
                                                 wantAligned ? d_out.as<float>() : nullptr, wantAvg ? d_sum.as<float>() : nullptr, wantInitial ? d_initial.as<float>() : nullptr));
                     if (wantAligned) {
                         xhCheck(xh_memcpy_d2h(g.c, host.data(), d_out.p, per * sizeof(float)));
-                        aligned.insert(aligned.end(), host.begin(), host.end());
+                        alignedStack->write((size_t)off, host.data());
                     }
                     ++Nsum;
                 }
+                if (wantAligned) alignedStack->finish();
                 if (wantAvg) { xhCheck(xh_memcpy_d2h(g.c, host.data(), d_sum.p, per * sizeof(float))); average.assign(host.begin(), host.end()); }
                 if (wantInitial) { xhCheck(xh_memcpy_d2h(g.c, host.data(), d_initial.p, per * sizeof(float))); initial.assign(host.begin(), host.end()); }
             }
@@ -229,7 +250,7 @@ public:
         const std::string out = fnOut.empty() ? fnMovie : fnOut;
         MetaDataVec mdIref;
         mdIref.setValue("ref", (long)(nfirst + ref), mdIref.addObject());
-        mdIref.write("referenceFrame@" + out, false);
+        mdIref.write("referenceFrame@" + out, true);           // MD_APPEND (movie_alignment_correlation_base.cpp:346): other blocks of an existing file stay
         if (!skipLocalAlignment) {
             // storeResults(localAlignment) (:460-514): how far the spline moves the patch centres from the global shift (2.5 % and
             // 97.5 % of the sorted distances), patches, coefficients, control points
@@ -264,11 +285,6 @@ public:
         if (!fnAvg.empty()) {
             for (double &v : average) v /= Nsum;
             writeVolume(fnAvg, average.data(), I.x, I.y, 1);
-        }
-        if (!fnAligned.empty()) {
-            FileName fa(fnAligned);
-            if (isMrcExt(fa.extension())) { std::vector<double> d(aligned.begin(), aligned.end()); writeVolume(fnAligned, d.data(), I.x, I.y, (size_t)Nsum); }
-            else writeStack(fa.path, aligned.data(), I.x, I.y, (size_t)Nsum);
         }
         movie.write("frameShifts@" + out, true);
     }
@@ -327,11 +343,12 @@ public:
         if (last >= (int)movie.size() || last < first) REPORT_ERROR(ERR_ARG_INCORRECT, "--frameRange outside the movie");
         CtxGuard g;
         xhCheck(xh_ctx_create_private(device, &g.c));
-        std::vector<float> frame, all;
+        std::vector<float> frame;
         ImageInfo I0;
         xh_fft2d *plan = nullptr;
         struct PlanGuard { xh_fft2d **p; ~PlanGuard() { if (*p) xh_fft2d_destroy(*p); } } pg{&plan};
         DeviceBuffer d_frame;
+        std::unique_ptr<StackWriter> stack;            // the frames keep their place in the stack (frame.write(fn, n + 1, ...)); one frame on the host at a time
         for (int n = 0; n <= last; ++n) {
             if (n < first) continue;
             std::string fn;
@@ -342,17 +359,16 @@ public:
                 I0 = I;
                 xhCheck(xh_fft2d_create(g.c, (int)I.y, (int)I.x, &plan));
                 d_frame.reserve(g.c, I.x * I.y * sizeof(float));
-                all.assign((size_t)(last + 1) * I.x * I.y, 0.f);          // the frames keep their place in the stack (frame.write(fn, n + 1, ...))
+                stack.reset(new StackWriter(fnOut, I.x, I.y, (size_t)(last + 1)));
             } else if (I.x != I0.x || I.y != I0.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnIn);
             const size_t per = I.x * I.y;
             xhCheck(xh_memcpy_h2d(g.c, d_frame.p, frame.data(), per * sizeof(float)));
             xhCheck(xh_movie_dose_filter(g.c, plan, d_frame.as<float>(), (int)I.y, (int)I.x, pixel_size, acceleration_voltage, (n * dose_per_frame) + pre_exposure_amount,
                                          ((n + 1) * dose_per_frame) + pre_exposure_amount));
-            xhCheck(xh_memcpy_d2h(g.c, all.data() + (size_t)n * per, d_frame.p, per * sizeof(float)));
+            xhCheck(xh_memcpy_d2h(g.c, frame.data(), d_frame.p, per * sizeof(float)));
+            stack->write((size_t)n, frame.data());
         }
-        FileName fo(fnOut);
-        if (isMrcExt(fo.extension())) { std::vector<double> d(all.begin(), all.end()); writeVolume(fnOut, d.data(), I0.x, I0.y, (size_t)(last + 1)); }
-        else writeStack(fo.path, all.data(), I0.x, I0.y, (size_t)(last + 1));
+        if (stack) stack->finish();
     }
 };
 
