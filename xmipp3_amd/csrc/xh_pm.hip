@@ -124,6 +124,7 @@ struct xh_pm {
     int use_idft3, use_mfma, contract_dbg, use_fir;
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
+    int s6_coarse_kernel;        // S6: the fp32 pass ends in k_pm_bestshift_coarse (0: k_pm_bestshift<float>, A/B)
     int s6_debug;                // profiling: xh_pm_translate returns decision margins instead of shifts
     int s6_capture;              // test hook: 32 / 64 = xh_pm_translate runs only that chain and leaves the correlation maps for xh_pm_debug_s6_maps
     int s6_captured;             // ... precision and count of the maps left behind
@@ -1845,7 +1846,7 @@ __global__ void k_pm_rot_mirror(const float *__restrict__ particles, const doubl
 }
 
 // partial statistics of a correlation map (k_pm_tr_irows -> k_pm_bestshift)
-struct XhTrPart { double s1, s2, maxv; int maxi; };
+struct XhTrPart { double s1, s2, maxv, secv; int maxi; };     // secv: the largest value beside the maximum (the fp32 pass only)
 
 // product FFT1 * conj(FFT2) * N from the packed spectrum Z (FFT of Mref + i Mimg), in place.
 // F1[k] = (Z[k] + conj(Z[-k]))/2, F2[k] = (Z[k] - conj(Z[-k]))/(2i); forward FFTs are /N in the
@@ -2150,6 +2151,180 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
     }
 }
 
+
+// The coarse (fp32) pass of xh_pm_translate has its own form of the kernel above: same decisions, same flags, a fraction of the
+// work.  (1) The window of bestShift: almost every element of a correlation map lies below max / 1.414, so the first failing
+// element is a few pixels from the maximum -- rings of growing Chebyshev radius around the maximum are scanned until one holds
+// a failing element (the kernel above reads the whole 64 K-element map for a window of ~100).  The runner-up the ambiguity
+// flag needs leaves k_pm_s6f_irows with the block maxima.  (2) correlationIndex of the reference and the translated particle:
+// the shift is one constant per particle, so the bilinear weights and the integer offsets are too (the wrap of translate() is a
+// shift by D: an index modulo D); products and the five sums stay in double.  D is a power of two here (64, 128, 256).
+// Every discrete decision -- arg-max, window, max_shift rejection -- that comes within eps |max| of flipping flags the
+// particle for the double-precision chain, exactly as before.
+__global__ void __launch_bounds__(256)
+k_pm_bestshift_coarse(const float *__restrict__ Rraw, const xh_cf *__restrict__ zimg, const int *__restrict__ refno,
+                      const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
+                      double *__restrict__ shiftY, double *__restrict__ maxCC, const XhTrPart *__restrict__ part, int nparts,
+                      unsigned char *__restrict__ flag, double eps)
+{
+    __shared__ double red[8];
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    __shared__ double sh[8];
+    const int p = blockIdx.x;
+    if (refno[p] < 0) {
+        if (threadIdx.x == 0) { shiftX[p] = 0; shiftY[p] = 0; maxCC[p] = 0; flag[p] = 0; }
+        return;
+    }
+    const int n = D * D, cen = D / 2, lgD = 31 - __clz(D), msk = D - 1;
+    const float *R = Rraw + (size_t)p * n;
+    if (threadIdx.x == 0) {
+        double a1 = 0, a2 = 0, mv = -1.0e300, sec = -1.0e300;
+        int mi = 0x7fffffff;
+        for (int q = 0; q < nparts; ++q) {
+            const XhTrPart P = part[(size_t)p * nparts + q];
+            a1 += P.s1; a2 += P.s2;
+            sec = fmax(sec, fmax(P.secv, fmin(P.maxv, mv)));
+            if (P.maxv > mv || (P.maxv == mv && P.maxi < mi)) { mv = P.maxv; mi = P.maxi; }
+        }
+        const double avg = a1 / n;
+        const double sd = sqrt(fabs(a2 / n - avg * avg));
+        const double a = sd != 0 ? 1.0 / sd : 0.0, b = sd != 0 ? -avg * a : 0.0;   // statisticsAdjust(0,1)
+        sh[0] = a; sh[1] = b; sh[2] = a * mv + b; sh[3] = a * sec + b; sh[4] = sd;
+        si[0] = mi;
+    }
+    __syncthreads();
+    const double a = sh[0], b = sh[1], mx = sh[2], secAdj = sh[3], sd = sh[4];
+    const int tmax = si[0];
+    const double thr = mx / 1.414;
+    const int start = -cen, fin = start + D - 1;
+    const int imax = (tmax >> lgD) + start, jmax = (tmax & msk) + start;
+    // centred map value at logical (li, lj): raw[(li mod D)][(lj mod D)] (CenterFFT(R, true))
+#define MCF(li, lj) (a * (double)R[((size_t)((li) & msk) << lgD) + ((lj) & msk)] + b)
+    const int nfBorder = min(min(imax - start, fin - imax), min(jmax - start, fin - jmax)) + 1;   // first window that leaves the map
+    __syncthreads();
+    // ---- the window: rings of Chebyshev radius (w0, w1] until one holds an element below the threshold
+    int n_max = nfBorder;
+    if (thr > mx) n_max = 0;                               // a negative maximum fails its own threshold
+    else
+    for (int w0 = 0, w1 = 4; w0 < nfBorder - 1; w0 = w1, w1 *= 2) {
+        const int wl = min(w1, nfBorder - 1);              // elements at distance nfBorder and beyond lie outside the map
+        const int wd = 2 * wl + 1;
+        int nf = 0x7fffffff;
+        for (int t = threadIdx.x; t < wd * wd; t += blockDim.x) {
+            const int i = t / wd - wl, j = t - (t / wd) * wd - wl;
+            const int d = max(abs(i), abs(j));
+            if (d <= w0) continue;
+            if (thr > MCF(imax + i, jmax + j)) nf = min(nf, d);
+        }
+        __syncthreads();
+        si[threadIdx.x] = nf;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) si[threadIdx.x] = min(si[threadIdx.x], si[threadIdx.x + o]); __syncthreads(); }
+        const int found = si[0];
+        __syncthreads();
+        if (found != 0x7fffffff) { n_max = found; break; }
+        if (wl >= nfBorder - 1) break;
+    }
+    if (imax - n_max < start) n_max = min(imax - start, n_max);
+    if (imax + n_max > fin) n_max = min(fin - imax, n_max);
+    if (jmax - n_max < start) n_max = min(jmax - start, n_max);
+    if (jmax + n_max > fin) n_max = min(fin - jmax, n_max);
+    // ---- centre of mass of the window (FIL:1700-1716), and how close an element of it comes to the threshold
+    double xmax = 0, ymax = 0, sumcorr = 0, mg = 1.0e300;
+    {
+        const int wd = 2 * n_max + 1;
+        for (int t = threadIdx.x; t < wd * wd; t += blockDim.x) {
+            const int i = t / wd - n_max, j = t % wd - n_max;
+            const int ia = i + imax, ja = j + jmax;
+            const double val = MCF(ia, ja);
+            ymax += ia * val;
+            xmax += ja * val;
+            sumcorr += val;
+            mg = fmin(mg, fabs(val - thr));
+        }
+    }
+#undef MCF
+    sv[threadIdx.x] = mg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sv[threadIdx.x] = fmin(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+    const double mgAll = sv[0];
+    __syncthreads();
+    const double YM = d_block_sum(ymax, red), XM = d_block_sum(xmax, red), SC = d_block_sum(sumcorr, red);
+    if (threadIdx.x == 0) {
+        const double lim = eps * fabs(mx);
+        unsigned char f = !(mgAll > lim && mx - secAdj > lim && sd != 0) ? 1 : 0;     // NaN-safe: anything unclear is repeated
+        double ox = 0, oy = 0;
+        if (SC != 0) { ox = XM / SC; oy = YM / SC; }
+        if (!(maxShift > 0)) ox = oy = 0.;
+        if (maxShift > 0 && fabs(sqrt(ox * ox + oy * oy) - (double)maxShift) < 1e-3) f = 1;   // the rejection of APM:841-842 is a decision too
+        if (ox * ox + oy * oy > maxShift * maxShift) ox = oy = 0.;
+        flag[p] = f;
+        sh[0] = ox; sh[1] = oy;
+    }
+    __syncthreads();
+    const double ox = sh[0], oy = sh[1];
+    // ---- translate(LINEAR, Mimg, (ox, oy), WRAP) + correlationIndex(Mref, Mtrans) (APM:850-851)
+    const xh_cf *Z = zimg + (size_t)p * n;    // .x = Mref, .y = Mimg
+    // out(x, y) samples Mimg at (x - ox, y - oy).  The taps of a column (row) depend on the column (row) only: every thread keeps
+    // its column's (256 is a multiple of D, so a thread stays in one column), the rows' go through LDS -- found with the reference's
+    // own expressions (translate -> applyGeometry LINEAR, WRAP: a coordinate up to half a pixel before the first sample is NOT
+    // wrapped but extrapolated with a negative weight, (int) truncates towards zero), so that the coarse pass and the
+    // double-precision chain interpolate the same samples.
+    const double minp = -cen, maxp = D - cen - 1;
+    auto tap1 = [&](int k, double o, int &k1, int &k2, float &w) {
+        double xp = (double)(k - cen) - o;
+        if (xp < minp - 1e-6 || xp > maxp + 1e-6) xp = d_realwrap<double>(xp, minp - 0.5, maxp + 0.5);
+        double wv = xp + cen;
+        k1 = (int)wv;
+        w = (float)(wv - k1);
+        k2 = k1 + 1;
+        if (k2 >= D) k2 = 0;
+    };
+    __shared__ int sN1[256], sN2[256];
+    __shared__ float sWy[256];
+    if ((int)threadIdx.x < D) { int n1, n2; float w; tap1(threadIdx.x, oy, n1, n2, w); sN1[threadIdx.x] = n1 << lgD; sN2[threadIdx.x] = n2 << lgD; sWy[threadIdx.x] = w; }
+    int m1, m2;
+    float wx;
+    tap1(threadIdx.x & msk, ox, m1, m2, wx);
+    __syncthreads();
+    const bool ident = ox == 0.0 && oy == 0.0;
+    double sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0;
+    for (int t0 = threadIdx.x; t0 < n; t0 += 4 * 256) {
+        float r[4], q00[4], q01[4], q10[4], q11[4], wy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256;
+            const xh_cf zc = Z[t];
+            r[u] = zc.x; q00[u] = zc.y; q01[u] = q10[u] = q11[u] = 0.f; wy[u] = 0.f;
+            if (!ident) {
+                const int i = t >> lgD;
+                const int r1 = sN1[i], r2 = sN2[i];
+                wy[u] = sWy[i];
+                q00[u] = Z[r1 + m1].y; q01[u] = Z[r1 + m2].y;
+                q10[u] = Z[r2 + m1].y; q11[u] = Z[r2 + m2].y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wy_1 = 1.f - wy[u], wx_1 = 1.f - wx;
+            const float vf = ident ? q00[u] : (wy_1 * (wx_1 * q00[u] + wx * q01[u]) + wy[u] * (wx_1 * q10[u] + wx * q11[u]));
+            const double val = (double)vf, rr = (double)r[u];
+            sx += rr; sxx += rr * rr; sy += val; syy += val * val; sxy += rr * val;
+        }
+    }
+    const double SX = d_block_sum(sx, red), SXX = d_block_sum(sxx, red), SY = d_block_sum(sy, red);
+    const double SYY = d_block_sum(syy, red), SXY = d_block_sum(sxy, red);
+    if (threadIdx.x == 0) {
+        const double mxr = SX / n, myr = SY / n;
+        const double sdx = sqrt(fabs(SXX / n - mxr * mxr)), sdy = sqrt(fabs(SYY / n - myr * myr));
+        double cc = 0;
+        if (!(fabs(sdx) < 1e-6 || fabs(sdy) < 1e-6)) cc = (SXY - n * mxr * myr) / ((sdx * sdy) * n);
+        maxCC[p] = cc;
+        shiftX[p] = flip[p] ? -ox : ox;     // APM:858-859
+        shiftY[p] = oy;
+    }
+}
 
 // ---- S6, register-blocked: D = R1*R2 line FFTs in two passes ------------------------------------
 // The radix-2 kernels below spend log2(D) LDS round trips per line and the step took seven kernels
@@ -2569,7 +2744,7 @@ k_pm_tr_irows(const xh_cd *__restrict__ w, double *__restrict__ Rout, const xh_c
             }
             __syncthreads();
         }
-        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
+        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], -1.0e300, redi[0]};
     }
 }
 
@@ -2749,10 +2924,10 @@ k_pm_s6f_irows(const xh_cf *__restrict__ w, float *__restrict__ Rout, const xh_c
     // (statisticsAdjust) and the first maximum in raster order of the centred map -- leaves with the map: one partial result
     // per block, combined in block order by k_pm_bestshift, which then reads the map once instead of three times.
     double *red = reinterpret_cast<double *>(smem);
-    int *redi = reinterpret_cast<int *>(red + 3 * 256);
+    int *redi = reinterpret_cast<int *>(red + 4 * 256);
     for (int h = 0; h < (PAIR ? 2 : 1); ++h) {
         if (h == 1 && p2 == p) break;
-        double s1 = 0, s2 = 0, bv = -1.0e300;
+        double s1 = 0, s2 = 0, bv = -1.0e300, sec = -1.0e300;      // sec: the largest value beside the maximum (k_pm_bestshift_coarse's flag)
         int bi = 0x7fffffff;
         if (tid < G::LN * R2) {
             const int l = tid / R2, n2 = tid - l * R2;
@@ -2762,11 +2937,12 @@ k_pm_s6f_irows(const xh_cf *__restrict__ w, float *__restrict__ Rout, const xh_c
                 const double x = h ? v[n1].y : v[n1].x;
                 const int t = ci + (n1 * R2 + n2 + D / 2) % D;
                 s1 += x; s2 += x * x;
-                if (x > bv || (x == bv && t < bi)) { bv = x; bi = t; }
+                if (x > bv || (x == bv && t < bi)) { sec = fmax(sec, bv); bv = x; bi = t; }
+                else sec = fmax(sec, x);
             }
         }
         __syncthreads();                                          // the exchange area (or the previous round) is free
-        red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; redi[tid] = bi;
+        red[tid] = s1; red[256 + tid] = s2; red[512 + tid] = bv; red[768 + tid] = sec; redi[tid] = bi;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if (tid < o) {
@@ -2774,11 +2950,13 @@ k_pm_s6f_irows(const xh_cf *__restrict__ w, float *__restrict__ Rout, const xh_c
                 red[256 + tid] += red[256 + tid + o];
                 const double ov = red[512 + tid + o];
                 const int oi = redi[tid + o];
+                // two (maximum, runner-up) pairs merge into (larger maximum, the best of the smaller maximum and both runners-up)
+                red[768 + tid] = fmax(fmax(red[768 + tid], red[768 + tid + o]), fmin(ov, red[512 + tid]));
                 if (ov > red[512 + tid] || (ov == red[512 + tid] && oi < redi[tid])) { red[512 + tid] = ov; redi[tid] = oi; }
             }
             __syncthreads();
         }
-        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], redi[0]};
+        if (tid == 0) part[(size_t)(h ? p2 : p) * gridDim.x + blockIdx.x] = XhTrPart{red[0], red[256], red[512], red[768], redi[0]};
     }
 }
 
@@ -3026,6 +3204,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma = 1;
     pm->use_mfma64 = 1;
     pm->s6_pair = 1;
+    pm->s6_coarse_kernel = 1;
     pm->s6_debug = 0;
     pm->s6_capture = 0;
     pm->s6_captured = 0;
@@ -3369,6 +3548,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_mfma")) pm->use_mfma = (int)value;
     else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
     else if (!strcmp(name, "s6_pair")) pm->s6_pair = (int)value;
+    else if (!strcmp(name, "s6_coarse_kernel")) pm->s6_coarse_kernel = (int)value;
     else if (!strcmp(name, "s6_debug")) pm->s6_debug = (int)value;
     else if (!strcmp(name, "s6_capture")) pm->s6_capture = (int)value;
     else if (!strcmp(name, "s6_fp32")) pm->s6_fp32 = (int)value;
@@ -3936,8 +4116,12 @@ int xh_pm_translate(xh_pm *pm, const float *d_particles, int32_t n, const int32_
             else XH_TRF(16, 16)
 #undef XH_TRF
             XH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_pm_bestshift<float>, dim3(m), dim3(256), 0, ctx->stream, (const float *)R, 1, (const xh_cf *)z, refno,
-                               flip, D, max_shift, sx, sy, cc, (const XhTrPart *)pm->d_trPart.p, nparts, 0, flag, pm->s6_eps);
+            if (pm->s6_coarse_kernel)
+                hipLaunchKernelGGL(k_pm_bestshift_coarse, dim3(m), dim3(256), 0, ctx->stream, (const float *)R, (const xh_cf *)z, refno, flip, D, max_shift, sx, sy, cc,
+                                   (const XhTrPart *)pm->d_trPart.p, nparts, flag, pm->s6_eps);
+            else
+                hipLaunchKernelGGL(k_pm_bestshift<float>, dim3(m), dim3(256), 0, ctx->stream, (const float *)R, 1, (const xh_cf *)z, refno,
+                                   flip, D, max_shift, sx, sy, cc, (const XhTrPart *)pm->d_trPart.p, nparts, 0, flag, pm->s6_eps);
             XH_LAUNCH_CHECK();
             return XH_OK;
         };
