@@ -68,6 +68,7 @@ def parse(argv=None):
                     help="local search (APM:615-631): every particle is matched against the K references nearest to its true "
                          "direction only (ascending lists, as a sampling file holds them); 0: the whole bank")
     ap.add_argument("--pm-opt", action="append", default=[], help="name=value passed to xh_pm_set_option (A/B runs)")
+    ap.add_argument("--main-priority", type=int, default=0, help="experiment: priority of the matcher's stream (-1 high, 0 default)")
     ap.add_argument("--side-priority", type=int, default=0, help="experiment: priority of the reconstruction stream (-1 high, 0 default)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: q of every 4 CU groups to the matcher's stream, the others to the "
                     "reconstruction stream (hipExtStreamCreateWithCUMask); 0: no masks")
@@ -422,6 +423,8 @@ def main():
         q_ = args.cu_split
         torch.cuda.set_stream(masked_stream(lambda i: (i // 8) % 4 < q_))
         masked_side = masked_stream(lambda i: (i // 8) % 4 >= q_)
+    if args.main_priority != 0 and args.cu_split == 0:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=args.main_priority))
     ctx = xa.Context(local)
     D, nrefs, B = args.box, args.nrefs, args.batch
     gen = torch.Generator(device=dev)

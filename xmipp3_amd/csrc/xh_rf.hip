@@ -258,6 +258,8 @@ struct xh_rf {
     bool cropped;
     int unit_z = 4;       // depth of a gridding unit (8 x 8 x unit_z voxels per wave): 4 or 8
     int grid_waves = 0;   // waves per CU of the gridding kernel; 0: the default of the unit depth
+    int grid_tile_budget = 0;   // tiles a workgroup of the gridding kernel processes before it retires; 0: persistent workgroups, one per CU
+    int ntiles[2] = {0, 0};
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
     int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)
 };
@@ -1305,6 +1307,7 @@ int xh_rf_create(xh_ctx *ctx, const xh_rf_params *p, xh_rf **out)
         };
         for (int c = 0; c < 8; ++c)
             std::sort(packed.begin() + classOff[c], packed.begin() + classOff[c + 1], [&](unsigned u, unsigned w) { return key(u) < key(w); });
+        rf->ntiles[v] = (int)packed.size();
         r = xh_buf_alloc(ctx, rf->d_gtiles[v], sizeof(unsigned) * std::max<size_t>(1, packed.size()));
         if (r == XH_OK) r = (hipMemcpy(rf->d_gtiles[v].p, packed.data(), sizeof(unsigned) * packed.size(), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
         if (r == XH_OK) r = (hipMemcpy((int *)rf->d_tileCounter.p + 32 + 16 * v, classOff, sizeof(classOff), hipMemcpyHostToDevice) == hipSuccess) ? XH_OK : XH_ERR_HIP;
@@ -1353,6 +1356,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
         rf->unit_z = (int)value;
     }
     else if (!strcmp(name, "grid_waves")) rf->grid_waves = (int)value;
+    else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(0, (int)value);
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
@@ -1742,15 +1746,19 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
         // accumulator block per wave, which the LDS holds for nine waves instead of twelve
         const int uz = rf->unit_z, tl = uz == 8 ? 1 : 0;
         const int nw = rf->grid_waves ? rf->grid_waves : (uz == 8 ? (br < 2.0 || fast ? 9 : 8) : 12);      // (6 x 6 footprints: larger patches)
+        // persistent workgroups (one per CU, multiples of eight: XCD classes), or, with a tile budget, as many as the tiles need plus
+        // one round of CUs (a workgroup that finds its streams empty retires at once)
+        const unsigned cuBlocks = 8u * (unsigned)std::max(1, ctx->num_cus / 8);
+        const unsigned gridBlocks = rf->grid_tile_budget > 0 ? cuBlocks + 8u * (unsigned)((rf->ntiles[tl] / rf->grid_tile_budget + 7) / 8) : cuBlocks;
 #ifndef XG_ABL
 #define XG_ABL 0
 #endif
 #define XH_GRID(W_, F_, Z_, N_)                                                                                                  \
-    hipLaunchKernelGGL((k_rf_grid<W_, F_, Z_, N_, XG_ABL>), dim3(8 * std::max(1, ctx->num_cus / 8)), dim3(64 * N_), 0, ctx->stream, \
+    hipLaunchKernelGGL((k_rf_grid<W_, F_, Z_, N_, XG_ABL>), dim3(gridBlocks), dim3(64 * N_), 0, ctx->stream, \
                        (const XgRec *)rf->d_grecs.p + s0, (const float4 *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, \
                        rf->mv, rf->iDeltaSqrt, br, (const unsigned *)rf->d_gtiles[tl].p, (const int *)rf->d_tileCounter.p + 32 + 16 * tl, \
                        (int *)rf->d_tileCounter.p + 128, (const int *)rf->d_superList.p, (const int *)rf->d_superCount.p,         \
-                       superDim, m, (const float4 *)superN, (const float4 *)superX, reach)
+                       superDim, m, (const float4 *)superN, (const float4 *)superX, reach, rf->grid_tile_budget)
 #define XH_GRID_WF(W_, F_)                                                                                                       \
     do {                                                                                                                         \
         if (uz == 8 && nw == 9 && W_ == 4) XH_GRID(4, F_, 8, 9);                                                                 \

@@ -269,7 +269,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
           float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
           const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter,
           const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
-          const float4 *__restrict__ superN, const float4 *__restrict__ superX, float4 reach)
+          const float4 *__restrict__ superN, const float4 *__restrict__ superX, float4 reach, int tileBudget)
 {
     using C = XgCfg<W, ZD, NW>;
     constexpr int PW = C::PW, PN = C::PN, NDMA = C::NDMA, NVOX = C::NVOX, KCAP = C::KCAP;
@@ -316,6 +316,9 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     auto produce = [&](int q) {
         while (q > 0 && atomicAdd(&sReady[(q - 1) % RS], 0) != q) __builtin_amdgcn_s_sleep(1);
         int tile = -1;
+        // tileBudget > 0: a workgroup retires after that many tiles and the launch has more workgroups than CUs (bounded residency: the
+        // kernels of another stream get CUs every few milliseconds instead of after the whole launch)
+        if (!(tileBudget > 0 && q >= tileBudget))
         for (;;) {
             const int hop = atomicAdd(sHop, 0);
             if (hop >= 8 * NSUB) break;
