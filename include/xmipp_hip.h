@@ -441,6 +441,14 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
  * initVoltage does); dose_start / dose_finish = n / (n + 1) x dosePerFrame + preExposure of frame n. */
 int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y, int32_t X, double pixel_size, double acc_voltage,
                          double dose_start, double dose_finish);
+/* --bin of the CUDA FlexAlign program: a frame binned while it is loaded (CUDAFlexAlignScale::runScaleIFT,
+ * reconstruction_cuda/cuda_flexalign_scale.cpp:101-121; scaleFFT2DKernel, cuda_scaleFFT_kernels.cu:44-79; sizes from
+ * AProgMovieAlignmentCorrelation::getMovieSize, reconstruction/movie_alignment_correlation_base.cpp:356-370): half spectrum of the
+ * raw frame (minus d_dark, times d_gain: loadFrame corrects before it bins; either may be null) cropped to the binned size, times
+ * 1 / (X Y), inverse transform.  d_frame [Y][X] -> d_out [Yb][Xb]; planRaw =
+ * xh_fft2d_create(ctx, Y, X), planBinned = xh_fft2d_create(ctx, Yb, Xb). */
+int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, const float *d_frame, const float *d_dark, const float *d_gain, int32_t Y,
+                       int32_t X, float *d_out, int32_t Yb, int32_t Xb);
 
 /* ---- batched estimator API, first slice ------------------------------------------------------
  * ExtremaFinder::SingleExtremaFinder<T> (reconstruction/single_extrema_finder.cpp:146-300): n signals [n][z][y][x] on the device;

@@ -139,6 +139,7 @@ def lib():
                            c_double_p, c_double_p, c_double_p]),
         "xo_fa_local_patch_shifts_f32": (i, [c_float_p, i, i, i, c_double_p, c_double_p, i, C.c_float, C.c_float, C.c_float, i, i, i, i, i, c_uint8_p,
                                              c_double_p, c_double_p, c_int32_p]),
+        "xo_fa_bin_frame": (None, [c_double_p, i, i, i, i, c_double_p]),
         "xo_es_rotation_corr_len": (i, [i, i]),
         "xo_es_polar_rotation": (None, [c_double_p, c_double_p, i, i, i, i, c_double_p, c_double_p]),
         "xo_es_shifts": (None, [c_float_p, c_float_p, i, i, i, i, c_float_p]),
@@ -439,6 +440,14 @@ def fa_local_patch_shifts(frames, g_shift_x, g_shift_y, ref, mask, Ts=1.0, max_s
     if rc != 0:
         raise ValueError("movie too small for the patches")
     return shifts, centers, tuple(int(v) for v in dims)
+
+
+def fa_bin_frame(frame, Yb, Xb):
+    """--bin of the CUDA FlexAlign program (xo_fa_bin_frame)"""
+    fr = f64(frame)
+    out = np.empty((Yb, Xb))
+    lib().xo_fa_bin_frame(_dp(fr), fr.shape[0], fr.shape[1], int(Yb), int(Xb), _dp(out))
+    return out
 
 
 def fa_bspline_shift(coeffsX, coeffsY, control_points, X, Y, N, x, y, n):

@@ -147,6 +147,8 @@ int xo_fa_local_alignment(const double *frames, int N, int Y, int X, const doubl
                           float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,
                           int patchesAvg, int lX, int lY, int lT, double *patchShifts, double *centers, double *coeffsX,
                           double *coeffsY, int *dims);
+/* --bin of the CUDA FlexAlign program: Fourier cropping of a frame (cuda_flexalign_scale.cpp:101-121, cuda_scaleFFT_kernels.cu:44-79) */
+void xo_fa_bin_frame(const double *frame, int Y, int X, int Yb, int Xb, double *out);
 /* the same on float frames for the patches patchMask [py][px] marks (full-size tests): centres of all, shifts of the marked ones, no fit */
 int xo_fa_local_patch_shifts_f32(const float *frames, int N, int Y, int X, const double *gShiftX, const double *gShiftY, int refFrame,
                                  float Ts, float maxShift, float maxRes, int patchesX, int patchesY, int patchSizeX, int patchSizeY,

@@ -565,3 +565,23 @@ void xo_dose_filter_frame(double *frame, int Y, int X, double pixel_size, double
 }
 
 }  // extern "C"
+
+extern "C" {
+// --bin of the CUDA program (CUDAFlexAlignScale::runScaleIFT, reconstruction_cuda/cuda_flexalign_scale.cpp:101-121; scaleFFT2DKernel,
+// cuda_scaleFFT_kernels.cu:44-79): forward transform of the raw frame, its half spectrum cropped to the binned size (columns
+// 0 .. Xb/2; rows 0 .. Yb/2 from the top, the others from the bottom) times 1 / (X Y), inverse real transform.
+void xo_fa_bin_frame(const double *frame, int Y, int X, int Yb, int Xb, double *out)
+{
+    const int xh = X / 2 + 1, xbh = Xb / 2 + 1, yhalf = Yb / 2;
+    std::vector<double> F((size_t)Y * xh * 2), H((size_t)Yb * xbh * 2);
+    xo_fft2d_r2c(frame, Y, X, F.data());                    // FourierTransformer convention: already divided by X Y
+    for (int idy = 0; idy < Yb; ++idy) {
+        const int origY = (idy <= yhalf) ? idy : (Y - (Yb - idy));
+        for (int idx = 0; idx < xbh; ++idx) {
+            H[((size_t)idy * xbh + idx) * 2] = F[((size_t)origY * xh + idx) * 2];
+            H[((size_t)idy * xbh + idx) * 2 + 1] = F[((size_t)origY * xh + idx) * 2 + 1];
+        }
+    }
+    xo_fft2d_c2r(H.data(), Yb, Xb, out);
+}
+}

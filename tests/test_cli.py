@@ -604,6 +604,34 @@ def test_cli_movie_sum_range_inside_the_alignment_range(bins, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_movie_binning(bins, tmp_path, oracle):
+    """--bin 2 (movie_alignment_correlation_base.cpp:39-42,356-370,376; movie_alignment_correlation_gpu.cpp:667-691): frames are corrected
+    and binned as they are loaded, the alignment runs on the binned movie at the binned sampling rate, the shifts go out multiplied
+    by the binning factor and the micrograph has the binned size."""
+    from tests.test_gpu_flexalign import synthetic_movie
+    N, Y, X = 6, 400, 520
+    frames, drift = synthetic_movie(N, Y, X, seed=17, max_step=2.5)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "out.xmd"), "--bin", "2", "--sampling", "1", "--maxShift", "40", "--maxResForCorrelation", "16",
+              "--skipLocalAlignment", "--oavgInitial", str(tmp_path / "initial.spi")])
+    assert r.returncode == 0, r.stderr
+    binned = np.stack([oracle.fa_bin_frame(f, Y // 2, X // 2) for f in frames])
+    exp = oracle.fa_global_alignment(binned.astype(np.float32), Ts=2.0, max_shift_px=40.0 / 2.0, max_res=16.0)
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"), block="frameShifts")
+    c = {l: i for i, l in enumerate(labels)}
+    for n, row in enumerate(rows):
+        assert abs(float(row[c["shiftX"]]) + 2 * exp["shiftX"][n]) < 1e-2 and abs(float(row[c["shiftY"]]) + 2 * exp["shiftY"][n]) < 1e-2
+    ini = xmipp_io.read_volume(str(tmp_path / "initial.spi"))[0]
+    assert ini.shape == (Y // 2, X // 2)
+    assert np.abs(ini - binned.mean(0)).max() < 1e-4 * np.abs(binned).max()
+    # and the drift that was put in comes out in pixels of the RAW movie
+    t = drift - drift[exp["ref"]]
+    got = np.array([[float(r_[c["shiftX"]]), float(r_[c["shiftY"]])] for r_ in rows])
+    assert np.abs(got - t).max() < 1.5
+
+
+@pytest.mark.gpu
 def test_cli_movie_local_alignment(bins, tmp_path, oracle):
     """xmipp_movie_alignment_correlation with the local alignment (run(), movie_alignment_correlation_base.cpp:531-586, steps of the
     CUDA program): localAlignment@out.xmd carries patches, control points and the spline coefficients; the aligned frames

@@ -168,6 +168,29 @@ def test_local_alignment_of_a_k3_movie(gpu, oracle):
     assert rms <= 0.9 and worst <= 3.2 and rms < 0.6 * grms and corr > 0.8 and 0.4 < slope < 1.1
 
 
+@pytest.mark.parametrize("Y,X,binning", [(300, 420, 1.5), (256, 256, 2.0), (243, 331, 1.3)])
+def test_binning_of_a_frame_against_the_oracle(gpu, oracle, Y, X, binning):
+    """--bin of the CUDA program (CUDAFlexAlignScale::runScaleIFT + scaleFFT2DKernel): a frame, dark- and gain-corrected, binned by
+    cropping its half spectrum; sizes as getMovieSize computes them (float arithmetic, truncated: 243 x 331 at 1.3 gives an odd
+    186 x 254 ... whatever comes out, the same on both sides); fp32 transforms against the oracle's double ones: 1e-5 of the range."""
+    xa, ctx, torch = gpu
+    from xmipp3_amd.api import movie_binned_size, movie_bin_frame
+    rng = np.random.default_rng(Y)
+    fr = rng.standard_normal((Y, X)).astype(np.float32)
+    dark = (0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    gain = (1.0 + 0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    Yb, Xb = movie_binned_size(Y, X, binning)
+    assert (Yb, Xb) == (int(np.float32(np.float32(np.float32(Y) / np.float32(binning)) / np.float32(2)) * np.float32(2)),
+                        int(np.float32(np.float32(np.float32(X) / np.float32(binning)) / np.float32(2)) * np.float32(2)))
+    fr_, fb_ = xa.Fft2D(ctx, Y, X), xa.Fft2D(ctx, Yb, Xb)
+    got = movie_bin_frame(fr_, fb_, torch.from_numpy(fr).cuda(), torch.from_numpy(dark).cuda(), torch.from_numpy(gain).cuda()).cpu().numpy()
+    exp = oracle.fa_bin_frame((fr.astype(np.float64) - dark) * gain, Yb, Xb)
+    assert got.shape == exp.shape == (Yb, Xb)
+    assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max()
+    # a binned frame keeps the mean of the frame (the zero frequency is copied, times 1 / (X Y), and comes back un-normalised)
+    assert abs(got.mean() - ((fr - dark) * gain).mean()) < 1e-4
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     with pytest.raises(xa.XhError):

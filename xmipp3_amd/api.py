@@ -611,6 +611,22 @@ class ShiftCorrEstimator:
         return inout
 
 
+def movie_binned_size(Y, X, binning):
+    """AProgMovieAlignmentCorrelation::getMovieSize (movie_alignment_correlation_base.cpp:356-370): float arithmetic, truncated"""
+    f = np.float32
+    return int(f(f(f(Y) / f(binning)) / f(2)) * f(2)), int(f(f(f(X) / f(binning)) / f(2)) * f(2))
+
+
+def movie_bin_frame(fft_raw, fft_binned, frame, dark=None, gain=None):
+    """--bin of the CUDA FlexAlign program: frame [Y, X] -> [Yb, Xb] by cropping its half spectrum (xh_movie_bin_frame)"""
+    torch = _torch()
+    assert frame.is_cuda and frame.dtype == torch.float32 and frame.is_contiguous() and tuple(frame.shape) == (fft_raw.ny, fft_raw.nx)
+    out = torch.empty((fft_binned.ny, fft_binned.nx), device=frame.device)
+    check(lib().xh_movie_bin_frame(fft_raw.ctx.h, fft_raw.h, fft_binned.h, _ptr(frame), _ptr(dark, torch.float32), _ptr(gain, torch.float32), fft_raw.ny, fft_raw.nx,
+                                   _ptr(out), fft_binned.ny, fft_binned.nx))
+    return out
+
+
 def movie_dose_filter(fft, frame, pixel_size, acc_voltage, dose_start, dose_finish):
     """ProgMovieFilterDose on one frame ([Y, X] float32 on the device, in place); fft = Fft2D(ctx, Y, X)."""
     torch = _torch()

@@ -1494,3 +1494,55 @@ int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y,
 }
 
 }  // extern "C"
+
+namespace {
+// Binning of a frame as the CUDA program's loader does it (CUDAFlexAlignScale::runScaleIFT, cuda_flexalign_scale.cpp:101-121 +
+// scaleFFT2DKernel, cuda_scaleFFT_kernels.cu:44-79): the half spectrum of the raw frame is cropped to the binned size -- columns
+// 0 .. Xb/2, rows 0 .. Yb/2 from the top and the last Yb - Yb/2 - 1 from the bottom, times 1 / (X Y) -- and transformed back.  The
+// inverse real transform of a half spectrum is the real part of the complex inverse of its Hermitian completion, which is what
+// this kernel writes: G[ky][kx] = H[ky][kx] for kx <= Xb/2, conj(H[(Yb - ky) % Yb][Xb - kx]) beyond.
+__global__ void __launch_bounds__(256) k_bin_crop(const fa_cf *__restrict__ F, fa_cf *__restrict__ G, int Y, int X, int Yb, int Xb, float norm)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)Yb * Xb) return;
+    const int ky = (int)(t / Xb), kx = (int)(t - (size_t)ky * Xb);
+    const int xh = Xb / 2, yhalf = Yb / 2;
+    const bool direct = kx <= xh;
+    const int idy = direct ? ky : (Yb - ky) % Yb, idx = direct ? kx : Xb - kx;
+    const int origY = (idy <= yhalf) ? idy : (Y - (Yb - idy));
+    fa_cf v = F[(size_t)origY * X + idx];
+    v.x *= norm; v.y *= norm;
+    if (!direct) v.y = -v.y;
+    G[t] = v;
+}
+}  // namespace
+
+extern "C" {
+
+int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, const float *d_frame, const float *d_dark, const float *d_gain, int32_t Y, int32_t X,
+                       float *d_out, int32_t Yb, int32_t Xb)
+{
+    XH_CHECK(ctx && planRaw && planBinned && d_frame && d_out && Y >= 2 && X >= 2 && Yb >= 2 && Xb >= 2 && Yb <= Y && Xb <= X, XH_ERR_ARG, "xh_movie_bin_frame: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t tot = (size_t)Y * X, totb = (size_t)Yb * Xb;
+    XhBuf wa, wb;
+    XH_TRY(xh_buf_alloc(ctx, wa, sizeof(fa_cf) * tot));
+    int rc = xh_buf_alloc(ctx, wb, sizeof(fa_cf) * totb);
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL(k_fa_load, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, (fa_cf *)wa.p, tot);
+        rc = xh_fft2d_exec(planRaw, (float *)wa.p, 0);
+    }
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL(k_bin_crop, dim3((unsigned)((totb + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wa.p, (fa_cf *)wb.p, Y, X, Yb, Xb,
+                           ((float)Xb * (float)Yb) / ((float)X * (float)Y));        // 1 / (X Y) of the reference; xh_fft2d's inverse divides by Xb Yb, cuFFT's does not
+        rc = xh_fft2d_exec(planBinned, (float *)wb.p, 1);
+    }
+    if (rc == XH_OK) {
+        hipLaunchKernelGGL(k_dose_store, dim3((unsigned)((totb + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wb.p, d_out, totb);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_movie_bin_frame: device error"); rc = XH_ERR_HIP; }
+    }
+    xh_buf_free(wa); xh_buf_free(wb);
+    return rc;
+}
+
+}  // extern "C"

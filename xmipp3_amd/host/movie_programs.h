@@ -2,8 +2,9 @@
 // (reconstruction/movie_alignment_correlation_base.cpp:36-150,519-586) over xh_fa_*, with the steps of the CUDA program
 // (reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp): global alignment, local (patch) alignment unless
 // --skipLocalAlignment, the B-spline warp of every summed frame (localFromGlobal when only the global alignment ran), the sums
-// and the metadata blocks referenceFrame / localAlignment / frameShifts. Not here: --bin other than 1 and the reference's search
-// for FFT-friendly patch and correlation sizes (it benchmarks cuFFT on the installed GPU; the requested sizes are used).
+// and the metadata blocks referenceFrame / localAlignment / frameShifts; --bin bins every frame while it is loaded (Fourier cropping,
+// xh_movie_bin_frame).  Not here: the reference's search for FFT-friendly patch and correlation sizes (it benchmarks cuFFT on the
+// installed GPU; the requested sizes are used).
 #ifndef XMIPP3_AMD_MOVIE_PROGRAMS_H
 #define XMIPP3_AMD_MOVIE_PROGRAMS_H
 #include "ctf_programs.h"
@@ -78,7 +79,6 @@ public:
         fnGain = getParam("--gain");
         binning = (float)getDoubleParam("--bin");
         if (binning < 1.0) REPORT_ERROR(ERR_ARG_INCORRECT, "Binning must be >= 1");
-        if (binning != 1.0) REPORT_ERROR(ERR_ARG_INCORRECT, "Binning is not supported. Please contact developers if you really need it.");       // movie_alignment_correlation.cpp:41-42
         Ts = (float)getDoubleParam("--sampling") * binning;
         maxShift = (float)getDoubleParam("--maxShift") / Ts;
         maxResForCorrelation = (float)getDoubleParam("--maxResForCorrelation");
@@ -135,9 +135,17 @@ public:
         std::string fn0;
         movie.getValue("image", fn0, (size_t)nfirst);
         readImage(fn0, frame, I);
-        const size_t per = I.x * I.y;
         if (!dark.empty() && (Id.x != I.x || Id.y != I.y)) REPORT_ERROR(ERR_ARG_INCORRECT, "The dark image size does not match the movie frame size.");
         if (!gain.empty() && (Ig.x != I.x || Ig.y != I.y)) REPORT_ERROR(ERR_ARG_INCORRECT, "The gain image size does not match the movie frame size.");
+        // getMovieSize (movie_alignment_correlation_base.cpp:356-370): with --bin the program works on, and stores, binned frames
+        const ImageInfo Iraw = I;
+        const bool doBin = binning != 1.0f;
+        if (doBin) {
+            I.x = (size_t)(((float)Iraw.x / binning) / 2.f * 2.f);
+            I.y = (size_t)(((float)Iraw.y / binning) / 2.f * 2.f);
+            if (I.x < 8 || I.y < 8) REPORT_ERROR(ERR_ARG_INCORRECT, "--bin leaves frames of " + std::to_string(I.x) + " x " + std::to_string(I.y));
+        }
+        const size_t per = I.x * I.y, perRaw = Iraw.x * Iraw.y;
         // setNoOfPatches (:516-528), getRequestedPatchSize (base.h:217-219), checkSettings (:80-86)
         const size_t reqPatch = (size_t)(minLocalRes / Ts);
         if (patchesX <= 0 || patchesY <= 0) {
@@ -168,9 +176,21 @@ public:
                 std::vector<float> f;
                 ImageInfo In;
                 readImage(fn, f, In);
-                if (In.x != I.x || In.y != I.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnMovie);
+                if (In.x != Iraw.x || In.y != Iraw.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnMovie);
                 return f;
             };
+            // --bin: a frame is corrected (dark, gain) and binned on its way in (loadFrame + CUDAFlexAlignScale::runScaleIFT,
+            // movie_alignment_correlation_gpu.cpp:667-691); everything after works on binned frames without dark / gain
+            xh_fft2d *planRaw = nullptr, *planBin = nullptr;
+            struct PlanGuard { xh_fft2d **a, **b; ~PlanGuard() { if (*a) xh_fft2d_destroy(*a); if (*b) xh_fft2d_destroy(*b); } } planGuard{&planRaw, &planBin};
+            DeviceBuffer d_raw;
+            if (doBin) {
+                xhCheck(xh_fft2d_create(g.c, (int)Iraw.y, (int)Iraw.x, &planRaw));
+                xhCheck(xh_fft2d_create(g.c, (int)I.y, (int)I.x, &planBin));
+                d_raw.reserve(g.c, perRaw * sizeof(float));
+                if (!dark.empty()) { d_dark.reserve(g.c, perRaw * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), perRaw * sizeof(float))); }
+                if (!gain.empty()) { d_gain.reserve(g.c, perRaw * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), perRaw * sizeof(float))); }
+            }
             const int ahead = 4;
             std::deque<std::future<std::vector<float>>> inFlight;
             for (int n = 0; n < std::min(ahead, N); ++n) inFlight.push_back(std::async(std::launch::async, readFrame, n));
@@ -178,11 +198,18 @@ public:
                 std::vector<float> cur = inFlight.front().get();          // re-throws what the reader threw
                 inFlight.pop_front();
                 if (n + ahead < N) inFlight.push_back(std::async(std::launch::async, readFrame, n + ahead));
-                xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), cur.data(), per * sizeof(float)));
+                if (doBin) {
+                    xhCheck(xh_memcpy_h2d(g.c, d_raw.p, cur.data(), perRaw * sizeof(float)));
+                    xhCheck(xh_movie_bin_frame(g.c, planRaw, planBin, d_raw.as<float>(), dark.empty() ? nullptr : d_dark.as<float>(), gain.empty() ? nullptr : d_gain.as<float>(),
+                                               (int)Iraw.y, (int)Iraw.x, d_frames.as<float>() + (size_t)n * per, (int)I.y, (int)I.x));
+                } else
+                    xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), cur.data(), per * sizeof(float)));
             }
-            if (!dark.empty()) { d_dark.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), per * sizeof(float))); }
-            if (!gain.empty()) { d_gain.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), per * sizeof(float))); }
-            const float *pd = dark.empty() ? nullptr : d_dark.as<float>(), *pg = gain.empty() ? nullptr : d_gain.as<float>();
+            if (!doBin) {
+                if (!dark.empty()) { d_dark.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), per * sizeof(float))); }
+                if (!gain.empty()) { d_gain.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), per * sizeof(float))); }
+            }
+            const float *pd = (dark.empty() || doBin) ? nullptr : d_dark.as<float>(), *pg = (gain.empty() || doBin) ? nullptr : d_gain.as<float>();
             xhCheck(xh_fa_global_alignment(fa, d_frames.as<float>(), N, pd, pg, maxShift, nullptr, nullptr, sx.data(), sy.data(), &ref));
             centers.resize((size_t)patchesX * patchesY * 2);
             const bool wantAligned = !fnAligned.empty(), wantAvg = !fnAvg.empty(), wantInitial = !fnInitialAvg.empty();
