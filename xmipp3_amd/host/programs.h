@@ -643,6 +643,11 @@ public:
         NiterWeight = (int)getIntParam("--iter");
         if (NiterWeight < 0) REPORT_ERROR(ERR_ARG_INCORRECT, "--iter must not be negative");
         if (rfArithmetic && useFast) REPORT_ERROR(ERR_ARG_INCORRECT, "--fast belongs to xmipp_reconstruct_fourier_accel");
+        if (rfArithmetic && !fn_fsc.empty() && NiterWeight > 1)
+            // correctWeight re-processes the images with processImages(0, last, !fn_fsc.empty(), true) (RF:1088): in the reference the replay
+            // passes re-enter the FSC branch and finish, write and zero the half maps once more per weight iteration. Not reproduced.
+            std::cerr << "xmipp_reconstruct_fourier: --prepare_fsc with --iter > 1: the half maps are finished once, before the weight iterations; "
+                         "the reference's replay passes would finish and zero them again (reconstruct_fourier.cpp:1088), which this program does not do\n";
         // the accel program has no weight iterations (RFA:61-79): under its own name --iter is accepted and ignored
     }
 
