@@ -264,8 +264,7 @@ def main_flexalign(args):
 
         def warp():
             total.zero_()
-            for n in range(N):
-                fa.apply_bspline(frames[n], loc["coeffsX"], loc["coeffsY"], cp, N, n, total=total)
+            fa.apply_bspline_frames(frames, loc["coeffsX"], loc["coeffsY"], cp, total=total)
         timed("warp_and_sum", record, warp)
         h_avg[slot].copy_(total, non_blocking=True)              # the aligned micrograph goes back to the host
         return gl, loc

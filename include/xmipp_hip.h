@@ -435,6 +435,11 @@ int xh_fa_local_from_global(xh_fa *h, int32_t N, const double *h_gShiftX, const 
 int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, const float *d_gain, const double *h_coeffsX,
                         const double *h_coeffsY, int32_t lX, int32_t lY, int32_t lT, int32_t N, int32_t n, float *d_out, float *d_sum,
                         float *d_initial_sum);
+/* the loop of applyShiftsComputeAverage (:479-560) in one call: frames n0 .. n1 of d_frames [N][Y][X] warped with their frame index and added
+ * into d_sum / d_initial_sum (nullable); d_out_stack (nullable, [n1 - n0 + 1][Y][X]) receives the aligned frames */
+int xh_fa_apply_bspline_frames(xh_fa *h, const float *d_frames, int32_t N, int32_t n0, int32_t n1, const float *d_dark, const float *d_gain,
+                               const double *h_coeffsX, const double *h_coeffsY, int32_t lX, int32_t lY, int32_t lT, float *d_out_stack, float *d_sum,
+                               float *d_initial_sum);
 
 /* ProgMovieFilterDose::applyDoseFilterToImage between the two transforms of a frame (reconstruction/movie_filter_dose.cpp:85-170,
  * 283-287): d_frame [Y][X] in place; plan = xh_fft2d_create(ctx, Y, X); acc_voltage 200 or 300 kV (anything else is refused like

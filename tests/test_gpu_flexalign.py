@@ -191,6 +191,24 @@ def test_binning_of_a_frame_against_the_oracle(gpu, oracle, Y, X, binning):
     assert abs(got.mean() - ((fr - dark) * gain).mean()) < 1e-4
 
 
+def test_warp_of_a_whole_movie_in_one_call(gpu):
+    """xh_fa_apply_bspline_frames = the per-frame calls: same sums, same aligned frames, bit for bit."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(8)
+    N, Y, X, cp = 5, 180, 260, (4, 3, 3)
+    fr = torch.from_numpy(rng.standard_normal((N, Y, X)).astype(np.float32)).cuda()
+    cx, cy = rng.uniform(-4, 4, 36), rng.uniform(-4, 4, 36)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+    t1, i1 = torch.zeros((Y, X), device="cuda"), torch.zeros((Y, X), device="cuda")
+    o1 = torch.empty((3, Y, X), device="cuda")
+    for n in range(1, 4):
+        fa.apply_bspline(fr[n], cx, cy, cp, N, n, out=o1[n - 1], total=t1, initial=i1)
+    t2, i2 = torch.zeros((Y, X), device="cuda"), torch.zeros((Y, X), device="cuda")
+    o2 = torch.empty((3, Y, X), device="cuda")
+    fa.apply_bspline_frames(fr, cx, cy, cp, 1, 3, out=o2, total=t2, initial=i2)
+    assert torch.equal(t1, t2) and torch.equal(i1, i2) and torch.equal(o1, o2) and t1.abs().max().item() > 0
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     with pytest.raises(xa.XhError):

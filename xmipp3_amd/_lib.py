@@ -106,6 +106,7 @@ SIGNATURES = {
     "xh_fa_correlate": (C.c_int, [vp, vp, i32, i32, i32, C.c_float, vp]),
     "xh_fa_local_from_global": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "xh_fa_apply_bspline": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "xh_fa_apply_bspline_frames": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "xh_ctfop_create": (C.c_int, [vp, i32, i32, d, pvp]),
     "xh_ctfop_destroy": (C.c_int, [vp]),
     "xh_ctfop_phase_flip": (C.c_int, [vp, vp, C.POINTER(CtfParams), d]),

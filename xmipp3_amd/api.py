@@ -487,6 +487,22 @@ class FlexAlign:
                                             _np_ptr(cx), _np_ptr(cy)))
         return cx, cy
 
+    def apply_bspline_frames(self, frames, coeffsX, coeffsY, control_points, n0=0, n1=None, dark=None, gain=None, out=None, total=None, initial=None):
+        """Frames n0 .. n1 of frames [N, Y, X] warped by the B-spline in one call (the loop of applyShiftsComputeAverage): total += the
+        aligned frames, initial += the corrected unaligned ones, out [n1 - n0 + 1, Y, X] = the aligned frames (each optional)."""
+        torch = _torch()
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape[1:]) == (self.Y, self.X)
+        N = frames.shape[0]
+        n1 = N - 1 if n1 is None else n1
+        for t in (total, initial):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.Y, self.X))
+        assert out is None or (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n1 - n0 + 1, self.Y, self.X))
+        lX, lY, lT = control_points
+        cx, cy = np.ascontiguousarray(coeffsX, np.float64), np.ascontiguousarray(coeffsY, np.float64)
+        assert cx.size == lX * lY * lT and cy.size == lX * lY * lT
+        check(lib().xh_fa_apply_bspline_frames(self.h, _ptr(frames), N, int(n0), int(n1), _ptr(dark, torch.float32), _ptr(gain, torch.float32), _np_ptr(cx), _np_ptr(cy),
+                                               lX, lY, lT, _ptr(out, torch.float32), _ptr(total, torch.float32), _ptr(initial, torch.float32)))
+
     def apply_bspline(self, frame, coeffsX, coeffsY, control_points, N, n, dark=None, gain=None, out=None, total=None, initial=None):
         """Frame n of N ([Y, X] float32 on the device) warped by the B-spline (applyBSplineTransform): out = aligned frame,
         total += it, initial += the corrected unaligned frame (each optional)."""

@@ -21,6 +21,8 @@
 // 30 A); transforms in fp32 (reference: double), peak statistics and centre of mass in double.
 // The patch (local) alignment of movie_alignment_correlation_gpu.cpp:289-430 is not here: the reference has no CPU form of it
 // to compare with (movie_alignment_correlation.cpp:63-76 throw "Not implemented").
+#include <map>
+#include <string>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -925,7 +927,26 @@ struct xh_fa {
     XhBuf work, spectra, lpf, pair, part, res, warpC;
     std::vector<float> warpCHost;         // the spline coefficients the device holds (uploaded once per set, not once per frame)
     int capFrames;
+    // tables and scratch of the two alignment calls stay with the handle (movie after movie: no allocation, no table upload):
+    // grow-only buffers by name, the tables re-made only when the parameters they depend on change
+    std::map<std::string, XhBuf> cache;
+    std::string gKey, lKey;
 };
+
+static int fa_scratch(xh_fa *h, const char *name, size_t bytes, XhBuf **out)
+{
+    XhBuf &b = h->cache[name];
+    XH_TRY(xh_buf_reserve(h->ctx, b, bytes));
+    *out = &b;
+    return XH_OK;
+}
+static int fa_table(xh_fa *h, const char *name, const void *src, size_t bytes, XhBuf **out)
+{
+    XH_TRY(fa_scratch(h, name, bytes, out));
+    XH_HIP(hipMemcpyAsync((*out)->p, src, bytes, hipMemcpyHostToDevice, h->ctx->stream));
+    XH_HIP(hipStreamSynchronize(h->ctx->stream));          // the source is a host temporary
+    return XH_OK;
+}
 
 extern "C" {
 
@@ -938,6 +959,7 @@ int xh_fa_destroy(xh_fa *h)
     if (h->cols) xh_fft2d_destroy(h->cols);
     if (h->small) xh_fft2d_destroy(h->small);
     xh_buf_free(h->work); xh_buf_free(h->spectra); xh_buf_free(h->lpf); xh_buf_free(h->pair); xh_buf_free(h->part); xh_buf_free(h->res); xh_buf_free(h->warpC);
+    for (auto &kv : h->cache) xh_buf_free(kv.second);
     delete h;
     return XH_OK;
 }
@@ -1031,8 +1053,9 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     }
     const int rows = N * (N - 1) / 2;
     std::vector<double> bx(rows), by(rows);
-    XhBuf resAll;
-    XH_TRY(xh_buf_alloc(ctx, resAll, sizeof(double) * 3 * (size_t)rows));
+    XhBuf *pResAll = nullptr;
+    XH_TRY(fa_scratch(h, "g_res", sizeof(double) * 3 * (size_t)rows, &pResAll));
+    XhBuf &resAll = *pResAll;
     const double dSize = (double)small;
     const int nparts = 256;
     int rc = XH_OK;
@@ -1054,27 +1077,36 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     const bool windowed = h->use_window && hy < nY / 2 - 1 && hx < nX / 2 - 1;
     if (windowed) {
         const int wy = 2 * hy + 1, wx = 2 * hx + 1, nxh = nX / 2 + 1;
-        std::vector<fa_cf> twY((size_t)nY * wy), twX((size_t)nxh * wx);
-        const double twoPi = 6.283185307179586476925286766559;
-        for (int ky = 0; ky < nY; ++ky)
-            for (int yy = 0; yy < wy; ++yy) {
-                const long long m = (((long long)ky * (yy - hy)) % nY + nY) % nY;
-                twY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(twoPi * m / nY), (float)std::sin(twoPi * m / nY)};
-            }
-        for (int kx = 0; kx < nxh; ++kx)
-            for (int xx = 0; xx < wx; ++xx) {
-                const long long m = (((long long)kx * (xx - hx)) % nX + nX) % nX;
-                twX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(twoPi * m / nX), (float)std::sin(twoPi * m / nX)};
-            }
-        XhBuf bTwY, bTwX, bU, bW, bStat, bOut;
-        auto freeWin = [&]() { XhBuf *all[] = {&bTwY, &bTwX, &bU, &bW, &bStat, &bOut}; for (XhBuf *q : all) xh_buf_free(*q); };
-        rc = fa_upload(twY.data(), bTwY, sizeof(fa_cf) * twY.size(), ctx);
-        if (rc == XH_OK) rc = fa_upload(twX.data(), bTwX, sizeof(fa_cf) * twX.size(), ctx);
-        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)rows * wy * nxh);
-        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)rows * wy * wx);
-        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bStat, sizeof(double) * 2 * (size_t)rows);
-        if (rc == XH_OK) rc = xh_buf_alloc(ctx, bOut, sizeof(double) * 4 * (size_t)rows);
-        if (rc == XH_OK && hipMemsetAsync(bStat.p, 0, sizeof(double) * 2 * (size_t)rows, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
+        XhBuf *pTwY = nullptr, *pTwX = nullptr, *pU = nullptr, *pW = nullptr, *pStat = nullptr, *pOut = nullptr;
+        char key[96];
+        snprintf(key, sizeof(key), "%d %d %d %d", nY, nX, hy, hx);
+        if (h->gKey != key) {
+            std::vector<fa_cf> twY((size_t)nY * wy), twX((size_t)nxh * wx);
+            const double twoPi = 6.283185307179586476925286766559;
+            for (int ky = 0; ky < nY; ++ky)
+                for (int yy = 0; yy < wy; ++yy) {
+                    const long long m = (((long long)ky * (yy - hy)) % nY + nY) % nY;
+                    twY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(twoPi * m / nY), (float)std::sin(twoPi * m / nY)};
+                }
+            for (int kx = 0; kx < nxh; ++kx)
+                for (int xx = 0; xx < wx; ++xx) {
+                    const long long m = (((long long)kx * (xx - hx)) % nX + nX) % nX;
+                    twX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(twoPi * m / nX), (float)std::sin(twoPi * m / nX)};
+                }
+            rc = fa_table(h, "g_twY", twY.data(), sizeof(fa_cf) * twY.size(), &pTwY);
+            if (rc == XH_OK) rc = fa_table(h, "g_twX", twX.data(), sizeof(fa_cf) * twX.size(), &pTwX);
+            if (rc == XH_OK) h->gKey = key;
+        }
+        if (rc == XH_OK) rc = fa_scratch(h, "g_twY", 0, &pTwY);
+        if (rc == XH_OK) rc = fa_scratch(h, "g_twX", 0, &pTwX);
+        if (rc == XH_OK) rc = fa_scratch(h, "g_U", sizeof(fa_cf) * (size_t)rows * wy * nxh, &pU);
+        if (rc == XH_OK) rc = fa_scratch(h, "g_W", sizeof(float) * (size_t)rows * wy * wx, &pW);
+        if (rc == XH_OK) rc = fa_scratch(h, "g_stat", sizeof(double) * 2 * (size_t)rows, &pStat);
+        if (rc == XH_OK) rc = fa_scratch(h, "g_out", sizeof(double) * 4 * (size_t)rows, &pOut);
+        auto freeWin = [&]() {};
+        if (rc != XH_OK) return rc;
+        XhBuf &bTwY = *pTwY, &bTwX = *pTwX, &bU = *pU, &bW = *pW, &bStat = *pStat, &bOut = *pOut;
+        if (hipMemsetAsync(bStat.p, 0, sizeof(double) * 2 * (size_t)rows, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
         std::vector<double> out4(4 * (size_t)rows);
         if (rc == XH_OK) {
             constexpr int RW = 16;
@@ -1110,7 +1142,6 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
         if (rc == XH_OK && hipMemcpyAsync(res.data(), resAll.p, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
         if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
     }
-    xh_buf_free(resAll);
     if (rc != XH_OK) { if (rc == XH_ERR_HIP) xh_set_error("xh_fa_global_alignment: device error"); return rc; }
     for (int r = 0; r < rows; ++r) { bx[r] = res[3 * r] / h->sizeFactor; by[r] = res[3 * r + 1] / h->sizeFactor; }       // scale to the movie's pixels
     if (h_bX) std::memcpy(h_bX, bx.data(), sizeof(double) * rows);
@@ -1227,45 +1258,60 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
                      sy + PY - 1);
             offs[((size_t)p * N + f) * 2] = sx; offs[((size_t)p * N + f) * 2 + 1] = sy;
         }
-    // tables: pruned forward transforms, low-pass of the correlation size with the 1 / (PX PY) of the transform, inverse twiddles
-    std::vector<fa_cf> Wx((size_t)PX * cxh), Wy((size_t)CY * PY);
-    const double twoPi = 6.283185307179586476925286766559;
-    for (int x = 0; x < PX; ++x)
-        for (int k = 0; k < cxh; ++k) { const double a = -twoPi * (double)(((long long)x * k) % PX) / PX; Wx[(size_t)x * cxh + k] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
-    for (int iy = 0; iy < CY; ++iy) {
-        const int origY = (iy <= CY / 2) ? iy : (PY - (CY - iy));          // rows 0 .. C/2 from the top, the others from the bottom (scaleFFT2DKernel)
-        for (int y = 0; y < PY; ++y) { const double a = -twoPi * (double)(((long long)origY * y) % PY) / PY; Wy[(size_t)iy * PY + y] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
-    }
-    const std::vector<float> filter = fa_make_lpf((double)(h->Ts / actualScale), h->maxRes, CX, CY, 1.0 / ((double)PX * PY));
+    // tables: pruned forward transforms, low-pass of the correlation size with the 1 / (PX PY) of the transform, inverse twiddles --
+    // made and uploaded when the sizes they depend on change (the first movie), kept with the handle afterwards
     const int yHalf = CY / 2, xHalf = CX / 2;
     const int y0 = std::max(0, yHalf - maxDist - 1), y1 = std::min(CY - 1, yHalf + maxDist + 1), wy = y1 - y0 + 1;
     const int x0 = std::max(0, xHalf - maxDist - 1), x1 = std::min(CX - 1, xHalf + maxDist + 1), wx = x1 - x0 + 1;
-    std::vector<fa_cf> tabY((size_t)CY * wy), tabX((size_t)cxh * wx);           // e^{2 pi i ky y / CY}, e^{2 pi i kx x / CX} of the window
-    for (int ky = 0; ky < CY; ++ky)
-        for (int yy = 0; yy < wy; ++yy) { const double a = twoPi * (double)(((long long)ky * (y0 + yy)) % CY) / CY; tabY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
-    for (int kx = 0; kx < cxh; ++kx)
-        for (int xx = 0; xx < wx; ++xx) { const double a = twoPi * (double)(((long long)kx * (x0 + xx)) % CX) / CX; tabX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
-
-    const double tB = now();
-    XhBuf bOffs, bWx, bWy, bTabY, bTabX, bFilter, bPatch, bT, bSingle, bS, bU, bW, bRes;
-    auto freeAll = [&]() { XhBuf *all[] = {&bOffs, &bWx, &bWy, &bTabY, &bTabX, &bFilter, &bPatch, &bT, &bSingle, &bS, &bU, &bW, &bRes}; for (XhBuf *q : all) xh_buf_free(*q); };
     const size_t E = (size_t)CY * cxh;
-    int rc = fa_upload(offs.data(), bOffs, sizeof(int) * offs.size(), ctx);
-    if (rc == XH_OK) rc = fa_upload(Wx.data(), bWx, sizeof(fa_cf) * Wx.size(), ctx);
-    if (rc == XH_OK) rc = fa_upload(Wy.data(), bWy, sizeof(fa_cf) * Wy.size(), ctx);
-    if (rc == XH_OK) rc = fa_upload(tabY.data(), bTabY, sizeof(fa_cf) * tabY.size(), ctx);
-    if (rc == XH_OK) rc = fa_upload(tabX.data(), bTabX, sizeof(fa_cf) * tabX.size(), ctx);
-    if (rc == XH_OK) rc = fa_upload(filter.data(), bFilter, sizeof(float) * filter.size(), ctx);
+    XhBuf *pOffs = nullptr, *pWx = nullptr, *pWy = nullptr, *pTabY = nullptr, *pTabX = nullptr, *pFilter = nullptr, *pPatch = nullptr, *pT = nullptr, *pSingle = nullptr, *pS = nullptr,
+          *pU = nullptr, *pW = nullptr, *pRes = nullptr;
+    int rc = XH_OK;
+    char key[160];
+    snprintf(key, sizeof(key), "%d %d %d %d %d %d %d %d %.9g %.9g", PX, PY, CX, CY, y0, wy, x0, wx, (double)(h->Ts / actualScale), (double)h->maxRes);
+    if (h->lKey != key) {
+        std::vector<fa_cf> Wx((size_t)PX * cxh), Wy((size_t)CY * PY);
+        const double twoPi = 6.283185307179586476925286766559;
+        for (int x = 0; x < PX; ++x)
+            for (int k = 0; k < cxh; ++k) { const double a = -twoPi * (double)(((long long)x * k) % PX) / PX; Wx[(size_t)x * cxh + k] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+        for (int iy = 0; iy < CY; ++iy) {
+            const int origY = (iy <= CY / 2) ? iy : (PY - (CY - iy));          // rows 0 .. C/2 from the top, the others from the bottom (scaleFFT2DKernel)
+            for (int y = 0; y < PY; ++y) { const double a = -twoPi * (double)(((long long)origY * y) % PY) / PY; Wy[(size_t)iy * PY + y] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+        }
+        const std::vector<float> filter = fa_make_lpf((double)(h->Ts / actualScale), h->maxRes, CX, CY, 1.0 / ((double)PX * PY));
+        std::vector<fa_cf> tabY((size_t)CY * wy), tabX((size_t)cxh * wx);           // e^{2 pi i ky y / CY}, e^{2 pi i kx x / CX} of the window
+        for (int ky = 0; ky < CY; ++ky)
+            for (int yy = 0; yy < wy; ++yy) { const double a = twoPi * (double)(((long long)ky * (y0 + yy)) % CY) / CY; tabY[(size_t)ky * wy + yy] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+        for (int kx = 0; kx < cxh; ++kx)
+            for (int xx = 0; xx < wx; ++xx) { const double a = twoPi * (double)(((long long)kx * (x0 + xx)) % CX) / CX; tabX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
+        rc = fa_table(h, "l_Wx", Wx.data(), sizeof(fa_cf) * Wx.size(), &pWx);
+        if (rc == XH_OK) rc = fa_table(h, "l_Wy", Wy.data(), sizeof(fa_cf) * Wy.size(), &pWy);
+        if (rc == XH_OK) rc = fa_table(h, "l_tabY", tabY.data(), sizeof(fa_cf) * tabY.size(), &pTabY);
+        if (rc == XH_OK) rc = fa_table(h, "l_tabX", tabX.data(), sizeof(fa_cf) * tabX.size(), &pTabX);
+        if (rc == XH_OK) rc = fa_table(h, "l_filter", filter.data(), sizeof(float) * filter.size(), &pFilter);
+        if (rc == XH_OK) h->lKey = key;
+    }
+    const double tB = now();
+    if (rc == XH_OK) rc = fa_scratch(h, "l_Wx", 0, &pWx);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_Wy", 0, &pWy);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_tabY", 0, &pTabY);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_tabX", 0, &pTabX);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_filter", 0, &pFilter);
+    if (rc == XH_OK) rc = fa_table(h, "l_offs", offs.data(), sizeof(int) * offs.size(), &pOffs);          // the patch corners move with the global shifts
     // PB patches at a time: the pair kernel has one wave per frame pair, and a single patch (780 waves for 40 frames) leaves
     // most of the device idle
     const int PB = std::min(nP, 16);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bPatch, sizeof(float) * (size_t)PB * N * PY * PX);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bT, sizeof(fa_cf) * (size_t)PB * N * PY * cxh);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bSingle, sizeof(fa_cf) * (size_t)PB * N * E);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bS, sizeof(fa_cf) * (size_t)PB * N * E);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bU, sizeof(fa_cf) * (size_t)PB * rows * wy * cxh);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bW, sizeof(float) * (size_t)PB * rows * wy * wx);
-    if (rc == XH_OK) rc = xh_buf_alloc(ctx, bRes, sizeof(double) * 2 * (size_t)rows * nP);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_patch", sizeof(float) * (size_t)PB * N * PY * PX, &pPatch);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_T", sizeof(fa_cf) * (size_t)PB * N * PY * cxh, &pT);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_single", sizeof(fa_cf) * (size_t)PB * N * E, &pSingle);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_S", sizeof(fa_cf) * (size_t)PB * N * E, &pS);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_U", sizeof(fa_cf) * (size_t)PB * rows * wy * cxh, &pU);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_W", sizeof(float) * (size_t)PB * rows * wy * wx, &pW);
+    if (rc == XH_OK) rc = fa_scratch(h, "l_res", sizeof(double) * 2 * (size_t)rows * nP, &pRes);
+    if (rc != XH_OK) return rc;
+    XhBuf &bOffs = *pOffs, &bWx = *pWx, &bWy = *pWy, &bTabY = *pTabY, &bTabX = *pTabX, &bFilter = *pFilter, &bPatch = *pPatch, &bT = *pT, &bSingle = *pSingle, &bS = *pS, &bU = *pU,
+          &bW = *pW, &bRes = *pRes;
+    auto freeAll = [&]() {};
     const double tC = now();
     for (int p0 = 0; p0 < nP && rc == XH_OK; p0 += PB) {
         const int pb = std::min(PB, nP - p0), nf = pb * N;
@@ -1428,6 +1474,20 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
                            (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
     }
     XH_LAUNCH_CHECK();
+    return XH_OK;
+}
+
+// applyShiftsComputeAverage's loop (movie_alignment_correlation_gpu.cpp:479-560) in one call: frames n0 .. n1 of d_frames [N][Y][X] warped by the
+// spline of their frame index and added into d_sum / d_initial_sum (either may be null); d_out_stack (null or [n1 - n0 + 1][Y][X])
+// receives the aligned frames.  Saves a host round trip per frame.
+int xh_fa_apply_bspline_frames(xh_fa *h, const float *d_frames, int32_t N, int32_t n0, int32_t n1, const float *d_dark, const float *d_gain, const double *h_coeffsX,
+                               const double *h_coeffsY, int32_t lX, int32_t lY, int32_t lT, float *d_out_stack, float *d_sum, float *d_initial_sum)
+{
+    XH_CHECK(h && d_frames && N >= 1 && n0 >= 0 && n1 >= n0 && n1 < N, XH_ERR_ARG, "xh_fa_apply_bspline_frames: bad argument");
+    const size_t per = (size_t)h->Y * h->X;
+    for (int n = n0; n <= n1; ++n)
+        XH_TRY(xh_fa_apply_bspline(h, d_frames + (size_t)n * per, d_dark, d_gain, h_coeffsX, h_coeffsY, lX, lY, lT, N, n, d_out_stack ? d_out_stack + (size_t)(n - n0) * per : nullptr,
+                                   d_sum, d_initial_sum));
     return XH_OK;
 }
 
