@@ -233,6 +233,7 @@ def main_flexalign(args):
     host, drifts = zip(*[make_movie(11 + 2 * rank + u) for u in range(nuniq)])
     torch.cuda.empty_cache()
     fa = xa.FlexAlign(ctx, Y, X, Ts, max_res)
+    fa.set_option("prefilter_ahead", 1)        # the warp's prefilter of the frames runs while the host fits the spline
     dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
     total = torch.zeros((Y, X), device=dev)
     h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]

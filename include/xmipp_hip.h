@@ -418,7 +418,10 @@ typedef struct xh_fa xh_fa;
 int xh_fa_create(xh_ctx *ctx, int32_t Y, int32_t X, float sampling_rate, float max_res_for_correlation, xh_fa **out);
 int xh_fa_destroy(xh_fa *h);
 int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor);
-int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: every pair correlation through the full inverse transform (A/B) */
+int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: every pair correlation through the full inverse transform (A/B);
+                                                                  "prefilter_ahead" 1: xh_fa_local_alignment ends with the warp's B-spline prefilter of every frame
+                                                                  (N Y X floats kept with the handle), run while the host fits the spline; the following
+                                                                  xh_fa_apply_bspline[_frames] calls on the same frames (without an initial sum) use it */
 int xh_fa_last_full_pairs(const xh_fa *h);                        /* pairs of the last global alignment that needed the full transform */
 int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, float max_shift_px,
                            double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref);

@@ -209,6 +209,36 @@ def test_warp_of_a_whole_movie_in_one_call(gpu):
     assert torch.equal(t1, t2) and torch.equal(i1, i2) and torch.equal(o1, o2) and t1.abs().max().item() > 0
 
 
+def test_prefilter_ahead_changes_nothing(gpu):
+    """xh_fa_set_option "prefilter_ahead": the local alignment leaves the prefiltered frames with the handle (computed while the host
+    fits the spline); the warp that follows gives the same bits as the warp that prefilters itself, and a warp with an initial sum,
+    other frames or after a new global alignment does not use them."""
+    from tests import synth
+    xa, ctx, torch = gpu
+    N, Y, X = 5, 300, 420
+    frames, drift, field = synth.movie(N, Y, X, seed=3, local=3.0)
+    d = torch.from_numpy(frames).cuda()
+    patches, psize, cp = (4, 4), (100, 90), (3, 3, 3)
+    out = {}
+    for ahead in (0, 1):
+        fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+        fa.set_option("prefilter_ahead", ahead)
+        g = fa.global_alignment(d, 25.0)
+        loc = fa.local_alignment(d, g["shiftX"], g["shiftY"], g["ref"], 25.0, patches, psize, 2, cp)
+        total, aligned = torch.zeros((Y, X), device="cuda"), torch.empty((N, Y, X), device="cuda")
+        fa.apply_bspline_frames(d, loc["coeffsX"], loc["coeffsY"], cp, out=aligned, total=total)
+        ini = torch.zeros((Y, X), device="cuda")
+        t2 = torch.zeros((Y, X), device="cuda")
+        fa.apply_bspline_frames(d, loc["coeffsX"], loc["coeffsY"], cp, total=t2, initial=ini)           # with an initial sum: the ordinary path
+        other = (d * 2).contiguous()
+        t3 = torch.zeros((Y, X), device="cuda")
+        fa.apply_bspline_frames(other, loc["coeffsX"], loc["coeffsY"], cp, total=t3)                     # other frames: the ordinary path
+        out[ahead] = (total, aligned, t2, ini, t3)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert torch.allclose(out[1][4], 2 * out[1][0], rtol=1e-5, atol=1e-4) and torch.equal(out[1][0], out[1][2])
+
+
 def test_errors_are_loud(gpu):
     xa, ctx, torch = gpu
     with pytest.raises(xa.XhError):

@@ -931,6 +931,11 @@ struct xh_fa {
     // grow-only buffers by name, the tables re-made only when the parameters they depend on change
     std::map<std::string, XhBuf> cache;
     std::string gKey, lKey;
+    // "prefilter_ahead": the local alignment ends with the B-spline prefilter of every frame (which does not need the spline it is
+    // about to fit on the host), so the device works while the host solves; xh_fa_apply_bspline then finds the coefficients ready
+    int prefilter_ahead = 0;
+    const float *aheadBase = nullptr, *aheadDark = nullptr, *aheadGain = nullptr;
+    int aheadN = 0;
 };
 
 static int fa_scratch(xh_fa *h, const char *name, size_t bytes, XhBuf **out)
@@ -1006,6 +1011,7 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value)
     XH_CHECK(h && name, XH_ERR_ARG, "xh_fa_set_option: bad argument");
     if (!strcmp(name, "window")) h->use_window = value != 0;
     else if (!strcmp(name, "mfma")) h->use_mfma = value != 0;
+    else if (!strcmp(name, "prefilter_ahead")) { h->prefilter_ahead = value != 0; h->aheadBase = nullptr; }
     else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
@@ -1025,6 +1031,7 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
                            double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref)
 {
     XH_CHECK(h && d_frames && N >= 2 && h_shiftX && h_shiftY && h_ref, XH_ERR_ARG, "xh_fa_global_alignment: bad argument");
+    h->aheadBase = nullptr;                  // a new movie: coefficients prefiltered ahead for the previous one are void
     xh_ctx *ctx = h->ctx;
     XH_HIP(hipSetDevice(ctx->device));
     const int nY = h->nY, nX = h->nX;
@@ -1343,6 +1350,21 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     if (rc == XH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
     const double tD = now();
     freeAll();
+    h->aheadBase = nullptr;
+    if (rc == XH_OK && h->prefilter_ahead) {
+        // the warp's prefilter of every frame, behind the results' copy: runs while the host solves below
+        XhBuf *pCoef = nullptr;
+        rc = fa_scratch(h, "w_coefAll", sizeof(float) * (size_t)N * Y * X, &pCoef);
+        if (rc == XH_OK) {
+            const XhFir F = xh_fir_taps();
+            const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
+            for (int n = 0; n < N; ++n)
+                hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * Y * X, d_dark, d_gain,
+                                   (float *)pCoef->p + (size_t)n * Y * X, (float *)nullptr, Y, X, tilesX, F);
+            if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
+            else { h->aheadBase = d_frames; h->aheadDark = d_dark; h->aheadGain = d_gain; h->aheadN = N; }
+        }
+    }
     const double tE = now();
     if (rc != XH_OK) { if (rc == XH_ERR_HIP) xh_set_error("xh_fa_local_alignment: device error"); return rc; }
     // computeAlignment (:776-797) per patch: deduct the centre, scale to the movie's pixels, solve, add the rounded global shift
@@ -1463,9 +1485,14 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
         XH_HIP(hipStreamSynchronize(ctx->stream));
     }
     float *coef = (float *)h->work.p;
-    const XhFir F = xh_fir_taps();
-    const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
-    hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, coef, d_initial_sum, Y, X, tilesX, F);
+    const bool ahead = h->aheadBase && !d_initial_sum && N == h->aheadN && d_frame == h->aheadBase + (size_t)n * Y * X && d_dark == h->aheadDark && d_gain == h->aheadGain &&
+                       h->cache.count("w_coefAll");
+    if (ahead) coef = (float *)h->cache["w_coefAll"].p + (size_t)n * Y * X;
+    else {
+        const XhFir F = xh_fir_taps();
+        const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
+        hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, coef, d_initial_sum, Y, X, tilesX, F);
+    }
     if (d_out || d_sum) {
         // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
         const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
