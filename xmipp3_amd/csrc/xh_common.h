@@ -54,6 +54,9 @@ void xh_buf_free(XhBuf &b);
 // grow-only scratch
 int xh_buf_reserve(xh_ctx *ctx, XhBuf &b, size_t bytes);
 
+// a grow-only device buffer that lives with a 2-D transform plan (frame-after-frame callers: dose filter, binning)
+int xh_fft2d_user_scratch(xh_fft2d *f, size_t bytes, void **p);
+
 static inline int xh_ilog2(int n)
 {
     int l = 0;

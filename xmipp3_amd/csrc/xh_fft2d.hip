@@ -251,7 +251,17 @@ struct xh_fft2d {
     int ny, nx;
     Axis ax, ay;
     XhBuf tmp;
+    XhBuf user;          // scratch of the callers that transform frame after frame with one plan (xh_fft2d_user_scratch): grow-only
 };
+
+// internal (xh_common.h): a device buffer of at least `bytes` that lives with the plan
+int xh_fft2d_user_scratch(xh_fft2d *f, size_t bytes, void **p)
+{
+    XH_CHECK(f && p, XH_ERR_ARG, "xh_fft2d_user_scratch: bad argument");
+    XH_TRY(xh_buf_reserve(f->ctx, f->user, bytes));
+    *p = f->user.p;
+    return XH_OK;
+}
 
 extern "C" {
 
@@ -275,7 +285,7 @@ int xh_fft2d_destroy(xh_fft2d *f)
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     axis_free(f->ax); axis_free(f->ay); xh_buf_free(f->tmp);
-    delete f;
+    xh_buf_free(f->user); delete f;
     return XH_OK;
 }
 

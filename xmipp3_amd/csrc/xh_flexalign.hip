@@ -1562,9 +1562,9 @@ int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y,
     else { xh_set_error("xh_movie_dose_filter: Bad acceleration voltage (must be 200 or 300 kV"); return XH_ERR_ARG; }     // initVoltage, :112-124
     XH_HIP(hipSetDevice(ctx->device));
     const size_t tot = (size_t)Y * X;
-    XhBuf work;
-    XH_TRY(xh_buf_alloc(ctx, work, sizeof(fa_cf) * tot));
-    fa_cf *F = (fa_cf *)work.p;
+    void *wp = nullptr;
+    XH_TRY(xh_fft2d_user_scratch(plan, sizeof(fa_cf) * tot, &wp));        // lives with the plan: no allocation per frame
+    fa_cf *F = (fa_cf *)wp;
     const unsigned grid = (unsigned)((tot + 255) / 256);
     hipLaunchKernelGGL(k_fa_load, dim3(grid), dim3(256), 0, ctx->stream, (const float *)d_frame, (const float *)nullptr, (const float *)nullptr, F, tot);
     int rc = xh_fft2d_exec(plan, (float *)F, 0);
@@ -1574,9 +1574,8 @@ int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y,
     }
     if (rc == XH_OK) {
         hipLaunchKernelGGL(k_dose_store, dim3(grid), dim3(256), 0, ctx->stream, (const fa_cf *)F, d_frame, tot);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_movie_dose_filter: device error"); rc = XH_ERR_HIP; }
+        if (hipGetLastError() != hipSuccess) { xh_set_error("xh_movie_dose_filter: device error"); rc = XH_ERR_HIP; }        // (no synchronisation: stream order)
     }
-    xh_buf_free(work);
     return rc;
 }
 
@@ -1612,9 +1611,9 @@ int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, con
     XH_CHECK(ctx && planRaw && planBinned && d_frame && d_out && Y >= 2 && X >= 2 && Yb >= 2 && Xb >= 2 && Yb <= Y && Xb <= X, XH_ERR_ARG, "xh_movie_bin_frame: bad argument");
     XH_HIP(hipSetDevice(ctx->device));
     const size_t tot = (size_t)Y * X, totb = (size_t)Yb * Xb;
-    XhBuf wa, wb;
-    XH_TRY(xh_buf_alloc(ctx, wa, sizeof(fa_cf) * tot));
-    int rc = xh_buf_alloc(ctx, wb, sizeof(fa_cf) * totb);
+    struct { void *p; } wa{nullptr}, wb{nullptr};
+    XH_TRY(xh_fft2d_user_scratch(planRaw, sizeof(fa_cf) * tot, &wa.p));
+    int rc = xh_fft2d_user_scratch(planBinned, sizeof(fa_cf) * totb, &wb.p);
     if (rc == XH_OK) {
         hipLaunchKernelGGL(k_fa_load, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, (fa_cf *)wa.p, tot);
         rc = xh_fft2d_exec(planRaw, (float *)wa.p, 0);
@@ -1626,9 +1625,8 @@ int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, con
     }
     if (rc == XH_OK) {
         hipLaunchKernelGGL(k_dose_store, dim3((unsigned)((totb + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wb.p, d_out, totb);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { xh_set_error("xh_movie_bin_frame: device error"); rc = XH_ERR_HIP; }
+        if (hipGetLastError() != hipSuccess) { xh_set_error("xh_movie_bin_frame: device error"); rc = XH_ERR_HIP; }
     }
-    xh_buf_free(wa); xh_buf_free(wb);
     return rc;
 }
 

@@ -166,6 +166,8 @@ public:
             xh_fa *fa = nullptr;
             xhCheck(xh_fa_create(g.c, (int)I.y, (int)I.x, Ts, maxResForCorrelation, &fa));
             struct FaGuard { xh_fa *f; ~FaGuard() { xh_fa_destroy(f); } } fg{fa};
+            // the warp's prefilter of the frames runs while the host fits the spline (not with --oavgInitial: its sum leaves the prefilter pass)
+            if (!skipLocalAlignment && fnInitialAvg.empty() && (!fnAvg.empty() || !fnAligned.empty())) xhCheck(xh_fa_set_option(fa, "prefilter_ahead", 1));
             DeviceBuffer d_frames, d_dark, d_gain, d_out, d_sum, d_initial;
             d_frames.reserve(g.c, (size_t)N * per * sizeof(float));
             // the frames are read a few ahead by their own threads while the one before them goes to the device (the reference loads
@@ -240,6 +242,12 @@ public:
                 std::vector<float> host(per, 0.f);
                 if (wantAvg) { d_sum.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_sum.p, host.data(), per * sizeof(float))); }
                 if (wantInitial) { d_initial.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_initial.p, host.data(), per * sizeof(float))); }
+                if (!wantAligned) {
+                    // only sums are asked for: the whole loop in one call
+                    xhCheck(xh_fa_apply_bspline_frames(fa, d_frames.as<float>(), N, nfirstSum - nfirst, nlastSum - nfirst, pd, pg, coeffsX.data(), coeffsY.data(), cpX, cpY, cpT,
+                                                       nullptr, wantAvg ? d_sum.as<float>() : nullptr, wantInitial ? d_initial.as<float>() : nullptr));
+                    Nsum = nlastSum - nfirstSum + 1;
+                } else
                 for (int fi = nfirstSum; fi <= nlastSum; ++fi) {
                     const int off = fi - nfirst;
                     xhCheck(xh_fa_apply_bspline(fa, d_frames.as<float>() + (size_t)off * per, pd, pg, coeffsX.data(), coeffsY.data(), cpX, cpY, cpT, N, off,
