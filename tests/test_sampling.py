@@ -92,6 +92,35 @@ def test_neighbourhoods_c1_match_the_reference_fixture(prog, tmp_path, only_winn
         assert got == exp
 
 
+def test_groups_write_one_sampling_file_per_block(prog, tmp_path):
+    """--groups (createGroupSamplingFiles, angular_project_library.cpp:405-470): for every block of the groups file the neighbours of
+    the experimental images in the block of that name are written to <root>_groupNNNNNN_sampling.xmd.  A group holding all three
+    images of the reference's fixture gives the neighbour lists of the ungrouped run; a group with the second image alone gives its
+    list as the only one."""
+    src = open(os.path.join(GOLD, "experimental_images.xmd")).read().splitlines()
+    head = [l for l in src if l.startswith("#")]
+    start = next(i for i, l in enumerate(src) if l.startswith("data_"))
+    body = src[start + 1:]
+    rows = [l for l in body if l.strip() and not l.strip().startswith(("_", "loop_"))]
+    labels = [l for l in body if l.strip().startswith(("_", "loop_"))]
+    exp = tmp_path / "exp.xmd"
+    exp.write_text("\n".join(head + ["data_all"] + labels + rows + ["data_second"] + labels + [rows[1]]) + "\n")
+    (tmp_path / "groups.xmd").write_text("# XMIPP_STAR_1 * \n# \ndata_all\nloop_\n _image\n x\ndata_second\nloop_\n _image\n x\n")
+    args = [prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "3", "--sym", "c1", "--experimental_images", "all@" + str(exp),
+            "--angular_distance", "5", "--compute_neighbors", "--groups", str(tmp_path / "groups.xmd"), "--only_create_sampling"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    def lists(fn):
+        l, rw = _block(fn, "neighbors")
+        c = {k: i for i, k in enumerate(l)}
+        return [[int(v) for v in q[c["neighbors"]].split()] for q in rw]
+    whole = lists(str(tmp_path / "g_sampling.xmd"))
+    assert lists(str(tmp_path / "g_group000001_sampling.xmd")) == whole and len(whole) == 3
+    assert lists(str(tmp_path / "g_group000002_sampling.xmd")) == [whole[1]]
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "h.stk"), "--groups", str(tmp_path / "groups.xmd"), "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+
+
 def test_cn_dn_units_and_loud_failures(prog, tmp_path):
     n = {}
     for sym in ("c1", "c4", "d2"):

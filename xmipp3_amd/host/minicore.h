@@ -183,6 +183,22 @@ public:
     }
 };
 
+// getBlocksInMetaDataFile (xmippCore metadata_extension): the names of the data_ blocks of a metadata file, in file order
+inline std::vector<std::string> getBlocksInMetaDataFile(const std::string &path)
+{
+    std::vector<std::string> out;
+    std::ifstream f(FileName(path).path);
+    if (!f.good()) REPORT_ERROR(ERR_IO_NOTEXIST, "MetaData::read: cannot open " + path);
+    std::string line;
+    while (std::getline(f, line))
+        if (line.compare(0, 5, "data_") == 0) {
+            std::string b = line.substr(5);
+            while (!b.empty() && (b.back() == ' ' || b.back() == '\r' || b.back() == '\t')) b.pop_back();
+            out.push_back(b);
+        }
+    return out;
+}
+
 // ------------------------------------------------------------------ images
 struct ImageInfo { size_t x = 0, y = 0, z = 1, n = 1; bool isStack = false; size_t headerBytes = 0, perImageHeader = 0; bool mrc = false, swap = false; };
 

@@ -1024,7 +1024,7 @@ public:
         // angular_project_library.cpp:249-397
         if (perturb_projection_vector != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--perturb is not available (it is seeded with time() in the reference)");
         if (compute_closer_sampling_point_bool) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--closer_sampling_points is not available yet");
-        if (!fn_groups.empty()) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--groups is not available yet");
+        if (!fn_groups.empty() && FnexperimentalImages.empty()) REPORT_ERROR(ERR_ARG_MISSING, "--groups needs --experimental_images");
         std::string fam, famN;
         int order, orderN;
         parseGroup(fn_sym, fam, order);
@@ -1075,6 +1075,27 @@ public:
             else std::cout << "There are no projections within the specified angular range and sampling" << std::endl;
         }
         std::remove((output_file_root + "_angles.doc").c_str());
+        if (!fn_groups.empty()) {
+            // createGroupSamplingFiles (angular_project_library.cpp:405-470): a sampling file per block of the groups file, with the
+            // neighbours of that block's experimental images (the block of the same name in the experimental metadata)
+            const std::string fn_exp = FileName(FnexperimentalImages).path;
+            int igrp = 1;
+            for (const std::string &block : getBlocksInMetaDataFile(fn_groups)) {
+                char num[16];
+                snprintf(num, sizeof(num), "%06d", igrp++);
+                const std::string root = output_file_root + "_group" + num;
+                std::cerr << "Writing group sampling file " << root << std::endl;
+                MetaDataVec SFBlock;
+                SFBlock.read(block + "@" + fn_exp);
+                if (SFBlock.size() > 0) {
+                    mysampling.fillExpDataProjectionDirectionByLR(SFBlock);
+                    if (compute_neighbors_bool) {
+                        mysampling.computeNeighbors(only_winner);
+                        mysampling.saveSamplingFile(root, false);
+                    }
+                }
+            }
+        }
         if (only_sampling) {
             // diagnostic: the rotations of the neighbourhood group (identity first), one 3x3 matrix per line
             std::ofstream f(output_file_root + "_symmetry.txt");
