@@ -179,6 +179,59 @@ k_pm_prefilter_fir64(const TIN *__restrict__ in, double *__restrict__ out, int D
     }
 }
 
+// Both fp64 passes in one kernel (the re-scored particles' prefilter was two kernels with a D x D double intermediate per slot): a
+// block owns 8 rows x 128 columns of a slot's image, filters down the columns (thread <-> column, the 32 either side too) into an
+// LDS tile and along the rows out of it; same taps, same mirror extension.  blockIdx.y: slot (gather / count as above).
+#define XH_FIR64_TW 128
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_fir64_2d(const TIN *__restrict__ in, double *__restrict__ out, int D, int tilesX, XhFir64 F, const int *__restrict__ gather,
+                        const int *__restrict__ count)
+{
+    constexpr int K = XH_FIR64_K, V = XH_FIR64_V, TW = XH_FIR64_TW;
+    __shared__ double tile[V][TW + 2 * K];
+    const int slot = blockIdx.y;
+    if (count && slot >= *count) return;
+    const TIN *src = in + (size_t)(gather ? gather[slot] : slot) * D * D;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x0 = tx * TW, y0 = ty * V;
+    const int xx = threadIdx.x;
+    if (xx < TW + 2 * K && x0 + xx - K < D + K) {
+        int p = x0 + xx - K;
+        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        double w[V + 2 * K];
+#pragma unroll
+        for (int i = 0; i < V + 2 * K; ++i) {
+            int q = y0 + i - K;
+            while (q < 0 || q >= D) q = q < 0 ? -1 - q : 2 * D - 1 - q;
+            w[i] = (double)src[(size_t)q * D + p];
+        }
+#pragma unroll
+        for (int o = 0; o < V; ++o) {
+            double acc = F.h[0] * w[o + K];
+#pragma unroll
+            for (int j = 1; j <= K; ++j) acc += F.h[j] * (w[o + K - j] + w[o + K + j]);
+            tile[o][xx] = acc;
+        }
+    }
+    __syncthreads();
+    // rows: thread <-> 4 consecutive outputs of one tile row
+    const int r = threadIdx.x / (TW / 4), seg = threadIdx.x - r * (TW / 4);
+    const int xo = x0 + seg * 4, y = y0 + r;
+    if (y >= D || xo >= D) return;
+    double w[4 + 2 * K];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * K; ++i) w[i] = tile[r][seg * 4 + i];
+    double *dst = out + (size_t)slot * D * D + (size_t)y * D + xo;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        double acc = F.h[0] * w[o + K];
+#pragma unroll
+        for (int j = 1; j <= K; ++j) acc += F.h[j] * (w[o + K - j] + w[o + K + j]);
+        if (xo + o < D) dst[o] = acc;
+    }
+}
+
 static inline XhFir64 xh_fir64_taps()
 {
     XhFir64 F;

@@ -125,6 +125,7 @@ struct xh_pm {
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
     int s6_coarse_kernel;        // S6: the fp32 pass ends in k_pm_bestshift_coarse (0: k_pm_bestshift<float>, A/B)
+    int fir64_fused;             // the fp64 prefilter as one kernel (0: rows then columns with an intermediate, A/B)
     int s6_debug;                // profiling: xh_pm_translate returns decision margins instead of shifts
     int s6_capture;              // test hook: 32 / 64 = xh_pm_translate runs only that chain and leaves the correlation maps for xh_pm_debug_s6_maps
     int s6_captured;             // ... precision and count of the maps left behind
@@ -3019,6 +3020,17 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         const XhFir64 F = xh_fir64_taps();
         const int segs = (D + XH_FIR64_V - 1) / XH_FIR64_V;
         const size_t nvec = (size_t)nslots * D * segs;
+        if (pm->fir64_fused && nslots <= 65535) {
+            // both passes in one kernel, no intermediate
+            const int tilesX = (D + XH_FIR64_TW - 1) / XH_FIR64_TW, tilesY = (D + XH_FIR64_V - 1) / XH_FIR64_V;
+            if (imgsAreFloat)
+                hipLaunchKernelGGL((k_pm_prefilter_fir64_2d<float>), dim3(tilesX * tilesY, nslots), dim3(256), 0, ctx->stream, (const float *)imgs, (double *)coefBuf.p, D, tilesX, F,
+                                   d_gather, d_count);
+            else
+                hipLaunchKernelGGL((k_pm_prefilter_fir64_2d<double>), dim3(tilesX * tilesY, nslots), dim3(256), 0, ctx->stream, (const double *)imgs, (double *)coefBuf.p, D, tilesX, F,
+                                   d_gather, d_count);
+            XH_LAUNCH_CHECK();
+        } else {
         XH_TRY(xh_buf_reserve(ctx, pm->d_firTmp64, sizeof(double) * (size_t)nslots * D * D));
         if (imgsAreFloat)
             hipLaunchKernelGGL((k_pm_prefilter_fir64<false, float>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -3029,6 +3041,7 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         hipLaunchKernelGGL((k_pm_prefilter_fir64<true, double>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double *)pm->d_firTmp64.p, (double *)coefBuf.p, D, nvec, F, (const int *)nullptr, d_count);
         XH_LAUNCH_CHECK();
+        }
     } else {
     const int TR = std::max(1, std::min(32, (int)(60000 / ((D + 1) * sizeof(T)))));
     const int tiles = (D + TR - 1) / TR;
@@ -3205,6 +3218,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma64 = 1;
     pm->s6_pair = 1;
     pm->s6_coarse_kernel = 1;
+    pm->fir64_fused = 1;
     pm->s6_debug = 0;
     pm->s6_capture = 0;
     pm->s6_captured = 0;
@@ -3549,6 +3563,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "use_mfma64")) pm->use_mfma64 = (int)value;
     else if (!strcmp(name, "s6_pair")) pm->s6_pair = (int)value;
     else if (!strcmp(name, "s6_coarse_kernel")) pm->s6_coarse_kernel = (int)value;
+    else if (!strcmp(name, "fir64_fused")) pm->fir64_fused = (int)value;
     else if (!strcmp(name, "s6_debug")) pm->s6_debug = (int)value;
     else if (!strcmp(name, "s6_capture")) pm->s6_capture = (int)value;
     else if (!strcmp(name, "s6_fp32")) pm->s6_fp32 = (int)value;
