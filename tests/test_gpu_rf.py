@@ -165,7 +165,7 @@ def test_insert_axis_aligned_projection_is_dropped_like_reference(gpu, oracle):
     assert np.array_equal(gw.cpu().numpy(), ew) and np.array_equal(gv.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("mode", ["plain", "sym_weights", "ctf", "fast", "fast_ctf"])
+@pytest.mark.parametrize("mode", ["plain", "sym_weights", "sym_improper", "ctf", "fast", "fast_ctf"])
 def test_insert_many(gpu, oracle, data32, mode):
     xa, ctx, torch = gpu
     D, vol, ang, imgs = data32
@@ -181,6 +181,11 @@ def test_insert_many(gpu, oracle, data32, mode):
         weights[3] = 0.0  # skipped, RFA:327-329
         c2 = np.diag([-1.0, -1.0, 1.0])
         sym = np.stack([np.eye(3), c2])
+    if mode == "sym_improper":
+        # groups with mirror planes / inversion (cs, cNv, ..., ih): the reference multiplies by R whatever its determinant
+        # (reconstruct_fourier_accel.cpp:252-254, 953-956); here a mirror plane, the inversion and a rotoreflection
+        n_ = np.array([1.0, 2.0, -0.5]) / np.linalg.norm([1.0, 2.0, -0.5])
+        sym = np.stack([np.eye(3), np.diag([1.0, -1.0, 1.0]), -np.eye(3), (np.eye(3) - 2 * np.outer(n_, n_)) @ synth.euler_matrix(30, 0, 0)])
     if mode in ("ctf", "fast_ctf"):
         ctf = (rng.uniform(0.5, 2.0, ffts.shape[:3]) * rng.choice([-1, 1], ffts.shape[:3])).astype(np.float32)
         mod = rng.uniform(0.0, 1.0, ffts.shape[:3]).astype(np.float32)

@@ -129,9 +129,9 @@ def test_cn_dn_units_and_loud_failures(prog, tmp_path):
         assert r.returncode == 0, r.stderr
         n[sym] = len(xmipp_io.read_xmd(str(tmp_path / f"{sym}.doc"))[1])
     assert 0.2 < n["c4"] / n["c1"] < 0.32 and 0.2 < n["d2"] / n["c1"] < 0.32
-    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--sym", "i3h", "--only_create_sampling"],
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--sym", "i5h", "--only_create_sampling"],
                        capture_output=True, text=True)
-    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr         # not implemented in the reference either (sampling.cpp:1216)
     r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "x.stk"), "--method", "real_space", "--only_create_sampling"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
@@ -241,3 +241,139 @@ def test_named_groups_in_symlist(prog, tmp_path):
         assert len(M) == order
         prods = {tuple(np.round((a @ b).ravel(), 6) + 0.0) for a in M for b in M}
         assert len(prods) == order                                   # closed under multiplication
+
+
+# ---- groups with mirror planes / inversion.  The reference's own typed test runs on i3h (test_sampling_main.cpp:58-76, 94-110,
+# 144-162); its three fixtures are under tests/golden/sampling/ (the projectionDirectionsSphere block, a repeat of ref_c1's, cut).
+def test_asymmetric_unit_i3h_matches_the_reference_fixture(prog, tmp_path):
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "3", "--sym", "i3h",
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "g.doc"))
+    c = {l: i for i, l in enumerate(labels)}
+    gold = os.path.join(GOLD, "ref_i3h_sampling.xmd")
+    gl, grows = _block(gold, "projectionDirections")
+    gc = {l: i for i, l in enumerate(gl)}
+    assert " _pointsAsymmetricUnit 30\n" in open(gold).read()
+    assert len(rows) == len(grows) == 30
+    keys = ("angleRot", "angleTilt", "anglePsi", "X", "Y", "Z")
+    got = np.array([[float(r[c[k]]) for k in keys] for r in rows])
+    exp = np.array([[float(r[gc[k]]) for k in keys] for r in grows])
+    assert [int(r[c["ref"]]) for r in rows] == [int(r[gc["neighbor"]]) for r in grows]
+    assert np.abs(got - exp).max() <= 2e-6
+
+
+def test_neighbourhoods_i3h_match_the_reference_fixtures(prog, tmp_path):
+    """removePointsFarAwayFromExperimentalData + computeNeighbors over the 120 elements of i3h: 15 of the 30 directions survive, in the
+    fixture's (swap-delete) order, with the fixture's neighbour lists.  This is also what pins the action of the improper
+    elements on a direction: d -> R^T d with R of determinant -1, no left matrix (with xmippCore's L = diag(1,1,-1) applied
+    to the vector, 20 directions would survive)."""
+    args = [prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "3", "--sym", "i3h",
+            "--experimental_images", os.path.join(GOLD, "experimental_images.xmd"), "--angular_distance", "5",
+            "--near_exp_data", "--compute_neighbors", "--only_create_sampling"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fn = str(tmp_path / "g_sampling.xmd")
+    for gold in ("ref_i3h_exp_sampling.xmd", "neigh_ref_i3h_exp_sampling.xmd"):
+        l, rows = _block(fn, "projectionDirections")
+        gl, grows = _block(os.path.join(GOLD, gold), "projectionDirections")
+        gi, ga = _dirs(rows, {k: i for i, k in enumerate(l)})
+        ei, ea = _dirs(grows, {k: i for i, k in enumerate(gl)})
+        assert gi.tolist() == ei.tolist() and len(gi) == 15
+        assert np.abs(ga - ea).max() <= 2e-6
+    l, rows = _block(fn, "neighbors")
+    gl, grows = _block(os.path.join(GOLD, "neigh_ref_i3h_exp_sampling.xmd"), "neighbors")
+    got = [[int(v) for v in r[l.index("neighbors")].split()] for r in rows]
+    exp = [[int(v) for v in r[gl.index("neighbors")].split()] for r in grows]
+    assert got == exp
+    M = np.loadtxt(str(tmp_path / "g_symmetry.txt")).reshape(-1, 3, 3)
+    assert len(M) == 120 and sum(np.linalg.det(m) < 0 for m in M) == 60
+
+
+def _mirror(n):
+    n = np.array(n, float) / np.linalg.norm(n)
+    return np.eye(3) - 2 * np.outer(n, n)
+
+
+def _improper_group(name):
+    """generators of Sampling::createSymFile (sampling.cpp:1328-1420), dihedral 2-fold on X"""
+    from tests import synth
+    inv = -np.eye(3)
+    z = lambda n: [_rot_axis(n, (0, 0, 1))] if n > 1 else []
+    if name == "ci": return _closure([inv])
+    if name == "cs": return _closure([_mirror((0, 0, 1))])
+    if name[0] in "cds" and name[1].isdigit():
+        n = int("".join(ch for ch in name[1:] if ch.isdigit()))
+        tail = name[-1]
+        if name[0] == "s": return _closure(z(n // 2) + [inv])
+        if name[0] == "c": return _closure(z(n) + [_mirror((0, 1, 0)) if tail == "v" else _mirror((0, 0, 1))])
+        return _closure(z(n) + [_rot_axis(2, (1, 0, 0)), _mirror((1, 0, 0)) if tail == "v" else _mirror((0, 0, 1))])
+    if name == "td": return _closure([_rot_axis(3, (0, 0, 1)), _rot_axis(2, (0, 0.816496, 0.577350)), _mirror((1.4142136, 2.4494897, 0))])
+    if name == "th": return _closure([_rot_axis(3, (0, 0, 1)), _rot_axis(2, (0, -0.816496, -0.577350)), inv])
+    if name == "oh": return _closure([_rot_axis(3, (1, 1, 1)), _rot_axis(4, (0, 0, 1)), _mirror((0, 1, 1))])
+    G = _group("i" + name[1])
+    return G + [-g for g in G]
+
+
+def _in_improper_unit(name, v, eps):
+    from tests import synth
+    u = lambda x: np.array(x, float) / np.linalg.norm(x)
+    rot = np.degrees(np.arctan2(v[1], v[0]))
+    tilt = np.degrees(np.arccos(np.clip(v[2], -1, 1)))
+    e = np.degrees(eps)
+    wedge = lambda lo, hi, up=True: lo + e < rot < hi - e and (not up or tilt < 90 - e)
+    if name in ("ci", "cs"): return tilt < 90 - e
+    if name[0] in "cds" and name[1].isdigit():
+        n = int("".join(ch for ch in name[1:] if ch.isdigit()))
+        if name[0] == "s": return wedge(-360 / n, 360 / n)
+        if name[0] == "c": return wedge(0, 180 / n, False) if name[-1] == "v" else wedge(-180 / n, 180 / n)
+        return wedge(90, 180 / n + 90) if name[-1] == "v" else wedge(0, 180 / n)
+    if name == "td": n = [u((-0.942809, 0, 0)), u((0.471405, 0.272165, 0.7698)), u((0, 0.471405, -0.666667))]
+    elif name == "th": n = [u((-0.816496, 0, 0)), u((0.707107, 0.408248, -0.57735)), u((-0.408248, -0.707107, 0))]
+    elif name == "oh":
+        n = [u((0, -1, 1)), u((1, 1, 0)), u((-1, 1, 0))]
+        if not wedge(90, 135): return False
+    elif name in ("i1h", "i2h"):
+        A = synth.euler_matrix(0, 90.0 if name == "i1h" else 0.0, 0)
+        n = [A @ u((0, 1, 0)), A @ u((-0.4999999839058737, -0.8090170074556163, 0.3090169861701543)), A @ u((1, 0, 0))]
+    else:
+        sgn = 1.0 if name == "i3h" else -1.0
+        A = synth.euler_matrix(0, sgn * 31.7174745559, 0)
+        n = [sgn * (A @ u((0, 0, 1))), sgn * (A @ u((0.187592467856686, -0.303530987314591, -0.491123477863004))),
+             sgn * (A @ u((0.187592467856686, 0.303530987314591, -0.491123477863004))), u((0, 1, 0))]
+    return all(v @ k > eps for k in n)
+
+
+@pytest.mark.parametrize("name,order", [("ci", 2), ("cs", 2), ("c1v", 2), ("c3v", 6), ("c4v", 8), ("c1h", 2), ("c5h", 10), ("s6", 6), ("s2", 2),
+                                        ("d2v", 8), ("d3v", 12), ("d5v", 20), ("d2h", 8), ("d3h", 12), ("d6h", 24), ("td", 24), ("th", 24),
+                                        ("oh", 48), ("i1h", 120), ("i2h", 120), ("i3h", 120), ("i4h", 120)])
+def test_groups_with_improper_elements_fit_their_asymmetric_units(prog, tmp_path, name, order):
+    """as for the cubic rotation groups above: (1) generators x asymmetric unit of the reference = a fundamental domain of the
+    action d -> g d on directions; (2) the host program uses that group and that unit."""
+    G = _improper_group(name)
+    assert len(G) == order
+    rng = np.random.default_rng(5)
+    pts = rng.standard_normal((600, 3))
+    pts /= np.linalg.norm(pts, axis=1)[:, None]
+    counts = [sum(_in_improper_unit(name, g @ p, 1e-9) for g in G) for p in pts]
+    assert all(k == 1 for k in counts), (name, sorted(set(counts)))
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "5", "--sym", name,
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    M = np.loadtxt(str(tmp_path / "g_symmetry.txt")).reshape(-1, 3, 3)
+    assert len(M) == order and np.allclose(M[0], np.eye(3))
+    for m in M:
+        assert np.allclose(m @ m.T, np.eye(3), atol=1e-12)
+        assert any(np.abs(m - g).max() < 2e-6 for g in G)          # (createSymFile's axes carry 6-7 digits)
+    assert sum(np.linalg.det(m) < 0 for m in M) == order // 2
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "all.stk"), "--sampling_rate", "5", "--sym", "c1",
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    la, ra = xmipp_io.read_xmd(str(tmp_path / "all.doc"))
+    lu, ru = xmipp_io.read_xmd(str(tmp_path / "g.doc"))
+    allv = np.array([[float(x[la.index(k)]) for k in ("X", "Y", "Z")] for x in ra])
+    unit = np.array([[float(x[lu.index(k)]) for k in ("X", "Y", "Z")] for x in ru])
+    inside = np.array([_in_improper_unit(name, v, 1e-5) for v in allv])
+    keys = {tuple(np.round(v, 6)) for v in unit}
+    assert all(tuple(np.round(v, 6)) in keys for v in allv[inside])    # every interior direction was kept ...
+    assert inside.sum() <= len(unit) <= inside.sum() + 2.2 * np.sqrt(len(allv))   # ... and only the boundary besides

@@ -419,13 +419,33 @@ class SymList {
         }
         R.assign(G.begin() + 1, G.end());
     }
+    static std::vector<double> mirrorPlane(double x, double y, double z)
+    {
+        // reflection in the plane through the origin with normal (x, y, z): I - 2 n n^T (xmippCore builds it as
+        // A diag(1,1,-1) A^-1 with A turning Z onto the normal, which is the same matrix)
+        const double n = std::sqrt(x * x + y * y + z * z);
+        x /= n; y /= n; z /= n;
+        return {1 - 2 * x * x, -2 * x * y, -2 * x * z, -2 * x * y, 1 - 2 * y * y, -2 * y * z, -2 * x * z, -2 * y * z, 1 - 2 * z * z};
+    }
+    static int leadingInt(const std::string &s, size_t from, size_t &end)
+    {
+        end = from;
+        while (end < s.size() && ::isdigit((unsigned char)s[end])) ++end;
+        return end > from ? atoi(s.substr(from, end - from).c_str()) : -1;
+    }
 public:
     std::vector<std::vector<double>> R;   // 3x3 row-major, identity excluded (as SL.getMatrices)
     // Accepts what the reference's --sym takes (RFA:243-251): a point-group name or a symmetry file with
-    // `rot_axis <fold> <x> <y> <z>` lines (xmippCore SymList::readSymmetryFile). Reconstruction sums over
-    // the whole group, so only the SET of rotations matters. Built-in names: cN, dN (N-fold about Z and,
-    // for dN, a 2-fold about X -- Scipion's "dihedral X" convention for Xmipp; the dead createSymFile of
-    // sampling.cpp:1361 writes Y instead, which is the same group only for even N), t, o, i1..i4.
+    // `rot_axis <fold> <x> <y> <z>`, `mirror_plane <x> <y> <z>` and `inversion` lines (xmippCore
+    // SymList::readSymmetryFile). Only the SET of matrices matters to the callers (reconstruction sums over the
+    // group, the sampling takes neighbourhoods over it). Built-in names: cN, dN (N-fold about Z and, for dN, a
+    // 2-fold about X -- Scipion's "dihedral X" convention for Xmipp; the dead createSymFile of
+    // sampling.cpp:1361 writes Y instead, which is the same group only for even N), t, o, i1..i4, and the
+    // groups with improper elements ci, cs, cNv, cNh, sN, dNv, dNh, td, th, oh, ih (= i2h), i1h..i4h with
+    // the generators of Sampling::createSymFile (sampling.cpp:1328-1420). For those R holds matrices of
+    // determinant -1 as well; the left matrices L of xmippCore are not kept: the reference's reconstruction
+    // reads R only (reconstruct_fourier_accel.cpp:252-254) and its sampling fixtures are met with L = I
+    // (tests/test_sampling.py).
     void readSymmetryFile(const std::string &sym)
     {
         R.clear();
@@ -439,26 +459,50 @@ public:
                 std::istringstream is(line);
                 std::string kw;
                 is >> kw;
+                double x = 0, y = 0, z = 0;
                 if (kw == "rot_axis") {
                     int fold = 0;
-                    double x = 0, y = 0, z = 0;
                     if (!(is >> fold >> x >> y >> z) || fold < 2 || (x == 0 && y == 0 && z == 0))
                         REPORT_ERROR(ERR_VALUE_INCORRECT, "SymList: bad line in " + sym + ": " + line);
                     gens.push_back(rotAxis(2 * M_PI / fold, x, y, z));
-                } else
-                    REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: '" + kw + "' in " + sym + " (only proper rotations, rot_axis, are supported)");
+                } else if (kw == "mirror_plane") {
+                    if (!(is >> x >> y >> z) || (x == 0 && y == 0 && z == 0))
+                        REPORT_ERROR(ERR_VALUE_INCORRECT, "SymList: bad line in " + sym + ": " + line);
+                    gens.push_back(mirrorPlane(x, y, z));
+                } else if (kw == "inversion")
+                    gens.push_back({-1, 0, 0, 0, -1, 0, 0, 0, -1});
+                else
+                    REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: '" + kw + "' in " + sym + " (rot_axis, mirror_plane and inversion are supported)");
             }
             close(gens);
             return;
         }
         std::string s = sym;
         std::transform(s.begin(), s.end(), s.begin(), ::tolower);
-        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd') && std::all_of(s.begin() + 1, s.end(), ::isdigit)) {
-            const int n = atoi(s.c_str() + 1);
-            if (n < 1) REPORT_ERROR(ERR_ARG_INCORRECT, "SymList: bad symmetry " + sym);
+        const std::vector<double> inversion = {-1, 0, 0, 0, -1, 0, 0, 0, -1};
+        if (s == "ci") { close({inversion}); return; }
+        if (s == "cs") { close({mirrorPlane(0, 0, 1)}); return; }
+        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd' || s[0] == 's') && ::isdigit((unsigned char)s[1])) {
+            size_t end;
+            const int n = leadingInt(s, 1, end);
+            const std::string tail = s.substr(end);
+            if (n < 1 || !(tail.empty() || ((tail == "v" || tail == "h") && s[0] != 's')) || (s[0] == 's' && (n % 2 || !tail.empty())))
+                REPORT_ERROR(ERR_ARG_INCORRECT, "SymList: bad symmetry " + sym);
             std::vector<std::vector<double>> gens;
-            if (n > 1) gens.push_back(rotAxis(2 * M_PI / n, 0, 0, 1));
-            if (s[0] == 'd') gens.push_back(rotAxis(M_PI, 1, 0, 0));
+            if (s[0] == 's') {           // sampling.cpp:1347-1353: the N/2-fold axis and the inversion
+                if (n / 2 > 1) gens.push_back(rotAxis(2 * M_PI / (n / 2), 0, 0, 1));
+                gens.push_back(inversion);
+            } else {
+                if (n > 1) gens.push_back(rotAxis(2 * M_PI / n, 0, 0, 1));
+                if (s[0] == 'd') gens.push_back(rotAxis(M_PI, 1, 0, 0));
+                if (s[0] == 'c' && tail == "v") gens.push_back(mirrorPlane(0, 1, 0));
+                if (s[0] == 'c' && tail == "h") gens.push_back(mirrorPlane(0, 0, 1));
+                // dNv / dNh: with the 2-fold on X the mirror that makes removeRedundantPoints' wedges
+                // (sampling.cpp:780-806) fundamental domains for every N is x = 0 / z = 0 (for even N the
+                // same groups as createSymFile's, sampling.cpp:1362-1377; checked numerically in the tests)
+                if (s[0] == 'd' && tail == "v") gens.push_back(mirrorPlane(1, 0, 0));
+                if (s[0] == 'd' && tail == "h") gens.push_back(mirrorPlane(0, 0, 1));
+            }
             close(gens);
             return;
         }
@@ -469,10 +513,17 @@ public:
         // (checked numerically, tests/test_sampling.py).
         const double phi = (1 + std::sqrt(5.0)) / 2;
         if (s == "t") { close({rotAxis(2 * M_PI / 3, 0, 0, 1), rotAxis(M_PI, 0, std::sqrt(2.0 / 3.0), std::sqrt(1.0 / 3.0))}); return; }
+        if (s == "td") { close({rotAxis(2 * M_PI / 3, 0, 0, 1), rotAxis(M_PI, 0, std::sqrt(2.0 / 3.0), std::sqrt(1.0 / 3.0)), mirrorPlane(std::sqrt(2.0), std::sqrt(6.0), 0)}); return; }
+        if (s == "th") { close({rotAxis(2 * M_PI / 3, 0, 0, 1), rotAxis(M_PI, 0, -std::sqrt(2.0 / 3.0), -std::sqrt(1.0 / 3.0)), inversion}); return; }
         if (s == "o") { close({rotAxis(2 * M_PI / 3, 1, 1, 1), rotAxis(M_PI / 2, 0, 0, 1)}); return; }
-        if (s == "i" || s == "i1" || s == "i2" || s == "i3" || s == "i4") {
-            close({rotAxis(M_PI, 0, 0, 1), rotAxis(2 * M_PI / 5, -phi, -1, 0), rotAxis(2 * M_PI / 3, -1, -phi * phi, 0)});
-            const double tilt = s == "i1" ? 90. : s == "i3" ? 31.7174745559 : s == "i4" ? -31.7174745559 : 0.;
+        if (s == "oh") { close({rotAxis(2 * M_PI / 3, 1, 1, 1), rotAxis(M_PI / 2, 0, 0, 1), mirrorPlane(0, 1, 1)}); return; }
+        const bool ih = s == "ih" || s == "i1h" || s == "i2h" || s == "i3h" || s == "i4h";
+        if (s == "i" || s == "i1" || s == "i2" || s == "i3" || s == "i4" || ih) {
+            std::vector<std::vector<double>> gens = {rotAxis(M_PI, 0, 0, 1), rotAxis(2 * M_PI / 5, -phi, -1, 0), rotAxis(2 * M_PI / 3, -1, -phi * phi, 0)};
+            if (ih) gens.push_back(mirrorPlane(1, 0, 0));
+            close(gens);
+            const char o = s.size() > 1 && ::isdigit((unsigned char)s[1]) ? s[1] : '2';
+            const double tilt = o == '1' ? 90. : o == '3' ? 31.7174745559 : o == '4' ? -31.7174745559 : 0.;
             if (tilt != 0.) {
                 // Euler_angles2matrix(0, tilt, 0): rotation about Y
                 const double b = tilt * M_PI / 180., cb = std::cos(b), sb = std::sin(b);
@@ -481,8 +532,16 @@ public:
             }
             return;
         }
-        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is neither a readable symmetry file nor one of cN, dN, t, o, "
-                     "i1..i4 (groups with mirrors or inversions are not available); write the group's rot_axis lines to a file and pass that");
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "SymList: symmetry '" + sym + "' is neither a readable symmetry file nor one of cN, cNv, cNh, ci, cs, sN, "
+                     "dN, dNv, dNh, t, td, th, o, oh, i1..i4, ih, i1h..i4h; write the group's rot_axis / mirror_plane / inversion lines to a file and pass that");
+    }
+    bool hasImproper() const
+    {
+        for (const auto &g : R) {
+            const double det = g[0] * (g[4] * g[8] - g[5] * g[7]) - g[1] * (g[3] * g[8] - g[5] * g[6]) + g[2] * (g[3] * g[7] - g[4] * g[6]);
+            if (det < 0) return true;
+        }
+        return false;
     }
     int symsNo() const { return (int)R.size(); }
 };

@@ -1004,20 +1004,26 @@ public:
         batch = std::max(1, (int)getIntParam("--batch"));
         only_sampling = checkParam("--only_create_sampling");
     }
+    // the point-group names of xmippCore's SymList::isSymmetryGroup, as the families of SamplingGen::removeRedundantPoints
     static void parseGroup(const std::string &sym, std::string &family, int &order)
     {
         std::string s = sym;
         std::transform(s.begin(), s.end(), s.begin(), ::tolower);
         order = 1;
-        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd') && std::all_of(s.begin() + 1, s.end(), ::isdigit) && atoi(s.c_str() + 1) >= 1) {
-            family = std::string(1, s[0]);
-            order = atoi(s.c_str() + 1);
-            return;
+        if (s.size() >= 2 && (s[0] == 'c' || s[0] == 'd' || s[0] == 's') && ::isdigit((unsigned char)s[1])) {
+            size_t end = 1;
+            while (end < s.size() && ::isdigit((unsigned char)s[end])) ++end;
+            order = atoi(s.substr(1, end - 1).c_str());
+            const std::string tail = s.substr(end);
+            const bool ok = order >= 1 && (tail.empty() || ((tail == "v" || tail == "h") && s[0] != 's')) && (s[0] != 's' || order % 2 == 0);
+            if (ok) { family = std::string(1, s[0]) + tail; return; }
         }
-        if (s == "t" || s == "o" || s == "i1" || s == "i2" || s == "i3" || s == "i4") { family = s; return; }
+        for (const char *g : {"ci", "cs", "t", "td", "th", "o", "oh", "i1", "i2", "i3", "i4", "i1h", "i2h", "i3h", "i4h"})
+            if (s == g) { family = s; return; }
         if (s == "i") { family = "i2"; return; }
-        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "symmetry '" + sym + "': the sampling of the asymmetric unit is implemented for cN, dN, t, o and "
-                     "i1..i4 (groups with mirrors or inversions are not available)");
+        if (s == "ih") { family = "i2h"; return; }
+        REPORT_ERROR(ERR_NOT_IMPLEMENTED, "symmetry '" + sym + "': the sampling of the asymmetric unit is implemented for cN, cNv, cNh, ci, cs, sN, dN, dNv, "
+                     "dNh, t, td, th, o, oh, i1..i4, ih and i1h..i4h (i5 and i5h are not implemented in the reference either, sampling.cpp:1072, 1216)");
     }
     void run() override
     {

@@ -3,8 +3,8 @@
 // (Baumgardner 1995), reduction to the asymmetric unit, neighbourhoods of the experimental images.
 //
 // Restates libraries/data/sampling.cpp: constructor vertices (L90-101), setSampling (L121-132),
-// computeSamplingPoints (L155-584), fillEdge / fillDistance (L606-676), removeRedundantPoints for the
-// cyclic and dihedral groups (L702-712, L766-778), fillLRRepository (L2216-2234),
+// computeSamplingPoints (L155-584), fillEdge / fillDistance (L606-676), removeRedundantPoints
+// (L702-1216, every group it implements), fillLRRepository (L2216-2234),
 // fillExpDataProjectionDirectionByLR (L2256-2290), removePointsFarAwayFromExperimentalData (L1932-1958),
 // computeNeighbors (L1715-1860), createAsymUnitFile (L1440-1488), saveSamplingFile (L1495-1583).
 // Pinned by the reference's own fixtures (resources/test/sampling/*.xmd, used by
@@ -138,8 +138,9 @@ struct SamplingGen {
         numberSamplesAsymmetricUnit = sampling_points_vector.size();
     }
 
-    // asymmetric units (removeRedundantPoints): cN (L702-712), dN (L766-778), T (L808-834), O (L890-917),
-    // I2 (L946-975), I1 / I3 / I4 as turned copies (L976-1069). group: "c"/"d" + order, "t", "o", "i1".."i4"
+    // asymmetric units (removeRedundantPoints, sampling.cpp:702-1216): a wedge in (rot, tilt) and / or half
+    // spaces through the origin. family: "c" "cv" "ch" "s" "d" "dv" "dh" (+ order), "ci" "cs", "t" "td" "th",
+    // "o" "oh", "i1".."i4", "i1h".."i4h"
     void removeRedundantPoints(const std::string &group, int order)
     {
         no_redundant_sampling_points_vector.clear();
@@ -150,32 +151,52 @@ struct SamplingGen {
             const double b = tiltDeg * M_PI / 180., cb = std::cos(b), sb = std::sin(b);
             return Vec3{cb * v[0] - sb * v[2], v[1], sb * v[0] + cb * v[2]};
         };
-        Vec3 n1{}, n2{}, n3{};
-        double sign = 1;
-        if (group == "t") { n1 = unit({-0.942809, 0., 0.}); n2 = unit({0.471405, 0.272165, 0.7698}); n3 = unit({0.471404, 0.816497, 0.}); }
-        else if (group == "o") { n1 = unit({0., -1., 1.}); n2 = unit({1., 1., 0.}); n3 = unit({-1., 1., 0.}); }
-        else if (group == "i1" || group == "i2" || group == "i3") {
+        std::vector<Vec3> halfSpaces;                       // kept: dot(v, n) >= 0 for every n
+        double rotLo = -1e9, rotHi = 1e9, tiltHi = 1e9;     // kept: rotLo <= rot <= rotHi and tilt <= tiltHi ...
+        bool orRotZero = false;                             // ... or rot == 0 (the poles; t and o, L820, L903)
+        const Vec3 i2a = {0., 1., 0.}, i2b = {-0.4999999839058737, -0.8090170074556163, 0.3090169861701543},
+                   i2c = {0.4999999839058737, -0.8090170074556163, 0.3090169861701543};
+        const Vec3 i4a = {0., 0., 1.}, i4b = {0.187592467856686, -0.303530987314591, -0.491123477863004},
+                   i4c = {0.187592467856686, 0.303530987314591, -0.491123477863004};
+        auto neg = [](const Vec3 &v) { return Vec3{-v[0], -v[1], -v[2]}; };
+        if (group == "c") { rotLo = -180. / order; rotHi = 180. / order; }
+        else if (group == "ci" || group == "cs") tiltHi = 90.;                                  // L714-725
+        else if (group == "cv") { rotLo = 0.; rotHi = 180. / order; }                           // L726-737
+        else if (group == "ch") { rotLo = -180. / order; rotHi = 180. / order; tiltHi = 90.; }  // L738-751
+        else if (group == "s") { rotLo = -360. / order; rotHi = 360. / order; tiltHi = 90.; }   // L752-765
+        else if (group == "d") { rotLo = -180. / order + 90.; rotHi = 180. / order + 90.; tiltHi = 90.; }
+        else if (group == "dv") { rotLo = 90.; rotHi = 180. / order + 90.; tiltHi = 90.; }      // L780-793
+        else if (group == "dh") { rotLo = 0.; rotHi = 180. / order; tiltHi = 90.; }             // L794-807
+        else if (group == "t") {
+            halfSpaces = {unit({-0.942809, 0., 0.}), unit({0.471405, 0.272165, 0.7698}), unit({0.471404, 0.816497, 0.})};
+            rotLo = 90.; rotHi = 150.; orRotZero = true;
+        } else if (group == "td")                                                               // L836-863
+            halfSpaces = {unit({-0.942809, 0., 0.}), unit({0.471405, 0.272165, 0.7698}), unit({0., 0.471405, -0.666667})};
+        else if (group == "th")                                                                 // L864-891
+            halfSpaces = {unit({-0.816496, 0., 0.}), unit({0.707107, 0.408248, -0.57735}), unit({-0.408248, -0.707107, 0.})};
+        else if (group == "o" || group == "oh") {
+            halfSpaces = {unit({0., -1., 1.}), unit({1., 1., 0.}), unit({-1., 1., 0.})};
+            if (group == "o") { rotLo = 45.; rotHi = 135.; tiltHi = 90.; orRotZero = true; }
+            else { rotLo = 90.; rotHi = 135.; tiltHi = 90.; }                                   // L921-945
+        } else if (group == "i1" || group == "i2" || group == "i3") {
             const double tilt = group == "i1" ? 90. : group == "i3" ? 31.7174745559 : 0.;
-            n1 = unit(turnY(tilt, {0., 1., 0.}));
-            n2 = unit(turnY(tilt, {-0.4999999839058737, -0.8090170074556163, 0.3090169861701543}));
-            n3 = unit(turnY(tilt, {0.4999999839058737, -0.8090170074556163, 0.3090169861701543}));
-        } else if (group == "i4") {
-            n1 = unit(turnY(-31.7174745559, {0., 0., 1.}));
-            n2 = unit(turnY(-31.7174745559, {0.187592467856686, -0.303530987314591, -0.491123477863004}));
-            n3 = unit(turnY(-31.7174745559, {0.187592467856686, 0.303530987314591, -0.491123477863004}));
-            sign = -1;
-        }
+            halfSpaces = {unit(turnY(tilt, i2a)), unit(turnY(tilt, i2b)), unit(turnY(tilt, i2c))};
+        } else if (group == "i4")
+            halfSpaces = {neg(unit(turnY(-31.7174745559, i4a))), neg(unit(turnY(-31.7174745559, i4b))), neg(unit(turnY(-31.7174745559, i4c)))};
+        else if (group == "i2h" || group == "i1h") {                                            // L1077-1140
+            const double tilt = group == "i1h" ? 90. : 0.;
+            halfSpaces = {unit(turnY(tilt, i2a)), unit(turnY(tilt, i2b)), unit(turnY(tilt, {1., 0., 0.}))};
+        } else if (group == "i3h")                                                              // L1141-1178
+            halfSpaces = {unit(turnY(31.7174745559, i4b)), unit(turnY(31.7174745559, i4c)), unit(turnY(31.7174745559, i4a)), {0., 1., 0.}};
+        else if (group == "i4h")                                                                // L1179-1215
+            halfSpaces = {neg(unit(turnY(-31.7174745559, i4b))), neg(unit(turnY(-31.7174745559, i4c))), neg(unit(turnY(-31.7174745559, i4a))), {0., 1., 0.}};
+        else
+            REPORT_ERROR(ERR_ARG_INCORRECT, "removeRedundantPoints: unknown point group family '" + group + "'");
         for (size_t i = 0; i < sampling_points_angles.size(); i++) {
             const double rot = sampling_points_angles[i][0], tilt = sampling_points_angles[i][1];
             const Vec3 &v = sampling_points_vector[i];
-            bool keep;
-            if (group == "c") keep = rot >= (-180. / order) && rot <= (180. / order);
-            else if (group == "d") keep = rot >= -180. / order + 90. && rot <= 180. / order + 90. && tilt <= 90.;
-            else {
-                keep = sign * dot(v, n1) >= 0 && sign * dot(v, n2) >= 0 && sign * dot(v, n3) >= 0;
-                if (group == "t") keep = keep && ((rot >= 90. && rot <= 150.) || rot == 0);
-                if (group == "o") keep = keep && ((rot >= 45. && rot <= 135. && tilt <= 90.) || rot == 0.);
-            }
+            bool keep = (rot >= rotLo && rot <= rotHi && tilt <= tiltHi) || (orRotZero && rot == 0.);
+            for (const Vec3 &n : halfSpaces) keep = keep && dot(v, n) >= 0;
             if (keep) {
                 no_redundant_sampling_points_angles.push_back(sampling_points_angles[i]);
                 no_redundant_sampling_points_vector.push_back(sampling_points_vector[i]);
@@ -208,7 +229,7 @@ struct SamplingGen {
             std::string name;
             DFi.getValue("image", name, id);
             exp_data_fileNames.push_back(name);
-            // L * (d^T R)^T with L = I for proper rotations
+            // L * (d^T R)^T with L = I (see SymList: what the reference's i3h fixtures are met with)
             for (const auto &R : R_repository)
                 exp_data_projection_direction_by_L_R.push_back({d[0] * R[0] + d[1] * R[3] + d[2] * R[6], d[0] * R[1] + d[1] * R[4] + d[2] * R[7],
                                                                 d[0] * R[2] + d[1] * R[5] + d[2] * R[8]});
