@@ -377,3 +377,32 @@ def test_groups_with_improper_elements_fit_their_asymmetric_units(prog, tmp_path
     keys = {tuple(np.round(v, 6)) for v in unit}
     assert all(tuple(np.round(v, 6)) in keys for v in allv[inside])    # every interior direction was kept ...
     assert inside.sum() <= len(unit) <= inside.sum() + 2.2 * np.sqrt(len(allv))   # ... and only the boundary besides
+
+
+@pytest.mark.parametrize("sym", ["c1", "d3", "i3h"])
+def test_closer_sampling_points(prog, tmp_path, sym):
+    """--closer_sampling_points (findClosestSamplingPoint, sampling.cpp:1991-2098): per experimental image the direction of the
+    asymmetric unit closest to any of its symmetry mates.  Checked by brute force over the program's own direction list and group."""
+    r = subprocess.run([prog, "-i", "none.vol", "-o", str(tmp_path / "g.stk"), "--sampling_rate", "3", "--sym", sym,
+                        "--experimental_images", os.path.join(GOLD, "experimental_images.xmd"), "--closer_sampling_points",
+                        "--only_create_sampling"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from tests import synth
+    l, rows = xmipp_io.read_xmd(str(tmp_path / "g_closest_sampling_points.doc"))
+    ld, rd = xmipp_io.read_xmd(str(tmp_path / "g.doc"))
+    le, re_ = xmipp_io.read_xmd(os.path.join(GOLD, "experimental_images.xmd"))
+    dirs = np.array([[float(x[ld.index(k)]) for k in ("X", "Y", "Z")] for x in rd])
+    M = np.loadtxt(str(tmp_path / "g_symmetry.txt")).reshape(-1, 3, 3)
+    assert len(rows) == len(re_) == 3
+    for row, e in zip(rows, re_):
+        assert row[l.index("image")] == e[le.index("image")]
+        d = synth.euler_matrix(float(e[le.index("angleRot")]), float(e[le.index("angleTilt")]), 0.0)[2]
+        mates = np.array([m.T @ d for m in M])
+        dots = mates @ dirs.T                         # [mate, direction]
+        w = int(row[l.index("ref")])
+        assert dots[:, w].max() >= dots.max() - 1e-6   # (the docfile's unit vectors carry 6 decimals)
+        assert int(row[l.index("neighbor")]) == w
+        got = [float(row[l.index(k)]) for k in ("angleRot", "angleTilt", "anglePsi")]
+        exp = [float(rd[w][ld.index(k)]) for k in ("angleRot", "angleTilt", "anglePsi")]
+        assert np.allclose(got, exp, atol=2e-6)
+        assert np.degrees(np.arccos(min(1.0, dots.max()))) < 2.2        # a 3-degree sampling: the closest one is within ~2

@@ -1029,7 +1029,7 @@ public:
     {
         // angular_project_library.cpp:249-397
         if (perturb_projection_vector != 0) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--perturb is not available (it is seeded with time() in the reference)");
-        if (compute_closer_sampling_point_bool) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--closer_sampling_points is not available yet");
+        if (compute_closer_sampling_point_bool && FnexperimentalImages.empty()) REPORT_ERROR(ERR_ARG_MISSING, "--closer_sampling_points needs --experimental_images");
         if (!fn_groups.empty() && FnexperimentalImages.empty()) REPORT_ERROR(ERR_ARG_MISSING, "--groups needs --experimental_images");
         std::string fam, famN;
         int order, orderN;
@@ -1047,6 +1047,7 @@ public:
             DFi.read(FnexperimentalImages);
             mysampling.fillExpDataProjectionDirectionByLR(DFi);
             if (remove_points_far_away_from_experimental_data_bool) mysampling.removePointsFarAwayFromExperimentalData();
+            if (compute_closer_sampling_point_bool) mysampling.findClosestSamplingPoint(DFi, output_file_root);
         }
         mysampling.createAsymUnitFile(output_file_root);
         if (compute_neighbors_bool) {
@@ -1095,6 +1096,7 @@ public:
                 SFBlock.read(block + "@" + fn_exp);
                 if (SFBlock.size() > 0) {
                     mysampling.fillExpDataProjectionDirectionByLR(SFBlock);
+                    if (compute_closer_sampling_point_bool) mysampling.findClosestSamplingPoint(SFBlock, root);
                     if (compute_neighbors_bool) {
                         mysampling.computeNeighbors(only_winner);
                         mysampling.saveSamplingFile(root, false);

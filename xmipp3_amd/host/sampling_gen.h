@@ -6,7 +6,7 @@
 // computeSamplingPoints (L155-584), fillEdge / fillDistance (L606-676), removeRedundantPoints
 // (L702-1216, every group it implements), fillLRRepository (L2216-2234),
 // fillExpDataProjectionDirectionByLR (L2256-2290), removePointsFarAwayFromExperimentalData (L1932-1958),
-// computeNeighbors (L1715-1860), createAsymUnitFile (L1440-1488), saveSamplingFile (L1495-1583).
+// computeNeighbors (L1715-1860), findClosestSamplingPoint (L1991-2098), createAsymUnitFile (L1440-1488), saveSamplingFile (L1495-1583).
 // Pinned by the reference's own fixtures (resources/test/sampling/*.xmd, used by
 // function_tests/test_sampling_main.cpp:128-179), copied as data under tests/golden/sampling/.
 #ifndef XH_SAMPLING_GEN_H
@@ -287,6 +287,38 @@ struct SamplingGen {
             }
             my_neighbors.push_back(aux);
         }
+    }
+
+    // findClosestSamplingPoint (sampling.cpp:1991-2098): for every experimental image the direction of the asymmetric unit
+    // closest to any of its symmetry mates (first maximum of the dot product) -> <root>_closest_sampling_points.doc.  The
+    // reference also stores the image's original angles and shifts as a per-row star comment, which carries no data a reader
+    // of the file sees; it is left out.
+    void findClosestSamplingPoint(const MetaDataVec &DFi, const std::string &root) const
+    {
+        MetaDataVec DFo;
+        DFo.comment = "Original rot, tilt, psi, Xoff, Yoff are stored as comments";
+        const size_t nR = R_repository.size();
+        size_t row = 0;
+        for (size_t i = 0; i < exp_data_projection_direction_by_L_R.size(); ++row) {
+            double best = -2;
+            long winner = -1;
+            for (size_t k = 0; k < nR; k++, i++)
+                for (size_t j = 0; j < no_redundant_sampling_points_vector.size(); j++) {
+                    const double d = dot(exp_data_projection_direction_by_L_R[i], no_redundant_sampling_points_vector[j]);
+                    if (d > best) { best = d; winner = (long)j; }
+                }
+            if (winner < 0) REPORT_ERROR(ERR_VALUE_INCORRECT, "findClosestSamplingPoint: no projection directions");
+            std::string fnImg;
+            DFi.getValue("image", fnImg, row);
+            const size_t id = DFo.addObject();
+            DFo.setValue("image", fnImg, id);
+            DFo.setValue("ref", winner, id);
+            DFo.setValue("neighbor", (long)no_redundant_sampling_points_index[winner], id);
+            DFo.setValue("angleRot", no_redundant_sampling_points_angles[winner][0], id);
+            DFo.setValue("angleTilt", no_redundant_sampling_points_angles[winner][1], id);
+            DFo.setValue("anglePsi", no_redundant_sampling_points_angles[winner][2], id);
+        }
+        if (!root.empty()) DFo.write(root + "_closest_sampling_points.doc");
     }
 
     void createAsymUnitFile(const std::string &root) const
