@@ -262,7 +262,9 @@ __global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ ang
 // W: footprint width (4 for a blob radius below 2, 6 below 3). FAST: processVoxel (RFA:595-625), nearest pixel, one voxel per row.
 // ZD: depth of a unit in z (4 or 8); NW: waves per workgroup (= per CU: the LDS budget admits one workgroup).
 // ABL: ablation switch for profiling builds (tools/ab_grid.sh); 0 in the product: 1 no wait for the patch copy, 2 no dense pass,
-// 3 no patch copy, 5 histogram of items per visit into tempV, 6 = 2 + 3, 7 = 6 without the sparse pass.
+// 3 no patch copy, 5 histogram of items per visit into tempV, 6 = 2 + 3, 7 = 6 without the sparse pass, 8 every patch copied
+// from the first megabyte of the records (the copy instructions without their HBM traffic), 9 every tap reads the patch's first
+// record, 10 every tap reads the table's first entry, 11 = 9 + 10 (the LDS reads without their bank conflicts).
 template <int W, bool FAST, int ZD, int NW, int ABL>
 __global__ void __launch_bounds__(64 * NW, (NW + 3) / 4)
 k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const float *__restrict__ blobTable,
@@ -494,7 +496,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                 }
                 // ---- the patch copy (origin found in the cull phase). The patch buffer is free: the previous dense pass has
                 // consumed its reads.
-                if constexpr (ABL != 3 && ABL != 6 && ABL != 7) xg_dma_patch<NDMA, C::PATCH_BYTES / 16>(pk + cell, dOff, patchBase, lane);
+                if constexpr (ABL != 3 && ABL != 6 && ABL != 7) xg_dma_patch<NDMA, C::PATCH_BYTES / 16>(pk + (ABL == 8 ? (cell & 0xffffu) : cell), dOff, patchBase, lane);
                 // ---- sparse pass (RFA:631-653 and the reach of the footprint), two z at a time
                 const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
@@ -600,8 +602,13 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                                 // reads and the wave then waits for all of them)
                                 xg_v4f q[NT];
 #pragma unroll
-                                for (int t = 0; t < NT; ++t)
+                                for (int t = 0; t < NT; ++t) {
+                                    if constexpr (ABL == 9 || ABL == 11) {      // profiling: every lane reads the patch's first record
+                                        asm volatile("" :: "v"(tap));
+                                        q[t] = ((const __attribute__((address_space(3))) xg_v4f *)(uintptr_t)patchBase)[0];
+                                    } else
                                     q[t] = tap[(h * NR + (t >> 2)) * PW + (t & 3)];
+                                }
                                 __builtin_amdgcn_sched_barrier(0);
                                 // table entry (int)(d2 * iDelta + 0.5) (RFA:682); a tap beyond the blob (d2 > r^2, RFA:679) reads a zero entry
                                 int aux[NT];
@@ -617,7 +624,11 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                                 }
                                 float wB[NT];
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) wB[t] = sBlob[aux[t]];
+                                for (int t = 0; t < NT; ++t) {
+                                    if constexpr (ABL == 10 || ABL == 11) { asm volatile("" :: "v"(aux[t])); wB[t] = sBlob[0]; }      // profiling: one table entry
+                                    else
+                                    wB[t] = sBlob[aux[t]];
+                                }
 #pragma unroll
                                 for (int t = 0; t < NT; ++t) {
                                     const xg_v2f w2 = {wB[t], wB[t]};
