@@ -378,8 +378,26 @@ def test_cli_symmetry_names_and_files(bins, tmp_path, oracle):
         vo[tag] = xmipp_io.read_volume(str(tmp_path / f"{tag}.vol"))
     assert np.abs(vo["oname"] - vo["ofile"]).max() <= 1e-4 * np.abs(vo["oname"]).max()   # the file has 7-digit axes
     assert np.abs(vo["oname"] - vols["name"]).max() > 1e-2 * np.abs(vo["oname"]).max()  # and it is not d2
+    # a group with a mirror plane: the reference multiplies by R whatever its determinant (reconstruct_fourier_accel.cpp:252-254,
+    # 953-956).  c2h by name == rot_axis + mirror_plane lines == the oracle over {I, Rz(180), mirror z, inversion}
+    (tmp_path / "c2h.sym").write_text("rot_axis 2 0 0 1\nmirror_plane 0 0 -1\n")
+    vm = {}
+    for tag, sym in (("mname", "c2h"), ("mfile", str(tmp_path / "c2h.sym"))):
+        r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / f"{tag}.vol"),
+                  "--sym", sym])
+        assert r.returncode == 0, r.stderr
+        vm[tag] = xmipp_io.read_volume(str(tmp_path / f"{tag}.vol"))
+    assert np.abs(vm["mname"] - vm["mfile"]).max() <= 2e-6 * np.abs(vm["mname"]).max()
+    rf = oracle.RF(D)
+    for i in range(n):
+        f = rf.prepare_image(imgs[i])
+        for R in (np.eye(3), np.diag([-1.0, -1.0, 1.0]), np.diag([1.0, 1.0, -1.0]), -np.eye(3)):
+            rf.insert(f, synth.euler_matrix(*ang6[i]).T, R=R)
+    rf.mirror_and_crop()
+    expm = rf.finish()
+    assert np.abs(vm["mname"] - expm).max() <= 1e-4 * np.abs(expm).max()
     # an unknown name must fail loudly, not reconstruct without symmetry
-    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i3h"])
+    r = _run([os.path.join(bins, "xmipp_reconstruct_fourier_accel"), "-i", str(tmp_path / "in.xmd"), "-o", str(tmp_path / "x.vol"), "--sym", "i5h"])
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr
 
 

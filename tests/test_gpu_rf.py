@@ -204,6 +204,13 @@ def test_insert_many(gpu, oracle, data32, mode):
     gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
     # identical voxel sets; sums differ only by float summation order
     assert ((ew != 0) == (gw != 0)).all()
+    if mode == "sym_improper":
+        # four placements per image: the centre voxel collects ~1100 float addends (every projection crosses it), where the order of
+        # summation shows (8e-6 of the largest weight, the same with four proper rotations: tools/diag_sym.py); 2e-6 everywhere else
+        dw, dv = np.abs(gw - ew), np.abs(gv - ev).max(-1) if gv.ndim == 4 else np.abs(gv - ev)
+        assert dw.max() <= 2e-5 * np.abs(ew).max() and (dw > 2e-6 * np.abs(ew).max()).sum() <= 2
+        assert dv.max() <= 2e-5 * np.abs(ev).max() and (dv > 2e-6 * np.abs(ev).max()).sum() <= 2
+        return
     assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
     assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
 
