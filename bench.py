@@ -59,6 +59,8 @@ def parse(argv=None):
                     help="full / match / grid: the refine iteration or one half of it; flexalign: BASELINE config 5, one K3 movie per step "
                          "(global + local alignment, warp + sum), movies streamed from page-locked host memory")
     ap.add_argument("--movie", default="40x4092x5760", help="flexalign mode: frames x rows x columns of a movie")
+    ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
+                    "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
     ap.add_argument("--tr-chunk-mb", type=int, default=0, help="S6 scratch per pass in MB (0: library default)")
@@ -232,86 +234,135 @@ def main_flexalign(args):
     nuniq = 2
     host, drifts = zip(*[make_movie(11 + 2 * rank + u) for u in range(nuniq)])
     torch.cuda.empty_cache()
-    fa = xa.FlexAlign(ctx, Y, X, Ts, max_res)
-    fa.set_option("prefilter_ahead", 1)        # the warp's prefilter of the frames runs while the host fits the spline
-    dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
-    total = torch.zeros((Y, X), device=dev)
-    h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-    copy_stream = torch.cuda.Stream(device=dev)
-    ready = [torch.cuda.Event(), torch.cuda.Event()]
-    done = [torch.cuda.Event(), torch.cuda.Event()]
-    timers = {"global_alignment": [], "local_alignment": [], "warp_and_sum": []}
-    results = []
+    import threading
+    nlanes = max(1, args.fa_lanes)
 
-    def timed(name, record, fn):
-        if not record:
-            return fn()
-        t = ctx.timer()
-        t.start()
-        r = fn()
-        t.stop()
-        timers[name].append(t)
-        return r
+    class Lane:
+        """one movie in flight: a stream, a library context bound to it, a FlexAlign handle, two device buffers (the copy of this lane's
+        next movie flies under the alignment of its current one) and the aligned sum"""
+        def __init__(self, idx):
+            self.idx = idx
+            self.stream = torch.cuda.current_stream(dev) if idx == 0 else torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self.stream):
+                self.ctx = ctx if idx == 0 else xa.Context(local)
+                self.fa = xa.FlexAlign(self.ctx, Y, X, Ts, max_res)
+                self.fa.set_option("prefilter_ahead", 1)        # the warp's prefilter of the frames runs while the host fits the spline
+                self.dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
+                self.total = torch.zeros((Y, X), device=dev)
+            self.h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self.copy_stream = torch.cuda.Stream(device=dev)
+            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.timers = {"global_alignment": [], "local_alignment": [], "warp_and_sum": []}
+            self.results = []
+            self.error = None
 
-    def fetch(k):
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(done[k & 1])
-            dbuf[k & 1].copy_(host[k % nuniq], non_blocking=True)
-            ready[k & 1].record(copy_stream)
+        def timed(self, name, record, fn):
+            if not record:
+                return fn()
+            t = self.ctx.timer()
+            t.start()
+            r = fn()
+            t.stop()
+            self.timers[name].append(t)
+            return r
 
-    def align(frames, record, slot):
-        gl = timed("global_alignment", record, lambda: fa.global_alignment(frames, max_shift))
-        loc = timed("local_alignment", record, lambda: fa.local_alignment(frames, gl["shiftX"], gl["shiftY"], gl["ref"], max_shift, patches, psize, 3, cp))
+        def fetch(self, j, movie):
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.done[j & 1])
+                self.dbuf[j & 1].copy_(host[movie % nuniq], non_blocking=True)
+                self.ready[j & 1].record(self.copy_stream)
 
-        def warp():
-            total.zero_()
-            fa.apply_bspline_frames(frames, loc["coeffsX"], loc["coeffsY"], cp, total=total)
-        timed("warp_and_sum", record, warp)
-        h_avg[slot].copy_(total, non_blocking=True)              # the aligned micrograph goes back to the host
-        return gl, loc
+        def align(self, frames, record, slot):
+            fa_ = self.fa
+            gl = self.timed("global_alignment", record, lambda: fa_.global_alignment(frames, max_shift))
+            loc = self.timed("local_alignment", record, lambda: fa_.local_alignment(frames, gl["shiftX"], gl["shiftY"], gl["ref"], max_shift, patches, psize, 3, cp))
+
+            def warp():
+                self.total.zero_()
+                fa_.apply_bspline_frames(frames, loc["coeffsX"], loc["coeffsY"], cp, total=self.total)
+            self.timed("warp_and_sum", record, warp)
+            self.h_avg[slot].copy_(self.total, non_blocking=True)              # the aligned micrograph goes back to the host
+            return gl, loc
+
+        def prime(self, movies):
+            for e in self.done:
+                e.record(self.stream)
+            if movies:
+                self.fetch(0, movies[0])
+
+        def run(self, movies, record):
+            # movies: the indices this lane aligns, in order
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(self.stream):
+                    for j, k in enumerate(movies):
+                        if j + 1 < len(movies):
+                            self.fetch(j + 1, movies[j + 1])
+                        self.stream.wait_event(self.ready[j & 1])
+                        r = self.align(self.dbuf[j & 1], record, j & 1)
+                        self.done[j & 1].record(self.stream)
+                        if record:
+                            self.results.append((k % nuniq, r[0]))
+            except BaseException as e:          # re-raised on the main thread
+                self.error = e
+
+    lanes = [Lane(i) for i in range(nlanes)]
+    fa = lanes[0].fa
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def streamed(nsteps, record):
-        for e in done:
-            e.record()
-        fetch(0)
+    def streamed(nsteps, record, use=None):
+        use = lanes if use is None else use
+        work = [list(range(i, nsteps, len(use))) for i in range(len(use))]
+        for ln, w in zip(use, work):
+            ln.prime(w)
         barrier()
         ta = time.perf_counter()
-        for k in range(nsteps):
-            if k + 1 < nsteps:
-                fetch(k + 1)
-            torch.cuda.current_stream().wait_event(ready[k & 1])
-            r = align(dbuf[k & 1], record, k & 1)
-            done[k & 1].record()
-            if record:
-                results.append((k % nuniq, r[0]))
+        if len(use) == 1:
+            use[0].run(work[0], record)
+        else:
+            th = [threading.Thread(target=ln.run, args=(w, record)) for ln, w in zip(use, work)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+        for ln in use:
+            if ln.error is not None:
+                raise ln.error
         barrier()
         return time.perf_counter() - ta
 
     if args.warmup:
-        streamed(args.warmup, False)
+        streamed(max(args.warmup, nlanes), False)
     elapsed = streamed(args.steps, True)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    # the same movies resident in HBM (what the host traffic costs)
+    results = [r for ln in lanes for r in ln.results]
+    stage_overlapped = {k_: float(sum(t.elapsed_ms() for ln in lanes for t in ln.timers[k_])) for k_ in lanes[0].timers}
+    # one lane alone, movies resident in HBM: what the host traffic and the second lane are worth, and the stages' own durations (the
+    # HIP-event times of the timed region include waiting for the other lane's kernels)
+    for ln in lanes:
+        ln.timers = {k_: [] for k_ in ln.timers}
+    nres = max(2, min(args.steps, 3))
     barrier()
     tr0 = time.perf_counter()
-    nres = max(2, min(args.steps, 3))
-    for k in range(nres):
-        align(dbuf[k & 1], False, k & 1)
+    with torch.cuda.stream(lanes[0].stream):
+        for k in range(nres):
+            lanes[0].align(lanes[0].dbuf[k & 1], True, k & 1)
     barrier()
     resident = nres * world / (time.perf_counter() - tr0)
+    timers = lanes[0].timers
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    stage = {k_: float(sum(t.elapsed_ms() for t in ts)) for k_, ts in timers.items()}
+    stage = {k_: float(sum(t.elapsed_ms() for t in ts)) for k_, ts in timers.items()}      # of the one-lane resident leg: nres movies
     # algorithmic bytes per movie of each stage: the global alignment reads every frame once and keeps the low-frequency columns of its
     # transform (complex, nY x (nX / 2 + 1)); the local alignment reads every patch of every frame and of the two frames averaged with it;
     # the warp reads a frame and writes (accumulates) a frame per frame
@@ -323,9 +374,9 @@ def main_flexalign(args):
             "local_alignment": "k_fa_gather + k_fa_gemm_mfma + pair windows (xh_fa_local_alignment)",
             "warp_and_sum": "k_fa_prefilter + k_fa_warp (xh_fa_apply_bspline, 40 frames)"}
     dom = max(stage, key=lambda k_: stage[k_])
-    mk = lambda k_: {"kernel": kern[k_], "bound": "hbm", "achieved": args.steps * by[k_] / (stage[k_] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": args.steps * by[k_] / (stage[k_] * 1e-3) / 1e9 / 8000.0, "traffic": None, "ms_in_timed_region": stage[k_],
-                     "avg_ms_per_movie": stage[k_] / args.steps, "algorithmic_bytes_per_movie": by[k_]}
+    mk = lambda k_: {"kernel": kern[k_], "bound": "hbm", "achieved": nres * by[k_] / (stage[k_] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": nres * by[k_] / (stage[k_] * 1e-3) / 1e9 / 8000.0, "traffic": None, "ms_one_lane_leg": stage[k_], "movies_one_lane_leg": nres,
+                     "avg_ms_per_movie": stage[k_] / nres, "algorithmic_bytes_per_movie": by[k_]}
     # physics check of the timed movies: the drift that was put in comes out of the global alignment
     err = 0.0
     for u, gl in results:
@@ -339,9 +390,14 @@ def main_flexalign(args):
                                   f"{req} px, control points {cp}, {max_res} A at {Ts} A/px", "mode": "flexalign", "movies_total": args.steps * world,
                       "unique_movies_per_gpu": nuniq,
                       "host_traffic": f"every movie ({N * Y * X * 4 / 1e9:.2f} GB of float32 frames) H2D from page-locked memory inside the timed region (two device buffers, "
-                                      "copy stream), the aligned sum D2H", "parallelism": f"movie replicas x{world}, no exchange"},
+                                      "copy stream per lane), the aligned sum D2H", "lanes_per_gpu": nlanes,
+                      "parallelism": f"movie replicas x{world}, no exchange; {nlanes} movies in flight per GPU (host threads, one stream and library handle each)"},
            "roofline": mk(dom), "roofline_other_kernels": {k_: mk(k_) for k_ in stage if k_ != dom},
-           "stage_ms": stage, "value_resident": resident, "global_shift_error_px": err}
+           "stage_ms": {k_: v / nres for k_, v in stage.items()},
+           "stage_ms_note": "per movie, HIP events of one lane alone on movies resident in HBM (the one-lane leg after the timed region); "
+                            "stage_ms_timed_region are the same events inside the timed region, per movie, where they include waiting for the other lanes' kernels",
+           "stage_ms_timed_region": {k_: v / args.steps for k_, v in stage_overlapped.items()},
+           "value_resident_one_lane": resident, "global_shift_error_px": err}
     if not args.no_cpu_baseline and world == 1:
         # the oracle's global alignment (ProgMovieAlignmentCorrelation<double>'s arithmetic, one thread) on the first 2 and the first 3 frames
         # of movie 0 at full size: T(n) = n t_frame + n (n - 1) / 2 t_pair, extrapolated to the movie's frames.  The local alignment and
