@@ -59,6 +59,8 @@ def parse(argv=None):
                     help="full / match / grid: the refine iteration or one half of it; flexalign: BASELINE config 5, one K3 movie per step "
                          "(global + local alignment, warp + sum), movies streamed from page-locked host memory")
     ap.add_argument("--movie", default="40x4092x5760", help="flexalign mode: frames x rows x columns of a movie")
+    ap.add_argument("--movie-mode", type=int, default=2, choices=[0, 1, 2, 6], help="flexalign mode: how the frames lie in host memory, as an MRC data mode: 2 float32 "
+                    "(default: 3.77 GB per K3 movie cross the link), 0 int8 / 1 int16 / 6 uint16 counts, cast to float on the device (xh_movie_frame_to_float)")
     ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
@@ -203,6 +205,8 @@ def main_flexalign(args):
 
     # ---- two synthetic movies: a smooth random field under a global drift (fast at first, settling) plus a dilation / shear that grows
     # with time, white noise per frame; generated on the device, kept in page-locked host memory
+    raw_dtype = {0: torch.int8, 1: torch.int16, 2: torch.float32, 6: torch.uint16}[args.movie_mode]
+
     def make_movie(seed):
         g = torch.Generator(device=dev).manual_seed(seed)
         base = torch.randn((Y + 128, X + 128), generator=g, device=dev)
@@ -227,6 +231,9 @@ def main_flexalign(args):
             mv[n] = torch.nn.functional.grid_sample(base[None, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
             mv[n] += 0.5 * torch.randn((Y, X), generator=g, device=dev)
             del grid, sx, sy
+        if args.movie_mode != 2:
+            # detector counts: the same frames scaled to mean 40, sigma 12 and rounded (they fit every integer mode)
+            mv = ((mv - mv.mean()) * (12.0 / mv.std()) + 40.0).round_().clamp_(0, 127).to(raw_dtype)
         hb = torch.empty(mv.shape, dtype=mv.dtype, pin_memory=True)
         hb.copy_(mv)
         del mv, base
@@ -248,6 +255,9 @@ def main_flexalign(args):
                 self.fa = xa.FlexAlign(self.ctx, Y, X, Ts, max_res)
                 self.fa.set_option("prefilter_ahead", 1)        # the warp's prefilter of the frames runs while the host fits the spline
                 self.dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
+                # frames that arrive as counts land here and are cast into dbuf by the lane's first kernel
+                self.rbuf = [torch.empty((N, Y, X), device=dev, dtype=raw_dtype) for _ in range(2)] if args.movie_mode != 2 else self.dbuf
+                self.src = host
                 self.total = torch.zeros((Y, X), device=dev)
             self.h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]
             self.copy_stream = torch.cuda.Stream(device=dev)
@@ -270,7 +280,7 @@ def main_flexalign(args):
         def fetch(self, j, movie):
             with torch.cuda.stream(self.copy_stream):
                 self.copy_stream.wait_event(self.done[j & 1])
-                self.dbuf[j & 1].copy_(host[movie % nuniq], non_blocking=True)
+                self.rbuf[j & 1].copy_(self.src[movie % nuniq], non_blocking=True)
                 self.ready[j & 1].record(self.copy_stream)
 
         def align(self, frames, record, slot):
@@ -300,6 +310,8 @@ def main_flexalign(args):
                         if j + 1 < len(movies):
                             self.fetch(j + 1, movies[j + 1])
                         self.stream.wait_event(self.ready[j & 1])
+                        if self.rbuf is not self.dbuf:
+                            xa.movie_frames_to_float(self.ctx, self.rbuf[j & 1], out=self.dbuf[j & 1])
                         r = self.align(self.dbuf[j & 1], record, j & 1)
                         self.done[j & 1].record(self.stream)
                         if record:
@@ -344,6 +356,35 @@ def main_flexalign(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     results = [r for ln in lanes for r in ln.results]
+    counts_leg = None
+    if args.movie_mode == 2 and not args.no_extra_legs:
+        # the same movies as 8-bit counts (what a K3 writes; MRC mode 0): a quarter of the bytes cross the link, the cast runs on the device
+        host8 = []
+        for hb in host:
+            d = hb.to(dev)
+            d = ((d - d.mean()) * (12.0 / d.std()) + 40.0).round_().clamp_(0, 127).to(torch.int8)
+            h8 = torch.empty(d.shape, dtype=torch.int8, pin_memory=True)
+            h8.copy_(d)
+            host8.append(h8)
+            del d
+        for ln in lanes:
+            with torch.cuda.stream(ln.stream):
+                ln.rbuf = [torch.empty((N, Y, X), device=dev, dtype=torch.int8) for _ in range(2)]
+            ln.src = host8
+            ln.results = []
+        streamed(nlanes, False)
+        e8 = streamed(args.steps, False)
+        if world > 1:
+            t = torch.tensor([e8], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e8 = t.item()
+        counts_leg = {"value": args.steps * world / e8, "unit": "movies/s", "ms_per_movie": 1e3 * e8 / args.steps, "steps": args.steps,
+                      "what": f"the same streamed steps with the frames in host memory as int8 counts (MRC mode 0, {N * Y * X / 1e9:.2f} GB per movie), "
+                              "cast to float on the device by xh_movie_frame_to_float; `--movie-mode 0` makes this the timed region"}
+        for ln in lanes:
+            ln.rbuf = ln.dbuf
+            ln.src = host
+        del host8
     stage_overlapped = {k_: float(sum(t.elapsed_ms() for ln in lanes for t in ln.timers[k_])) for k_ in lanes[0].timers}
     # one lane alone, movies resident in HBM: what the host traffic and the second lane are worth, and the stages' own durations (the
     # HIP-event times of the timed region include waiting for the other lane's kernels)
@@ -389,7 +430,7 @@ def main_flexalign(args):
            "config": {"workload": f"FlexAlign movie alignment, {N} frames of {Y}x{X} (BASELINE config 5), patch cross-correlation path: {patches[0]}x{patches[1]} patches of "
                                   f"{req} px, control points {cp}, {max_res} A at {Ts} A/px", "mode": "flexalign", "movies_total": args.steps * world,
                       "unique_movies_per_gpu": nuniq,
-                      "host_traffic": f"every movie ({N * Y * X * 4 / 1e9:.2f} GB of float32 frames) H2D from page-locked memory inside the timed region (two device buffers, "
+                      "host_traffic": f"every movie ({N * Y * X * host[0].element_size() / 1e9:.2f} GB of {str(raw_dtype).replace('torch.', '')} frames) H2D from page-locked memory inside the timed region (two device buffers, "
                                       "copy stream per lane), the aligned sum D2H", "lanes_per_gpu": nlanes,
                       "parallelism": f"movie replicas x{world}, no exchange; {nlanes} movies in flight per GPU (host threads, one stream and library handle each)"},
            "roofline": mk(dom), "roofline_other_kernels": {k_: mk(k_) for k_ in stage if k_ != dom},
@@ -398,12 +439,14 @@ def main_flexalign(args):
                             "stage_ms_timed_region are the same events inside the timed region, per movie, where they include waiting for the other lanes' kernels",
            "stage_ms_timed_region": {k_: v / args.steps for k_, v in stage_overlapped.items()},
            "value_resident_one_lane": resident, "global_shift_error_px": err}
+    if counts_leg:
+        out["int8_frames_leg"] = counts_leg
     if not args.no_cpu_baseline and world == 1:
         # the oracle's global alignment (ProgMovieAlignmentCorrelation<double>'s arithmetic, one thread) on the first 2 and the first 3 frames
         # of movie 0 at full size: T(n) = n t_frame + n (n - 1) / 2 t_pair, extrapolated to the movie's frames.  The local alignment and
         # the warp are NOT in it (the reference has no CPU form of the patch path): a lower bound of the CPU cost of a movie.
         from oracle import pyoracle as o
-        f3 = host[0][:3].numpy()
+        f3 = host[0][:3].to(torch.float32).numpy()
         tb = []
         for n in (2, 3):
             t0 = time.perf_counter()

@@ -458,6 +458,12 @@ int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y,
 int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, const float *d_frame, const float *d_dark, const float *d_gain, int32_t Y,
                        int32_t X, float *d_out, int32_t Yb, int32_t Xb);
 
+/* A frame as the detector stores it -> float32 on the device: the cast Image<float>::read does on the host while it reads
+ * (xmippCore rwMRC / castPage2T; the movie programs read through it, reconstruction/movie_alignment_correlation_base.cpp:262-266,
+ * movie_alignment_correlation_gpu.cpp:667-691), moved behind the host copy so that counts cross the link, not floats.  mode: the MRC
+ * data mode of the file -- 0 int8, 1 int16, 2 float32 (a copy), 6 uint16 -- or 100 for uint8 (not an MRC mode); n elements. */
+int xh_movie_frame_to_float(xh_ctx *ctx, const void *d_raw, int32_t mode, int64_t n, float *d_out);
+
 /* ---- batched estimator API, first slice ------------------------------------------------------
  * ExtremaFinder::SingleExtremaFinder<T> (reconstruction/single_extrema_finder.cpp:146-300): n signals [n][z][y][x] on the device;
  * search_type 0 Max, 1 Lowest (first of equals, like std::max_element / min_element), 2 MaxAroundCenter, 3 LowestAroundCenter (2-D

@@ -736,3 +736,44 @@ def test_cli_movie_filter_dose(bins, tmp_path, oracle):
         assert np.abs(exp - frames[n]).max() > 0.1                    # the filter does something
     r = _run([prog, "-i", str(tmp_path / "movie.stk"), "-o", str(tmp_path / "x.stk"), "--accVoltage", "250"])
     assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and "acceleration voltage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 6])
+def test_cli_movie_of_integer_counts(bins, tmp_path, mode):
+    """Movies as detectors write them: MRC stacks of int8 / int16 / uint16 counts (modes 0, 1, 6).  The program sends the counts to the
+    device and casts there (xh_movie_frame_to_float) -- same shifts, same sums, bit for bit, as from the float32 stack of the same
+    values, with dark and gain, with and without --bin."""
+    from tests.test_gpu_flexalign import synthetic_movie
+    N, Y, X = 5, 256, 328
+    frames, drift = synthetic_movie(N, Y, X, seed=23, max_step=2.0)
+    lo, hi = {0: (-100, 100), 1: (-20000, 20000), 6: (0, 60000)}[mode]
+    f = frames - frames.min()
+    counts = np.round(lo + f / f.max() * (hi - lo)).astype(np.float32)
+    xmipp_io.write_mrcs(str(tmp_path / "counts.mrcs"), counts, mode)
+    xmipp_io.write_mrcs(str(tmp_path / "floats.mrcs"), counts, 2)
+    rng = np.random.default_rng(4)
+    xmipp_io.write_volume(str(tmp_path / "dark.spi"), rng.uniform(0, 2, (1, Y, X)).astype(np.float32))
+    xmipp_io.write_volume(str(tmp_path / "gain.spi"), rng.uniform(0.9, 1.1, (1, Y, X)).astype(np.float32))
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    for extra in ([], ["--bin", "2"]):
+        out = {}
+        for tag in ("counts", "floats"):
+            r = _run([prog, "-i", str(tmp_path / f"{tag}.mrcs"), "-o", str(tmp_path / f"{tag}.xmd"), "--sampling", "1", "--maxShift", "30", "--maxResForCorrelation", "16",
+                      "--skipLocalAlignment", "--dark", str(tmp_path / "dark.spi"), "--gain", str(tmp_path / "gain.spi"), "--oavgInitial", str(tmp_path / f"{tag}.spi")] + extra)
+            assert r.returncode == 0, r.stderr
+            labels, rows = xmipp_io.read_xmd(str(tmp_path / f"{tag}.xmd"), block="frameShifts")
+            out[tag] = (rows, xmipp_io.read_volume(str(tmp_path / f"{tag}.spi")))
+        c = {l: i for i, l in enumerate(labels)}
+        num = lambda rows: [(r_[c["shiftX"]], r_[c["shiftY"]]) for r_ in rows]
+        assert num(out["counts"][0]) == num(out["floats"][0]) and len(out["counts"][0]) == N
+        assert np.array_equal(out["counts"][1], out["floats"][1])
+    c = {l: i for i, l in enumerate(labels)}
+    got = np.array([[float(r_[c["shiftX"]]), float(r_[c["shiftY"]])] for r_ in out["counts"][0]])
+    assert np.abs(np.diff(got, axis=0) - np.diff(drift, axis=0)).max() < 1.5          # and they are the drift that was put in
+    # a mode the reader does not know is refused, not misread
+    bad = bytearray(open(tmp_path / "counts.mrcs", "rb").read())
+    bad[12:16] = (4).to_bytes(4, "little")
+    open(tmp_path / "bad.mrcs", "wb").write(bytes(bad))
+    r = _run([prog, "-i", str(tmp_path / "bad.mrcs"), "-o", str(tmp_path / "bad.xmd"), "--skipLocalAlignment"])
+    assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr

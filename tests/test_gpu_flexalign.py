@@ -427,3 +427,26 @@ def test_wide_correlation_maxima_take_the_full_transform(gpu, oracle):
     print("pairs through the full transform:", fa.last_full_pairs(), "of", len(exp["bX"]))
     assert fa.last_full_pairs() > 0
     assert np.abs(got["bX"] - exp["bX"]).max() <= 5e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 5e-3 and got["ref"] == exp["ref"]
+
+
+@pytest.mark.parametrize("dtype", ["int8", "int16", "uint16", "uint8", "float32"])
+def test_frames_as_counts_become_floats_on_the_device(gpu, dtype):
+    """xh_movie_frame_to_float: the cast of Image<float>::read behind the host copy; whole range of every type, sizes that are not
+    multiples of the 16 bytes a thread converts, misaligned starts."""
+    xa, ctx, torch = gpu
+    rng = np.random.default_rng(1)
+    for n, off in ((4092 * 5760 // 64, 0), (1000003, 0), (777, 3), (5, 1), (0, 0)):
+        if dtype == "float32":
+            a = rng.standard_normal(n + off).astype(np.float32)
+        else:
+            info = np.iinfo(dtype)
+            a = rng.integers(info.min, info.max + 1, n + off).astype(dtype)
+            a[: min(2, n + off)] = (info.min, info.max)[: min(2, n + off)]
+        d = torch.from_numpy(a).cuda()[off:]
+        if n == 0:
+            continue
+        out = xa.movie_frames_to_float(ctx, d.contiguous() if off == 0 else d)       # (a slice of a 1-D tensor stays contiguous: misaligned pointer)
+        assert out.dtype == torch.float32 and torch.equal(out.cpu(), torch.from_numpy(a[off:].astype(np.float32)))
+    o2 = torch.empty(17, device="cuda")
+    xa.movie_frames_to_float(ctx, torch.arange(17, dtype=torch.int16, device="cuda"), out=o2)
+    assert torch.equal(o2.cpu(), torch.arange(17, dtype=torch.float32))

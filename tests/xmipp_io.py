@@ -96,3 +96,19 @@ def _split_row(t):
             out.append(t[i:j])
             i = j
     return out
+
+
+def write_mrcs(path, imgs, mode=2):
+    """MRC2014 stack (.mrcs): mode 0 int8, 1 int16, 2 float32, 6 uint16; imgs [n, y, x]"""
+    dt = {0: np.int8, 1: np.int16, 2: np.float32, 6: np.uint16}[mode]
+    a = np.ascontiguousarray(imgs).astype(dt)
+    n, y, x = a.shape
+    h = np.zeros(256, np.int32)
+    h[0], h[1], h[2], h[3] = x, y, n, mode
+    h[7], h[8], h[9] = x, y, n
+    h[16], h[17], h[18] = 1, 2, 3
+    h[52] = int.from_bytes(b"MAP ", "little")
+    h[53] = 0x00004444
+    with open(path, "wb") as f:
+        f.write(h.tobytes())
+        f.write(a.tobytes())

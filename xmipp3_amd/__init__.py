@@ -8,4 +8,4 @@ a Context without the built library or without a gfx950 device raises.
 """
 from ._lib import XhError, lib, lib_path  # noqa: F401
 from .api import (Context, CtfOps, ShiftCorrEstimator, apply_geometry2d, correlation_merit, extrema_find, iterative_alignment, rotation_estimate, CtfParams, Fft2D, FlexAlign, FourierProjector, ProjectionMatcher, RecFourier, RecFourier2, search5d_offsets, shard_range,  # noqa: F401
-                  allreduce_reconstruction, fa_correlate, frc_dpr, movie_dose_filter, reduce_reconstructions)
+                  allreduce_reconstruction, fa_correlate, frc_dpr, movie_bin_frame, movie_binned_size, movie_dose_filter, movie_frames_to_float, reduce_reconstructions)

@@ -633,6 +633,19 @@ def movie_binned_size(Y, X, binning):
     return int(f(f(f(Y) / f(binning)) / f(2)) * f(2)), int(f(f(f(X) / f(binning)) / f(2)) * f(2))
 
 
+def movie_frames_to_float(ctx, raw, out=None):
+    """Frames as the detector stores them (int8, int16, uint16, uint8 or float32 tensor on the device, any shape) -> float32, the
+    cast of Image<float>::read (xh_movie_frame_to_float): copy the counts to the device, convert there."""
+    torch = _torch()
+    modes = {torch.int8: 0, torch.int16: 1, torch.float32: 2, torch.uint16: 6, torch.uint8: 100}
+    assert raw.is_cuda and raw.is_contiguous() and raw.dtype in modes
+    if out is None:
+        out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
+    assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == raw.numel()
+    check(lib().xh_movie_frame_to_float(ctx.h, C.c_void_p(raw.data_ptr()), modes[raw.dtype], raw.numel(), _ptr(out)))
+    return out
+
+
 def movie_bin_frame(fft_raw, fft_binned, frame, dark=None, gain=None):
     """--bin of the CUDA FlexAlign program: frame [Y, X] -> [Yb, Xb] by cropping its half spectrum (xh_movie_bin_frame)"""
     torch = _torch()

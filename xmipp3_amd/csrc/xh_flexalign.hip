@@ -1603,7 +1603,51 @@ __global__ void __launch_bounds__(256) k_bin_crop(const fa_cf *__restrict__ F, f
 }
 }  // namespace
 
+// ---- frames as the detector stores them: MRC modes 0 (int8), 1 (int16), 6 (uint16), 2 (float32, a copy) and, beyond MRC, 100 (uint8)
+// -> float32, the cast of Image<float>::read (xmippCore castPage2T) done after the host copy instead of before it: a K3 frame crosses
+// the link as 23.6 MB of counts instead of 94 MB of floats.  A thread converts 16 bytes of input.
+namespace {
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_frame_to_float(const TIN *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    constexpr int V = 16 / (int)sizeof(TIN);
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 >= n) return;
+    if (i0 + V <= n && ((uintptr_t)in & 15) == 0) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(in + i0);
+        const TIN *v = reinterpret_cast<const TIN *>(&raw);
+#pragma unroll
+        for (int k = 0; k < V; k += 4) {
+            const float4 f = make_float4((float)v[k], (float)v[k + 1], (float)v[k + 2], (float)v[k + 3]);
+            if (((uintptr_t)out & 15) == 0) *reinterpret_cast<float4 *>(out + i0 + k) = f;
+            else { out[i0 + k] = f.x; out[i0 + k + 1] = f.y; out[i0 + k + 2] = f.z; out[i0 + k + 3] = f.w; }
+        }
+    } else
+        for (size_t i = i0; i < n && i < i0 + V; ++i) out[i] = (float)in[i];
+}
+}  // namespace
+
 extern "C" {
+
+int xh_movie_frame_to_float(xh_ctx *ctx, const void *d_raw, int32_t mode, int64_t n, float *d_out)
+{
+    XH_CHECK(ctx && d_raw && d_out && n >= 0, XH_ERR_ARG, "xh_movie_frame_to_float: bad argument");
+    XH_CHECK(mode == 0 || mode == 1 || mode == 2 || mode == 6 || mode == 100, XH_ERR_UNSUPPORTED,
+             "xh_movie_frame_to_float: mode %d (0 int8, 1 int16, 2 float32, 6 uint16, 100 uint8)", (int)mode);
+    XH_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return XH_OK;
+    const size_t N = (size_t)n;
+#define XH_F2F(T_) hipLaunchKernelGGL((k_frame_to_float<T_>), dim3((unsigned)((N + 256 * (16 / sizeof(T_)) - 1) / (256 * (16 / sizeof(T_))))), dim3(256), 0, ctx->stream, \
+                                      (const T_ *)d_raw, d_out, N)
+    if (mode == 0) XH_F2F(signed char);
+    else if (mode == 1) XH_F2F(short);
+    else if (mode == 6) XH_F2F(unsigned short);
+    else if (mode == 100) XH_F2F(unsigned char);
+    else XH_HIP(hipMemcpyAsync(d_out, d_raw, N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+#undef XH_F2F
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
 
 int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, const float *d_frame, const float *d_dark, const float *d_gain, int32_t Y, int32_t X,
                        float *d_out, int32_t Yb, int32_t Xb)

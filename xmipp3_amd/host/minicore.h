@@ -200,7 +200,9 @@ inline std::vector<std::string> getBlocksInMetaDataFile(const std::string &path)
 }
 
 // ------------------------------------------------------------------ images
-struct ImageInfo { size_t x = 0, y = 0, z = 1, n = 1; bool isStack = false; size_t headerBytes = 0, perImageHeader = 0; bool mrc = false, swap = false; };
+struct ImageInfo { size_t x = 0, y = 0, z = 1, n = 1; bool isStack = false; size_t headerBytes = 0, perImageHeader = 0; bool mrc = false, swap = false;
+                   int mode = 2;          // MRC data mode of the file: 0 int8, 1 int16, 2 float32, 6 uint16 (Spider files: 2)
+                   size_t bytesPerPixel() const { return mode == 0 ? 1 : (mode == 1 || mode == 6) ? 2 : 4; } };
 
 inline bool isMrcExt(const std::string &e) { return e == "mrc" || e == "mrcs" || e == "map" || e == "st"; }
 
@@ -214,8 +216,10 @@ inline ImageInfo readInfo(const std::string &path)
         int32_t h[256];
         f.read((char *)h, 1024);
         if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short MRC header in " + fn.path);
-        if (h[3] != 2) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: only MRC mode 2 (float32) is supported: " + fn.path);
-        I.mrc = true; I.x = h[0]; I.y = h[1];
+        // MRC2014 data modes as xmippCore's reader takes them (rwMRC: 0 signed bytes, 1 int16, 2 float32, 6 uint16), cast to float
+        if (h[3] != 0 && h[3] != 1 && h[3] != 2 && h[3] != 6)
+            REPORT_ERROR(ERR_IO_NOREAD, "Image::read: MRC mode " + std::to_string(h[3]) + " is not supported (0 int8, 1 int16, 2 float32, 6 uint16): " + fn.path);
+        I.mrc = true; I.x = h[0]; I.y = h[1]; I.mode = h[3];
         const bool stack = fn.extension() == "mrcs" || fn.extension() == "st";
         if (stack) { I.z = 1; I.n = h[2]; I.isStack = true; } else { I.z = h[2]; I.n = 1; }
         I.headerBytes = 1024 + (size_t)h[23];
@@ -235,7 +239,8 @@ inline ImageInfo readInfo(const std::string &path)
 }
 
 // reads image `index` (1-based for stacks; 0 => the only image / whole volume) as float
-inline void readImage(const std::string &name, std::vector<float> &data, ImageInfo &I)
+// the bytes of one image as the file holds them (I.mode tells what they are): the movie program sends counts to the device
+inline void readImageRaw(const std::string &name, std::vector<unsigned char> &raw, ImageInfo &I)
 {
     FileName fn(name);
     // consecutive reads usually hit the same stack: keep its header and its stream (one per host thread; a file
@@ -253,16 +258,28 @@ inline void readImage(const std::string &name, std::vector<float> &data, ImageIn
     std::ifstream &f = cache.f;
     f.clear();
     size_t idx = fn.hasNumber() ? fn.number() : 0;
-    const size_t per = I.x * I.y * I.z;
+    const size_t per = I.x * I.y * I.z, bpp = I.bytesPerPixel();
     size_t off;
-    if (I.mrc) off = I.headerBytes + (idx > 0 ? (idx - 1) * per * 4 : 0);
+    if (I.mrc) off = I.headerBytes + (idx > 0 ? (idx - 1) * per * bpp : 0);
     else if (I.isStack) { if (idx == 0) idx = 1; off = I.headerBytes + (idx - 1) * (I.perImageHeader + per * 4) + I.perImageHeader; }
     else off = I.headerBytes;
     if (I.isStack && idx > I.n) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: image " + std::to_string(idx) + " beyond the end of " + fn.path);
-    data.resize(per);
+    raw.resize(per * bpp);
     f.seekg((std::streamoff)off);
-    f.read((char *)data.data(), per * 4);
+    f.read((char *)raw.data(), per * bpp);
     if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short read in " + fn.path);
+}
+
+inline void readImage(const std::string &name, std::vector<float> &data, ImageInfo &I)
+{
+    static thread_local std::vector<unsigned char> raw;
+    readImageRaw(name, raw, I);
+    const size_t per = I.x * I.y * I.z;
+    data.resize(per);
+    if (I.mode == 2) memcpy(data.data(), raw.data(), per * 4);
+    else if (I.mode == 0) { const signed char *p = (const signed char *)raw.data(); for (size_t i = 0; i < per; ++i) data[i] = (float)p[i]; }
+    else if (I.mode == 1) { const int16_t *p = (const int16_t *)raw.data(); for (size_t i = 0; i < per; ++i) data[i] = (float)p[i]; }
+    else { const uint16_t *p = (const uint16_t *)raw.data(); for (size_t i = 0; i < per; ++i) data[i] = (float)p[i]; }
 }
 
 inline void spiderHeader(std::vector<float> &h, size_t x, size_t y, size_t z, int iform, int istack, size_t maxim, size_t imgnum)

@@ -172,20 +172,23 @@ public:
             d_frames.reserve(g.c, (size_t)N * per * sizeof(float));
             // the frames are read a few ahead by their own threads while the one before them goes to the device (the reference loads
             // with a thread pool beside its two GPU streams, movie_alignment_correlation_gpu.cpp:667-691)
+            // (frames of integer counts -- MRC modes 0, 1, 6 -- travel as they are and become floats on the device, xh_movie_frame_to_float)
             auto readFrame = [&](int n) {
                 std::string fn;
                 movie.getValue("image", fn, (size_t)(nfirst + n));
-                std::vector<float> f;
+                std::vector<unsigned char> f;
                 ImageInfo In;
-                readImage(fn, f, In);
-                if (In.x != Iraw.x || In.y != Iraw.y) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes in " + fnMovie);
+                readImageRaw(fn, f, In);
+                if (In.x != Iraw.x || In.y != Iraw.y || In.mode != Iraw.mode) REPORT_ERROR(ERR_MULTIDIM_SIZE, "frames of different sizes or data types in " + fnMovie);
                 return f;
             };
             // --bin: a frame is corrected (dark, gain) and binned on its way in (loadFrame + CUDAFlexAlignScale::runScaleIFT,
             // movie_alignment_correlation_gpu.cpp:667-691); everything after works on binned frames without dark / gain
             xh_fft2d *planRaw = nullptr, *planBin = nullptr;
             struct PlanGuard { xh_fft2d **a, **b; ~PlanGuard() { if (*a) xh_fft2d_destroy(*a); if (*b) xh_fft2d_destroy(*b); } } planGuard{&planRaw, &planBin};
-            DeviceBuffer d_raw;
+            DeviceBuffer d_raw, d_counts;
+            const size_t rawBytes = perRaw * Iraw.bytesPerPixel();
+            if (Iraw.mode != 2) d_counts.reserve(g.c, rawBytes);
             if (doBin) {
                 xhCheck(xh_fft2d_create(g.c, (int)Iraw.y, (int)Iraw.x, &planRaw));
                 xhCheck(xh_fft2d_create(g.c, (int)I.y, (int)I.x, &planBin));
@@ -194,18 +197,21 @@ public:
                 if (!gain.empty()) { d_gain.reserve(g.c, perRaw * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), perRaw * sizeof(float))); }
             }
             const int ahead = 4;
-            std::deque<std::future<std::vector<float>>> inFlight;
+            std::deque<std::future<std::vector<unsigned char>>> inFlight;
             for (int n = 0; n < std::min(ahead, N); ++n) inFlight.push_back(std::async(std::launch::async, readFrame, n));
             for (int n = 0; n < N; ++n) {
-                std::vector<float> cur = inFlight.front().get();          // re-throws what the reader threw
+                std::vector<unsigned char> cur = inFlight.front().get();          // re-throws what the reader threw
                 inFlight.pop_front();
                 if (n + ahead < N) inFlight.push_back(std::async(std::launch::async, readFrame, n + ahead));
-                if (doBin) {
-                    xhCheck(xh_memcpy_h2d(g.c, d_raw.p, cur.data(), perRaw * sizeof(float)));
+                float *dst = doBin ? d_raw.as<float>() : d_frames.as<float>() + (size_t)n * per;
+                if (Iraw.mode == 2) xhCheck(xh_memcpy_h2d(g.c, dst, cur.data(), rawBytes));
+                else {
+                    xhCheck(xh_memcpy_h2d(g.c, d_counts.p, cur.data(), rawBytes));
+                    xhCheck(xh_movie_frame_to_float(g.c, d_counts.p, Iraw.mode, (int64_t)perRaw, dst));
+                }
+                if (doBin)
                     xhCheck(xh_movie_bin_frame(g.c, planRaw, planBin, d_raw.as<float>(), dark.empty() ? nullptr : d_dark.as<float>(), gain.empty() ? nullptr : d_gain.as<float>(),
                                                (int)Iraw.y, (int)Iraw.x, d_frames.as<float>() + (size_t)n * per, (int)I.y, (int)I.x));
-                } else
-                    xhCheck(xh_memcpy_h2d(g.c, (char *)d_frames.p + (size_t)n * per * sizeof(float), cur.data(), per * sizeof(float)));
             }
             if (!doBin) {
                 if (!dark.empty()) { d_dark.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), per * sizeof(float))); }
