@@ -133,6 +133,54 @@ __global__ void __launch_bounds__(256) k_fft2d_small(xh_cf *__restrict__ data, c
     }
 }
 
+// The first two steps of a four-step ROW transform whose input is a real frame, two rows per complex row (row 2r real part, row
+// 2r + 1 imaginary part, (frame - dark) * gain like loadFrame): the n1-point DFTs over n1 (n1 odd, <= 64), times the step-2 factor
+// exp(-2 pi i k1 m2 / n) -- the pass k_fa_load2 + k_fft2d_small + k_fft2d_twiddle make in three trips through memory.  out[r][k1 n2 + m2].
+__global__ void __launch_bounds__(256) k_fft2d_small_pairs(const float *__restrict__ frame, const float *__restrict__ dark, const float *__restrict__ gain, int Y, int X,
+                                                           xh_cf *__restrict__ out, const xh_cf *__restrict__ tw1, const xh_cf *__restrict__ twN, int n1, int n2,
+                                                           size_t nlines)
+{
+    extern __shared__ xh_cf ssm[];            // [n1][128] samples, then [n1] twiddles
+    xh_cf *sx = ssm, *sw = ssm + (size_t)n1 * 128;
+    const size_t l0 = (size_t)blockIdx.x * 128;
+    for (int j = threadIdx.x; j < n1; j += 256) sw[j] = tw1[j];
+    for (int i = threadIdx.x; i < n1 * 128; i += 256) {
+        const int j = i >> 7, ll = i & 127;
+        const size_t l = l0 + ll;
+        xh_cf v = xh_cf{0.f, 0.f};
+        if (l < nlines) {
+            const size_t r = l / n2, m2 = l - r * n2;
+            const size_t s0 = (2 * r) * (size_t)X + m2 + (size_t)j * n2, s1 = s0 + X;
+            float v0 = frame[s0], v1 = 0.f;
+            if (dark) v0 -= dark[s0];
+            if (gain) v0 *= gain[s0];
+            if (2 * r + 1 < (size_t)Y) {
+                v1 = frame[s1];
+                if (dark) v1 -= dark[s1];
+                if (gain) v1 *= gain[s1];
+            }
+            v = xh_cf{v0, v1};
+        }
+        sx[i] = v;
+    }
+    __syncthreads();
+    const int ll = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const size_t l = l0 + ll;
+    if (l >= nlines) return;
+    const size_t r = l / n2, m2 = l - r * n2;
+    xh_cf *dst = out + r * (size_t)X + m2;
+    for (int k = half; k < n1; k += 2) {
+        float re = 0.f, im = 0.f;
+        int m = 0;
+        for (int j = 0; j < n1; ++j) {
+            const xh_cf x = sx[(j << 7) + ll], w = sw[m];
+            re += x.x * w.x - x.y * w.y; im += x.x * w.y + x.y * w.x;
+            m += k; if (m >= n1) m -= n1;
+        }
+        dst[(size_t)k * n2] = xh_cmul(xh_cf{re, im}, twN[(size_t)k * m2]);         // k m2 < n1 n2 = n
+    }
+}
+
 int small_lines(xh_ctx *ctx, xh_cf *data, const Axis &A, size_t nlines, size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, bool inverse)
 {
     const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
@@ -260,6 +308,27 @@ int xh_fft2d_user_scratch(xh_fft2d *f, size_t bytes, void **p)
     XH_CHECK(f && p, XH_ERR_ARG, "xh_fft2d_user_scratch: bad argument");
     XH_TRY(xh_buf_reserve(f->ctx, f->user, bytes));
     *p = f->user.p;
+    return XH_OK;
+}
+
+// internal (xh_common.h): the forward transform of the rows of a real frame, two rows per complex row of the plan (ny = (Y + 1) / 2,
+// nx = X), steps 1-3 of the four steps only: d_work[r][n2 k1 + k2] = X_r[k1 + n1 k2] -- the caller reads the columns it keeps through
+// that map instead of paying for the untangling pass.  *n1 = 0: this plan's rows are not (odd <= 64) x (power of two); nothing done.
+int xh_fft2d_rows_of_real_pairs(xh_fft2d *f, const float *d_frame, const float *d_dark, const float *d_gain, int Y, float *d_work, int *n1, int *n2)
+{
+    XH_CHECK(f && d_frame && d_work && n1 && n2 && (Y + 1) / 2 == f->ny, XH_ERR_ARG, "xh_fft2d_rows_of_real_pairs: bad argument");
+    const Axis &A = f->ax;
+    *n1 = 0; *n2 = 0;
+    if (A.n2 == 1 || !A.small1) return XH_OK;
+    xh_ctx *ctx = f->ctx;
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t nlines = (size_t)f->ny * A.n2;
+    const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
+    hipLaunchKernelGGL(k_fft2d_small_pairs, dim3((unsigned)((nlines + 127) / 128)), dim3(256), smem, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (xh_cf *)d_work,
+                       (const xh_cf *)A.tw1.p, (const xh_cf *)A.tw.p, A.n1, A.n2, nlines);
+    XH_LAUNCH_CHECK();
+    XH_TRY(lines(ctx, (xh_cf *)d_work, A.p2.plan, (size_t)f->ny * A.n1, (size_t)A.n1, (size_t)f->nx, (size_t)A.n2, 1, false));
+    *n1 = A.n1; *n2 = A.n2;
     return XH_OK;
 }
 

@@ -116,13 +116,16 @@ __global__ void __launch_bounds__(256) k_fa_load2(const float *__restrict__ fram
 
 // ... and apart again for the nc columns the reduced frame keeps: with Z = F(a + i b), F(a)[k] = (Z[k] + conj Z[-k]) / 2,
 // F(b)[k] = (Z[k] - conj Z[-k]) / 2i. C: [Y][nc]
-__global__ void __launch_bounds__(256) k_fa_unpack(const fa_cf *__restrict__ Z, fa_cf *__restrict__ C, int Y, int X, int nc)
+// (n1 > 0: Z as xh_fft2d_rows_of_real_pairs leaves it, frequency k of a row at n2 (k % n1) + k / n1)
+__global__ void __launch_bounds__(256) k_fa_unpack(const fa_cf *__restrict__ Z, fa_cf *__restrict__ C, int Y, int X, int nc, int n1, int n2)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int Yh = (Y + 1) / 2;
     if (t >= (size_t)Yh * nc) return;
     const int r = (int)(t / nc), k = (int)(t - (size_t)r * nc);
-    const fa_cf zk = Z[(size_t)r * X + k], zm = Z[(size_t)r * X + (k ? X - k : 0)];
+    int pk = k, pm = k ? X - k : 0;
+    if (n1 > 0) { pk = n2 * (pk % n1) + pk / n1; pm = n2 * (pm % n1) + pm / n1; }
+    const fa_cf zk = Z[(size_t)r * X + pk], zm = Z[(size_t)r * X + pm];
     C[(size_t)(2 * r) * nc + k] = fa_cf{0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
     if (2 * r + 1 < Y) C[(size_t)(2 * r + 1) * nc + k] = fa_cf{0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
 }
@@ -1048,10 +1051,16 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     fa_cf *Cc = wk + (size_t)Yh * h->X;
     for (int n = 0; n < N; ++n) {
         const size_t tz = (size_t)Yh * h->X, tc = (size_t)Yh * nc;
-        hipLaunchKernelGGL(k_fa_load2, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, h->Y, h->X);
-        XH_LAUNCH_CHECK();
-        XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
-        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cc, h->Y, h->X, nc);
+        // rows: from the real frame straight into the first line pass, the result left where the third step puts it (a K3 frame's
+        // 5760 = 45 x 128: two trips through memory instead of six); any other length: pack, transform, read in natural order
+        int t1 = 0, t2 = 0;
+        XH_TRY(xh_fft2d_rows_of_real_pairs(h->rows, d_frames + (size_t)n * big, d_dark, d_gain, h->Y, (float *)wk, &t1, &t2));
+        if (t1 == 0) {
+            hipLaunchKernelGGL(k_fa_load2, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, h->Y, h->X);
+            XH_LAUNCH_CHECK();
+            XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
+        }
+        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cc, h->Y, h->X, nc, t1, t2);
         XH_LAUNCH_CHECK();
         XH_TRY(xh_fft2d_exec_axis(h->cols, (float *)Cc, 0, 1));
         hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)Cc, h->Y, nc, S + (size_t)n * small, nY, nX,
