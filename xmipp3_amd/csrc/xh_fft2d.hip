@@ -181,6 +181,87 @@ __global__ void __launch_bounds__(256) k_fft2d_small_pairs(const float *__restri
     }
 }
 
+
+// ---- 45 points in registers: 45 = 5 x 9 (Cooley-Tukey, every index a compile-time constant).  W45^j = exp(-2 pi i j / 45).
+__device__ __forceinline__ xh_cf xh_w45(int j)
+{
+    constexpr float c[45] = {1.000000000e+00f, 9.902680687e-01f, 9.612616959e-01f, 9.135454576e-01f, 8.480480962e-01f, 7.660444431e-01f, 6.691306064e-01f, 5.591929035e-01f, 4.383711468e-01f, 3.090169944e-01f, 1.736481777e-01f, 3.489949670e-02f, -1.045284633e-01f, -2.419218956e-01f, -3.746065934e-01f, -5.000000000e-01f, -6.156614753e-01f, -7.193398003e-01f, -8.090169944e-01f, -8.829475929e-01f, -9.396926208e-01f, -9.781476007e-01f, -9.975640503e-01f, -9.975640503e-01f, -9.781476007e-01f, -9.396926208e-01f, -8.829475929e-01f, -8.090169944e-01f, -7.193398003e-01f, -6.156614753e-01f, -5.000000000e-01f, -3.746065934e-01f, -2.419218956e-01f, -1.045284633e-01f, 3.489949670e-02f, 1.736481777e-01f, 3.090169944e-01f, 4.383711468e-01f, 5.591929035e-01f, 6.691306064e-01f, 7.660444431e-01f, 8.480480962e-01f, 9.135454576e-01f, 9.612616959e-01f, 9.902680687e-01f};
+    constexpr float s[45] = {-0.000000000e+00f, -1.391731010e-01f, -2.756373558e-01f, -4.067366431e-01f, -5.299192642e-01f, -6.427876097e-01f, -7.431448255e-01f, -8.290375726e-01f, -8.987940463e-01f, -9.510565163e-01f, -9.848077530e-01f, -9.993908270e-01f, -9.945218954e-01f, -9.702957263e-01f, -9.271838546e-01f, -8.660254038e-01f, -7.880107536e-01f, -6.946583705e-01f, -5.877852523e-01f, -4.694715628e-01f, -3.420201433e-01f, -2.079116908e-01f, -6.975647374e-02f, 6.975647374e-02f, 2.079116908e-01f, 3.420201433e-01f, 4.694715628e-01f, 5.877852523e-01f, 6.946583705e-01f, 7.880107536e-01f, 8.660254038e-01f, 9.271838546e-01f, 9.702957263e-01f, 9.945218954e-01f, 9.993908270e-01f, 9.848077530e-01f, 9.510565163e-01f, 8.987940463e-01f, 8.290375726e-01f, 7.431448255e-01f, 6.427876097e-01f, 5.299192642e-01f, 4.067366431e-01f, 2.756373558e-01f, 1.391731010e-01f};
+    return xh_cf{c[j], s[j]};
+}
+// a[9 n1 + n2] = x[9 n1 + n2] on entry; X[k1 + 5 k2] = a[9 k1 + k2] on return
+__device__ __forceinline__ void xh_dft45(xh_cf (&a)[45])
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 9; ++n2) {
+        xh_cf t[5];
+#pragma unroll
+        for (int k1 = 0; k1 < 5; ++k1) {
+            xh_cf acc = a[n2];
+#pragma unroll
+            for (int n1 = 1; n1 < 5; ++n1) {
+                const int e = (9 * n1 * k1) % 45;
+                const xh_cf x = a[9 * n1 + n2];
+                if (e == 0) { acc.x += x.x; acc.y += x.y; }
+                else { const xh_cf w = xh_w45(e); acc.x += x.x * w.x - x.y * w.y; acc.y += x.x * w.y + x.y * w.x; }
+            }
+            const int e2 = (n2 * k1) % 45;
+            t[k1] = e2 == 0 ? acc : xh_cmul(acc, xh_w45(e2));
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 5; ++k1) a[9 * k1 + n2] = t[k1];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1) {
+        xh_cf t[9];
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) {
+            xh_cf acc = a[9 * k1];
+#pragma unroll
+            for (int n2 = 1; n2 < 9; ++n2) {
+                const int e = (5 * n2 * k2) % 45;
+                const xh_cf x = a[9 * k1 + n2];
+                if (e == 0) { acc.x += x.x; acc.y += x.y; }
+                else { const xh_cf w = xh_w45(e); acc.x += x.x * w.x - x.y * w.y; acc.y += x.x * w.y + x.y * w.x; }
+            }
+            t[k2] = acc;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) a[9 * k1 + k2] = t[k2];
+    }
+}
+
+// k_fft2d_small_pairs for n1 = 45 (a K3 frame's 5760 = 45 x 128): a thread owns a line -- its 45 samples are 45 coalesced loads (lanes
+// are neighbouring m2), the transform runs in registers with constant factors (630 complex multiply-adds instead of 2025, no LDS), the
+// 45 results are 45 coalesced stores.
+__global__ void __launch_bounds__(256) k_fft2d_45_pairs(const float *__restrict__ frame, const float *__restrict__ dark, const float *__restrict__ gain, int Y, int X,
+                                                        xh_cf *__restrict__ out, const xh_cf *__restrict__ twN, int n2, size_t nlines)
+{
+    const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlines) return;
+    const size_t r = l / n2, m2 = l - r * n2;
+    const bool two = 2 * r + 1 < (size_t)Y;
+    const size_t s0 = (2 * r) * (size_t)X + m2;
+    xh_cf a[45];
+#pragma unroll
+    for (int j = 0; j < 45; ++j) {
+        const size_t o = s0 + (size_t)j * n2;
+        float v0 = frame[o], v1 = two ? frame[o + X] : 0.f;
+        if (dark) { v0 -= dark[o]; if (two) v1 -= dark[o + X]; }
+        if (gain) { v0 *= gain[o]; if (two) v1 *= gain[o + X]; }
+        a[j] = xh_cf{v0, v1};
+    }
+    xh_dft45(a);
+    xh_cf *dst = out + r * (size_t)X + m2;
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) {
+            const int k = k1 + 5 * k2;
+            dst[(size_t)k * n2] = xh_cmul(a[9 * k1 + k2], twN[(size_t)k * m2]);         // k m2 < 45 n2 = n
+        }
+}
+
 int small_lines(xh_ctx *ctx, xh_cf *data, const Axis &A, size_t nlines, size_t inner, size_t outerStride, size_t innerStride, size_t elemStride, bool inverse)
 {
     const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
@@ -324,6 +405,10 @@ int xh_fft2d_rows_of_real_pairs(xh_fft2d *f, const float *d_frame, const float *
     XH_HIP(hipSetDevice(ctx->device));
     const size_t nlines = (size_t)f->ny * A.n2;
     const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
+    if (A.n1 == 45 && !getenv("XH_FFT2D_NO_45"))
+        hipLaunchKernelGGL(k_fft2d_45_pairs, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (xh_cf *)d_work,
+                           (const xh_cf *)A.tw.p, A.n2, nlines);
+    else
     hipLaunchKernelGGL(k_fft2d_small_pairs, dim3((unsigned)((nlines + 127) / 128)), dim3(256), smem, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (xh_cf *)d_work,
                        (const xh_cf *)A.tw1.p, (const xh_cf *)A.tw.p, A.n1, A.n2, nlines);
     XH_LAUNCH_CHECK();
