@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--movie", default="40x4092x5760", help="flexalign mode: frames x rows x columns of a movie")
     ap.add_argument("--movie-mode", type=int, default=2, choices=[0, 1, 2, 6], help="flexalign mode: how the frames lie in host memory, as an MRC data mode: 2 float32 "
                     "(default: 3.77 GB per K3 movie cross the link), 0 int8 / 1 int16 / 6 uint16 counts, cast to float on the device (xh_movie_frame_to_float)")
+    ap.add_argument("--fa-shared-copy", type=int, default=1, help="flexalign mode: 1 one copy stream for all lanes, 0 one per lane")
     ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
@@ -260,7 +261,9 @@ def main_flexalign(args):
                 self.src = host
                 self.total = torch.zeros((Y, X), device=dev)
             self.h_avg = [torch.empty((Y, X), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-            self.copy_stream = torch.cuda.Stream(device=dev)
+            # one copy stream for all lanes: the movies cross the link one after the other anyway, and two host copies in flight on
+            # two streams make the runtime move one of them with a shader kernel
+            self.copy_stream = Lane.shared_copy_stream if args.fa_shared_copy else torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.done = [torch.cuda.Event(), torch.cuda.Event()]
             self.timers = {"global_alignment": [], "local_alignment": [], "warp_and_sum": []}
@@ -319,6 +322,7 @@ def main_flexalign(args):
             except BaseException as e:          # re-raised on the main thread
                 self.error = e
 
+    Lane.shared_copy_stream = torch.cuda.Stream(device=dev)
     lanes = [Lane(i) for i in range(nlanes)]
     fa = lanes[0].fa
 
