@@ -774,6 +774,81 @@ __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef,
     if (sum) sum[o] += columns;
 }
 
+// The same for lX, lY >= 4 (every pixel then has four control points per axis in x and y).  What differs is how the 64 terms are fed:
+// the control points of the (at most four) layers around tPos lie in LDS as QUADS -- for every layer, control row and first column the
+// four neighbours C[x0 .. x0 + 3] as one 16-byte record -- so a (layer, row) pair costs two ds_read_b128 (X and Y field; the lanes of a
+// wave share the cell almost always: a broadcast) instead of eight ds_read_b32, and the 1e-4 cut multiplies a dropped term by zero
+// instead of branching around it (sx + C * 0 = sx).  Same terms, same order (layer, column, row), same products bY (bX bT).
+__global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__ coef, const float *__restrict__ cX, const float *__restrict__ cY, int lX, int lY, int lT,
+                                                       float hX, float hY, float tPos, int Y, int X, float *__restrict__ out, float *__restrict__ sum)
+{
+    extern __shared__ float4 sq[];
+    const int nl = lX * lY, qx = lX - 3, nq = qx * lY;
+    const int tB = (int)tPos - 1, t1 = min((int)tPos + 2, lT - 2), nT = t1 - tB + 1;       // tB >= -1: layers tB + 1 .. t1 + 1 of the arrays
+    float4 *sqX = sq, *sqY = sq + nT * nq;
+    for (int i = threadIdx.x; i < nT * nq; i += 256) {
+        const int a = i / nq, rem = i - a * nq, yy = rem / qx, x0 = rem - yy * qx;
+        const float *px = cX + (size_t)(tB + 1 + a) * nl + yy * lX + x0, *py = cY + (size_t)(tB + 1 + a) * nl + yy * lX + x0;
+        sqX[i] = make_float4(px[0], px[1], px[2], px[3]);
+        sqY[i] = make_float4(py[0], py[1], py[2], py[3]);
+    }
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= X || y >= Y) return;
+    const float delta = 0.0001f;
+    const float xPos = x / hX, yPos = y / hY;
+    const int xi = (int)xPos, yi = (int)yPos;                 // first control column / row of the pixel: xB + 1, yB + 1
+    float bT[4], bX[4], bY[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bT[i] = d_fa_b3(tPos - (tB + i)); bX[i] = d_fa_b3(xPos - (xi - 1 + i)); bY[i] = d_fa_b3(yPos - (yi - 1 + i)); }
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (a >= nT) break;
+        float4 QX[4], QY[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int o = a * nq + (yi + c) * qx + xi; QX[c] = sqX[o]; QY[c] = sqY[o]; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float tX = bX[b] * bT[a];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float tmp = bY[c] * tX;
+                tmp = tmp > delta ? tmp : 0.f;
+                const float vx = b == 0 ? QX[c].x : b == 1 ? QX[c].y : b == 2 ? QX[c].z : QX[c].w;
+                const float vy = b == 0 ? QY[c].x : b == 1 ? QY[c].y : b == 2 ? QY[c].z : QY[c].w;
+                sx += vx * tmp; sy += vy * tmp;
+            }
+        }
+    }
+    const int xc = (int)ceilf(-sx), yc = (int)ceilf(-sy);
+    const float xd = 2.f - (sx + xc), yd = 2.f - (sy + yc);
+    const int l1 = x + xc - 2, m1 = y + yc - 2;
+    float wx[4];
+    int lx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int l = l1 + i;
+        wx[i] = d_fa_b3(xd - i);
+        while (l < 0 || l >= X) l = l < 0 ? -l - 1 : 2 * X - l - 1;
+        lx[i] = l;
+    }
+    float columns = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m1 + i;
+        while (m < 0 || m >= Y) m = m < 0 ? -m - 1 : 2 * Y - m - 1;
+        const float *ref = coef + (size_t)m * X;
+        float rows = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rows += ref[lx[j]] * wx[j];
+        columns += rows * d_fa_b3(yd - i);
+    }
+    const size_t o = (size_t)y * X + x;
+    if (out) out[o] = columns;
+    if (sum) sum[o] += columns;
+}
+
 // ---- host: EquationSystemSolver::solve + computeAlignment ------------------------------------------------------------------
 void mean_stddev(const std::vector<double> &v, double &mean, double &sd)
 {
@@ -1506,6 +1581,11 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
         // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
         const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
         const float tPos = n / hT;
+        static const bool plain = getenv("XH_FA_WARP_PLAIN") != nullptr;        // A/B runs
+        if (lX >= 4 && lY >= 4 && !plain)
+            hipLaunchKernelGGL(k_fa_warp_quads, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), sizeof(float4) * 2 * 4 * (lX - 3) * lY, ctx->stream, (const float *)coef,
+                               (const float *)h->warpC.p, (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
+        else
         hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), sizeof(float) * 2 * 4 * lX * lY, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
                            (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
     }
