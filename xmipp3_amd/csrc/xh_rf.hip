@@ -17,6 +17,7 @@
 //   k_rf_insert             gridding: slab traversal + blob gather + 3 float atomics/voxel HBM atomics  <-- dominant
 //   k_rf_mirror, k_rf_hermitian, k_rf_weights, k_rf_expand, xh_k_fft_lines (xh_plan.h), k_rf_c2r_window   O(volume) once
 #include "xh_common.h"
+#include "xh_rf_cell.h"
 #include "xh_fft.h"
 #include "xh_fftreg.h"
 #include "xh_plan.h"
@@ -734,7 +735,7 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
 
 template <int R1, int R2, bool PACK>
 __global__ void __launch_bounds__(256)
-k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, float4 *__restrict__ pk, const XhCtfDev *__restrict__ cp,
+k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, XgCell *__restrict__ pk, const XhCtfDev *__restrict__ cp,
            const float *__restrict__ weights, const xh_cf *__restrict__ W, int D, int TD, int sizeX, double maxResSqr, int nlines,
            double iTs, double minCTF, int phaseFlipped)
 {
@@ -794,9 +795,9 @@ k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, float4 *__restr
         const double fy = (double)k / (double)P;
         if (PACK && tid < 2 * PAD) {                          // the frame cells left and right of the two rows
             const int xc = tid < PAD ? tid : sizeX + tid;
-            float4 *dst = pk + (size_t)img * SX * SY;
-            if (row1) dst[(size_t)(r1 + PAD) * SX + xc] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row2) dst[(size_t)(r2 + PAD) * SX + xc] = make_float4(0.f, 0.f, 0.f, 0.f);
+            XgCell *dst = pk + (size_t)img * SX * SY;
+            if (row1) xg_put(dst + (size_t)(r1 + PAD) * SX + xc, 0.f, 0.f, 0.f);
+            if (row2) xg_put(dst + (size_t)(r2 + PAD) * SX + xc, 0.f, 0.f, 0.f);
         }
         for (int j = tid; j < sizeX; j += 256) {             // thread <-> kx: every wave has the same number of CTF values to find
             const int xc = j + PAD;
@@ -827,9 +828,9 @@ k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, float4 *__restr
                     const float mw = mv_ * w;
                     v2 = make_float4(o2.x * mw * cv, o2.y * mw * cv, mw, 0.f);
                 }
-                float4 *dst = pk + (size_t)img * SX * SY;
-                if (row1) dst[(size_t)(r1 + PAD) * SX + xc] = v1;
-                if (row2) dst[(size_t)(r2 + PAD) * SX + xc] = v2;
+                XgCell *dst = pk + (size_t)img * SX * SY;
+                if (row1) xg_put(dst + (size_t)(r1 + PAD) * SX + xc, v1.x, v1.y, v1.z);
+                if (row2) xg_put(dst + (size_t)(r2 + PAD) * SX + xc, v2.x, v2.y, v2.z);
             }
         }
     }
@@ -1438,7 +1439,7 @@ static bool fft_cols_rows_ok(const xh_rf *rf)
     return (rf->P == 512 || rf->P == 256 || rf->P == 128) && rf->sizeY == rf->P && rf->fft_variant == 0;
 }
 // n images -> half spectra (d_fft) or, with d_pk, the gridding kernel's padded records (CTF of rf->d_ctfp, weights or null)
-static int fft_cols_rows(xh_rf *rf, const float *d_imgs, int n, xh_cf *d_fft, float4 *d_pk, const float *d_weights)
+static int fft_cols_rows(xh_rf *rf, const float *d_imgs, int n, xh_cf *d_fft, XgCell *d_pk, const float *d_weights)
 {
     xh_ctx *ctx = rf->ctx;
     const int D = rf->D, P = rf->P, sizeX = rf->sizeX;
@@ -1465,7 +1466,7 @@ static int fft_cols_rows(xh_rf *rf, const float *d_imgs, int n, xh_cf *d_fft, fl
                                rf->p.phase_flipped);                                                                                \
         else                                                                                                                        \
             hipLaunchKernelGGL((k_rf_rowsB<A_, B_, false>), dim3(m * ((nlines + G::LN - 1) / G::LN)), dim3(256), G::smem, ctx->stream, \
-                               (const xh_cf *)rf->d_rows.p, d_fft + (size_t)i0 * rf->sizeY * sizeX, (float4 *)nullptr,               \
+                               (const xh_cf *)rf->d_rows.p, d_fft + (size_t)i0 * rf->sizeY * sizeX, (XgCell *)nullptr,               \
                                (const XhCtfDev *)nullptr, (const float *)nullptr, (const xh_cf *)rf->d_twP32.p, D, TD, sizeX, maxResSqr, \
                                nlines, 0.0, 0.0, 0);                                                                                \
     }
@@ -1694,8 +1695,8 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     XH_CHECK(cells < ((size_t)1 << 31), XH_ERR_ARG, "xh_rf_insert: more than 2^31 record cells in one call; insert in smaller batches");
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
-    XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(float4)));
-    if (rf->packImgs) XH_TRY(fft_cols_rows(rf, rf->packImgs, n, nullptr, (float4 *)rf->d_pack.p, d_weights));
+    XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(XgCell) + 16));          // (the patch copy reads 16 bytes from the last record too)
+    if (rf->packImgs) XH_TRY(fft_cols_rows(rf, rf->packImgs, n, nullptr, (XgCell *)rf->d_pack.p, d_weights));
     else
     for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
         const int m = std::min(65535, n - i0);
@@ -1704,12 +1705,12 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
             const int dc = rf->P / 2, K = std::max(rf->sizeY + XG_PAD - dc, dc + XG_PAD + 1);
             hipLaunchKernelGGL(k_rf_pack_grid_ctf, dim3((unsigned)((K * SXp + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft + o,
                                (const XhCtfDev *)rf->d_ctfp.p + i0, d_weights ? d_weights + i0 : nullptr,
-                               (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, rf->sizeX, rf->sizeY, rf->P, 1.0 / rf->p.sampling,
+                               (XgCell *)rf->d_pack.p + (size_t)i0 * SXp * SYp, rf->sizeX, rf->sizeY, rf->P, 1.0 / rf->p.sampling,
                                rf->p.min_ctf, rf->p.phase_flipped);
         } else
         hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((SXp * SYp + XG_PACK_CELLS - 1) / XG_PACK_CELLS), m), dim3(256), 0, ctx->stream,
                            (const xh_cf *)d_fft + o, d_ctf ? d_ctf + o : nullptr, d_mod ? d_mod + o : nullptr, d_weights ? d_weights + i0 : nullptr,
-                           (float4 *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
+                           (XgCell *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
         XH_LAUNCH_CHECK();
     }
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds
@@ -1755,7 +1756,7 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
 #endif
 #define XH_GRID(W_, F_, Z_, N_)                                                                                                  \
     hipLaunchKernelGGL((k_rf_grid<W_, F_, Z_, N_, XG_ABL>), dim3(gridBlocks), dim3(64 * N_), 0, ctx->stream, \
-                       (const XgRec *)rf->d_grecs.p + s0, (const float4 *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, \
+                       (const XgRec *)rf->d_grecs.p + s0, (const XgCell *)rf->d_pack.p, (const float *)rf->d_blob.p, tempV, tempW, \
                        rf->mv, rf->iDeltaSqrt, br, (const unsigned *)rf->d_gtiles[tl].p, (const int *)rf->d_tileCounter.p + 32 + 16 * tl, \
                        (int *)rf->d_tileCounter.p + 128, (const int *)rf->d_superList.p, (const int *)rf->d_superCount.p,         \
                        superDim, m, (const float4 *)superN, (const float4 *)superX, reach, rf->grid_tile_budget)

@@ -31,6 +31,8 @@
 #define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
 #endif
 
+#include "xh_rf_cell.h"
+
 // Compile-time shape of a kernel instance. A unit is 8 x 8 x ZD voxels (ZD = 4 or 8); NW waves share a CU.
 //   PN   pixels per patch row / column a footprint can reach: the image extent of a unit is at most its diagonal
 //        (10.4 / 12.2 pixels), so first footprint pixels lie 0..11 / 0..13 behind the patch origin, and a footprint is W wide
@@ -97,13 +99,13 @@ typedef float xg_v4f __attribute__((ext_vector_type(4)));
 #define XG_PACK_CELLS 1024
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
-               const float *__restrict__ weights, float4 *__restrict__ pk, int n, int sizeX, int sizeY)
+               const float *__restrict__ weights, XgCell *__restrict__ pk, int n, int sizeX, int sizeY)
 {
     const unsigned SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD, cells = SX * SY;
     const unsigned img = blockIdx.y;
     const float w = weights ? weights[img] : 1.f;
     const size_t src = (size_t)img * sizeX * sizeY;
-    float4 *dst = pk + (size_t)img * cells;
+    XgCell *dst = pk + (size_t)img * cells;
     // all loads of the thread's four cells first (bytes in flight are what a streaming kernel runs on), then the stores
     constexpr int NC = XG_PACK_CELLS / 256;
     xh_cf f[NC];
@@ -131,7 +133,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
             if (ctfs) { const float mw = cm[k] * w; v = make_float4(f[k].x * mw * cc[k], f[k].y * mw * cc[k], mw, 0.f); }
             else v = make_float4(f[k].x * w, f[k].y * w, w, 0.f);
         }
-        dst[c] = v;
+        xg_put(dst + c, v.x, v.y, v.z);
     }
 }
 
@@ -141,7 +143,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
 // and its mirror row (x, dc - k): a non-astigmatic CTF is the same on both, evaluated once (see k_rf_ctf).
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ cp, const float *__restrict__ weights,
-                   float4 *__restrict__ pk, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+                   XgCell *__restrict__ pk, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
 {
     const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
     const int dc = P / 2;
@@ -153,7 +155,7 @@ k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ 
     const XhCtfDev par = cp[img];
     const float w = weights ? weights[img] : 1.f;
     const xh_cf *src = ffts + (size_t)img * sizeX * sizeY;
-    float4 *dst = pk + (size_t)img * SX * SY;
+    XgCell *dst = pk + (size_t)img * SX * SY;
     const int y1 = dc + k, y2 = dc - k;
     const bool row1 = y1 < sizeY + XG_PAD, row2 = k > 0 && y2 >= -XG_PAD && y2 < sizeY + XG_PAD;
     const bool inx = x >= 0 && x < sizeX;
@@ -174,8 +176,8 @@ k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ 
         const float mw = mv_ * w;
         v2 = make_float4(f2.x * mw * cv, f2.y * mw * cv, mw, 0.f);
     }
-    if (row1) dst[(size_t)(y1 + XG_PAD) * SX + (x + XG_PAD)] = v1;
-    if (row2) dst[(size_t)(y2 + XG_PAD) * SX + (x + XG_PAD)] = v2;
+    if (row1) xg_put(dst + (size_t)(y1 + XG_PAD) * SX + (x + XG_PAD), v1.x, v1.y, v1.z);
+    if (row2) xg_put(dst + (size_t)(y2 + XG_PAD) * SX + (x + XG_PAD), v2.x, v2.y, v2.z);
 }
 
 // Host side of the row-visit test. getX (RFA:479-490) intersects the voxel row (y, z) with a face of the slab:
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ ang
 // record, 10 every tap reads the table's first entry, 11 = 9 + 10 (the LDS reads without their bank conflicts).
 template <int W, bool FAST, int ZD, int NW, int ABL>
 __global__ void __launch_bounds__(64 * NW, (NW + 3) / 4)
-k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const float *__restrict__ blobTable,
+k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const float *__restrict__ blobTable,
           float *__restrict__ tempV, float *__restrict__ tempW, int mv, float iDeltaSqrt, double blobRadius,
           const unsigned *__restrict__ tileList, const int *__restrict__ classOff, int *__restrict__ counter,
           const int *__restrict__ superList, const int *__restrict__ superCount, int superDim, int superCap,
@@ -305,7 +307,7 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
     // pixel of their row / the last row, which costs no further cache line)
     unsigned dOff[NDMA];
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) { const int slot = 64 * i + lane, row = slot / PW, col = slot - row * PW; dOff[i] = (unsigned)(min(row, PN - 1) * SX + min(col, PN - 1)) * 16u; }
+    for (int i = 0; i < NDMA; ++i) { const int slot = 64 * i + lane, row = slot / PW, col = slot - row * PW; dOff[i] = (unsigned)(min(row, PN - 1) * SX + min(col, PN - 1)) * (unsigned)sizeof(XgCell); }
 
     // ---- work distribution: a tile ring (tiles = 2 x 2 x 2 units, eight XCD classes dealt into NSUB interleaved streams, one
     // global grab per tile, eight tickets per tile drawn by the waves of the workgroup)
@@ -480,7 +482,8 @@ k_rf_grid(const XgRec *__restrict__ recs, const float4 *__restrict__ pk, const f
                                 int imgY = (int)(iy + 0.5f + mv / 2);
                                 imgY = imgY > sizeY - 1 ? sizeY - 1 : imgY;
                                 imgY = imgY < 0 ? 0 : imgY;
-                                const float4 q = pk[((size_t)__float_as_int(R0.w) * SY + (imgY + XG_PAD)) * SX + (imgX + XG_PAD)];
+                                const XgCell qc = pk[((size_t)__float_as_int(R0.w) * SY + (imgY + XG_PAD)) * SX + (imgX + XG_PAD)];
+                                const float4 q = make_float4(qc.v[0], qc.v[1], qc.v[2], 0.f);
                                 const int ai = rz * 64 + ry * 8 + (vx - x0);
                                 sAcc[ai] += q.z;
                                 sAcc[NVOX + ai] += q.x;
