@@ -915,7 +915,7 @@ def main():
                     roofline["traffic_source"] = "profiles/traffic_k_rf_grid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             # the kernel's own bound is not HBM: vector issue and the LDS pipeline, from the committed PMC passes
             # of tools/pmc_grid.sh over the same 4096-projection launch (counters cannot be read from inside the process)
-            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_b_pmc_k_rf_grid.json")
+            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_c_pmc_k_rf_grid.json")
             if os.path.exists(pf) and B == 4096 and D == 256:
                 c = {k_: v_["mean"] for k_, v_ in json.load(open(pf))["counters_per_dispatch"].items()}
                 if all(k_ in c for k_ in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")):
@@ -926,7 +926,7 @@ def main():
                         "valu_issue_frac_at_4_cycles_per_instruction": 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc),
                         "lds_pipeline_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc),
                         "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                        "source": "profiles/r04_b_pmc_k_rf_grid.json (rocprofv3 --pmc, separate passes, tools/pmc_grid.sh); a packed fp32 "
+                        "source": "profiles/r04_c_pmc_k_rf_grid.json (rocprofv3 --pmc, separate passes, tools/pmc_grid.sh); a packed fp32 "
                                   "instruction costs 5.2 and a conversion 4+ cycles (profiles/experiments/r03_ubench_valu_lds.txt), so the issue "
                                   "fraction at the real mix is ~1.15 x the 4-cycle figure"}
     others = {k: {"bound": v[0], "achieved": v[1], "peak": v[2], "unit": v[3], "frac": v[1] / v[2], "ms": v[4], "counted": v[5]}
