@@ -445,9 +445,13 @@ __global__ void __launch_bounds__(256) k_fa_gemm(const float *__restrict__ A, si
 // real product over 2 K with the rows of i B = (-Bi, Br) formed while B is staged. Block = 128 x 128 of the real C, four waves of
 // 64 x 64 (2 x 2 MFMA tiles), K in steps of 16 through LDS.
 typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
-template <bool ACPLX>
+// GATHER (real A only): A is the movie itself -- row m = (patch frame f = m / PY, patch row y = m % PY) of the product is the window of
+// frame f % nFrames at the frame's rounded global shift, (frame - dark) * gain like k_fa_gather, read where it lies: the patch copy
+// (k_fa_gather: 4.3 GB written and read back per K3 movie) disappears.
+struct FaGather { const float *dark, *gain; const int *offs; int nFrames, Y, X, PY; };
+template <bool ACPLX, bool GATHER = false>
 __global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ A, size_t lda, size_t sA, const fa_cf *__restrict__ B, size_t ldb, size_t sB,
-                                                      fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K)
+                                                      fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K, FaGather G = FaGather{})
 {
     constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
     __shared__ float As[BK][LD], Bs[BK][LD];
@@ -466,6 +470,12 @@ __global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int arow = t >> 1, akseg = (t & 1) * 8;                  // A tile: 128 rows x 16 k, eight consecutive k per thread
     const int bk = t >> 4, bcseg = (t & 15) * 8;                   // B tile: 16 k x 128 real columns, eight consecutive columns per thread
+    size_t gsrc = 0, gfrm = 0;             // GATHER: where row m0 + arow starts in its frame, and that frame
+    if (GATHER && m0 + arow < M) {
+        const int m = m0 + arow, f = m / G.PY, y = m - f * G.PY;
+        gsrc = (size_t)(G.offs[2 * f + 1] + y) * G.X + G.offs[2 * f];
+        gfrm = (size_t)(f % G.nFrames) * G.Y * G.X;
+    }
     for (int k0 = 0; k0 < K2; k0 += BK) {
         float av[8], bv[8];
         {
@@ -475,7 +485,11 @@ __global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ 
                 const int kk = k0 + akseg + q;
                 float v = 0.f;
                 if (m < M && kk < K2) {
-                    if (!ACPLX) v = A[(size_t)m * lda + kk];
+                    if (GATHER) {
+                        v = A[gfrm + gsrc + kk];
+                        if (G.dark) v -= G.dark[gsrc + kk];
+                        if (G.gain) v *= G.gain[gsrc + kk];
+                    } else if (!ACPLX) v = A[(size_t)m * lda + kk];
                     else v = kk < K ? A[((size_t)m * lda + kk) * 2] : A[((size_t)m * lda + (kk - K)) * 2 + 1];
                 }
                 av[q] = v;
@@ -1407,19 +1421,27 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     for (int p0 = 0; p0 < nP && rc == XH_OK; p0 += PB) {
         const int pb = std::min(PB, nP - p0), nf = pb * N;
         const size_t tot = (size_t)nf * PY * PX;
-        hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2,
-                           (float *)bPatch.p, nf, N, Y, X, PY, PX);
-        // along x, all frames of all patches of the batch at once: [pb N PY][PX] x [PX][cxh]
-        if (h->use_mfma)
+        static const bool copyPatches = getenv("XH_FA_COPY_PATCHES") != nullptr;        // A/B runs
+        const bool fused = h->use_mfma && !copyPatches;
+        if (!fused)
+            hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2,
+                               (float *)bPatch.p, nf, N, Y, X, PY, PX);
+        // along x, all frames of all patches of the batch at once: [pb N PY][PX] x [PX][cxh]; the matrix-core product reads the patches
+        // out of the frames
+        if (fused) {
+            FaGather G{d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2, N, Y, X, PY};
+            hipLaunchKernelGGL((k_fa_gemm_mfma<false, true>), dim3((2 * cxh + 127) / 128, (unsigned)(((size_t)nf * PY + 127) / 128), 1), dim3(256), 0, ctx->stream, d_frames,
+                               (size_t)PX, (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX, G);
+        } else if (h->use_mfma)
             hipLaunchKernelGGL((k_fa_gemm_mfma<false>), dim3((2 * cxh + 127) / 128, (unsigned)(((size_t)nf * PY + 127) / 128), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p,
-                               (size_t)PX, (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX);
+                               (size_t)PX, (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX, FaGather{});
         else
         hipLaunchKernelGGL((k_fa_gemm<false>), dim3((cxh + 31) / 32, (unsigned)(((size_t)nf * PY + 63) / 64), 1), dim3(256), 0, ctx->stream, (const float *)bPatch.p, (size_t)PX,
                            (size_t)0, (const fa_cf *)bWx.p, (size_t)cxh, (size_t)0, (fa_cf *)bT.p, (size_t)cxh, (size_t)0, nf * PY, cxh, PX);
         // along y, frame by frame: [CY][PY] x [PY][cxh]
         if (h->use_mfma)
             hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * cxh + 127) / 128, (CY + 127) / 128, nf), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
-                               (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
+                               (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY, FaGather{});
         else
         hipLaunchKernelGGL((k_fa_gemm<true>), dim3((cxh + 31) / 32, (CY + 63) / 64, nf), dim3(256), 0, ctx->stream, (const float *)bWy.p, (size_t)PY, (size_t)0,
                            (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
