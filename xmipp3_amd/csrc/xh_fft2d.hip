@@ -51,7 +51,9 @@ bool factorise(int n, int &n1, int &n2)
         const int b = n / a;
         if (!direct_ok(a) || !direct_ok(b)) continue;
         // cost: LDS line lengths the two passes run at (Bluestein lines cost their padded length three times)
-        auto cost = [](int m) { int M = 1; while (M < (xh_is_pow2(m) ? m : 2 * m - 1)) M <<= 1; return (long)(xh_is_pow2(m) ? M : 3 * M); };
+        // (+ 64 per line whatever its length: measured on the 4092 rows of a K3 frame, where 4 x 1023 -- 4-point lines that cost as much
+        // as 128-point ones, and Bluestein lines of 2048 -- lost to 44 x 93 by 1.3 ms per 40-frame movie)
+        auto cost = [](int m) { int M = 1; while (M < (xh_is_pow2(m) ? m : 2 * m - 1)) M <<= 1; return (long)(xh_is_pow2(m) ? M : 3 * M) + 64; };
         const long c = cost(a) * b + cost(b) * a;
         if (best < 0 || c < best) { best = c; n1 = a; n2 = b; }
     }
@@ -285,7 +287,13 @@ int axis_create(xh_ctx *ctx, int n, Axis &A)
     int odd = n, p2 = 1;
     while ((odd & 1) == 0) { odd >>= 1; p2 <<= 1; }
     if (odd > 1 && odd <= 64 && p2 >= 2 && direct_ok(p2) && !getenv("XH_FFT2D_NO_SMALL")) { A.n1 = odd; A.n2 = p2; A.small1 = true; }
-    else XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
+    else {
+        XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
+        if (const char *f = getenv("XH_FFT2D_N1")) {              // A/B runs: force the first factor
+            const int a = atoi(f);
+            if (a >= 2 && n % a == 0 && direct_ok(a) && direct_ok(n / a)) { A.n1 = a; A.n2 = n / a; }
+        }
+    }
     if (A.small1) {
         const long double PI1 = 3.14159265358979323846264338327950288L;
         std::vector<xh_cf> w1(A.n1);
