@@ -450,3 +450,52 @@ def test_frames_as_counts_become_floats_on_the_device(gpu, dtype):
     o2 = torch.empty(17, device="cuda")
     xa.movie_frames_to_float(ctx, torch.arange(17, dtype=torch.int16, device="cuda"), out=o2)
     assert torch.equal(o2.cpu(), torch.arange(17, dtype=torch.float32))
+
+
+def test_two_movies_in_flight_on_one_device(gpu):
+    """bench.py --mode flexalign keeps two movies in flight per GPU: a host thread per movie, each with its own stream, context and
+    FlexAlign handle.  The library keeps no state outside its handles, so the two threads must return what the same calls return
+    one after the other: shifts, patch shifts, spline coefficients and the aligned sums, bit for bit."""
+    import threading
+    xa, ctx, torch = gpu
+    N, Y, X = 6, 512, 640
+    movies = [synthetic_movie(N, Y, X, seed=31 + i, max_step=2.0)[0] for i in range(2)]
+    cp, patches, psize = (4, 4, 3), (3, 3), (256, 256)
+
+    def run(lane_ctx, fa, frames):
+        d = torch.from_numpy(frames).cuda()
+        g = fa.global_alignment(d, 20.0)
+        loc = fa.local_alignment(d, g["shiftX"], g["shiftY"], g["ref"], 20.0, patches, psize, 3, cp)
+        total = torch.zeros((Y, X), device="cuda")
+        fa.apply_bspline_frames(d, loc["coeffsX"], loc["coeffsY"], cp, total=total)
+        lane_ctx.sync()
+        return g["shiftX"].copy(), g["shiftY"].copy(), np.asarray(loc["patch_shifts"]).copy(), np.asarray(loc["coeffsX"]).copy(), total.cpu().numpy()
+
+    seq = []
+    for m in movies:
+        fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+        seq.append(run(ctx, fa, m))
+    out, err = [None, None], []
+
+    def lane(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                c = xa.Context(0)
+                fa = xa.FlexAlign(c, Y, X, 1.0, 8.0)
+                fa.set_option("prefilter_ahead", 1)
+                for _ in range(3):              # several rounds: the lanes overlap in every phase
+                    out[i] = run(c, fa, movies[i])
+        except BaseException as e:
+            err.append(e)
+
+    th = [threading.Thread(target=lane, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        for a, b in zip(seq[i], out[i]):
+            assert np.array_equal(a, b)
