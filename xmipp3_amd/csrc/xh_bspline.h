@@ -80,7 +80,9 @@ __global__ void k_pm_prefilter_cols(T *__restrict__ coefs, int D, int nslots, co
 // form, every output independent, eight outputs per thread from one 40-sample window. The fp64 paths
 // (reference library, re-scoring) use the 65-tap form below; the gallery projector keeps the recursion.
 #define XH_FIR_K 16
+#ifndef XH_FIR_V
 #define XH_FIR_V 8
+#endif
 struct XhFir { float h[XH_FIR_K + 1]; };
 template <bool COLS>
 __global__ void __launch_bounds__(256)
@@ -248,18 +250,21 @@ static inline XhFir xh_fir_taps()
     return F;
 }
 
-// Both passes in one kernel: a block owns XH_FIR_V rows x XH_FIR_TW columns of an image. Its threads first filter down the
+// Both passes in one kernel: a block owns XH_FIR2D_V rows x XH_FIR_TW columns of an image. Its threads first filter down the
 // columns (thread <-> column, 40-row window, coalesced; the 16 columns either side of the tile too, mirrored at the image
 // border) into an LDS tile, then along the rows out of LDS (thread <-> 8 outputs of one row). The image is read once and
 // written once; the two-kernel form above wrote and re-read the row-filtered intermediate.
 #define XH_FIR_TW 256
+#ifndef XH_FIR2D_V
+#define XH_FIR2D_V 32        // tile rows of the two-pass kernel: 64 rows read per 32 written (8: 40 per 8; prep32 4.5 -> 4.2 ms per 4096 particles)
+#endif
 template <int TW>
 __global__ void __launch_bounds__(256)
 k_pm_prefilter_fir2d(const float *__restrict__ in, float *__restrict__ out, int D, int tilesX, XhFir F)
 {
-    __shared__ __align__(16) float tile[XH_FIR_V][XH_FIR_TW + 2 * XH_FIR_K];
+    __shared__ __align__(16) float tile[XH_FIR2D_V][XH_FIR_TW + 2 * XH_FIR_K];
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
-    const int x0 = tx * XH_FIR_TW, y0 = ty * XH_FIR_V;
+    const int x0 = tx * XH_FIR_TW, y0 = ty * XH_FIR2D_V;
     const size_t base = (size_t)blockIdx.y * D * D;
     const float *src = in + base;
     for (int xx = threadIdx.x; xx < XH_FIR_TW + 2 * XH_FIR_K; xx += 256) {
@@ -267,15 +272,15 @@ k_pm_prefilter_fir2d(const float *__restrict__ in, float *__restrict__ out, int 
         if (p >= D + XH_FIR_K) break;                   // beyond the halo of the last, partial tile
         // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
         while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
-        float w[XH_FIR_V + 2 * XH_FIR_K];
+        float w[XH_FIR2D_V + 2 * XH_FIR_K];
 #pragma unroll
-        for (int i = 0; i < XH_FIR_V + 2 * XH_FIR_K; ++i) {
+        for (int i = 0; i < XH_FIR2D_V + 2 * XH_FIR_K; ++i) {
             int q = y0 + i - XH_FIR_K;
             while (q < 0 || q >= D) q = q < 0 ? -1 - q : 2 * D - 1 - q;
             w[i] = src[(size_t)q * D + p];
         }
 #pragma unroll
-        for (int o = 0; o < XH_FIR_V; ++o) {
+        for (int o = 0; o < XH_FIR2D_V; ++o) {
             float acc = F.h[0] * w[o + XH_FIR_K];
 #pragma unroll
             for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
@@ -283,39 +288,46 @@ k_pm_prefilter_fir2d(const float *__restrict__ in, float *__restrict__ out, int 
         }
     }
     __syncthreads();
-    const int r = threadIdx.x / (XH_FIR_TW / 8), seg = threadIdx.x - r * (XH_FIR_TW / 8);
-    const int xo = x0 + seg * 8, y = y0 + r;
-    if (y >= D || xo >= D) return;
-    float w[8 + 2 * XH_FIR_K];
-    const float4 *t4 = reinterpret_cast<const float4 *>(&tile[r][seg * 8]);
+    // rows: 256 threads cover 256 / (TW / 8) = 8 tile rows at a time
+    constexpr int RPP = 256 / (XH_FIR_TW / 8);
+    const int seg = threadIdx.x % (XH_FIR_TW / 8);
+    const int xo = x0 + seg * 8;
+    if (xo >= D) return;
 #pragma unroll
-    for (int i = 0; i < (8 + 2 * XH_FIR_K) / 4; ++i) {
-        const float4 q = t4[i];
-        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    for (int r = threadIdx.x / (XH_FIR_TW / 8); r < XH_FIR2D_V; r += RPP) {
+        const int y = y0 + r;
+        if (y >= D) break;
+        float w[8 + 2 * XH_FIR_K];
+        const float4 *t4 = reinterpret_cast<const float4 *>(&tile[r][seg * 8]);
+#pragma unroll
+        for (int i = 0; i < (8 + 2 * XH_FIR_K) / 4; ++i) {
+            const float4 q = t4[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+        float res[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float acc = F.h[0] * w[o + XH_FIR_K];
+#pragma unroll
+            for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
+            res[o] = acc;
+        }
+        float *dst = out + base + (size_t)y * D + xo;
+        if ((D & 3) == 0 && xo + 8 <= D) {
+            reinterpret_cast<float4 *>(dst)[0] = make_float4(res[0], res[1], res[2], res[3]);
+            reinterpret_cast<float4 *>(dst)[1] = make_float4(res[4], res[5], res[6], res[7]);
+        } else
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (xo + o < D) dst[o] = res[o];
     }
-    float res[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        float acc = F.h[0] * w[o + XH_FIR_K];
-#pragma unroll
-        for (int j = 1; j <= XH_FIR_K; ++j) acc += F.h[j] * (w[o + XH_FIR_K - j] + w[o + XH_FIR_K + j]);
-        res[o] = acc;
-    }
-    float *dst = out + base + (size_t)y * D + xo;
-    if ((D & 3) == 0 && xo + 8 <= D) {
-        reinterpret_cast<float4 *>(dst)[0] = make_float4(res[0], res[1], res[2], res[3]);
-        reinterpret_cast<float4 *>(dst)[1] = make_float4(res[4], res[5], res[6], res[7]);
-    } else
-#pragma unroll
-        for (int o = 0; o < 8; ++o)
-            if (xo + o < D) dst[o] = res[o];
 }
 
 // n images [n][D][D]: in -> out (must not alias)
 static inline void xh_prefilter_fir_launch(hipStream_t stream, const float *in, float *out, int D, size_t n)
 {
     const XhFir F = xh_fir_taps();
-    const int tilesX = (D + XH_FIR_TW - 1) / XH_FIR_TW, tilesY = (D + XH_FIR_V - 1) / XH_FIR_V;
+    const int tilesX = (D + XH_FIR_TW - 1) / XH_FIR_TW, tilesY = (D + XH_FIR2D_V - 1) / XH_FIR2D_V;
     const size_t img = (size_t)D * D;
     for (size_t i0 = 0; i0 < n; i0 += 65535) {
         const unsigned m = (unsigned)std::min<size_t>(65535, n - i0);
