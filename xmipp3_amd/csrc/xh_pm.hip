@@ -2340,8 +2340,10 @@ k_pm_bestshift_coarse(const float *__restrict__ Rraw, const xh_cf *__restrict__ 
 // 16 taps of a pixel used to be gathered from the 512-KB coefficient image in global memory (the L1's tag lookups bound
 // k_pm_tr_rows: 6.9 ms per 4096 particles of 256 px); the rotated tile only reaches a 28 x 28 patch of it, staged here in
 // LDS with the mirror boundary already applied. Same weights, same summation order as d_interp: same bits.
+#ifndef XH_TRB
 #define XH_TRB 32           // output tile edge: four pixels per thread
 #define XH_TRBW 52          // 2 * 15.5 * sqrt(2) + 6 (taps, ceilings) + slack
+#endif
 // cos / sin of the in-plane angles, once per particle in double precision
 __global__ void k_pm_tr_angles(const int *__restrict__ psi, double2 *__restrict__ cs, int n, int N)
 {

@@ -374,7 +374,9 @@ k_rf_cols(const xh_cf *__restrict__ rows, xh_cf *__restrict__ out, XhPlan<float>
 // their weights, and their footprints overlap in all but one row each, so the row sums (the inner loop of
 // interpolatedElementBSpline2D) are formed once per source row -- XH_SHIFT_V + 3 of them instead of 4 XH_SHIFT_V -- with the
 // expressions and the order d_interp uses: same bits.
+#ifndef XH_SHIFT_V
 #define XH_SHIFT_V 4
+#endif
 __global__ void __launch_bounds__(256)
 k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
            const float2 *__restrict__ shifts, const unsigned char *__restrict__ flips,
