@@ -7,6 +7,8 @@
 #define XH_BSPLINE_H
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
+#include <algorithm>
 
 // cubic B-spline prefilter, pole sqrt(3)-2, half-sample mirror boundary (xmippCore
 // produceSplineCoefficients; in-tree GPU twin reconstruction_cuda/cuda_gpu_iirconvolve.cu:28-41)
@@ -323,9 +325,125 @@ k_pm_prefilter_fir2d(const float *__restrict__ in, float *__restrict__ out, int 
     }
 }
 
+// ---- the same filter in its recursive form, tile by tile ---------------------------------------------------------------
+// The 33-tap convolution costs 33 operations per output and axis (k_pm_prefilter_fir2d: 66 vector instructions per pixel, its
+// row pass reading LDS with 32-byte lane strides). The recursion costs three -- c+[k] = s[k] + z c+[k-1] forwards,
+// c[k] = z (c[k+1] - c+[k]) backwards -- and a thread may enter it anywhere: whatever it starts from is forgotten as z^k
+// (0.268^14 = 1e-8, below fp32 resolution), so XH_REC_K = 14 warm-up samples either side of a run of 32 outputs give
+// (32 + 28) + 2 (32 + 14) + 32 = 184 operations per 32 outputs, 5.8 per pixel and axis, on the same mirror-extended samples
+// as the convolution (its own truncation is z^17).  A block owns 32 rows x 256 columns: down the columns from global memory
+// (thread <-> column, coalesced) into an LDS tile, along the rows out of it (thread <-> (row, 32 columns); rows 324 floats
+// apart: the sixteen lanes of a ds_read_b128 sit on sixteen different rows = all 64 banks), the results back into the tile
+// and out as whole rows (one kilobyte per wave and store instruction).
+#define XH_REC_K 14
+#define XH_REC_V 32
+#define XH_REC_S 324
+template <int TW>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_rec2d(const float *__restrict__ in, float *__restrict__ out, int D, int tilesX)
+{
+    constexpr int K = XH_REC_K, V = XH_REC_V, S = XH_REC_S, NW = V + 2 * K;
+    static_assert(S >= TW + 2 * K && S % 4 == 0 && S % 64 == 4 && TW == 256, "tile layout");
+    __shared__ __align__(16) float tile[V * S];
+    const float z = -0.26794919243112270647f, zend = z / (z - 1.f);
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x0 = tx * TW, y0 = ty * V;
+    const size_t base = (size_t)blockIdx.y * D * D;
+    const float *src = in + base;
+    // the tile spans the image's rows: the halo columns are mirror images of columns the block filters anyway
+    const bool full = tilesX == 1 && D >= 2 * K;
+    for (int xx = tid; xx < TW + 2 * K; xx += 256) {
+        int p = x0 + xx - K;
+        if (p >= D + K) break;                          // beyond the halo of the last, partial tile
+        if (full && (p < 0 || p >= D)) continue;
+        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
+        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        float w[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            int q = y0 + i - K;
+            while (q < 0 || q >= D) q = q < 0 ? -1 - q : 2 * D - 1 - q;
+            w[i] = src[(size_t)q * D + p];
+        }
+#pragma unroll
+        for (int i = 1; i < NW; ++i) w[i] = __builtin_fmaf(z, w[i - 1], w[i]);
+        float a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            if (i < V + K) tile[(i - K) * S + xx] = 6.f * a;
+        }
+    }
+    __syncthreads();
+    if (full) {
+        for (int e = tid; e < V * 2 * K; e += 256) {
+            const int r = e / (2 * K), i = e - r * 2 * K;
+            if (i < K) tile[r * S + K - 1 - i] = tile[r * S + K + i];
+            else tile[r * S + K + D + (i - K)] = tile[r * S + K + D - 1 - (i - K)];
+        }
+        __syncthreads();
+    }
+    // rows: thread <-> (row r, columns 32 sg .. 32 sg + 31 of the tile); its window starts K columns earlier = tile column 32 sg
+    const int r = tid & (V - 1), sg = tid >> 5;
+    float w[NW];
+    {
+        const float4 *t4 = reinterpret_cast<const float4 *>(&tile[r * S + 32 * sg]);
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) {
+            const float4 q = t4[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < NW; ++i) w[i] = __builtin_fmaf(z, w[i - 1], w[i]);
+    {
+        float a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            w[i] = 6.f * a;
+        }
+    }
+    __syncthreads();                                    // every window has been read
+    {
+        float4 *t4 = reinterpret_cast<float4 *>(&tile[r * S + 32 * sg]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t4[i] = make_float4(w[K + 4 * i], w[K + 4 * i + 1], w[K + 4 * i + 2], w[K + 4 * i + 3]);
+    }
+    __syncthreads();
+    const bool vec = (D & 3) == 0;
+    for (int e = tid; e < V * (TW / 4); e += 256) {
+        const int rr = e / (TW / 4), c4 = e - rr * (TW / 4);
+        const int y = y0 + rr, x = x0 + 4 * c4;
+        if (y >= D || x >= D) continue;
+        const float4 q = *reinterpret_cast<const float4 *>(&tile[rr * S + 4 * c4]);
+        float *dst = out + base + (size_t)y * D + x;
+        if (vec) *reinterpret_cast<float4 *>(dst) = q;
+        else { dst[0] = q.x; if (x + 1 < D) dst[1] = q.y; if (x + 2 < D) dst[2] = q.z; if (x + 3 < D) dst[3] = q.w; }
+    }
+}
+
+// which form xh_prefilter_fir_launch runs: 1 the recursion tile by tile (k_pm_prefilter_rec2d), 0 the 33-tap convolution
+// (k_pm_prefilter_fir2d); XH_PREFILTER_FORM in the environment picks for A/B runs
+static inline int xh_prefilter_form()
+{
+    static const int form = [] { const char *e = getenv("XH_PREFILTER_FORM"); return e ? atoi(e) : 1; }();
+    return form;
+}
+
 // n images [n][D][D]: in -> out (must not alias)
 static inline void xh_prefilter_fir_launch(hipStream_t stream, const float *in, float *out, int D, size_t n)
 {
+    if (xh_prefilter_form() == 1) {
+        const int tilesX = (D + XH_FIR_TW - 1) / XH_FIR_TW, tilesY = (D + XH_REC_V - 1) / XH_REC_V;
+        const size_t img = (size_t)D * D;
+        for (size_t i0 = 0; i0 < n; i0 += 65535) {
+            const unsigned m = (unsigned)std::min<size_t>(65535, n - i0);
+            hipLaunchKernelGGL((k_pm_prefilter_rec2d<XH_FIR_TW>), dim3(tilesX * tilesY, m), dim3(256), 0, stream, in + i0 * img, out + i0 * img, D, tilesX);
+        }
+        return;
+    }
     const XhFir F = xh_fir_taps();
     const int tilesX = (D + XH_FIR_TW - 1) / XH_FIR_TW, tilesY = (D + XH_FIR2D_V - 1) / XH_FIR2D_V;
     const size_t img = (size_t)D * D;
@@ -358,6 +476,25 @@ template <typename T> __device__ __forceinline__ void d_bspline03_w4(T x, int l1
         if (t == 0 || t == 3) w[t] = a < (T)2 ? outer : (T)0;
         else w[t] = a < (T)1 ? a * a * (a - (T)2) * (T)0.5 + (T)(2.0 / 3.0) : outer;
     }
+}
+
+// The same four weights for the fp32 coarse passes (S1 polar sampling, S6 rotation), as polynomials of t = x - (l1 + 1) in (0, 1]:
+//   w0 = (1 - t)^3 / 6,  w1 = 2/3 - t^2 (2 - t) / 2,  w2 = 2/3 - (1 - t)^2 (1 + t) / 2,  w3 = t^3 / 6
+// 14 operations instead of ~32, no selects; they differ from d_bspline03_w4's by float rounding (the coarse passes carry their own
+// error margins: tau_rel for the rotational search, s6_eps for the shifts; the fp64 chains keep the expressions above).
+__device__ __forceinline__ void d_bspline03_w4_lean(float x, int l1, float w[4])
+{
+    const float t = x - (float)(l1 + 1), o = 1.f - t;
+    const float t2 = t * t, o2 = o * o;
+    w[0] = o2 * o * (1.f / 6.f);
+    w[3] = t2 * t * (1.f / 6.f);
+    w[1] = __builtin_fmaf(t2 * (t - 2.f), 0.5f, 2.f / 3.f);
+    w[2] = __builtin_fmaf(o2 * (o - 2.f), 0.5f, 2.f / 3.f);
+}
+template <typename T> __device__ __forceinline__ void d_bspline03_w4_coarse(T x, int l1, T w[4])
+{
+    if constexpr (sizeof(T) == 4) d_bspline03_w4_lean(x, l1, w);
+    else d_bspline03_w4<T>(x, l1, w);
 }
 
 // interpolatedElementBSpline2D degree 3 at logical (x,y); reconstruction_cuda/cuda_gpu_multidim_array.cu:78-157

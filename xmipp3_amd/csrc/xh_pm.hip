@@ -235,20 +235,30 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
     if (count && slot >= *count) return;
     const T *c = coefs + (size_t)slot * D * D;
     const int2 org = cellOrg[cell];                      // first tap column / row of the patch, image index space
-    // six loads in flight per thread (the plain loop compiles to load - wait - store)
-    for (int e0 = threadIdx.x; e0 < XH_PCW * XH_PCW; e0 += 6 * 256) {
-        T v[6];
+    // wave <-> patch rows w, w + 4, ..., lane <-> patch column: the row's mirror index is wave-uniform (scalar unit), the column's
+    // is found once per lane, all of a thread's 17 loads are in flight before its first store; the four columns beyond the 64th
+    // are a second, short pass.  (Element by element the index arithmetic was 28 vector instructions per element.)
+    {
+        static_assert(XH_PCW == 68, "patch staging is written for 64 + 4 columns");
+        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        auto mir = [D](int a) { int e = a < 0 ? -a - 1 : (a >= D ? 2 * D - a - 1 : a); return min(max(e, 0), D - 1); };
+        const int el = mir(org.x + lane);
+        T v[17];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int e = min(e0 + u * 256, XH_PCW * XH_PCW - 1);
-            const int m = org.y + e / XH_PCW, l = org.x + e % XH_PCW;
-            int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
-            em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
-            v[u] = c[(size_t)em * D + el];
+        for (int k = 0; k < 17; ++k) v[k] = c[(unsigned)(mir(org.y + wv + 4 * k) * D + el)];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) sC[(wv + 4 * k) * XH_PCW + lane] = v[k];
+        T v2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = threadIdx.x + 256 * u;                    // 68 rows x 4 columns = 272 elements
+            v2[u] = t < 4 * XH_PCW ? c[(unsigned)(mir(org.y + (t >> 2)) * D + mir(org.x + 64 + (t & 3)))] : (T)0;
         }
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            if (e0 + u * 256 < XH_PCW * XH_PCW) sC[e0 + u * 256] = v[u];
+        for (int u = 0; u < 2; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            if (t < 4 * XH_PCW) sC[(t >> 2) * XH_PCW + 64 + (t & 3)] = v2[u];
+        }
     }
     __syncthreads();
     double sw = 0, swv = 0, swv2 = 0;
@@ -256,6 +266,7 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
     // four samples per thread and step: their 16-byte records (x, y, sample index, ring) first, then the ring weights,
     // then the interpolation (the one-sample loop waited out a chain of four dependent loads per sample)
     const int qEnd = cellStart[cell + 1];
+    T *polarSlot = polar + (size_t)slot * nsamples;
     for (int q0 = cellStart[cell] + threadIdx.x; q0 < qEnd; q0 += 4 * 256) {
         float4 rec[4];
         double wr[4];
@@ -270,10 +281,19 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
             const T x = (T)rec[u].x - start, y = (T)rec[u].y - start;
             const int l1 = (int)ceil(x - (T)2), m1 = (int)ceil(y - (T)2);
             T wx[4], wy[4];
-            d_bspline03_w4<T>(x, l1, wx);
-            d_bspline03_w4<T>(y, m1, wy);
+            d_bspline03_w4_coarse<T>(x, l1, wx);
+            d_bspline03_w4_coarse<T>(y, m1, wy);
             const T *base = sC + (m1 - org.y) * XH_PCW + (l1 - org.x);
             T columns = 0;
+            if constexpr (sizeof(T) == 4) {
+                // the coarse pass: polynomial weights, fused multiply-adds written out (see k_pm_tr_build)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float *row = base + t * XH_PCW;
+                    const float rows = __builtin_fmaf(row[3], wx[3], __builtin_fmaf(row[2], wx[2], __builtin_fmaf(row[1], wx[1], row[0] * wx[0])));
+                    columns = t ? __builtin_fmaf(rows, wy[t], columns) : rows * wy[0];
+                }
+            } else
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const T *row = base + t * XH_PCW;
@@ -282,7 +302,7 @@ k_pm_polar_cells(const T *__restrict__ coefs, T *__restrict__ polar, const float
                 for (int v = 0; v < 4; ++v) rows += row[v] * wx[v];
                 columns += rows * wy[t];
             }
-            polar[(size_t)slot * nsamples + i] = columns;
+            polarSlot[i] = columns;
             const double w = wr[u];
             const double dv = (double)columns;
             sw += w; swv += w * dv; swv2 += w * dv * dv;
@@ -2373,25 +2393,38 @@ k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoe
     const int lmin = (int)ceil(xpc - ext - 2.0) - 1, mmin = (int)ceil(ypc - ext - 2.0) - 1;
     if (ref >= 0) {
         const TC *coef = refCoef + (size_t)ref * D * D;
-        // four loads in flight per thread (written out: the plain loop compiles to load - wait - store)
-        for (int e0 = tid; e0 < XH_TRBW * XH_TRBW; e0 += 4 * 256) {
-            TC v[4];
+        // thread <-> (patch column tid % 64, patch rows tid / 64 + 4 k): the column's mirror index once per thread, a row's per load,
+        // all of the thread's loads in flight before the first store (the element-by-element form spent 27 vector instructions per
+        // element on index arithmetic -- 73 per output pixel, half as many as the interpolation itself)
+        static_assert(XH_TRBW <= 64, "patch columns per wave");
+        const int lc = tid & 63, mr = tid >> 6;
+        if (lc < XH_TRBW) {
+            const int l = lmin + lc;
+            int el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
+            el = min(max(el, 0), D - 1);
+            constexpr int NR = (XH_TRBW + 3) / 4;
+            TC v[NR];
+            if (mmin >= 0 && mmin + XH_TRBW + 3 <= D) {          // (block-uniform) every row of the patch lies inside the image
+                const TC *c0 = coef + (unsigned)((mmin + mr) * D + el);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * 256, XH_TRBW * XH_TRBW - 1);
-                const int m = mmin + e / XH_TRBW, l = lmin + e % XH_TRBW;
+                for (int k = 0; k < NR; ++k) v[k] = c0[(unsigned)(4 * k * D)];
+            } else
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int m = mmin + min(mr + 4 * k, XH_TRBW - 1);
                 // mirror indices of interpolatedElementBSpline2D; taps further out than one mirror image are never used
-                int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m), el = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l);
-                em = min(max(em, 0), D - 1); el = min(max(el, 0), D - 1);
-                v[u] = coef[(size_t)em * D + el];
+                int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
+                em = min(max(em, 0), D - 1);
+                v[k] = coef[(unsigned)(em * D + el)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e0 + u * 256 < XH_TRBW * XH_TRBW) sC[e0 + u * 256] = (T)v[u];
+            for (int k = 0; k < NR; ++k)
+                if (mr + 4 * k < XH_TRBW) sC[(mr + 4 * k) * XH_TRBW + lc] = (T)v[k];
         }
     }
     __syncthreads();
     const float *img = particles + (size_t)p * D * D;
+    xh_c2<T> *zp = z + (size_t)p * D * D;
     const bool fl = flip[p] != 0;
     const int j = tj0 + (tid & (XH_TRB - 1));
     // the particle's pixels first: four independent loads in flight under the interpolation
@@ -2406,7 +2439,7 @@ k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoe
 #pragma unroll
     for (int k = 0; k < XH_TRB * XH_TRB / 256; ++k) {
         const int i = ti0 + (tid / XH_TRB) + (256 / XH_TRB) * k;
-        pix[k] = pixOk ? img[(size_t)i * D + jsrc] : 0.f;
+        pix[k] = pixOk ? img[(unsigned)(i * D + jsrc)] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < XH_TRB * XH_TRB / 256; ++k) {
@@ -2421,10 +2454,20 @@ k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoe
                 yp -= (T)(-cen);
                 const int l1 = (int)ceil(xp - (T)2), m1 = (int)ceil(yp - (T)2);
                 T wx[4], wy[4];
-                d_bspline03_w4<T>(xp, l1, wx);
-                d_bspline03_w4<T>(yp, m1, wy);
+                d_bspline03_w4_coarse<T>(xp, l1, wx);
+                d_bspline03_w4_coarse<T>(yp, m1, wy);
                 const T *base = sC + (m1 - mmin) * XH_TRBW + (l1 - lmin);
                 T columns = 0;
+                if constexpr (sizeof(T) == 4) {
+                    // the coarse pass: fused multiply-adds written out (left alone, the compiler pairs the products into packed
+                    // multiplies and adds them one by one: 35 instead of 20 operations)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float *row = base + t * XH_TRBW;
+                        const float rows = __builtin_fmaf(row[3], wx[3], __builtin_fmaf(row[2], wx[2], __builtin_fmaf(row[1], wx[1], row[0] * wx[0])));
+                        columns = t ? __builtin_fmaf(rows, wy[t], columns) : rows * wy[0];
+                    }
+                } else
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const T *row = base + t * XH_TRBW;
@@ -2436,7 +2479,7 @@ k_pm_tr_build(const float *__restrict__ particles, const TC *__restrict__ refCoe
                 out.x = columns;
             }
         }
-        z[((size_t)p * D + i) * D + j] = out;
+        zp[(unsigned)(i * D + j)] = out;
     }
 }
 

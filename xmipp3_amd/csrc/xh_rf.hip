@@ -262,6 +262,7 @@ struct xh_rf {
     int grid_tile_budget = 0;   // tiles a workgroup of the gridding kernel processes before it retires; 0: persistent workgroups, one per CU
     int ntiles[2] = {0, 0};
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
+    int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
     int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)
 };
 
@@ -453,6 +454,10 @@ k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
 struct XhCtfDev {
     double K1, K2, K3, K5, K6, K7, Ksin, Kcos, rad_azimuth, defocus_average, defocus_deviation;
     double DeltaR, K, envR0, envR1, envR2, phase_shift, VPP_radius;
+    // d_ctf_pixel_fast (filled by ctf_params_upload; fast == 0: the general formula only):
+    //   Ksin sin(a) - Kcos cos(a) = amp sin(a - phi);  E = E0 + envR2 u^2;  cos / sin of twice the azimuth
+    double amp = 0, phi = 0, E0 = 0, c2az = 0, s2az = 0;
+    int fast = 0, pad_ = 0;
 };
 // ---- register-blocked variants of k_rf_rows / k_rf_cols for P = R1*R2 (xh_fftreg.h) ---------------
 // Same arithmetic contract (pad about the Xmipp origin, CenterFFT, forward FFT, crop, 1/P^2), one LDS
@@ -705,6 +710,71 @@ __device__ __forceinline__ void d_ctf_pixel(const XhCtfDev &c, int x, int y, int
     ctfOut = CTFVal;
     modOut = modulatorVal;
 }
+// The same pixel for the CTFs most particles carry -- no envelope terms, no phase plate (fast != 0) --, an order of
+// magnitude cheaper: Ksin sin(a) - Kcos cos(a) is ONE sinusoid amp sin(a - phi); its argument is formed and reduced to
+// [-pi/2, pi/2] in double (the argument reaches hundreds of radians), the sine of the reduced argument is a float
+// polynomial (relative error 1.2e-7, also next to the zeros of the CTF, where 1 / CTF amplifies absolute errors), the
+// astigmatic defocus needs no atan2 / cos: cos(2 (theta - az)) u^2 = (X^2 - Y^2) cos 2az + 2 X Y sin 2az.  The value is a
+// float in the reference too (RFA:566); it differs from the general formula's by float rounding (2e-7 relative).  The
+// one discontinuous decision, |CTF| < minCTF, is never taken on such a value: within 1e-5 of the threshold (and for
+// anything that is not finite) the function returns false and the caller evaluates the general formula.
+__device__ __forceinline__ bool d_ctf_pixel_fast(const XhCtfDev &c, int x, int y, int P, double iTs, double minCTF, int phaseFlipped,
+                                                 float &ctfOut, float &modOut)
+{
+    const bool pow2 = (P & (P - 1)) == 0;
+    const float freqY = pow2 ? (y - (P / 2.f)) * (1.0f / (float)P) : (y - (P / 2.f)) / (float)P;
+    const double xr = (double)(x <= P / 2 ? x : x - P);
+    const float freqX = (float)(pow2 ? xr * (1.0 / (double)P) : xr / (double)P);
+    const double X = freqX * iTs, Y = freqY * iTs;
+    const double X2 = X * X, Y2 = Y * Y;
+    const double u2 = X2 + Y2;
+    double dfu2;                                             // deltaf u^2
+    if (fabs(X) < 1e-6 && fabs(Y) < 1e-6) dfu2 = 0;
+    else if (c.defocus_deviation == 0) dfu2 = c.defocus_average * u2;
+    else dfu2 = c.defocus_average * u2 + c.defocus_deviation * ((X2 - Y2) * c.c2az + 2.0 * (X * Y) * c.s2az);
+    const double a = fma(c.K1, dfu2, fma(c.K2 * u2, u2, -c.phi));
+    const double n = rint(a * 0.31830988618379067154);
+    double r = fma(-n, 3.141592653589793116, a);
+    r = fma(-n, 1.2246467991473532e-16, r);
+    const float rf = (float)r, t = rf * rf;
+    float p = -2.3866480347578545e-08f;
+    p = __builtin_fmaf(p, t, 2.7523994958755793e-06f);
+    p = __builtin_fmaf(p, t, -0.00019840836466755718f);
+    p = __builtin_fmaf(p, t, 0.008333330973982811f);
+    p = __builtin_fmaf(p, t, -0.1666666716337204f);
+    float sn = __builtin_fmaf(rf * t, p, rf);
+    if (((long long)n) & 1) sn = -sn;
+    double E = c.E0 + c.envR2 * u2;
+    if (E < 0) E = 0;
+    float CTFVal = (float)((-(c.K * c.K) * c.amp * E) * (double)sn);
+    const double mag = fabs((double)CTFVal);
+    if (!(fabs(mag - minCTF) > 1e-5 * minCTF) || !(mag < 1e30)) return false;       // (NaN compares false: general path)
+    float modulatorVal = 1.f;
+    if (mag < minCTF) {
+        modulatorVal = fabsf(CTFVal);
+        CTFVal = (CTFVal >= 0) ? 1.f : -1.f;
+    } else CTFVal = 1.0f / CTFVal;
+    if (phaseFlipped) CTFVal = fabsf(CTFVal);
+    ctfOut = CTFVal;
+    modOut = modulatorVal;
+    return true;
+}
+// (a real call: inlined, the general formula's double-precision sincos / exp / Bessel code sets the register budget of every kernel
+// that evaluates a CTF -- 178 registers and two waves per SIMD for the row pass of the FFT that packs the records)
+__device__ __attribute__((noinline)) void d_ctf_pixel_call(const XhCtfDev &c, int x, int y, int P, double iTs, double minCTF, int phaseFlipped,
+                                                           float &ctfOut, float &modOut)
+{
+    d_ctf_pixel(c, x, y, P, iTs, minCTF, phaseFlipped, ctfOut, modOut);
+}
+// what the kernels call: the fast form where the image's CTF allows it (block-uniform), the general formula for the rest
+template <bool CALL = false>
+__device__ __forceinline__ void d_ctf_eval(const XhCtfDev &c, int x, int y, int P, double iTs, double minCTF, int phaseFlipped,
+                                           float &ctfOut, float &modOut)
+{
+    if (c.fast && d_ctf_pixel_fast(c, x, y, P, iTs, minCTF, phaseFlipped, ctfOut, modOut)) return;
+    if (CALL) d_ctf_pixel_call(c, x, y, P, iTs, minCTF, phaseFlipped, ctfOut, modOut);
+    else d_ctf_pixel(c, x, y, P, iTs, minCTF, phaseFlipped, ctfOut, modOut);
+}
 // thread per pixel of the rows at or above the DC row; its mirror row (-freqY) is written by the same thread: a
 // non-astigmatic CTF depends on (X, Y) through X*X + Y*Y only, so the value is the same bit for bit and is computed once
 __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ctf, float *__restrict__ mod,
@@ -722,14 +792,14 @@ __global__ void k_rf_ctf(const XhCtfDev *__restrict__ cp, float *__restrict__ ct
     float cv = 0.f, mv_ = 0.f;
     bool have = false;
     if (y1 < sizeY) {
-        d_ctf_pixel(c, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        d_ctf_eval(c, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
         ctf[base + (size_t)y1 * sizeX + x] = cv;
         mod[base + (size_t)y1 * sizeX + x] = mv_;
         have = true;
     }
     if (k > 0 && y2 >= 0 && y2 < sizeY) {
         // rows dc+k and dc-k have opposite freqY only for even P (freqY = (y - P/2)/P)
-        if (!(have && c.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_pixel(c, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        if (!(have && c.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_eval(c, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
         ctf[base + (size_t)y2 * sizeX + x] = cv;
         mod[base + (size_t)y2 * sizeX + x] = mv_;
     }
@@ -820,13 +890,13 @@ k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, XgCell *__restr
                 float cv = 0.f, mv_ = 0.f;
                 float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
                 if (in1) {
-                    d_ctf_pixel(par, j, r1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+                    d_ctf_eval<true>(par, j, r1, P, iTs, minCTF, phaseFlipped, cv, mv_);
                     const float mw = mv_ * w;
                     v1 = make_float4(o1.x * mw * cv, o1.y * mw * cv, mw, 0.f);
                 }
                 if (in2) {
                     // rows sizeX + k and sizeX - k have opposite freqY (sizeX = P / 2, P even): see k_rf_ctf
-                    if (!(in1 && par.defocus_deviation == 0)) d_ctf_pixel(par, j, r2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+                    if (!(in1 && par.defocus_deviation == 0)) d_ctf_eval<true>(par, j, r2, P, iTs, minCTF, phaseFlipped, cv, mv_);
                     const float mw = mv_ * w;
                     v2 = make_float4(o2.x * mw * cv, o2.y * mw * cv, mw, 0.f);
                 }
@@ -1361,6 +1431,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "grid_waves")) rf->grid_waves = (int)value;
     else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(0, (int)value);
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
+    else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
@@ -1630,6 +1701,13 @@ static int ctf_params_upload(xh_rf *rf, const xh_ctf_params *h_ctf, int n)
         d.defocus_deviation = -(c.DeltafU - c.DeltafV) * 0.5;
         d.DeltaR = c.DeltaR; d.K = c.K; d.envR0 = c.envR0; d.envR1 = c.envR1; d.envR2 = c.envR2;
         d.phase_shift = c.phase_shift; d.VPP_radius = c.VPP_radius;
+        // d_ctf_pixel_fast: no phase plate, no energy spread / focal spread / convergence cone / DeltaR term, no envR1 (which needs u)
+        d.amp = std::hypot(d.Ksin, d.Kcos);
+        d.phi = std::atan2(d.Kcos, d.Ksin);
+        d.E0 = 57568490574.0 / 57568490411.0 + c.envR0;      // the J0(0) quotient of d_ctf_pixel
+        d.c2az = std::cos(2 * d.rad_azimuth); d.s2az = std::sin(2 * d.rad_azimuth);
+        d.fast = rf->ctf_fast && std::round(c.VPP_radius * 1000) == 0 && d.K3 == 0 && d.K5 == 0 && d.K6 == 0 && c.DeltaR == 0 && c.envR1 == 0
+                 && std::isfinite(d.amp) && std::isfinite(d.E0) && rf->p.min_ctf > 0;
     }
     XH_TRY(xh_buf_reserve(ctx, rf->d_ctfp, sizeof(XhCtfDev) * n));
     XH_TRY(stage_upload(rf, rf->d_ctfp.p, hc.data(), sizeof(XhCtfDev) * n));

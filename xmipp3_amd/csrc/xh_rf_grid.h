@@ -166,13 +166,13 @@ k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ 
     float cv = 0.f, mv_ = 0.f;
     float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
     if (in1) {
-        d_ctf_pixel(par, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        d_ctf_eval(par, x, y1, P, iTs, minCTF, phaseFlipped, cv, mv_);
         const float mw = mv_ * w;
         v1 = make_float4(f1.x * mw * cv, f1.y * mw * cv, mw, 0.f);
     }
     if (in2) {
         // rows dc+k and dc-k have opposite freqY only for even P (freqY = (y - P/2)/P)
-        if (!(in1 && par.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_pixel(par, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
+        if (!(in1 && par.defocus_deviation == 0 && (P & 1) == 0)) d_ctf_eval(par, x, y2, P, iTs, minCTF, phaseFlipped, cv, mv_);
         const float mw = mv_ * w;
         v2 = make_float4(f2.x * mw * cv, f2.y * mw * cv, mw, 0.f);
     }
