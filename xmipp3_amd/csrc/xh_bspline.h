@@ -353,18 +353,29 @@ k_pm_prefilter_rec2d(const float *__restrict__ in, float *__restrict__ out, int 
     const float *src = in + base;
     // the tile spans the image's rows: the halo columns are mirror images of columns the block filters anyway
     const bool full = tilesX == 1 && D >= 2 * K;
-    for (int xx = tid; xx < TW + 2 * K; xx += 256) {
+    auto refl = [D](int a) { const int b = a < 0 ? -1 - a : (a >= D ? 2 * D - 1 - a : a); return min(max(b, 0), D - 1); };
+    // a tile the image does not fill: the row pass's windows reach columns no thread filters; whatever the LDS held there (NaN
+    // bit patterns included) would enter the backward recursion, so they start as zeros
+    if (x0 + TW > D) {
+        for (int e = tid; e < V * S; e += 256) tile[e] = 0.f;
+        __syncthreads();
+    }
+    // (full: thread <-> image column, one round; otherwise the halo columns either side are filtered too, a second round for 28 lanes)
+    const int xbeg = full ? K : 0, xend = full ? K + min(D, TW) : TW + 2 * K;
+    for (int xx = xbeg + tid; xx < xend; xx += 256) {
         int p = x0 + xx - K;
         if (p >= D + K) break;                          // beyond the halo of the last, partial tile
-        if (full && (p < 0 || p >= D)) continue;
-        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i (repeated for tiny images)
-        while (p < 0 || p >= D) p = p < 0 ? -1 - p : 2 * D - 1 - p;
+        // half-sample-symmetric extension: -1-i <-> i, D+i <-> D-1-i. One reflection and a clamp: the launcher keeps D >= 32, so a
+        // row that would need a second reflection lies 32 or more rows beyond the last output of the tile (z^32 = 5e-19)
+        p = refl(p);
         float w[NW];
+        if (y0 >= K && y0 + V + K <= D) {                  // (block-uniform) every row of the window lies inside the image
+            const float *c0 = src + (unsigned)((y0 - K) * D + p);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            int q = y0 + i - K;
-            while (q < 0 || q >= D) q = q < 0 ? -1 - q : 2 * D - 1 - q;
-            w[i] = src[(size_t)q * D + p];
+            for (int i = 0; i < NW; ++i) w[i] = c0[(unsigned)(i * D)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = src[(unsigned)(refl(y0 + i - K) * D + p)];
         }
 #pragma unroll
         for (int i = 1; i < NW; ++i) w[i] = __builtin_fmaf(z, w[i - 1], w[i]);
