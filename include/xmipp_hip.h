@@ -422,7 +422,13 @@ int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor
 int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: every pair correlation through the full inverse transform (A/B);
                                                                   "prefilter_ahead" 1: xh_fa_local_alignment ends with the warp's B-spline prefilter of every frame
                                                                   (N Y X floats kept with the handle), run while the host fits the spline; the following
-                                                                  xh_fa_apply_bspline[_frames] calls on the same frames (without an initial sum) use it */
+                                                                  xh_fa_apply_bspline[_frames] calls on the same frames (without an initial sum) use it.
+                                                                  CONTRACT: the frames are recognised by their device address (d_frames, d_dark, d_gain, N): a caller
+                                                                  that rewrites d_frames in place after xh_fa_local_alignment must call it (or xh_fa_global_alignment)
+                                                                  again, or switch the option off, before warping. When the device cannot spare the N Y X floats
+                                                                  the option silently does nothing (the warp prefilters frame by frame).
+                                                                  Control grids: a layer of lX x lY control points must fit 64 KB of LDS (lX lY <= 2048), else
+                                                                  xh_fa_apply_bspline fails with XH_ERR_UNSUPPORTED */
 int xh_fa_last_full_pairs(const xh_fa *h);                        /* pairs of the last global alignment that needed the full transform */
 int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const float *d_dark, const float *d_gain, float max_shift_px,
                            double *h_bX, double *h_bY, double *h_shiftX, double *h_shiftY, int32_t *h_ref);

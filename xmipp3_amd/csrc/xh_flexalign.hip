@@ -708,6 +708,104 @@ __global__ void __launch_bounds__(256) k_fa_prefilter(const float *__restrict__ 
     }
 }
 
+// The same filter in its recursive form (xh_bspline.h, k_pm_prefilter_rec2d: three operations per output and axis instead of 33, a
+// run of 32 outputs entered 14 samples early on either side), for frames: a block owns 32 rows x 224 columns, so that the columns it
+// filters -- 14 halo columns either side -- are 252, one per thread; along the rows thread <-> (row, 32 columns) out of an LDS tile
+// whose rows lie 324 floats apart (the sixteen lanes of a ds_read_b128 on sixteen rows = all banks); the results go back through the
+// tile and leave as whole rows.
+#define XH_FA_REC_TW 224
+__global__ void __launch_bounds__(256) k_fa_prefilter_rec(const float *__restrict__ in, const float *__restrict__ dark, const float *__restrict__ gain,
+                                                          float *__restrict__ out, float *__restrict__ plain, int Y, int X, int tilesX)
+{
+    constexpr int K = XH_REC_K, V = XH_REC_V, S = XH_REC_S, NW = V + 2 * K, TW = XH_FA_REC_TW;
+    static_assert(TW + 2 * K <= 256 && TW % 32 == 0 && S >= TW + 2 * K, "one column per thread");
+    __shared__ __align__(16) float tile[V * S];
+    const float z = -0.26794919243112270647f, zend = z / (z - 1.f);
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x0 = tx * TW, y0 = ty * V;
+    if (x0 + TW + K > X) {                               // a tile the frame does not fill: see k_pm_prefilter_rec2d
+        for (int e = tid; e < V * S; e += 256) tile[e] = 0.f;
+        __syncthreads();
+    }
+    auto reflX = [X](int a) { const int b = a < 0 ? -1 - a : (a >= X ? 2 * X - 1 - a : a); return min(max(b, 0), X - 1); };
+    auto reflY = [Y](int a) { const int b = a < 0 ? -1 - a : (a >= Y ? 2 * Y - 1 - a : a); return min(max(b, 0), Y - 1); };
+    if (tid < TW + 2 * K && x0 + tid - K < X + K) {
+        const int pu = x0 + tid - K, p = reflX(pu);
+        float w[NW];
+        const bool inside = y0 >= K && y0 + V + K <= Y;   // (block-uniform) every row of the window lies inside the frame
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const size_t src = (size_t)(inside ? y0 - K + i : reflY(y0 + i - K)) * X + p;
+            float v = in[src];
+            if (dark) v -= dark[src];
+            if (gain) v *= gain[src];
+            w[i] = v;
+        }
+        if (plain && tid >= K && tid < K + TW && pu < X) {
+#pragma unroll
+            for (int o = 0; o < V; ++o)
+                if (y0 + o < Y) plain[(size_t)(y0 + o) * X + pu] += w[o + K];
+        }
+#pragma unroll
+        for (int i = 1; i < NW; ++i) w[i] = __builtin_fmaf(z, w[i - 1], w[i]);
+        float a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            if (i < V + K) tile[(i - K) * S + tid] = 6.f * a;
+        }
+    }
+    __syncthreads();
+    const int r = tid & (V - 1), sg = tid >> 5;
+    float w[NW];
+    if (sg < TW / 32) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(&tile[r * S + 32 * sg]);
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) {
+            const float4 q = t4[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+#pragma unroll
+        for (int i = 1; i < NW; ++i) w[i] = __builtin_fmaf(z, w[i - 1], w[i]);
+        float a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            w[i] = 6.f * a;
+        }
+    }
+    __syncthreads();                                    // every window has been read
+    if (sg < TW / 32) {
+        float4 *t4 = reinterpret_cast<float4 *>(&tile[r * S + 32 * sg]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t4[i] = make_float4(w[K + 4 * i], w[K + 4 * i + 1], w[K + 4 * i + 2], w[K + 4 * i + 3]);
+    }
+    __syncthreads();
+    const bool vec = (X & 3) == 0;
+    for (int e = tid; e < V * (TW / 4); e += 256) {
+        const int rr = e / (TW / 4), c4 = e - rr * (TW / 4);
+        const int y = y0 + rr, x = x0 + 4 * c4;
+        if (y >= Y || x >= X) continue;
+        const float4 q = *reinterpret_cast<const float4 *>(&tile[rr * S + 4 * c4]);
+        float *dst = out + (size_t)y * X + x;
+        if (vec) *reinterpret_cast<float4 *>(dst) = q;
+        else { dst[0] = q.x; if (x + 1 < X) dst[1] = q.y; if (x + 2 < X) dst[2] = q.z; if (x + 3 < X) dst[3] = q.w; }
+    }
+}
+// which form the frames' prefilter takes: the recursion (default) or the 33-tap convolution (XH_PREFILTER_FORM=0, A/B)
+static void fa_prefilter_launch(hipStream_t stream, const float *in, const float *dark, const float *gain, float *out, float *plain, int Y, int X)
+{
+    if (xh_prefilter_form() == 1 && Y >= 32 && X >= 32) {
+        const int tilesX = (X + XH_FA_REC_TW - 1) / XH_FA_REC_TW, tilesY = (Y + XH_REC_V - 1) / XH_REC_V;
+        hipLaunchKernelGGL(k_fa_prefilter_rec, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, stream, in, dark, gain, out, plain, Y, X, tilesX);
+        return;
+    }
+    const XhFir F = xh_fir_taps();
+    const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
+    hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, stream, in, dark, gain, out, plain, Y, X, tilesX, F);
+}
+
 __device__ __forceinline__ float d_fa_b3(float x)
 {
     // bspline03, reconstruction_cuda/cuda_gpu_bilib.cu:16-25
@@ -793,6 +891,7 @@ __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef,
 // four neighbours C[x0 .. x0 + 3] as one 16-byte record -- so a (layer, row) pair costs two ds_read_b128 (X and Y field; the lanes of a
 // wave share the cell almost always: a broadcast) instead of eight ds_read_b32, and the 1e-4 cut multiplies a dropped term by zero
 // instead of branching around it (sx + C * 0 = sx).  Same terms, same order (layer, column, row), same products bY (bX bT).
+#define XH_FA_WARP_RG 8
 __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__ coef, const float *__restrict__ cX, const float *__restrict__ cY, int lX, int lY, int lT,
                                                        float hX, float hY, float tPos, int Y, int X, float *__restrict__ out, float *__restrict__ sum)
 {
@@ -807,8 +906,13 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
         sqY[i] = make_float4(py[0], py[1], py[2], py[3]);
     }
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= X || y >= Y) return;
+    // XH_FA_WARP_RG groups of four rows per block: the quads are staged once for 64 x 4 XH_FA_WARP_RG pixels (with one group a block
+    // spent more time staging them and waiting at the barrier than on its 256 pixels)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (x >= X) return;
+    for (int rg = 0; rg < XH_FA_WARP_RG; ++rg) {
+    const int y = (blockIdx.y * XH_FA_WARP_RG + rg) * 4 + (threadIdx.x >> 6);
+    if (y >= Y) break;
     const float delta = 0.0001f;
     const float xPos = x / hX, yPos = y / hY;
     const int xi = (int)xPos, yi = (int)yPos;                 // first control column / row of the pixel: xB + 1, yB + 1
@@ -861,6 +965,7 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
     const size_t o = (size_t)y * X + x;
     if (out) out[o] = columns;
     if (sum) sum[o] += columns;
+    }
 }
 
 // ---- host: EquationSystemSolver::solve + computeAlignment ------------------------------------------------------------------
@@ -1459,14 +1564,12 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     h->aheadBase = nullptr;
     if (rc == XH_OK && h->prefilter_ahead) {
         // the warp's prefilter of every frame, behind the results' copy: runs while the host solves below
+        // (N Y X floats, 3.8 GB for a K3 movie: when the device cannot spare them the warp prefilters frame by frame as it always could)
         XhBuf *pCoef = nullptr;
-        rc = fa_scratch(h, "w_coefAll", sizeof(float) * (size_t)N * Y * X, &pCoef);
-        if (rc == XH_OK) {
-            const XhFir F = xh_fir_taps();
-            const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
+        if (fa_scratch(h, "w_coefAll", sizeof(float) * (size_t)N * Y * X, &pCoef) != XH_OK) { (void)hipGetLastError(); pCoef = nullptr; }
+        if (pCoef) {
             for (int n = 0; n < N; ++n)
-                hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * Y * X, d_dark, d_gain,
-                                   (float *)pCoef->p + (size_t)n * Y * X, (float *)nullptr, Y, X, tilesX, F);
+                fa_prefilter_launch(ctx->stream, d_frames + (size_t)n * Y * X, d_dark, d_gain, (float *)pCoef->p + (size_t)n * Y * X, (float *)nullptr, Y, X);
             if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
             else { h->aheadBase = d_frames; h->aheadDark = d_dark; h->aheadGain = d_gain; h->aheadN = N; }
         }
@@ -1595,20 +1698,22 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
                        h->cache.count("w_coefAll");
     if (ahead) coef = (float *)h->cache["w_coefAll"].p + (size_t)n * Y * X;
     else {
-        const XhFir F = xh_fir_taps();
-        const int tilesX = (X + 255) / 256, tilesY = (Y + XH_FIR_V - 1) / XH_FIR_V;
-        hipLaunchKernelGGL(k_fa_prefilter, dim3((unsigned)(tilesX * tilesY)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, coef, d_initial_sum, Y, X, tilesX, F);
+        fa_prefilter_launch(ctx->stream, d_frame, d_dark, d_gain, coef, d_initial_sum, Y, X);
     }
     if (d_out || d_sum) {
         // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
         const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
         const float tPos = n / hT;
         static const bool plain = getenv("XH_FA_WARP_PLAIN") != nullptr;        // A/B runs
-        if (lX >= 4 && lY >= 4 && !plain)
-            hipLaunchKernelGGL(k_fa_warp_quads, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), sizeof(float4) * 2 * 4 * (lX - 3) * lY, ctx->stream, (const float *)coef,
+        // dynamic LDS of the two forms: four layers of quads (16 bytes per control row and first column, both fields) or of plain control
+        // points; a control grid whose quads do not fit 64 KB takes the plain kernel, one that fits neither is refused
+        const size_t ldsQuads = sizeof(float4) * 2 * 4 * (size_t)(lX - 3) * lY, ldsPlain = sizeof(float) * 2 * 4 * (size_t)lX * lY;
+        XH_CHECK(ldsPlain <= 64 * 1024, XH_ERR_UNSUPPORTED, "xh_fa_apply_bspline: %d x %d control points per layer exceed the 64 KB of LDS the warp kernel stages them in", lX, lY);
+        if (lX >= 4 && lY >= 4 && !plain && ldsQuads <= 64 * 1024)
+            hipLaunchKernelGGL(k_fa_warp_quads, dim3((X + 63) / 64, (Y + 4 * XH_FA_WARP_RG - 1) / (4 * XH_FA_WARP_RG)), dim3(256), ldsQuads, ctx->stream, (const float *)coef,
                                (const float *)h->warpC.p, (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
         else
-        hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), sizeof(float) * 2 * 4 * lX * lY, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
+        hipLaunchKernelGGL(k_fa_warp, dim3((X + 63) / 64, (Y + 3) / 4), dim3(256), ldsPlain, ctx->stream, (const float *)coef, (const float *)h->warpC.p,
                            (const float *)h->warpC.p + Cc, lX, lY, lT, hX, hY, tPos, Y, X, d_out, d_sum);
     }
     XH_LAUNCH_CHECK();

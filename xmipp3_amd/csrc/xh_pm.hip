@@ -122,6 +122,8 @@ struct xh_pm {
     hipEvent_t ev[6];
     double stage_ms[8];   // prep32, contract, idft_max, select, rescore(fp64), translate
     int use_idft3, use_mfma, contract_dbg, use_fir;
+    int store_cut;               // S2 of a bank that is not band limited: frequencies whose coefficients are kept for S3 (0: none, bounds only; -1: all, rounds 1-4)
+    int contract_shape;          // S2: particle x reference tiles per workgroup of k_pm_contract_mfma as a two-digit number (14, 22, 24, 42, 44)
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
     int s6_coarse_kernel;        // S6: the fp32 pass ends in k_pm_bestshift_coarse (0: k_pm_bestshift<float>, A/B)
@@ -770,13 +772,19 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
 // block = 4 waves = 4 reference tiles
 #define XH_PW2 1
 #define XH_KSPLIT 8        // the frequency range is cut into slices of equal work: more waves in flight
-__global__ void __launch_bounds__(256)
+// PT x QT waves per workgroup: wave (i, j) owns particle tile blockIdx.y PT + i and reference tile blockIdx.x QT + j. The operands
+// come straight from global memory (no LDS): what the waves of a workgroup share -- an A tile among the QT waves of a row, a B tile
+// among the PT waves of a column -- is served by the CU's L1, so the L2 delivers (PT + QT) tiles per PT QT products: 1.25 per
+// product for the 1 x 4 workgroup of rounds 1-4, 0.5 for 4 x 4 (the full-frequency contraction moved 106 GB through the L2s per
+// 4096 particles x 1000 references and was bound by exactly that).
+template <int PT, int QT>
+__global__ void __launch_bounds__(64 * PT * QT)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
                    const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
-                   int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart, int rawStride)
+                   int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart, int rawStride, int kStore)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qtile = blockIdx.x * 4 + wv, ptile0 = blockIdx.y * XH_PW2;
+    const int qtile = blockIdx.x * QT + wv % QT, ptile0 = (blockIdx.y * PT + wv / QT) * XH_PW2;
     const int kBeg = kbounds[blockIdx.z], kEnd = kbounds[blockIdx.z + 1];
     if (qtile >= nqtiles) return;
     const float4 *A[XH_PW2];
@@ -870,8 +878,9 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                         o0 = make_float4(theirs[0][0], mine[2][0], theirs[0][1], mine[2][1]);
                         o1 = make_float4(theirs[1][0], mine[3][0], theirs[1][1], mine[3][1]);
                     }
-                    if (kA < kEnd) dst[kA] = o0;
-                    if (kA + 1 < kEnd) dst[kA + 1] = o1;
+                    // (kStore < kEnd: the contraction runs for the bounds alone -- S3 contracts the few rows that survive them once more)
+                    if (kA < kEnd && kA < kStore) dst[kA] = o0;
+                    if (kA + 1 < kEnd && kA + 1 < kStore) dst[kA + 1] = o1;
                     if (bpart) {
                         if (kA < kEnd) modulus(o0, kA, bndS[t][g][h2], bndM[t][g][h2]);
                         if (kA + 1 < kEnd) modulus(o1, kA + 1, bndS[t][g][h2], bndM[t][g][h2]);
@@ -3279,6 +3288,8 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
     pm->use_fir = 1;
+    pm->contract_shape = 14;
+    pm->store_cut = 0;
     pm->use_fir64 = 1;
     pm->contract_dbg = 0;
     pm->tie_rel = 1e-12;
@@ -3624,6 +3635,8 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
         XH_TRY(set_k0(pm, value <= 0 ? pm->K0auto : (int)value));
     }
     else if (!strcmp(name, "use_fir")) pm->use_fir = (int)value;
+    else if (!strcmp(name, "contract_shape")) pm->contract_shape = (int)value;
+    else if (!strcmp(name, "store_cut")) pm->store_cut = (int)value;
     else if (!strcmp(name, "use_fir64")) pm->use_fir64 = (int)value;
     else if (!strcmp(name, "contract_dbg")) pm->contract_dbg = (int)value;
     else { xh_set_error("xh_pm_set_option: unknown option %s", name); return XH_ERR_ARG; }
@@ -3714,11 +3727,16 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     XH_CHECK(!d_mask || pruning, XH_ERR_STATE, "xh_pm_match: internal error, a masked search must take the pruning path");
     if (pruning) XH_TRY(xh_buf_reserve(ctx, pm->d_bpart, sizeof(float2) * (size_t)XH_KSPLIT * nrows));
     const int K0 = pruning ? pm->K0 : L.nk;          // two-level S2 needs the bounds
-    const int rawStride = std::min(K0, L.nk);
-    XH_TRY(xh_buf_reserve(ctx, pm->d_raw, sizeof(float4) * (size_t)nrows * rawStride));
+    // A bank that is not band limited (K0 = nk) is contracted at every frequency -- the branch and bound needs the sums of moduli --
+    // but its coefficients are not kept: 16 bytes x nk x rows (26 GB for 4096 particles x 1000 references) were written for the
+    // 0.1-0.6 % of the rows the bounds let through, and writing them was half of the kernel's time. S3 contracts those rows itself
+    // (d_row_high from frequency store_cut on, the path the two-level form takes above K0).
+    const bool boundsOnly = pruning && K0 >= L.nk && pm->store_cut >= 0 && pm->store_cut < L.nk;
+    const int rawStride = boundsOnly ? pm->store_cut : std::min(K0, L.nk);
+    XH_TRY(xh_buf_reserve(ctx, pm->d_raw, sizeof(float4) * std::max<size_t>(1, (size_t)nrows * rawStride)));
     XhHigh H;
     H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
-    H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
+    H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = boundsOnly ? rawStride : K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
     H.rowLow = nullptr; H.aT = H.bT = nullptr; H.nk = L.nk; H.nrefs = pm->nrefs; H.noMirror = pm->no_mirror;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
@@ -3729,10 +3747,18 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                            (const int *)pm->d_nsam.p, L.nrings, L.ncoef, L.nk, pm->totalQuads, m, (const int *)nullptr,
                            K0 < L.nk ? pm->quadsLow : pm->totalQuads);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pm_contract_mfma, dim3((qtiles + 3) / 4, (ptiles + XH_PW2 - 1) / XH_PW2, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
-                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,
-                           (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles, pm->contract_dbg,
-                           pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr, rawStride);
+#define XH_CONTRACT(PT_, QT_)                                                                                                                    \
+        hipLaunchKernelGGL((k_pm_contract_mfma<PT_, QT_>), dim3((qtiles + QT_ - 1) / QT_, (ptiles + PT_ * XH_PW2 - 1) / (PT_ * XH_PW2), XH_KSPLIT),     \
+                           dim3(64 * PT_ * QT_), 0, ctx->stream, (const float4 *)pm->d_Apack.p,                                                      \
+                           (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,                                          \
+                           (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles,             \
+                           pm->contract_dbg, pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr, rawStride, rawStride)
+        if (pm->contract_shape == 44) XH_CONTRACT(4, 4);
+        else if (pm->contract_shape == 24) XH_CONTRACT(2, 4);
+        else if (pm->contract_shape == 22) XH_CONTRACT(2, 2);
+        else if (pm->contract_shape == 42) XH_CONTRACT(4, 2);
+        else XH_CONTRACT(1, 4);
+#undef XH_CONTRACT
     } else if (dense)
         hipLaunchKernelGGL((k_pm_contract<4, 4>), dim3((unsigned)desc.size()), dim3(nt), 0, ctx->stream,
                            (const BlockDesc *)pm->d_desc.p, (const xh_cf *)pm->d_A32.p, (const xh_cf *)pm->d_refsB.p,
@@ -3785,7 +3811,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
             grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
-            H.zeroHigh = 1;
+            H.zeroHigh = boundsOnly ? 0 : 1;       // (bounds only: there is no tail estimate to charge the missing frequencies to -- the rows are contracted in full)
             XH_IDFT3_ANY();
             H.zeroHigh = 0;
             XH_LAUNCH_CHECK();

@@ -1429,7 +1429,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
         rf->unit_z = (int)value;
     }
     else if (!strcmp(name, "grid_waves")) rf->grid_waves = (int)value;
-    else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(0, (int)value);
+    else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(-1, (int)value);     // (-1: experiment, every interior visit reuses the previous queue: timing only)
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;

@@ -450,6 +450,12 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
             int kid = kw & 0x3fffffff;
             int kidN = __builtin_amdgcn_readfirstlane(sKept[min(1, nk - 1)]) & 0x3fffffff;
             float4 R0 = recs[kid].r0, R1 = recs[kid].r1, R2 = recs[kid].r2;
+            // the queue of the previous visit serves this one too when both projections have the same plane (the traverse spaces of
+            // a launch are ordered by direction: particles assigned to one gallery direction differ in their in-plane angle only)
+            // and neither needs more than the slab test: which voxels lie within the blob radius of the plane is then the same set
+            int qn = 0;
+            float pNx = 0.f, pNy = 0.f, pNz = 0.f;
+            bool prevInterior = false;
             for (int k = 0; k < nk; ++k) {
                 const float4 N0 = recs[kidN].r0, N1 = recs[kidN].r1, N2 = recs[kidN].r2;
                 const int kidNN = sKept[min(k + 2, nk - 1)], kwN = sKept[min(k + 1, nk - 1)];
@@ -504,9 +510,12 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
                 const int yy = __float_as_int(R1.w), zz = __float_as_int(R2.w);
                 const bool yok = !(y < (yy & 0xffff) || y > (yy >> 16));
                 const float ax = R0.x * px + R0.y * py, ay = R1.x * px + R1.y * py, az = R2.x * px + R2.y * py;
-                int qn = 0;
+                const bool sameQueue = interior && prevInterior && ((R2.x == pNx && R2.y == pNy && R2.z == pNz) || tileBudget == -1);
+                pNx = R2.x; pNy = R2.y; pNz = R2.z; prevInterior = interior;
+                if (!sameQueue) qn = 0;
                 if constexpr (ABL != 7) {
-                if (interior) {
+                if (sameQueue) {
+                } else if (interior) {
                     // the slab test alone (the sphere bit stays: the unit may straddle the sphere the reference keeps)
 #pragma unroll
                     for (int zp = 0; zp < ZD / 2; ++zp) {
