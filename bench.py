@@ -59,8 +59,9 @@ def parse(argv=None):
                     help="full / match / grid: the refine iteration or one half of it; flexalign: BASELINE config 5, one K3 movie per step "
                          "(global + local alignment, warp + sum), movies streamed from page-locked host memory")
     ap.add_argument("--movie", default="40x4092x5760", help="flexalign mode: frames x rows x columns of a movie")
-    ap.add_argument("--movie-mode", type=int, default=2, choices=[0, 1, 2, 6], help="flexalign mode: how the frames lie in host memory, as an MRC data mode: 2 float32 "
-                    "(default: 3.77 GB per K3 movie cross the link), 0 int8 / 1 int16 / 6 uint16 counts, cast to float on the device (xh_movie_frame_to_float)")
+    ap.add_argument("--movie-mode", type=int, default=0, choices=[0, 1, 2, 6], help="flexalign mode: how the frames lie in host memory, as an MRC data mode: 0 int8 counts "
+                    "(default: what a K3 writes, 0.94 GB per movie cross the link), 1 int16 / 6 uint16 counts -- all cast to float on the device "
+                    "(xh_movie_frame_to_float) --, 2 float32 (3.77 GB per movie: the link then bounds the rate)")
     ap.add_argument("--fa-shared-copy", type=int, default=1, help="flexalign mode: 1 one copy stream for all lanes, 0 one per lane")
     ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
@@ -80,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--rf-opt", action="append", default=[], help="name=value passed to xh_rf_set_option (A/B runs)")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
+    ap.add_argument("--no-flexalign", action="store_true", help="skip the FlexAlign leg (config 5, a child process) of the default line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
     ap.add_argument("--pipeline", type=int, default=1, help="1: the reconstruction half (shift, CTF, FFT, gridding) of batch k runs on a second "
                     "stream beside the matching of batch k+1")
@@ -907,17 +909,25 @@ def main():
             roofline["algorithmic_MB_per_projection"] = bytes_grid / 1e6
             # HBM bytes per launch from the PMC passes of tools/collect_traffic.sh over this same command
             # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); PMC cannot be read from inside the process
+            # Both side files carry the hash of the library sources they were collected with (tools/libhash.py); collected with other
+            # sources than the ones this run was built from they are printed with "stale": true
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            from libhash import source_hash
+            lib_sha = source_hash()
+            roofline["library_source_sha16"] = lib_sha
             tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_k_rf_grid.json")
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 if tj.get("projections_per_launch") == B:
                     roofline["traffic"] = tj["traffic_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/traffic_k_rf_grid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    roofline["traffic_stale"] = tj.get("library_source_sha16") != lib_sha
             # the kernel's own bound is not HBM: vector issue and the LDS pipeline, from the committed PMC passes
             # of tools/pmc_grid.sh over the same 4096-projection launch (counters cannot be read from inside the process)
-            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_c_pmc_k_rf_grid.json")
+            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k_rf_grid.json")
             if os.path.exists(pf) and B == 4096 and D == 256:
-                c = {k_: v_["mean"] for k_, v_ in json.load(open(pf))["counters_per_dispatch"].items()}
+                pj = json.load(open(pf))
+                c = {k_: v_["mean"] for k_, v_ in pj["counters_per_dispatch"].items()}
                 if all(k_ in c for k_ in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")):
                     cyc = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the eight XCDs
                     roofline["second_bound"] = {
@@ -926,7 +936,8 @@ def main():
                         "valu_issue_frac_at_4_cycles_per_instruction": 4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc),
                         "lds_pipeline_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc),
                         "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                        "source": "profiles/r04_c_pmc_k_rf_grid.json (rocprofv3 --pmc, separate passes, tools/pmc_grid.sh); a packed fp32 "
+                        "stale": pj.get("library_source_sha16") != lib_sha,
+                        "source": "profiles/pmc_k_rf_grid.json (rocprofv3 --pmc, separate passes, tools/pmc_grid.sh); a packed fp32 "
                                   "instruction costs 5.2 and a conversion 4+ cycles (profiles/experiments/r03_ubench_valu_lds.txt), so the issue "
                                   "fraction at the real mix is ~1.15 x the 4-cycle figure"}
     others = {k: {"bound": v[0], "achieved": v[1], "peak": v[2], "unit": v[3], "frac": v[1] / v[2], "ms": v[4], "counted": v[5]}
@@ -1046,9 +1057,35 @@ def main():
             out["parity_volume_particles"] = nv
             with on_rf_stream():
                 rf.reset()
+    if args.mode == "full" and world == 1 and not args.no_extra_legs and not args.no_flexalign:
+        out["flexalign"] = flexalign_leg()
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def flexalign_leg():
+    """BASELINE config 5 in the default line: `bench.py --mode flexalign` (two K3 movies of int8 counts streamed from page-locked memory, two
+    in flight) as a CHILD process -- its own runtime, its own contexts; nothing is exec'ed over this process's GPU state -- reduced to the
+    figures a reader needs: movies/s and the three stages' times and roofline fractions."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "flexalign", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extra-legs"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        d = json.loads(line[-1])
+        fr = {k_: v_["frac"] for k_, v_ in d.get("roofline_other_kernels", {}).items()}
+        fr.update({k_: d["roofline"]["frac"] for k_ in d["stage_ms"] if k_ not in fr})      # the dominant stage is the one left over
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_movie": d["ms_per_step"],
+                "frames": d["config"]["host_traffic"].split(" H2D")[0], "lanes_per_gpu": d["config"]["lanes_per_gpu"],
+                "stage_ms_one_lane": d["stage_ms"],
+                "stage_roofline_frac": fr,
+                "global_shift_error_px": d.get("global_shift_error_px"),
+                "what": "`python bench.py --mode flexalign --steps 4 --warmup 2` run as a child process after the timed region of the refine iteration"}
+    except Exception as e:      # the headline must not depend on this leg
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":

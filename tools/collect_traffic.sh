@@ -38,3 +38,4 @@ doc = {"kernel": "k_rf_grid<4,false>", "command": "rocprofv3 --pmc <C> -- python
 json.dump(doc, open(f"{out}/../traffic_k_rf_grid.json", "w"), indent=1)
 print(json.dumps(doc))
 PY
+python3 $root/tools/libhash.py $root/gpurun_out/traffic_k_rf_grid.json > /dev/null

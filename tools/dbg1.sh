@@ -1,10 +1,9 @@
-cd $GRAFT_REPO_ROOT
-pr() { python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().split('\n')[-1])
-print('$1', round(d['value']), round(d['ms_per_step'],2), {k:round(v/d['steps'],2) for k,v in d['stage_ms'].items() if k in ('contract','idft_max','prep32','rescore_fp64')}, d.get('parity_sample_identical'), d.get('rescored_fraction'))
-"; }
-python3 bench.py --no-cpu-baseline --no-extra-legs --pipeline 0 --steps 3 --refs noise --pm-opt store_cut=-1 2>/dev/null | pr "noise all stored"
-python3 bench.py --no-cpu-baseline --no-extra-legs --pipeline 0 --steps 3 --refs noise 2>/dev/null | pr "noise bounds only"
-python3 bench.py --no-extra-legs --steps 3 --refs noise 2>/dev/null | pr "noise bounds only, two streams, with parity"
-timeout 900 python3 -m pytest tests/test_gpu_pm.py -q -x 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+root=$GRAFT_REPO_ROOT
+for f in 1 0; do
+rm -rf /tmp/pfa; export XH_PREFILTER_FORM=$f
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfa -o fa -- python3 $root/bench.py --mode flexalign --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+c=$(find /tmp/pfa -name '*kernel_stats.csv' | head -1)
+cp $c $root/gpurun_out/r05b_fa_stats_form$f.csv
+python3 $root/tools/kstats.py $c 14 5 | cut -c1-150
+done

@@ -47,3 +47,4 @@ json.dump(doc, open(f"{out}/../pmc_{tag}.json", "w"), indent=1)
 for c in sorted(res):
     print(f"{c:34s} {res[c]['last']:.4g}  (n={res[c]['dispatches']})")
 PY
+python3 $root/tools/libhash.py $root/gpurun_out/pmc_${tag}.json > /dev/null

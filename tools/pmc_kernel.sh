@@ -40,3 +40,4 @@ json.dump({"kernel": kern, "counters_per_dispatch": res}, open(f"{out}/../pmc_{t
 for c in sorted(res):
     print(f"{c:34s} mean {res[c]['mean']:.4g}  max {res[c]['max']:.4g}  (n={res[c]['dispatches']})")
 PY
+python3 $root/tools/libhash.py $root/gpurun_out/pmc_${tag}.json > /dev/null
