@@ -146,6 +146,7 @@ def lib():
         "xo_es_rotations": (None, [c_float_p, c_float_p, i, i, i, i, c_float_p]),
         "xo_es_iterative_pass": (None, [c_float_p, c_float_p, i, i, i, i, i, i, i, c_float_p, c_float_p]),
         "xo_es_iterative_alignment": (None, [c_float_p, c_float_p, i, i, i, i, i, i, c_float_p, c_float_p]),
+        "xo_es_iterative_pass_ties": (None, [c_float_p, c_float_p, i, i, i, i, i, i, c_int32_p, c_int32_p, c_float_p, c_float_p]),
         "xo_es_test_population": (i, [i, i, c_float_p, c_float_p]),
         "xo_es_test_add_noise": (None, [c_float_p, C.c_size_t]),
         "xo_es_test_make_others": (None, [c_float_p, i, i, c_float_p, c_float_p, c_float_p]),
@@ -750,6 +751,48 @@ def es_iterative_alignment(ref, others, max_shift, iters=3, first_ring=None, las
     else:
         lib().xo_es_iterative_pass(_fp(ref), _fp(others), n, D, int(max_shift), first_ring, last_ring, int(iters), int(order == "RS"), _fp(poses), _fp(merit))
     return poses, merit
+
+
+def es_iterative_reachable(ref, other, max_shift, iters=3, first_ring=None, last_ring=None, limit=64):
+    """Every (pose, merit) IterativeAlignmentEstimator::compute can end at for ONE image when the arg-max ties of its shift steps --
+    positions whose correlation value, as the float the reference compares, lies within two ulps of the maximum -- are resolved either
+    way: the reference's own choice among them is made by the rounding of its float FFT.  Returns the list of (pose [3][3], merit, ties
+    met) over both orders' choice trees combined the way compute() combines them (the better merit of RS / SR)."""
+    ref, other = _f32(ref), _f32(other)
+    D = ref.shape[0]
+    a, b = es_default_rings(D)
+    first_ring, last_ring = first_ring or a, last_ring or b
+
+    def half(rs):
+        out, todo = [], [()]
+        while todo and len(out) < limit:
+            pre = todo.pop()
+            picks = np.zeros(iters, np.int32); picks[:len(pre)] = pre
+            counts = np.zeros(iters, np.int32)
+            pose, merit = np.empty((3, 3), np.float32), np.empty(1, np.float32)
+            lib().xo_es_iterative_pass_ties(_fp(ref), _fp(other), D, int(max_shift), first_ring, last_ring, int(iters), int(rs),
+                                            picks.ctypes.data_as(c_int32_p), counts.ctypes.data_as(c_int32_p), _fp(pose), _fp(merit))
+            out.append((pose.copy(), float(merit[0]), int((counts > 1).sum())))
+            # branch at the first step beyond the prefix that had a tie
+            for k in range(len(pre), iters):
+                if counts[k] > 1:
+                    for c in range(1, int(counts[k])):
+                        todo.append(tuple(picks[:k]) + (c,))
+                    # (deeper steps of the c = 0 branch are explored through their own ties below)
+            # ties after the first tied step on the all-zero continuation
+            first = next((k for k in range(len(pre), iters) if counts[k] > 1), None)
+            if first is not None:
+                for k in range(first + 1, iters):
+                    if counts[k] > 1:
+                        for c in range(1, int(counts[k])):
+                            todo.append(tuple(picks[:k]) + (c,))
+        return out
+    rs, sr = half(True), half(False)
+    res = []
+    for pr, mr, tr in rs:
+        for ps, ms_, ts in sr:
+            res.append((ps, ms_, tr + ts) if mr < ms_ else (pr, mr, tr + ts))
+    return res
 
 
 def es_test_population(draw, n):

@@ -30,7 +30,9 @@ namespace {
 // computeShifts2DOneToN (shift_corr_estimator.cpp:248-283): correlation in the Fourier domain, ref * conj(other), multiplied by
 // (-1)^(x + y) over the half spectrum so that the inverse transform comes out centred (:178-196), then the first maximum within
 // maxShift of the centre (single_extrema_finder.cpp:265-311) as (x - X / 2, y - Y / 2)
-void shift_one(const std::vector<double> &Fref, const float *other, int Y, int X, int maxShift, float *sx, float *sy, double *map_out)
+// ties: null, or {pick, count}: the positions whose float value lies within two float ulps of the maximum are counted (in scan order) into
+// ties[1] and the one with index ties[0] (clamped) is returned instead of the first maximum -- see xo_es_iterative_pass_ties
+void shift_one(const std::vector<double> &Fref, const float *other, int Y, int X, int maxShift, float *sx, float *sy, double *map_out, int *ties = nullptr)
 {
     const int xh = X / 2 + 1;
     std::vector<double> img((size_t)Y * X), F((size_t)Y * xh * 2), map((size_t)Y * X);
@@ -63,6 +65,22 @@ void shift_one(const std::vector<double> &Fref, const float *other, int Y, int X
             const float tmp = (float)map[y * X + x];
             if (tmp > extrema) { extrema = tmp; pos = (float)(y * X + x); }
         }
+    }
+    if (ties) {
+        const float floor2 = std::nextafterf(std::nextafterf(extrema, -INFINITY), -INFINITY);
+        int cnt = 0;
+        float chosen = pos;
+        for (size_t y = minY; y <= maxY; ++y) {
+            const int logicY = (int)y - (int)yHalf;
+            const size_t ySq = (size_t)(logicY * logicY);
+            for (size_t x = minX; x <= maxX; ++x) {
+                const int logicX = (int)x - (int)xHalf;
+                if ((ySq + (size_t)(logicX * logicX)) > maxDistSq) continue;
+                if ((float)map[y * X + x] >= floor2) { if (cnt == ties[0]) chosen = (float)(y * X + x); ++cnt; }
+            }
+        }
+        ties[1] = cnt;
+        pos = chosen;
     }
     *sx = (float)(((int)pos % X) - (int)xHalf);
     *sy = (float)(((int)pos / X) - (int)yHalf);
@@ -122,9 +140,11 @@ void transform(const float *src, const std::vector<float> &poses, int n, int D, 
     }
 }
 
+// picks / counts (n == 1 only, else null): picks[k] chooses among the tied maxima of the k-th shift step, counts[k] receives their number
 void pass(const float *ref, const float *others, int n, int D, int maxShift, int first, int last, int iters, bool rotationFirst,
-          std::vector<float> &poses, std::vector<float> &merit)
+          std::vector<float> &poses, std::vector<float> &merit, const int *picks = nullptr, int *counts = nullptr)
 {
+    int shiftStep = 0;
     const size_t per = (size_t)D * D;
     std::vector<float> dest(others, others + per * n);          // copySrcToDest
     poses.assign(9 * (size_t)n, 0.f);
@@ -149,6 +169,15 @@ void pass(const float *ref, const float *others, int n, int D, int maxShift, int
         transform(others, poses, n, D, dest.data());
     };
     auto stepShift = [&] {
+        if (picks && n == 1) {
+            const int xh = D / 2 + 1;
+            std::vector<double> img(per), Fref((size_t)D * xh * 2);
+            for (size_t i = 0; i < per; ++i) img[i] = ref[i];
+            xo_fft2d_r2c(img.data(), D, D, Fref.data());
+            int t[2] = {picks[shiftStep], 0};
+            shift_one(Fref, dest.data(), D, D, maxShift, &sh[0], &sh[1], nullptr, t);
+            counts[shiftStep++] = t[1];
+        } else
         shifts(ref, dest.data(), n, D, D, maxShift, sh.data());
         for (int j = 0; j < n; ++j) { poses[9 * (size_t)j + 2] += sh[2 * j]; poses[9 * (size_t)j + 5] += sh[2 * j + 1]; }
         transform(others, poses, n, D, dest.data());
@@ -187,6 +216,19 @@ void xo_es_iterative_pass(const float *ref, const float *others, int n, int D, i
     pass(ref, others, n, D, maxShift, first_ring, last_ring, iters, rotationFirst != 0, p, m);
     std::memcpy(poses, p.data(), sizeof(float) * p.size());
     std::memcpy(merit, m.data(), sizeof(float) * m.size());
+}
+
+// The same for ONE image with the arg-max ties of the shift steps resolved by the caller: picks[k] (k-th shift step) selects among the
+// positions whose correlation value, as a float, lies within two ulps of the maximum; counts[k] returns how many there were.  The
+// reference's map is a float computed by a float FFT: which of such positions wins there is decided by that transform's rounding,
+// which neither this restatement (double transforms) nor the device can reproduce -- the tests enumerate the choices instead.
+void xo_es_iterative_pass_ties(const float *ref, const float *other, int D, int maxShift, int first_ring, int last_ring, int iters,
+                               int rotationFirst, const int *picks, int *counts, float *pose, float *merit)
+{
+    std::vector<float> p, m;
+    pass(ref, other, 1, D, maxShift, first_ring, last_ring, iters, rotationFirst != 0, p, m, picks, counts);
+    std::memcpy(pose, p.data(), sizeof(float) * 9);
+    *merit = m[0];
 }
 
 // IterativeAlignmentEstimator<T>::compute(others, iters) (:148-169): both orders, the better merit per image

@@ -217,8 +217,12 @@ def test_iterative_alignment_on_the_reference_tests_population(gpu, oracle, nois
     shifts within 1 px and 90 % within 1.8 / 1.86; with noise 41 % within 1 px, 51 / 53 % within 2 px.  The rotation criterion is
     applied as the test applies it (it indexes the sorted rotation errors with the number of SIZES) and, stricter, as it reads:
     90 % (67 % with noise) of the rotations within 2 x (10 x) the angle a pixel subtends.  Against the oracle's restatement of the
-    chain: the same pose for at least 97 % of the images of every size (what is left are arg-max ties between the fp32 FFT
-    correlation of the device's shift estimator and the oracle's double one)."""
+    chain: the SAME pose for every image -- except where a shift step met an arg-max tie: positions of the correlation map whose
+    values, as the floats the reference compares (ShiftCorrEstimator<float>), lie within two ulps of the maximum.  Which of them
+    wins in the reference is decided by the rounding of its float FFT; device and oracle both transform in double, with different
+    factorisations, and may round such a pair to either side.  For those images (`tools/diag_iterative.py`: 1-3 of 40, always in the
+    shift -> rotation half, whose first step correlates the still-rotated image) the device's pose must be one of the poses the
+    oracle reaches when the ties are resolved either way (`oracle.es_iterative_reachable`)."""
     xa, ctx, torch = gpu
     dX, dY, dR, eR = [], [], [], []
     for k in range(8):
@@ -234,8 +238,11 @@ def test_iterative_alignment_on_the_reference_tests_population(gpu, oracle, nois
             m = min(n, 40)
             eposes, emerit = oracle.es_iterative_alignment(ref, others[:m], max_shift, 3)
             same = np.array([np.allclose(poses[i], eposes[i], rtol=0, atol=1e-5) for i in range(m)])
-            assert same.mean() >= 0.97, (D, same.mean())
             assert np.abs(merit[:m][same] - emerit[same]).max() <= 1e-4
+            assert same.mean() >= 0.9, (D, same.mean())              # ties are the exception
+            for i in np.nonzero(~same)[0]:
+                reach = oracle.es_iterative_reachable(ref, others[i], max_shift, 3)
+                assert any(t > 0 and np.allclose(poses[i], p_, rtol=0, atol=1e-5) and abs(merit[i] - m_) <= 1e-4 for p_, m_, t in reach), (D, int(i), len(reach))
     if not noise:
         refR = _pct(eR, 0.9)
         assert _pct(dR, 0.9, len(eR)) <= 2 * refR                      # :75, as written
@@ -263,7 +270,9 @@ def test_iterative_alignment_step_by_step_against_the_oracle(gpu, oracle):
         poses, merit = xa.iterative_alignment(ctx, dref, doth, max_shift, iters)
         eposes, emerit = oracle.es_iterative_alignment(ref, others, max_shift, iters)
         same = np.array([np.allclose(poses[i], eposes[i], rtol=0, atol=1e-5) for i in range(len(others))])
-        assert same.mean() >= 0.95, (iters, same.mean())
+        for i in np.nonzero(~same)[0]:          # only where a shift step met an arg-max tie (see the test above)
+            reach = oracle.es_iterative_reachable(ref, others[i], max_shift, iters)
+            assert any(t > 0 and np.allclose(poses[i], p_, rtol=0, atol=1e-5) for p_, m_, t in reach), (iters, int(i), len(reach))
     pure = np.stack([oracle.apply_geometry2d(ref.astype(np.float64), np.array([[1, 0, s[0]], [0, 1, s[1]], [0, 0, 1.0]]), 1, False, False) for s in sh[:4]]).astype(np.float32)
     poses, merit = xa.iterative_alignment(ctx, dref, torch.from_numpy(pure).cuda(), max_shift, 1)
     assert all(-poses[i][0, 2] == sh[i][0] and -poses[i][1, 2] == sh[i][1] for i in range(4)) and merit.min() > 0.999
