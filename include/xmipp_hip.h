@@ -115,7 +115,9 @@ int xh_rf_destroy(xh_rf *rf);
 /* profiling / A-B knobs of the reconstruction handle (defaults are the product path): "unit_z" 4 | 8 (depth of a wave's voxel unit in
  * k_rf_grid), "grid_waves" 0 (= the configuration's default) | 8 | 9 | 12 | 16, "fuse_ctf" 1 | 0 (CTF evaluated while the records
  * are packed, or through planes), "ctf_fast" 1 | 0 (CTFs without envelope terms evaluated by the cheap form of preloadCTF's value, or the
- * general double-precision formula for every pixel), "records_from_images" 0 | 1 (records written by the FFT's row pass), "tile_max_spaces",
+ * general double-precision formula for every pixel), "records_from_images" 0 | 1 (records written by the FFT's row pass), "order_spaces" 1 | 0 (the traverse spaces of a launch
+ * ordered by plane -- the gridding kernel then shares the voxel queue between projections of one direction -- or in input order; the order
+ * permutes the launch's float additions), "tile_max_spaces",
  * "fft_variant" 1 | 2 (columns-first / rows-first projection FFT). Unknown names fail with XH_ERR_ARG. */
 int xh_rf_set_option(xh_rf *rf, const char *name, double value);
 /* derived sizes (RFA:196-199): paddedImgSize P, maxVolumeIndexYZ mv, fft crop sizeX=mv/2, sizeY=mv */

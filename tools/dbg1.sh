@@ -1,9 +1,7 @@
-cd /tmp && export TMPDIR=/tmp
-root=$GRAFT_REPO_ROOT
-for f in 1 0; do
-rm -rf /tmp/pfa; export XH_PREFILTER_FORM=$f
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfa -o fa -- python3 $root/bench.py --mode flexalign --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-c=$(find /tmp/pfa -name '*kernel_stats.csv' | head -1)
-cp $c $root/gpurun_out/r05b_fa_stats_form$f.csv
-python3 $root/tools/kstats.py $c 14 5 | cut -c1-150
-done
+cd $GRAFT_REPO_ROOT
+timeout 900 python3 -m pytest tests/test_gpu_rf.py tests/test_gpu_pipeline.py tests/test_gpu_pm.py -q -x 2>&1 | tail -3
+bash tools/ab_bench.sh 2 base base -- --no-extra-legs 2>/dev/null | cut -c1-330
+for r in 1 2; do for o in 0 1; do python3 bench.py --no-cpu-baseline --no-extra-legs --rf-opt order_spaces=$o 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('order_spaces $o', round(d['value']), round(d['ms_per_step'],2), 'grid', round(d['stage_ms']['k_rf_grid']/d['steps'],2))"; done; done

@@ -1739,16 +1739,19 @@ __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restric
                           const CandRes *__restrict__ cand, RowMap M, int pBase, int parity, int N, double tieAbs,
                           int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per ambiguous particle, the candidates strided over its lanes (a thread per particle walked the whole candidate list
+    // twice on its own: 0.19 ms per 4096-particle batch for a few hundred comparisons each)
+    const int a = blockIdx.x, lane = threadIdx.x;
     if (a >= counters[0]) return;
     const int p = ambList[a];
     const int nc = counters[1];
     const bool forward = (((pBase + p + parity) & 1) == 0);
     double best = -1.0e300;
-    for (int c = 0; c < nc; ++c)
+    for (int c = lane; c < nc; c += 64)
         if (d_row_slot(M, cand[c].row) / M.nt == p && cand[c].val > best) best = cand[c].val;
+    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o, 64));
     int bestRow = -1, bestIdx = 0, bestOrder = 0x7fffffff;
-    for (int c = 0; c < nc; ++c) {
+    for (int c = lane; c < nc; c += 64) {
         const int row = cand[c].row;
         if (d_row_slot(M, row) / M.nt != p) continue;
         if (cand[c].val >= best - tieAbs) {
@@ -1756,7 +1759,12 @@ __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restric
             if (order < bestOrder) { bestOrder = order; bestRow = row; bestIdx = cand[c].idx; }
         }
     }
-    if (bestRow >= 0) {
+    // the earliest visited among the lanes' (a row has one position in the visiting order: no two lanes hold the same)
+    for (int o = 32; o > 0; o >>= 1) {
+        const int oo = __shfl_xor(bestOrder, o, 64), orow = __shfl_xor(bestRow, o, 64), oidx = __shfl_xor(bestIdx, o, 64);
+        if (oo < bestOrder) { bestOrder = oo; bestRow = orow; bestIdx = oidx; }
+    }
+    if (lane == 0 && bestRow >= 0) {
         const int gp = pBase + p;
         refno[gp] = d_row_ref(M, bestRow, d_row_slot(M, bestRow));
         psi[gp] = bestIdx % N;
@@ -4044,7 +4052,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
                                (const xh_cd *)pm->d_csN.p, (const int *)pm->d_nsam.p, (const int *)pm->d_coff.p, L.nrings, L.Ri,
                                L.ncoef, L.N, L.nk, (CandRes *)pm->d_candRes.p, (double *)nullptr, 1, 0.0);
             XH_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_pm_pick, dim3((na + 63) / 64), dim3(64), 0, ctx->stream, (const int *)pm->d_counters.p,
+            hipLaunchKernelGGL(k_pm_pick, dim3(na), dim3(64), 0, ctx->stream, (const int *)pm->d_counters.p,
                                (const int *)pm->d_ambList.p, (const CandRes *)pm->d_candRes.p, M, p0, parity, L.N, tieAbs,
                                d_refno, d_psi, d_flip);
             XH_LAUNCH_CHECK();

@@ -262,6 +262,8 @@ struct xh_rf {
     int grid_tile_budget = 0;   // tiles a workgroup of the gridding kernel processes before it retires; 0: persistent workgroups, one per CU
     int ntiles[2] = {0, 0};
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
+    int order_spaces = 1; // the traverse spaces of a launch ordered by plane, so that k_rf_grid reuses voxel queues (0: input order, for A/B)
+    XhBuf d_spacePos;
     int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
     int records_from_images = 0;   // ... and write the records from the row pass of the FFT (measured slower: profiles/README.md)
 };
@@ -1402,7 +1404,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_shiftCoef); xh_buf_free(rf->d_shiftXY);
     xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec);
-    xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles);
+    xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles); xh_buf_free(rf->d_spacePos);
     if (rf->h_stage) (void)hipHostFree(rf->h_stage);
     if (rf->stageEv) (void)hipEventDestroy(rf->stageEv);
     xh_buf_free(rf->d_gtiles[0]); xh_buf_free(rf->d_gtiles[1]); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
@@ -1432,6 +1434,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(-1, (int)value);     // (-1: experiment, every interior visit reuses the previous queue: timing only)
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
+    else if (!strcmp(name, "order_spaces")) rf->order_spaces = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
@@ -1892,6 +1895,14 @@ static int insert_common(xh_rf *rf, const float *d_fft, const float *d_ctf, cons
     build_spaces(rf, h_ainv, h_weights, n, h_sym, nsym, spaces);
     const int ns = (int)spaces.size();
     if (ns == 0) return XH_OK;
+    // launch order: spaces that share a plane next to each other (k_rf_grid takes the previous visit's voxel queue for them); the
+    // order only permutes the float additions of the launch
+    if (rf->order_spaces)
+        std::stable_sort(spaces.begin(), spaces.end(), [](const XhSpace &a, const XhSpace &b) {
+            if (a.tInv[6] != b.tInv[6]) return a.tInv[6] < b.tInv[6];
+            if (a.tInv[7] != b.tInv[7]) return a.tInv[7] < b.tInv[7];
+            return a.tInv[8] < b.tInv[8];
+        });
     return grid_insert(rf, spaces, d_fft, d_ctf, d_mod, h_weights, n);
 }
 
@@ -1988,8 +1999,14 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
     }
     XH_TRY(xh_buf_reserve(ctx, rf->d_cull, sizeof(float4) * 2 * (size_t)ns));
     XH_TRY(xh_buf_reserve(ctx, rf->d_grecs, sizeof(XgRec) * (size_t)ns));
+    const int *d_pos = nullptr;
+    if (rf->order_spaces) {
+        XH_TRY(xh_buf_reserve(ctx, rf->d_spacePos, sizeof(int) * (size_t)ns));
+        hipLaunchKernelGGL(k_rf_space_order, dim3(1), dim3(1024), 0, ctx->stream, d_angles, n, nsym, (int *)rf->d_spacePos.p);
+        d_pos = (const int *)rf->d_spacePos.p;
+    }
     hipLaunchKernelGGL(k_rf_spaces, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, d_angles, d_weights, d_sym, n, nsym, rf->mv,
-                       rf->p.blob_radius, rf->p.use_fast, (XgRec *)rf->d_grecs.p, (float4 *)rf->d_cull.p, (float4 *)rf->d_cull.p + ns);
+                       rf->p.blob_radius, rf->p.use_fast, (XgRec *)rf->d_grecs.p, (float4 *)rf->d_cull.p, (float4 *)rf->d_cull.p + ns, d_pos);
     XH_LAUNCH_CHECK();
     rf->packCtf = fuse;
     rf->packImgs = fromImages ? d_imgs : nullptr;

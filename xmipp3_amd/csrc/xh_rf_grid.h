@@ -230,12 +230,56 @@ __host__ __device__ static inline void xg_fill_rec(XgRec &G, float4 &nv, float4 
     G.h2.w = 3.5f * (std::fabs(S.tInv[3]) + std::fabs(S.tInv[4])) + 1.5f * std::fabs(S.tInv[5]) + 0.01f + (float)blobRadius;
 }
 
+// Launch order of the traverse spaces: those that share a plane next to each other.  Particles assigned to one gallery direction
+// carry the same (rot, tilt) and differ in their in-plane angle only; their slabs are one slab, and the gridding kernel, which
+// visits the spaces of a list in launch order, takes the voxel queue of the previous visit when the plane is the same (k_rf_grid,
+// `sameQueue`).  One workgroup; chunks of XG_ORD spaces are ordered independently by a bitonic sort of (key, index) pairs in LDS --
+// key: a hash of the bits of rot and tilt and the symmetry index, so equal directions meet whatever else the order is.  The order
+// only permutes the launch's float additions (RFA:300-388 grids in metadata order).  pos[idx]: the space's place in the launch.
+#define XG_ORD 4096
+__global__ void __launch_bounds__(1024) k_rf_space_order(const double *__restrict__ angles, int n, int nsym, int *__restrict__ pos)
+{
+    __shared__ unsigned long long sk[XG_ORD];
+    __shared__ int si[XG_ORD];
+    const int ns = n * nsym;
+    for (int c0 = 0; c0 < ns; c0 += XG_ORD) {
+        for (int t = threadIdx.x; t < XG_ORD; t += 1024) {
+            const int idx = c0 + t;
+            unsigned long long k = ~0ull;
+            if (idx < ns) {
+                const int i = idx / nsym, sy = idx - i * nsym;
+                const unsigned long long a = (unsigned long long)__double_as_longlong(angles[3 * i]), b = (unsigned long long)__double_as_longlong(angles[3 * i + 1]);
+                k = (a * 0x9E3779B97F4A7C15ull) ^ ((b + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full) ^ ((unsigned long long)sy * 0x165667B19E3779F9ull);
+                k ^= k >> 29;
+                k >>= 1;                                    // below the padding key
+            }
+            sk[t] = k; si[t] = idx;
+        }
+        __syncthreads();
+        for (int size = 2; size <= XG_ORD; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = threadIdx.x; t < XG_ORD / 2; t += 1024) {
+                    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const unsigned long long ka = sk[lo], kb = sk[hi];
+                    const int ia = si[lo], ib = si[hi];
+                    const bool gt = ka > kb || (ka == kb && ia > ib);
+                    if (gt == up) { sk[lo] = kb; sk[hi] = ka; si[lo] = ib; si[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        for (int t = threadIdx.x; t < XG_ORD; t += 1024)
+            if (si[t] < ns) pos[si[t]] = c0 + t;
+        __syncthreads();
+    }
+}
+
 // The same on the device, from Euler angles that never left it (xh_rf_insert_images_dev): one thread per (projection,
 // symmetry matrix). A projection of weight 0 keeps its slot with NaN cull vectors, which no list admits (RFA:327-329).
 __global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ angles, const float *__restrict__ weights,
                                                    const double *__restrict__ sym, int n, int nsym, int mv, double blobRadius,
                                                    int useFast, XgRec *__restrict__ recs, float4 *__restrict__ cullN,
-                                                   float4 *__restrict__ cullX)
+                                                   float4 *__restrict__ cullX, const int *__restrict__ pos)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * nsym) return;
@@ -256,9 +300,10 @@ __global__ void __launch_bounds__(64) k_rf_spaces(const double *__restrict__ ang
         nv = make_float4(q, q, q, q);
         xv = nv;
     }
-    recs[idx] = G;
-    cullN[idx] = nv;
-    cullX[idx] = xv;
+    const int o = pos ? pos[idx] : idx;            // launch order (k_rf_space_order)
+    recs[o] = G;
+    cullN[o] = nv;
+    cullX[o] = xv;
 }
 
 // W: footprint width (4 for a blob radius below 2, 6 below 3). FAST: processVoxel (RFA:595-625), nearest pixel, one voxel per row.
