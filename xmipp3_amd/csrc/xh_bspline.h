@@ -435,6 +435,104 @@ k_pm_prefilter_rec2d(const float *__restrict__ in, float *__restrict__ out, int 
     }
 }
 
+// The recursion in double for the re-scored particles (k_pm_prefilter_fir64_2d: 65 taps per output and axis).  z^28 = 1e-16: a run
+// entered 28 samples early has forgotten its start to double resolution, which is also what the reference's own recursion carries
+// as rounding over a 256-sample line.  16 rows x 256 columns per block, thread <-> column, then thread <-> (row, 16 columns); LDS rows
+// 322 doubles apart (the sixteen lanes of a ds_read_b128 on sixteen rows = all banks).  in: float or double images [src][D][D]
+// (gather / count as for the convolution form), out [slot][D][D] double; blockIdx.y: slot.
+#define XH_REC64_K 28
+#define XH_REC64_V 16
+#define XH_REC64_S 322
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+k_pm_prefilter_rec64_2d(const TIN *__restrict__ in, double *__restrict__ out, int D, int tilesX, const int *__restrict__ gather,
+                        const int *__restrict__ count)
+{
+    constexpr int K = XH_REC64_K, V = XH_REC64_V, S = XH_REC64_S, NW = V + 2 * K, TW = 256;
+    static_assert(S >= TW + 2 * K && S % 2 == 0 && S % 32 == 2, "tile layout");
+    __shared__ __align__(16) double tile[V * S];
+    const int slot = blockIdx.y;
+    if (count && slot >= *count) return;
+    const double z = -0.26794919243112270647, zend = z / (z - 1.0);
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x0 = tx * TW, y0 = ty * V;
+    const TIN *src = in + (size_t)(gather ? gather[slot] : slot) * D * D;
+    const bool full = tilesX == 1 && D >= 2 * K;
+    auto refl = [D](int a) { const int b = a < 0 ? -1 - a : (a >= D ? 2 * D - 1 - a : a); return min(max(b, 0), D - 1); };
+    if (x0 + TW > D) {
+        for (int e = tid; e < V * S; e += 256) tile[e] = 0.0;
+        __syncthreads();
+    }
+    const int xbeg = full ? K : 0, xend = full ? K + min(D, TW) : TW + 2 * K;
+    for (int xx = xbeg + tid; xx < xend; xx += 256) {
+        int p = x0 + xx - K;
+        if (p >= D + K) break;
+        p = refl(p);
+        double w[NW];
+        if (y0 >= K && y0 + V + K <= D) {
+            const TIN *c0 = src + (unsigned)((y0 - K) * D + p);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = (double)c0[(unsigned)(i * D)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = (double)src[(unsigned)(refl(y0 + i - K) * D + p)];
+        }
+#pragma unroll
+        for (int i = 1; i < NW; ++i) w[i] = fma(z, w[i - 1], w[i]);
+        double a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            if (i < V + K) tile[(i - K) * S + xx] = 6.0 * a;
+        }
+    }
+    __syncthreads();
+    if (full) {
+        for (int e = tid; e < V * 2 * K; e += 256) {
+            const int r = e / (2 * K), i = e - r * 2 * K;
+            if (i < K) tile[r * S + K - 1 - i] = tile[r * S + K + i];
+            else tile[r * S + K + D + (i - K)] = tile[r * S + K + D - 1 - (i - K)];
+        }
+        __syncthreads();
+    }
+    const int r = tid & (V - 1), sg = tid >> 4;
+    double w[NW];
+    {
+        const double2 *t2 = reinterpret_cast<const double2 *>(&tile[r * S + 16 * sg]);
+#pragma unroll
+        for (int i = 0; i < NW / 2; ++i) { const double2 q = t2[i]; w[2 * i] = q.x; w[2 * i + 1] = q.y; }
+    }
+#pragma unroll
+    for (int i = 1; i < NW; ++i) w[i] = fma(z, w[i - 1], w[i]);
+    {
+        double a = zend * w[NW - 1];
+#pragma unroll
+        for (int i = NW - 2; i >= K; --i) {
+            a = z * (a - w[i]);
+            w[i] = 6.0 * a;
+        }
+    }
+    __syncthreads();
+    {
+        double2 *t2 = reinterpret_cast<double2 *>(&tile[r * S + 16 * sg]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t2[i] = make_double2(w[K + 2 * i], w[K + 2 * i + 1]);
+    }
+    __syncthreads();
+    double *dstImg = out + (size_t)slot * D * D;
+    const bool vec = (D & 1) == 0;
+    for (int e = tid; e < V * (TW / 2); e += 256) {
+        const int rr = e / (TW / 2), c2 = e - rr * (TW / 2);
+        const int y = y0 + rr, x = x0 + 2 * c2;
+        if (y >= D || x >= D) continue;
+        const double2 q = *reinterpret_cast<const double2 *>(&tile[rr * S + 2 * c2]);
+        double *dst = dstImg + (size_t)y * D + x;
+        if (vec) *reinterpret_cast<double2 *>(dst) = q;
+        else { dst[0] = q.x; if (x + 1 < D) dst[1] = q.y; }
+    }
+}
+
 // which form xh_prefilter_fir_launch runs: 1 the recursion tile by tile (k_pm_prefilter_rec2d), 0 the 33-tap convolution
 // (k_pm_prefilter_fir2d); XH_PREFILTER_FORM in the environment picks for A/B runs
 static inline int xh_prefilter_form()

@@ -127,7 +127,7 @@ struct xh_pm {
     int use_mfma64;              // fp64 ring DFT on v_mfma_f64_16x16x4_f64 (0: the direct sum, for A/B)
     int s6_pair;                 // S6: two particles per inverse transform (k_pm_tr_cols_pair)
     int s6_coarse_kernel;        // S6: the fp32 pass ends in k_pm_bestshift_coarse (0: k_pm_bestshift<float>, A/B)
-    int fir64_fused;             // the fp64 prefilter as one kernel (0: rows then columns with an intermediate, A/B)
+    int fir64_fused;             // the fp64 prefilter: 2 the recursion tile by tile, 1 the 65-tap convolution as one kernel, 0 rows then columns with an intermediate (A/B)
     int s6_debug;                // profiling: xh_pm_translate returns decision margins instead of shifts
     int s6_capture;              // test hook: 32 / 64 = xh_pm_translate runs only that chain and leaves the correlation maps for xh_pm_debug_s6_maps
     int s6_captured;             // ... precision and count of the maps left behind
@@ -3082,7 +3082,17 @@ static int run_prep(xh_pm *pm, const void *imgs, bool imgsAreFloat, const int *d
         const XhFir64 F = xh_fir64_taps();
         const int segs = (D + XH_FIR64_V - 1) / XH_FIR64_V;
         const size_t nvec = (size_t)nslots * D * segs;
-        if (pm->fir64_fused && nslots <= 65535) {
+        if (pm->fir64_fused == 2 && nslots <= 65535 && D >= 2 * XH_REC64_K) {
+            // the recursion tile by tile (k_pm_prefilter_rec64_2d)
+            const int tilesX = (D + 255) / 256, tilesY = (D + XH_REC64_V - 1) / XH_REC64_V;
+            if (imgsAreFloat)
+                hipLaunchKernelGGL((k_pm_prefilter_rec64_2d<float>), dim3(tilesX * tilesY, nslots), dim3(256), 0, ctx->stream, (const float *)imgs, (double *)coefBuf.p, D, tilesX,
+                                   d_gather, d_count);
+            else
+                hipLaunchKernelGGL((k_pm_prefilter_rec64_2d<double>), dim3(tilesX * tilesY, nslots), dim3(256), 0, ctx->stream, (const double *)imgs, (double *)coefBuf.p, D, tilesX,
+                                   d_gather, d_count);
+            XH_LAUNCH_CHECK();
+        } else if (pm->fir64_fused && nslots <= 65535) {
             // both passes in one kernel, no intermediate
             const int tilesX = (D + XH_FIR64_TW - 1) / XH_FIR64_TW, tilesY = (D + XH_FIR64_V - 1) / XH_FIR64_V;
             if (imgsAreFloat)
@@ -3280,7 +3290,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->use_mfma64 = 1;
     pm->s6_pair = 1;
     pm->s6_coarse_kernel = 1;
-    pm->fir64_fused = 1;
+    pm->fir64_fused = 2;
     pm->s6_debug = 0;
     pm->s6_capture = 0;
     pm->s6_captured = 0;
