@@ -483,7 +483,10 @@ int xh_extrema_find(xh_ctx *ctx, const float *d_data, int32_t n, int32_t zdim, i
 /* Alignment::ShiftCorrEstimator<T>, AlignType::OneToN (reconstruction/shift_corr_estimator.cpp:33-300): create = init2D (even sizes,
  * 0 < max_shift < size / 2); load_reference = load2DReferenceOneToN(const T *); correlate = the static
  * computeCorrelations2DOneToN (d_inout [n][fy][fx] complex spectra <- ref conj(inout), times (-1)^(x+y) when center);
- * compute_shifts = computeShift2DOneToN + getShifts2D: h_shifts [n][2] = (x, y) as the reference returns them. */
+ * compute_shifts = computeShift2DOneToN + getShifts2D: h_shifts [n][2] = (x, y) as the reference returns them.
+ * The transforms run in double through line plans that keep a (padded) line in the 64 KB of LDS a workgroup may take: powers of two up
+ * to 4096 samples per side, other sizes (Bluestein, padded to the next power of two above 2 n) up to ~2048; larger sides fail with
+ * XH_ERR_UNSUPPORTED at create (the typed tests of the reference stop at 768). */
 typedef struct xh_shiftcorr xh_shiftcorr;
 int xh_shiftcorr_create(xh_ctx *ctx, int32_t xdim, int32_t ydim, int32_t max_shift, xh_shiftcorr **out);
 int xh_shiftcorr_destroy(xh_shiftcorr *h);

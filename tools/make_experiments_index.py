@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Builds docs/experiments.md: ONE table of every variant that was built or costed, with the file that holds the numbers, what it did and
+whether it was adopted.  Rounds 1-4 are read out of profiles/README.md (tables headed `idea | result` = not adopted, `change | before ->
+after` = adopted); round 5 is listed below by hand.    python3 tools/make_experiments_index.py"""
+import os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R5 = [
+    # (area, variant, where the numbers are, result, adopted)
+    ("gridding CTF", "preloadCTF's value for envelope-free CTFs as ONE sinusoid: argument reduced in double, float sine polynomial, no atan2 (`d_ctf_pixel_fast`); general formula within 1e-5 of the minCTF threshold", "profiles/r05_a_kernel_stats_onestream.csv", "`k_rf_pack_grid_ctf` 2.30 -> 1.99 ms (now at the HBM rate of its 11.2 GB)", "yes"),
+    ("gridding records", "records written by the FFT's row pass with the cheap CTF (`records_from_images` 1)", "DESIGN.md 5 (round 5)", "3.48 ms against 1.47 + 1.99: equal; 3.20 without any CTF evaluation -- the row kernel's store phase, not the CTF, is what costs (2.2 TB/s of stores at 4 workgroups per CU)", "no"),
+    ("gridding records", "... with the CTF values of a block's lines evaluated before the store loop", "DESIGN.md 5 (round 5)", "4.62 ms (336 bytes of scratch per lane)", "no"),
+    ("matcher S1", "fp32 prefilter as a tile recursion (`k_pm_prefilter_rec2d`: 3 operations per output and axis, 14 warm-up samples)", "profiles/r05_a_kernel_stats_onestream.csv", "1.03 -> 0.52 ms", "yes"),
+    ("matcher S1 / S6", "polynomial B-spline weights, fused multiply-adds written out, patch staging row by row (`k_pm_tr_build`, `k_pm_polar_cells`)", "profiles/r05_a_kernel_stats_onestream.csv", "`k_pm_tr_build<float>` 1.42 -> 0.88 ms (224 -> 98 vector instructions per pixel); `k_pm_polar_cells<float>` 1.11 -> 1.06 (not instruction bound)", "yes"),
+    ("matcher S2", "workgroup of 2 x 2 / 2 x 4 / 4 x 2 / 4 x 4 waves sharing operand tiles through the L1 (`contract_shape`)", "DESIGN.md 5 (round 5)", "noise gallery 20.3 / 20.7 / 22.3 / 23.3 ms against 20.3 (1 x 4): the L2 was not the bound", "no"),
+    ("matcher S2", "bank without a band limit: contraction for the bounds alone, no coefficients stored (`store_cut` 0); S3 contracts the surviving rows", "profiles/r05_a_bench_default.json (`noise_gallery`)", "contraction 23.8 -> 13.2 ms, S3 1.0 -> 3.1 ms; noise gallery 60.7 -> 70.3 k particles/s (the stores and moduli were half the kernel: 12.0 ms without them)", "yes"),
+    ("matcher S5", "fp64 prefilter of the re-scored particles as a tile recursion (`k_pm_prefilter_rec64_2d`); `k_pm_pick` one wave per particle", "DESIGN.md 5 (round 5)", "re-score stage 2.1 -> 1.87 ms per step", "yes"),
+    ("gridding kernel", "traverse spaces ordered by plane, voxel queue of the previous visit reused for interior visits of the same plane", "DESIGN.md 5 (round 5)", "24.4 -> 24.0 ms per launch on the bench's 4.1 particles per direction (upper bound with every interior visit reusing: 22.4)", "yes"),
+    ("gridding kernel", "x-adjacent voxel pairs as items (VERDICT r04 item 3)", "DESIGN.md 5 (round 5), costed from the ISA", "the second voxel's footprint is displaced by (R0.x, R1.x) -- a general 2-D vector -- so the union window is 5 x 5 and its records cannot be shared without per-lane selects (16 taps x 3 v_cndmask); what remains is the set-up (48 -> ~35 per voxel) against half-empty pairs at odd run lengths: > 170 instructions per 64 voxels, not built", "no"),
+    ("gridding kernel", "batches across visits (leftover items of visit k in the first batch of visit k + 1)", "DESIGN.md 5 (round 5), costed", "needs two patch buffers per wave: 2 x 60 KB + table 40 + sums 36 > 160 KB at twelve waves; eight waves fit -- not built", "no"),
+    ("FlexAlign", "frame prefilter as a tile recursion (`k_fa_prefilter_rec`), eight row groups per warp workgroup", "profiles/r05_a_bench_default.json (`flexalign`)", "warp + sum 15.5 -> 14.1 ms per movie (the prefilter runs beside the host's spline fit and was already hidden); 17.1 -> 18.4 movies/s", "yes"),
+]
+
+
+def main():
+    src = open(os.path.join(ROOT, "profiles", "README.md")).read().split("\n")
+    rows, mode, section = [], None, ""
+    for l in src:
+        if l.startswith("#"):
+            section = l.lstrip("# ").strip(); mode = None; continue
+        if re.match(r"^\|\s*idea\s*\|\s*result", l): mode = "no"; continue
+        if re.match(r"^\|\s*change\s*\|", l): mode = "yes"; continue
+        if not l.startswith("|"):
+            if l.strip() == "": mode = mode
+            else: mode = None if not l.startswith("|") and mode and not l.strip().startswith("|") and l.strip() else mode
+            continue
+        if mode and not re.match(r"^\|\s*-", l):
+            c = [x.strip() for x in l.strip().strip("|").split("|")]
+            if len(c) >= 2:
+                rows.append((section, c[0], c[1], mode))
+    out = ["# Experiments index", "",
+           "Every variant that was built or costed, one line each.  Rounds 1-4 are lifted from the tables of `profiles/README.md` (which keeps the",
+           "commands and the longer readings); `profiles/experiments/*` hold the raw A/B records.  Generated by `tools/make_experiments_index.py`.", "",
+           "## Round 5", "", "| area | variant | numbers in | result | adopted |", "|---|---|---|---|---|"]
+    for a, v, f, r, ad in R5:
+        out.append(f"| {a} | {v} | {f} | {r} | {ad} |")
+    out += ["", "## Rounds 1-4 (from profiles/README.md)", "", "| section of profiles/README.md | variant | result | adopted |", "|---|---|---|---|"]
+    for s, v, r, ad in rows:
+        out.append(f"| {s[:60]} | {v} | {r} | {ad} |")
+    os.makedirs(os.path.join(ROOT, "docs"), exist_ok=True)
+    open(os.path.join(ROOT, "docs", "experiments.md"), "w").write("\n".join(out) + "\n")
+    print(len(R5), "+", len(rows), "rows")
+
+
+if __name__ == "__main__":
+    main()

@@ -694,7 +694,7 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
         return r2;
     };
     std::vector<float> pRS, mRS, pSR, mSR;
-    // test hook (tools/diag_iterative.py): XH_ES_ORDER=RS / SR returns that half alone, the way the oracle's xo_es_iterative_pass does
+    // test hook (tools/diag_iterative.py): XH_ES_ORDER=RS / SR returns that half of compute() alone
     const char *only = getenv("XH_ES_ORDER");
     if (rc == XH_OK) rc = pass(!(only && !strcmp(only, "SR")), pRS, mRS);
     if (only) { pSR = pRS; mSR = mRS; }

@@ -155,16 +155,27 @@ public:
         const std::string block = (fn.prefix.empty() || fn.hasNumber()) ? "noname" : fn.prefix;
         const bool exists = fileExists(fn.path);
         if (append && exists) {
-            // MD_APPEND: a block of this name already in the file is replaced, the other blocks stay
+            // MD_APPEND: a block of this name already in the file is replaced, the other blocks stay.  The name is compared the way
+            // getBlocksInMetaDataFile reads it (trailing blanks / CR of files written elsewhere do not make a second block), and the
+            // kept content goes through a temporary file that is renamed over the original: a crash in between loses nothing
             std::ifstream in(fn.path);
             std::string line, kept;
             bool skipping = false, dropped = false;
             while (std::getline(in, line)) {
-                if (line.compare(0, 5, "data_") == 0) { skipping = (line.substr(5) == block); dropped = dropped || skipping; }
+                if (line.compare(0, 5, "data_") == 0) {
+                    std::string b = line.substr(5);
+                    while (!b.empty() && (b.back() == ' ' || b.back() == '\r' || b.back() == '\t')) b.pop_back();
+                    skipping = (b == block);
+                    dropped = dropped || skipping;
+                }
                 if (!skipping) kept += line + "\n";
             }
             in.close();
-            if (dropped) { std::ofstream o(fn.path, std::ios::trunc); o << kept; }
+            if (dropped) {
+                const std::string tmp = fn.path + ".tmp_md_append";
+                { std::ofstream o(tmp, std::ios::trunc); o << kept; if (!o.good()) REPORT_ERROR(ERR_IO_NOREAD, "MetaData::write: cannot write " + tmp); }
+                if (std::rename(tmp.c_str(), fn.path.c_str()) != 0) REPORT_ERROR(ERR_IO_NOREAD, "MetaData::write: cannot replace " + fn.path);
+            }
         }
         std::ofstream f(fn.path, append ? std::ios::app : std::ios::trunc);
         if (!f.good()) REPORT_ERROR(ERR_IO_NOREAD, "MetaData::write: cannot write " + fn.path);

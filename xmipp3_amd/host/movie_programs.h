@@ -8,6 +8,9 @@
 #ifndef XMIPP3_AMD_MOVIE_PROGRAMS_H
 #define XMIPP3_AMD_MOVIE_PROGRAMS_H
 #include "ctf_programs.h"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <deque>
 #include <future>
 #include <memory>
@@ -196,13 +199,37 @@ public:
                 if (!dark.empty()) { d_dark.reserve(g.c, perRaw * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_dark.p, dark.data(), perRaw * sizeof(float))); }
                 if (!gain.empty()) { d_gain.reserve(g.c, perRaw * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), perRaw * sizeof(float))); }
             }
+            // four reader threads for the whole movie, reader w takes frames w, w + 4, ... (a thread per frame -- std::async -- opened and
+            // parsed the stack anew for every frame: readImageRaw's header / stream cache is thread_local); a reader runs at most two
+            // of its frames ahead of the consumer
             const int ahead = 4;
-            std::deque<std::future<std::vector<unsigned char>>> inFlight;
-            for (int n = 0; n < std::min(ahead, N); ++n) inFlight.push_back(std::async(std::launch::async, readFrame, n));
+            std::vector<std::promise<std::vector<unsigned char>>> prom(N);
+            std::vector<std::future<std::vector<unsigned char>>> fut;
+            for (auto &pr : prom) fut.push_back(pr.get_future());
+            std::mutex rdM;
+            std::condition_variable rdCv;
+            int consumed = 0;
+            bool rdStop = false;
+            std::vector<std::thread> readers;
+            for (int w = 0; w < std::min(ahead, N); ++w)
+                readers.emplace_back([&, w] {
+                    for (int n = w; n < N; n += ahead) {
+                        {
+                            std::unique_lock<std::mutex> lk(rdM);
+                            rdCv.wait(lk, [&] { return rdStop || n < consumed + 2 * ahead; });
+                            if (rdStop) { prom[n].set_exception(std::make_exception_ptr(std::runtime_error("movie read cancelled"))); continue; }
+                        }
+                        try { prom[n].set_value(readFrame(n)); } catch (...) { prom[n].set_exception(std::current_exception()); }
+                    }
+                });
+            struct JoinReaders {
+                std::vector<std::thread> &t; std::mutex &m; std::condition_variable &cv; bool &stop;
+                ~JoinReaders() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &x : t) if (x.joinable()) x.join(); }
+            } joinReaders{readers, rdM, rdCv, rdStop};
             for (int n = 0; n < N; ++n) {
-                std::vector<unsigned char> cur = inFlight.front().get();          // re-throws what the reader threw
-                inFlight.pop_front();
-                if (n + ahead < N) inFlight.push_back(std::async(std::launch::async, readFrame, n + ahead));
+                std::vector<unsigned char> cur = fut[n].get();                    // re-throws what the reader threw
+                { std::lock_guard<std::mutex> lk(rdM); consumed = n + 1; }
+                rdCv.notify_all();
                 float *dst = doBin ? d_raw.as<float>() : d_frames.as<float>() + (size_t)n * per;
                 if (Iraw.mode == 2) xhCheck(xh_memcpy_h2d(g.c, dst, cur.data(), rawBytes));
                 else {

@@ -592,6 +592,8 @@ public:
         addParamsLine("   -i <md_file>                : Metadata file with input projections");
         addParamsLine("  [-o <volume_file=\"rec_fourier.vol\">]  : Filename for output volume");
         addParamsLine("  [--sym <symfile=c1>]              : Enforce symmetry in projections");
+        addParamsLine("                                    : (point group name or symmetry file; dNv / dNh with ODD N take their 2-fold on X,");
+        addParamsLine("                                    :  where Sampling::createSymFile puts it on Y -- DESIGN history 8)");
         addParamsLine("  [--padding <proj=2.0> <vol=2.0>]  : Padding used for projections and volume");
         addParamsLine("  [--max_resolution <p=0.5>]     : Max resolution (Nyquist=0.5)");
         addParamsLine("  [--weight]                     : Use weights stored in the image metadata");
