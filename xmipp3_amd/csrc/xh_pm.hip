@@ -1122,19 +1122,23 @@ struct XhHigh {          // what S3 needs to finish a row the contraction left a
     int nk, nrefs;
     int noMirror;                // 1: only the straight particle is a candidate (option "mirror" 0: the rotation estimator)
 };
+#ifndef XH_HIGH_RINGS
+#define XH_HIGH_RINGS 8
+#endif
 // the four real sums (ac, ad, bc, bd) of frequency k for (slot, ref), ring order ascending like k_pm_contract
 __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref, int k)
 {
     const xh_cf *a = H.A + (size_t)slot * H.ncoef + k, *b = H.B + (size_t)ref * H.ncoef + k;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int r = H.rstart[k];
-    // eight rings per step: sixteen independent loads in flight (the loop is latency bound otherwise)
-    for (; r + 8 <= H.nrings; r += 8) {
-        xh_cf x[8], y[8];
+    // XH_HIGH_RINGS rings per step: twice as many independent loads in flight (the loop is latency bound: a wave is alone with
+    // its row, two workgroups per CU)
+    for (; r + XH_HIGH_RINGS <= H.nrings; r += XH_HIGH_RINGS) {
+        xh_cf x[XH_HIGH_RINGS], y[XH_HIGH_RINGS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int o = H.coff[r + u]; x[u] = a[o]; y[u] = b[o]; }
+        for (int u = 0; u < XH_HIGH_RINGS; ++u) { const int o = H.coff[r + u]; x[u] = a[o]; y[u] = b[o]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < XH_HIGH_RINGS; ++u) {
             acc.x = fmaf(x[u].x, y[u].x, acc.x);
             acc.y = fmaf(x[u].x, y[u].y, acc.y);
             acc.z = fmaf(x[u].y, y[u].x, acc.z);
@@ -1177,7 +1181,16 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
     const int half = N / 2;
     int skipped = 0;
     if (nrowsDev) nrows = *nrowsDev;     // length of rowList decided on the device (k_pm_survivors)
-    for (int it = blockIdx.x * 4 + wv; it < nrows; it += gridDim.x * 4) {
+    // Which list entries a wave takes.  The lists are particle by particle (the four planned rows, then the ~6 survivors of a particle
+    // are neighbours), and rows of one particle read the same 205 KB of its coefficients in d_row_high: chunks of 32 consecutive
+    // entries go to the workgroups of ONE XCD (block b runs on XCD b % 8), so that a particle's coefficients are fetched into one
+    // L2 instead of up to eight.  Entry it = 256 g + 32 x + r belongs to XCD x; its workgroups deal them out four at a time.
+    const bool xcdMap = rowList != nullptr && (gridDim.x & 7) == 0;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    for (int ex = (xcdMap ? jb : blockIdx.x) * 4 + wv;; ex += (xcdMap ? nbx : gridDim.x) * 4) {
+        const int it = xcdMap ? 256 * (ex >> 5) + 32 * xcd + (ex & 31) : ex;
+        if (xcdMap ? 256 * (ex >> 5) >= nrows : it >= nrows) break;
+        if (it >= nrows) continue;
         const int row = rowList ? rowList[it] : it;
         // branch and bound: the row cannot reach (best of its particle - 2 tau), see k_pm_prune_plan
         if (rowBound && (rowBound[row] == -INFINITY || rowBound[row] < thr[row / rowsPerParticle])) {
@@ -3828,7 +3841,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             XH_LAUNCH_CHECK();
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
-            grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
+            grid = std::max(8, std::min((nr + 3) / 4, ctx->num_cus * 8) / 8 * 8);      // a multiple of eight: see the kernel's XCD mapping
             H.zeroHigh = boundsOnly ? 0 : 1;       // (bounds only: there is no tail estimate to charge the missing frequencies to -- the rows are contracted in full)
             XH_IDFT3_ANY();
             H.zeroHigh = 0;
@@ -3847,7 +3860,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
             if (earlyExit) { thr = (const float *)pm->d_thr.p; rowsPer = nrows / nparticles; H.rowLow = (const float4 *)pm->d_rowLow.p; H.aT = (const float *)pm->d_aT.p; H.bT = (const float *)pm->d_bT.p; H.nk = L.nk; H.nrefs = pm->nrefs; }
         }
-        grid = std::max(1, std::min((nr + 3) / 4, ctx->num_cus * 8));
+        grid = std::max(8, std::min((nr + 3) / 4, ctx->num_cus * 8) / 8 * 8);
         XH_IDFT3_ANY();
 #undef XH_IDFT3_ANY
 #undef XH_IDFT3
