@@ -1,3 +1,8 @@
-cd $GRAFT_REPO_ROOT
-timeout 600 python3 -m pytest tests/test_gpu_pm.py -q -x -k "branch_and_bound or full_size or exact_indices or ties" 2>&1 | tail -3
-bash tools/trace_onestream.sh r05d 2>/dev/null | grep -i "idft_max3\|span"
+cd /tmp && export TMPDIR=/tmp
+root=$GRAFT_REPO_ROOT
+rm -rf /tmp/pfa
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfa -o fa -- python3 $root/bench.py --mode flexalign --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --fa-lanes 1 > $root/gpurun_out/r05_fa_under_rocprof.json 2> $root/gpurun_out/r05_fa_under_rocprof.err
+echo "rc $?"
+c=$(find /tmp/pfa -name '*kernel_stats.csv' | head -1)
+cp $c $root/gpurun_out/r05_fa_kernel_stats.csv
+python3 $root/tools/kstats.py $c 24 4 | cut -c1-170
