@@ -3940,7 +3940,9 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
     // (with the two-level contraction a row only holds the frequencies below K0: far more rows per chunk)
     const bool willPrune = !lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1;
-    const size_t rawStride = willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
+    // (a bank without a band limit stores store_cut coefficients per row, none by default: the whole batch is one chunk)
+    const bool willBoundsOnly = willPrune && pm->K0 >= L.nk && pm->store_cut >= 0 && pm->store_cut < L.nk;
+    const size_t rawStride = willBoundsOnly ? (size_t)std::max(1, pm->store_cut) : willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
     size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (rawStride * sizeof(float4)));
     // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
     if (n_orient > 1) maxRows = std::min<size_t>(maxRows, std::max<size_t>(1024, ((size_t)1 << 30) / (sizeof(CandRes) * n_orient)));
