@@ -499,3 +499,20 @@ def test_two_movies_in_flight_on_one_device(gpu):
     for i in range(2):
         for a, b in zip(seq[i], out[i]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_warp_with_a_large_control_grid_takes_the_plain_kernel(gpu, oracle):
+    """the quad form of the warp kernel stages 32 (lX - 3) lY bytes per layer pair in LDS; a control grid whose quads
+    exceed 64 KB (here 30 x 30 x 5, as `--controlPoints 30 30 5` would ask for) must fall back to the plain kernel, not fail the
+    launch.  Checked against the oracle's applyBSplineTransform."""
+    xa, ctx, torch = gpu
+    Y, X, N, cp = 192, 224, 6, (30, 30, 5)
+    rng = np.random.default_rng(3)
+    frame = rng.standard_normal((Y, X)).astype(np.float32)
+    cx, cy = rng.uniform(-3, 3, cp[0] * cp[1] * cp[2]), rng.uniform(-3, 3, cp[0] * cp[1] * cp[2])
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+    out = torch.empty((Y, X), device="cuda")
+    fa.apply_bspline(torch.from_numpy(frame).cuda(), cx, cy, cp, N, 2, out=out)
+    exp = oracle.fa_apply_bspline(frame.astype(np.float64), cx.astype(np.float32), cy.astype(np.float32), cp, N, 2)
+    assert np.abs(out.cpu().numpy() - exp).max() <= 2e-4 * (frame.max() - frame.min())

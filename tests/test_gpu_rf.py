@@ -739,3 +739,55 @@ def test_errors_are_loud(gpu):
     rf.mirror_and_crop()
     with pytest.raises(xa.XhError):
         rf.insert(torch.zeros((1, 64, 32, 2), device="cuda"), np.zeros((1, 3)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["round", "astigmatic"])
+def test_cheap_ctf_form_against_the_general_formula(gpu, oracle, kind):
+    """d_ctf_pixel_fast (envelope-free CTFs: one sinusoid, argument reduced in double, float sine polynomial) against the general
+    double-precision formula of the same library (option ctf_fast 0) and against the oracle, at the bench's size: the DECISION
+    |CTF| < minCTF is the same for every pixel (within 1e-5 of the threshold the general formula is evaluated), the modulators are
+    equal to float rounding, the factors 1 / CTF to 1e-6 relative."""
+    xa, ctx, torch = gpu
+    D = 256
+    from xmipp3_amd.api import ctf_params
+    kw = dict(kV=300.0, Cs=2.7, Q0=0.07, DeltafU=21000.0, DeltafV=21000.0 if kind == "round" else 19500.0, azimuthal_angle=37.0, K=1.0)
+    res = {}
+    for fast in (1, 0):
+        rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
+        rf.set_option("ctf_fast", fast)
+        c, m = rf.ctf_arrays([ctf_params(**kw)])
+        res[fast] = (c.cpu().numpy()[0], m.cpu().numpy()[0])
+    (cf, mf), (cs, ms) = res[1], res[0]
+    assert np.array_equal(mf == 1.0, ms == 1.0)                       # the same pixels below the threshold
+    assert np.abs(mf - ms).max() <= 1e-7
+    assert (np.abs(cf - cs) / np.maximum(1.0, np.abs(cs))).max() <= 1e-6
+    o = oracle.RF(D, min_ctf=0.01, sampling=1.0, use_ctf=True)
+    ce, me = o.ctf_arrays(oracle.ctf_params(**kw))
+    assert (np.abs(cf - ce) / np.maximum(1.0, np.abs(ce))).max() < 1e-4 and np.abs(mf - me).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_launch_order_by_plane_changes_only_the_summation_order(gpu):
+    """order_spaces 1 (the product: the traverse spaces of a launch ordered by plane, voxel queues shared between projections of one
+    direction) against 0 (input order): the same voxels, sums equal to float rounding -- on orientations as the matcher assigns them
+    (a few directions, many in-plane angles), through the device-side entry point, and with a symmetry group."""
+    xa, ctx, torch = gpu
+    D, n = 64, 96
+    rng = np.random.default_rng(5)
+    dirs = synth.fibonacci_directions(7)
+    ang = np.stack([np.array([dirs[i % 7][0], dirs[i % 7][1], rng.uniform(0, 360)]) for i in range(n)])
+    imgs = torch.from_numpy(rng.standard_normal((n, D, D)).astype(np.float32)).cuda()
+    from xmipp3_amd.api import ctf_params
+    ctfs = xa.RecFourier.ctf_param_array([ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=15000.0 + 100 * i, DeltafV=15000.0 + 100 * i) for i in range(n)])
+    temps = []
+    for order in (1, 0):
+        rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
+        rf.set_option("order_spaces", order)
+        rf.insert_images(imgs, torch.from_numpy(ang).cuda(), ctf_array=ctfs)
+        v, w = rf.temp_spaces()
+        temps.append((v.cpu().numpy(), w.cpu().numpy()))
+    (v1, w1), (v0, w0) = temps
+    assert (w0 != 0).sum() > 50_000
+    assert np.array_equal(w1 != 0, w0 != 0)
+    assert np.abs(w1 - w0).max() <= 2e-6 * np.abs(w0).max() and np.abs(v1 - v0).max() <= 2e-6 * np.abs(v0).max()
