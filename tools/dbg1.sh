@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python3 bench.py --no-extra-legs --steps 3 --refs noise 2>/dev/null | tail -1 | python3 -c "
+for r in 1 2; do for w in 12 8; do timeout 300 python3 bench.py --no-cpu-baseline --no-extra-legs --rf-opt grid_waves=$w 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('noise', round(d['value']), round(d['ms_per_step'],2), {k:round(v/d['steps'],2) for k,v in d['stage_ms'].items() if k in ('contract','idft_max','prep32','rescore_fp64')}, d.get('parity_sample_identical'))"
+print('grid_waves $w', round(d['value']), round(d['ms_per_step'],2), 'grid', round(d['stage_ms']['k_rf_grid']/d['steps'],2), {k:round(v/d['steps'],2) for k,v in d['stage_ms'].items() if k in ('prep32','contract','idft_max','rescore_fp64','translate_s6')})"; done; done

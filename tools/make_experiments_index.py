@@ -17,7 +17,11 @@ R5 = [
     ("gridding kernel", "traverse spaces ordered by plane, voxel queue of the previous visit reused for interior visits of the same plane", "DESIGN.md 5 (round 5)", "24.4 -> 24.0 ms per launch on the bench's 4.1 particles per direction (upper bound with every interior visit reusing: 22.4)", "yes"),
     ("gridding kernel", "x-adjacent voxel pairs as items (VERDICT r04 item 3)", "DESIGN.md 5 (round 5), costed from the ISA", "the second voxel's footprint is displaced by (R0.x, R1.x) -- a general 2-D vector -- so the union window is 5 x 5 and its records cannot be shared without per-lane selects (16 taps x 3 v_cndmask); what remains is the set-up (48 -> ~35 per voxel) against half-empty pairs at odd run lengths: > 170 instructions per 64 voxels, not built", "no"),
     ("gridding kernel", "batches across visits (leftover items of visit k in the first batch of visit k + 1)", "DESIGN.md 5 (round 5), costed", "needs two patch buffers per wave: 2 x 60 KB + table 40 + sums 36 > 160 KB at twelve waves; eight waves fit -- not built", "no"),
-    ("FlexAlign", "frame prefilter as a tile recursion (`k_fa_prefilter_rec`), eight row groups per warp workgroup", "profiles/r05_a_bench_default.json (`flexalign`)", "warp + sum 15.5 -> 14.1 ms per movie (the prefilter runs beside the host's spline fit and was already hidden); 17.1 -> 18.4 movies/s", "yes"),
+    ("gridding kernel", "waves per CU: 8 / 12 / 16 (`grid_waves`)", "DESIGN.md 5 (round 5)", "26.3 / 23.6 / 23.9 ms per launch alone; default bench with 8 waves (room for other kernels' registers and LDS on every CU): 45.0 ms per step against 41.2 -- nothing co-runs usefully", "no (12 stays)"),
+    ("matcher S3", "list entries dealt to workgroups XCD by XCD (a particle's rows in one L2); 16 instead of 8 rings per step in `d_row_high`", "DESIGN.md 5 (round 5)", "`k_pm_idft_max3` (survivors) 1.73 -> 1.68 ms; 1.75 with 16 rings: the 8.6 GB of operands per step (350 KB per surviving row) at 4.9 TB/s are the bound", "yes / no"),
+    ("matcher S2", "bounds-only contraction in one chunk per batch (the chunk size had still been computed for stored coefficients)", "profiles/r05_b_bench_refsnoise.json", "noise gallery 72 -> 76.6 k particles/s (contraction 13.2 -> 10.7 ms alone)", "yes"),
+    ("FlexAlign", "rocprofv3 over the two-lane bench (two host threads)", "tools/collect_r05.sh", "hangs (twice, 40 GPU-minutes lost); one lane profiles fine -- the FlexAlign kernel table is collected with `--fa-lanes 1`", "-"),
+    ("FlexAlign", "frame prefilter as a tile recursion (`k_fa_prefilter_rec`), eight row groups per warp workgroup", "profiles/r05_a_bench_default.json (`flexalign`)", "`k_fa_prefilter` 0.278 -> `k_fa_prefilter_rec` 0.058 ms per K3 frame (hidden behind the host's spline fit either way), `k_fa_warp_quads` 0.48 -> 0.36 ms per frame; warp + sum 15.5 -> 14.1 ms per movie; 17.1 -> 18.4-18.7 movies/s", "yes"),
 ]
 
 
