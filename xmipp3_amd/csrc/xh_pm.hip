@@ -807,6 +807,17 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
         if (k == 0 || k == nk - 1) { bs += fabsf(fsr); bm += fabsf(fmr); }     // c2r drops their imaginary parts
         else { bs += 2.f * sqrtf(fsr * fsr + fsi * fsi); bm += 2.f * sqrtf(fmr * fmr + fmi * fmi); }
     };
+    // The packed operands of consecutive frequencies follow each other (quad qoff[k + 1] comes right after the last quad of k): the
+    // operand pipeline runs THROUGH the frequency boundaries -- the quad a step prefetches is the next frequency's first when the
+    // current one ends.  (Restarting it per frequency cost a full L2 round trip 399 times per tile pair: the high frequencies have
+    // one or two quads each.)  Set 0 always holds the quad to be multiplied next.
+    float4 a0[XH_PW2], a1[XH_PW2], b0, b1;
+    {
+        const int q0 = min(qoff[kBeg], lastQuad);
+        b0 = B[(size_t)q0 * 64]; b1 = b0;
+#pragma unroll
+        for (int t = 0; t < XH_PW2; ++t) { a0[t] = A[t][(size_t)q0 * 64]; a1[t] = a0[t]; }
+    }
     for (int k0 = kBeg; k0 < kEnd; k0 += 4) {
         xh_f32x16 acc[XH_PW2][4];
 #pragma unroll
@@ -821,9 +832,6 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                 // software pipeline: the next quad's operands are in flight while this quad's MFMAs issue. Two register sets,
                 // the loop body is two quads (no copies; written out because the compiler turns the one-set form into
                 // load - wait - multiply)
-                float4 a0[XH_PW2], a1[XH_PW2], b0 = B[(size_t)qb * 64], b1 = b0;
-#pragma unroll
-                for (int t = 0; t < XH_PW2; ++t) { a0[t] = A[t][(size_t)qb * 64]; a1[t] = a0[t]; }
 #define XH_CT_STEP(AC, BC, AN, BN, QN)                                                                        \
                 {                                                                                              \
                     const int qn_ = (QN) <= lastQuad ? (QN) : lastQuad;                                        \
@@ -843,6 +851,11 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
                     if (qd + 1 < qe) XH_CT_STEP(a1, b1, a0, b0, qd + 2)
                 }
 #undef XH_CT_STEP
+                if ((qe - qb) & 1) {                 // an odd number of quads leaves the prefetched one in set 1
+                    b0 = b1;
+#pragma unroll
+                    for (int t = 0; t < XH_PW2; ++t) a0[t] = a1[t];
+                }
             }
         }
         // lane (j, hi) holds column j = (reference qj, Re|Im) for rows i = (reg&3) + 8*(reg>>2) + 4*hi.
