@@ -241,10 +241,15 @@ struct xh_rf {
     XhBuf d_cull, d_pack, d_superList, d_superCount, d_superVec;
     XhBuf d_gtiles[2], d_grecs, d_gweights, d_planes, d_spectra;   // d_planes, d_spectra: scratch of xh_rf_insert_images   // k_rf_grid: tile list (16 x 16 x 8 tiles), records, per-image weights
     // pinned staging of the small host arrays (records, shifts, CTF parameters): uploads never wait for the stream
+    // pinned staging area of the small per-call host arrays: two halves used in turn, an event per half (recorded after the half's last
+    // copy).  Entering a half waits for ITS event -- recorded a whole half ago -- so the host never waits for the copy it has just
+    // queued.  (One area with one event made the host wait, at every wrap, until the stream had reached the previous call's copies:
+    // with 200-byte CTF records a 4096-projection call wraps every second step, 9 ms of idle device per step in `--mode grid`.)
     unsigned char *h_stage = nullptr;
-    size_t stageCap = 0, stageUsed = 0;
-    hipEvent_t stageEv = nullptr;
-    bool stagePending = false;
+    size_t stageCap = 0, stageUsed = 0;          // capacity of ONE half, bytes used in the current half
+    int stageHalf = 0;
+    hipEvent_t stageEv[2] = {nullptr, nullptr};
+    bool stagePending[2] = {false, false};
     XhBuf d_sym, d_angles;          // device-side inputs of k_rf_spaces
     bool packCtf = false;           // xh_rf_insert_images: the pack kernel evaluates the CTF of d_ctfp itself
     const float *packImgs = nullptr; // ... and the records come straight from the images (k_rf_colsA + k_rf_rowsB<PACK>)
@@ -275,22 +280,30 @@ static int stage_upload(xh_rf *rf, void *d_dst, const void *h_src, size_t bytes)
     if (bytes == 0) return XH_OK;
     xh_ctx *ctx = rf->ctx;
     const size_t need = (bytes + 255) & ~(size_t)255;
-    if (!rf->stageEv) XH_HIP(hipEventCreateWithFlags(&rf->stageEv, hipEventDisableTiming));
+    for (int h = 0; h < 2; ++h)
+        if (!rf->stageEv[h]) XH_HIP(hipEventCreateWithFlags(&rf->stageEv[h], hipEventDisableTiming));
     if (rf->stageUsed + need > rf->stageCap) {
-        if (rf->stagePending) { XH_HIP(hipEventSynchronize(rf->stageEv)); rf->stagePending = false; }
         if (need > rf->stageCap) {
+            // a larger area: every copy out of the old one must have left it
+            for (int h = 0; h < 2; ++h)
+                if (rf->stagePending[h]) { XH_HIP(hipEventSynchronize(rf->stageEv[h])); rf->stagePending[h] = false; }
             if (rf->h_stage) XH_HIP(hipHostFree(rf->h_stage));
             rf->h_stage = nullptr;
-            rf->stageCap = std::max(need, std::max<size_t>(2 * rf->stageCap, (size_t)4 << 20));
-            XH_HIP(hipHostMalloc((void **)&rf->h_stage, rf->stageCap, hipHostMallocDefault));
+            rf->stageCap = std::max(need, std::max<size_t>(2 * rf->stageCap, (size_t)8 << 20));
+            XH_HIP(hipHostMalloc((void **)&rf->h_stage, 2 * rf->stageCap, hipHostMallocDefault));
+            rf->stageHalf = 0;
+        } else {
+            rf->stageHalf ^= 1;
+            if (rf->stagePending[rf->stageHalf]) { XH_HIP(hipEventSynchronize(rf->stageEv[rf->stageHalf])); rf->stagePending[rf->stageHalf] = false; }
         }
         rf->stageUsed = 0;
     }
-    memcpy(rf->h_stage + rf->stageUsed, h_src, bytes);
-    XH_HIP(hipMemcpyAsync(d_dst, rf->h_stage + rf->stageUsed, bytes, hipMemcpyHostToDevice, ctx->stream));
+    unsigned char *slot = rf->h_stage + (size_t)rf->stageHalf * rf->stageCap + rf->stageUsed;
+    memcpy(slot, h_src, bytes);
+    XH_HIP(hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
     rf->stageUsed += need;
-    XH_HIP(hipEventRecord(rf->stageEv, ctx->stream));
-    rf->stagePending = true;
+    XH_HIP(hipEventRecord(rf->stageEv[rf->stageHalf], ctx->stream));
+    rf->stagePending[rf->stageHalf] = true;
     return XH_OK;
 }
 
@@ -1406,7 +1419,8 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec);
     xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles); xh_buf_free(rf->d_spacePos);
     if (rf->h_stage) (void)hipHostFree(rf->h_stage);
-    if (rf->stageEv) (void)hipEventDestroy(rf->stageEv);
+    for (int h = 0; h < 2; ++h)
+        if (rf->stageEv[h]) (void)hipEventDestroy(rf->stageEv[h]);
     xh_buf_free(rf->d_gtiles[0]); xh_buf_free(rf->d_gtiles[1]); xh_buf_free(rf->d_grecs); xh_buf_free(rf->d_gweights); xh_buf_free(rf->d_planes); xh_buf_free(rf->d_spectra);
     for (hipEvent_t e : rf->evPool) (void)hipEventDestroy(e);
     delete rf;
