@@ -701,14 +701,20 @@ def main():
             imgs = timed("shift_images", record, lambda: rf.shift_images(parts, shifts, flips=flips, coefs=pm.last_coefficients(B) if pm is not None else None))
             timed("gridding_insert_images", record, lambda: rf.insert_images(imgs, ang, ctf_array=ctf_arr))      # CTF planes + FFT + records + gridding
 
+    fin_ev = []          # (start, end) event pairs of the tail on the reconstruction stream: its duration on the DEVICE
+
     def finish():
         if rf is None:
             return
         with on_rf_stream():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             rf.mirror_and_crop()
             xa.allreduce_reconstruction(rf)
             rf.finish()
             rf.reset()
+            e1.record()
+            fin_ev.append((e0, e1))
 
     for _ in range(args.warmup):
         step(False)
@@ -761,7 +767,11 @@ def main():
 
     t0, t_fin0, t1 = streamed_steps(args.steps, True)
     elapsed = t1 - t0
-    finish_s = t1 - t_fin0
+    # the once-per-run tail (mirror/crop + all-reduce + finaliser + reset) as the device saw it: events on the reconstruction stream
+    # around it.  (The host clock from "all steps queued" to the end -- what rounds 3-4 printed here -- also holds the steps the
+    # device had not finished yet: 37 ms where the tail itself is 8.)
+    finish_s = fin_ev[-1][0].elapsed_time(fin_ev[-1][1]) * 1e-3 if fin_ev else 0.0
+    finish_host_s = t1 - t_fin0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -988,7 +998,7 @@ def main():
                    "pipeline": ("reconstruction half of batch k on a second stream beside the matching of batch k+1" if pipelined else "one stream"),
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
-        "stage_ms": stage, "finish_and_allreduce_s": finish_s,
+        "stage_ms": stage, "finish_and_allreduce_s": finish_s, "host_clock_from_last_step_queued_to_end_s": finish_host_s,
         # the step rate without the once-per-run tail (mirror/crop + all-reduce + finaliser): config 4 is 1 M particles = 30.5 steps of
         # 4096 per GPU on 8 GPUs, so a run of fewer steps over-weights the tail in `value` -- run --steps 31 for that comparison
         "value_steps_only": total_particles / max(1e-9, elapsed - finish_s),

@@ -286,11 +286,18 @@ class RecFourier:
     def finish(self):
         # page-locked result buffer: the D^3 doubles leave the device at DMA speed (134 MB at D=256; pageable memory
         # makes this copy the longest part of the finaliser)
+        # Page-locking 134 MB takes 25-30 ms -- three times the finaliser's kernels -- so the buffer is kept with the handle and handed
+        # out again once the caller has dropped the previous result (nobody but this object and the local name holds it)
+        import sys
         torch = _torch()
-        try:
-            out = torch.empty((self.D, self.D, self.D), dtype=torch.float64, pin_memory=True).numpy()
-        except RuntimeError:
-            out = np.empty((self.D, self.D, self.D), np.float64)
+        out = getattr(self, "_fin_out", None)
+        if out is None or sys.getrefcount(out) > 3:
+            try:
+                self._fin_pin = torch.empty((self.D, self.D, self.D), dtype=torch.float64, pin_memory=True)
+                out = self._fin_pin.numpy()
+            except RuntimeError:
+                out = np.empty((self.D, self.D, self.D), np.float64)
+            self._fin_out = out
         check(lib().xh_rf_finish(self.h, _np_ptr(out)))
         return out
 

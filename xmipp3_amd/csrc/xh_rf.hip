@@ -267,6 +267,7 @@ struct xh_rf {
     int grid_tile_budget = 0;   // tiles a workgroup of the gridding kernel processes before it retires; 0: persistent workgroups, one per CU
     int ntiles[2] = {0, 0};
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
+    XhBuf d_finSpec, d_finVol, d_finFbt;   // the finaliser's expanded spectrum, output volume and Fourier blob table
     int order_spaces = 1; // the traverse spaces of a launch ordered by plane, so that k_rf_grid reuses voxel queues (0: input order, for A/B)
     XhBuf d_spacePos;
     int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
@@ -1418,6 +1419,7 @@ int xh_rf_destroy(xh_rf *rf)
     xh_buf_free(rf->d_tileCounter); xh_buf_free(rf->d_cull); xh_buf_free(rf->d_pack);
     xh_buf_free(rf->d_superList); xh_buf_free(rf->d_superCount); xh_buf_free(rf->d_superVec);
     xh_buf_free(rf->d_sym); xh_buf_free(rf->d_angles); xh_buf_free(rf->d_spacePos);
+    xh_buf_free(rf->d_finSpec); xh_buf_free(rf->d_finVol); xh_buf_free(rf->d_finFbt);
     if (rf->h_stage) (void)hipHostFree(rf->h_stage);
     for (int h = 0; h < 2; ++h)
         if (rf->stageEv[h]) (void)hipEventDestroy(rf->stageEv[h]);
@@ -2255,12 +2257,14 @@ int xh_rf_finish(xh_rf *rf, double *h_volume)
     XH_LAUNCH_CHECK();
     // expanded spectrum + output volume live in scratch
     const size_t specElems = (size_t)P * P * xh;
-    XhBuf spec, vol, fbt;
-    int r = xh_buf_alloc(ctx, spec, specElems * sizeof(xh_cd));
-    if (r == XH_OK) r = xh_buf_alloc(ctx, vol, sizeof(double) * (size_t)D * D * D);
-    if (r == XH_OK) r = xh_buf_alloc(ctx, fbt, sizeof(double) * XH_BLOB_TABLE);
-    if (r != XH_OK) { xh_buf_free(spec); xh_buf_free(vol); xh_buf_free(fbt); return r; }
-    auto cleanup = [&]() { xh_buf_free(spec); xh_buf_free(vol); xh_buf_free(fbt); };
+    // (kept with the handle: allocating and freeing 1.2 GB per call -- hipFree waits for the device -- was most of the 36-60 ms a
+    // finish took; its kernels are 10 ms)
+    XhBuf &spec = rf->d_finSpec, &vol = rf->d_finVol, &fbt = rf->d_finFbt;
+    int r = xh_buf_reserve(ctx, spec, specElems * sizeof(xh_cd));
+    if (r == XH_OK) r = xh_buf_reserve(ctx, vol, sizeof(double) * (size_t)D * D * D);
+    if (r == XH_OK) r = xh_buf_reserve(ctx, fbt, sizeof(double) * XH_BLOB_TABLE);
+    if (r != XH_OK) return r;
+    auto cleanup = [&]() {};
 #define XH_HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { xh_set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return XH_ERR_HIP; } } while (0)
     XH_HIP_C(hipMemcpyAsync(fbt.p, rf->fourierBlobTable.data(), fbt.bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_rf_expand, dim3((unsigned)((specElems + 255) / 256)), dim3(256), 0, ctx->stream, (const xh_cf *)V, (xh_cd *)spec.p, mv, P);
