@@ -11,16 +11,19 @@ shard of synthetic 256x256 particles resident in HBM and, per step, pushes one b
 
 and, after the K steps, mirror+crop, ONE all-reduce (RCCL) of [volume | weights] and the
 finaliser (3-D inverse FFT + blob correction) on every rank.  All of it is inside the timed
-region, and so is the traffic SURVEY.md 8d puts inside the metric: every batch comes from page-locked
-host memory (two device buffers; the copy of batch k+1 runs on its own stream under step k, only the
-very first copy precedes the clock) and every step's results (reference, in-plane angle, mirror,
-shifts, maxCC) go back to page-locked host memory.  Four distinct batches are cycled.  Weak scaling:
-per-GPU work is fixed as N grows.
+region.  Per the task statement `value` is measured with the inputs resident in HBM when the clock starts
+(four distinct batches, 16 384 particles, cycled; every step's results -- reference, in-plane angle,
+mirror, shifts, maxCC -- still go back to page-locked host memory inside the clock); the PCIe-inclusive
+rate of SURVEY.md 8d -- every batch copied from page-locked host memory inside the clock, two device
+buffers, the copy of batch k+1 on its own stream under step k -- is printed beside it as `value_streamed`
+(`--timed streamed` makes it the timed region, as it was in rounds 3-4).  Weak scaling: per-GPU work is
+fixed as N grows.
 
 One JSON line on rank 0 (see the driver contract in the task statement), with
   roofline      -- the kernel that dominates the timed region, algorithmic work / HIP-event time
   worst_case    -- the same step with the data-dependent shortcuts of the matcher switched off
-  value_resident -- the same steps on a batch that already lies in HBM (no host traffic)
+  value_streamed -- the same steps + finish with every batch H2D inside the clock
+  noise_gallery / compact_phantom / flexalign -- the data dependence of the headline, and BASELINE config 5
   cpu_baseline  -- the CPU oracle ("port" of the reference algorithm; Xmipp itself cannot be
                    built here: xmippCore/FFTW absent) timed on a bounded sample on rank 0.
 
@@ -81,6 +84,10 @@ def parse(argv=None):
     ap.add_argument("--rf-opt", action="append", default=[], help="name=value passed to xh_rf_set_option (A/B runs)")
     ap.add_argument("--no-prune", action="store_true", help="transform every correlation row (S3 branch and bound off)")
     ap.add_argument("--tau-rel", type=float, default=0, help="ambiguity margin of the coarse pass relative to S (0: library default)")
+    ap.add_argument("--timed", default="resident", choices=["resident", "streamed"],
+                    help="what the timed region of `value` feeds on: resident = the batches lie in HBM when the clock starts (the task statement's contract: "
+                         "the PCIe-inclusive rate is never `value`); streamed = every batch H2D from page-locked memory inside the timed region (SURVEY.md 8d's "
+                         "metric, `value` of rounds 3-4). The other one is printed beside it (`value_streamed` / `value_resident`)")
     ap.add_argument("--no-flexalign", action="store_true", help="skip the FlexAlign leg (config 5, a child process) of the default line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the worst-case and host-streaming legs after the timed region")
     ap.add_argument("--pipeline", type=int, default=1, help="1: the reconstruction half (shift, CTF, FFT, gridding) of batch k runs on a second "
@@ -765,7 +772,20 @@ def main():
         barrier()
         return ta, tb, time.perf_counter()
 
-    t0, t_fin0, t1 = streamed_steps(args.steps, True)
+    # the batches of the resident form: all of them in HBM before the clock starts (4 GB at the defaults), cycled like the host ones
+    dres = [particles] + [h.to(dev) for h in host[1:]] if args.timed == "resident" or not args.no_extra_legs else [particles]
+
+    def resident_steps(nsteps, record):
+        barrier()
+        ta = time.perf_counter()
+        for k in range(nsteps):
+            step(record, dres[k % len(dres)], k % len(dres), k & 1)
+        tb = time.perf_counter()
+        finish()
+        barrier()
+        return ta, tb, time.perf_counter()
+
+    t0, t_fin0, t1 = (resident_steps if args.timed == "resident" else streamed_steps)(args.steps, True)
     elapsed = t1 - t0
     # the once-per-run tail (mirror/crop + all-reduce + finaliser + reset) as the device saw it: events on the reconstruction stream
     # around it.  (The host clock from "all steps queued" to the end -- what rounds 3-4 printed here -- also holds the steps the
@@ -784,21 +804,23 @@ def main():
     # ---- extra legs, outside the timed region (every rank runs them: same collectives, same barriers)
     extra = {}
     if not args.no_extra_legs:
-        # (1) the same steps on a batch that already lies in HBM: what the host traffic costs is value_resident - value
+        # (1) the same steps + finish fed the other way: what the host traffic costs is value_resident - value_streamed
         nres = max(2, min(args.steps, 4))
-        barrier()
-        th0 = time.perf_counter()
-        for _ in range(nres):
-            step(False)
-        finish()
-        barrier()
-        el = time.perf_counter() - th0
+        nleg = max(2, min(args.steps, 8))
+        ta_, _, tb_ = (streamed_steps if args.timed == "resident" else resident_steps)(nleg, False)
+        el = tb_ - ta_
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
-        extra["value_resident"] = nres * B * world / el
-        extra["resident_leg"] = {"steps": nres, "what": "same steps + finish on a batch resident in HBM, no host traffic"}
+        if args.timed == "resident":
+            extra["value_streamed"] = nleg * B * world / el
+            extra["streamed_leg"] = {"steps": nleg, "what": "SURVEY.md 8d's PCIe-inclusive rate (`value` of rounds 3-4): the same steps + finish with every batch copied "
+                                                             "from page-locked host memory inside the clock (two device buffers, the copy of batch k + 1 under step k), results "
+                                                             "copied back; on a box whose host link is shared with other jobs it falls below `value` (seen: 85 k against 102 k)"}
+        else:
+            extra["value_resident"] = nleg * B * world / el
+            extra["resident_leg"] = {"steps": nleg, "what": "same steps + finish on batches resident in HBM, no batch copies"}
         if pipelined:
             # (1b) the same without the second stream: every stage of a step behind the one before it
             if rf is not None:
@@ -994,7 +1016,10 @@ def main():
                    "mode": args.mode, "box": D, "nrefs": nrefs, "references": args.refs, "neighbours": args.neighbours or None,
                    "particles_per_step_per_gpu": B,
                    "particles_total": total_particles, "unique_particles_per_gpu": nuniq * B,
-                   "host_traffic": "every batch H2D from page-locked memory (double-buffered, second stream), results D2H, inside the timed region",
+                   "timed": args.timed,
+                   "host_traffic": ("batches resident in HBM when the clock starts (the task statement's `value`), results D2H inside the timed region; the rate with "
+                                    "every batch H2D inside the clock is `value_streamed`" if args.timed == "resident" else
+                                    "every batch H2D from page-locked memory (double-buffered, second stream), results D2H, inside the timed region"),
                    "pipeline": ("reconstruction half of batch k on a second stream beside the matching of batch k+1" if pipelined else "one stream"),
                    "parallelism": f"particle shards x{world}, one all-reduce"},
         "roofline": roofline, "roofline_other_kernels": others,
