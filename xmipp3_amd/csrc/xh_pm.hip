@@ -777,23 +777,39 @@ __global__ void k_pm_pack_tiles(const xh_cf *__restrict__ src, float4 *__restric
 // among the PT waves of a column -- is served by the CU's L1, so the L2 delivers (PT + QT) tiles per PT QT products: 1.25 per
 // product for the 1 x 4 workgroup of rounds 1-4, 0.5 for 4 x 4 (the full-frequency contraction moved 106 GB through the L2s per
 // 4096 particles x 1000 references and was bound by exactly that).
-template <int PT, int QT>
+// LDS (PT = 1 only): the operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, many quads in flight), a
+// stage of XH_CT_NQ quads at a time into one of two buffers -- the A quads once per workgroup, every wave its own B quads --, and the
+// waves read their float4 out of LDS one quad ahead of the matrix instructions.  The quads of a frequency slice are consecutive in
+// memory, so stage s is simply quads [q0 + s NQ, q0 + (s + 1) NQ).  A stage switch is one s_waitcnt + one workgroup barrier per
+// 4 NQ matrix instructions and wave; the waves of a workgroup walk the same quads, so they arrive together.  Same products in
+// the same order as the direct form: the same bits.
+#define XH_CT_NQ 4
+template <int PT, int QT, bool LDS = false>
 __global__ void __launch_bounds__(64 * PT * QT)
 k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ Bpack, float4 *__restrict__ raw,
                    const int *__restrict__ qoff, const int *__restrict__ kbounds, int nk, int totalQuads, int nparticles,
                    int nq, int nqtiles, int nptiles, int dbg, float2 *__restrict__ bpart, int rawStride, int kStore)
 {
+    static_assert(!LDS || (PT == 1 && XH_PW2 == 1 && XH_CT_NQ % QT == 0), "the LDS form shares one particle tile per workgroup");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qtile = blockIdx.x * QT + wv % QT, ptile0 = (blockIdx.y * PT + wv / QT) * XH_PW2;
+    int qtile = blockIdx.x * QT + wv % QT;
+    const int ptile0 = (blockIdx.y * PT + wv / QT) * XH_PW2;
     const int kBeg = kbounds[blockIdx.z], kEnd = kbounds[blockIdx.z + 1];
-    if (qtile >= nqtiles) return;
+    if (!LDS && qtile >= nqtiles) return;
+    // (with barriers in the loop every wave stays: a wave beyond the last reference tile multiplies the last tile again, its rows
+    // q >= nq are never stored)
+    const int qtileStore = qtile;
+    qtile = min(qtile, nqtiles - 1);
     const float4 *A[XH_PW2];
 #pragma unroll
     for (int t = 0; t < XH_PW2; ++t) A[t] = Apack + (size_t)min(ptile0 + t, nptiles - 1) * totalQuads * 64 + lane;
     const float4 *B = Bpack + (size_t)qtile * totalQuads * 64 + lane;
+    constexpr int STAGE_F4 = LDS ? (XH_CT_NQ + QT * XH_CT_NQ) * 64 : 1;          // float4 per stage buffer
+    __shared__ float4 sOp[2 * STAGE_F4];
+    const unsigned sBase = LDS ? (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float4 *)sOp : 0u;
     const int hi = lane >> 5, j = lane & 31;
     const int qj = j >> 1, odd = j & 1;
-    const int q = qtile * 16 + qj;
+    const int q = qtileStore * 16 + qj;
     const int lastQuad = qoff[nk] - 1;
     // branch-and-bound of S3 (k_pm_prune_plan): sum over this slice's frequencies of the moduli of the straight
     // and mirror coefficients of each (particle, reference) row this lane writes
@@ -812,12 +828,51 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
     // current one ends.  (Restarting it per frequency cost a full L2 round trip 399 times per tile pair: the high frequencies have
     // one or two quads each.)  Set 0 always holds the quad to be multiplied next.
     float4 a0[XH_PW2], a1[XH_PW2], b0, b1;
-    {
-        const int q0 = min(qoff[kBeg], lastQuad);
-        b0 = B[(size_t)q0 * 64]; b1 = b0;
+    const int qFirst = min(qoff[kBeg], lastQuad);
+    int curStage = -1;
+    // stage s of the slice into buffer s & 1: this wave's B quads and its share of the A quads
+    // (everything the copy instructions take through scalar registers is made wave-uniform for the compiler's benefit)
+    const int wvq = __builtin_amdgcn_readfirstlane(wv % QT), qtileU = __builtin_amdgcn_readfirstlane(qtile);
+    const int ptileU = __builtin_amdgcn_readfirstlane(min(ptile0, nptiles - 1));
+    auto issueStage = [&](int st) {
+        const unsigned buf = sBase + (unsigned)(st & 1) * (unsigned)(STAGE_F4 * 16);
+        const unsigned off = (unsigned)lane * 16u;
 #pragma unroll
-        for (int t = 0; t < XH_PW2; ++t) { a0[t] = A[t][(size_t)q0 * 64]; a1[t] = a0[t]; }
-    }
+        for (int jq = 0; jq < XH_CT_NQ; ++jq) {
+            const int qd = min(qFirst + st * XH_CT_NQ + jq, lastQuad);
+            const char *gb = reinterpret_cast<const char *>(Bpack) + ((size_t)qtileU * totalQuads + qd) * 1024;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(gb),
+                         "s"(buf + (unsigned)(XH_CT_NQ + wvq * XH_CT_NQ + jq) * 1024u) : "memory");
+            if (jq % QT == wvq) {
+                const char *ga = reinterpret_cast<const char *>(Apack) + ((size_t)ptileU * totalQuads + qd) * 1024;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(ga), "s"(buf + (unsigned)jq * 1024u) : "memory");
+            }
+        }
+    };
+    // the operands of quad qd into (av, bv); LDS: out of the stage buffers, switching stage when qd is the first quad of the next one
+    auto fetch = [&](int qd, float4 (&av)[XH_PW2], float4 &bv) {
+        if constexpr (!LDS) {
+            bv = B[(size_t)qd * 64];
+#pragma unroll
+            for (int t = 0; t < XH_PW2; ++t) av[t] = A[t][(size_t)qd * 64];
+        } else {
+            const int rel = qd - qFirst, st = rel / XH_CT_NQ, jq = rel - st * XH_CT_NQ;
+            if (st > curStage) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of stage st have landed ...
+                __syncthreads();                                        // ... everybody's have, and nobody reads buffer (st + 1) & 1 any more
+                curStage = st;
+                issueStage(st + 1);
+            }
+            const float4 *bufp = sOp + (size_t)(st & 1) * STAGE_F4;
+            av[0] = bufp[jq * 64 + lane];
+            bv = bufp[(XH_CT_NQ + wvq * XH_CT_NQ + jq) * 64 + lane];
+        }
+    };
+    if constexpr (LDS) issueStage(0);
+    fetch(qFirst, a0, b0);
+    b1 = b0;
+#pragma unroll
+    for (int t = 0; t < XH_PW2; ++t) a1[t] = a0[t];
     for (int k0 = kBeg; k0 < kEnd; k0 += 4) {
         xh_f32x16 acc[XH_PW2][4];
 #pragma unroll
@@ -835,8 +890,7 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
 #define XH_CT_STEP(AC, BC, AN, BN, QN)                                                                        \
                 {                                                                                              \
                     const int qn_ = (QN) <= lastQuad ? (QN) : lastQuad;                                        \
-                    BN = B[(size_t)qn_ * 64];                                                                  \
-                    _Pragma("unroll") for (int t = 0; t < XH_PW2; ++t) AN[t] = A[t][(size_t)qn_ * 64];         \
+                    fetch(qn_, AN, BN);                                                                        \
                     __builtin_amdgcn_sched_barrier(0);                                                         \
                     _Pragma("unroll") for (int t = 0; t < XH_PW2; ++t) {                                       \
                         acc[t][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[t].x, BC.x, acc[t][kk], 0, 0, 0); \
@@ -3797,6 +3851,14 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
                            (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,                                          \
                            (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles,             \
                            pm->contract_dbg, pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr, rawStride, rawStride)
+        // the LDS-DMA form pays where a frequency has many quads (the two-level cut keeps the low frequencies: every ring, 16 quads each:
+        // 1.87 -> 1.73 ms per 4096 x 1000 rows); over all frequencies its barriers cost more than the deeper pipeline saves (11.7 -> 12.6 ms)
+        if (pm->contract_shape == 141 || (pm->contract_shape == 14 && K0 < L.nk)) {
+            hipLaunchKernelGGL((k_pm_contract_mfma<1, 4, true>), dim3((qtiles + 3) / 4, ptiles, XH_KSPLIT), dim3(256), 0, ctx->stream, (const float4 *)pm->d_Apack.p,
+                               (const float4 *)pm->d_Bpack.p, (float4 *)pm->d_raw.p, (const int *)pm->d_qoff.p,
+                               (const int *)(K0 < L.nk ? pm->d_kboundsLow.p : pm->d_kbounds.p), L.nk, pm->totalQuads, m, nq, qtiles, ptiles,
+                               pm->contract_dbg, pruning ? (float2 *)pm->d_bpart.p : (float2 *)nullptr, rawStride, rawStride);
+        } else
         if (pm->contract_shape == 44) XH_CONTRACT(4, 4);
         else if (pm->contract_shape == 24) XH_CONTRACT(2, 4);
         else if (pm->contract_shape == 22) XH_CONTRACT(2, 2);
