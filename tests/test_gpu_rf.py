@@ -771,7 +771,7 @@ def test_cheap_ctf_form_against_the_general_formula(gpu, oracle, kind):
 def test_launch_order_by_plane_changes_only_the_summation_order(gpu):
     """order_spaces 1 (the product: the traverse spaces of a launch ordered by plane, voxel queues shared between projections of one
     direction) against 0 (input order): the same voxels, sums equal to float rounding -- on orientations as the matcher assigns them
-    (a few directions, many in-plane angles), through the device-side entry point, and with a symmetry group."""
+    (a few directions, many in-plane angles), through the device-side and the host-side entry point, without and with a symmetry group (c4)."""
     xa, ctx, torch = gpu
     D, n = 64, 96
     rng = np.random.default_rng(5)
@@ -780,14 +780,16 @@ def test_launch_order_by_plane_changes_only_the_summation_order(gpu):
     imgs = torch.from_numpy(rng.standard_normal((n, D, D)).astype(np.float32)).cuda()
     from xmipp3_amd.api import ctf_params
     ctfs = xa.RecFourier.ctf_param_array([ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=15000.0 + 100 * i, DeltafV=15000.0 + 100 * i) for i in range(n)])
-    temps = []
-    for order in (1, 0):
-        rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
-        rf.set_option("order_spaces", order)
-        rf.insert_images(imgs, torch.from_numpy(ang).cuda(), ctf_array=ctfs)
-        v, w = rf.temp_spaces()
-        temps.append((v.cpu().numpy(), w.cpu().numpy()))
-    (v1, w1), (v0, w0) = temps
-    assert (w0 != 0).sum() > 50_000
-    assert np.array_equal(w1 != 0, w0 != 0)
-    assert np.abs(w1 - w0).max() <= 2e-6 * np.abs(w0).max() and np.abs(v1 - v0).max() <= 2e-6 * np.abs(v0).max()
+    c4 = np.stack([synth.euler_matrix(90.0 * k, 0.0, 0.0) for k in range(4)])
+    for sym, dev_angles in ((None, True), (c4, True), (c4, False)):
+        temps = []
+        for order in (1, 0):
+            rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
+            rf.set_option("order_spaces", order)
+            rf.insert_images(imgs, torch.from_numpy(ang).cuda() if dev_angles else ang, ctf_array=ctfs, sym=sym)
+            v, w = rf.temp_spaces()
+            temps.append((v.cpu().numpy(), w.cpu().numpy()))
+        (v1, w1), (v0, w0) = temps
+        assert (w0 != 0).sum() > 50_000
+        assert np.array_equal(w1 != 0, w0 != 0)
+        assert np.abs(w1 - w0).max() <= 2e-6 * np.abs(w0).max() and np.abs(v1 - v0).max() <= 2e-6 * np.abs(v0).max()
