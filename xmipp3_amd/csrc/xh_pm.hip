@@ -2279,6 +2279,9 @@ k_pm_bestshift(const T *__restrict__ Rraw, int rstride, const xh_c2<T> *__restri
 // shift by D: an index modulo D); products and the five sums stay in double.  D is a power of two here (64, 128, 256).
 // Every discrete decision -- arg-max, window, max_shift rejection -- that comes within eps |max| of flipping flags the
 // particle for the double-precision chain, exactly as before.
+#ifndef XH_BS_BAND
+#define XH_BS_BAND 16
+#endif
 __global__ void __launch_bounds__(256)
 k_pm_bestshift_coarse(const float *__restrict__ Rraw, const xh_cf *__restrict__ zimg, const int *__restrict__ refno,
                       const unsigned char *__restrict__ flip, int D, double maxShift, double *__restrict__ shiftX,
@@ -2408,6 +2411,52 @@ k_pm_bestshift_coarse(const float *__restrict__ Rraw, const xh_cf *__restrict__ 
     __syncthreads();
     const bool ident = ox == 0.0 && oy == 0.0;
     double sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0;
+    // D = 256 (a thread <-> a column): the rows a band of XH_BS_BAND output rows interpolates from are, almost always, XH_BS_BAND + 1
+    // consecutive rows of Mimg (tap rows r1, r1 + 1 modulo D) -- staged in LDS once, every pixel then takes its four taps from there
+    // instead of from global memory (five 8-byte loads per pixel, of which the vector cache served four: the kernel's time).  A band
+    // that holds the wrap seam or the extrapolated row (tap1) is not consecutive and takes the loads below.  Same values in the same
+    // order: the same sums.
+    __shared__ float sImg[XH_BS_BAND + 1][256];
+    __shared__ int sContig;
+    const bool tiled = D == 256 && !ident;
+    if (tiled)
+    for (int i0 = 0; i0 < D; i0 += XH_BS_BAND) {
+        if (threadIdx.x == 0) sContig = 1;
+        __syncthreads();
+        const int rb = sN1[i0] >> lgD;
+        if (threadIdx.x < XH_BS_BAND) {
+            const int i = i0 + threadIdx.x;
+            if ((sN1[i] >> lgD) != ((rb + (int)threadIdx.x) & msk) || (sN2[i] >> lgD) != ((rb + (int)threadIdx.x + 1) & msk)) sContig = 0;
+        }
+        __syncthreads();
+        const bool contig = sContig != 0;
+        if (contig) {
+            float st[XH_BS_BAND + 1];
+#pragma unroll
+            for (int r = 0; r < XH_BS_BAND + 1; ++r) st[r] = Z[(((rb + r) & msk) << lgD) + threadIdx.x].y;
+#pragma unroll
+            for (int r = 0; r < XH_BS_BAND + 1; ++r) sImg[r][threadIdx.x] = st[r];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < XH_BS_BAND; ++rr) {
+            const int i = i0 + rr, t = (i << lgD) + threadIdx.x;
+            const xh_cf zc = Z[t];
+            const float wyv = sWy[i];
+            float q00, q01, q10, q11;
+            if (contig) { q00 = sImg[rr][m1]; q01 = sImg[rr][m2]; q10 = sImg[rr + 1][m1]; q11 = sImg[rr + 1][m2]; }
+            else {
+                const int r1 = sN1[i], r2 = sN2[i];
+                q00 = Z[r1 + m1].y; q01 = Z[r1 + m2].y; q10 = Z[r2 + m1].y; q11 = Z[r2 + m2].y;
+            }
+            const float wy_1 = 1.f - wyv, wx_1 = 1.f - wx;
+            const float vf = wy_1 * (wx_1 * q00 + wx * q01) + wyv * (wx_1 * q10 + wx * q11);
+            const double val = (double)vf, rr_ = (double)zc.x;
+            sx += rr_; sxx += rr_ * rr_; sy += val; syy += val * val; sxy += rr_ * val;
+        }
+        __syncthreads();
+    }
+    else
     for (int t0 = threadIdx.x; t0 < n; t0 += 4 * 256) {
         float r[4], q00[4], q01[4], q10[4], q11[4], wy[4];
 #pragma unroll
