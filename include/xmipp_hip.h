@@ -117,7 +117,7 @@ int xh_rf_destroy(xh_rf *rf);
  * are packed, or through planes), "ctf_fast" 1 | 0 (CTFs without envelope terms evaluated by the cheap form of preloadCTF's value, or the
  * general double-precision formula for every pixel), "records_from_images" 0 | 1 (records written by the FFT's row pass), "order_spaces" 1 | 0 (the traverse spaces of a launch
  * ordered by plane -- the gridding kernel then shares the voxel queue between projections of one direction -- or in input order; the order
- * permutes the launch's float additions), "tile_max_spaces",
+ * permutes the launch's float additions), "shift_bands" 1 | 0 (256-px images shifted band by band out of LDS, or by k_rf_shift: same bits), "tile_max_spaces",
  * "fft_variant" 1 | 2 (columns-first / rows-first projection FFT). Unknown names fail with XH_ERR_ARG. */
 int xh_rf_set_option(xh_rf *rf, const char *name, double value);
 /* derived sizes (RFA:196-199): paddedImgSize P, maxVolumeIndexYZ mv, fft crop sizeX=mv/2, sizeY=mv */

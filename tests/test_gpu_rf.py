@@ -793,3 +793,27 @@ def test_launch_order_by_plane_changes_only_the_summation_order(gpu):
         assert (w0 != 0).sum() > 50_000
         assert np.array_equal(w1 != 0, w0 != 0)
         assert np.abs(w1 - w0).max() <= 2e-6 * np.abs(w0).max() and np.abs(v1 - v0).max() <= 2e-6 * np.abs(v0).max()
+
+
+@pytest.mark.gpu
+def test_shift_band_by_band_gives_the_same_bits(gpu):
+    """k_rf_shift_band (256-px images: the coefficients of a band of rows staged in LDS) against k_rf_shift (option shift_bands 0):
+    the same expressions in the same order, so the same bits -- fractional and whole shifts, shifts that wrap, mirrored particles,
+    untouched ones."""
+    xa, ctx, torch = gpu
+    D, n = 256, 12
+    rng = np.random.default_rng(21)
+    imgs = torch.from_numpy(rng.standard_normal((n, D, D)).astype(np.float32)).cuda()
+    shifts = rng.uniform(-9, 9, (n, 2))
+    shifts[0] = 0.0
+    shifts[1] = (3.0, -2.0)
+    shifts[2] = (130.25, -131.5)
+    flips = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    flips[0] = 0
+    outs = []
+    for bands in (1, 0):
+        rf = xa.RecFourier(ctx, D)
+        rf.set_option("shift_bands", bands)
+        outs.append(rf.shift_images(imgs, shifts, flips=flips).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][0], imgs[0].cpu().numpy())

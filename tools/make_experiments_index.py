@@ -22,6 +22,7 @@ R5 = [
     ("matcher S2", "bounds-only contraction in one chunk per batch (the chunk size had still been computed for stored coefficients)", "profiles/r05_b_bench_refsnoise.json", "noise gallery 72 -> 76.6 k particles/s (contraction 13.2 -> 10.7 ms alone)", "yes"),
     ("matcher S2", "operands through LDS by LDS-DMA (`global_load_lds_dwordx4`), stages of four quads in two buffers, one barrier per stage (`k_pm_contract_mfma<1, 4, true>`); same products in the same order", "DESIGN.md 5 (round 5)", "two-level contraction (K0 = 28, sixteen quads per frequency) 1.87 -> 1.73 ms; all 399 frequencies 11.7 -> 12.6 ms: adopted for the first, not for the second -- operand delivery is not what holds the matrix pipes at 51-54 %", "yes / no"),
     ("matcher S6", "`k_pm_bestshift_coarse`: the translated particle's taps from LDS-staged bands of 16 + 1 rows of Mimg instead of four global gathers per pixel (bands with the wrap seam or the extrapolated row keep the gathers)", "DESIGN.md 5 (round 5)", "0.95 -> 0.665 ms (bands of 32 rows: 0.70)", "yes"),
+    ("gridding front end", "`k_rf_shift_band`: 256-px images shifted band by band, the 19 coefficient rows of a band of 16 staged in LDS (1.2 instead of 7 coefficient loads per pixel); same bits", "DESIGN.md 5 (round 5)", "0.81 -> 0.73 ms: the loads were not the bound (the B-spline weights of every row, evaluated with the reference's expressions, are half of it)", "yes"),
     ("bench", "three warm-up steps instead of one; `value` on batches resident in HBM, the PCIe-inclusive rate beside it", "profiles/r05_c_bench_default.json", "with one warm-up step the first form measured read 3 % low (buffers of data-dependent size still growing inside the clock); a box with a busy host link ran the streamed form at 85 k where the resident one gave 102 k", "yes"),
     ("library", "pinned staging area of the small host arrays in two halves with an event each", "profiles/r05_c_bench_modegrid.json", "`--mode grid` 105 -> 131 k projections/s (the host waited, at every wrap, for the copies it had just queued)", "yes"),
     ("FlexAlign", "rocprofv3 over the two-lane bench (two host threads)", "tools/collect_r05.sh", "hangs (twice, 40 GPU-minutes lost); one lane profiles fine -- the FlexAlign kernel table is collected with `--fa-lanes 1`", "-"),

@@ -268,6 +268,7 @@ struct xh_rf {
     int ntiles[2] = {0, 0};
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
     XhBuf d_finSpec, d_finVol, d_finFbt;   // the finaliser's expanded spectrum, output volume and Fourier blob table
+    int shift_bands = 1;  // 256-px images shifted band by band out of LDS (k_rf_shift_band; 0: k_rf_shift, for A/B)
     int order_spaces = 1; // the traverse spaces of a launch ordered by plane, so that k_rf_grid reuses voxel queues (0: input order, for A/B)
     XhBuf d_spacePos;
     int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
@@ -457,6 +458,82 @@ k_rf_shift(const float *__restrict__ coefs, const float *__restrict__ imgs,
     }
 #pragma unroll
     for (int k = 0; k < XH_SHIFT_V; ++k) {
+        float wy[4];
+        d_bspline03_w4<float>(ys[k], m1[k], wy);
+        float columns = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) columns += rows[k + tt] * wy[tt];
+        out[base + (size_t)(i0 + k) * D + j] = columns;
+    }
+}
+
+// The same for 256-px images, band by band: a workgroup owns XH_SHB output rows of an image, thread <-> column.  The XH_SHB + 3 rows of
+// coefficients a band interpolates from are staged in LDS once (k_rf_shift's threads fetched 7 coefficients per output pixel through
+// the vector cache; here 1.2), the row sums are formed out of LDS, same expressions in the same order: the same bits.  A band that
+// holds the wrap of the shifted rows falls back to interpolatedElementBSpline2D pixel by pixel, like a group of k_rf_shift does.
+#define XH_SHB 16
+__global__ void __launch_bounds__(256)
+k_rf_shift_band(const float *__restrict__ coefs, const float *__restrict__ imgs, const float2 *__restrict__ shifts,
+                const unsigned char *__restrict__ flips, float *__restrict__ out, int D)
+{
+    __shared__ float sC[XH_SHB + 3][256];
+    const int p = blockIdx.y, i0 = blockIdx.x * XH_SHB, j = threadIdx.x;
+    const float2 sh = shifts[p];
+    const bool flip = flips && flips[p];
+    const size_t base = (size_t)p * D * D;
+    if (!flip && sh.x == 0.f && sh.y == 0.f) {
+#pragma unroll
+        for (int k = 0; k < XH_SHB; ++k) out[base + (size_t)(i0 + k) * D + j] = imgs[base + (size_t)(i0 + k) * D + j];
+        return;
+    }
+    const int cen = D / 2;
+    const float minp = -cen, maxp = D - cen - 1;
+    float xp = flip ? sh.x - (float)(j - cen) : (float)(j - cen) - sh.x;
+    if (xp < minp - 1e-6f || xp > maxp + 1e-6f) xp = d_realwrap<float>(xp, minp - 0.5f, maxp + 0.5f);
+    float yp[XH_SHB], ys[XH_SHB];
+    int m1[XH_SHB];
+    bool chain = true;
+#pragma unroll
+    for (int k = 0; k < XH_SHB; ++k) {
+        yp[k] = (float)(i0 + k - cen) - sh.y;
+        if (yp[k] < minp - 1e-6f || yp[k] > maxp + 1e-6f) yp[k] = d_realwrap<float>(yp[k], minp - 0.5f, maxp + 0.5f);
+        ys[k] = yp[k] - (float)(-cen);
+        m1[k] = (int)ceilf(ys[k] - 2.f);
+        chain = chain && m1[k] == m1[0] + k;
+    }
+    const float *cf = coefs + base;
+    if (!chain) {                                       // (the same for every thread of the band: the rows depend on the row index only)
+#pragma unroll
+        for (int k = 0; k < XH_SHB; ++k) out[base + (size_t)(i0 + k) * D + j] = d_interp<float>(cf, D, xp, yp[k]);
+        return;
+    }
+    float st[XH_SHB + 3];
+#pragma unroll
+    for (int r = 0; r < XH_SHB + 3; ++r) {
+        const int m = m1[0] + r;
+        const int em = m < 0 ? -m - 1 : (m >= D ? 2 * D - m - 1 : m);
+        st[r] = cf[(size_t)em * D + j];
+    }
+#pragma unroll
+    for (int r = 0; r < XH_SHB + 3; ++r) sC[r][j] = st[r];
+    __syncthreads();
+    const float xs = xp - (float)(-cen);
+    const int l1 = (int)ceilf(xs - 2.f);
+    float wx[4];
+    d_bspline03_w4<float>(xs, l1, wx);
+    int el[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int l = l1 + u; el[u] = l < 0 ? -l - 1 : (l >= D ? 2 * D - l - 1 : l); }
+    float rows[XH_SHB + 3];
+#pragma unroll
+    for (int r = 0; r < XH_SHB + 3; ++r) {
+        float acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += sC[r][el[u]] * wx[u];
+        rows[r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < XH_SHB; ++k) {
         float wy[4];
         d_bspline03_w4<float>(ys[k], m1[k], wy);
         float columns = 0;
@@ -1451,6 +1528,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
     else if (!strcmp(name, "order_spaces")) rf->order_spaces = (int)value;
+    else if (!strcmp(name, "shift_bands")) rf->shift_bands = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
     else if (!strcmp(name, "fft_variant")) rf->fft_variant = (int)value;
@@ -1684,6 +1762,10 @@ static int shift_images_run(xh_rf *rf, const float *d_imgs, const float *d_coefs
     for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
         const int m = std::min(65535, n - i0);
         const size_t o = (size_t)i0 * D * D;
+        if (D == 256 && rf->shift_bands)
+            hipLaunchKernelGGL(k_rf_shift_band, dim3(D / XH_SHB, m), dim3(256), 0, ctx->stream, coefs + o, d_imgs + o, d_shiftXY + i0, d_flip ? d_flip + i0 : nullptr,
+                               d_out + o, D);
+        else
         hipLaunchKernelGGL(k_rf_shift, dim3((D * ((D + XH_SHIFT_V - 1) / XH_SHIFT_V) + 255) / 256, m), dim3(256), 0, ctx->stream, coefs + o, d_imgs + o,
                            d_shiftXY + i0, d_flip ? d_flip + i0 : nullptr, d_out + o, D);
         XH_LAUNCH_CHECK();
