@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--movie-mode", type=int, default=0, choices=[0, 1, 2, 6], help="flexalign mode: how the frames lie in host memory, as an MRC data mode: 0 int8 counts "
                     "(default: what a K3 writes, 0.94 GB per movie cross the link), 1 int16 / 6 uint16 counts -- all cast to float on the device "
                     "(xh_movie_frame_to_float) --, 2 float32 (3.77 GB per movie: the link then bounds the rate)")
+    ap.add_argument("--fa-opt", action="append", default=[], metavar="NAME=VALUE", help="flexalign mode: xh_fa_set_option on every lane (A/B runs), "
+                    "e.g. --fa-opt pruned_columns=0 --fa-opt pairwin_form=0")
     ap.add_argument("--fa-shared-copy", type=int, default=1, help="flexalign mode: 1 one copy stream for all lanes, 0 one per lane")
     ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
@@ -264,6 +266,8 @@ def main_flexalign(args):
                 self.ctx = ctx if idx == 0 else xa.Context(local)
                 self.fa = xa.FlexAlign(self.ctx, Y, X, Ts, max_res)
                 self.fa.set_option("prefilter_ahead", 1)        # the warp's prefilter of the frames runs while the host fits the spline
+                for kv in args.fa_opt:
+                    self.fa.set_option(kv.split("=")[0], float(kv.split("=")[1]))
                 self.dbuf = [torch.empty((N, Y, X), device=dev), torch.empty((N, Y, X), device=dev)]
                 # frames that arrive as counts land here and are cast into dbuf by the lane's first kernel
                 self.rbuf = [torch.empty((N, Y, X), device=dev, dtype=raw_dtype) for _ in range(2)] if args.movie_mode != 2 else self.dbuf

@@ -49,6 +49,28 @@ def test_global_alignment_against_the_oracle(gpu, oracle, N, Y, X, ts, res):
     assert np.abs(got["shiftX"] + t[:, 0]).max() < 0.6 and np.abs(got["shiftY"] + t[:, 1]).max() < 0.6
 
 
+@pytest.mark.parametrize("N,Y,X,ts,res", [(4, 1240, 640, 1.0, 30.0), (4, 992, 700, 1.0, 24.0), (5, 512, 512, 1.0, 8.0)])
+def test_pruned_column_pass_and_packed_pair_windows_change_nothing(gpu, oracle, N, Y, X, ts, res):
+    """The column pass of the frame transform as two matrix products that compute the kept rows only (1240 = 124 x 10 keeps 4 of 10
+    second-step frequencies, 992 = 124 x 8 keeps 4 of 8, 512 = 128 x 4 keeps all) and the pair windows with packed multiply-adds, against
+    the full-length line transforms + the plain pair-window kernel (5e-4 px: two fp32 summation orders) and against the oracle."""
+    xa, ctx, torch = gpu
+    frames, drift = synthetic_movie(N, Y, X, seed=N + Y, smooth=6.0)
+    max_shift = 30.0
+    d = torch.from_numpy(frames).cuda()
+    fa = xa.FlexAlign(ctx, Y, X, ts, res)
+    got = fa.global_alignment(d, max_shift)
+    fa.set_option("pruned_columns", 0)
+    fa.set_option("pairwin_form", 0)
+    old = fa.global_alignment(d, max_shift)
+    assert np.abs(old["bX"] - got["bX"]).max() <= 5e-4 and np.abs(old["bY"] - got["bY"]).max() <= 5e-4 and old["ref"] == got["ref"]
+    fa.set_option("pruned_columns", 1)
+    mid = fa.global_alignment(d, max_shift)
+    assert np.abs(mid["bX"] - got["bX"]).max() <= 5e-4 and np.abs(mid["bY"] - got["bY"]).max() <= 5e-4
+    exp = oracle.fa_global_alignment(frames, Ts=ts, max_shift_px=max_shift, max_res=res)
+    assert np.abs(got["bX"] - exp["bX"]).max() <= 2e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 2e-3 and got["ref"] == exp["ref"]
+
+
 def test_global_alignment_of_k3_sized_frames(gpu):
     """BASELINE config 5 movie (40 frames of 4096 x 5760, the K3 sensor rotated as the FFT test has it; 780 frame pairs): no oracle at this size
     (a double-precision CPU transform of 23.6 Mpixel frames takes minutes); the known drift of the synthetic movie comes out to

@@ -181,6 +181,60 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_a(const fa_cf *__restrict__ 
     }
 }
 
+// The same, one wave per workgroup, RW rows per thread out of a table padded to whole groups of RW rows (zeros beyond wy): no
+// conditions inside the loop, the RW factors of a ky are wave-uniform and arrive by scalar loads, and every complex multiply-add is two
+// packed fused multiply-adds (v_pk_fma_f32): (re, im) += (pr, pr) (tx, ty); (re, im) += (-pi, pi) (ty, tx).
+typedef float fa_v2 __attribute__((ext_vector_type(2)));
+template <int RW>
+__global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ S, int N, int nY, int nX, const fa_v2 *__restrict__ twYp, int wy, int wyp,
+                                                      fa_cf *__restrict__ U, double *__restrict__ stat)
+{
+    const int nxh = nX / 2 + 1;
+    const int kx = blockIdx.x * 64 + threadIdx.x;
+    int a = 0, rem = blockIdx.y;
+    while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
+    const int b = a + 1 + rem;
+    const size_t small = (size_t)nY * nX;
+    const int kxc = min(kx, nxh - 1);
+    const fa_cf *Sa = S + (size_t)a * small + kxc, *Sb = S + (size_t)b * small + kxc;
+    const int yy0 = blockIdx.z * RW;
+    const bool first = blockIdx.z == 0;
+    fa_v2 acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = fa_v2{0.f, 0.f};
+    float ss = 0.f, c0 = 0.f;
+    const float wgt = (kx == 0 || 2 * kx == nX) ? 1.f : 2.f;
+    const fa_v2 *w = twYp + yy0;
+    for (int ky = 0; ky < nY; ++ky, w += wyp) {
+        const fa_cf p = Sa[(size_t)ky * nX], q = Sb[(size_t)ky * nX];
+        const float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
+        if (first) {
+            if (ky == 0) c0 = pr;
+            else ss += wgt * (pr * pr + pi * pi);
+            if (ky == 0 && kx != 0) ss += wgt * (pr * pr + pi * pi);
+        }
+        const fa_v2 vr = fa_v2{pr, pr}, vi = fa_v2{-pi, pi};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const fa_v2 t = w[r];
+            acc[r] = __builtin_elementwise_fma(vr, t, acc[r]);
+            acc[r] = __builtin_elementwise_fma(vi, fa_v2{t.y, t.x}, acc[r]);
+        }
+    }
+    if (kx < nxh) {
+        fa_cf *u = U + ((size_t)blockIdx.y * wy + yy0) * nxh + kx;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (yy0 + r < wy) u[(size_t)r * nxh] = fa_cf{acc[r].x, acc[r].y};
+    }
+    if (first) {
+        if (kx >= nxh) ss = 0.f;
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (threadIdx.x == 0) atomicAdd(&stat[2 * blockIdx.y + 1], (double)ss);
+        if (kx == 0) stat[2 * blockIdx.y] = (double)c0;
+    }
+}
+
 // sum and sum of squares of the correlation map (real part of the inverse transform), one partial per block
 __global__ void __launch_bounds__(256) k_fa_stats(const fa_cf *__restrict__ M, size_t tot, double *__restrict__ part)
 {
@@ -1127,7 +1181,11 @@ struct xh_fa {
     // tables and scratch of the two alignment calls stay with the handle (movie after movie: no allocation, no table upload):
     // grow-only buffers by name, the tables re-made only when the parameters they depend on change
     std::map<std::string, XhBuf> cache;
-    std::string gKey, lKey;
+    std::string gKey, lKey, cKey;
+    // "pruned_columns": the column pass of the frame transform as two matrix products that compute the kept rows only (below)
+    int pruned_cols = 1;
+    int pairwin_form = 1;                 // 1: k_fa_pairwin_a2 (packed multiply-adds, scalar-loaded factors); 0: k_fa_pairwin_a
+    int cn1 = 0, cn2 = 0, cP = 0;         // Y = cn1 cn2; cP of the cn2 second-step frequencies are kept
     // "prefilter_ahead": the local alignment ends with the B-spline prefilter of every frame (which does not need the spline it is
     // about to fit on the host), so the device works while the host solves; xh_fa_apply_bspline then finds the coefficients ready
     int prefilter_ahead = 0;
@@ -1135,6 +1193,13 @@ struct xh_fa {
     int aheadN = 0;
 };
 
+// rows per thread of k_fa_pairwin_a2 for a window of wy rows: the group size in {12, 16, 20} that pads wy least, the larger on a tie
+static int fa_rw_sel(int wy)
+{
+    int best = 20, pad = (wy + 19) / 20 * 20;
+    for (int rw : {16, 12}) { const int p = (wy + rw - 1) / rw * rw; if (p < pad) { pad = p; best = rw; } }
+    return best;
+}
 static int fa_scratch(xh_fa *h, const char *name, size_t bytes, XhBuf **out)
 {
     XhBuf &b = h->cache[name];
@@ -1208,6 +1273,8 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value)
     XH_CHECK(h && name, XH_ERR_ARG, "xh_fa_set_option: bad argument");
     if (!strcmp(name, "window")) h->use_window = value != 0;
     else if (!strcmp(name, "mfma")) h->use_mfma = value != 0;
+    else if (!strcmp(name, "pairwin_form")) h->pairwin_form = (int)value;
+    else if (!strcmp(name, "pruned_columns")) { h->pruned_cols = value != 0; h->cKey.clear(); }
     else if (!strcmp(name, "prefilter_ahead")) { h->prefilter_ahead = value != 0; h->aheadBase = nullptr; }
     else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
@@ -1243,6 +1310,62 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     const int Yh = (h->Y + 1) / 2, nc = h->nc;
     XH_CHECK((size_t)Yh * h->X + (size_t)h->Y * nc <= big, XH_ERR_ARG, "xh_fa_global_alignment: frames of %d x %d are too small", h->Y, h->X);
     fa_cf *Cc = wk + (size_t)Yh * h->X;
+    // Column pass. The reduced frame keeps the nY lowest of the Y frequencies along y (scaleToSizeFourier), so the columns are not
+    // transformed in full: Y = n1 n2, y = b + n2 a, k = k1 + n1 k2,
+    //     T[k1][b]  = sum_a  W_n1^(a k1) C[b + n2 a]                             every k1, every b
+    //     F[k]      = sum_b  W_Y^(b k1) W_n2^(b k2) T[k1][b]                     the k2 whose k is kept only
+    // both as complex matrix products on the matrix cores (k_fa_gemm_mfma), the kept k2 being the first Plow and the last Phigh, so
+    // that the rows of the result are a spectrum of P n1 rows in the usual order and k_fa_reduce reads it like the full one.
+    // n1: the largest divisor of Y that fits one 128-row tile. (4092 = 124 x 33 keeps 8 of 33: 0.36 G complex multiply-adds per K3
+    // frame against two Bluestein line passes + twiddle + transpose over all 4092 rows.)
+    bool colsPruned = false;
+    int cn1 = 0, cn2 = 0, cP = 0;
+    XhBuf *pW1 = nullptr, *pW2 = nullptr, *pT = nullptr, *pR = nullptr;
+    if (h->pruned_cols) {
+        char key[64];
+        snprintf(key, sizeof(key), "%d %d", h->Y, nY);
+        if (h->cKey != key) {
+            int n1 = 0;
+            for (int d = 128; d >= 8; --d) if (h->Y % d == 0) { n1 = d; break; }
+            h->cn1 = 0;
+            if (n1) {
+                const int n2 = h->Y / n1;
+                const int ihalf = std::min(nY / 2 + 1, h->Y / 2 + 1);             // d_fa_crop: rows 0 .. ihalf-1 and Y-(ihalf-2) .. Y-1
+                int Plow = (ihalf + n1 - 1) / n1, Phigh = (std::max(ihalf - 2, 0) + n1 - 1) / n1;
+                if (Plow + Phigh >= n2) { Plow = n2; Phigh = 0; }
+                const int P = Plow + Phigh;
+                const long double twoPi = 6.28318530717958647692528676655900577L;
+                std::vector<fa_cf> W1((size_t)n1 * n1), W2((size_t)n1 * P * n2);
+                for (int k1 = 0; k1 < n1; ++k1)
+                    for (int a = 0; a < n1; ++a) {
+                        const long double ang = -twoPi * (long double)(((long long)k1 * a) % n1) / n1;
+                        W1[(size_t)k1 * n1 + a] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
+                    }
+                for (int k1 = 0; k1 < n1; ++k1)
+                    for (int q = 0; q < P; ++q) {
+                        const int k2 = q < Plow ? q : n2 - Phigh + (q - Plow);
+                        const long long k = k1 + (long long)n1 * k2;
+                        for (int b = 0; b < n2; ++b) {
+                            const long double ang = -twoPi * (long double)((k * b) % h->Y) / h->Y;      // W_Y^(b k1) W_n2^(b k2) = W_Y^(b k)
+                            W2[((size_t)k1 * P + q) * n2 + b] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
+                        }
+                    }
+                XhBuf *t1b = nullptr, *t2b = nullptr;
+                XH_TRY(fa_table(h, "c_W1", W1.data(), sizeof(fa_cf) * W1.size(), &t1b));
+                XH_TRY(fa_table(h, "c_W2", W2.data(), sizeof(fa_cf) * W2.size(), &t2b));
+                h->cn1 = n1; h->cn2 = n2; h->cP = P;
+            }
+            h->cKey = key;
+        }
+        if (h->cn1) {
+            cn1 = h->cn1; cn2 = h->cn2; cP = h->cP;
+            XH_TRY(fa_scratch(h, "c_W1", 0, &pW1));
+            XH_TRY(fa_scratch(h, "c_W2", 0, &pW2));
+            XH_TRY(fa_scratch(h, "c_T", sizeof(fa_cf) * (size_t)h->Y * nc, &pT));
+            XH_TRY(fa_scratch(h, "c_R", sizeof(fa_cf) * (size_t)cP * cn1 * nc, &pR));
+            colsPruned = true;
+        }
+    }
     for (int n = 0; n < N; ++n) {
         const size_t tz = (size_t)Yh * h->X, tc = (size_t)Yh * nc;
         // rows: from the real frame straight into the first line pass, the result left where the third step puts it (a K3 frame's
@@ -1256,6 +1379,18 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
         }
         hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cc, h->Y, h->X, nc, t1, t2);
         XH_LAUNCH_CHECK();
+        if (colsPruned) {
+            // T[k1 n2 + b][kx] = sum_a W[k1][a] C[b + n2 a][kx], one product per b
+            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cn1 + 127) / 128, cn2), dim3(256), 0, ctx->stream, (const float *)pW1->p, (size_t)cn1,
+                               (size_t)0, (const fa_cf *)Cc, (size_t)cn2 * nc, (size_t)nc, (fa_cf *)pT->p, (size_t)cn2 * nc, (size_t)nc, cn1, nc, cn1);
+            // R[q n1 + k1][kx] = sum_b A2[k1][q][b] T[k1 n2 + b][kx], one product per k1
+            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cP + 127) / 128, cn1), dim3(256), 0, ctx->stream, (const float *)pW2->p, (size_t)cn2,
+                               (size_t)cP * cn2, (const fa_cf *)pT->p, (size_t)nc, (size_t)cn2 * nc, (fa_cf *)pR->p, (size_t)cn1 * nc, (size_t)nc, cP, nc, cn2);
+            hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)pR->p, cP * cn1, nc, S + (size_t)n * small, nY, nX,
+                               (const float *)h->lpf.p, inorm);
+            XH_LAUNCH_CHECK();
+            continue;
+        }
         XH_TRY(xh_fft2d_exec_axis(h->cols, (float *)Cc, 0, 1));
         hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)Cc, h->Y, nc, S + (size_t)n * small, nY, nX,
                            (const float *)h->lpf.p, inorm);
@@ -1304,6 +1439,15 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
                     twX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(twoPi * m / nX), (float)std::sin(twoPi * m / nX)};
                 }
             rc = fa_table(h, "g_twY", twY.data(), sizeof(fa_cf) * twY.size(), &pTwY);
+            {
+                // the same factors in rows of wyp = whole groups of rwSel(wy) entries, zeros beyond wy (k_fa_pairwin_a2)
+                const int rw = fa_rw_sel(wy), wyp = (wy + rw - 1) / rw * rw;
+                std::vector<fa_cf> twYp((size_t)nY * wyp, fa_cf{0.f, 0.f});
+                for (int ky = 0; ky < nY; ++ky)
+                    for (int yy = 0; yy < wy; ++yy) twYp[(size_t)ky * wyp + yy] = twY[(size_t)ky * wy + yy];
+                XhBuf *pP = nullptr;
+                if (rc == XH_OK) rc = fa_table(h, "g_twYp", twYp.data(), sizeof(fa_cf) * twYp.size(), &pP);
+            }
             if (rc == XH_OK) rc = fa_table(h, "g_twX", twX.data(), sizeof(fa_cf) * twX.size(), &pTwX);
             if (rc == XH_OK) h->gKey = key;
         }
@@ -1318,10 +1462,23 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
         XhBuf &bTwY = *pTwY, &bTwX = *pTwX, &bU = *pU, &bW = *pW, &bStat = *pStat, &bOut = *pOut;
         if (hipMemsetAsync(bStat.p, 0, sizeof(double) * 2 * (size_t)rows, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
         std::vector<double> out4(4 * (size_t)rows);
+        XhBuf *pTwYp = nullptr;
+        if (rc == XH_OK) rc = fa_scratch(h, "g_twYp", 0, &pTwYp);
         if (rc == XH_OK) {
-            constexpr int RW = 16;
-            hipLaunchKernelGGL((k_fa_pairwin_a<RW>), dim3((nxh + 255) / 256, rows, (wy + RW - 1) / RW), dim3(256), 0, ctx->stream, (const fa_cf *)S, N, nY, nX,
-                               (const fa_cf *)bTwY.p, wy, (fa_cf *)bU.p, (double *)bStat.p);
+            const int rw = fa_rw_sel(wy), nz = (wy + rw - 1) / rw, wyp = nz * rw;
+            if (h->pairwin_form == 0) {
+                constexpr int RW = 16;
+                hipLaunchKernelGGL((k_fa_pairwin_a<RW>), dim3((nxh + 255) / 256, rows, (wy + RW - 1) / RW), dim3(256), 0, ctx->stream, (const fa_cf *)S, N, nY, nX,
+                                   (const fa_cf *)bTwY.p, wy, (fa_cf *)bU.p, (double *)bStat.p);
+            } else if (rw == 20)
+                hipLaunchKernelGGL((k_fa_pairwin_a2<20>), dim3((nxh + 63) / 64, rows, nz), dim3(64), 0, ctx->stream, (const fa_cf *)S, N, nY, nX, (const fa_v2 *)pTwYp->p, wy, wyp,
+                                   (fa_cf *)bU.p, (double *)bStat.p);
+            else if (rw == 16)
+                hipLaunchKernelGGL((k_fa_pairwin_a2<16>), dim3((nxh + 63) / 64, rows, nz), dim3(64), 0, ctx->stream, (const fa_cf *)S, N, nY, nX, (const fa_v2 *)pTwYp->p, wy, wyp,
+                                   (fa_cf *)bU.p, (double *)bStat.p);
+            else
+                hipLaunchKernelGGL((k_fa_pairwin_a2<12>), dim3((nxh + 63) / 64, rows, nz), dim3(64), 0, ctx->stream, (const fa_cf *)S, N, nY, nX, (const fa_v2 *)pTwYp->p, wy, wyp,
+                                   (fa_cf *)bU.p, (double *)bStat.p);
             hipLaunchKernelGGL(k_fa_pairwin_b, dim3(rows), dim3(256), 0, ctx->stream, (const fa_cf *)bU.p, (const fa_cf *)bTwX.p, (const double *)bStat.p, nY, nX, hy, hx, ms,
                                (float *)bW.p, (double *)bOut.p);
             if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
