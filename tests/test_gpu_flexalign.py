@@ -291,6 +291,10 @@ def test_local_alignment_against_the_oracle(gpu, oracle, N, Y, X, patches, psize
     d = np.abs(got["patch_shifts"] - exp["patch_shifts"])
     print("patch shifts: max difference", d.max())
     assert d.max() <= 5e-3
+    # windows of at most 32 rows take the kernel with packed multiply-adds (the 1024-pixel case): the plain kernel gives the same shifts
+    fa.set_option("pairwin_form", 0)
+    old = fa.local_alignment(torch.from_numpy(frames).cuda(), g["shiftX"], g["shiftY"], g["ref"], max_shift, patches, psize, avg, cp)
+    assert np.abs(old["patch_shifts"] - got["patch_shifts"]).max() <= 1e-3
     worst = 0.0
     for n in range(N):
         for y in range(0, Y, 37):

@@ -703,6 +703,103 @@ __global__ void __launch_bounds__(256) k_fa_patch_corr(const fa_cf *__restrict__
     out[2 * pairIdx] = posX; out[2 * pairIdx + 1] = posY;
 }
 
+// k_fa_patch_corr with the first pruned transform like k_fa_pairwin_a2 (all RW >= wy rows of the window per thread in one sweep over ky, the
+// factors of a ky by scalar loads out of a table padded to RW entries per ky, packed multiply-adds) and U in LDS instead of global
+// scratch for the second. Dynamic LDS: wy cxh complex values.
+template <int RW>
+__global__ void __launch_bounds__(256) k_fa_patch_corr2(const fa_cf *__restrict__ S, int N, int CY, int CX, const fa_v2 *__restrict__ twYp, const fa_cf *__restrict__ twX,
+                                                        int y0, int wy, int x0, int wx, int maxDist, float *__restrict__ Wall, double *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char fa_pc_smem[];
+    fa_cf *U = reinterpret_cast<fa_cf *>(fa_pc_smem);
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int cxh = CX / 2 + 1, nt = blockDim.x;
+    int a = 0, rem = blockIdx.x;
+    while (rem >= N - 1 - a) { rem -= N - 1 - a; ++a; }
+    const int b = a + 1 + rem;
+    const size_t pairIdx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;                // blockIdx.y: patch of the batch
+    const fa_cf *Sp = S + (size_t)blockIdx.y * N * CY * cxh;
+    float *W = Wall + pairIdx * wy * wx;
+    for (int kx0 = 0; kx0 < cxh; kx0 += nt) {
+        const int kx = kx0 + threadIdx.x, kxc = min(kx, cxh - 1);
+        const fa_cf *Sa = Sp + (size_t)a * CY * cxh + kxc, *Sb = Sp + (size_t)b * CY * cxh + kxc;
+        fa_v2 acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r] = fa_v2{0.f, 0.f};
+        float sgn = (kxc & 1) ? -1.f : 1.f;                                         // (-1)^(kx + ky) centres the correlation
+        const fa_v2 *w = twYp;
+        for (int ky = 0; ky < CY; ++ky, w += RW, sgn = -sgn) {
+            const fa_cf p = Sa[(size_t)ky * cxh], q = Sb[(size_t)ky * cxh];
+            const float pr = (p.x * q.x + p.y * q.y) * sgn, pi = (p.y * q.x - p.x * q.y) * sgn;
+            const fa_v2 vr = fa_v2{pr, pr}, vi = fa_v2{-pi, pi};
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const fa_v2 t = w[r];
+                acc[r] = __builtin_elementwise_fma(vr, t, acc[r]);
+                acc[r] = __builtin_elementwise_fma(vi, fa_v2{t.y, t.x}, acc[r]);
+            }
+        }
+        if (kx < cxh) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                if (r < wy) U[(size_t)r * cxh + kx] = fa_cf{acc[r].x, acc[r].y};
+        }
+    }
+    __syncthreads();
+    // along x, real part: what a complex-to-real transform of the half spectrum returns
+    for (int o = threadIdx.x; o < wy * wx; o += nt) {
+        const int yy = o / wx, xx = o - yy * wx;
+        const fa_cf *u = U + (size_t)yy * cxh;
+        const fa_cf *w = twX + xx;
+        float acc = 0.f;
+        for (int kx = 0; kx < cxh; ++kx) {
+            const fa_cf t = w[(size_t)kx * wx], v = u[kx];
+            const float r = v.x * t.x - v.y * t.y;
+            acc += (kx == 0 || 2 * kx == CX) ? r : 2.f * r;
+        }
+        W[o] = acc;
+    }
+    __syncthreads();
+    const int xHalf = CX / 2, yHalf = CY / 2;
+    float best = -3.402823466e+38f;
+    int bestIdx = 0x7fffffff;
+    for (int o = threadIdx.x; o < wy * wx; o += nt) {
+        const int yy = o / wx, xx = o - yy * wx;
+        const int ly = y0 + yy - yHalf, lx = x0 + xx - xHalf;
+        if (ly * ly + lx * lx > maxDist * maxDist) continue;
+        const float v = W[o];
+        if (v > best) { best = v; bestIdx = o; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bestIdx;
+    for (int o = nt + threadIdx.x; o < 256; o += nt) { sv[o] = -3.402823466e+38f; si[o] = 0x7fffffff; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        for (int t = threadIdx.x; t < o; t += nt) {
+            const float v = sv[t + o];
+            const int k = si[t + o];
+            if (v > sv[t] || (v == sv[t] && k < si[t])) { sv[t] = v; si[t] = k; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double posX = 0, posY = 0;
+    if (si[0] != 0x7fffffff) {
+        const int refY = y0 + si[0] / wx, refX = x0 + si[0] % wx;
+        double refVal = (double)sv[0];
+        refVal = (refVal == 0) ? 0 : 1.0 / refVal;
+        double sw = 0, slx = 0, sly = 0;
+        for (int y = max(0, refY - 1); y <= min(CY - 1, refY + 1); ++y)
+            for (int x = max(0, refX - 1); x <= min(CX - 1, refX + 1); ++x) {
+                const double rel = (double)W[(size_t)(y - y0) * wx + (x - x0)] * refVal;
+                sw += rel; slx += x * rel; sly += y * rel;
+            }
+        sw = (sw == 0) ? 0 : 1.0 / sw;
+        posX = slx * sw; posY = sly * sw;
+    }
+    out[2 * pairIdx] = posX; out[2 * pairIdx + 1] = posY;
+}
+
 // ---- B-spline warp: applyBSplineTransform(3, ...) (cuda_gpu_geo_transformer.cpp:186-239) ---------------------------------------
 // cubic B-spline prefilter of the (dark / gain corrected) frame as a convolution (xh_bspline.h: exactly the recursion with the
 // half-sample mirror, 33 taps in fp32), both passes in one kernel like k_pm_prefilter_fir2d, for frames that are not square:
@@ -1652,6 +1749,15 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
         for (int kx = 0; kx < cxh; ++kx)
             for (int xx = 0; xx < wx; ++xx) { const double a = twoPi * (double)(((long long)kx * (x0 + xx)) % CX) / CX; tabX[(size_t)kx * wx + xx] = fa_cf{(float)std::cos(a), (float)std::sin(a)}; }
         rc = fa_table(h, "l_Wx", Wx.data(), sizeof(fa_cf) * Wx.size(), &pWx);
+        if (rc == XH_OK && wy <= 32) {
+            // the window's row factors in groups of rwp = wy rounded up to a multiple of four entries per ky, zeros beyond wy (k_fa_patch_corr2)
+            const int rwp = (wy + 3) / 4 * 4;
+            std::vector<fa_cf> tabYp((size_t)CY * rwp, fa_cf{0.f, 0.f});
+            for (int ky = 0; ky < CY; ++ky)
+                for (int yy = 0; yy < wy; ++yy) tabYp[(size_t)ky * rwp + yy] = tabY[(size_t)ky * wy + yy];
+            XhBuf *pP = nullptr;
+            rc = fa_table(h, "l_tabYp", tabYp.data(), sizeof(fa_cf) * tabYp.size(), &pP);
+        }
         if (rc == XH_OK) rc = fa_table(h, "l_Wy", Wy.data(), sizeof(fa_cf) * Wy.size(), &pWy);
         if (rc == XH_OK) rc = fa_table(h, "l_tabY", tabY.data(), sizeof(fa_cf) * tabY.size(), &pTabY);
         if (rc == XH_OK) rc = fa_table(h, "l_tabX", tabX.data(), sizeof(fa_cf) * tabX.size(), &pTabX);
@@ -1709,6 +1815,28 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
                            (const fa_cf *)bT.p, (size_t)cxh, (size_t)PY * cxh, (fa_cf *)bSingle.p, (size_t)cxh, E, CY, cxh, PY);
         hipLaunchKernelGGL(k_fa_patch_sum, dim3((unsigned)(((size_t)nf * E + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)bSingle.p, (fa_cf *)bS.p,
                            (const float *)bFilter.p, nf, N, E, patchesAvg);
+        const size_t ldsU = sizeof(fa_cf) * (size_t)wy * cxh;
+        if (h->pairwin_form != 0 && wy <= 32 && ldsU <= 48 * 1024) {
+            XhBuf *pP = nullptr;
+            rc = fa_scratch(h, "l_tabYp", 0, &pP);
+            if (rc != XH_OK) break;
+            const dim3 g(rows, pb), bdim(std::min(256, 64 * ((cxh + 63) / 64)));
+            double *o = (double *)bRes.p + 2 * (size_t)rows * p0;
+#define XH_FA_PC2(RW_)                                                                                                                                                  \
+    hipLaunchKernelGGL((k_fa_patch_corr2<RW_>), g, bdim, ldsU, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_v2 *)pP->p, (const fa_cf *)bTabX.p, y0, wy, x0, wx, \
+                       maxDist, (float *)bW.p, o)
+            switch ((wy + 3) / 4) {
+            case 1: XH_FA_PC2(4); break;
+            case 2: XH_FA_PC2(8); break;
+            case 3: XH_FA_PC2(12); break;
+            case 4: XH_FA_PC2(16); break;
+            case 5: XH_FA_PC2(20); break;
+            case 6: XH_FA_PC2(24); break;
+            case 7: XH_FA_PC2(28); break;
+            default: XH_FA_PC2(32); break;
+            }
+#undef XH_FA_PC2
+        } else
         hipLaunchKernelGGL(k_fa_patch_corr, dim3(rows, pb), dim3(std::min(256, 64 * ((cxh + 63) / 64))), 0, ctx->stream, (const fa_cf *)bS.p, N, CY, CX, (const fa_cf *)bTabY.p,
                            (const fa_cf *)bTabX.p, y0, wy, x0, wx, maxDist, (fa_cf *)bU.p, (float *)bW.p, (double *)bRes.p + 2 * (size_t)rows * p0);
         if (hipGetLastError() != hipSuccess) { xh_set_error("xh_fa_local_alignment: kernel launch failed"); rc = XH_ERR_HIP; }
