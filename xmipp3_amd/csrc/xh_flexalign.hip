@@ -37,6 +37,7 @@
 
 namespace {
 typedef float2 fa_cf;
+typedef float fa_v2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ fa_cf fa_conj(fa_cf a) { return fa_cf{a.x, -a.y}; }
 
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(256) k_fa_reduce(const fa_cf *__restrict__ B, 
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)nY * nX) return;
+    B += (size_t)blockIdx.y * Y * X; S += (size_t)blockIdx.y * nY * nX;            // blockIdx.y: frame of a batch
     int i = (int)(t / nX), j = (int)(t - (size_t)i * nX);
     const bool mirror = j > nX / 2;
     if (mirror) { j = nX - j; i = (nY - i) % nY; }
@@ -184,7 +186,6 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_a(const fa_cf *__restrict__ 
 // The same, one wave per workgroup, RW rows per thread out of a table padded to whole groups of RW rows (zeros beyond wy): no
 // conditions inside the loop, the RW factors of a ky are wave-uniform and arrive by scalar loads, and every complex multiply-add is two
 // packed fused multiply-adds (v_pk_fma_f32): (re, im) += (pr, pr) (tx, ty); (re, im) += (-pi, pi) (ty, tx).
-typedef float fa_v2 __attribute__((ext_vector_type(2)));
 template <int RW>
 __global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ S, int N, int nY, int nX, const fa_v2 *__restrict__ twYp, int wy, int wyp,
                                                       fa_cf *__restrict__ U, double *__restrict__ stat)
@@ -503,18 +504,21 @@ typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
 // frame f % nFrames at the frame's rounded global shift, (frame - dark) * gain like k_fa_gather, read where it lies: the patch copy
 // (k_fa_gather: 4.3 GB written and read back per K3 movie) disappears.
 struct FaGather { const float *dark, *gain; const int *offs; int nFrames, Y, X, PY; };
+// a second batch level: blockIdx.z = z1 Z0 + z0, matrices at s z0 + s1 z1 (Z0 = 0: one level, blockIdx.z = z0)
+struct FaBatch2 { int Z0; size_t sA1, sB1, sC1; };
 template <bool ACPLX, bool GATHER = false>
 __global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ A, size_t lda, size_t sA, const fa_cf *__restrict__ B, size_t ldb, size_t sB,
-                                                      fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K, FaGather G = FaGather{})
+                                                      fa_cf *__restrict__ C, size_t ldc, size_t sC, int M, int Nc, int K, FaGather G = FaGather{}, FaBatch2 Z = FaBatch2{})
 {
     constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
     __shared__ float As[BK][LD], Bs[BK][LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w & 1, wn = w >> 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;          // n0: real column
     const int N2 = 2 * Nc, K2 = ACPLX ? 2 * K : K;
-    A += sA * blockIdx.z * (ACPLX ? 2 : 1);
-    const float *Bf = reinterpret_cast<const float *>(B + sB * blockIdx.z);
-    float *Cf = reinterpret_cast<float *>(C + sC * blockIdx.z);
+    const size_t z1 = Z.Z0 ? blockIdx.z / Z.Z0 : 0, z0 = blockIdx.z - z1 * Z.Z0;
+    A += (sA * z0 + Z.sA1 * z1) * (ACPLX ? 2 : 1);
+    const float *Bf = reinterpret_cast<const float *>(B + sB * z0 + Z.sB1 * z1);
+    float *Cf = reinterpret_cast<float *>(C + sC * z0 + Z.sC1 * z1);
     fa_f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1049,12 +1053,13 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
     extern __shared__ float4 sq[];
     const int nl = lX * lY, qx = lX - 3, nq = qx * lY;
     const int tB = (int)tPos - 1, t1 = min((int)tPos + 2, lT - 2), nT = t1 - tB + 1;       // tB >= -1: layers tB + 1 .. t1 + 1 of the arrays
-    float4 *sqX = sq, *sqY = sq + nT * nq;
+    // record i = (layer, control row, first column): (X0, Y0, X1, Y1), (X2, Y2, X3, Y3) -- the X and Y field of a control point side by
+    // side, so that (sx, sy) += (CX, CY) * tmp is one packed fused multiply-add
     for (int i = threadIdx.x; i < nT * nq; i += 256) {
         const int a = i / nq, rem = i - a * nq, yy = rem / qx, x0 = rem - yy * qx;
         const float *px = cX + (size_t)(tB + 1 + a) * nl + yy * lX + x0, *py = cY + (size_t)(tB + 1 + a) * nl + yy * lX + x0;
-        sqX[i] = make_float4(px[0], px[1], px[2], px[3]);
-        sqY[i] = make_float4(py[0], py[1], py[2], py[3]);
+        sq[2 * i] = make_float4(px[0], py[0], px[1], py[1]);
+        sq[2 * i + 1] = make_float4(px[2], py[2], px[3], py[3]);
     }
     __syncthreads();
     // XH_FA_WARP_RG groups of four rows per block: the quads are staged once for 64 x 4 XH_FA_WARP_RG pixels (with one group a block
@@ -1070,13 +1075,13 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
     float bT[4], bX[4], bY[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bT[i] = d_fa_b3(tPos - (tB + i)); bX[i] = d_fa_b3(xPos - (xi - 1 + i)); bY[i] = d_fa_b3(yPos - (yi - 1 + i)); }
-    float sx = 0.f, sy = 0.f;
+    fa_v2 sxy = fa_v2{0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (a >= nT) break;
-        float4 QX[4], QY[4];
+        float4 Q0[4], Q1[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int o = a * nq + (yi + c) * qx + xi; QX[c] = sqX[o]; QY[c] = sqY[o]; }
+        for (int c = 0; c < 4; ++c) { const int o = a * nq + (yi + c) * qx + xi; Q0[c] = sq[2 * o]; Q1[c] = sq[2 * o + 1]; }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const float tX = bX[b] * bT[a];
@@ -1084,12 +1089,12 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
             for (int c = 0; c < 4; ++c) {
                 float tmp = bY[c] * tX;
                 tmp = tmp > delta ? tmp : 0.f;
-                const float vx = b == 0 ? QX[c].x : b == 1 ? QX[c].y : b == 2 ? QX[c].z : QX[c].w;
-                const float vy = b == 0 ? QY[c].x : b == 1 ? QY[c].y : b == 2 ? QY[c].z : QY[c].w;
-                sx += vx * tmp; sy += vy * tmp;
+                const fa_v2 C = b == 0 ? fa_v2{Q0[c].x, Q0[c].y} : b == 1 ? fa_v2{Q0[c].z, Q0[c].w} : b == 2 ? fa_v2{Q1[c].x, Q1[c].y} : fa_v2{Q1[c].z, Q1[c].w};
+                sxy = __builtin_elementwise_fma(C, fa_v2{tmp, tmp}, sxy);             // the CUDA kernel's sx += C * tmp contracts to a fused multiply-add as well
             }
         }
     }
+    const float sx = sxy.x, sy = sxy.y;
     const int xc = (int)ceilf(-sx), yc = (int)ceilf(-sy);
     const float xd = 2.f - (sx + xc), yd = 2.f - (sy + yc);
     const int l1 = x + xc - 2, m1 = y + yc - 2;
@@ -1417,7 +1422,8 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
     // frame against two Bluestein line passes + twiddle + transpose over all 4092 rows.)
     bool colsPruned = false;
     int cn1 = 0, cn2 = 0, cP = 0;
-    XhBuf *pW1 = nullptr, *pW2 = nullptr, *pT = nullptr, *pR = nullptr;
+    XhBuf *pW1 = nullptr, *pW2 = nullptr, *pT = nullptr, *pR = nullptr, *pC = nullptr;
+    int FB = 1;
     if (h->pruned_cols) {
         char key[64];
         snprintf(key, sizeof(key), "%d %d", h->Y, nY);
@@ -1458,8 +1464,11 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
             cn1 = h->cn1; cn2 = h->cn2; cP = h->cP;
             XH_TRY(fa_scratch(h, "c_W1", 0, &pW1));
             XH_TRY(fa_scratch(h, "c_W2", 0, &pW2));
-            XH_TRY(fa_scratch(h, "c_T", sizeof(fa_cf) * (size_t)h->Y * nc, &pT));
-            XH_TRY(fa_scratch(h, "c_R", sizeof(fa_cf) * (size_t)cP * cn1 * nc, &pR));
+            // FB frames per pair of products (one frame's 363 + 1364 workgroups of a few steps each leave the device waiting)
+            FB = std::min(N, 10);
+            XH_TRY(fa_scratch(h, "c_C", sizeof(fa_cf) * (size_t)FB * h->Y * nc, &pC));
+            XH_TRY(fa_scratch(h, "c_T", sizeof(fa_cf) * (size_t)FB * h->Y * nc, &pT));
+            XH_TRY(fa_scratch(h, "c_R", sizeof(fa_cf) * (size_t)FB * cP * cn1 * nc, &pR));
             colsPruned = true;
         }
     }
@@ -1474,17 +1483,23 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
             XH_LAUNCH_CHECK();
             XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
         }
-        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cc, h->Y, h->X, nc, t1, t2);
+        fa_cf *Cn = colsPruned ? (fa_cf *)pC->p + (size_t)(n % FB) * h->Y * nc : Cc;
+        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cn, h->Y, h->X, nc, t1, t2);
         XH_LAUNCH_CHECK();
         if (colsPruned) {
-            // T[k1 n2 + b][kx] = sum_a W[k1][a] C[b + n2 a][kx], one product per b
-            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cn1 + 127) / 128, cn2), dim3(256), 0, ctx->stream, (const float *)pW1->p, (size_t)cn1,
-                               (size_t)0, (const fa_cf *)Cc, (size_t)cn2 * nc, (size_t)nc, (fa_cf *)pT->p, (size_t)cn2 * nc, (size_t)nc, cn1, nc, cn1);
-            // R[q n1 + k1][kx] = sum_b A2[k1][q][b] T[k1 n2 + b][kx], one product per k1
-            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cP + 127) / 128, cn1), dim3(256), 0, ctx->stream, (const float *)pW2->p, (size_t)cn2,
-                               (size_t)cP * cn2, (const fa_cf *)pT->p, (size_t)nc, (size_t)cn2 * nc, (fa_cf *)pR->p, (size_t)cn1 * nc, (size_t)nc, cP, nc, cn2);
-            hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)pR->p, cP * cn1, nc, S + (size_t)n * small, nY, nX,
-                               (const float *)h->lpf.p, inorm);
+            if ((n + 1) % FB != 0 && n + 1 != N) continue;
+            const int nf = n % FB + 1, f0 = n - (nf - 1);                     // frames f0 .. n lie in c_C
+            const size_t fr = (size_t)h->Y * nc;
+            // T[f][k1 n2 + b][kx] = sum_a W[k1][a] C[f][b + n2 a][kx], one product per (f, b)
+            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cn1 + 127) / 128, cn2 * nf), dim3(256), 0, ctx->stream, (const float *)pW1->p, (size_t)cn1,
+                               (size_t)0, (const fa_cf *)pC->p, (size_t)cn2 * nc, (size_t)nc, (fa_cf *)pT->p, (size_t)cn2 * nc, (size_t)nc, cn1, nc, cn1, FaGather{},
+                               FaBatch2{cn2, (size_t)0, fr, fr});
+            // R[f][q n1 + k1][kx] = sum_b A2[k1][q][b] T[f][k1 n2 + b][kx], one product per (f, k1)
+            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cP + 127) / 128, cn1 * nf), dim3(256), 0, ctx->stream, (const float *)pW2->p, (size_t)cn2,
+                               (size_t)cP * cn2, (const fa_cf *)pT->p, (size_t)nc, (size_t)cn2 * nc, (fa_cf *)pR->p, (size_t)cn1 * nc, (size_t)nc, cP, nc, cn2, FaGather{},
+                               FaBatch2{cn1, (size_t)0, fr, (size_t)cP * cn1 * nc});
+            hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256), nf), dim3(256), 0, ctx->stream, (const fa_cf *)pR->p, cP * cn1, nc, S + (size_t)f0 * small, nY,
+                               nX, (const float *)h->lpf.p, inorm);
             XH_LAUNCH_CHECK();
             continue;
         }
