@@ -423,7 +423,9 @@ int xh_fa_destroy(xh_fa *h);
 int xh_fa_info(const xh_fa *h, int32_t *newY, int32_t *newX, double *size_factor);
 int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: every pair correlation through the full inverse transform (A/B);
                                                                   "pruned_columns" 0: the column pass of the frame transform as full-length line transforms (A/B; default 1:
-                                                                  two matrix products that compute the rows the reduced frame keeps only);
+                                                                  two steps that compute the rows the reduced frame keeps only, as small DFTs on the vector ALUs when Y
+                                                                  has a divisor that allows it, else -- or with 2 -- as products on the matrix cores);
+                                                                  "pairwin_form" 0: pair / patch correlation windows by the plain kernels (A/B; default 1: packed multiply-adds);
                                                                   "prefilter_ahead" 1: xh_fa_local_alignment ends with the warp's B-spline prefilter of every frame
                                                                   (N Y X floats kept with the handle), run while the host fits the spline; the following
                                                                   xh_fa_apply_bspline[_frames] calls on the same frames (without an initial sum) use it.

@@ -51,8 +51,9 @@ def test_global_alignment_against_the_oracle(gpu, oracle, N, Y, X, ts, res):
 
 @pytest.mark.parametrize("N,Y,X,ts,res", [(4, 1240, 640, 1.0, 30.0), (4, 992, 700, 1.0, 24.0), (5, 512, 512, 1.0, 8.0)])
 def test_pruned_column_pass_and_packed_pair_windows_change_nothing(gpu, oracle, N, Y, X, ts, res):
-    """The column pass of the frame transform as two matrix products that compute the kept rows only (1240 = 124 x 10 keeps 4 of 10
-    second-step frequencies, 992 = 124 x 8 keeps 4 of 8, 512 = 128 x 4 keeps all) and the pair windows with packed multiply-adds, against
+    """The column pass of the frame transform as two steps that compute the kept rows only (as matrix products: 1240 = 124 x 10 keeps 4 of 10
+    second-step frequencies, 992 = 124 x 8 keeps 4 of 8, 512 = 128 x 4 keeps all; as small DFTs: 1240 = 20 x 62 keeps 15 of 62, 992 = 16 x 62
+    keeps 18, 512 = 32 x 16 keeps 14) and the pair windows with packed multiply-adds, against
     the full-length line transforms + the plain pair-window kernel (5e-4 px: two fp32 summation orders) and against the oracle."""
     xa, ctx, torch = gpu
     frames, drift = synthetic_movie(N, Y, X, seed=N + Y, smooth=6.0)
@@ -64,9 +65,10 @@ def test_pruned_column_pass_and_packed_pair_windows_change_nothing(gpu, oracle, 
     fa.set_option("pairwin_form", 0)
     old = fa.global_alignment(d, max_shift)
     assert np.abs(old["bX"] - got["bX"]).max() <= 5e-4 and np.abs(old["bY"] - got["bY"]).max() <= 5e-4 and old["ref"] == got["ref"]
-    fa.set_option("pruned_columns", 1)
-    mid = fa.global_alignment(d, max_shift)
-    assert np.abs(mid["bX"] - got["bX"]).max() <= 5e-4 and np.abs(mid["bY"] - got["bY"]).max() <= 5e-4
+    for form in (1, 2):          # 1: both steps as small DFTs on the vector ALUs (the default), 2: as products on the matrix cores
+        fa.set_option("pruned_columns", form)
+        mid = fa.global_alignment(d, max_shift)
+        assert np.abs(mid["bX"] - got["bX"]).max() <= 5e-4 and np.abs(mid["bY"] - got["bY"]).max() <= 5e-4
     exp = oracle.fa_global_alignment(frames, Ts=ts, max_shift_px=max_shift, max_res=res)
     assert np.abs(got["bX"] - exp["bX"]).max() <= 2e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 2e-3 and got["ref"] == exp["ref"]
 

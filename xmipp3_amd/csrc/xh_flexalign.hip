@@ -236,6 +236,39 @@ __global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ 
     }
 }
 
+// A DFT of at most 32 outputs per line, lines side by side: out[j][col] = sum_i W[i][j] in[i][col], a lane per column, the JP (= J rounded
+// up to a multiple of four, zeros beyond J) factors of an i wave-uniform and fetched by scalar loads, every complex multiply-add two
+// packed fused multiply-adds (the pattern of k_fa_pairwin_a2). blockIdx.y / .z: two batch levels (in, out and -- y only -- W move).
+// The two steps of the pruned column pass of the frame transform (xh_fa_global_alignment).
+template <int JP>
+__global__ void __launch_bounds__(64) k_fa_small_dft(const fa_v2 *__restrict__ in, size_t inI, size_t inZ0, size_t inZ1, fa_v2 *__restrict__ out, size_t outJ, size_t outZ0,
+                                                     size_t outZ1, const fa_v2 *__restrict__ W, size_t wZ0, int I, int J, int ncols)
+{
+    const int col = blockIdx.x * 64 + threadIdx.x, colc = min(col, ncols - 1);
+    in += inZ0 * blockIdx.y + inZ1 * blockIdx.z + colc;
+    W += wZ0 * blockIdx.y;
+    fa_v2 acc[JP];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) acc[j] = fa_v2{0.f, 0.f};
+#pragma unroll 2
+    for (int i = 0; i < I; ++i) {
+        const fa_v2 t = in[(size_t)i * inI];
+        const fa_v2 vr = fa_v2{t.x, t.x}, vi = fa_v2{-t.y, t.y};
+        const fa_v2 *w = W + (size_t)i * JP;
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+            const fa_v2 f = w[j];
+            acc[j] = __builtin_elementwise_fma(vr, f, acc[j]);
+            acc[j] = __builtin_elementwise_fma(vi, fa_v2{f.y, f.x}, acc[j]);
+        }
+    }
+    if (col >= ncols) return;
+    out += outZ0 * blockIdx.y + outZ1 * blockIdx.z + col;
+#pragma unroll
+    for (int j = 0; j < JP; ++j)
+        if (j < J) out[(size_t)j * outJ] = acc[j];
+}
+
 // sum and sum of squares of the correlation map (real part of the inverse transform), one partial per block
 __global__ void __launch_bounds__(256) k_fa_stats(const fa_cf *__restrict__ M, size_t tot, double *__restrict__ part)
 {
@@ -1288,6 +1321,7 @@ struct xh_fa {
     int pruned_cols = 1;
     int pairwin_form = 1;                 // 1: k_fa_pairwin_a2 (packed multiply-adds, scalar-loaded factors); 0: k_fa_pairwin_a
     int cn1 = 0, cn2 = 0, cP = 0;         // Y = cn1 cn2; cP of the cn2 second-step frequencies are kept
+    int cForm = 0;                        // 1: both steps by k_fa_small_dft, 2: by k_fa_gemm_mfma
     // "prefilter_ahead": the local alignment ends with the B-spline prefilter of every frame (which does not need the spline it is
     // about to fit on the host), so the device works while the host solves; xh_fa_apply_bspline then finds the coefficients ready
     int prefilter_ahead = 0;
@@ -1376,7 +1410,7 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value)
     if (!strcmp(name, "window")) h->use_window = value != 0;
     else if (!strcmp(name, "mfma")) h->use_mfma = value != 0;
     else if (!strcmp(name, "pairwin_form")) h->pairwin_form = (int)value;
-    else if (!strcmp(name, "pruned_columns")) { h->pruned_cols = value != 0; h->cKey.clear(); }
+    else if (!strcmp(name, "pruned_columns")) { h->pruned_cols = (int)value; h->cKey.clear(); }
     else if (!strcmp(name, "prefilter_ahead")) { h->prefilter_ahead = value != 0; h->aheadBase = nullptr; }
     else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
@@ -1428,21 +1462,39 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
         char key[64];
         snprintf(key, sizeof(key), "%d %d", h->Y, nY);
         if (h->cKey != key) {
-            int n1 = 0;
-            for (int d = 128; d >= 8; --d) if (h->Y % d == 0) { n1 = d; break; }
+            const int ihalf = std::min(nY / 2 + 1, h->Y / 2 + 1);             // d_fa_crop: rows 0 .. ihalf-1 and Y-(ihalf-2) .. Y-1
+            auto kept = [&](int n1, int &Plow, int &Phigh) {
+                const int n2 = h->Y / n1;
+                Plow = (ihalf + n1 - 1) / n1; Phigh = (std::max(ihalf - 2, 0) + n1 - 1) / n1;
+                if (Plow + Phigh >= n2) { Plow = n2; Phigh = 0; }
+                return Plow + Phigh;
+            };
+            // the two steps on the vector ALUs (k_fa_small_dft): n1 <= 32 outputs in the first, P <= 32 in the second, least n1 + P
+            int n1 = 0, form = 0, lo = 0, hi = 0;
+            if (h->pruned_cols == 1)
+                for (int d = 2; d <= 32; ++d) {
+                    if (h->Y % d) continue;
+                    const int P = kept(d, lo, hi);
+                    if (P > 32) continue;
+                    int l2, h2;
+                    if (!n1 || d + P < n1 + kept(n1, l2, h2)) { n1 = d; form = 1; }
+                }
+            // or as matrix products (k_fa_gemm_mfma): n1 the largest divisor of Y that fits one 128-row tile
+            if (!n1)
+                for (int d = 128; d >= 8; --d) if (h->Y % d == 0) { n1 = d; form = 2; break; }
             h->cn1 = 0;
             if (n1) {
                 const int n2 = h->Y / n1;
-                const int ihalf = std::min(nY / 2 + 1, h->Y / 2 + 1);             // d_fa_crop: rows 0 .. ihalf-1 and Y-(ihalf-2) .. Y-1
-                int Plow = (ihalf + n1 - 1) / n1, Phigh = (std::max(ihalf - 2, 0) + n1 - 1) / n1;
-                if (Plow + Phigh >= n2) { Plow = n2; Phigh = 0; }
-                const int P = Plow + Phigh;
+                int Plow, Phigh;
+                const int P = kept(n1, Plow, Phigh);
                 const long double twoPi = 6.28318530717958647692528676655900577L;
-                std::vector<fa_cf> W1((size_t)n1 * n1), W2((size_t)n1 * P * n2);
+                // form 2: W1 [k1][a], W2 [k1][q][b]; form 1: W1 [a][k1 padded to a multiple of 4], W2 [k1][b][q padded]
+                const int J1 = form == 1 ? (n1 + 3) / 4 * 4 : n1, J2 = form == 1 ? (P + 3) / 4 * 4 : P;
+                std::vector<fa_cf> W1((size_t)n1 * J1, fa_cf{0.f, 0.f}), W2((size_t)n1 * J2 * n2, fa_cf{0.f, 0.f});
                 for (int k1 = 0; k1 < n1; ++k1)
                     for (int a = 0; a < n1; ++a) {
                         const long double ang = -twoPi * (long double)(((long long)k1 * a) % n1) / n1;
-                        W1[(size_t)k1 * n1 + a] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
+                        W1[form == 1 ? (size_t)a * J1 + k1 : (size_t)k1 * n1 + a] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
                     }
                 for (int k1 = 0; k1 < n1; ++k1)
                     for (int q = 0; q < P; ++q) {
@@ -1450,13 +1502,13 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
                         const long long k = k1 + (long long)n1 * k2;
                         for (int b = 0; b < n2; ++b) {
                             const long double ang = -twoPi * (long double)((k * b) % h->Y) / h->Y;      // W_Y^(b k1) W_n2^(b k2) = W_Y^(b k)
-                            W2[((size_t)k1 * P + q) * n2 + b] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
+                            W2[form == 1 ? ((size_t)k1 * n2 + b) * J2 + q : ((size_t)k1 * P + q) * n2 + b] = fa_cf{(float)cosl(ang), (float)sinl(ang)};
                         }
                     }
                 XhBuf *t1b = nullptr, *t2b = nullptr;
                 XH_TRY(fa_table(h, "c_W1", W1.data(), sizeof(fa_cf) * W1.size(), &t1b));
                 XH_TRY(fa_table(h, "c_W2", W2.data(), sizeof(fa_cf) * W2.size(), &t2b));
-                h->cn1 = n1; h->cn2 = n2; h->cP = P;
+                h->cn1 = n1; h->cn2 = n2; h->cP = P; h->cForm = form;
             }
             h->cKey = key;
         }
@@ -1490,14 +1542,32 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
             if ((n + 1) % FB != 0 && n + 1 != N) continue;
             const int nf = n % FB + 1, f0 = n - (nf - 1);                     // frames f0 .. n lie in c_C
             const size_t fr = (size_t)h->Y * nc;
-            // T[f][k1 n2 + b][kx] = sum_a W[k1][a] C[f][b + n2 a][kx], one product per (f, b)
-            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cn1 + 127) / 128, cn2 * nf), dim3(256), 0, ctx->stream, (const float *)pW1->p, (size_t)cn1,
-                               (size_t)0, (const fa_cf *)pC->p, (size_t)cn2 * nc, (size_t)nc, (fa_cf *)pT->p, (size_t)cn2 * nc, (size_t)nc, cn1, nc, cn1, FaGather{},
-                               FaBatch2{cn2, (size_t)0, fr, fr});
-            // R[f][q n1 + k1][kx] = sum_b A2[k1][q][b] T[f][k1 n2 + b][kx], one product per (f, k1)
-            hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cP + 127) / 128, cn1 * nf), dim3(256), 0, ctx->stream, (const float *)pW2->p, (size_t)cn2,
-                               (size_t)cP * cn2, (const fa_cf *)pT->p, (size_t)nc, (size_t)cn2 * nc, (fa_cf *)pR->p, (size_t)cn1 * nc, (size_t)nc, cP, nc, cn2, FaGather{},
-                               FaBatch2{cn1, (size_t)0, fr, (size_t)cP * cn1 * nc});
+            if (h->cForm == 1) {
+                const dim3 g1((nc + 63) / 64, cn2, nf), g2((nc + 63) / 64, cn1, nf);
+                const int J1 = (cn1 + 3) / 4 * 4, J2 = (cP + 3) / 4 * 4;
+                // T[f][k1 n2 + b][kx] = sum_a W1[a][k1] C[f][b + n2 a][kx]: batch (b, f), lines n2 nc apart in and out
+#define XH_FA_SD1(JP_) hipLaunchKernelGGL((k_fa_small_dft<JP_>), g1, dim3(64), 0, ctx->stream, (const fa_v2 *)pC->p, (size_t)cn2 * nc, (size_t)nc, fr, (fa_v2 *)pT->p, \
+                                          (size_t)cn2 * nc, (size_t)nc, fr, (const fa_v2 *)pW1->p, (size_t)0, cn1, cn1, nc)
+                // R[f][q n1 + k1][kx] = sum_b W2[k1][b][q] T[f][k1 n2 + b][kx]: batch (k1, f)
+#define XH_FA_SD2(JP_) hipLaunchKernelGGL((k_fa_small_dft<JP_>), g2, dim3(64), 0, ctx->stream, (const fa_v2 *)pT->p, (size_t)nc, (size_t)cn2 * nc, fr, (fa_v2 *)pR->p, \
+                                          (size_t)cn1 * nc, (size_t)nc, (size_t)cP * cn1 * nc, (const fa_v2 *)pW2->p, (size_t)cn2 * J2, cn2, cP, nc)
+#define XH_FA_SDSW(M_, J_) switch ((J_) / 4) { case 1: M_(4); break; case 2: M_(8); break; case 3: M_(12); break; case 4: M_(16); break; case 5: M_(20); break; \
+                                               case 6: M_(24); break; case 7: M_(28); break; default: M_(32); break; }
+                XH_FA_SDSW(XH_FA_SD1, J1)
+                XH_FA_SDSW(XH_FA_SD2, J2)
+#undef XH_FA_SD1
+#undef XH_FA_SD2
+#undef XH_FA_SDSW
+            } else {
+                // T[f][k1 n2 + b][kx] = sum_a W[k1][a] C[f][b + n2 a][kx], one product per (f, b)
+                hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cn1 + 127) / 128, cn2 * nf), dim3(256), 0, ctx->stream, (const float *)pW1->p, (size_t)cn1,
+                                   (size_t)0, (const fa_cf *)pC->p, (size_t)cn2 * nc, (size_t)nc, (fa_cf *)pT->p, (size_t)cn2 * nc, (size_t)nc, cn1, nc, cn1, FaGather{},
+                                   FaBatch2{cn2, (size_t)0, fr, fr});
+                // R[f][q n1 + k1][kx] = sum_b A2[k1][q][b] T[f][k1 n2 + b][kx], one product per (f, k1)
+                hipLaunchKernelGGL((k_fa_gemm_mfma<true>), dim3((2 * nc + 127) / 128, (cP + 127) / 128, cn1 * nf), dim3(256), 0, ctx->stream, (const float *)pW2->p, (size_t)cn2,
+                                   (size_t)cP * cn2, (const fa_cf *)pT->p, (size_t)nc, (size_t)cn2 * nc, (fa_cf *)pR->p, (size_t)cn1 * nc, (size_t)nc, cP, nc, cn2, FaGather{},
+                                   FaBatch2{cn1, (size_t)0, fr, (size_t)cP * cn1 * nc});
+            }
             hipLaunchKernelGGL(k_fa_reduce, dim3((unsigned)((small + 255) / 256), nf), dim3(256), 0, ctx->stream, (const fa_cf *)pR->p, cP * cn1, nc, S + (size_t)f0 * small, nY,
                                nX, (const float *)h->lpf.p, inorm);
             XH_LAUNCH_CHECK();
