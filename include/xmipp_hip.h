@@ -425,6 +425,8 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value); /* "window" 0: e
                                                                   "pruned_columns" 0: the column pass of the frame transform as full-length line transforms (A/B; default 1:
                                                                   two steps that compute the rows the reduced frame keeps only, as small DFTs on the vector ALUs when Y
                                                                   has a divisor that allows it, else -- or with 2 -- as products on the matrix cores);
+                                                                  "rows_kept" 0: the row pass of frames with 5760-point rows by the general kernels (A/B; default 1: one kernel that
+                                                                  writes the kept columns only);
                                                                   "pairwin_form" 0: pair / patch correlation windows by the plain kernels (A/B; default 1: packed multiply-adds);
                                                                   "prefilter_ahead" 1: xh_fa_local_alignment ends with the warp's B-spline prefilter of every frame
                                                                   (N Y X floats kept with the handle), run while the host fits the spline; the following

@@ -73,6 +73,24 @@ def test_pruned_column_pass_and_packed_pair_windows_change_nothing(gpu, oracle, 
     assert np.abs(got["bX"] - exp["bX"]).max() <= 2e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 2e-3 and got["ref"] == exp["ref"]
 
 
+@pytest.mark.parametrize("N,Y,X", [(3, 248, 5760), (3, 249, 5760)])
+def test_row_pass_that_writes_the_kept_columns_only(gpu, oracle, N, Y, X):
+    """Frames as wide as a K3's (5760 = 45 x 128 points per row) take one kernel for the whole row pass (45-point transforms in registers,
+    the 128-point ones for the kept frequencies only, the two rows of a complex row apart): against the three-kernel path it replaces
+    (5e-4 px) and against the oracle; an odd number of rows leaves the last complex row half empty."""
+    xa, ctx, torch = gpu
+    frames, drift = synthetic_movie(N, Y, X, seed=N + Y, smooth=6.0)
+    max_shift, res = 30.0, 30.0
+    d = torch.from_numpy(frames).cuda()
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, res)
+    got = fa.global_alignment(d, max_shift)
+    fa.set_option("rows_kept", 0)
+    old = fa.global_alignment(d, max_shift)
+    assert np.abs(old["bX"] - got["bX"]).max() <= 5e-4 and np.abs(old["bY"] - got["bY"]).max() <= 5e-4 and old["ref"] == got["ref"]
+    exp = oracle.fa_global_alignment(frames, Ts=1.0, max_shift_px=max_shift, max_res=res)
+    assert np.abs(got["bX"] - exp["bX"]).max() <= 2e-3 and np.abs(got["bY"] - exp["bY"]).max() <= 2e-3 and got["ref"] == exp["ref"]
+
+
 def test_global_alignment_of_k3_sized_frames(gpu):
     """BASELINE config 5 movie (40 frames of 4096 x 5760, the K3 sensor rotated as the FFT test has it; 780 frame pairs): no oracle at this size
     (a double-precision CPU transform of 23.6 Mpixel frames takes minutes); the known drift of the synthetic movie comes out to

@@ -57,6 +57,7 @@ int xh_buf_reserve(xh_ctx *ctx, XhBuf &b, size_t bytes);
 // a grow-only device buffer that lives with a 2-D transform plan (frame-after-frame callers: dose filter, binning)
 int xh_fft2d_user_scratch(xh_fft2d *f, size_t bytes, void **p);
 int xh_fft2d_rows_of_real_pairs(xh_fft2d *f, const float *d_frame, const float *d_dark, const float *d_gain, int Y, float *d_work, int *n1, int *n2);
+int xh_fft2d_rows_of_real_pairs_kept(xh_fft2d *f, const float *d_frame, const float *d_dark, const float *d_gain, int Y, int nc, float *d_C, int *done);
 
 static inline int xh_ilog2(int n)
 {

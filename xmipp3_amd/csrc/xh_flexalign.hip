@@ -1319,6 +1319,7 @@ struct xh_fa {
     std::string gKey, lKey, cKey;
     // "pruned_columns": the column pass of the frame transform as two matrix products that compute the kept rows only (below)
     int pruned_cols = 1;
+    int rows_kept = 1;                    // the row pass of 45 x 128-point rows by the kernel that writes the kept columns only (0: A/B)
     int pairwin_form = 1;                 // 1: k_fa_pairwin_a2 (packed multiply-adds, scalar-loaded factors); 0: k_fa_pairwin_a
     int cn1 = 0, cn2 = 0, cP = 0;         // Y = cn1 cn2; cP of the cn2 second-step frequencies are kept
     int cForm = 0;                        // 1: both steps by k_fa_small_dft, 2: by k_fa_gemm_mfma
@@ -1410,6 +1411,7 @@ int xh_fa_set_option(xh_fa *h, const char *name, double value)
     if (!strcmp(name, "window")) h->use_window = value != 0;
     else if (!strcmp(name, "mfma")) h->use_mfma = value != 0;
     else if (!strcmp(name, "pairwin_form")) h->pairwin_form = (int)value;
+    else if (!strcmp(name, "rows_kept")) h->rows_kept = value != 0;
     else if (!strcmp(name, "pruned_columns")) { h->pruned_cols = (int)value; h->cKey.clear(); }
     else if (!strcmp(name, "prefilter_ahead")) { h->prefilter_ahead = value != 0; h->aheadBase = nullptr; }
     else { xh_set_error("xh_fa_set_option: unknown option %s", name); return XH_ERR_ARG; }
@@ -1528,16 +1530,21 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
         const size_t tz = (size_t)Yh * h->X, tc = (size_t)Yh * nc;
         // rows: from the real frame straight into the first line pass, the result left where the third step puts it (a K3 frame's
         // 5760 = 45 x 128: two trips through memory instead of six); any other length: pack, transform, read in natural order
-        int t1 = 0, t2 = 0;
-        XH_TRY(xh_fft2d_rows_of_real_pairs(h->rows, d_frames + (size_t)n * big, d_dark, d_gain, h->Y, (float *)wk, &t1, &t2));
-        if (t1 == 0) {
-            hipLaunchKernelGGL(k_fa_load2, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, h->Y, h->X);
-            XH_LAUNCH_CHECK();
-            XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
-        }
         fa_cf *Cn = colsPruned ? (fa_cf *)pC->p + (size_t)(n % FB) * h->Y * nc : Cc;
-        hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cn, h->Y, h->X, nc, t1, t2);
-        XH_LAUNCH_CHECK();
+        int kept = 0;
+        // (a K3 frame's rows: one kernel that writes the kept columns only)
+        if (h->rows_kept) XH_TRY(xh_fft2d_rows_of_real_pairs_kept(h->rows, d_frames + (size_t)n * big, d_dark, d_gain, h->Y, nc, (float *)Cn, &kept));
+        if (!kept) {
+            int t1 = 0, t2 = 0;
+            XH_TRY(xh_fft2d_rows_of_real_pairs(h->rows, d_frames + (size_t)n * big, d_dark, d_gain, h->Y, (float *)wk, &t1, &t2));
+            if (t1 == 0) {
+                hipLaunchKernelGGL(k_fa_load2, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, ctx->stream, d_frames + (size_t)n * big, d_dark, d_gain, wk, h->Y, h->X);
+                XH_LAUNCH_CHECK();
+                XH_TRY(xh_fft2d_exec_axis(h->rows, (float *)wk, 0, 0));
+            }
+            hipLaunchKernelGGL(k_fa_unpack, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, ctx->stream, (const fa_cf *)wk, Cn, h->Y, h->X, nc, t1, t2);
+            XH_LAUNCH_CHECK();
+        }
         if (colsPruned) {
             if ((n + 1) % FB != 0 && n + 1 != N) continue;
             const int nf = n % FB + 1, f0 = n - (nf - 1);                     // frames f0 .. n lie in c_C
