@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(256) k_fft2d_45_pairs(const float *__restrict_
 //   3. the two rows apart, F(a)[k] = (Z[k] + conj Z[-k]) / 2, F(b)[k] = (Z[k] - conj Z[-k]) / 2i, written as C[2r][k], C[2r + 1][k], k < nc.
 // 1.8 G packed multiply-adds and 115 MB of traffic per K3 frame instead of three kernels and 400 MB.
 typedef float xh_v2 __attribute__((ext_vector_type(2)));
+template <bool CG>          // CG: dark and / or gain given
 __global__ void __launch_bounds__(256) k_fft2d_45x128_rows_kept(const float *__restrict__ frame, const float *__restrict__ dark, const float *__restrict__ gain, int Y, int X,
                                                                 const xh_cf *__restrict__ twN, const xh_v2 *__restrict__ W45, const xh_v2 *__restrict__ Wq, int PL, int nc, xh_cf *__restrict__ C)
 {
@@ -289,19 +290,36 @@ __global__ void __launch_bounds__(256) k_fft2d_45x128_rows_kept(const float *__r
 #pragma unroll
         for (int q = 0; q < 24; ++q) acc[q] = xh_v2{0.f, 0.f};
         const xh_v2 *w = W45 + hh * 24;
-#pragma unroll 3
-        for (int j = 0; j < 45; ++j, w += 48) {
+        // five samples ahead: the loads of group g + 1 fly while group g is summed (a load per 48 packed multiply-adds left the wave waiting
+        // for memory 45 times)
+        auto fetch = [&](int j, float &v0, float &v1) {
             const size_t o = s0 + (size_t)j * 128;
-            float v0 = frame[o], v1 = two ? frame[o + X] : 0.f;
-            if (dark) { v0 -= dark[o]; if (two) v1 -= dark[o + X]; }
-            if (gain) { v0 *= gain[o]; if (two) v1 *= gain[o + X]; }
-            const xh_v2 vr = xh_v2{v0, v0}, vi = xh_v2{-v1, v1};
-#pragma unroll
-            for (int q = 0; q < 24; ++q) {
-                const xh_v2 f = w[q];
-                acc[q] = __builtin_elementwise_fma(vr, f, acc[q]);
-                acc[q] = __builtin_elementwise_fma(vi, xh_v2{f.y, f.x}, acc[q]);
+            v0 = frame[o]; v1 = two ? frame[o + X] : 0.f;
+            if (CG) {
+                if (dark) { v0 -= dark[o]; if (two) v1 -= dark[o + X]; }
+                if (gain) { v0 *= gain[o]; if (two) v1 *= gain[o + X]; }
             }
+        };
+        float c0[5], c1[5], n0[5], n1[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) fetch(u, c0[u], c1[u]);
+        for (int g = 0; g < 9; ++g) {
+            if (g < 8) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) fetch(5 * (g + 1) + u, n0[u], n1[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u, w += 48) {
+                const xh_v2 vr = xh_v2{c0[u], c0[u]}, vi = xh_v2{-c1[u], c1[u]};
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    const xh_v2 f = w[q];
+                    acc[q] = __builtin_elementwise_fma(vr, f, acc[q]);
+                    acc[q] = __builtin_elementwise_fma(vi, xh_v2{f.y, f.x}, acc[q]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
         }
 #pragma unroll
         for (int q = 0; q < 24; ++q) {
@@ -318,15 +336,19 @@ __global__ void __launch_bounds__(256) k_fft2d_45x128_rows_kept(const float *__r
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = xh_v2{0.f, 0.f};
     const xh_v2 *w = Wq + wv * 8;
-#pragma unroll 2
-    for (int m = 0; m < 128; ++m, w += 32) {
-        const xh_v2 z = T[m * 45 + k1];
-        const xh_v2 vr = xh_v2{z.x, z.x}, vi = xh_v2{-z.y, z.y};
+    for (int m0 = 0; m0 < 128; m0 += 4) {
+        xh_v2 z[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const xh_v2 f = w[q];
-            acc[q] = __builtin_elementwise_fma(vr, f, acc[q]);
-            acc[q] = __builtin_elementwise_fma(vi, xh_v2{f.y, f.x}, acc[q]);
+        for (int u = 0; u < 4; ++u) z[u] = T[(m0 + u) * 45 + k1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u, w += 32) {
+            const xh_v2 vr = xh_v2{z[u].x, z[u].x}, vi = xh_v2{-z[u].y, z[u].y};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const xh_v2 f = w[q];
+                acc[q] = __builtin_elementwise_fma(vr, f, acc[q]);
+                acc[q] = __builtin_elementwise_fma(vi, xh_v2{f.y, f.x}, acc[q]);
+            }
         }
     }
     __syncthreads();
@@ -537,8 +559,12 @@ int xh_fft2d_rows_of_real_pairs_kept(xh_fft2d *f, const float *d_frame, const fl
         XH_HIP(hipStreamSynchronize(ctx->stream));
         f->keptPL = PL;
     }
-    hipLaunchKernelGGL(k_fft2d_45x128_rows_kept, dim3((unsigned)f->ny), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (const xh_cf *)A.tw.p,
-                       (const xh_v2 *)f->keptW.p + 128 * 32, (const xh_v2 *)f->keptW.p, PL, nc, (xh_cf *)d_C);
+    if (d_dark || d_gain)
+        hipLaunchKernelGGL((k_fft2d_45x128_rows_kept<true>), dim3((unsigned)f->ny), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (const xh_cf *)A.tw.p,
+                           (const xh_v2 *)f->keptW.p + 128 * 32, (const xh_v2 *)f->keptW.p, PL, nc, (xh_cf *)d_C);
+    else
+        hipLaunchKernelGGL((k_fft2d_45x128_rows_kept<false>), dim3((unsigned)f->ny), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (const xh_cf *)A.tw.p,
+                           (const xh_v2 *)f->keptW.p + 128 * 32, (const xh_v2 *)f->keptW.p, PL, nc, (xh_cf *)d_C);
     XH_LAUNCH_CHECK();
     *done = 1;
     return XH_OK;
