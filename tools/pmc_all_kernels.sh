@@ -30,7 +30,7 @@ res = collections.defaultdict(dict)
 for f in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("(anonymous namespace)::", "")
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", ""))
         per[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, cs in per.items():
         for c, d in cs.items():
