@@ -355,8 +355,9 @@ __global__ void __launch_bounds__(256) k_fa_bestshift(const fa_cf *__restrict__ 
 // ... then along x (real part: the spectra are Hermitian) into the block's window W[wy][wx], and bestShift as k_fa_bestshift does
 // it on the full map. out[pair] = (shiftX, shiftY, max, overflow): overflow = 1 when the square grown around the maximum reaches
 // beyond the window; the host repeats such a pair through the full transform.
+#define XH_FA_PWB_KC 32
 __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ Uall, const fa_cf *__restrict__ twX, const double *__restrict__ stat, int nY, int nX,
-                                                      int hy, int hx, int maxShift, float *__restrict__ Wall, double *__restrict__ out)
+                                                      int hy, int hx, int maxShift, float *__restrict__ Wall, double *__restrict__ out, int ldsRows)
 {
     __shared__ double sv[256];
     __shared__ int si[256];
@@ -364,6 +365,47 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ 
     const fa_cf *U = Uall + (size_t)blockIdx.x * wy * nxh;
     float *W = Wall + (size_t)blockIdx.x * wy * wx;
     const double dSize = (double)nY * (double)nX;
+    if (ldsRows > 0) {
+        // a lane per column xx of the window and group of up to 16 rows (256 / wx groups side by side); kx in chunks of XH_FA_PWB_KC whose
+        // U values are staged through LDS (coalesced in, broadcast out), the lane's factor twX[kx][xx] loaded once per kx
+        extern __shared__ fa_cf sU[];                                                  // [ldsRows][XH_FA_PWB_KC + 1]
+        constexpr int KC = XH_FA_PWB_KC, LD = KC + 1;
+        const int G = max(1, min(min(256 / wx, wy), ldsRows / 16)), grp = threadIdx.x / wx, xx = threadIdx.x - grp * wx;
+        for (int yb = 0; yb < wy; yb += 16 * G) {
+            const int yq = yb + grp * 16, nr = min(wy - yb, 16 * G);
+            const bool act = grp < G && yq < wy;
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int k0 = 0; k0 < nxh; k0 += KC) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < nr * KC; i += 256) {
+                    const int rr = i / KC, kk = i - rr * KC;
+                    sU[rr * LD + kk] = k0 + kk < nxh ? U[(size_t)(yb + rr) * nxh + k0 + kk] : fa_cf{0.f, 0.f};
+                }
+                __syncthreads();
+                if (act) {
+                    const int kn = min(KC, nxh - k0);
+                    for (int kk = 0; kk < kn; ++kk) {
+                        const int kx = k0 + kk;
+                        fa_cf t = twX[(size_t)kx * wx + xx];
+                        const float wgt = (kx == 0 || 2 * kx == nX) ? 1.f : 2.f;
+                        t.x *= wgt; t.y *= -wgt;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const fa_cf v = sU[min(grp * 16 + i, nr - 1) * LD + kk];
+                            acc[i] = fmaf(v.x, t.x, acc[i]);
+                            acc[i] = fmaf(v.y, t.y, acc[i]);
+                        }
+                    }
+                }
+            }
+            if (act)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (yq + i < wy) W[(size_t)(yq + i) * wx + xx] = acc[i] * (float)dSize;
+        }
+    } else
     for (int o = threadIdx.x; o < wy * wx; o += 256) {
         const int yy = o / wx, xx = o - yy * wx;
         const fa_cf *u = U + (size_t)yy * nxh;
@@ -1686,8 +1728,11 @@ int xh_fa_global_alignment(xh_fa *h, const float *d_frames, int32_t N, const flo
             else
                 hipLaunchKernelGGL((k_fa_pairwin_a2<12>), dim3((nxh + 63) / 64, rows, nz), dim3(64), 0, ctx->stream, (const fa_cf *)S, N, nY, nX, (const fa_v2 *)pTwYp->p, wy, wyp,
                                    (fa_cf *)bU.p, (double *)bStat.p);
-            hipLaunchKernelGGL(k_fa_pairwin_b, dim3(rows), dim3(256), 0, ctx->stream, (const fa_cf *)bU.p, (const fa_cf *)bTwX.p, (const double *)bStat.p, nY, nX, hy, hx, ms,
-                               (float *)bW.p, (double *)bOut.p);
+            // rows of U staged per chunk of kx: all of the window's when 256 / wx groups of 16 cover them, at most 96 (25 KB); windows wider
+            // than 256 columns (or the A/B form) keep the thread-per-output loop
+            const int ldsRows = (wx <= 256 && h->pairwin_form != 0) ? std::min(96, (std::min(256 / wx, (wy + 15) / 16)) * 16) : 0;
+            hipLaunchKernelGGL(k_fa_pairwin_b, dim3(rows), dim3(256), sizeof(fa_cf) * (size_t)ldsRows * (XH_FA_PWB_KC + 1), ctx->stream, (const fa_cf *)bU.p, (const fa_cf *)bTwX.p,
+                               (const double *)bStat.p, nY, nX, hy, hx, ms, (float *)bW.p, (double *)bOut.p, ldsRows);
             if (hipGetLastError() != hipSuccess) rc = XH_ERR_HIP;
         }
         if (rc == XH_OK && hipMemcpyAsync(out4.data(), bOut.p, sizeof(double) * out4.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = XH_ERR_HIP;
