@@ -23,6 +23,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fa
 f=$(find /tmp/prof_fa -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" $root/gpurun_out/${tag}_flexalign_kernel_stats_one_lane.csv
 cd $root
+# counters of every FlexAlign kernel (one lane, two movies)
+timeout 600 bash tools/pmc_all_kernels.sh ${tag}_flexalign bench.py --mode flexalign --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --fa-lanes 1 2>&1 | grep -v "at::native" > gpurun_out/${tag}_flexalign_pmc_all_kernels.txt
+cp gpurun_out/pmc_all_${tag}_flexalign.json gpurun_out/${tag}_flexalign_pmc_all_kernels.json 2>/dev/null
+rm -rf gpurun_out/pmca_${tag}_flexalign
 timeout 300 python3 bench.py --mode flexalign --steps 6 --warmup 2 > gpurun_out/${tag}_flexalign_bench.json 2> /dev/null
 for m in "--mode match --box 128" "--mode grid" "--refs noise"; do
   n=$(echo $m | tr -d ' -' ); timeout 300 python3 bench.py $m --no-cpu-baseline --no-extra-legs > gpurun_out/${tag}_bench_${n}.json 2>/dev/null
