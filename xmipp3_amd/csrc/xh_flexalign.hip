@@ -1926,10 +1926,13 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     if (rc == XH_OK) rc = fa_scratch(h, "l_tabX", 0, &pTabX);
     if (rc == XH_OK) rc = fa_scratch(h, "l_filter", 0, &pFilter);
     if (rc == XH_OK) rc = fa_table(h, "l_offs", offs.data(), sizeof(int) * offs.size(), &pOffs);          // the patch corners move with the global shifts
-    // PB patches at a time: the pair kernel has one wave per frame pair, and a single patch (780 waves for 40 frames) leaves
-    // most of the device idle
-    const int PB = std::min(nP, 16);
-    if (rc == XH_OK) rc = fa_scratch(h, "l_patch", sizeof(float) * (size_t)PB * N * PY * PX, &pPatch);
+    // PB patches at a time: the pair kernel has one wave per frame pair, the second product one workgroup per patch frame -- a single patch (780
+    // waves, 40 workgroups for 40 frames) leaves most of the device idle; 36 (three launches for the 108 patches of a K3 movie) against
+    // 16: local alignment 18.5 -> 17.5 ms per movie
+    static const int pbEnv = getenv("XH_FA_PB") ? atoi(getenv("XH_FA_PB")) : 0;        // A/B runs
+    const int PB = std::min(nP, pbEnv > 0 ? pbEnv : 36);
+    static const bool copyPatchesEnv = getenv("XH_FA_COPY_PATCHES") != nullptr;
+    if (rc == XH_OK) rc = fa_scratch(h, "l_patch", (h->use_mfma && !copyPatchesEnv) ? 16 : sizeof(float) * (size_t)PB * N * PY * PX, &pPatch);      // the fused product reads the frames
     if (rc == XH_OK) rc = fa_scratch(h, "l_T", sizeof(fa_cf) * (size_t)PB * N * PY * cxh, &pT);
     if (rc == XH_OK) rc = fa_scratch(h, "l_single", sizeof(fa_cf) * (size_t)PB * N * E, &pSingle);
     if (rc == XH_OK) rc = fa_scratch(h, "l_S", sizeof(fa_cf) * (size_t)PB * N * E, &pS);
