@@ -609,43 +609,47 @@ __global__ void __launch_bounds__(256) k_fa_gemm_mfma(const float *__restrict__ 
         gsrc = (size_t)(G.offs[2 * f + 1] + y) * G.X + G.offs[2 * f];
         gfrm = (size_t)(f % G.nFrames) * G.Y * G.X;
     }
-    for (int k0 = 0; k0 < K2; k0 += BK) {
-        float av[8], bv[8];
-        {
-            const int m = m0 + arow;
+    // the tile of step k + 1 is fetched into registers before the products of step k are issued (its latency flies under them), and goes
+    // to LDS when they are done
+    auto fetch = [&](int k0, float (&av)[8], float (&bv)[8]) {
+        const int m = m0 + arow;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int kk = k0 + akseg + q;
-                float v = 0.f;
-                if (m < M && kk < K2) {
-                    if (GATHER) {
-                        v = A[gfrm + gsrc + kk];
-                        if (G.dark) v -= G.dark[gsrc + kk];
-                        if (G.gain) v *= G.gain[gsrc + kk];
-                    } else if (!ACPLX) v = A[(size_t)m * lda + kk];
-                    else v = kk < K ? A[((size_t)m * lda + kk) * 2] : A[((size_t)m * lda + (kk - K)) * 2 + 1];
-                }
-                av[q] = v;
+        for (int q = 0; q < 8; ++q) {
+            const int kk = k0 + akseg + q;
+            float v = 0.f;
+            if (m < M && kk < K2) {
+                if (GATHER) {
+                    v = A[gfrm + gsrc + kk];
+                    if (G.dark) v -= G.dark[gsrc + kk];
+                    if (G.gain) v *= G.gain[gsrc + kk];
+                } else if (!ACPLX) v = A[(size_t)m * lda + kk];
+                else v = kk < K ? A[((size_t)m * lda + kk) * 2] : A[((size_t)m * lda + (kk - K)) * 2 + 1];
             }
-            const int kk = k0 + bk;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = n0 + bcseg + q;
-                float v = 0.f;
-                if (kk < K2 && c < N2) {
-                    if (!ACPLX || kk < K) v = Bf[(size_t)kk * 2 * ldb + c];
-                    else {
-                        const float *br = Bf + (size_t)(kk - K) * 2 * ldb;        // row of i B: (-Bi, Br)
-                        v = (c & 1) ? br[c - 1] : -br[c + 1];
-                    }
-                }
-                bv[q] = v;
-            }
+            av[q] = v;
         }
-        __syncthreads();
+        const int kk = k0 + bk;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = n0 + bcseg + q;
+            float v = 0.f;
+            if (kk < K2 && c < N2) {
+                if (!ACPLX || kk < K) v = Bf[(size_t)kk * 2 * ldb + c];
+                else {
+                    const float *br = Bf + (size_t)(kk - K) * 2 * ldb;        // row of i B: (-Bi, Br)
+                    v = (c & 1) ? br[c - 1] : -br[c + 1];
+                }
+            }
+            bv[q] = v;
+        }
+    };
+    float av[8], bv[8];
+    fetch(0, av, bv);
+    for (int k0 = 0; k0 < K2; k0 += BK) {
+        __syncthreads();                           // the products of the previous step have read the tile
 #pragma unroll
         for (int q = 0; q < 8; ++q) { As[akseg + q][arow] = av[q]; Bs[bk][bcseg + q] = bv[q]; }
         __syncthreads();
+        if (k0 + BK < K2) fetch(k0 + BK, av, bv);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (lane >> 5), l31 = lane & 31;
