@@ -267,8 +267,8 @@ __global__ void __launch_bounds__(256) k_fft2d_45_pairs(const float *__restrict_
 // The whole row pass of a frame whose rows are 5760 = 45 x 128 points when only the nc <= 45 PL lowest frequencies of every row are kept
 // (FlexAlign's reduced frame keeps 653 of a K3 frame's 2881): one workgroup per pair of rows (row 2r real part, row 2r + 1 imaginary
 // part), nothing but the frame read and the kept columns written.
-//   1. the 45-point transform over j of z[128 j + m] (a thread per m and half of the outputs k1, the factors of a j by scalar loads from
-//      W45[j][48], packed multiply-adds), times exp(-2 pi i k1 m / 5760), into LDS T[m][k1];
+//   1. the 45-point transform over j of z[128 j + m] (a lane per pair of lines m, m + 64, a wave per quarter of the outputs k1, the factors
+//      of a j by scalar loads from W45[j][48], packed multiply-adds), times exp(-2 pi i k1 m / 5760), into LDS T[m][k1];
 //   2. the 128-point transform over m for the 2 PL kept k2 only (k = k1 + 45 k2: k2 < PL and k2 >= 128 - PL, the latter for the
 //      mirror frequencies the separation of the two rows needs): a lane per k1, eight k2 per wave, the factors exp(-2 pi i m k2 / 128) of
 //      an m wave-uniform (scalar loads from Wq[m][32]), every complex multiply-add two packed fused multiply-adds;
@@ -283,50 +283,59 @@ __global__ void __launch_bounds__(256) k_fft2d_45x128_rows_kept(const float *__r
     const int r = blockIdx.x, t = threadIdx.x;
     const bool two = 2 * r + 1 < Y;
     {
-        // a thread per (m, half of the 45 outputs): 45 samples in, 24 sums; the factors W45[j][k1] of a j are the same for the whole wave
-        const int m = t & 127, hh = __builtin_amdgcn_readfirstlane(t >> 7);
+        // a lane per pair of lines (m, m + 64), a wave per quarter of the 45 outputs: 2 x 45 samples in, 2 x 12 sums; the twelve factors
+        // W45[j][k1] of a j are the same for the whole wave and serve 48 packed multiply-adds (with one line per lane and 24 outputs per
+        // wave it was 24 factors for the same 48: the wave waited for its scalar loads)
+        const int m = t & 63, hq = __builtin_amdgcn_readfirstlane(t >> 6);
         const size_t s0 = (size_t)(2 * r) * X + m;
-        xh_v2 acc[24];
+        xh_v2 acc[2][12];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) acc[q] = xh_v2{0.f, 0.f};
-        const xh_v2 *w = W45 + hh * 24;
-        // five samples ahead: the loads of group g + 1 fly while group g is summed (a load per 48 packed multiply-adds left the wave waiting
-        // for memory 45 times)
-        auto fetch = [&](int j, float &v0, float &v1) {
+        for (int q = 0; q < 12; ++q) { acc[0][q] = xh_v2{0.f, 0.f}; acc[1][q] = xh_v2{0.f, 0.f}; }
+        const xh_v2 *w = W45 + hq * 12;
+        auto fetch = [&](int j, float (&v)[4]) {
             const size_t o = s0 + (size_t)j * 128;
-            v0 = frame[o]; v1 = two ? frame[o + X] : 0.f;
+            v[0] = frame[o]; v[1] = two ? frame[o + X] : 0.f; v[2] = frame[o + 64]; v[3] = two ? frame[o + 64 + X] : 0.f;
             if (CG) {
-                if (dark) { v0 -= dark[o]; if (two) v1 -= dark[o + X]; }
-                if (gain) { v0 *= gain[o]; if (two) v1 *= gain[o + X]; }
+                if (dark) { v[0] -= dark[o]; v[2] -= dark[o + 64]; if (two) { v[1] -= dark[o + X]; v[3] -= dark[o + 64 + X]; } }
+                if (gain) { v[0] *= gain[o]; v[2] *= gain[o + 64]; if (two) { v[1] *= gain[o + X]; v[3] *= gain[o + 64 + X]; } }
             }
         };
-        float c0[5], c1[5], n0[5], n1[5];
+        // three samples ahead: the loads of group g + 1 fly while group g is summed
+        float c[3][4], n[3][4];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) fetch(u, c0[u], c1[u]);
-        for (int g = 0; g < 9; ++g) {
-            if (g < 8) {
+        for (int u = 0; u < 3; ++u) fetch(u, c[u]);
+        for (int g = 0; g < 15; ++g) {
+            if (g < 14) {
 #pragma unroll
-                for (int u = 0; u < 5; ++u) fetch(5 * (g + 1) + u, n0[u], n1[u]);
+                for (int u = 0; u < 3; ++u) fetch(3 * (g + 1) + u, n[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 5; ++u, w += 48) {
-                const xh_v2 vr = xh_v2{c0[u], c0[u]}, vi = xh_v2{-c1[u], c1[u]};
+            for (int u = 0; u < 3; ++u, w += 48) {
+                const xh_v2 ar = xh_v2{c[u][0], c[u][0]}, ai = xh_v2{-c[u][1], c[u][1]}, br = xh_v2{c[u][2], c[u][2]}, bi = xh_v2{-c[u][3], c[u][3]};
 #pragma unroll
-                for (int q = 0; q < 24; ++q) {
-                    const xh_v2 f = w[q];
-                    acc[q] = __builtin_elementwise_fma(vr, f, acc[q]);
-                    acc[q] = __builtin_elementwise_fma(vi, xh_v2{f.y, f.x}, acc[q]);
+                for (int q = 0; q < 12; ++q) {
+                    const xh_v2 f = w[q], fs = xh_v2{f.y, f.x};
+                    acc[0][q] = __builtin_elementwise_fma(ar, f, acc[0][q]);
+                    acc[0][q] = __builtin_elementwise_fma(ai, fs, acc[0][q]);
+                    acc[1][q] = __builtin_elementwise_fma(br, f, acc[1][q]);
+                    acc[1][q] = __builtin_elementwise_fma(bi, fs, acc[1][q]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 5; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[u][e] = n[u][e];
         }
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
-            const int k = hh * 24 + q;
+        for (int q = 0; q < 12; ++q) {
+            const int k = hq * 12 + q;
             if (k < 45) {
-                const xh_cf v = xh_cmul(xh_cf{acc[q].x, acc[q].y}, twN[(size_t)k * m]);         // k m < 45 x 128
-                T[m * 45 + k] = xh_v2{v.x, v.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int mm = m + 64 * e;
+                    const xh_cf v = xh_cmul(xh_cf{acc[e][q].x, acc[e][q].y}, twN[(size_t)k * mm]);         // k m < 45 x 128
+                    T[mm * 45 + k] = xh_v2{v.x, v.y};
+                }
             }
         }
     }
