@@ -52,7 +52,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4)         # = the number of distinct batches: every batch has been a step once before the clock starts
     ap.add_argument("--box", type=int, default=256, help="particle box D")
     ap.add_argument("--nrefs", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=4096, help="particles per step per GPU")
