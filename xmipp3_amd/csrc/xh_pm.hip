@@ -1760,22 +1760,29 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
     int bi = 0x7fffffff;
     const int half = N / 2;
     const int ncand = M.noMirror ? N : 2 * N;
-    for (int i = threadIdx.x; i < ncand; i += blockDim.x) {
-        const xh_cd *F = i < N ? Fs : Fm;
-        const int ii = i < N ? i : i - N;
-        double acc = F[0].x + ((ii & 1) ? -F[half].x : F[half].x);
+    // a thread owns shift ii of BOTH rows (straight and mirrored): one gather of cs[ii k mod N] serves the two sums (the gathers, not the
+    // multiply-adds, are what this loop waits for); every sum is formed exactly as before
+    for (int ii = threadIdx.x; ii < N; ii += blockDim.x) {
+        double accS = Fs[0].x + ((ii & 1) ? -Fs[half].x : Fs[half].x), accM = Fm[0].x + ((ii & 1) ? -Fm[half].x : Fm[half].x);
         int j = 0;
-        double t = 0;
+        double tS = 0, tM = 0;
         for (int k = 1; k < half; ++k) {
             j += ii;
             if (j >= N) j -= N;
-            t += F[k].x * cs[j].x - F[k].y * cs[j].y;
+            const xh_cd w = cs[j], fs = Fs[k], fm = Fm[k];
+            tS += fs.x * w.x - fs.y * w.y;
+            tM += fm.x * w.x - fm.y * w.y;
         }
-        acc += 2.0 * t;
-        const double v = acc / den;
-        if (dbgRow) dbgRow[i] = v;
-        if (K > 1) vals[i] = v;
-        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        accS += 2.0 * tS; accM += 2.0 * tM;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && M.noMirror) break;
+            const int i = ii + h * N;
+            const double v = (h ? accM : accS) / den;
+            if (dbgRow) dbgRow[i] = v;
+            if (K > 1) vals[i] = v;
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
     }
     __shared__ double sbv[256];
     __shared__ int sbi[256];
