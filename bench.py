@@ -1139,7 +1139,7 @@ def flexalign_leg():
     in flight) as a CHILD process -- its own runtime, its own contexts; nothing is exec'ed over this process's GPU state -- reduced to the
     figures a reader needs: movies/s and the three stages' times and roofline fractions."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "flexalign", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extra-legs"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "flexalign", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-extra-legs"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -1153,7 +1153,7 @@ def flexalign_leg():
                 "stage_ms_one_lane": d["stage_ms"],
                 "stage_roofline_frac": fr,
                 "global_shift_error_px": d.get("global_shift_error_px"),
-                "what": "`python bench.py --mode flexalign --steps 4 --warmup 2` run as a child process after the timed region of the refine iteration"}
+                "what": "`python bench.py --mode flexalign --steps 8 --warmup 2` run as a child process after the timed region of the refine iteration"}
     except Exception as e:      # the headline must not depend on this leg
         return {"error": repr(e)}
 
