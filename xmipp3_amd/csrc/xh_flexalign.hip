@@ -1173,6 +1173,10 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bT[i] = d_fa_b3(tPos - (tB + i)); bX[i] = d_fa_b3(xPos - (xi - 1 + i)); bY[i] = d_fa_b3(yPos - (yi - 1 + i)); }
     fa_v2 sxy = fa_v2{0.f, 0.f};
+    // The 1e-4 cut as an execution mask: v_cmpx switches the lanes whose term is dropped off for the one packed multiply-add that follows
+    // (compare + select + multiply-add were three vector instructions per term, 192 of a pixel's 540; this is two and a scalar move).
+    const unsigned long long lanesOn = __builtin_amdgcn_read_exec();
+    (void)delta;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (a >= nT) break;
@@ -1184,10 +1188,17 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
             const float tX = bX[b] * bT[a];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float tmp = bY[c] * tX;
-                tmp = tmp > delta ? tmp : 0.f;
+                fa_v2 tt;
+                tt.x = bY[c] * tX;                                              // the packed instruction reads the low half for both products (op_sel_hi 0)
+                asm("" : "=v"(tt.y));                                          // (the high half is never read: no move to fill it)
                 const fa_v2 C = b == 0 ? fa_v2{Q0[c].x, Q0[c].y} : b == 1 ? fa_v2{Q0[c].z, Q0[c].w} : b == 2 ? fa_v2{Q1[c].x, Q1[c].y} : fa_v2{Q1[c].z, Q1[c].w};
-                sxy = __builtin_elementwise_fma(C, fa_v2{tmp, tmp}, sxy);             // the CUDA kernel's sx += C * tmp contracts to a fused multiply-add as well
+                // tmp > 1e-4 (0x38d1b717) ? (sx, sy) += (CX, CY) tmp : nothing -- the CUDA kernel's sx += C * tmp contracts to a fused multiply-add as well
+                asm volatile("v_cmpx_lt_f32_e32 vcc, 0x38d1b717, %[t]\n\t"
+                             "v_pk_fma_f32 %[acc], %[cc], %[tt], %[acc] op_sel_hi:[1,0,1]\n\t"
+                             "s_mov_b64 exec, %[on]"
+                             : [acc] "+v"(sxy)
+                             : [t] "v"(tt.x), [cc] "v"(C), [tt] "v"(tt), [on] "s"(lanesOn)
+                             : "vcc");
             }
         }
     }
