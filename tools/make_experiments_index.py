@@ -27,19 +27,20 @@ R5 = [
     ("library", "pinned staging area of the small host arrays in two halves with an event each", "profiles/r05_c_bench_modegrid.json", "`--mode grid` 105 -> 131 k projections/s (the host waited, at every wrap, for the copies it had just queued)", "yes"),
     ("FlexAlign", "rocprofv3 over the two-lane bench (two host threads)", "tools/collect_r05.sh", "hangs (twice, 40 GPU-minutes lost); one lane profiles fine -- the FlexAlign kernel table is collected with `--fa-lanes 1`", "-"),
     ("FlexAlign", "frame prefilter as a tile recursion (`k_fa_prefilter_rec`), eight row groups per warp workgroup", "profiles/r05_a_bench_default.json (`flexalign`)", "`k_fa_prefilter` 0.278 -> `k_fa_prefilter_rec` 0.058 ms per K3 frame (hidden behind the host's spline fit either way), `k_fa_warp_quads` 0.48 -> 0.36 ms per frame; warp + sum 15.5 -> 14.1 ms per movie; 17.1 -> 18.4-18.7 movies/s", "yes"),
-    ("FlexAlign global", "pair windows (`k_fa_pairwin_a2`): all rows of a chunk per thread without conditions, the factors of a ky by scalar loads out of a padded table, every complex multiply-add as two `v_pk_fma_f32`", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "4.8 -> 2.1 ms per K3 movie (0.82 of the vector issue slots busy)", "yes"),
+    ("FlexAlign global", "pair windows (`k_fa_pairwin_a2`): all rows of a chunk per thread without conditions, the factors of a ky by scalar loads out of a padded table, every complex multiply-add as two `v_pk_fma_f32`", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "4.8 -> 2.1 ms per K3 movie (0.82 of the vector issue slots busy)", "yes"),
     ("FlexAlign global", "column pass of the frame transform pruned to the kept rows, two steps as matrix products on the matrix cores (4092 = 124 x 33, 8 of 33 kept; `pruned_columns` 2)", "gpurun A/B, DESIGN.md 5b", "two Bluestein line passes + twiddle + transpose 215 us -> 144 us per frame; 100 us with ten frames per launch (the second step pads 8 rows to a 128-row tile)", "kept as the fallback"),
-    ("FlexAlign global", "... as two small DFTs on the vector ALUs (`k_fa_small_dft`: a lane per column, <= 32 outputs in registers, factors by scalar loads, packed multiply-adds; 4092 = 31 x 132, 30 of 132 kept)", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "21 us per frame (0.84 ms per movie against 8.6)", "yes"),
-    ("FlexAlign global", "row pass of 5760-point rows in one kernel that writes the kept columns only (`k_fft2d_45x128_rows_kept`)", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "45-point transforms in registers (`xh_dft45`): 466 registers, one wave per SIMD, 185 us per frame against 170 for the three kernels; as 45 x 24 sums with scalar-loaded factors: 143 us (latency bound at 2.4 waves per SIMD: 46 KB of LDS per row pair); samples five ahead: no change", "yes (143 us)"),
+    ("FlexAlign global", "... as two small DFTs on the vector ALUs (`k_fa_small_dft`: a lane per column, <= 32 outputs in registers, factors by scalar loads, packed multiply-adds; 4092 = 31 x 132, 30 of 132 kept)", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "21 us per frame (0.84 ms per movie against 8.6)", "yes"),
+    ("FlexAlign global", "row pass of 5760-point rows in one kernel that writes the kept columns only (`k_fft2d_45x128_rows_kept`)", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "45-point transforms in registers (`xh_dft45`): 466 registers, one wave per SIMD, 185 us per frame against 170 for the three kernels; as 45 x 24 sums with scalar-loaded factors: 143 us (latency bound at 2.4 waves per SIMD: 46 KB of LDS per row pair); samples five ahead: no change", "yes (143 us)"),
     ("FlexAlign global", "second pass of the pair windows: a lane per window column and group of rows, U staged through LDS", "gpurun A/B", "global alignment 10.3 -> 9.8 ms per movie", "yes"),
-    ("FlexAlign local", "patch correlations (`k_fa_patch_corr2`): first pass like `k_fa_pairwin_a2`, U in LDS; second pass one sweep over kx per lane", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "9.5 -> 3.9 -> 2.9 ms per movie", "yes"),
-    ("FlexAlign warp", "(sx, sy) += (CX, CY) tmp as one packed fused multiply-add on control points stored side by side", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "475 -> 299 vector instructions per pixel for the 64 terms, 356 -> 303 us per frame", "yes"),
+    ("FlexAlign local", "patch correlations (`k_fa_patch_corr2`): first pass like `k_fa_pairwin_a2`, U in LDS; second pass one sweep over kx per lane", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "9.5 -> 3.9 -> 2.9 ms per movie", "yes"),
+    ("FlexAlign warp", "(sx, sy) += (CX, CY) tmp as one packed fused multiply-add on control points stored side by side", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "475 -> 299 vector instructions per pixel for the 64 terms, 356 -> 303 us per frame", "yes"),
     ("FlexAlign warp", "what the pixels of a row share taken out of the pixel: G[j] = sum over (layer, row) per image row (a pre-kernel), the pixel sums 4 terms and subtracts the dropped ones, found by 64 wave-uniform tests", "gpurun A/B", "warp stage 12.0 -> 16.7 ms per movie (a scalar load, a compare and a branch per term, in order); inner columns only (16 tests): 12.9", "no"),
-    ("FlexAlign warp", "spline weights without selects (the branch is known from the argument's range), weight products two per instruction", "gpurun A/B", "12.0 -> 12.5 ms: the compiler's version was as short; the kernel issues a vector instruction every cycle (counters: `profiles/r05_f_flexalign_pmc_all_kernels.txt`), 468 per row of 64 pixels", "no"),
-    ("FlexAlign global", "row kernel, first step: two lines per lane and twelve outputs per wave (half the scalar loads per multiply-add)", "profiles/r05_f_flexalign_kernel_stats_one_lane.csv", "143 -> 115 us per frame", "yes"),
+    ("FlexAlign warp", "spline weights without selects (the branch is known from the argument's range), weight products two per instruction", "gpurun A/B", "12.0 -> 12.5 ms: the compiler's version was as short; the kernel issues a vector instruction every cycle (counters: `profiles/r05_g_flexalign_pmc_all_kernels.txt`), 468 per row of 64 pixels", "no"),
+    ("FlexAlign global", "row kernel, first step: two lines per lane and twelve outputs per wave (half the scalar loads per multiply-add)", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "143 -> 115 us per frame", "yes"),
     ("FlexAlign local", "36 instead of 16 patches per batch; the products' next tile fetched under the current products; K in steps of 32", "gpurun A/B", "local alignment 18.5 -> 17.5 ms per movie; products 4.95 + 2.85 -> 4.69 + 2.49 ms; steps of 32: 4.92 + 2.64", "yes / yes / no"),
     ("FlexAlign local", "U of the patch correlations through global scratch instead of LDS (more waves per CU)", "gpurun A/B", "922 -> 1554 us per launch", "no"),
-    ("matcher S5", "`k_pm_rescore_row`: a thread owns a shift of both rows (straight and mirrored), one gather of the twiddle for the two sums; same sums", "profiles/r05_f_step_trace.txt", "377 -> 289 us per step", "yes"),
+    ("matcher S5", "`k_pm_rescore_row`: a thread owns a shift of both rows (straight and mirrored), one gather of the twiddle for the two sums; same sums", "profiles/r05_g_step_trace.txt", "377 -> 289 us per step", "yes"),
+    ("FlexAlign warp", "the 1e-4 cut as an execution mask: `v_cmpx_lt_f32` switches the dropped lanes off for the one packed multiply-add of the term (inline assembly, EXEC restored in the same statement)", "profiles/r05_g_flexalign_kernel_stats_one_lane.csv", "compare + select + multiply-add -> compare + multiply-add: 299 -> 237 vector instructions for the 64 terms, 303 -> 281 us per frame, 27.5-28 -> 29-29.7 movies/s", "yes"),
     ("FlexAlign", "three and four movies in flight", "gpurun A/B", "25.7 / 27.6 movies/s against 27.8 with two", "no"),
 ]
 
