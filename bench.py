@@ -722,7 +722,7 @@ def main():
             e0.record()
             rf.mirror_and_crop()
             xa.allreduce_reconstruction(rf)
-            rf.finish()
+            rf.finish(reuse=True)          # (the volume is not looked at here: one page-locked result buffer for every call)
             rf.reset()
             e1.record()
             fin_ev.append((e0, e1))
@@ -812,7 +812,7 @@ def main():
     if not args.no_extra_legs:
         # (1) the same steps + finish fed the other way: what the host traffic costs is value_resident - value_streamed
         nres = max(2, min(args.steps, 4))
-        nleg = max(2, min(args.steps, 8))
+        nleg = max(2, args.steps)          # the same number of steps as `value`: both forms amortise the tail alike
         ta_, _, tb_ = (streamed_steps if args.timed == "resident" else resident_steps)(nleg, False)
         el = tb_ - ta_
         if world > 1:
@@ -821,11 +821,13 @@ def main():
             el = t.item()
         if args.timed == "resident":
             extra["value_streamed"] = nleg * B * world / el
+            extra["ms_per_step_streamed"] = 1e3 * el / nleg
             extra["streamed_leg"] = {"steps": nleg, "what": "SURVEY.md 8d's PCIe-inclusive rate (`value` of rounds 3-4): the same steps + finish with every batch copied "
                                                              "from page-locked host memory inside the clock (two device buffers, the copy of batch k + 1 under step k), results "
                                                              "copied back; on a box whose host link is shared with other jobs it falls below `value` (seen: 85 k against 102 k)"}
         else:
             extra["value_resident"] = nleg * B * world / el
+            extra["ms_per_step_resident"] = 1e3 * el / nleg
             extra["resident_leg"] = {"steps": nleg, "what": "same steps + finish on batches resident in HBM, no batch copies"}
         if pipelined:
             # (1b) the same without the second stream: every stage of a step behind the one before it
@@ -1014,6 +1016,7 @@ def main():
         "metric": "particles/s projection-matched+reconstructed, 256x256 box",
         "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "value_definition": args.timed, "value_definition_changed_in": "r05 (rounds 1-4: streamed; both forms are in every line since r05, over equal step counts since r06)",
         "vs_baseline": None, "dtype": "f32 (coarse search, gridding) + f64 (exact re-score, shifts, finaliser)",
         "data": "synthetic",
         "config": {"workload": {"full": f"full refine iteration (match + CTF + reconstruct), {D}x{D} particles vs {nrefs} references (BASELINE config 4 per GPU)",

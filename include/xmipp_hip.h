@@ -67,6 +67,18 @@ int xh_free(xh_ctx *ctx, void *d_ptr);
 int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* synchronous */
 int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
+/* Page-locked host memory and copies that only enqueue: what a loader thread needs to feed the device while it computes
+ * (pinMemory / unpinMemory, cuda_gpu_reconstruct_fourier.h:134-136, gpu.h:78-113; the loader of
+ * reconstruct_fourier_accel.cpp:300-388).  The async copies return when enqueued on the context's stream; the host
+ * buffer must stay untouched until xh_ctx_sync (or a later synchronous call) on that context.  With pageable host
+ * memory they are still correct, only not asynchronous. */
+int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr);
+int xh_host_free(xh_ctx *ctx, void *h_ptr);
+int xh_memcpy_h2d_async(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* everything enqueued so far on `other`'s stream happens before what is enqueued on ctx's stream from now on
+ * (an event recorded on one stream and waited for on the other; no host wait).  Both contexts on one device. */
+int xh_ctx_wait_for(xh_ctx *ctx, xh_ctx *other);
 /* elapsed-time probes on the context stream (HIP events), for bench.py's roofline object */
 int xh_timer_create(xh_ctx *ctx, void **timer);
 int xh_timer_start(xh_ctx *ctx, void *timer);

@@ -45,6 +45,11 @@ SIGNATURES = {
     "xh_memset": (C.c_int, [vp, vp, C.c_int, sz]),
     "xh_memcpy_h2d": (C.c_int, [vp, vp, vp, sz]),
     "xh_memcpy_d2h": (C.c_int, [vp, vp, vp, sz]),
+    "xh_host_alloc": (C.c_int, [vp, sz, pvp]),
+    "xh_host_free": (C.c_int, [vp, vp]),
+    "xh_memcpy_h2d_async": (C.c_int, [vp, vp, vp, sz]),
+    "xh_memcpy_d2h_async": (C.c_int, [vp, vp, vp, sz]),
+    "xh_ctx_wait_for": (C.c_int, [vp, vp]),
     "xh_timer_create": (C.c_int, [vp, pvp]),
     "xh_timer_start": (C.c_int, [vp, vp]),
     "xh_timer_stop": (C.c_int, [vp, vp]),

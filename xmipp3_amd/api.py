@@ -283,21 +283,21 @@ class RecFourier:
         check(lib().xh_rf_cropped_import(self.h, _ptr(buf), 1 if add else 0))
         self.cropped = True
 
-    def finish(self):
-        # page-locked result buffer: the D^3 doubles leave the device at DMA speed (134 MB at D=256; pageable memory
-        # makes this copy the longest part of the finaliser)
-        # Page-locking 134 MB takes 25-30 ms -- three times the finaliser's kernels -- so the buffer is kept with the handle and handed
-        # out again once the caller has dropped the previous result (nobody but this object and the local name holds it)
-        import sys
+    def finish(self, reuse=False):
+        """The finaliser; returns the D^3 volume as a numpy float64 array in page-locked memory (134 MB at D=256; from pageable
+        memory the copy is the longest part of the finaliser).  Page-locking takes 25-30 ms, three times the finaliser's kernels:
+        a caller that is done with the previous result before it asks for the next one says reuse=True and gets the SAME buffer
+        again (its previous contents are overwritten); by default every call returns a fresh array."""
         torch = _torch()
-        out = getattr(self, "_fin_out", None)
-        if out is None or sys.getrefcount(out) > 3:
+        out = getattr(self, "_fin_out", None) if reuse else None
+        if out is None:
             try:
-                self._fin_pin = torch.empty((self.D, self.D, self.D), dtype=torch.float64, pin_memory=True)
-                out = self._fin_pin.numpy()
+                pin = torch.empty((self.D, self.D, self.D), dtype=torch.float64, pin_memory=True)
+                out = pin.numpy()
             except RuntimeError:
                 out = np.empty((self.D, self.D, self.D), np.float64)
-            self._fin_out = out
+            if reuse:
+                self._fin_out = out
         check(lib().xh_rf_finish(self.h, _np_ptr(out)))
         return out
 

@@ -158,6 +158,56 @@ int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return XH_OK;
 }
 
+int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr)
+{
+    XH_CHECK(ctx && h_ptr, XH_ERR_ARG, "xh_host_alloc: null argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *h_ptr = nullptr;
+        xh_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return XH_ERR_NOMEM;
+    }
+    return XH_OK;
+}
+int xh_host_free(xh_ctx *ctx, void *h_ptr)
+{
+    XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    if (!h_ptr) return XH_OK;
+    XH_HIP(hipSetDevice(ctx->device));
+    XH_HIP(hipStreamSynchronize(ctx->stream));
+    XH_HIP(hipHostFree(h_ptr));
+    return XH_OK;
+}
+int xh_memcpy_h2d_async(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
+    XH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return XH_OK;
+}
+int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    XH_CHECK(ctx, XH_ERR_ARG, "null context");
+    XH_HIP(hipSetDevice(ctx->device));
+    XH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return XH_OK;
+}
+int xh_ctx_wait_for(xh_ctx *ctx, xh_ctx *other)
+{
+    XH_CHECK(ctx && other, XH_ERR_ARG, "null context");
+    XH_CHECK(ctx->device == other->device, XH_ERR_ARG, "xh_ctx_wait_for: contexts on devices %d and %d", ctx->device, other->device);
+    if (ctx->stream == other->stream) return XH_OK;
+    XH_HIP(hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    XH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, other->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+    (void)hipEventDestroy(ev);      // released when the recorded work has completed
+    XH_HIP(e);
+    return XH_OK;
+}
+
 struct XhTimer {
     hipEvent_t a, b;
 };

@@ -1,0 +1,497 @@
+// fastio.h -- the host side of the two hot-path programs at the rate the device consumes particles.
+//
+// The reference feeds its kernels from one loader thread (loadImageThread / preloadBuffer,
+// reconstruction/reconstruct_fourier_accel.cpp:300-388,969-995) and reads its inputs through MetaData rows and
+// Image<T>::read, one object at a time (angular_projection_matching.cpp:991-1191 processSomeImages,
+// data/sampling.cpp:1592-1659 readSamplingFile).  At 100-300 k particles per second per device that is what bounds a
+// run, not the kernels, so this file holds:
+//   * MappedFile / FastTable : an "# XMIPP_STAR_1" block read in place (mmap), rows split and tokenised by several
+//                              threads, cells kept as (offset, length) into the mapping, numbers converted on demand
+//   * parseNeighbourRows     : the `neighbors` block of a _sampling.xmd (5 KB of text per image at 1000 references)
+//                              into CSR lists, identical consecutive rows shared
+//   * StackSource            : "n@stack" names resolved to (descriptor, offset) once per stack file
+//   * BatchFeeder            : page-locked double buffer; reader threads pread() images straight into it and enqueue
+//                              their piece of the batch on a copy stream while the device works on the previous batch
+// No numerics here: everything below moves bytes.
+#ifndef XMIPP3_AMD_FASTIO_H
+#define XMIPP3_AMD_FASTIO_H
+#include "minicore.h"
+#include "../../include/xmipp_hip.h"
+#include <atomic>
+#include <charconv>
+#include <chrono>
+#include <exception>
+#include <fcntl.h>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <string_view>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <unordered_map>
+
+namespace mc {
+
+inline void xhCheck(int rc) { if (rc != XH_OK) REPORT_ERROR(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error()); }
+
+inline double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// f(g) for g < n, one host thread per g; the first exception is re-thrown on the caller's thread
+template <class F> inline void runOnSlots(size_t n, F f)
+{
+    if (n == 1) { f((size_t)0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(n);
+    for (size_t g = 0; g < n; ++g)
+        th.emplace_back([&, g] { try { f(g); } catch (...) { err[g] = std::current_exception(); } });
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < n; ++g) if (err[g]) std::rethrow_exception(err[g]);
+}
+
+inline int hostThreads(int wanted = 0)
+{
+    if (wanted > 0) return wanted;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw / 2 : 4u));
+}
+
+// ------------------------------------------------------------------ a file read where it lies
+struct MappedFile {
+    const char *p = nullptr;
+    size_t n = 0;
+    std::string path;
+    explicit MappedFile(const std::string &fn) : path(fn)
+    {
+        const int fd = ::open(fn.c_str(), O_RDONLY);
+        if (fd < 0) REPORT_ERROR(ERR_IO_NOTEXIST, "MetaData::read: cannot open " + fn);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); REPORT_ERROR(ERR_IO_NOREAD, "MetaData::read: cannot stat " + fn); }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); REPORT_ERROR(ERR_IO_NOREAD, "MetaData::read: cannot map " + fn); }
+            p = (const char *)m;
+            madvise(m, n, MADV_SEQUENTIAL);
+        }
+        ::close(fd);
+    }
+    ~MappedFile() { if (p) munmap((void *)p, n); }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
+inline bool isBlank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+
+// One data_ block of a metadata file.  Same reading rules as MetaDataVec::read (minicore.h): comment lines (# ;) and
+// empty lines skipped, `_label [value]` lines up to the first row, quoted cells may hold blanks, short rows are padded
+// with empty cells, an empty cell reads as "label absent".
+class FastTable {
+public:
+    struct Cell { uint32_t off = 0, len = 0; };            // relative to the row's first byte
+    std::shared_ptr<MappedFile> file;
+    std::vector<std::string> labels;
+    std::vector<const char *> rowStart;
+    std::vector<Cell> cells;                               // [row][label]
+    std::vector<std::string> single;                       // values of a block without loop_
+
+    size_t size() const { return single.empty() ? rowStart.size() : 1; }
+    bool containsLabel(const std::string &l) const { return col(l) >= 0; }
+    int col(const std::string &l) const
+    {
+        auto it = std::find(labels.begin(), labels.end(), l);
+        return it == labels.end() ? -1 : (int)(it - labels.begin());
+    }
+    std::string_view cell(int c, size_t row) const
+    {
+        if (c < 0) return {};
+        if (!single.empty()) return single[c];
+        const Cell &e = cells[row * labels.size() + (size_t)c];
+        return std::string_view(rowStart[row] + e.off, e.len);
+    }
+    static double toDouble(std::string_view s, double def)
+    {
+        if (s.empty()) return def;
+        if (s[0] == '+') s.remove_prefix(1);
+        double v = def;
+        auto r = std::from_chars(s.data(), s.data() + s.size(), v);
+        return r.ec == std::errc() ? v : atof(std::string(s).c_str());
+    }
+    static long toLong(std::string_view s, long def)
+    {
+        if (s.empty()) return def;
+        if (s[0] == '+') s.remove_prefix(1);
+        long v = def;
+        auto r = std::from_chars(s.data(), s.data() + s.size(), v);
+        return r.ec == std::errc() ? v : atol(std::string(s).c_str());
+    }
+    double getDouble(int c, size_t row, double def) const { return toDouble(cell(c, row), def); }
+    long getLong(int c, size_t row, long def) const { return toLong(cell(c, row), def); }
+    // the MetaDataVec spellings (label looked up per call: fine outside the per-image loops)
+    bool getValue(const std::string &l, std::string &v, size_t row) const { auto s = cell(col(l), row); if (s.empty()) return false; v.assign(s); return true; }
+    bool getValue(const std::string &l, long &v, size_t row) const { auto s = cell(col(l), row); if (s.empty()) return false; v = toLong(s, v); return true; }
+    double getDouble(const std::string &l, size_t row, double def) const { return getDouble(col(l), row, def); }
+
+    // fn may be "block@file"; empty block => first block of the file
+    void read(const std::string &fnFull, int threads = 0)
+    {
+        FileName fn(fnFull);
+        read(std::make_shared<MappedFile>(fn.path), fn.hasNumber() ? "" : fn.prefix, threads);
+    }
+    void read(std::shared_ptr<MappedFile> f, const std::string &block, int threads = 0)
+    {
+        file = std::move(f);
+        labels.clear(); rowStart.clear(); cells.clear(); single.clear();
+        const char *p = file->p, *end = p + file->n;
+        // the block's first line: "data_<name>" at the start of a line
+        const char *b = nullptr;
+        for (const char *q = p; q && q < end;) {
+            const char *hit = (q == p && end - p >= 5 && memcmp(p, "data_", 5) == 0) ? p : nullptr;
+            if (!hit) {
+                const char *m = (const char *)memmem(q, (size_t)(end - q), "\ndata_", 6);
+                if (!m) break;
+                hit = m + 1;
+            }
+            const char *e = (const char *)memchr(hit, '\n', (size_t)(end - hit));
+            if (!e) e = end;
+            const char *t = e;
+            while (t > hit + 5 && isBlank(t[-1])) --t;
+            if (block.empty() || std::string_view(hit + 5, (size_t)(t - hit - 5)) == block) { b = e; break; }
+            q = e;
+        }
+        if (!b) REPORT_ERROR(ERR_MD_NOOBJ, "MetaData::read: block '" + block + "' not found in " + file->path);
+        const char *next = (const char *)memmem(b, (size_t)(end - b), "\ndata_", 6);
+        const char *stop = next ? next + 1 : end;
+        // header: loop_ and the _label lines
+        bool loop = false;
+        const char *q = b < end ? b + 1 : end;
+        std::vector<std::string> values;
+        while (q < stop) {
+            const char *e = (const char *)memchr(q, '\n', (size_t)(stop - q));
+            if (!e) e = stop;
+            const char *t = q;
+            while (t < e && isBlank(*t)) ++t;
+            if (t == e || *t == '#' || *t == ';') { q = e + 1; continue; }
+            if (e - t >= 5 && memcmp(t, "loop_", 5) == 0) { loop = true; q = e + 1; continue; }
+            if (*t != '_') break;
+            std::vector<std::string> tk = MetaDataVec::tokenize(std::string(t, (size_t)(e - t)));
+            labels.push_back(tk[0].substr(1));
+            values.push_back(tk.size() > 1 ? tk[1] : "");
+            q = e + 1;
+        }
+        if (!loop) { single = values; return; }       // one row of `_label value` pairs
+        if (q >= stop || labels.empty()) return;
+        // rows: T pieces cut at line ends, each split and tokenised by its own thread
+        const size_t bytes = (size_t)(stop - q), L = labels.size();
+        const size_t T = (size_t)std::max(1, std::min(hostThreads(threads), (int)(bytes / (1 << 20)) + 1));
+        std::vector<const char *> cut(T + 1, stop);
+        cut[0] = q;
+        for (size_t t = 1; t < T; ++t) {
+            const char *c = q + bytes * t / T;
+            c = (const char *)memchr(c, '\n', (size_t)(stop - c));
+            cut[t] = c ? c + 1 : stop;
+        }
+        std::vector<std::vector<const char *>> rs(T);
+        std::vector<std::vector<Cell>> cs(T);
+        runOnSlots(T, [&](size_t t) {
+            auto &R = rs[t];
+            auto &Cc = cs[t];
+            for (const char *s = cut[t]; s < cut[t + 1];) {
+                const char *e = (const char *)memchr(s, '\n', (size_t)(cut[t + 1] - s));
+                if (!e) e = cut[t + 1];
+                const char *a = s;
+                while (a < e && isBlank(*a)) ++a;
+                if (a < e && *a != '#' && *a != ';') {
+                    R.push_back(a);
+                    const size_t base = Cc.size();
+                    Cc.resize(base + L);
+                    size_t k = 0;
+                    const char *c = a;
+                    while (c < e && k < L) {
+                        while (c < e && isBlank(*c)) ++c;
+                        if (c >= e) break;
+                        if (*c == '\'' || *c == '"') {
+                            const char *z = (const char *)memchr(c + 1, *c, (size_t)(e - c - 1));
+                            if (!z) z = e;
+                            Cc[base + k++] = Cell{(uint32_t)(c + 1 - a), (uint32_t)(z - c - 1)};
+                            c = z < e ? z + 1 : e;
+                        } else {
+                            const char *z = c;
+                            while (z < e && !isBlank(*z)) ++z;
+                            Cc[base + k++] = Cell{(uint32_t)(c - a), (uint32_t)(z - c)};
+                            c = z;
+                        }
+                    }
+                }
+                s = e + 1;
+            }
+        });
+        size_t n = 0;
+        for (auto &r : rs) n += r.size();
+        rowStart.reserve(n);
+        cells.reserve(n * L);
+        for (size_t t = 0; t < T; ++t) {
+            rowStart.insert(rowStart.end(), rs[t].begin(), rs[t].end());
+            cells.insert(cells.end(), cs[t].begin(), cs[t].end());
+            std::vector<const char *>().swap(rs[t]);
+            std::vector<Cell>().swap(cs[t]);
+        }
+    }
+    // rows whose `enabled` cell is <= 0 dropped (MetaData::removeDisabled)
+    void removeDisabled()
+    {
+        const int c = col("enabled");
+        if (c < 0 || !single.empty()) return;
+        const size_t L = labels.size();
+        size_t w = 0;
+        for (size_t r = 0; r < rowStart.size(); ++r) {
+            if (getLong(c, r, 0) <= 0) continue;
+            if (w != r) { rowStart[w] = rowStart[r]; std::copy(cells.begin() + r * L, cells.begin() + (r + 1) * L, cells.begin() + w * L); }
+            ++w;
+        }
+        rowStart.resize(w);
+        cells.resize(w * L);
+    }
+};
+
+// The `neighbors` column of a _sampling.xmd: one blank-separated list of reference numbers per image.  Lists equal to
+// the previous image's (byte for byte) are stored once.  listOf[i] -> (first, count) into ids.
+struct NeighbourLists {
+    std::vector<uint32_t> listOf;                  // image -> list
+    std::vector<std::pair<size_t, uint32_t>> span; // list -> (first, count)
+    std::vector<int32_t> ids;
+    size_t size() const { return listOf.size(); }
+    const int32_t *begin(size_t image) const { return ids.data() + span[listOf[image]].first; }
+    uint32_t count(size_t image) const { return span[listOf[image]].second; }
+};
+inline void parseNeighbourRows(const FastTable &t, int column, NeighbourLists &out, int threads = 0)
+{
+    const size_t n = t.size();
+    out.listOf.assign(n, 0);
+    out.span.clear();
+    out.ids.clear();
+    if (!n || column < 0) return;
+    const size_t T = (size_t)std::max(1, std::min(hostThreads(threads), (int)(n / 256) + 1));
+    struct Part { std::vector<uint32_t> listOf; std::vector<std::pair<size_t, uint32_t>> span; std::vector<int32_t> ids; };
+    std::vector<Part> part(T);
+    runOnSlots(T, [&](size_t k) {
+        Part &P = part[k];
+        std::string_view prev;
+        bool havePrev = false;
+        for (size_t i = n * k / T; i < n * (k + 1) / T; ++i) {
+            const std::string_view s = t.cell(column, i);
+            if (havePrev && s.size() == prev.size() && memcmp(s.data(), prev.data(), s.size()) == 0) { P.listOf.push_back((uint32_t)P.span.size() - 1); continue; }
+            const size_t first = P.ids.size();
+            const char *c = s.data(), *e = c + s.size();
+            while (c < e) {
+                while (c < e && (unsigned char)(*c - '0') > 9) ++c;
+                if (c >= e) break;
+                int32_t v = 0;
+                while (c < e && (unsigned char)(*c - '0') <= 9) v = v * 10 + (*c++ - '0');
+                P.ids.push_back(v);
+            }
+            P.span.emplace_back(first, (uint32_t)(P.ids.size() - first));
+            P.listOf.push_back((uint32_t)P.span.size() - 1);
+            prev = s;
+            havePrev = true;
+        }
+    });
+    // stitch the parts; a part whose first list equals the previous part's last shares it as well
+    size_t w = 0;
+    for (size_t k = 0; k < T; ++k) {
+        Part &P = part[k];
+        if (P.span.empty()) continue;
+        uint32_t shift = (uint32_t)out.span.size();
+        bool merged = false;
+        if (!out.span.empty()) {
+            const auto &a = out.span.back();
+            const auto &b = P.span.front();
+            merged = a.second == b.second && memcmp(out.ids.data() + a.first, P.ids.data() + b.first, (size_t)a.second * 4) == 0;
+        }
+        const size_t idBase = out.ids.size();
+        const size_t skipIds = merged ? P.span.front().second : 0;
+        out.ids.insert(out.ids.end(), P.ids.begin() + skipIds, P.ids.end());
+        for (size_t s = merged ? 1 : 0; s < P.span.size(); ++s) out.span.emplace_back(idBase + P.span[s].first - skipIds, P.span[s].second);
+        if (merged) shift -= 1;
+        for (uint32_t l : P.listOf) out.listOf[w++] = shift + l;
+    }
+}
+
+// ------------------------------------------------------------------ image stacks
+// "n@stack.stk" / "n@stack.mrcs" / single-image files -> where the pixels lie.  One descriptor per file, kept open.
+class StackSource {
+public:
+    struct Loc { int32_t fd = -1; int32_t mode = 2; uint64_t off = 0; };    // self-contained: readers never look at `files`
+    struct File { std::string path; int fd = -1; ImageInfo info; };
+    std::vector<File> files;
+    ~StackSource() { for (File &f : files) if (f.fd >= 0) ::close(f.fd); }
+    // not thread-safe: called by the one thread that assembles a batch.  dim: the expected image size (dim x dim x 1)
+    Loc locate(std::string_view name, size_t dim)
+    {
+        size_t at = name.find('@');
+        size_t idx = 0;
+        std::string_view path = name;
+        if (at != std::string_view::npos) {
+            bool digits = at > 0;
+            for (size_t i = 0; i < at; ++i) digits = digits && (unsigned char)(name[i] - '0') <= 9;
+            if (digits) { for (size_t i = 0; i < at; ++i) idx = idx * 10 + (size_t)(name[i] - '0'); path = name.substr(at + 1); }
+        }
+        int fid = -1;
+        if (last >= 0 && files[(size_t)last].path == path) fid = last;
+        else {
+            auto it = index.find(std::string(path));
+            if (it != index.end()) fid = it->second;
+            else {
+                File f;
+                f.path = std::string(path);
+                f.info = readInfo(f.path);
+                f.fd = ::open(f.path.c_str(), O_RDONLY);
+                if (f.fd < 0) REPORT_ERROR(ERR_IO_NOTEXIST, "Image::read: cannot open " + f.path);
+                files.push_back(f);
+                fid = (int)files.size() - 1;
+                index.emplace(f.path, fid);
+            }
+            last = fid;
+        }
+        const ImageInfo &I = files[(size_t)fid].info;
+        if (I.x != dim || I.y != dim || I.z != 1) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + std::string(name) + " has a different size");
+        const size_t per = I.x * I.y * I.z, bpp = I.bytesPerPixel();
+        Loc l;
+        l.fd = files[(size_t)fid].fd;
+        l.mode = I.mode;
+        if (I.mrc) l.off = I.headerBytes + (idx > 0 ? (idx - 1) * per * bpp : 0);
+        else if (I.isStack) { if (idx == 0) idx = 1; l.off = I.headerBytes + (idx - 1) * (I.perImageHeader + per * 4) + I.perImageHeader; }
+        else l.off = I.headerBytes;
+        if (I.isStack && idx > I.n) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: image " + std::to_string(idx) + " beyond the end of " + files[(size_t)fid].path);
+        return l;
+    }
+    // thread-safe (pread): the image as floats
+    static void readFloats(const Loc &l, float *dst, size_t dim, std::vector<unsigned char> &scratch)
+    {
+        const size_t per = dim * dim, bytes = per * (l.mode == 0 ? 1 : (l.mode == 1 || l.mode == 6) ? 2 : 4);
+        char *to = (char *)dst;
+        if (l.mode != 2) { scratch.resize(bytes); to = (char *)scratch.data(); }
+        for (size_t got = 0; got < bytes;) {
+            const ssize_t r = pread(l.fd, to + got, bytes - got, (off_t)(l.off + got));
+            if (r <= 0) REPORT_ERROR(ERR_IO_NOREAD, "Image::read: short read of an image (file truncated?)");
+            got += (size_t)r;
+        }
+        struct { int mode; } I{l.mode};
+        if (I.mode == 0) { const signed char *p = (const signed char *)to; for (size_t i = 0; i < per; ++i) dst[i] = (float)p[i]; }
+        else if (I.mode == 1) { const int16_t *p = (const int16_t *)to; for (size_t i = 0; i < per; ++i) dst[i] = (float)p[i]; }
+        else if (I.mode == 6) { const uint16_t *p = (const uint16_t *)to; for (size_t i = 0; i < per; ++i) dst[i] = (float)p[i]; }
+    }
+
+private:
+    std::unordered_map<std::string, int> index;
+    int last = -1;
+};
+
+// wall-clock seconds of the host side of a run, printed under XMIPP_HIP_TIMING=1.  `load` runs on the loader's threads
+// under the device's work (it is on the critical path only through `stall`).
+struct HostTiming {
+    double setup = 0;         // device contexts, page-locked buffers
+    double parse = 0;         // metadata files -> tables, neighbour lists
+    double bank = 0;          // APM: reading the gallery + xh_pm_create
+    double loop = 0;          // the image loop, wall clock (all devices side by side)
+    double stall = 0;         //   main thread(s) waiting for the loader: the part of `load` that was NOT hidden
+    double device = 0;        //   main thread(s) inside the library's calls (enqueue + waits for results)
+    double load = 0;          //   loader threads: pread of the batches into page-locked memory + their H2D, under the device's work
+    double h2d = 0;           //     of which waiting for the copy stream after the last read
+    double format = 0;        //   result rows -> text (a worker thread, under the device's work)
+    double finish = 0;        // RFA: mirror/crop, reduction, finaliser, volume D2H
+    double write = 0;         // output files
+    double total = 0;
+    size_t images = 0;
+    void add(const HostTiming &o)
+    {
+        setup += o.setup; parse += o.parse; bank += o.bank; load += o.load; h2d += o.h2d; stall += o.stall; device += o.device;
+        format += o.format; finish += o.finish; write += o.write; images += o.images;
+    }
+    // one line, also machine readable: tools/bench_cli.py reads the key=value pairs
+    void print(const char *prog) const
+    {
+        fprintf(stderr, "timing %s: total=%.4f setup=%.4f parse=%.4f bank=%.4f loop=%.4f stall=%.4f device=%.4f load=%.4f h2d_wait=%.4f format=%.4f "
+                        "finish=%.4f write=%.4f images=%zu images_per_s_loop=%.0f images_per_s_total=%.0f\n",
+                prog, total, setup, parse, bank, loop, stall, device, load, h2d, format, finish, write, images, images / std::max(1e-9, loop),
+                images / std::max(1e-9, total));
+    }
+};
+
+// Two page-locked host buffers and two device buffers of `capacity` images; request(k) starts reading batch k into
+// buffer k & 1 on `readers` threads, each enqueueing its images on the copy context as soon as it has read them;
+// take(k) waits until the batch is in HBM.  The copy stream first waits (on the device) for everything the compute
+// context had been given when request() was called: the device buffer it overwrites was last read by batch k - 2.
+class BatchFeeder {
+public:
+    StackSource source;
+    size_t dim = 0, capacity = 0;
+    int readers = 0;
+    HostTiming *timing = nullptr;
+
+    ~BatchFeeder() { release(); }
+    void release()
+    {
+        if (pending.valid()) { try { pending.get(); } catch (...) {} }
+        for (int s = 0; s < 2; ++s) {
+            if (h[s]) xh_host_free(copyCtx, h[s]);
+            if (d[s]) xh_free(copyCtx, d[s]);
+            h[s] = nullptr; d[s] = nullptr;
+        }
+        if (copyCtx) xh_ctx_destroy(copyCtx);
+        copyCtx = nullptr;
+    }
+    void create(int device, size_t dim_, size_t capacity_, int readers_, HostTiming *tm)
+    {
+        dim = dim_; capacity = capacity_; readers = hostThreads(readers_); timing = tm;
+        xhCheck(xh_ctx_create_private(device, &copyCtx));
+        const size_t bytes = capacity * dim * dim * sizeof(float);
+        for (int s = 0; s < 2; ++s) {
+            xhCheck(xh_host_alloc(copyCtx, bytes, (void **)&h[s]));
+            xhCheck(xh_malloc(copyCtx, bytes, (void **)&d[s]));
+        }
+    }
+    // names of batch k -> device buffer k & 1; `compute`: the context whose queued work must finish before the buffer is overwritten
+    void request(size_t k, std::vector<StackSource::Loc> locs, xh_ctx *compute)
+    {
+        if (locs.size() > capacity) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: batch larger than the buffers");
+        if (pending.valid()) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: request() before take()");
+        if (compute) xhCheck(xh_ctx_wait_for(copyCtx, compute));
+        const int s = (int)(k & 1);
+        pending = std::async(std::launch::async, [this, s, locs = std::move(locs)] {
+            const double t0 = nowSeconds();
+            const size_t n = locs.size(), per = dim * dim;
+            const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)readers, (n + 63) / 64));
+            runOnSlots(T, [&](size_t t) {
+                std::vector<unsigned char> scratch;
+                const size_t lo = n * t / T, hi = n * (t + 1) / T, piece = std::max<size_t>(1, (8u << 20) / (per * 4));
+                for (size_t a = lo; a < hi; a += piece) {
+                    const size_t b = std::min(hi, a + piece);
+                    for (size_t i = a; i < b; ++i) source.readFloats(locs[i], h[s] + i * per, dim, scratch);
+                    xhCheck(xh_memcpy_h2d_async(copyCtx, d[s] + a * per, h[s] + a * per, (b - a) * per * sizeof(float)));
+                }
+            });
+            const double t1 = nowSeconds();
+            xhCheck(xh_ctx_sync(copyCtx));
+            const double t2 = nowSeconds();
+            if (timing) { timing->load += t2 - t0; timing->h2d += t2 - t1; }
+        });
+    }
+    float *take(size_t k)
+    {
+        const double t0 = nowSeconds();
+        pending.get();                      // re-throws what a reader threw
+        if (timing) timing->stall += nowSeconds() - t0;
+        return d[k & 1];
+    }
+    float *hostBuffer(size_t k) { return h[k & 1]; }
+
+private:
+    xh_ctx *copyCtx = nullptr;
+    float *h[2] = {nullptr, nullptr}, *d[2] = {nullptr, nullptr};
+    std::future<void> pending;
+};
+
+} // namespace mc
+#endif

@@ -10,7 +10,7 @@
 #ifndef XMIPP3_AMD_PROGRAMS_H
 #define XMIPP3_AMD_PROGRAMS_H
 #include "minicore.h"
-#include "../../include/xmipp_hip.h"
+#include "fastio.h"
 #include "sampling_gen.h"
 #include <chrono>
 #include <exception>
@@ -18,8 +18,6 @@
 #include <thread>
 
 namespace mc {
-
-inline void xhCheck(int rc) { if (rc != XH_OK) REPORT_ERROR(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error()); }
 
 // --device <id> / --gpus <n> / --devices <list>: the HIP devices one program drives, one host thread each
 // (cf. the --device/--gpus flags of reconstruct_fourier_gpu, RFG:56-57). --devices may repeat an id.
@@ -47,44 +45,6 @@ inline std::vector<int> parseDevices(int device, int gpus, const std::string &li
                 REPORT_ERROR(ERR_ARG_INCORRECT, "device " + std::to_string(id) + " requested but this node has " + std::to_string(count));
     return d;
 }
-
-// f(g) for g < n, one host thread per device slot; the first exception is re-thrown on the caller's thread
-template <class F> inline void runOnSlots(size_t n, F f)
-{
-    if (n == 1) { f((size_t)0); return; }
-    std::vector<std::thread> th;
-    std::vector<std::exception_ptr> err(n);
-    for (size_t g = 0; g < n; ++g)
-        th.emplace_back([&, g] { try { f(g); } catch (...) { err[g] = std::current_exception(); } });
-    for (auto &t : th) t.join();
-    for (size_t g = 0; g < n; ++g) if (err[g]) std::rethrow_exception(err[g]);
-}
-
-// The images of one device batch, read by a few threads (each with its own stream on the stack files) while the device
-// works on the previous batch: the loader of the reference (loadImageThread, RFA:300-388) with more than one reader.
-struct ImageBatchLoader {
-    size_t dim = 0;
-    int readers = 4;
-    std::future<std::vector<float>> pending;
-    static std::vector<float> load(std::vector<std::string> names, size_t dim, int readers)
-    {
-        const size_t n = names.size(), per = dim * dim;
-        std::vector<float> out(n * per);
-        const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)readers, (n + 255) / 256));
-        runOnSlots(T, [&](size_t t) {
-            std::vector<float> one;
-            ImageInfo ii;
-            for (size_t k = (t * n) / T; k < ((t + 1) * n) / T; ++k) {
-                readImage(names[k], one, ii);
-                if (ii.x != dim || ii.y != dim || ii.z != 1) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Image " + names[k] + " has a different size");
-                std::copy(one.begin(), one.end(), out.begin() + k * per);
-            }
-        });
-        return out;
-    }
-    void request(std::vector<std::string> names) { pending = std::async(std::launch::async, load, std::move(names), dim, readers); }
-    std::vector<float> take() { return pending.get(); }     // re-throws what a reader threw
-};
 
 struct DeviceBuffer {
     xh_ctx *ctx = nullptr; void *p = nullptr; size_t bytes = 0;
@@ -134,36 +94,30 @@ inline double ctfValueAt(const xh_ctf_params &c, double X, double Y)
     return -c.K * (Ksin * std::sin(arg) - Kcos * std::cos(arg)) * E;
 }
 
-// Sampling::readSamplingFile (data/sampling.cpp:1592-1659): blocks extra / neighbors / projectionDirections
+// Sampling::readSamplingFile (data/sampling.cpp:1592-1659): blocks extra / neighbors / projectionDirections.
+// my_neighbors[image] is kept as shared lists (fastio.h: NeighbourLists): with every image searching the whole gallery
+// the block is 5 KB of text per image, read in place by several threads.
 struct Sampling {
-    std::vector<std::vector<size_t>> my_neighbors;
+    NeighbourLists my_neighbors;
     std::vector<size_t> no_redundant_sampling_points_index;
     std::vector<std::vector<double>> no_redundant_sampling_points_angles;
     size_t numberSamplesAsymmetricUnit = 0;
-    void readSamplingFile(const std::string &base)
+    void readSamplingFile(const std::string &base, int threads = 0)
     {
-        const std::string fn = base + "_sampling.xmd";
-        MetaDataVec md;
-        md.read("extra@" + fn);
-        long n = 0;
-        if (md.size() && md.getValue("pointsAsymmetricUnit", n, 0)) numberSamplesAsymmetricUnit = (size_t)n;
-        md.read("neighbors@" + fn);
-        my_neighbors.resize(md.size());
-        for (size_t i = 0; i < md.size(); ++i) {
-            std::string s;
-            md.getValue("neighbors", s, i);
-            std::istringstream is(s);
-            size_t v;
-            while (is >> v) my_neighbors[i].push_back(v);
-        }
-        md.read("projectionDirections@" + fn);
+        auto f = std::make_shared<MappedFile>(base + "_sampling.xmd");
+        FastTable md;
+        md.read(f, "extra");
+        if (md.size()) numberSamplesAsymmetricUnit = (size_t)std::max(0L, md.getLong(md.col("pointsAsymmetricUnit"), 0, 0));
+        md.read(f, "neighbors", threads);
+        parseNeighbourRows(md, md.col("neighbors"), my_neighbors, threads);
+        md.read(f, "projectionDirections", threads);
         no_redundant_sampling_points_index.resize(md.size());
         no_redundant_sampling_points_angles.resize(md.size());
+        const int cn = md.col("neighbor"), cr = md.col("angleRot"), ct = md.col("angleTilt"), cp = md.col("anglePsi");
         for (size_t i = 0; i < md.size(); ++i) {
-            long idx = 0;
-            md.getValue("neighbor", idx, i);
+            const long idx = md.getLong(cn, i, 0);
             no_redundant_sampling_points_index[i] = (size_t)idx;
-            no_redundant_sampling_points_angles[i] = {md.getDouble("angleRot", i, 0), md.getDouble("angleTilt", i, 0), md.getDouble("anglePsi", i, 0)};
+            no_redundant_sampling_points_angles[i] = {md.getDouble(cr, i, 0), md.getDouble(ct, i, 0), md.getDouble(cp, i, 0)};
             numberSamplesAsymmetricUnit = std::max(numberSamplesAsymmetricUnit, (size_t)idx + 1);
         }
     }
@@ -176,12 +130,17 @@ public:
     double pad = 1, max_shift = -1, avail_memory = 1;
     int Ri = 1, Ro = -1, search5d_shift = 0, search5d_step = 2, numOrientations = 1, threads = 1;
     bool phase_flipped = false, do_scale = false, do_append = false;
-    int device = 0, gpus = 1, batch = 4096;
+    int device = 0, gpus = 1, batch = 4096, readers = 0;
     std::string deviceList;
     // side info
-    MetaDataVec DFexp, DFo;
+    FastTable DFexp;
+    MetaDataVec DFo;
     Sampling mysampling;
     std::vector<int> convert_refno_to_stack_position;
+    std::vector<int32_t> stackPositions;          // mysampling.my_neighbors.ids through convert_refno_to_stack_position
+    std::vector<uint8_t> listIsWholeGallery;      // per neighbour list: every reference, in stack order
+    HostTiming timing;
+    std::mutex timingMutex;
     std::vector<int32_t> search5d_xoff, search5d_yoff;
     size_t dim = 0, total_nr_refs = 0;
     bool loop_forward_refs = true;
@@ -232,13 +191,16 @@ public:
         addParamsLine("                     : CTF parameter file or a 2D image with the CTF amplitudes");
         addParamsLine("  [--pad <pad=1>]             : Padding factor (for CTF correction only)");
         addParamsLine("  [--phase_flipped]            : Use this if the experimental images have been phase flipped");
-        addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads");
+        addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads (accepted; the search runs on the device in the order of");
+        addParamsLine("                               : --thr 1. With --thr n the reference merges n per-thread lists (APM:1063-1108), which");
+        addParamsLine("                               : differs only in which of two EXACTLY equal correlation values is kept)");
         addParamsLine("  [--number_orientations <numOrientations=1>]  : Number of possible orientations for each experimental image");
         addParamsLine("  [--append]                : Append (versus overwrite) data to the output file");
         addParamsLine("  [--device <id=0>]         : first HIP device");
         addParamsLine("  [--gpus <n=1>]            : number of consecutive HIP devices, one host thread each");
         addParamsLine("  [--devices <list=\"\">]    : explicit comma-separated device ids (overrides --device/--gpus)");
         addParamsLine("  [--batch <n=4096>]        : Particles per device batch");
+        addParamsLine("  [--readers <n=0>]         : Host threads reading images into page-locked memory (0: half the cores, at most 16)");
     }
 
     void readParams() override
@@ -264,6 +226,7 @@ public:
         gpus = (int)getIntParam("--gpus");
         deviceList = getParam("--devices");
         batch = std::max(1, (int)getIntParam("--batch"));
+        readers = std::max(0, (int)getIntParam("--readers"));
     }
 
     void show()
@@ -301,7 +264,8 @@ public:
                     }
         }
         if (do_scale) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "--scale is not supported (the reference loops forever at scale 1.0, APM:947-948)");
-        DFexp.read(fn_exp);
+        const double tp0 = nowSeconds();
+        DFexp.read(fn_exp, readers);
         if (DFexp.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "Empty input metadata " + fn_exp);
         std::string fn_img;
         DFexp.getValue("image", fn_img, 0);
@@ -313,19 +277,43 @@ public:
         if (max_shift < 0) max_shift = (double)(dim / 2);
         if (Ri < 1) Ri = 1;
         if (Ro < 0) Ro = (int)(dim / 2) - 1;
-        mysampling.readSamplingFile(FileName(fn_ref).removeAllExtensions());
+        mysampling.readSamplingFile(FileName(fn_ref).removeAllExtensions(), readers);
         total_nr_refs = mysampling.no_redundant_sampling_points_angles.size();
         if (rinfo.n < total_nr_refs) REPORT_ERROR(ERR_MULTIDIM_SIZE, "Reference stack holds fewer images than the sampling file lists");
         convert_refno_to_stack_position.assign(mysampling.numberSamplesAsymmetricUnit, -1);
         for (size_t i = 0; i < mysampling.no_redundant_sampling_points_index.size(); i++)
             convert_refno_to_stack_position[mysampling.no_redundant_sampling_points_index[i]] = (int)i;
+        // the neighbour lists in stack positions, once per distinct list (the per-image loop of APM:1117 does it per image)
+        {
+            const NeighbourLists &nl = mysampling.my_neighbors;
+            stackPositions.resize(nl.ids.size());
+            for (size_t i = 0; i < nl.ids.size(); ++i) {
+                const int32_t r = nl.ids[i];
+                if (r < 0 || (size_t)r >= convert_refno_to_stack_position.size() || convert_refno_to_stack_position[(size_t)r] < 0)
+                    REPORT_ERROR(ERR_VALUE_INCORRECT, "Wrong reference number " + std::to_string(r));
+                stackPositions[i] = convert_refno_to_stack_position[(size_t)r];
+            }
+            listIsWholeGallery.assign(nl.span.size(), 0);
+            for (size_t l = 0; l < nl.span.size(); ++l) {
+                bool whole = nl.span[l].second == total_nr_refs;
+                for (size_t j = 0; j < nl.span[l].second && whole; ++j) whole = stackPositions[nl.span[l].first + j] == (int32_t)j;
+                listIsWholeGallery[l] = whole ? 1 : 0;
+            }
+        }
+        timing.parse += nowSeconds() - tp0;
         loop_forward_refs = true;
+        const double tb0 = nowSeconds();
         // reference library on the device, in stack order (getCurrentReference, APM:408-528)
-        std::vector<float> refs(total_nr_refs * dim * dim), one;
-        ImageInfo ii;
-        for (size_t r = 0; r < total_nr_refs; ++r) {
-            readImage(std::to_string(r + 1) + "@" + fn_ref, one, ii);
-            std::copy(one.begin(), one.end(), refs.begin() + r * dim * dim);
+        std::vector<float> refs(total_nr_refs * dim * dim);
+        {
+            StackSource src;
+            std::vector<StackSource::Loc> locs(total_nr_refs);
+            for (size_t r = 0; r < total_nr_refs; ++r) locs[r] = src.locate(std::to_string(r + 1) + "@" + fn_ref, dim);
+            const size_t T = (size_t)std::max(1, std::min(hostThreads(readers), (int)(total_nr_refs / 32) + 1));
+            runOnSlots(T, [&](size_t t) {
+                std::vector<unsigned char> scratch;
+                for (size_t r = total_nr_refs * t / T; r < total_nr_refs * (t + 1) / T; ++r) src.readFloats(locs[r], refs.data() + r * dim * dim, dim, scratch);
+            });
         }
         // CTF filter of the gallery (APM:366-402): a 2-D image of amplitudes or a CTF parameter file
         std::vector<double> Mctf;
@@ -379,6 +367,7 @@ public:
         int32_t nn;
         xhCheck(xh_pm_info(slots[0].pm, &nn, nullptr, nullptr));
         N = nn;
+        timing.bank += nowSeconds() - tb0;
     }
 
     virtual void processAllImages()
@@ -396,70 +385,141 @@ public:
         const size_t G = slots.size(), count = imagesToProcess.size();
         std::vector<MetaDataVec> out(G);
         const bool forward0 = loop_forward_refs;
+        const double tl0 = nowSeconds();
         runOnSlots(G, [&](size_t g) {
             const size_t lo = (g * count) / G, hi = ((g + 1) * count) / G;
             if (hi == lo) return;
             std::vector<size_t> mine(imagesToProcess.begin() + lo, imagesToProcess.begin() + hi);
             processShard(slots[g], mine, (lo & 1) ? !forward0 : forward0, out[g]);
         });
+        timing.loop += nowSeconds() - tl0;
         if (count & 1) loop_forward_refs = !loop_forward_refs;
         for (MetaDataVec &o : out) {
             if (o.rows.empty()) continue;
             if (DFo.labels.empty()) DFo.labels = o.labels;
             if (DFo.labels != o.labels) REPORT_ERROR(ERR_VALUE_INCORRECT, "internal: per-device result tables differ in labels");
-            for (auto &r : o.rows) DFo.rows.push_back(std::move(r));
+            if (DFo.rows.empty()) DFo.rows.swap(o.rows);
+            else for (auto &r : o.rows) DFo.rows.push_back(std::move(r));
         }
     }
 
+    // what the host knows about one device batch before the device sees it: where the pixels lie, the previous shifts, the
+    // neighbour lists in stack positions (CSR), assembled by a worker thread while the device is on the previous batch
+    struct BatchInput {
+        size_t b0 = 0, n = 0;
+        std::vector<StackSource::Loc> locs;
+        std::vector<float> prevShift;
+        std::vector<int32_t> off, idsv;
+        bool anyShift = false, wholeGallery = false;
+    };
+    // the matches of one batch as they come back from the device
+    struct BatchResult {
+        size_t b0 = 0, n = 0;
+        std::vector<int32_t> refpos, psi;
+        std::vector<uint8_t> flip;
+        std::vector<double> f64;
+        std::vector<float> prevShift;
+    };
+
     void processShard(Slot &slot, const std::vector<size_t> &imagesToProcess, bool loop_forward_refs, MetaDataVec &DFo)
     {
-        // APM:991-1192, batched. Row order and labels as APM:1149-1165.
+        // APM:991-1192, batched and pipelined: reader threads + copy stream (fastio.h: BatchFeeder) fill batch k + 1, a worker
+        // assembles the lists of batch k + 2 and another turns the matches of batch k - 1 into rows while the device is on
+        // batch k. Row order and labels as APM:1149-1165.
         xh_ctx *ctx = slot.ctx;
         xh_pm *pm = slot.pm;
         xh_rf *&shifter = slot.shifter;
-        const size_t per = dim * dim;
-        DeviceBuffer d_part, d_shifted, d_i32a, d_i32b, d_u8, d_f64;
-        std::vector<float> h_part;
-        ImageBatchLoader loader;
-        loader.dim = dim;
-        auto namesOf = [&](size_t b0) {
-            std::vector<std::string> names;
-            for (size_t k = b0; k < std::min(b0 + (size_t)batch, imagesToProcess.size()); ++k) {
-                std::string fn;
-                DFexp.getValue("image", fn, imagesToProcess[k]);
-                names.push_back(fn);
-            }
-            return names;
-        };
-        if (!imagesToProcess.empty()) loader.request(namesOf(0));
-        for (size_t b0 = 0; b0 < imagesToProcess.size(); b0 += (size_t)batch) {
-            const size_t n = std::min((size_t)batch, imagesToProcess.size() - b0);
-            h_part = loader.take();
-            if (b0 + (size_t)batch < imagesToProcess.size()) loader.request(namesOf(b0 + (size_t)batch));   // read ahead
-            std::vector<float> prevShift(2 * n, 0.f);
-            std::vector<int32_t> off(n + 1, 0), idsv;
-            bool anyShift = false;
-            for (size_t k = 0; k < n; ++k) {
-                const size_t id = imagesToProcess[b0 + k];
-                prevShift[2 * k] = (float)DFexp.getDouble("shiftX", id, 0.);
-                prevShift[2 * k + 1] = (float)DFexp.getDouble("shiftY", id, 0.);
+        const size_t per = dim * dim, total = imagesToProcess.size(), B = (size_t)batch, nb = (total + B - 1) / B;
+        if (!total) return;
+        DeviceBuffer d_shifted, d_i32a, d_i32b, d_u8, d_f64;
+        HostTiming timing;                          // this device's share; added to the program's at the end
+        const double ts0 = nowSeconds();
+        BatchFeeder feeder;
+        feeder.create(slot.device, dim, std::min(B, total), std::max(1, hostThreads(readers) / (int)slots.size()), &timing);
+        timing.setup += nowSeconds() - ts0;
+        const int cImage = DFexp.col("image"), cSx = DFexp.col("shiftX"), cSy = DFexp.col("shiftY"), cScale = DFexp.col("scale"), cItem = DFexp.col("itemId");
+        const size_t K = (size_t)numOrientations;
+        DFo.labels = {"itemId", "image", "angleRot", "angleTilt", "anglePsi", "shiftX", "shiftY", "ref", "flip", "scale", "maxCC"};
+
+        auto prepare = [&](size_t k) {
+            BatchInput in;
+            in.b0 = k * B;
+            in.n = std::min(B, total - in.b0);
+            in.locs.resize(in.n);
+            in.prevShift.assign(2 * in.n, 0.f);
+            in.off.assign(in.n + 1, 0);
+            bool oneList = true;
+            for (size_t i = 0; i < in.n; ++i) {
+                const size_t id = imagesToProcess[in.b0 + i];
+                in.locs[i] = feeder.source.locate(DFexp.cell(cImage, id), dim);
+                in.prevShift[2 * i] = (float)DFexp.getDouble(cSx, id, 0.);
+                in.prevShift[2 * i + 1] = (float)DFexp.getDouble(cSy, id, 0.);
                 // getCurrentImage folds MDL_SCALE into the transformation it applies (APM:1222-1233); only shifts are
                 // resampled here, so a scaled input row would silently give other matches than the reference
-                if (std::fabs(DFexp.getDouble("scale", id, 1.0) - 1.0) > 1e-9)
+                if (std::fabs(DFexp.getDouble(cScale, id, 1.0) - 1.0) > 1e-9)
                     REPORT_ERROR(ERR_NOT_IMPLEMENTED, "input image " + std::to_string(id + 1) + " carries scale != 1: scaled inputs are not resampled by this build");
-                anyShift = anyShift || prevShift[2 * k] != 0.f || prevShift[2 * k + 1] != 0.f;
+                in.anyShift = in.anyShift || in.prevShift[2 * i] != 0.f || in.prevShift[2 * i + 1] != 0.f;
                 if (id >= mysampling.my_neighbors.size()) REPORT_ERROR(ERR_MD_NOOBJ, "No neighbour list for image " + std::to_string(id + 1));
-                for (size_t r : mysampling.my_neighbors[id]) {
-                    if (r >= convert_refno_to_stack_position.size() || convert_refno_to_stack_position[r] < 0)
-                        REPORT_ERROR(ERR_VALUE_INCORRECT, "Wrong reference number " + std::to_string(r));
-                    idsv.push_back(convert_refno_to_stack_position[r]);
-                }
-                off[k + 1] = (int32_t)idsv.size();
+                oneList = oneList && mysampling.my_neighbors.listOf[id] == mysampling.my_neighbors.listOf[imagesToProcess[in.b0]];
+                in.off[i + 1] = in.off[i] + (int32_t)mysampling.my_neighbors.count(id);
             }
-            d_part.reserve(ctx, n * per * sizeof(float));
-            xhCheck(xh_memcpy_h2d(ctx, d_part.p, h_part.data(), n * per * sizeof(float)));
-            float *d_imgs = d_part.as<float>();
-            if (anyShift) {
+            // every image of the batch searching the whole gallery in stack order: the library's dense mode, no lists at all
+            in.wholeGallery = oneList && listIsWholeGallery[mysampling.my_neighbors.listOf[imagesToProcess[in.b0]]];
+            if (!in.wholeGallery) {
+                in.idsv.resize((size_t)in.off[in.n]);
+                for (size_t i = 0; i < in.n; ++i) {
+                    const size_t id = imagesToProcess[in.b0 + i];
+                    const int32_t *src = stackPositions.data() + (mysampling.my_neighbors.begin(id) - mysampling.my_neighbors.ids.data());
+                    std::copy(src, src + mysampling.my_neighbors.count(id), in.idsv.begin() + in.off[i]);
+                }
+                if (in.idsv.empty()) in.idsv.push_back(0);
+            }
+            return in;
+        };
+        auto format = [&](BatchResult r) {
+            const double t0 = nowSeconds();
+            char b[64];
+            auto real = [&b](double v) { snprintf(b, sizeof(b), "%.6f", v); return std::string(b); };
+            for (size_t k = 0; k < r.n; ++k)
+                for (size_t o = 0; o < K; ++o) {
+                    const size_t e = k * K + o;
+                    if (r.refpos[e] < 0) break;   // no (further) valid correlation: the reference writes no row (APM:1068-1090,1115)
+                    const double *res = r.f64.data() + 3 * r.n * o;
+                    const size_t id = imagesToProcess[r.b0 + k];
+                    const std::vector<double> &ang = mysampling.no_redundant_sampling_points_angles[r.refpos[e]];
+                    std::vector<std::string> row(11);
+                    row[0] = std::to_string(DFexp.getLong(cItem, id, 0));
+                    row[1].assign(DFexp.cell(cImage, id));
+                    row[2] = real(ang[0]);
+                    row[3] = real(ang[1]);
+                    row[4] = real((double)r.psi[e] * (360. / N));
+                    row[5] = real(res[k] + r.prevShift[2 * k]);
+                    row[6] = real(res[r.n + k] + r.prevShift[2 * k + 1]);
+                    row[7] = std::to_string((long)mysampling.no_redundant_sampling_points_index[r.refpos[e]]);
+                    row[8] = std::to_string((long)r.flip[e]);
+                    row[9] = real(DFexp.getDouble(cScale, id, 1.0));
+                    row[10] = real(res[2 * r.n + k]);
+                    DFo.rows.push_back(std::move(row));
+                }
+            timing.format += nowSeconds() - t0;
+        };
+
+        std::future<BatchInput> prepared = std::async(std::launch::async, prepare, (size_t)0);
+        std::future<void> formatted;
+        BatchInput cur = prepared.get();
+        feeder.request(0, cur.locs, nullptr);
+        if (nb > 1) prepared = std::async(std::launch::async, prepare, (size_t)1);
+        for (size_t k = 0; k < nb; ++k) {
+            const size_t n = cur.n;
+            float *d_imgs = feeder.take(k);
+            BatchInput next;
+            if (k + 1 < nb) {
+                next = prepared.get();
+                feeder.request(k + 1, next.locs, ctx);     // (the copy stream waits for the work the device already has: batch k - 1)
+                if (k + 2 < nb) prepared = std::async(std::launch::async, prepare, k + 2);
+            }
+            const double td0 = nowSeconds();
+            if (cur.anyShift) {
                 // getCurrentImage applies the previous shifts with BSPLINE3 + WRAP (APM:1228-1233)
                 if (!shifter) {
                     xh_rf_params p{};
@@ -467,89 +527,73 @@ public:
                     p.blob_radius = 1.9; p.blob_order = 0; p.blob_alpha = 15; p.min_ctf = 0.01; p.sampling = 1;
                     xhCheck(xh_rf_create(ctx, &p, &shifter));
                 }
-                d_shifted.reserve(ctx, n * per * sizeof(float));
-                xhCheck(xh_rf_shift_images(shifter, d_imgs, prevShift.data(), nullptr, (int)n, d_shifted.as<float>()));
+                d_shifted.reserve(ctx, B * per * sizeof(float));
+                xhCheck(xh_rf_shift_images(shifter, d_imgs, cur.prevShift.data(), nullptr, (int)n, d_shifted.as<float>()));
                 d_imgs = d_shifted.as<float>();
             }
-            const size_t K = (size_t)numOrientations;
-            d_i32a.reserve(ctx, n * K * 4); d_i32b.reserve(ctx, n * K * 4); d_u8.reserve(ctx, n * K); d_f64.reserve(ctx, n * 8 * 3);
-            if (idsv.empty()) idsv.push_back(0);
+            d_i32a.reserve(ctx, B * K * 4); d_i32b.reserve(ctx, B * K * 4); d_u8.reserve(ctx, B * K); d_f64.reserve(ctx, B * 8 * 3);
             // the visiting order of the references flips once per image (APM:1112)
             const int ntrans = search5d_xoff.size() > 1 ? (int)search5d_xoff.size() : 0;
-            xhCheck(xh_pm_match_ex(pm, d_imgs, (int)n, off.data(), idsv.data(), loop_forward_refs ? 0 : 1, (int)K, ntrans,
-                                   search5d_xoff.data(), search5d_yoff.data(), d_i32a.as<int32_t>(), d_i32b.as<int32_t>(),
-                                   d_u8.as<uint8_t>()));
+            xhCheck(xh_pm_match_ex(pm, d_imgs, (int)n, cur.wholeGallery ? nullptr : cur.off.data(), cur.wholeGallery ? nullptr : cur.idsv.data(),
+                                   loop_forward_refs ? 0 : 1, (int)K, ntrans, search5d_xoff.data(), search5d_yoff.data(), d_i32a.as<int32_t>(),
+                                   d_i32b.as<int32_t>(), d_u8.as<uint8_t>()));
             if (n & 1) loop_forward_refs = !loop_forward_refs;
-            std::vector<int32_t> refpos(n * K), psi(n * K);
-            std::vector<uint8_t> flip(n * K);
-            xhCheck(xh_memcpy_d2h(ctx, refpos.data(), d_i32a.p, n * K * 4));
-            xhCheck(xh_memcpy_d2h(ctx, psi.data(), d_i32b.p, n * K * 4));
-            xhCheck(xh_memcpy_d2h(ctx, flip.data(), d_u8.p, n * K));
+            BatchResult res;
+            res.b0 = cur.b0; res.n = n;
+            res.refpos.resize(n * K); res.psi.resize(n * K); res.flip.resize(n * K); res.f64.resize(3 * n * K);
+            res.prevShift = std::move(cur.prevShift);
             // translational step per kept orientation (APM:1117-1124)
-            std::vector<double> f64(3 * n * K);
             double *d_sx = d_f64.as<double>(), *d_sy = d_sx + n, *d_cc = d_sy + n;
             if (K == 1) {
                 xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_i32a.as<int32_t>(), d_i32b.as<int32_t>(), d_u8.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
-                xhCheck(xh_memcpy_d2h(ctx, f64.data(), d_f64.p, n * 8 * 3));
+                xhCheck(xh_memcpy_d2h_async(ctx, res.refpos.data(), d_i32a.p, n * 4));
+                xhCheck(xh_memcpy_d2h_async(ctx, res.psi.data(), d_i32b.p, n * 4));
+                xhCheck(xh_memcpy_d2h_async(ctx, res.flip.data(), d_u8.p, n));
+                xhCheck(xh_memcpy_d2h(ctx, res.f64.data(), d_f64.p, n * 8 * 3));
             } else {
+                xhCheck(xh_memcpy_d2h(ctx, res.refpos.data(), d_i32a.p, n * K * 4));
+                xhCheck(xh_memcpy_d2h(ctx, res.psi.data(), d_i32b.p, n * K * 4));
+                xhCheck(xh_memcpy_d2h(ctx, res.flip.data(), d_u8.p, n * K));
                 DeviceBuffer d_r1, d_p1, d_f1;
                 d_r1.reserve(ctx, n * 4); d_p1.reserve(ctx, n * 4); d_f1.reserve(ctx, n);
                 std::vector<int32_t> r1(n), p1(n);
                 std::vector<uint8_t> f1(n);
                 for (size_t o = 0; o < K; ++o) {
-                    for (size_t k = 0; k < n; ++k) { r1[k] = refpos[k * K + o]; p1[k] = psi[k * K + o]; f1[k] = flip[k * K + o]; }
+                    for (size_t i = 0; i < n; ++i) { r1[i] = res.refpos[i * K + o]; p1[i] = res.psi[i * K + o]; f1[i] = res.flip[i * K + o]; }
                     xhCheck(xh_memcpy_h2d(ctx, d_r1.p, r1.data(), n * 4));
                     xhCheck(xh_memcpy_h2d(ctx, d_p1.p, p1.data(), n * 4));
                     xhCheck(xh_memcpy_h2d(ctx, d_f1.p, f1.data(), n));
                     xhCheck(xh_pm_translate(pm, d_imgs, (int)n, d_r1.as<int32_t>(), d_p1.as<int32_t>(), d_f1.as<uint8_t>(), max_shift, d_sx, d_sy, d_cc));
-                    xhCheck(xh_memcpy_d2h(ctx, f64.data() + 3 * n * o, d_f64.p, n * 8 * 3));
+                    xhCheck(xh_memcpy_d2h(ctx, res.f64.data() + 3 * n * o, d_f64.p, n * 8 * 3));
                 }
             }
-            for (size_t k = 0; k < n; ++k)
-                for (size_t o = 0; o < K; ++o) {
-                    const size_t e = k * K + o;
-                    if (refpos[e] < 0) break;   // no (further) valid correlation: the reference writes no row (APM:1068-1090,1115)
-                    const double *res = f64.data() + 3 * n * o;
-                    const size_t id = imagesToProcess[b0 + k];
-                    const size_t row = DFo.addObject();
-                    std::string fn;
-                    DFexp.getValue("image", fn, id);
-                    long itemId = 0;
-                    if (!DFexp.getValue("itemId", itemId, id)) itemId = 0;
-                    const std::vector<double> &ang = mysampling.no_redundant_sampling_points_angles[refpos[e]];
-                    DFo.setValue("itemId", itemId, row);
-                    DFo.setValue("image", fn, row);
-                    DFo.setValue("angleRot", ang[0], row);
-                    DFo.setValue("angleTilt", ang[1], row);
-                    DFo.setValue("anglePsi", (double)psi[e] * (360. / N), row);
-                    DFo.setValue("shiftX", res[k] + prevShift[2 * k], row);
-                    DFo.setValue("shiftY", res[n + k] + prevShift[2 * k + 1], row);
-                    DFo.setValue("ref", (long)mysampling.no_redundant_sampling_points_index[refpos[e]], row);
-                    DFo.setValue("flip", (long)flip[e], row);
-                    DFo.setValue("scale", DFexp.getDouble("scale", id, 1.0), row);
-                    DFo.setValue("maxCC", res[2 * n + k], row);
-                }
+            timing.device += nowSeconds() - td0;
+            timing.images += n;
+            if (formatted.valid()) formatted.get();
+            formatted = std::async(std::launch::async, format, std::move(res));
+            cur = std::move(next);
         }
+        if (formatted.valid()) formatted.get();
+        feeder.release();
+        std::lock_guard<std::mutex> lock(timingMutex);
+        this->timing.add(timing);
     }
 
     virtual void writeOutputFiles() { DFo.write(fn_out, do_append); }
 
     void run() override
     {
-        // XMIPP_HIP_TIMING=1: wall-clock seconds of the three phases on stderr
-        const bool timing = getenv("XMIPP_HIP_TIMING") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
+        // XMIPP_HIP_TIMING=1: where the wall-clock seconds of the run went, on stderr (fastio.h: HostTiming)
+        const bool show_timing = getenv("XMIPP_HIP_TIMING") != nullptr;
+        const double t0 = nowSeconds();
         produceSideInfo();
-        const auto t1 = std::chrono::steady_clock::now();
         show();
         processAllImages();
-        const auto t2 = std::chrono::steady_clock::now();
+        const double t2 = nowSeconds();
         writeOutputFiles();
-        const auto t3 = std::chrono::steady_clock::now();
-        if (timing) {
-            auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-            std::cerr << "timing: side info " << sec(t0, t1) << " s, images " << sec(t1, t2) << " s, output " << sec(t2, t3) << " s" << std::endl;
-        }
+        timing.write = nowSeconds() - t2;
+        timing.total = nowSeconds() - t0;
+        if (show_timing) timing.print("xmipp_angular_projection_matching");
         if (verbose) std::cout << "done!" << std::endl;
     }
 };
@@ -561,9 +605,11 @@ public:
     bool do_weights = false, useFast = false, useCTF = false, isPhaseFlipped = false;
     double padding_factor_proj = 2, padding_factor_vol = 2, maxResolution = 0.5, minCTF = 0.01, Ts = 1;
     double blob_radius = 1.9, blob_alpha = 15;
-    int blob_order = 0, bufferSize = 25, device = 0, gpus = 1, batch = 4096;
+    int blob_order = 0, bufferSize = 25, device = 0, gpus = 1, batch = 4096, readers = 0;
     std::string deviceList, fn_fsc;
-    MetaDataVec SF;
+    FastTable SF;
+    HostTiming timing;
+    std::mutex timingMutex;
     size_t imgSize = 0;
     std::vector<double> R_repository;   // nsym x 9
     // one slot per device: its own context (stream), gridding handle and temp spaces; slot 0 finishes
@@ -615,6 +661,7 @@ public:
         addParamsLine("  [--gpus <n=1>]                 : number of consecutive HIP devices, one host thread each");
         addParamsLine("  [--devices <list=\"\">]         : explicit comma-separated device ids (overrides --device/--gpus)");
         addParamsLine("  [--batch <n=4096>]             : Projections per device batch");
+        addParamsLine("  [--readers <n=0>]              : Host threads reading images into page-locked memory (0: half the cores, at most 16)");
         addExampleLine("   xmipp_reconstruct_fourier_accel  -i reconstruction.sel --sym c2 --weight");
     }
 
@@ -641,6 +688,7 @@ public:
         gpus = (int)getIntParam("--gpus");
         deviceList = getParam("--devices");
         batch = std::max(1, (int)getIntParam("--batch"));
+        readers = std::max(0, (int)getIntParam("--readers"));
         if (checkParam("--prepare_fsc")) fn_fsc = getParam("--prepare_fsc");
         NiterWeight = (int)getIntParam("--iter");
         if (NiterWeight < 0) REPORT_ERROR(ERR_ARG_INCORRECT, "--iter must not be negative");
@@ -673,14 +721,10 @@ public:
     void produceSideinfo()
     {
         // RFA:175-257
-        SF.read(fn_in);
-        // removeDisabled
-        if (SF.containsLabel("enabled")) {
-            std::vector<std::vector<std::string>> keep;
-            const int c = SF.col("enabled");
-            for (auto &r : SF.rows) if (atoi(r[c].c_str()) > 0) keep.push_back(r);
-            SF.rows.swap(keep);
-        }
+        const double tp0 = nowSeconds();
+        SF.read(fn_in, readers);
+        SF.removeDisabled();
+        timing.parse += nowSeconds() - tp0;
         if (SF.size() == 0) REPORT_ERROR(ERR_MD_NOOBJ, "No enabled images in " + fn_in);
         std::string fnImg;
         SF.getValue("image", fnImg, 0);
@@ -697,6 +741,7 @@ public:
         p.imgSize = (int)imgSize; p.padding_proj = padding_factor_proj; p.padding_vol = padding_factor_vol;
         p.max_resolution = maxResolution; p.blob_radius = blob_radius; p.blob_order = blob_order; p.blob_alpha = blob_alpha;
         p.use_fast = useFast; p.phase_flipped = isPhaseFlipped; p.min_ctf = minCTF; p.sampling = Ts;
+        const double tc0 = nowSeconds();
         for (int d : parseDevices(device, gpus, deviceList)) {
             slots.emplace_back();
             Slot &s = slots.back();
@@ -706,6 +751,7 @@ public:
             if (rfArithmetic) xhCheck(xh_rf2_create(s.ctx, &p, NiterWeight, &s.rf2));
             else xhCheck(xh_rf_reset(s.rf));
         }
+        timing.setup += nowSeconds() - tc0;
     }
 
     // Images first..last (inclusive) go to the devices in contiguous ranges (the reference's
@@ -714,10 +760,12 @@ public:
     {
         if (last < first || last == (size_t)-1) return;
         const size_t count = last - first + 1, G = slots.size();
+        const double tl0 = nowSeconds();
         runOnSlots(G, [&](size_t g) {
             const size_t lo = first + (g * count) / G, hi = first + ((g + 1) * count) / G;
             if (hi > lo) processShard(slots[g], lo, hi - 1);
         });
+        timing.loop += nowSeconds() - tl0;
     }
 
     // every device's partial sums -> slot 0 (mirrorAndCropTempSpaces on each, then one tree reduction)
@@ -733,84 +781,124 @@ public:
 
     void resetSpaces() { for (Slot &s : slots) xhCheck(xh_rf_reset(s.rf)); }
 
+    // the host's view of one device batch, assembled by a worker thread while the device is on the previous one
+    struct BatchInput {
+        size_t n = 0;
+        std::vector<StackSource::Loc> locs;
+        std::vector<double> ang;
+        std::vector<float> w, sh;
+        std::vector<uint8_t> fl;
+        std::vector<xh_ctf_params> ctfs;
+        bool anyGeo = false;
+    };
+
     void processShard(Slot &slot, size_t first, size_t last)
     {
-        // loadImageThread/preloadBuffer + processBuffer (RFA:300-388,939-966), batched on the device
+        // loadImageThread/preloadBuffer + processBuffer (RFA:300-388,939-966), batched on the device: reader threads and a copy stream
+        // bring batch k + 1 into HBM (fastio.h: BatchFeeder), a worker reads the metadata columns of batch k + 2, the device grids batch k;
+        // nothing on this thread waits for the device inside the loop -- the copy stream waits, on the device, for the batch whose buffer it reuses
         xh_ctx *ctx = slot.ctx;
         xh_rf *rf = slot.rf;
-        const size_t per = imgSize * imgSize;
-        int32_t P, mv, sx, sy;
-        xhCheck(xh_rf_sizes(rf, &P, &mv, &sx, &sy));
+        const size_t per = imgSize * imgSize, B = (size_t)batch, total = last - first + 1, nb = (total + B - 1) / B;
         const bool hasCTF = useCTF && (SF.containsLabel("ctfModel") || SF.containsLabel("ctfDefocusU"));
-        DeviceBuffer d_img, d_shift;
-        std::vector<float> h_img;
-        ImageBatchLoader loader;
-        loader.dim = imgSize;
-        auto namesOf = [&](size_t b0) {
-            std::vector<std::string> names;
-            for (size_t id = b0; id <= std::min(b0 + (size_t)batch - 1, last); ++id) {
-                std::string fn;
-                SF.getValue("image", fn, id);
-                names.push_back(fn);
-            }
-            return names;
-        };
-        loader.request(namesOf(first));
-        for (size_t b0 = first; b0 <= last; b0 += (size_t)batch) {
-            const size_t n = std::min((size_t)batch, last + 1 - b0);
-            h_img = loader.take();
-            if (b0 + (size_t)batch <= last) loader.request(namesOf(b0 + (size_t)batch));   // read ahead
-            std::vector<double> ang(3 * n);
-            std::vector<float> w(n, 1.f), sh(2 * n, 0.f);
-            std::vector<uint8_t> fl(n, 0);
-            std::vector<xh_ctf_params> ctfs(hasCTF ? n : 0);
-            bool anyGeo = false;
-            for (size_t k = 0; k < n; ++k) {
-                const size_t id = b0 + k;
-                ang[3 * k] = SF.getDouble("angleRot", id, 0); ang[3 * k + 1] = SF.getDouble("angleTilt", id, 0); ang[3 * k + 2] = SF.getDouble("anglePsi", id, 0);
-                sh[2 * k] = (float)SF.getDouble("shiftX", id, 0); sh[2 * k + 1] = (float)SF.getDouble("shiftY", id, 0);
-                fl[k] = SF.getDouble("flip", id, 0) != 0 ? 1 : 0;
-                anyGeo = anyGeo || sh[2 * k] != 0.f || sh[2 * k + 1] != 0.f || fl[k];
-                if (do_weights) w[k] = (float)SF.getDouble("weight", id, 1.0);
+        if (hasCTF && !SF.containsLabel("ctfDefocusU"))
+            REPORT_ERROR(ERR_NOT_IMPLEMENTED, "ctfModel files are not read by this build; put the CTF columns in the metadata");
+        HostTiming timing;                          // this device's share; added to the program's at the end
+        const double ts0 = nowSeconds();
+        BatchFeeder feeder;
+        feeder.create(slot.device, imgSize, std::min(B, total), std::max(1, hostThreads(readers) / (int)slots.size()), &timing);
+        DeviceBuffer d_shift;
+        timing.setup += nowSeconds() - ts0;
+        const int cImage = SF.col("image"), cRot = SF.col("angleRot"), cTilt = SF.col("angleTilt"), cPsi = SF.col("anglePsi"), cSx = SF.col("shiftX"),
+                  cSy = SF.col("shiftY"), cFlip = SF.col("flip"), cWeight = SF.col("weight");
+        const char *ctfLabels[16] = {"ctfSamplingRate", "ctfVoltage", "ctfDefocusU", "ctfDefocusV", "ctfDefocusAngle", "ctfSphericalAberration", "ctfChromaticAberration",
+                                     "ctfEnergyLoss", "ctfLensStability", "ctfConvergenceCone", "ctfLongitudinalDisplacement", "ctfTransversalDisplacement", "ctfQ0",
+                                     "ctfK", "ctfPhaseShift", "ctfVPPRadius"};
+        int cCtf[16];
+        for (int i = 0; i < 16; ++i) cCtf[i] = SF.col(ctfLabels[i]);
+
+        auto prepare = [&](size_t k) {
+            BatchInput in;
+            const size_t b0 = first + k * B;
+            const size_t n = in.n = std::min(B, last + 1 - b0);
+            in.locs.resize(n);
+            in.ang.resize(3 * n);
+            in.w.assign(n, 1.f);
+            in.sh.assign(2 * n, 0.f);
+            in.fl.assign(n, 0);
+            in.ctfs.resize(hasCTF ? n : 0);
+            for (size_t i = 0; i < n; ++i) {
+                const size_t id = b0 + i;
+                in.locs[i] = feeder.source.locate(SF.cell(cImage, id), imgSize);
+                in.ang[3 * i] = SF.getDouble(cRot, id, 0); in.ang[3 * i + 1] = SF.getDouble(cTilt, id, 0); in.ang[3 * i + 2] = SF.getDouble(cPsi, id, 0);
+                in.sh[2 * i] = (float)SF.getDouble(cSx, id, 0); in.sh[2 * i + 1] = (float)SF.getDouble(cSy, id, 0);
+                in.fl[i] = SF.getDouble(cFlip, id, 0) != 0 ? 1 : 0;
+                in.anyGeo = in.anyGeo || in.sh[2 * i] != 0.f || in.sh[2 * i + 1] != 0.f || in.fl[i];
+                if (do_weights) in.w[i] = (float)SF.getDouble(cWeight, id, 1.0);
                 if (hasCTF) {
-                    if (!SF.containsLabel("ctfDefocusU")) REPORT_ERROR(ERR_NOT_IMPLEMENTED, "ctfModel files are not read by this build; put the CTF columns in the metadata");
-                    xh_ctf_params &c = ctfs[k];
+                    xh_ctf_params &c = in.ctfs[i];
                     xh_ctf_defaults(&c);     // data/ctf.cpp:365-388
-                    c.Tm = SF.getDouble("ctfSamplingRate", id, 1); c.kV = SF.getDouble("ctfVoltage", id, 100);
-                    c.DeltafU = SF.getDouble("ctfDefocusU", id, 0); c.DeltafV = SF.getDouble("ctfDefocusV", id, c.DeltafU);
-                    c.azimuthal_angle = SF.getDouble("ctfDefocusAngle", id, 0); c.Cs = SF.getDouble("ctfSphericalAberration", id, 0);
-                    c.Ca = SF.getDouble("ctfChromaticAberration", id, 0); c.espr = SF.getDouble("ctfEnergyLoss", id, 0);
-                    c.ispr = SF.getDouble("ctfLensStability", id, 0); c.alpha = SF.getDouble("ctfConvergenceCone", id, 0);
-                    c.DeltaF = SF.getDouble("ctfLongitudinalDisplacement", id, 0); c.DeltaR = SF.getDouble("ctfTransversalDisplacement", id, 0);
-                    c.Q0 = SF.getDouble("ctfQ0", id, 0); c.K = SF.getDouble("ctfK", id, 1);
-                    c.phase_shift = SF.getDouble("ctfPhaseShift", id, 0); c.VPP_radius = SF.getDouble("ctfVPPRadius", id, 0);
+                    c.Tm = SF.getDouble(cCtf[0], id, 1); c.kV = SF.getDouble(cCtf[1], id, 100);
+                    c.DeltafU = SF.getDouble(cCtf[2], id, 0); c.DeltafV = SF.getDouble(cCtf[3], id, c.DeltafU);
+                    c.azimuthal_angle = SF.getDouble(cCtf[4], id, 0); c.Cs = SF.getDouble(cCtf[5], id, 0);
+                    c.Ca = SF.getDouble(cCtf[6], id, 0); c.espr = SF.getDouble(cCtf[7], id, 0);
+                    c.ispr = SF.getDouble(cCtf[8], id, 0); c.alpha = SF.getDouble(cCtf[9], id, 0);
+                    c.DeltaF = SF.getDouble(cCtf[10], id, 0); c.DeltaR = SF.getDouble(cCtf[11], id, 0);
+                    c.Q0 = SF.getDouble(cCtf[12], id, 0); c.K = SF.getDouble(cCtf[13], id, 1);
+                    c.phase_shift = SF.getDouble(cCtf[14], id, 0); c.VPP_radius = SF.getDouble(cCtf[15], id, 0);
                 }
             }
-            d_img.reserve(ctx, n * per * 4);
-            xhCheck(xh_memcpy_h2d(ctx, d_img.p, h_img.data(), n * per * 4));
-            float *imgs = d_img.as<float>();
-            if (anyGeo) {   // Projection::readApplyGeo with only_apply_shifts (RFA:311-323)
-                d_shift.reserve(ctx, n * per * 4);
-                xhCheck(xh_rf_shift_images(rf, imgs, sh.data(), fl.data(), (int)n, d_shift.as<float>()));
+            return in;
+        };
+
+        std::future<BatchInput> prepared = std::async(std::launch::async, prepare, (size_t)0);
+        BatchInput cur = prepared.get();
+        feeder.request(0, cur.locs, nullptr);
+        if (nb > 1) prepared = std::async(std::launch::async, prepare, (size_t)1);
+        for (size_t k = 0; k < nb; ++k) {
+            const size_t n = cur.n;
+            float *imgs = feeder.take(k);
+            BatchInput next;
+            if (k + 1 < nb) {
+                next = prepared.get();
+                feeder.request(k + 1, next.locs, ctx);     // (the copy stream waits for what the device already has: batch k - 1)
+                if (k + 2 < nb) prepared = std::async(std::launch::async, prepare, k + 2);
+            }
+            const double td0 = nowSeconds();
+            if (cur.anyGeo) {   // Projection::readApplyGeo with only_apply_shifts (RFA:311-323)
+                d_shift.reserve(ctx, B * per * 4);
+                xhCheck(xh_rf_shift_images(rf, imgs, cur.sh.data(), cur.fl.data(), (int)n, d_shift.as<float>()));
                 imgs = d_shift.as<float>();
             }
             // processBufferGPU in one call (RFG:417-473): FFT, CTF factor and modulator evaluated while the gridding records
             // are packed (no CTF planes, same records bit for bit as the three separate steps), insertion
             if (rfArithmetic)
-                xhCheck(xh_rf2_insert(slot.rf2, imgs, hasCTF ? ctfs.data() : nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n,
+                xhCheck(xh_rf2_insert(slot.rf2, imgs, hasCTF ? cur.ctfs.data() : nullptr, cur.ang.data(), do_weights ? cur.w.data() : nullptr, (int)n,
                                       R_repository.data(), (int)(R_repository.size() / 9), 0));
             else
-            xhCheck(xh_rf_insert_images(rf, imgs, hasCTF ? ctfs.data() : nullptr, ang.data(), do_weights ? w.data() : nullptr, (int)n,
-                                        R_repository.data(), (int)(R_repository.size() / 9)));
-            xhCheck(xh_ctx_sync(ctx));
+                xhCheck(xh_rf_insert_images(rf, imgs, hasCTF ? cur.ctfs.data() : nullptr, cur.ang.data(), do_weights ? cur.w.data() : nullptr, (int)n,
+                                            R_repository.data(), (int)(R_repository.size() / 9)));
+            timing.device += nowSeconds() - td0;
+            timing.images += n;
+            cur = std::move(next);
         }
+        const double td1 = nowSeconds();
+        xhCheck(xh_ctx_sync(ctx));
+        timing.device += nowSeconds() - td1;
+        feeder.release();
+        std::lock_guard<std::mutex> lock(timingMutex);
+        this->timing.add(timing);
     }
 
     void finishComputations(const std::string &out_name)
     {
+        const double t0 = nowSeconds();
         std::vector<double> vol(imgSize * imgSize * imgSize);
         xhCheck(xh_rf_finish(slots[0].rf, vol.data()));
+        const double t1 = nowSeconds();
         writeVolume(out_name, vol.data(), imgSize, imgSize, imgSize);
+        timing.finish += t1 - t0;
+        timing.write += nowSeconds() - t1;
     }
 
     // ---- xmipp_reconstruct_fourier (RF:124-180): every device's Fourier volume and weights summed into slot 0 through host memory
@@ -892,14 +980,20 @@ public:
 
     void run() override
     {
-        // RFA:139-156
+        // RFA:139-156.  XMIPP_HIP_TIMING=1: where the wall-clock seconds of the run went, on stderr (fastio.h: HostTiming)
+        struct Report {
+            HostTiming &t; double t0 = nowSeconds();
+            ~Report() { t.total = nowSeconds() - t0; if (getenv("XMIPP_HIP_TIMING")) t.print("xmipp_reconstruct_fourier_accel"); }
+        } report{timing};
         show();
         produceSideinfo();
         if (rfArithmetic) { runDouble(); return; }
         const size_t last = SF.size() - 1;
         if (fn_fsc.empty()) {
             processImages(0, last);
+            const double tg0 = nowSeconds();
             gatherCropped();
+            timing.finish += nowSeconds() - tg0;
             finishComputations(fn_out);
             return;
         }
