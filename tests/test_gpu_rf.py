@@ -636,6 +636,48 @@ def test_gridding_at_full_size_against_the_oracle(gpu, oracle):
     assert sel.sum() > 50 and frc[sel].min() >= 0.999
 
 
+@pytest.mark.parametrize("sym", [False, True])
+def test_gridding_of_particles_that_share_directions_at_full_size_against_the_oracle(gpu, oracle, sym):
+    """What a refinement hands over: several particles per gallery direction, differing in the in-plane angle only.  The launch is
+    ordered by plane and an interior visit whose plane equals the previous visit's reuses its voxel queue (xh_rf_grid.h `sameQueue`),
+    which random orientations never exercise.  A few directions x several in-plane angles at 256 px with CTF and weights, with and without a
+    symmetry matrix, against the oracle: same voxels, 2e-6.  (VERDICT r05 test hole b: this path was held against itself only.)"""
+    xa, ctx, torch = gpu
+    D, ndir, nin = (256, 3, 4) if sym else (256, 4, 6)         # (24 placements either way: the oracle takes seconds per placement at this size)
+    n = ndir * nin
+    rng = np.random.default_rng(23)
+    dirs = synth.fibonacci_directions(200)[rng.choice(200, ndir, replace=False)]
+    ang = np.array([[d[0], d[1], 360.0 * rng.integers(0, 796) / 796.0] for d in dirs for _ in range(nin)])
+    ang = ang[rng.permutation(n)]                      # metadata order: directions interleaved, the library sorts them by plane
+    imgs = (0.05 * rng.standard_normal((n, D, D))).astype(np.float32)
+    imgs[:, 100:156, 100:156] += rng.standard_normal((n, 56, 56)).astype(np.float32)
+    rf = xa.RecFourier(ctx, D, min_ctf=0.01, sampling=1.0)
+    o = oracle.RF(D, use_ctf=True, min_ctf=0.01)
+    from xmipp3_amd.api import ctf_params
+    ctfs = [ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d)) for d in rng.uniform(10000.0, 30000.0, n)]
+    weights = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    R = [np.eye(3)]
+    if sym:
+        c2 = np.diag([-1.0, -1.0, 1.0])                # a two-fold about z: its planes are shared by the same groups of particles
+        R.append(c2)
+    c, m = rf.ctf_arrays(xa.RecFourier.ctf_param_array(ctfs))
+    f = rf.prepare_images(torch.from_numpy(imgs).cuda())
+    hf, hc, hm = f.cpu().numpy(), c.cpu().numpy(), m.cpu().numpy()
+    for i in range(n):
+        for Rs in R:
+            o.insert(hf[i], synth.euler_matrix(*ang[i]).T, R=Rs, weight=float(weights[i]), ctf=hc[i], modulator=hm[i])
+    rf.insert(f, ang, weights=weights, ctf=c, modulator=m, sym=np.stack(R) if sym else None)
+    ev, ew = o.temp()
+    gv, gw = rf.temp_spaces()
+    gv, gw = gv.cpu().numpy(), gw.cpu().numpy()
+    assert (ew != 0).sum() > 1_000_000
+    assert ((ew != 0) == (gw != 0)).all()
+    assert np.abs(gw - ew).max() <= 2e-6 * np.abs(ew).max()
+    assert np.abs(gv - ev).max() <= 2e-6 * np.abs(ev).max()
+    # (six placements per plane -- eight with the two-fold about z, which maps every plane onto itself -- so most interior visits of a
+    # unit take the previous visit's queue)
+
+
 def test_device_volume_against_the_double_precision_program(gpu, oracle):
     """BASELINE config 1 is quoted on xmipp_reconstruct_fourier (ProgRecFourier, RF); the device runs the accel
     arithmetic under that name too. Against the RF restatement (double scatter, FFTW layout, correctWeight): 2e-3 of

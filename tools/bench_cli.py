@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--readers", type=int, default=0)
     ap.add_argument("--keep", action="store_true", help="leave the files in --dir")
     ap.add_argument("--no-library", action="store_true", help="skip the library legs (rates and output comparison)")
+    ap.add_argument("--env", action="append", default=[], metavar="NAME=VALUE", help="environment of the two programs (A/B runs, e.g. HSA_ENABLE_SDMA=0)")
+    ap.add_argument("--repeat", type=int, default=1, help="run the pair of programs this many times on the same files; the last run is reported")
     ap.add_argument("--neighbours", type=int, default=0, help="K > 0: every particle lists its K nearest references instead of the whole gallery")
     args = ap.parse_args()
 
@@ -154,6 +156,9 @@ def main():
 
     # ---- the two programs, as a pipeline would start them
     env = dict(os.environ, XMIPP_HIP_TIMING="1")
+    for kv in args.env:
+        k_, v_ = kv.split("=", 1)
+        env[k_] = v_
     rd = ["--readers", str(args.readers)] if args.readers else []
     t_apm, tm_apm = run_program([f"{BIN}/xmipp_angular_projection_matching", "-i", f"{tmp}/exp.xmd", "-o", f"{tmp}/out.xmd", "--ref", f"{tmp}/ref.stk",
                                  "--batch", str(B)] + rd, env)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "xh_ctx_sync": (C.c_int, [vp]),
     "xh_ctx_stream": (vp, [vp]),
     "xh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "xh_device_numa_node": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "xh_malloc": (C.c_int, [vp, sz, pvp]),
     "xh_free": (C.c_int, [vp, vp]),
     "xh_memset": (C.c_int, [vp, vp, C.c_int, sz]),

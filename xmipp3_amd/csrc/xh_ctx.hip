@@ -1,6 +1,7 @@
 // xh_ctx.hip -- context, memory and timer entry points of the C ABI.
 #include "xh_common.h"
 #include <cstring>
+#include <cctype>
 
 static thread_local std::string g_err;
 
@@ -52,6 +53,22 @@ int xh_device_count(int *count)
 {
     XH_CHECK(count, XH_ERR_ARG, "xh_device_count: null pointer");
     XH_HIP(hipGetDeviceCount(count));
+    return XH_OK;
+}
+
+int xh_device_numa_node(int device, int *node)
+{
+    XH_CHECK(node, XH_ERR_ARG, "xh_device_numa_node: null pointer");
+    *node = -1;
+    char bdf[64] = {0};
+    XH_HIP(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device));
+    for (char *c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return XH_OK;
+    int v = -1;
+    if (fscanf(f, "%d", &v) == 1) *node = v;
+    fclose(f);
     return XH_OK;
 }
 

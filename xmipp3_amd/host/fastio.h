@@ -19,12 +19,14 @@
 #include "../../include/xmipp_hip.h"
 #include <atomic>
 #include <charconv>
+#include <condition_variable>
 #include <chrono>
 #include <exception>
 #include <fcntl.h>
 #include <future>
 #include <memory>
 #include <mutex>
+#include <sched.h>
 #include <string_view>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -55,6 +57,35 @@ inline int hostThreads(int wanted = 0)
     if (wanted > 0) return wanted;
     const unsigned hw = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(16u, hw ? hw / 2 : 4u));
+}
+
+// The calling thread (and every thread it starts afterwards) onto the CPUs of the NUMA node the device hangs off.  With the
+// loader's threads and its page-locked memory spread over both sockets of the host the H2D copy and the readers beside it
+// run at 21 + 20 GB/s; on one node, either one, at 56 + 56 (tools/ubench_hostfeed.hip).  XMIPP_HIP_NO_BIND=1 leaves the
+// affinity alone (a host that is shared by several jobs may have given this process its CPUs already).
+inline int bindToDeviceNode(int device)
+{
+    if (getenv("XMIPP_HIP_NO_BIND")) return -1;
+    int node = -1;
+    if (xh_device_numa_node(device, &node) != XH_OK || node < 0) return -1;
+    FILE *f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return -1;
+    char buf[4096] = {0};
+    const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!ok) return -1;
+    cpu_set_t allowed, set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
+    int count = 0;
+    for (const char *c = buf; *c;) {
+        if (!isdigit((unsigned char)*c)) { ++c; continue; }
+        int a = (int)strtol(c, (char **)&c, 10), b = a;
+        if (*c == '-') b = (int)strtol(c + 1, (char **)&c, 10);
+        for (int k = a; k <= b && k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &allowed)) { CPU_SET(k, &set); ++count; }
+    }
+    if (count == 0 || sched_setaffinity(0, sizeof(set), &set) != 0) return -1;     // (none of the node's CPUs is ours: stay where we are)
+    return node;
 }
 
 // ------------------------------------------------------------------ a file read where it lies
@@ -419,78 +450,179 @@ struct HostTiming {
     }
 };
 
-// Two page-locked host buffers and two device buffers of `capacity` images; request(k) starts reading batch k into
-// buffer k & 1 on `readers` threads, each enqueueing its images on the copy context as soon as it has read them;
-// take(k) waits until the batch is in HBM.  The copy stream first waits (on the device) for everything the compute
-// context had been given when request() was called: the device buffer it overwrites was last read by batch k - 2.
+// Two device buffers of `capacity` images and the threads that fill them.  `readers` reader threads take 4 MB pieces of a batch
+// (runs of consecutive images) off a counter and pread() them into page-locked memory, two pieces per reader; two copier threads, a copy
+// stream each, are the only ones to talk to the runtime: each enqueues pieces that are ready, waits for its stream and hands them
+// back.  (Measured on the 256-core host: readers that enqueue their own copies on their own streams get slower with every reader added --
+// 75 k particles/s with 16, 30 k with 64 -- the runtime serialises them and the compute thread's launches with them.  Page-locking
+// costs ~0.25 s per GB, so the batch itself is never page-locked.)
+// request(k) starts batch k into device buffer k & 1; take(k) waits until it is in HBM.  The copy stream first waits (on the device)
+// for everything the compute context had been given when request() was called: the buffer it overwrites was last read by batch k - 2.
 class BatchFeeder {
 public:
     StackSource source;
     size_t dim = 0, capacity = 0;
-    int readers = 0;
     HostTiming *timing = nullptr;
 
     ~BatchFeeder() { release(); }
     void release()
     {
-        if (pending.valid()) { try { pending.get(); } catch (...) {} }
-        for (int s = 0; s < 2; ++s) {
-            if (h[s]) xh_host_free(copyCtx, h[s]);
-            if (d[s]) xh_free(copyCtx, d[s]);
-            h[s] = nullptr; d[s] = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (!started) return;
+            cvDone.wait(lk, [&] { return !active || done + failed == npieces; });
+            stop = true;
+            started = false;
         }
-        if (copyCtx) xh_ctx_destroy(copyCtx);
+        cvWork.notify_all();
+        cvCopy.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+        for (Reader &r : rd) for (int s = 0; s < 2; ++s) if (r.pin[s]) xh_host_free(copyCtx, r.pin[s]);
+        rd.clear();
+        for (int s = 0; s < 2; ++s) { if (d[s]) xh_free(copyCtx, d[s]); d[s] = nullptr; }
+        for (xh_ctx *c : copiers) if (c) xh_ctx_destroy(c);
+        copiers.clear();
         copyCtx = nullptr;
     }
-    void create(int device, size_t dim_, size_t capacity_, int readers_, HostTiming *tm)
+    void create(int device, size_t dim_, size_t capacity_, int readers, HostTiming *tm)
     {
-        dim = dim_; capacity = capacity_; readers = hostThreads(readers_); timing = tm;
+        dim = dim_; capacity = capacity_; timing = tm;
+        const size_t per = dim * dim;
+        const char *ePiece = getenv("XMIPP_HIP_PIECE_MB"), *eCop = getenv("XMIPP_HIP_COPIERS");      // (A/B knobs of tools/cli_sweep.sh)
+        const size_t pieceBytes = (size_t)std::max(1, ePiece ? atoi(ePiece) : 8) << 20;
+        const size_t ncop = (size_t)std::max(1, std::min(4, eCop ? atoi(eCop) : 2));
+        pieceImages = std::max<size_t>(1, pieceBytes / (per * sizeof(float)));
+        const size_t nr = std::max<size_t>(1, std::min<size_t>((size_t)hostThreads(readers), (capacity + pieceImages - 1) / pieceImages));
         xhCheck(xh_ctx_create_private(device, &copyCtx));
-        const size_t bytes = capacity * dim * dim * sizeof(float);
-        for (int s = 0; s < 2; ++s) {
-            xhCheck(xh_host_alloc(copyCtx, bytes, (void **)&h[s]));
-            xhCheck(xh_malloc(copyCtx, bytes, (void **)&d[s]));
-        }
-    }
-    // names of batch k -> device buffer k & 1; `compute`: the context whose queued work must finish before the buffer is overwritten
-    void request(size_t k, std::vector<StackSource::Loc> locs, xh_ctx *compute)
-    {
-        if (locs.size() > capacity) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: batch larger than the buffers");
-        if (pending.valid()) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: request() before take()");
-        if (compute) xhCheck(xh_ctx_wait_for(copyCtx, compute));
-        const int s = (int)(k & 1);
-        pending = std::async(std::launch::async, [this, s, locs = std::move(locs)] {
-            const double t0 = nowSeconds();
-            const size_t n = locs.size(), per = dim * dim;
-            const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)readers, (n + 63) / 64));
-            runOnSlots(T, [&](size_t t) {
-                std::vector<unsigned char> scratch;
-                const size_t lo = n * t / T, hi = n * (t + 1) / T, piece = std::max<size_t>(1, (8u << 20) / (per * 4));
-                for (size_t a = lo; a < hi; a += piece) {
-                    const size_t b = std::min(hi, a + piece);
-                    for (size_t i = a; i < b; ++i) source.readFloats(locs[i], h[s] + i * per, dim, scratch);
-                    xhCheck(xh_memcpy_h2d_async(copyCtx, d[s] + a * per, h[s] + a * per, (b - a) * per * sizeof(float)));
-                }
-            });
-            const double t1 = nowSeconds();
-            xhCheck(xh_ctx_sync(copyCtx));
-            const double t2 = nowSeconds();
-            if (timing) { timing->load += t2 - t0; timing->h2d += t2 - t1; }
+        copiers.assign(ncop, nullptr);
+        copiers[0] = copyCtx;
+        for (size_t c = 1; c < ncop; ++c) xhCheck(xh_ctx_create_private(device, &copiers[c]));
+        for (int s = 0; s < 2; ++s) xhCheck(xh_malloc(copyCtx, capacity * per * sizeof(float), (void **)&d[s]));
+        rd.resize(nr);
+        runOnSlots(std::min<size_t>(nr, 8), [&](size_t t) {                 // (page-locking is per call: a few threads lock the pieces side by side)
+            for (size_t r = t; r < nr; r += std::min<size_t>(nr, 8))
+                for (int s = 0; s < 2; ++s) xhCheck(xh_host_alloc(copyCtx, pieceImages * per * sizeof(float), (void **)&rd[r].pin[s]));
         });
+        stop = false; started = true; active = false;
+        for (size_t r = 0; r < nr; ++r) threads.emplace_back([this, r] { readerLoop(r); });
+        for (size_t c = 0; c < ncop; ++c) threads.emplace_back([this, c] { copierLoop(copiers[c]); });
+    }
+    // where the images of batch k lie -> device buffer k & 1; `compute`: the context whose queued work must finish before the buffer is overwritten
+    void request(size_t k, std::vector<StackSource::Loc> locs_, xh_ctx *compute)
+    {
+        if (locs_.size() > capacity) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: batch larger than the buffers");
+        if (compute) for (xh_ctx *c : copiers) xhCheck(xh_ctx_wait_for(c, compute));
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (active) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: request() before take()");
+            locs = std::move(locs_);
+            slot = (int)(k & 1);
+            npieces = (locs.size() + pieceImages - 1) / pieceImages;
+            next = 0; done = 0; failed = 0; err = nullptr;
+            active = true;
+            ++generation;
+            t0 = nowSeconds();
+        }
+        cvWork.notify_all();
     }
     float *take(size_t k)
     {
-        const double t0 = nowSeconds();
-        pending.get();                      // re-throws what a reader threw
-        if (timing) timing->stall += nowSeconds() - t0;
+        const double w0 = nowSeconds();
+        std::unique_lock<std::mutex> lk(m);
+        cvDone.wait(lk, [&] { return done + failed == npieces; });
+        active = false;
+        if (timing) { timing->stall += nowSeconds() - w0; timing->load += tEnd - t0; }
+        if (err) std::rethrow_exception(err);
         return d[k & 1];
     }
-    float *hostBuffer(size_t k) { return h[k & 1]; }
 
 private:
-    xh_ctx *copyCtx = nullptr;
-    float *h[2] = {nullptr, nullptr}, *d[2] = {nullptr, nullptr};
-    std::future<void> pending;
+    struct Reader { float *pin[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; };
+    struct CopyJob { size_t reader; int buf; size_t first, count; };
+    std::vector<Reader> rd;
+    std::vector<std::thread> threads;
+    std::vector<CopyJob> queue;
+    std::mutex m;
+    std::condition_variable cvWork, cvCopy, cvDone, cvBuf;
+    xh_ctx *copyCtx = nullptr;              // = copiers[0]; owns the buffers
+    std::vector<xh_ctx *> copiers;          // one stream per copier thread: the copies of one are queued while the other waits for its own
+    float *d[2] = {nullptr, nullptr};
+    std::vector<StackSource::Loc> locs;
+    size_t pieceImages = 1, npieces = 0, next = 0, done = 0, failed = 0;
+    uint64_t generation = 0;
+    int slot = 0;
+    bool stop = false, started = false, active = false;
+    double t0 = 0, tEnd = 0;
+    std::exception_ptr err;
+
+    void readerLoop(size_t r)
+    {
+        std::vector<unsigned char> scratch;
+        uint64_t seen = 0;
+        int b = 0;
+        const size_t per = dim * dim;
+        for (;;) {
+            size_t piece;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cvWork.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                if (next >= npieces) { seen = generation; continue; }
+                piece = next++;
+                cvBuf.wait(lk, [&] { return stop || !rd[r].busy[b]; });
+                if (stop) return;
+            }
+            const size_t first = piece * pieceImages, count = std::min(pieceImages, locs.size() - first);
+            try {
+                for (size_t i = 0; i < count; ++i) StackSource::readFloats(locs[first + i], rd[r].pin[b] + i * per, dim, scratch);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m);
+                if (!err) err = std::current_exception();
+                ++failed;
+                tEnd = nowSeconds();
+                cvDone.notify_all();
+                continue;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                rd[r].busy[b] = true;
+                queue.push_back(CopyJob{r, b, first, count});
+            }
+            cvCopy.notify_one();
+            b ^= 1;
+        }
+    }
+    void copierLoop(xh_ctx *ctx)
+    {
+        const size_t per = dim * dim;
+        std::vector<CopyJob> jobs;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cvCopy.wait(lk, [&] { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                // (with another copier at work, take half of what is ready: both streams stay busy)
+                const size_t take = copiers.size() > 1 ? (queue.size() + 1) / 2 : queue.size();
+                jobs.assign(queue.begin(), queue.begin() + take);
+                queue.erase(queue.begin(), queue.begin() + take);
+            }
+            bool bad = false;
+            for (const CopyJob &j : jobs)
+                bad = bad || xh_memcpy_h2d_async(ctx, d[slot] + j.first * per, rd[j.reader].pin[j.buf], j.count * per * sizeof(float)) != XH_OK;
+            bad = (xh_ctx_sync(ctx) != XH_OK) || bad;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                for (const CopyJob &j : jobs) rd[j.reader].busy[j.buf] = false;
+                if (bad) { if (!err) err = std::make_exception_ptr(XmippError(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error())); failed += jobs.size(); }
+                else done += jobs.size();
+                tEnd = nowSeconds();
+            }
+            jobs.clear();
+            cvBuf.notify_all();
+            cvDone.notify_all();
+        }
+    }
 };
 
 } // namespace mc

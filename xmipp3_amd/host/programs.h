@@ -150,6 +150,7 @@ public:
         xh_ctx *ctx = nullptr;
         xh_pm *pm = nullptr;
         xh_rf *shifter = nullptr;   // only used for xh_rf_shift_images (previous shifts, APM:1228-1233)
+        std::unique_ptr<BatchFeeder> feeder;   // loader threads + page-locked pieces + the two device batches (fastio.h)
     };
     std::vector<Slot> slots;
     int N = 0;
@@ -157,6 +158,7 @@ public:
     ~ProgAngularProjectionMatching() override
     {
         for (Slot &s : slots) {
+            s.feeder.reset();
             if (s.pm) xh_pm_destroy(s.pm);
             if (s.shifter) xh_rf_destroy(s.shifter);
             if (s.ctx) xh_ctx_destroy(s.ctx);
@@ -358,11 +360,18 @@ public:
         }
         runOnSlots(slots.size(), [&](size_t g) {
             Slot &s = slots[g];
+            bindToDeviceNode(s.device);
             xhCheck(xh_ctx_create_private(s.device, &s.ctx));
+            // the loader (page-locking its pieces takes tens of ms) is set up beside the reference bank
+            s.feeder.reset(new BatchFeeder);
+            auto feederReady = std::async(std::launch::async, [&] {
+                s.feeder->create(s.device, dim, std::min((size_t)batch, DFexp.size()), std::max(1, hostThreads(readers) / (int)slots.size()), nullptr);
+            });
             DeviceBuffer d_refs;
             d_refs.reserve(s.ctx, refs.size() * sizeof(float));
             xhCheck(xh_memcpy_h2d(s.ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
             xhCheck(xh_pm_create(s.ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), Mctf.empty() ? nullptr : Mctf.data(), paddim, &s.pm));
+            feederReady.get();
         });
         int32_t nn;
         xhCheck(xh_pm_info(slots[0].pm, &nn, nullptr, nullptr));
@@ -389,6 +398,7 @@ public:
         runOnSlots(G, [&](size_t g) {
             const size_t lo = (g * count) / G, hi = ((g + 1) * count) / G;
             if (hi == lo) return;
+            bindToDeviceNode(slots[g].device);          // this thread and the loader threads it starts: the device's side of the host
             std::vector<size_t> mine(imagesToProcess.begin() + lo, imagesToProcess.begin() + hi);
             processShard(slots[g], mine, (lo & 1) ? !forward0 : forward0, out[g]);
         });
@@ -433,10 +443,8 @@ public:
         if (!total) return;
         DeviceBuffer d_shifted, d_i32a, d_i32b, d_u8, d_f64;
         HostTiming timing;                          // this device's share; added to the program's at the end
-        const double ts0 = nowSeconds();
-        BatchFeeder feeder;
-        feeder.create(slot.device, dim, std::min(B, total), std::max(1, hostThreads(readers) / (int)slots.size()), &timing);
-        timing.setup += nowSeconds() - ts0;
+        BatchFeeder &feeder = *slot.feeder;
+        feeder.timing = &timing;
         const int cImage = DFexp.col("image"), cSx = DFexp.col("shiftX"), cSy = DFexp.col("shiftY"), cScale = DFexp.col("scale"), cItem = DFexp.col("itemId");
         const size_t K = (size_t)numOrientations;
         DFo.labels = {"itemId", "image", "angleRot", "angleTilt", "anglePsi", "shiftX", "shiftY", "ref", "flip", "scale", "maxCC"};
@@ -574,7 +582,7 @@ public:
             cur = std::move(next);
         }
         if (formatted.valid()) formatted.get();
-        feeder.release();
+        feeder.timing = nullptr;
         std::lock_guard<std::mutex> lock(timingMutex);
         this->timing.add(timing);
     }
@@ -613,7 +621,7 @@ public:
     size_t imgSize = 0;
     std::vector<double> R_repository;   // nsym x 9
     // one slot per device: its own context (stream), gridding handle and temp spaces; slot 0 finishes
-    struct Slot { int device = 0; xh_ctx *ctx = nullptr; xh_rf *rf = nullptr; xh_rf2 *rf2 = nullptr; };
+    struct Slot { int device = 0; xh_ctx *ctx = nullptr; xh_rf *rf = nullptr; xh_rf2 *rf2 = nullptr; std::unique_ptr<BatchFeeder> feeder; };
     std::vector<Slot> slots;
     // xmipp_reconstruct_fourier (ProgRecFourier, reconstruction/reconstruct_fourier.cpp): its own double-precision arithmetic on the
     // device (xh_rf2_*); NiterWeight = --iter (RF:44,96)
@@ -623,6 +631,7 @@ public:
     ~ProgRecFourierAccel() override
     {
         for (Slot &s : slots) {
+            s.feeder.reset();
             if (s.rf2) xh_rf2_destroy(s.rf2);
             if (s.rf) xh_rf_destroy(s.rf);
             if (s.ctx) xh_ctx_destroy(s.ctx);
@@ -746,11 +755,21 @@ public:
             slots.emplace_back();
             Slot &s = slots.back();
             s.device = d;
-            xhCheck(xh_ctx_create_private(d, &s.ctx));
+        }
+        runOnSlots(slots.size(), [&](size_t g) {
+            Slot &s = slots[g];
+            bindToDeviceNode(s.device);
+            xhCheck(xh_ctx_create_private(s.device, &s.ctx));
+            // the loader (page-locking its pieces takes tens of ms) is set up beside the temp spaces
+            s.feeder.reset(new BatchFeeder);
+            auto feederReady = std::async(std::launch::async, [&] {
+                s.feeder->create(s.device, imgSize, std::min((size_t)batch, SF.size()), std::max(1, hostThreads(readers) / (int)slots.size()), nullptr);
+            });
             xhCheck(xh_rf_create(s.ctx, &p, &s.rf));       // (the double-precision program uses it for the shifts of readApplyGeo only)
             if (rfArithmetic) xhCheck(xh_rf2_create(s.ctx, &p, NiterWeight, &s.rf2));
             else xhCheck(xh_rf_reset(s.rf));
-        }
+            feederReady.get();
+        });
         timing.setup += nowSeconds() - tc0;
     }
 
@@ -763,6 +782,7 @@ public:
         const double tl0 = nowSeconds();
         runOnSlots(G, [&](size_t g) {
             const size_t lo = first + (g * count) / G, hi = first + ((g + 1) * count) / G;
+            bindToDeviceNode(slots[g].device);          // this thread and the loader threads it starts: the device's side of the host
             if (hi > lo) processShard(slots[g], lo, hi - 1);
         });
         timing.loop += nowSeconds() - tl0;
@@ -804,11 +824,9 @@ public:
         if (hasCTF && !SF.containsLabel("ctfDefocusU"))
             REPORT_ERROR(ERR_NOT_IMPLEMENTED, "ctfModel files are not read by this build; put the CTF columns in the metadata");
         HostTiming timing;                          // this device's share; added to the program's at the end
-        const double ts0 = nowSeconds();
-        BatchFeeder feeder;
-        feeder.create(slot.device, imgSize, std::min(B, total), std::max(1, hostThreads(readers) / (int)slots.size()), &timing);
+        BatchFeeder &feeder = *slot.feeder;
+        feeder.timing = &timing;
         DeviceBuffer d_shift;
-        timing.setup += nowSeconds() - ts0;
         const int cImage = SF.col("image"), cRot = SF.col("angleRot"), cTilt = SF.col("angleTilt"), cPsi = SF.col("anglePsi"), cSx = SF.col("shiftX"),
                   cSy = SF.col("shiftY"), cFlip = SF.col("flip"), cWeight = SF.col("weight");
         const char *ctfLabels[16] = {"ctfSamplingRate", "ctfVoltage", "ctfDefocusU", "ctfDefocusV", "ctfDefocusAngle", "ctfSphericalAberration", "ctfChromaticAberration",
@@ -885,7 +903,7 @@ public:
         const double td1 = nowSeconds();
         xhCheck(xh_ctx_sync(ctx));
         timing.device += nowSeconds() - td1;
-        feeder.release();
+        feeder.timing = nullptr;
         std::lock_guard<std::mutex> lock(timingMutex);
         this->timing.add(timing);
     }
