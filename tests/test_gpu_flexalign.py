@@ -117,6 +117,31 @@ def test_global_alignment_of_k3_sized_frames(gpu):
     assert np.corrcoef(got["shiftX"], -t[:, 0])[0, 1] > 0.95 and np.corrcoef(got["shiftY"], -t[:, 1])[0, 1] > 0.95
 
 
+def test_global_alignment_of_k3_sized_frames_against_the_oracle(gpu, oracle):
+    """The hole round 5 fell through: at K3 size the pruned transforms and the packed pair windows sum 926 and 132 terms per output, and
+    with one running fp32 sum each the pair shifts drifted from 1.5e-6 to 7.9e-4 px of the oracle without any test noticing (every oracle
+    test ran on frames of at most 1240 rows at 2e-3 px).  Three 4092 x 5760 frames of the bench's kind (int8 counts of a smooth field under
+    drift and a growing dilation; tools/diag_fa_precision.py makes them) against ProgMovieAlignmentCorrelation<double>'s arithmetic:
+    1e-4 px (measured with the sums in blocks, round 6: 3.5e-5; with full-length transforms and full inverse transforms per pair: 2.0e-5)."""
+    xa, ctx, torch = gpu
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from diag_fa_precision import k3_frames
+    frames, drift = k3_frames(torch, torch.device("cuda", 0))
+    Y, X = frames.shape[1:]
+    exp = oracle.fa_global_alignment(frames.cpu().numpy(), Ts=1.0, max_shift_px=50.0, max_res=30.0)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 30.0)
+    assert fa.new_dims == exp["new_dims"]
+    got = fa.global_alignment(frames, 50.0)
+    assert got["ref"] == exp["ref"]
+    assert np.abs(got["bX"] - exp["bX"]).max() <= 1e-4 and np.abs(got["bY"] - exp["bY"]).max() <= 1e-4
+    assert np.abs(got["shiftX"] - exp["shiftX"]).max() <= 1e-4 and np.abs(got["shiftY"] - exp["shiftY"]).max() <= 1e-4
+    # every pair through the full inverse transform: the same to 5e-5
+    fa.set_option("window", 0)
+    full = fa.global_alignment(frames, 50.0)
+    assert np.abs(full["bX"] - got["bX"]).max() <= 5e-5 and np.abs(full["bY"] - got["bY"]).max() <= 5e-5
+
+
 def test_local_alignment_of_a_k3_movie(gpu, oracle):
     """BASELINE config 5 on the path it names: 40 frames of 4092 x 5760 (K3), the program's defaults -- 12 x 9 patches of 500 px
     (ceil(size / 500), movie_alignment_correlation_base.cpp:218-224), 3 frames per patch, 6 x 6 x 5 control points, 30 A at 1 A/px --
