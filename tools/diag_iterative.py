@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where xh_iterative_alignment and the oracle's chain part ways: per order (RS / SR) and per number of rounds, the
+"""(needs a library built with XH_DEBUG_HOOKS=1 xmipp3_amd/csrc/build.sh: the XH_ES_ORDER hook is not in the product build)
+Where xh_iterative_alignment and the oracle's chain part ways: per order (RS / SR) and per number of rounds, the
 images whose pose differs, and whether the two orders' merits of such an image are within float rounding of each other (then the final
 "better merit" choice is a coin toss between two valid poses).  Run on the GPU box: python3 tools/diag_iterative.py"""
 import os, sys, subprocess, json

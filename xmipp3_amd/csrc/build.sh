@@ -4,6 +4,8 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result"
+# XH_DEBUG_HOOKS=1: the A/B and test knobs of xh_common.h (environment variables, wrong-by-design experiment options) compiled in
+[ -n "$XH_DEBUG_HOOKS" ] && COMMON="$COMMON -DXH_DEBUG_HOOKS"
 mkdir -p build
 pids=()
 # geometry of the gridding must round like the reference's scalar code: no FMA contraction

@@ -537,7 +537,7 @@ k_pm_prefilter_rec64_2d(const TIN *__restrict__ in, double *__restrict__ out, in
 // (k_pm_prefilter_fir2d); XH_PREFILTER_FORM in the environment picks for A/B runs
 static inline int xh_prefilter_form()
 {
-    static const int form = [] { const char *e = getenv("XH_PREFILTER_FORM"); return e ? atoi(e) : 1; }();
+    static const int form = [] { const char *e = xh_debug_env("XH_PREFILTER_FORM"); return e ? atoi(e) : 1; }();
     return form;
 }
 

@@ -59,6 +59,20 @@ int xh_fft2d_user_scratch(xh_fft2d *f, size_t bytes, void **p);
 int xh_fft2d_rows_of_real_pairs(xh_fft2d *f, const float *d_frame, const float *d_dark, const float *d_gain, int Y, float *d_work, int *n1, int *n2);
 int xh_fft2d_rows_of_real_pairs_kept(xh_fft2d *f, const float *d_frame, const float *d_dark, const float *d_gain, int Y, int nc, float *d_C, int *done);
 
+// A/B and test knobs read from the environment (XH_FA_PB, XH_FA_COPY_PATCHES, XH_FA_WARP_PLAIN, XH_PREFILTER_FORM, XH_FFT2D_NO_SMALL,
+// XH_FFT2D_N1, XH_FFT2D_NO_45: other correct forms of a kernel; XH_ES_ORDER: one half of xh_iterative_alignment's compute(), a WRONG
+// result by design, for tools/diag_iterative.py) exist only in a library built with -DXH_DEBUG_HOOKS (XH_DEBUG_HOOKS=1 csrc/build.sh);
+// the product build never looks at them.  XH_ALLOC_TRACE and XH_FA_TIMING only print.
+static inline const char *xh_debug_env(const char *name)
+{
+#ifdef XH_DEBUG_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 static inline int xh_ilog2(int n)
 {
     int l = 0;

@@ -695,7 +695,7 @@ int xh_iterative_alignment(xh_ctx *ctx, const float *d_ref, const float *d_other
     };
     std::vector<float> pRS, mRS, pSR, mSR;
     // test hook (tools/diag_iterative.py): XH_ES_ORDER=RS / SR returns that half of compute() alone
-    const char *only = getenv("XH_ES_ORDER");
+    const char *only = xh_debug_env("XH_ES_ORDER");
     if (rc == XH_OK) rc = pass(!(only && !strcmp(only, "SR")), pRS, mRS);
     if (only) { pSR = pRS; mSR = mRS; }
     else if (rc == XH_OK) rc = pass(false, pSR, mSR);

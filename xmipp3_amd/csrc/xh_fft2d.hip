@@ -397,10 +397,10 @@ int axis_create(xh_ctx *ctx, int n, Axis &A)
     // an odd factor of at most 64 points times a power of two: the odd part directly, the rest by the radix kernels
     int odd = n, p2 = 1;
     while ((odd & 1) == 0) { odd >>= 1; p2 <<= 1; }
-    if (odd > 1 && odd <= 64 && p2 >= 2 && direct_ok(p2) && !getenv("XH_FFT2D_NO_SMALL")) { A.n1 = odd; A.n2 = p2; A.small1 = true; }
+    if (odd > 1 && odd <= 64 && p2 >= 2 && direct_ok(p2) && !xh_debug_env("XH_FFT2D_NO_SMALL")) { A.n1 = odd; A.n2 = p2; A.small1 = true; }
     else {
         XH_CHECK(factorise(n, A.n1, A.n2), XH_ERR_UNSUPPORTED, "xh_fft2d: %d has no factorisation into two LDS-sized line lengths", n);
-        if (const char *f = getenv("XH_FFT2D_N1")) {              // A/B runs: force the first factor
+        if (const char *f = xh_debug_env("XH_FFT2D_N1")) {              // A/B runs: force the first factor
             const int a = atoi(f);
             if (a >= 2 && n % a == 0 && direct_ok(a) && direct_ok(n / a)) { A.n1 = a; A.n2 = n / a; }
         }
@@ -526,7 +526,7 @@ int xh_fft2d_rows_of_real_pairs(xh_fft2d *f, const float *d_frame, const float *
     XH_HIP(hipSetDevice(ctx->device));
     const size_t nlines = (size_t)f->ny * A.n2;
     const size_t smem = sizeof(xh_cf) * ((size_t)A.n1 * 128 + A.n1);
-    if (A.n1 == 45 && !getenv("XH_FFT2D_NO_45"))
+    if (A.n1 == 45 && !xh_debug_env("XH_FFT2D_NO_45"))
         hipLaunchKernelGGL(k_fft2d_45_pairs, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, ctx->stream, d_frame, d_dark, d_gain, Y, f->nx, (xh_cf *)d_work,
                            (const xh_cf *)A.tw.p, A.n2, nlines);
     else
@@ -545,7 +545,7 @@ int xh_fft2d_rows_of_real_pairs_kept(xh_fft2d *f, const float *d_frame, const fl
     XH_CHECK(f && d_frame && d_C && done && (Y + 1) / 2 == f->ny, XH_ERR_ARG, "xh_fft2d_rows_of_real_pairs_kept: bad argument");
     *done = 0;
     const Axis &A = f->ax;
-    if (A.n2 != 128 || !A.small1 || A.n1 != 45 || nc < 1 || nc > 720 || getenv("XH_FFT2D_NO_45")) return XH_OK;
+    if (A.n2 != 128 || !A.small1 || A.n1 != 45 || nc < 1 || nc > 720 || xh_debug_env("XH_FFT2D_NO_45")) return XH_OK;
     xh_ctx *ctx = f->ctx;
     XH_HIP(hipSetDevice(ctx->device));
     const int PL = (nc + 44) / 45;

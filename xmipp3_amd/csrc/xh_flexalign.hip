@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ 
     const bool first = blockIdx.z == 0;
     // The sum over ky (926 terms on a K3 frame) in blocks of XH_FA_SUMBLK terms, the block sums added up separately: a running fp32
     // sum of n terms carries ~n/2 roundings of the SUM's magnitude, blocks carry XH_FA_SUMBLK / 2 of a block sum's + n / XH_FA_SUMBLK
-    // of the total's (round 5's one-accumulator form read 8e-4 px against the oracle on the bench's K3 frames where round 4's full
+    // of the total's (round 5's one-accumulator form read 8e-4 px against the double-precision CPU restatement on K3 frames where round 4's full
     // transforms had read 1.5e-6; RW more additions per block of 2 RW XH_FA_SUMBLK multiply-adds)
     fa_v2 acc[RW], tot[RW];
 #pragma unroll
@@ -1970,9 +1970,9 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     // PB patches at a time: the pair kernel has one wave per frame pair, the second product one workgroup per patch frame -- a single patch (780
     // waves, 40 workgroups for 40 frames) leaves most of the device idle; 36 (three launches for the 108 patches of a K3 movie) against
     // 16: local alignment 18.5 -> 17.5 ms per movie
-    static const int pbEnv = getenv("XH_FA_PB") ? atoi(getenv("XH_FA_PB")) : 0;        // A/B runs
+    static const int pbEnv = xh_debug_env("XH_FA_PB") ? atoi(xh_debug_env("XH_FA_PB")) : 0;        // A/B runs
     const int PB = std::min(nP, pbEnv > 0 ? pbEnv : 36);
-    static const bool copyPatchesEnv = getenv("XH_FA_COPY_PATCHES") != nullptr;
+    static const bool copyPatchesEnv = xh_debug_env("XH_FA_COPY_PATCHES") != nullptr;
     if (rc == XH_OK) rc = fa_scratch(h, "l_patch", (h->use_mfma && !copyPatchesEnv) ? 16 : sizeof(float) * (size_t)PB * N * PY * PX, &pPatch);      // the fused product reads the frames
     if (rc == XH_OK) rc = fa_scratch(h, "l_T", sizeof(fa_cf) * (size_t)PB * N * PY * cxh, &pT);
     if (rc == XH_OK) rc = fa_scratch(h, "l_single", sizeof(fa_cf) * (size_t)PB * N * E, &pSingle);
@@ -1988,7 +1988,7 @@ int xh_fa_local_alignment(xh_fa *h, const float *d_frames, int32_t N, const floa
     for (int p0 = 0; p0 < nP && rc == XH_OK; p0 += PB) {
         const int pb = std::min(PB, nP - p0), nf = pb * N;
         const size_t tot = (size_t)nf * PY * PX;
-        static const bool copyPatches = getenv("XH_FA_COPY_PATCHES") != nullptr;        // A/B runs
+        static const bool copyPatches = xh_debug_env("XH_FA_COPY_PATCHES") != nullptr;        // A/B runs
         const bool fused = h->use_mfma && !copyPatches;
         if (!fused)
             hipLaunchKernelGGL(k_fa_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, d_dark, d_gain, (const int *)bOffs.p + (size_t)p0 * N * 2,
@@ -2188,7 +2188,7 @@ int xh_fa_apply_bspline(xh_fa *h, const float *d_frame, const float *d_dark, con
         // hX, hY, tPos in float on the host like applyBSplineTransform (cuda_gpu_geo_transformer.cpp:206-210)
         const float hX = (lX == 3) ? (float)X : (X / (float)(lX - 3)), hY = (lY == 3) ? (float)Y : (Y / (float)(lY - 3)), hT = (lT == 3) ? (float)N : (N / (float)(lT - 3));
         const float tPos = n / hT;
-        static const bool plain = getenv("XH_FA_WARP_PLAIN") != nullptr;        // A/B runs
+        static const bool plain = xh_debug_env("XH_FA_WARP_PLAIN") != nullptr;        // A/B runs
         // dynamic LDS of the two forms: four layers of quads (16 bytes per control row and first column, both fields) or of plain control
         // points; a control grid whose quads do not fit 64 KB takes the plain kernel, one that fits neither is refused
         const size_t ldsQuads = sizeof(float4) * 2 * 4 * (size_t)(lX - 3) * lY, ldsPlain = sizeof(float) * 2 * 4 * (size_t)lX * lY;

@@ -834,6 +834,10 @@ k_pm_contract_mfma(const float4 *__restrict__ Apack, const float4 *__restrict__ 
     // (everything the copy instructions take through scalar registers is made wave-uniform for the compiler's benefit)
     const int wvq = __builtin_amdgcn_readfirstlane(wv % QT), qtileU = __builtin_amdgcn_readfirstlane(qtile);
     const int ptileU = __builtin_amdgcn_readfirstlane(min(ptile0, nptiles - 1));
+    // (M0 carries the LDS address of a copy.  It is a reserved register of the AMDGPU back end -- the compiler writes it right before every use
+    // it generates and keeps no value in it across instructions -- and naming it as a clobber is refused: "inline asm clobber list contains
+    // reserved registers: m0 [-Winline-asm] ... clobbering them may lead to undefined behaviour"; the clobber lists name memory only, as in
+    // xg_dma_patch, xh_rf_grid.h.  ADVICE r05.)
     auto issueStage = [&](int st) {
         const unsigned buf = sBase + (unsigned)(st & 1) * (unsigned)(STAGE_F4 * 16);
         const unsigned off = (unsigned)lane * 16u;

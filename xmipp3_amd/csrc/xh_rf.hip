@@ -1524,7 +1524,14 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
         rf->unit_z = (int)value;
     }
     else if (!strcmp(name, "grid_waves")) rf->grid_waves = (int)value;
-    else if (!strcmp(name, "grid_tile_budget")) rf->grid_tile_budget = std::max(-1, (int)value);     // (-1: experiment, every interior visit reuses the previous queue: timing only)
+    else if (!strcmp(name, "grid_tile_budget")) {
+#ifdef XH_DEBUG_HOOKS
+        rf->grid_tile_budget = std::max(-1, (int)value);     // (-1: experiment, every interior visit reuses the previous queue: timing only, WRONG volume)
+#else
+        XH_CHECK(value >= 0, XH_ERR_ARG, "xh_rf_set_option: grid_tile_budget -1 (timing experiment with a wrong volume) needs a library built with XH_DEBUG_HOOKS");
+        rf->grid_tile_budget = (int)value;
+#endif
+    }
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
     else if (!strcmp(name, "order_spaces")) rf->order_spaces = (int)value;
