@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--nrefs", type=int, default=1000)
+    ap.add_argument("--s6-eps", type=float, default=-1, help=">= 0: xh_pm_set_option s6_eps (0: no fp64 repeats, whose kernels do not fit beside the gridding kernel)")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -49,6 +50,8 @@ def main():
     parts = (refs[idx] + math.sqrt(10.0) * torch.randn((B, D, D), generator=gen, device=dev)).contiguous()
     pm = xa.ProjectionMatcher(ctx, refs)
     refno, psi, flip = pm.match(parts)
+    if args.s6_eps >= 0:
+        pm.set_option("s6_eps", args.s6_eps)
     rng = np.random.default_rng(1)
     ctf_arr = xa.RecFourier.ctf_param_array([ctf_params(kV=300.0, Cs=2.7, Q0=0.07, K=1.0, DeltafU=float(d), DeltafV=float(d)) for d in rng.uniform(1e4, 3e4, B)])
     ang = torch.cat([torch.from_numpy(np.ascontiguousarray(dirs[:, :2])).to(dev)[refno.long()], (psi.double() * (360.0 / pm.N))[:, None]], 1).contiguous()
@@ -83,8 +86,9 @@ def main():
             both = timed(s6, grid)
             bothm = timed(match, grid)
             both2 = timed(lambda: (s6(), s6(), s6(), s6()), grid)
+            s4 = timed(lambda: (s6(), s6(), s6(), s6()), None)
             print(f"grid_waves {waves:2d}: insert_images alone {g[2]:6.2f} ms | S6 alone {s[1]:5.2f} | match alone {m[1]:5.2f} | together with S6: wall {both[0]:6.2f} (S6 {both[1]:5.2f}, insert {both[2]:6.2f}) | "
-                  f"with 4 x S6: wall {both2[0]:6.2f} (S6s {both2[1]:6.2f}, insert {both2[2]:6.2f}) | with match: wall {bothm[0]:6.2f} (match {bothm[1]:6.2f}, insert {bothm[2]:6.2f})", flush=True)
+                  f"4 x S6 alone {s4[1]:6.2f}, beside insert: wall {both2[0]:6.2f} (S6s {both2[1]:6.2f}, insert {both2[2]:6.2f}) | with match: wall {bothm[0]:6.2f} (match {bothm[1]:6.2f}, insert {bothm[2]:6.2f})", flush=True)
         with torch.cuda.stream(side):
             rf.close() if hasattr(rf, "close") else None
             del rf

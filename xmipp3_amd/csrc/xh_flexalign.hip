@@ -93,7 +93,9 @@ __global__ void __launch_bounds__(256) k_fa_pair(const fa_cf *__restrict__ A, co
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= tot) return;
     const fa_cf a = A[t], b = Bs[t];
-    P[t] = fa_cf{(a.x * b.x + a.y * b.y) * scale, (a.y * b.x - a.x * b.y) * scale};
+    // element 0 is the mean of the correlation map, which bestShift subtracts again (statisticsAdjust) and which is orders of magnitude
+    // above every other coefficient: left at zero, the inverse transform rounds at the signal's magnitude instead of the mean's
+    P[t] = t == 0 ? fa_cf{0.f, 0.f} : fa_cf{(a.x * b.x + a.y * b.y) * scale, (a.y * b.x - a.x * b.y) * scale};
 }
 
 // Two real rows per complex row: row 2r in the real part, row 2r+1 in the imaginary part (one transform along x for both)
@@ -159,11 +161,14 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_a(const fa_cf *__restrict__ 
         const float wgt = (kx == 0 || 2 * kx == nX) ? 1.f : 2.f;
         for (int ky = 0; ky < nY; ++ky) {
             const fa_cf p = Sa[(size_t)ky * nX + kx], q = Sb[(size_t)ky * nX + kx];
-            const float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
+            float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
             if (first) {
                 if (ky == 0 && kx == 0) c0 = pr;
                 else ss += wgt * (pr * pr + pi * pi);
             }
+            // The mean of the map (its (0, 0) coefficient) stays out of the window: bestShift subtracts it again (statisticsAdjust), and it
+            // is orders of magnitude above everything else -- summed in, every later term is rounded at ITS magnitude (k_fa_pairwin_b)
+            if (ky == 0 && kx == 0) { pr = 0.f; pi = 0.f; }
             const fa_cf *w = twY + (size_t)ky * wy + yy0;
 #pragma unroll
             for (int r = 0; r < RW; ++r)
@@ -186,7 +191,6 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_a(const fa_cf *__restrict__ 
 // The same, one wave per workgroup, RW rows per thread out of a table padded to whole groups of RW rows (zeros beyond wy): no
 // conditions inside the loop, the RW factors of a ky are wave-uniform and arrive by scalar loads, and every complex multiply-add is two
 // packed fused multiply-adds (v_pk_fma_f32): (re, im) += (pr, pr) (tx, ty); (re, im) += (-pi, pi) (ty, tx).
-#define XH_FA_SUMBLK 32
 template <int RW>
 __global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ S, int N, int nY, int nX, const fa_v2 *__restrict__ twYp, int wy, int wyp,
                                                       fa_cf *__restrict__ U, double *__restrict__ stat)
@@ -201,46 +205,34 @@ __global__ void __launch_bounds__(64) k_fa_pairwin_a2(const fa_cf *__restrict__ 
     const fa_cf *Sa = S + (size_t)a * small + kxc, *Sb = S + (size_t)b * small + kxc;
     const int yy0 = blockIdx.z * RW;
     const bool first = blockIdx.z == 0;
-    // The sum over ky (926 terms on a K3 frame) in blocks of XH_FA_SUMBLK terms, the block sums added up separately: a running fp32
-    // sum of n terms carries ~n/2 roundings of the SUM's magnitude, blocks carry XH_FA_SUMBLK / 2 of a block sum's + n / XH_FA_SUMBLK
-    // of the total's (round 5's one-accumulator form read 8e-4 px against the double-precision CPU restatement on K3 frames where round 4's full
-    // transforms had read 1.5e-6; RW more additions per block of 2 RW XH_FA_SUMBLK multiply-adds)
-    fa_v2 acc[RW], tot[RW];
+    fa_v2 acc[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) tot[r] = fa_v2{0.f, 0.f};
+    for (int r = 0; r < RW; ++r) acc[r] = fa_v2{0.f, 0.f};
     float ss = 0.f, c0 = 0.f;
     const float wgt = (kx == 0 || 2 * kx == nX) ? 1.f : 2.f;
     const fa_v2 *w = twYp + yy0;
-    for (int kb = 0; kb < nY; kb += XH_FA_SUMBLK) {
-#pragma unroll
-        for (int r = 0; r < RW; ++r) acc[r] = fa_v2{0.f, 0.f};
-        const int ke = min(nY, kb + XH_FA_SUMBLK);
-        float sb = 0.f;
-        for (int ky = kb; ky < ke; ++ky, w += wyp) {
-            const fa_cf p = Sa[(size_t)ky * nX], q = Sb[(size_t)ky * nX];
-            const float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
-            if (first) {
-                if (ky == 0) c0 = pr;
-                else sb += wgt * (pr * pr + pi * pi);
-                if (ky == 0 && kx != 0) sb += wgt * (pr * pr + pi * pi);
-            }
-            const fa_v2 vr = fa_v2{pr, pr}, vi = fa_v2{-pi, pi};
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const fa_v2 t = w[r];
-                acc[r] = __builtin_elementwise_fma(vr, t, acc[r]);
-                acc[r] = __builtin_elementwise_fma(vi, fa_v2{t.y, t.x}, acc[r]);
-            }
+    for (int ky = 0; ky < nY; ++ky, w += wyp) {
+        const fa_cf p = Sa[(size_t)ky * nX], q = Sb[(size_t)ky * nX];
+        float pr = p.x * q.x + p.y * q.y, pi = p.y * q.x - p.x * q.y;
+        if (first) {
+            if (ky == 0) c0 = pr;
+            else ss += wgt * (pr * pr + pi * pi);
+            if (ky == 0 && kx != 0) ss += wgt * (pr * pr + pi * pi);
         }
-        ss += sb;
+        if (ky == 0 && kx == 0) { pr = 0.f; pi = 0.f; }     // the map's mean stays out of the window (see k_fa_pairwin_a)
+        const fa_v2 vr = fa_v2{pr, pr}, vi = fa_v2{-pi, pi};
 #pragma unroll
-        for (int r = 0; r < RW; ++r) tot[r] += acc[r];
+        for (int r = 0; r < RW; ++r) {
+            const fa_v2 t = w[r];
+            acc[r] = __builtin_elementwise_fma(vr, t, acc[r]);
+            acc[r] = __builtin_elementwise_fma(vi, fa_v2{t.y, t.x}, acc[r]);
+        }
     }
     if (kx < nxh) {
         fa_cf *u = U + ((size_t)blockIdx.y * wy + yy0) * nxh + kx;
 #pragma unroll
         for (int r = 0; r < RW; ++r)
-            if (yy0 + r < wy) u[(size_t)r * nxh] = fa_cf{tot[r].x, tot[r].y};
+            if (yy0 + r < wy) u[(size_t)r * nxh] = fa_cf{acc[r].x, acc[r].y};
     }
     if (first) {
         if (kx >= nxh) ss = 0.f;
@@ -261,34 +253,26 @@ __global__ void __launch_bounds__(64) k_fa_small_dft(const fa_v2 *__restrict__ i
     const int col = blockIdx.x * 64 + threadIdx.x, colc = min(col, ncols - 1);
     in += inZ0 * blockIdx.y + inZ1 * blockIdx.z + colc;
     W += wZ0 * blockIdx.y;
-    // (sums of more than 16 terms in blocks of 16, see k_fa_pairwin_a2)
-    fa_v2 acc[JP], tot[JP];
+    fa_v2 acc[JP];
 #pragma unroll
-    for (int j = 0; j < JP; ++j) tot[j] = fa_v2{0.f, 0.f};
-    for (int i0 = 0; i0 < I; i0 += 16) {
-#pragma unroll
-        for (int j = 0; j < JP; ++j) acc[j] = fa_v2{0.f, 0.f};
-        const int ie = min(I, i0 + 16);
+    for (int j = 0; j < JP; ++j) acc[j] = fa_v2{0.f, 0.f};
 #pragma unroll 2
-        for (int i = i0; i < ie; ++i) {
-            const fa_v2 t = in[(size_t)i * inI];
-            const fa_v2 vr = fa_v2{t.x, t.x}, vi = fa_v2{-t.y, t.y};
-            const fa_v2 *w = W + (size_t)i * JP;
+    for (int i = 0; i < I; ++i) {
+        const fa_v2 t = in[(size_t)i * inI];
+        const fa_v2 vr = fa_v2{t.x, t.x}, vi = fa_v2{-t.y, t.y};
+        const fa_v2 *w = W + (size_t)i * JP;
 #pragma unroll
-            for (int j = 0; j < JP; ++j) {
-                const fa_v2 f = w[j];
-                acc[j] = __builtin_elementwise_fma(vr, f, acc[j]);
-                acc[j] = __builtin_elementwise_fma(vi, fa_v2{f.y, f.x}, acc[j]);
-            }
+        for (int j = 0; j < JP; ++j) {
+            const fa_v2 f = w[j];
+            acc[j] = __builtin_elementwise_fma(vr, f, acc[j]);
+            acc[j] = __builtin_elementwise_fma(vi, fa_v2{f.y, f.x}, acc[j]);
         }
-#pragma unroll
-        for (int j = 0; j < JP; ++j) tot[j] += acc[j];
     }
     if (col >= ncols) return;
     out += outZ0 * blockIdx.y + outZ1 * blockIdx.z + col;
 #pragma unroll
     for (int j = 0; j < JP; ++j)
-        if (j < J) out[(size_t)j * outJ] = tot[j];
+        if (j < J) out[(size_t)j * outJ] = acc[j];
 }
 
 // sum and sum of squares of the correlation map (real part of the inverse transform), one partial per block
@@ -396,12 +380,10 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ 
         for (int yb = 0; yb < wy; yb += 16 * G) {
             const int yq = yb + grp * 16, nr = min(wy - yb, 16 * G);
             const bool act = grp < G && yq < wy;
-            float acc[16], tot[16];                 // (a chunk's sum apart from the total: see k_fa_pairwin_a2)
+            float acc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) tot[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             for (int k0 = 0; k0 < nxh; k0 += KC) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
                 __syncthreads();
                 for (int i = threadIdx.x; i < nr * KC; i += 256) {
                     const int rr = i / KC, kk = i - rr * KC;
@@ -423,13 +405,11 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ 
                         }
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tot[i] += acc[i];
             }
             if (act)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (yq + i < wy) W[(size_t)(yq + i) * wx + xx] = tot[i] * (float)dSize;
+                    if (yq + i < wy) W[(size_t)(yq + i) * wx + xx] = acc[i] * (float)dSize;
         }
     } else
     for (int o = threadIdx.x; o < wy * wx; o += 256) {
@@ -445,12 +425,13 @@ __global__ void __launch_bounds__(256) k_fa_pairwin_b(const fa_cf *__restrict__ 
         W[o] = acc * (float)dSize;
     }
     __syncthreads();
-    const double avg = dSize * stat[2 * blockIdx.x];
+    // statisticsAdjust(0, 1): (value - mean) / sd.  The window was summed WITHOUT the map's mean (the (0, 0) coefficient was left out by
+    // k_fa_pairwin_a / a2; stat[0] still holds it), so there is nothing left to subtract
     const double sd = dSize * sqrt(stat[2 * blockIdx.x + 1]);
-    double a = 0, b = 0;
-    if (sd != 0) { a = 1.0 / sd; b = -avg * a; }
+    double a = 0;
+    if (sd != 0) a = 1.0 / sd;
     const int starty = -(nY / 2), startx = -(nX / 2), finy = starty + nY - 1, finx = startx + nX - 1;
-    auto val = [&](int i, int j) { return a * (double)W[(size_t)(i + hy) * wx + (j + hx)] + b; };
+    auto val = [&](int i, int j) { return a * (double)W[(size_t)(i + hy) * wx + (j + hx)]; };
     const int w = 2 * maxShift + 1;
     double best = -1.79769313486231570815e+308;
     int bestIdx = 0x7fffffff;
