@@ -1006,6 +1006,20 @@ def main():
                     roofline["traffic"] = tj["traffic_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/traffic_k_rf_grid.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                     roofline["traffic_stale"] = tj.get("library_source_sha16") != lib_sha
+            # What the formulation itself can reach (the kernel is closed, its ceiling printed beside the HBM fraction):
+            # the USEFUL arithmetic of a launch -- a (voxel, pixel) pair inside the blob is three multiply-adds (re, im, weight) -- against
+            # the fp32 vector peak.  A slab voxel has pi rho^2 pixels within reach, rho^2 = r^2 - z^2, z uniform in [-r, r]: 2 pi r^2 / 3.
+            r_blob = 1.9
+            pairs = B * nvox * (2.0 * math.pi * r_blob * r_blob / 3.0)
+            roofline["arithmetic"] = {
+                "useful_pairs_per_launch": pairs, "useful_flops_per_launch": 6.0 * pairs,
+                "achieved_TFLOPs": 6.0 * pairs / (k_ms / max(1, k_launches) * 1e-3) / 1e12, "fp32_vector_peak_TFLOPs": 157.3,
+                "frac": 6.0 * pairs / (k_ms / max(1, k_launches) * 1e-3) / 1e12 / 157.3,
+                "what": "useful tap multiply-adds of a launch / fp32 vector peak.  The kernel issues ~43 lane-instructions per useful (voxel, pixel) pair "
+                        "(profiles/pmc_k_rf_grid.json: SQ_INSTS_VALU x 64 / pairs) where the three multiply-adds are 2 (one packed): every tap slot of the "
+                        "4 x 4 footprint pays distance, table index, compare + select, convert, shift and the table read whether the pixel lies inside the "
+                        "blob or not (47 % do), batches are 67 % full, and the reference's float expressions are kept operation for operation so that the "
+                        "voxel sets and table entries stay the reference's -- that, not HBM, is the ceiling of this formulation (DESIGN.md 5)"}
             # the kernel's own bound is not HBM: vector issue and the LDS pipeline, from the committed PMC passes
             # of tools/pmc_grid.sh over the same 4096-projection launch (counters cannot be read from inside the process)
             pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_k_rf_grid.json")
@@ -1014,6 +1028,7 @@ def main():
                 c = {k_: v_["mean"] for k_, v_ in pj["counters_per_dispatch"].items()}
                 if all(k_ in c for k_ in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")):
                     cyc = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the eight XCDs
+                    roofline["arithmetic"]["lane_instructions_per_useful_pair"] = 64.0 * c["SQ_INSTS_VALU"] / pairs
                     roofline["second_bound"] = {
                         "bound": "vector issue + LDS pipeline", "kernel_cycles": cyc,
                         "valu_instructions_per_launch": c["SQ_INSTS_VALU"],

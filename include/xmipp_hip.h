@@ -489,6 +489,10 @@ int xh_movie_dose_filter(xh_ctx *ctx, xh_fft2d *plan, float *d_frame, int32_t Y,
 int xh_movie_bin_frame(xh_ctx *ctx, xh_fft2d *planRaw, xh_fft2d *planBinned, const float *d_frame, const float *d_dark, const float *d_gain, int32_t Y,
                        int32_t X, float *d_out, int32_t Yb, int32_t Xb);
 
+/* The top-left cropY x cropX window of N frames of Y x X floats, frame after frame (getCroppedFrame,
+ * reconstruction_adapt_cuda/movie_alignment_correlation_gpu.cpp:727-734: the CUDA program correlates frames cropped to an
+ * FFT-friendly size, findGoodCropSize :73-88).  d_dst: N x cropY x cropX floats. */
+int xh_movie_crop_frames(xh_ctx *ctx, const float *d_src, int32_t N, int32_t Y, int32_t X, int32_t cropY, int32_t cropX, float *d_dst);
 /* A frame as the detector stores it -> float32 on the device: the cast Image<float>::read does on the host while it reads
  * (xmippCore rwMRC / castPage2T; the movie programs read through it, reconstruction/movie_alignment_correlation_base.cpp:262-266,
  * movie_alignment_correlation_gpu.cpp:667-691), moved behind the host copy so that counts cross the link, not floats.  mode: the MRC

@@ -592,6 +592,45 @@ def test_cli_movie_global_alignment(bins, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_movie_size_search_stand_in(bins, tmp_path, oracle):
+    """--sizeSearch smooth: the deterministic stand-in for the CUDA program's search of FFT-friendly sizes (findGoodCropSize /
+    findGoodPatchSize, movie_alignment_correlation_gpu.cpp:73-121 -- they time cuFFT plans on the installed card).  Frames of 200 x 262:
+    262 = 2 x 131 -> the global alignment runs on the top-left 200 x 256 window (getCroppedFrame, :727-734), which is what the oracle gets;
+    patches of 100 px stay (100 = 2^2 5^2), patches of 110 px grow to 112 = 2^4 7."""
+    from tests.test_gpu_flexalign import synthetic_movie
+    N, Y, X = 6, 200, 262
+    frames, drift = synthetic_movie(N, Y, X, seed=23)
+    rng = np.random.default_rng(4)
+    dark = (0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    gain = (1.0 + 0.05 * rng.standard_normal((Y, X))).astype(np.float32)
+    xmipp_io.write_stack(str(tmp_path / "movie.stk"), frames)
+    xmipp_io.write_stack(str(tmp_path / "dark.stk"), dark[None])
+    xmipp_io.write_stack(str(tmp_path / "gain.stk"), gain[None])
+    prog = os.path.join(bins, "xmipp_movie_alignment_correlation")
+    common = [prog, "-i", str(tmp_path / "movie.stk"), "--sampling", "1.25", "--maxShift", "25", "--maxResForCorrelation", "10",
+              "--dark", f"1@{tmp_path}/dark.stk", "--gain", f"1@{tmp_path}/gain.stk"]
+    r = _run(common + ["-o", str(tmp_path / "out.xmd"), "--skipLocalAlignment", "--sizeSearch", "smooth"])
+    assert r.returncode == 0, r.stderr
+    assert "global alignment on the top-left 256 x 200 of 262 x 200" in r.stdout
+    exp = oracle.fa_global_alignment(frames[:, :200, :256], Ts=1.25, max_shift_px=25.0 / 1.25, max_res=10.0, dark=dark[:200, :256], igain=gain[:200, :256])
+    whole = oracle.fa_global_alignment(frames, Ts=1.25, max_shift_px=25.0 / 1.25, max_res=10.0, dark=dark, igain=gain)
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"), block="frameShifts")
+    c = {l: i for i, l in enumerate(labels)}
+    got = np.array([[float(row[c["shiftX"]]), float(row[c["shiftY"]])] for row in rows])
+    assert np.abs(got[:, 0] + exp["shiftX"]).max() < 3e-3 and np.abs(got[:, 1] + exp["shiftY"]).max() < 3e-3
+    # ... and that is not what the whole frames give (the flag did something), while both see the same drift
+    assert max(np.abs(got[:, 0] + whole["shiftX"]).max(), np.abs(got[:, 1] + whole["shiftY"]).max()) > 1e-3
+    assert np.abs(exp["shiftX"] - whole["shiftX"]).max() < 0.5
+    # patch sizes: 100 px stays, 110 px grows to 112
+    for res, size in ((125, 100), (138, 112)):
+        r = _run(common + ["-o", str(tmp_path / f"loc{res}.xmd"), "--sizeSearch", "smooth", "--minLocalRes", str(res), "--patches", "4", "4", "--controlPoints", "3", "3", "3"])
+        assert r.returncode == 0, r.stderr
+        assert f"patches of {size} px" in r.stdout and f"of {size} x {size} px" in r.stdout
+    r = _run(common + ["-o", str(tmp_path / "x.xmd"), "--sizeSearch", "fastest"])
+    assert r.returncode != 0 and "--sizeSearch" in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_movie_sum_range_inside_the_alignment_range(bins, tmp_path, oracle):
     """--frameRangeSum inside --frameRange (movie_alignment_correlation_gpu.cpp:519-541): frame fi of the aligned movie lands in slot
     fi - nfirst + 1 of --oaligned, the stack is nlastSum - nfirst + 1 images long and the slots before the first summed frame stay

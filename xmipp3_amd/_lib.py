@@ -109,6 +109,7 @@ SIGNATURES = {
     "xh_rotation_estimate": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "xh_movie_dose_filter": (C.c_int, [vp, vp, vp, i32, i32, d, d, d, d]),
     "xh_movie_bin_frame": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32]),
+    "xh_movie_crop_frames": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "xh_movie_frame_to_float": (C.c_int, [vp, vp, i32, C.c_int64, vp]),
     "xh_fa_correlate": (C.c_int, [vp, vp, i32, i32, i32, C.c_float, vp]),
     "xh_fa_local_from_global": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -2288,6 +2288,15 @@ __global__ void __launch_bounds__(256) k_bin_crop(const fa_cf *__restrict__ F, f
 // -> float32, the cast of Image<float>::read (xmippCore castPage2T) done after the host copy instead of before it: a K3 frame crosses
 // the link as 23.6 MB of counts instead of 94 MB of floats.  A thread converts 16 bytes of input.
 namespace {
+__global__ void __launch_bounds__(256) k_movie_crop(const float *__restrict__ src, float *__restrict__ dst, int Y, int X, int cy, int cx, size_t tot)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= tot) return;
+    const size_t per = (size_t)cy * cx, n = t / per, r = t - n * per;
+    const int y = (int)(r / cx), x = (int)(r - (size_t)y * cx);
+    dst[t] = src[(n * Y + y) * (size_t)X + x];
+}
+
 template <typename TIN>
 __global__ void __launch_bounds__(256) k_frame_to_float(const TIN *__restrict__ in, float *__restrict__ out, size_t n)
 {
@@ -2309,6 +2318,16 @@ __global__ void __launch_bounds__(256) k_frame_to_float(const TIN *__restrict__ 
 }  // namespace
 
 extern "C" {
+
+int xh_movie_crop_frames(xh_ctx *ctx, const float *d_src, int32_t N, int32_t Y, int32_t X, int32_t cropY, int32_t cropX, float *d_dst)
+{
+    XH_CHECK(ctx && d_src && d_dst && N >= 1 && cropY >= 1 && cropX >= 1 && cropY <= Y && cropX <= X, XH_ERR_ARG, "xh_movie_crop_frames: bad argument");
+    XH_HIP(hipSetDevice(ctx->device));
+    const size_t tot = (size_t)N * cropY * cropX;
+    hipLaunchKernelGGL(k_movie_crop, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_src, d_dst, Y, X, cropY, cropX, tot);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+}
 
 int xh_movie_frame_to_float(xh_ctx *ctx, const void *d_raw, int32_t mode, int64_t n, float *d_out)
 {

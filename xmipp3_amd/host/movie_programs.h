@@ -24,6 +24,7 @@ public:
     int nfirst = -1, nlast = -1, nfirstSum = -1, nlastSum = -1, device = 0;
     int cpX = 6, cpY = 6, cpT = 5, patchesX = 0, patchesY = 0, patchesAvg = 3, minLocalRes = 500;
     bool skipLocalAlignment = false;
+    std::string sizeSearch = "off";
 
     // BSplineHelper::getShift (bspline_helper.cpp:104-148)
     void splineShift(const std::vector<double> &cX, const std::vector<double> &cY, int X, int Y, int N, int x, int y, int n, double &sx, double &sy) const
@@ -41,6 +42,20 @@ public:
                         sx += cX[o] * tmp; sy += cY[o] * tmp;
                     }
                 }
+    }
+
+    // --sizeSearch smooth.  What CudaFFT::findOptimal / cuFFTAdvisor (an external dependency, not in the reference tree) look for: sizes near
+    // the requested one whose prime factors are 2, 3, 5 and 7 -- below it when cropping, above it otherwise, within sigPercChange per cent
+    // (10 for the crop, 20 for patches; movie_alignment_correlation_gpu.cpp:80,95,112) -- of which they time the candidates on the card and
+    // keep the fastest.  The stand-in keeps the candidate nearest to the request (the largest below / the smallest above): no timing, the
+    // same answer on every machine.  Even sizes only (the correlation code halves them).
+    static size_t smoothSize(size_t n, int percent, bool crop)
+    {
+        auto smooth = [](size_t v) { for (size_t p : {2, 3, 5, 7}) while (v % p == 0) v /= p; return v == 1; };
+        const size_t lo = crop ? (size_t)std::ceil(n * (100 - percent) / 100.0) : n, hi = crop ? n : (size_t)std::floor(n * (100 + percent) / 100.0);
+        if (crop) { for (size_t v = hi & ~(size_t)1; v >= std::max<size_t>(lo, 2); v -= 2) if (smooth(v)) return v; }
+        else for (size_t v = (lo + 1) & ~(size_t)1; v <= hi; v += 2) if (smooth(v)) return v;
+        return n & ~(size_t)1;
     }
 
     void defineParams() override
@@ -68,6 +83,12 @@ public:
         addParamsLine("  [--minLocalRes <R=500>]      : Minimal resolution (in A) of patches during local alignment");
         addParamsLine("  [--patchesAvg <avg=3>]       : Number of near frames used for averaging a single patch");
         addParamsLine("  [--device <id=0>]            : HIP device");
+        addParamsLine("  [--sizeSearch <mode=off>]    : off: frames, patches and correlations at the sizes the parameters ask for (results depend on the");
+        addParamsLine("                               : inputs only).  smooth: a deterministic stand-in for the CUDA program's search of FFT-friendly sizes");
+        addParamsLine("                               : (findGoodCropSize / findGoodPatchSize, movie_alignment_correlation_gpu.cpp:73-121, time cuFFT plans on the");
+        addParamsLine("                               : installed card): the global alignment runs on the top-left window of the largest even size with prime");
+        addParamsLine("                               : factors 2, 3, 5, 7 within 10 % below the frame, the patches are the smallest such size within 20 % above");
+        addParamsLine("                               : the requested one");
         addExampleLine("xmipp_movie_alignment_correlation -i movie.xmd --oaligned alignedMovie.stk --oavg alignedMicrograph.mrc");
     }
 
@@ -93,6 +114,8 @@ public:
         nlastSum = (int)getIntParam("--frameRangeSum", 1);
         skipLocalAlignment = checkParam("--skipLocalAlignment");
         device = (int)getIntParam("--device");
+        sizeSearch = getParam("--sizeSearch");
+        if (sizeSearch != "off" && sizeSearch != "smooth") REPORT_ERROR(ERR_ARG_INCORRECT, "--sizeSearch is off or smooth");
         minLocalRes = (int)getIntParam("--minLocalRes");
         cpX = (int)getIntParam("--controlPoints", 0);
         cpY = (int)getIntParam("--controlPoints", 1);
@@ -150,13 +173,25 @@ public:
         }
         const size_t per = I.x * I.y, perRaw = Iraw.x * Iraw.y;
         // setNoOfPatches (:516-528), getRequestedPatchSize (base.h:217-219), checkSettings (:80-86)
-        const size_t reqPatch = (size_t)(minLocalRes / Ts);
+        size_t reqPatch = (size_t)(minLocalRes / Ts);
         if (patchesX <= 0 || patchesY <= 0) {
             patchesX = (int)std::ceil((float)I.x / (float)reqPatch);
             patchesY = (int)std::ceil((float)I.y / (float)reqPatch);
         }
         if (!skipLocalAlignment && (patchesX <= cpX || patchesY <= cpY))
             REPORT_ERROR(ERR_LOGIC_ERROR, "More control points than patches. Decrease the number of control points.");
+        // --sizeSearch smooth: the patch grows to an FFT-friendly size (findGoodPatchSize), the global alignment sees a cropped frame (findGoodCropSize)
+        size_t cropX = I.x, cropY = I.y;
+        if (sizeSearch == "smooth") {
+            const size_t want = reqPatch;
+            reqPatch = std::min(smoothSize(reqPatch, 20, false), std::min(I.x, I.y) & ~(size_t)1);
+            if (!doBin) {       // (the reference crops only when it does not bin, GAOptimize :601)
+                cropX = smoothSize(I.x, 10, true);
+                cropY = I.x == I.y ? cropX : smoothSize(I.y, 10, true);        // squareOnly for square frames
+            }
+            if (verbose) std::cout << "Size search (smooth): patches of " << reqPatch << " px (requested " << want << "), global alignment on the top-left "
+                                   << cropX << " x " << cropY << " of " << I.x << " x " << I.y << "\n";
+        }
         if (verbose) std::cout << "Computing global alignment ...\n";
         CtxGuard g;
         xhCheck(xh_ctx_create_private(device, &g.c));
@@ -245,6 +280,20 @@ public:
                 if (!gain.empty()) { d_gain.reserve(g.c, per * sizeof(float)); xhCheck(xh_memcpy_h2d(g.c, d_gain.p, gain.data(), per * sizeof(float))); }
             }
             const float *pd = (dark.empty() || doBin) ? nullptr : d_dark.as<float>(), *pg = (gain.empty() || doBin) ? nullptr : d_gain.as<float>();
+            if (cropX != I.x || cropY != I.y) {
+                // getCroppedFrame (:727-734): the correlations see the top-left window of every frame (and of dark / gain); everything after
+                // the global alignment works on the whole frames again
+                xh_fa *faCrop = nullptr;
+                xhCheck(xh_fa_create(g.c, (int)cropY, (int)cropX, Ts, maxResForCorrelation, &faCrop));
+                struct FaGuard2 { xh_fa *f; ~FaGuard2() { xh_fa_destroy(f); } } fg2{faCrop};
+                DeviceBuffer d_crop, d_dc, d_gc;
+                d_crop.reserve(g.c, (size_t)N * cropX * cropY * sizeof(float));
+                xhCheck(xh_movie_crop_frames(g.c, d_frames.as<float>(), N, (int)I.y, (int)I.x, (int)cropY, (int)cropX, d_crop.as<float>()));
+                if (pd) { d_dc.reserve(g.c, cropX * cropY * sizeof(float)); xhCheck(xh_movie_crop_frames(g.c, pd, 1, (int)I.y, (int)I.x, (int)cropY, (int)cropX, d_dc.as<float>())); }
+                if (pg) { d_gc.reserve(g.c, cropX * cropY * sizeof(float)); xhCheck(xh_movie_crop_frames(g.c, pg, 1, (int)I.y, (int)I.x, (int)cropY, (int)cropX, d_gc.as<float>())); }
+                xhCheck(xh_fa_global_alignment(faCrop, d_crop.as<float>(), N, pd ? d_dc.as<float>() : nullptr, pg ? d_gc.as<float>() : nullptr, maxShift, nullptr, nullptr,
+                                               sx.data(), sy.data(), &ref));
+            } else
             xhCheck(xh_fa_global_alignment(fa, d_frames.as<float>(), N, pd, pg, maxShift, nullptr, nullptr, sx.data(), sy.data(), &ref));
             centers.resize((size_t)patchesX * patchesY * 2);
             const bool wantAligned = !fnAligned.empty(), wantAvg = !fnAvg.empty(), wantInitial = !fnInitialAvg.empty();
