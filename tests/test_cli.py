@@ -19,8 +19,8 @@ def bins():
     return BIN
 
 
-def _run(args, **kw):
-    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, **kw)
+def _run(args, timeout=600, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, **kw)
 
 
 def test_help_and_argument_errors(bins):
@@ -142,6 +142,37 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
     rf.mirror_and_crop()
     exp = rf.finish()
     assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max()
+
+
+@pytest.mark.gpu
+def test_cli_loader_failures_end_the_programs_cleanly(bins, tmp_path):
+    """The image loops are pipelines (reader threads, copier threads, workers that assemble and format batches: host/fastio.h): an
+    image that cannot be read -- a missing stack, a stack that ends early, an image of another size -- somewhere in the MIDDLE of a run
+    has to surface as the reference's XMIPP_ERROR exit, promptly, with no output file and no thread left waiting."""
+    refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path, D=32, n=9)
+    n = len(parts)
+    apm = os.path.join(bins, "xmipp_angular_projection_matching")
+    rfa = os.path.join(bins, "xmipp_reconstruct_fourier_accel")
+    ok = _run([apm, "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "good.xmd"), "--ref", str(tmp_path / "ref.stk"), "--batch", "2"], timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    # a table whose seventh row names a stack that does not exist, whose eighth an image beyond the end, whose fifth an image of another size
+    xmipp_io.write_stack(str(tmp_path / "other.stk"), np.zeros((2, 16, 16), np.float32))
+    cases = {"missing": (6, f"1@{tmp_path}/nowhere.stk", "cannot open"), "beyond": (7, f"{n + 5}@{tmp_path}/parts.stk", "beyond the end"),
+             "size": (4, f"1@{tmp_path}/other.stk", "different size")}
+    labels, rows = xmipp_io.read_xmd(str(tmp_path / "good.xmd"))
+    ci = labels.index("image")
+    for name, (row, image, msg) in cases.items():
+        xmipp_io.write_xmd(str(tmp_path / f"exp_{name}.xmd"), [("noname", ["itemId", "image"],
+                           [[100 + i, image if i == row else f"{i + 1}@{tmp_path}/parts.stk"] for i in range(n)])])
+        r = _run([apm, "-i", str(tmp_path / f"exp_{name}.xmd"), "-o", str(tmp_path / f"out_{name}.xmd"), "--ref", str(tmp_path / "ref.stk"), "--batch", "2"], timeout=120)
+        assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and msg in r.stderr, (name, r.stderr[-400:])
+        assert not (tmp_path / f"out_{name}.xmd").exists()
+        bad = [list(x) for x in rows]
+        bad[row][ci] = image
+        xmipp_io.write_xmd(str(tmp_path / f"rec_{name}.xmd"), [("noname", labels, bad)])
+        r = _run([rfa, "-i", str(tmp_path / f"rec_{name}.xmd"), "-o", str(tmp_path / f"rec_{name}.vol"), "--batch", "2"], timeout=120)
+        assert r.returncode != 0 and "XMIPP_ERROR" in r.stderr and msg in r.stderr, (name, r.stderr[-400:])
+        assert not (tmp_path / f"rec_{name}.vol").exists()
 
 
 @pytest.mark.gpu
