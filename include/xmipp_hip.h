@@ -299,7 +299,12 @@ int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned);
  * Cauchy-Schwarz term in their bound. K0 == nk: the bank is not band limited, everything is contracted.
  * set_option("k0", v) overrides (0 = automatic). Identical results for every K0. */
 int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk);
-/* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk */
+/* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk.
+ * "threads" n (1..16): the reference program's --thr (angular_projection_matching.cpp:64,631,1018-1108).  Its n worker threads take
+ * the positions i % n of a particle's neighbour list and their results are merged, worker 0 first, strictly greater wins -- which
+ * only shows where two correlation values are EXACTLY equal (duplicated references): the winner is then the one with the smallest
+ * (i % n, position in the image's visiting order) instead of the first visited.  xh_pm_match[_ex] reproduces that order, for the
+ * running top-N (n_orient > 1) as well. */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 /* current value of "tau_rel" (ambiguity margin of the fp32 coarse search, relative to sum_r 2 pi r) or "s6_eps" (margin of the
  * fp32 pass of xh_pm_translate, relative to the maximum of the correlation map): the tests hold the measured fp32 errors against them */

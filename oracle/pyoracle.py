@@ -83,6 +83,8 @@ def lib():
         "xo_pm_prepare_particle": (None, [vp, c_double_p, d, d, c_double_p, c_double_p, c_double_p]),
         "xo_pm_match": (None, [vp, c_double_p, i, c_int32_p, c_int32_p, i, i, c_int32_p, c_int32_p,
                                i, i, c_int32_p, c_int32_p, c_uint8_p, c_double_p]),
+        "xo_pm_match_thr": (None, [vp, c_double_p, i, c_int32_p, c_int32_p, i, i, c_int32_p, c_int32_p,
+                                   i, i, i, c_int32_p, c_int32_p, c_uint8_p, c_double_p]),
         "xo_pm_corr_rows": (None, [vp, c_double_p, i, c_double_p]),
         "xo_pm_translate": (None, [vp, c_double_p, i, c_int32_p, c_int32_p, c_uint8_p, d, i,
                                    c_double_p, c_double_p, c_double_p]),
@@ -356,7 +358,9 @@ class PM:
         return out
 
     def match(self, particles, nbr_off=None, nbr_ids=None, parity=0, n_orient=1, xoff5d=None,
-              yoff5d=None, nthreads=0):
+              yoff5d=None, nthreads=0, ref_threads=1):
+        """ref_threads: the program's --thr (worker c takes the list positions i % ref_threads == c, the per-worker lists are merged,
+        APM:631,1063-1108); it only matters where two correlation values are exactly equal"""
         particles = f64(particles)
         n = particles.shape[0]
         refno = np.empty((n, n_orient), np.int32)
@@ -371,9 +375,9 @@ class PM:
             xoff5d = np.ascontiguousarray(xoff5d, np.int32)
             yoff5d = np.ascontiguousarray(yoff5d, np.int32)
             nt = len(xoff5d)
-        lib().xo_pm_match(self.h, _dp(particles), n, _ip(nbr_off), _ip(nbr_ids), parity, n_orient,
-                          _ip(xoff5d), _ip(yoff5d), nt, nthreads, _ip(refno), _ip(psi),
-                          flip.ctypes.data_as(c_uint8_p), _dp(cc))
+        lib().xo_pm_match_thr(self.h, _dp(particles), n, _ip(nbr_off), _ip(nbr_ids), parity, n_orient,
+                              _ip(xoff5d), _ip(yoff5d), nt, nthreads, int(ref_threads), _ip(refno), _ip(psi),
+                              flip.ctypes.data_as(c_uint8_p), _dp(cc))
         return refno, psi, flip, cc
 
     def translate(self, particles, refno, psi_idx, flip, max_shift=-1.0, nthreads=0):

@@ -107,6 +107,10 @@ void xo_pm_match(const xo_pm *, const double *particles, int n, const int32_t *n
                  const int32_t *nbr_ids, int first_image_parity, int n_orient,
                  const int32_t *xoff5d, const int32_t *yoff5d, int ntrans, int nthreads,
                  int32_t *refno, int32_t *psi_idx, uint8_t *flip, double *cc);
+void xo_pm_match_thr(const xo_pm *, const double *particles, int n, const int32_t *nbr_off,
+                 const int32_t *nbr_ids, int first_image_parity, int n_orient,
+                 const int32_t *xoff5d, const int32_t *yoff5d, int ntrans, int nthreads, int ref_threads /* the program's --thr: APM:631,1063-1108 */,
+                 int32_t *refno, int32_t *psi_idx, uint8_t *flip, double *cc);
 /* full correlation rows for one (particle, ref): corr[2N] = straight || mirror, normalised */
 void xo_pm_corr_rows(const xo_pm *, const double *img, int ref, double *corr2N);
 /* Translational step (APM:776-868); max_shift<0 => dim/2 as in APM:262-263 */

@@ -331,6 +331,18 @@ void xo_pm_match(const xo_pm *pm, const double *particles, int n, const int32_t 
                  const int32_t *xoff5d, const int32_t *yoff5d, int ntrans, int nthreads,
                  int32_t *refno, int32_t *psi_idx, uint8_t *flip, double *cc)
 {
+    xo_pm_match_thr(pm, particles, n, nbr_off, nbr_ids, first_image_parity, n_orient, xoff5d, yoff5d, ntrans, nthreads, 1, refno, psi_idx, flip, cc);
+}
+
+// ref_threads = the program's --thr (APM:64,537,631): worker c of ref_threads takes the list positions i with i % ref_threads == c, in
+// the image's visiting order, and keeps its own running top-N (APM:714-735); the lists are merged afterwards (APM:1063-1108): rank n of
+// the result is the head of the list whose head is strictly greatest, the lowest worker among equals.  ref_threads == 1 is the plain loop.
+void xo_pm_match_thr(const xo_pm *pm, const double *particles, int n, const int32_t *nbr_off,
+                     const int32_t *nbr_ids, int first_image_parity, int n_orient,
+                     const int32_t *xoff5d, const int32_t *yoff5d, int ntrans, int nthreads, int ref_threads,
+                     int32_t *refno, int32_t *psi_idx, uint8_t *flip, double *cc)
+{
+    if (ref_threads < 1) ref_threads = 1;
     const Layout &L = pm->L;
     const int N = L.nsam[L.nrings - 1];
     const int D = pm->D;
@@ -348,6 +360,11 @@ void xo_pm_match(const xo_pm *pm, const double *particles, int n, const int32_t 
         std::vector<cd> fP((size_t)ntrans * L.ncoefs), fPm((size_t)ntrans * L.ncoefs);
         std::vector<double> stddev_img(ntrans);
         std::vector<double> maxcorr(n_orient);
+        // --thr > 1: worker c's running list (APM:1026-1056)
+        const int T = ref_threads;
+        std::vector<double> tcorr((size_t)T * n_orient);
+        std::vector<int32_t> tref((size_t)T * n_orient), tpsi((size_t)T * n_orient);
+        std::vector<uint8_t> tflip((size_t)T * n_orient);
 #pragma omp for schedule(dynamic, 1)
         for (int imgno = 0; imgno < n; ++imgno) {
             const double *img = particles + (size_t)imgno * D * D;
@@ -369,6 +386,66 @@ void xo_pm_match(const xo_pm *pm, const double *particles, int n, const int32_t 
             if (nbr_off) { nn = nbr_off[imgno + 1] - nbr_off[imgno]; ids = nbr_ids + nbr_off[imgno]; }
             else nn = pm->nrefs;
             const bool forward = (((imgno + first_image_parity) & 1) == 0);
+            if (T > 1) {
+                for (int c = 0; c < T; ++c)
+                    for (int no = 0; no < n_orient; ++no) {
+                        tcorr[(size_t)c * n_orient + no] = -99.e99; tref[(size_t)c * n_orient + no] = -1;
+                        tpsi[(size_t)c * n_orient + no] = 0; tflip[(size_t)c * n_orient + no] = 0;
+                    }
+                for (int c = 0; c < T; ++c) {
+                    double *mc = &tcorr[(size_t)c * n_orient];
+                    for (int t = 0; t < nn; ++t) {
+                        const int i = forward ? t : nn - 1 - t;
+                        if (i % T != c) continue;                                  // APM:631
+                        const int ref = ids ? ids[i] : i;
+                        const cd *fr = &pm->fP_ref[(size_t)ref * L.ncoefs];
+                        for (int it = 0; it < ntrans; ++it) {
+                            const double den = pm->stddev_ref[ref] * stddev_img[it];
+                            rot_corr(L, &fP[(size_t)it * L.ncoefs], fr, corr.data(), S);
+                            for (int k = 0; k < N; ++k) allCorr[k] = corr[k] / den;
+                            rot_corr(L, &fPm[(size_t)it * L.ncoefs], fr, corr.data(), S);
+                            for (int k = 0; k < N; ++k) allCorr[N + k] = corr[k] / den;
+                            const int nIter = n_orient < N ? n_orient : N;
+                            double bestLastCorr = 99e99;
+                            for (int no = 0; no < nIter; no++) {
+                                for (int k = 0; k < 2 * N; k++)
+                                    if ((allCorr[k] > mc[no]) && (allCorr[k] < bestLastCorr)) {
+                                        mc[no] = allCorr[k];
+                                        tpsi[(size_t)c * n_orient + no] = k % N;
+                                        tref[(size_t)c * n_orient + no] = ref;
+                                        tflip[(size_t)c * n_orient + no] = (k >= N);
+                                    }
+                                bestLastCorr = mc[no];
+                            }
+                        }
+                    }
+                }
+                // APM:1063-1108
+                std::vector<int> indexThreads(T, 0);
+                for (int no = 0; no < n_orient; ++no) {
+                    double tempCorr = -99.e99;
+                    bool validCorr = false;
+                    int best = 0;
+                    for (int c = 0; c < T; ++c) {
+                        // (a worker that has handed out all its ranks has nothing left: the reference reads one past its list here)
+                        if (indexThreads[c] >= n_orient) continue;
+                        if (tcorr[(size_t)c * n_orient + indexThreads[c]] > tempCorr) {
+                            validCorr = true;
+                            best = c;
+                            tempCorr = tcorr[(size_t)c * n_orient + indexThreads[c]];
+                        }
+                    }
+                    if (!validCorr) break;
+                    const size_t src = (size_t)best * n_orient + indexThreads[best];
+                    refno[(size_t)imgno * n_orient + no] = tref[src];
+                    psi_idx[(size_t)imgno * n_orient + no] = tpsi[src];
+                    flip[(size_t)imgno * n_orient + no] = tflip[src];
+                    maxcorr[no] = tcorr[src];
+                    indexThreads[best]++;
+                }
+                for (int i = 0; i < n_orient; ++i) cc[(size_t)imgno * n_orient + i] = maxcorr[i];
+                continue;
+            }
             for (int t = 0; t < nn; ++t) {
                 const int i = forward ? t : nn - 1 - t;
                 const int ref = ids ? ids[i] : i;

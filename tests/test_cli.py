@@ -100,8 +100,10 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
     the oracle run on the same files' contents. box=40: no power of two anywhere on the path."""
     refs, dirs, parts, ids, nbrs = _write_dataset(tmp_path, D=box)
     n, nrefs, D = len(parts), len(refs), refs.shape[1]
+    # (box 40 with --thr 3, as the reference's own test of the program runs it, test_programs.py:150-159)
+    thr = 3 if box == 40 else 1
     r = _run([os.path.join(bins, "xmipp_angular_projection_matching"), "-i", str(tmp_path / "exp.xmd"), "-o", str(tmp_path / "out.xmd"),
-              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4"])
+              "--ref", str(tmp_path / "ref.stk"), "--max_shift", "6", "--batch", "4", "--thr", str(thr)])
     assert r.returncode == 0, r.stderr
     labels, rows = xmipp_io.read_xmd(str(tmp_path / "out.xmd"))
     assert labels == ["itemId", "image", "angleRot", "angleTilt", "anglePsi", "shiftX", "shiftY", "ref", "flip", "scale", "maxCC"]
@@ -112,7 +114,7 @@ def test_cli_pipeline_matches_oracle(bins, tmp_path, oracle, box):
     off = np.zeros(n + 1, np.int32)
     off[1:] = np.cumsum([len(l) for l in lists])
     pm = oracle.PM(refs)
-    er, ep, ef, _ = pm.match(parts, off, np.concatenate(lists).astype(np.int32))
+    er, ep, ef, _ = pm.match(parts, off, np.concatenate(lists).astype(np.int32), ref_threads=thr)
     ex, ey, ec = pm.translate(parts, er[:, 0], ep[:, 0], ef[:, 0], 6.0)
     c = {l: i for i, l in enumerate(labels)}
     for i, row in enumerate(rows):

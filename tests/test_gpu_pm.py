@@ -427,6 +427,54 @@ def test_exact_ties_follow_the_visiting_order(gpu, oracle, lib64):
     assert pm.last_stats()["rescored_particles"] == 6
 
 
+@pytest.mark.parametrize("thr", [2, 3, 4])
+def test_exact_ties_follow_the_worker_threads_of_thr(gpu, oracle, lib64, thr):
+    """--thr n (APM:631,1018-1108): worker c of n takes the list positions i % n == c in the image's visiting order, the workers'
+    results are merged, worker 0 first, strictly greater wins.  With duplicated references at list positions 3, 10 and 21 the winner
+    is decided by (position % n, visiting order) -- 10 for n = 2 (3 % 2 = 1, 10 % 2 = 0, 21 % 2 = 1), 3 / 21 alternating for n = 3
+    (all three positions are worker 0's), 3 / 10 ... -- and the device (option "threads") follows the oracle's restatement of it;
+    lists in any order (gathered rows), ascending lists (they lose the whole-bank mode with threads > 1) and the running top-N too."""
+    xa, ctx, torch = gpu
+    D, refs, parts, truth = lib64
+    refs2 = np.concatenate([refs[:10], refs[3:4], refs[10:20], refs[3:4]])  # ref 3 also at 10 and 21
+    rng = np.random.default_rng(21)
+    pp = np.stack([refs2[3] + 0.3 * refs2[3].std() * rng.standard_normal((D, D)).astype(np.float32) for _ in range(6)])
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(refs2).cuda())
+    pm.set_option("threads", thr)
+    o = oracle.PM(refs2)
+    dp = torch.from_numpy(pp).cuda()
+    seen = set()
+    for parity in (0, 1):
+        refno, psi, flip = pm.match(dp, parity=parity)
+        er, ep, ef, _ = o.match(pp, parity=parity, ref_threads=thr)
+        assert set(er[:, 0]) <= {3, 10, 21}
+        assert np.array_equal(refno.cpu().numpy(), er[:, 0]) and np.array_equal(psi.cpu().numpy(), ep[:, 0]) and np.array_equal(flip.cpu().numpy(), ef[:, 0])
+        seen |= set(er[:, 0])
+        e1 = o.match(pp, parity=parity)[0]
+        if thr == 2:
+            assert (er[:, 0] == 10).all() and not np.array_equal(e1[:, 0], er[:, 0])       # the order of --thr 1 gives 3 / 21
+    # neighbour lists: positions in the LIST decide (here the duplicates sit at list positions 0, 1, 2 of a shuffled / ascending list)
+    for ascending in (False, True):
+        lists = [np.array([21, 3, 10, 5, 7, 12][:5 + (i % 2)]) for i in range(6)]
+        if ascending:
+            lists = [np.sort(l) for l in lists]
+        off = np.zeros(7, np.int32)
+        off[1:] = np.cumsum([len(l) for l in lists])
+        ids = np.concatenate(lists).astype(np.int32)
+        refno, psi, flip = pm.match(dp, off, ids, parity=1)
+        er, ep, ef, _ = o.match(pp, off, ids, parity=1, ref_threads=thr)
+        assert np.array_equal(refno.cpu().numpy(), er[:, 0]) and np.array_equal(psi.cpu().numpy(), ep[:, 0]) and np.array_equal(flip.cpu().numpy(), ef[:, 0])
+    # the running top-N of every worker and their merge
+    refno, psi, flip = pm.match(dp, parity=0, n_orient=3)
+    er, ep, ef, _ = o.match(pp, parity=0, n_orient=3, ref_threads=thr)
+    assert np.array_equal(refno.cpu().numpy(), er)
+    valid = er >= 0
+    assert np.array_equal(psi.cpu().numpy()[valid], ep[valid]) and np.array_equal(flip.cpu().numpy()[valid], ef[valid])
+    pm.set_option("threads", 1)
+    refno, _, _ = pm.match(dp, parity=0)
+    assert np.array_equal(refno.cpu().numpy(), o.match(pp, parity=0)[0][:, 0])
+
+
 @pytest.mark.parametrize("mode", ["dense", "lists", "ascending_lists"])
 def test_5d_search_indices_bit_identical(gpu, oracle, lib64, mode):
     """--search5d_shift 3 --search5d_step 2 (APM:321-348,575-589,676): 9 extra polar transforms per

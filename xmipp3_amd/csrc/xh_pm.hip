@@ -115,7 +115,8 @@ struct xh_pm {
     int ncells, use_cells;
     XhBuf d_coef64, d_polar64, d_A64, d_stat64;     // S1<double> (ambiguous particles)
     XhBuf d_raw, d_rowres, d_desc, d_nbr, d_poff;
-    XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters, d_offs5d;
+    XhBuf d_ambList, d_ambSlot, d_candRow, d_candRes, d_counters, d_offs5d, d_thrLists;
+    int ref_threads = 1;         // the program's --thr (option "threads"): the order among exactly equal values only
     XhBuf d_t1, d_t2, d_t3;      // S6 scratch
     int64_t stat_rows, stat_resc_p, stat_resc_r;
     int coefFirst, coefCount;      // particles whose fp32 B-spline coefficients d_coef32 holds (last match call)
@@ -1462,7 +1463,8 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
 // contiguous, poff[slot]..poff[slot+1]; the rows of a particle are therefore contiguous too.
 // dense (nq > 0): every slot is compared with references 0..nq-1; otherwise rowSlot/refIds give the
 // slot and the reference of every row (neighbour lists, APM:609-626).
-struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; int noMirror = 0; /* 1: the mirrored particle is not a candidate */ };
+struct RowMap { const int *poff; const int *rowSlot; const int *refIds; int nt, nq; int noMirror = 0; /* 1: the mirrored particle is not a candidate */
+                int thr = 1;   /* the program's --thr: list position i belongs to worker i % thr (APM:631), the workers' results are merged (APM:1063-1108) */ };
 __device__ __forceinline__ int d_row_slot(const RowMap &M, int row) { return M.rowSlot ? M.rowSlot[row] : row / M.nq; }
 __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { return M.refIds ? M.refIds[row] : row - slot * M.nq; }
 
@@ -1820,11 +1822,15 @@ k_pm_rescore_row(const int *__restrict__ counters, const int *__restrict__ candR
 // and backward for odd ones, the 5-D translations innermost in ascending order, and replaces the
 // incumbent only on a strictly greater value (APM:609-626,676,715-735,1112) => among (near-)equal
 // maxima the earliest visited row wins.
+// Among exactly equal values the reference keeps the one it meets first (strict >).  With --thr T worker c = i % T walks the list
+// positions i it owns in the image's visiting order and the merge of the workers' results (APM:1063-1108, strict > again, worker 0
+// first) keeps the lowest worker among equals: the key is (worker, visiting position).
 __device__ __forceinline__ int d_visit_order(const RowMap &M, int row, bool forward)
 {
     const int slot = d_row_slot(M, row);
     const int j = row - M.poff[slot], nn = M.poff[slot + 1] - M.poff[slot];
-    return (forward ? j : nn - 1 - j) * M.nt + slot % M.nt;
+    const int pos = (forward ? j : nn - 1 - j) * M.nt + slot % M.nt;
+    return M.thr > 1 ? (j % M.thr) * (nn * M.nt) + pos : pos;
 }
 __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restrict__ ambList,
                           const CandRes *__restrict__ cand, RowMap M, int pBase, int parity, int N, double tieAbs,
@@ -1870,7 +1876,8 @@ __global__ void k_pm_pick(const int *__restrict__ counters, const int *__restric
 // cand holds the K = n_orient largest distinct values of every row (all rows are candidates, c == row).
 #define XH_MAX_ORIENT 16
 __global__ void k_pm_pick_multi(const CandRes *__restrict__ cand, RowMap M, int m, int pBase, int parity, int N, int K,
-                                double eps, int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip)
+                                double eps, int *__restrict__ refno, int *__restrict__ psi, unsigned char *__restrict__ flip,
+                                double *__restrict__ wcorr, int *__restrict__ wref, int *__restrict__ wpsi)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
@@ -1881,6 +1888,50 @@ __global__ void k_pm_pick_multi(const CandRes *__restrict__ cand, RowMap M, int 
     const int s0 = p * M.nt;
     const int nn = M.poff[s0 + 1] - M.poff[s0];
     const int nIter = K < 2 * N ? K : 2 * N;
+    if (M.thr > 1) {
+        // --thr T: worker c's running top-N over the list positions j % T == c, written to its own slice of the scratch (wcorr and
+        // friends: [particle][worker][K]), then the merge of APM:1063-1108
+        const int T = M.thr;
+        double *wc = wcorr + (size_t)p * T * K;
+        int *wr = wref + (size_t)p * T * K, *wp = wpsi + (size_t)p * T * K;
+        for (int i = 0; i < T * K; ++i) { wc[i] = -99.e99; wr[i] = -1; wp[i] = 0; }
+        for (int c = 0; c < T; ++c)
+            for (int t = 0; t < nn; ++t) {
+                const int j = forward ? t : nn - 1 - t;
+                if (j % T != c) continue;
+                for (int it = 0; it < M.nt; ++it) {
+                    const int row = M.poff[s0 + it] + j;
+                    const int ref = d_row_ref(M, row, s0 + it);
+                    const CandRes *cr = cand + (size_t)row * K;
+                    double bestLast = 99e99;
+                    for (int n = 0; n < nIter; ++n) {
+                        for (int q = 0; q < K; ++q) {
+                            if (cr[q].idx < 0) break;
+                            if (cr[q].val < bestLast - eps) {
+                                if (cr[q].val > wc[c * K + n] + eps) { wc[c * K + n] = cr[q].val; wr[c * K + n] = ref; wp[c * K + n] = cr[q].idx; }
+                                break;
+                            }
+                        }
+                        bestLast = wc[c * K + n];
+                    }
+                }
+            }
+        int head[XH_MAX_ORIENT];
+        for (int c = 0; c < T; ++c) head[c] = 0;
+        for (int n = 0; n < K; ++n) {
+            double tempCorr = -99.e99;
+            int best = -1;
+            for (int c = 0; c < T; ++c)
+                if (head[c] < K && wc[c * K + head[c]] > tempCorr + eps) { best = c; tempCorr = wc[c * K + head[c]]; }
+            if (best < 0) break;
+            const int src = best * K + head[best];
+            refno[gp + n] = wr[src];
+            psi[gp + n] = wp[src] % N;
+            flip[gp + n] = wp[src] >= N ? 1 : 0;
+            ++head[best];
+        }
+        return;
+    }
     for (int t = 0; t < nn; ++t) {
         const int j = forward ? t : nn - 1 - t;
         for (int it = 0; it < M.nt; ++it) {
@@ -3341,7 +3392,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData, &pm->d_thrLists};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -3786,6 +3837,12 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "early_exit")) pm->use_early_exit = value != 0;
     else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
+    else if (!strcmp(name, "threads")) {
+        // the program's --thr: which of two EXACTLY equal correlation values is kept follows the reference's split of a neighbour list over
+        // its worker threads and the merge of their results (APM:631,1063-1108); nothing else depends on it
+        XH_CHECK(value >= 1 && value <= XH_MAX_ORIENT, XH_ERR_ARG, "xh_pm_set_option: threads in [1, %d]", XH_MAX_ORIENT);
+        pm->ref_threads = (int)value;
+    }
     else if (!strcmp(name, "tr_chunk_mb")) pm->tr_chunk_mb = (int)value;
     else if (!strcmp(name, "k0")) {      // two-level S2 cut: 0 = the automatic choice, >= nk = off
         XH_HIP(hipSetDevice(pm->ctx->device));
@@ -4048,7 +4105,8 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     // that is not on the particle's list before anything else is computed for it (k_pm_prune_plan). Rows, visiting
     // order and results are those of the list search. Lists in another order keep the gather path below.
     bool masked = false;
-    if (!dense && pm->use_mask_lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1) {
+    // (with --thr > 1 a row's worker is its LIST position modulo thr, which the whole-bank rows of this mode do not carry: lists are gathered)
+    if (!dense && pm->use_mask_lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1 && pm->ref_threads <= 1) {
         masked = true;
         for (int p = 0; p < n && masked; ++p) {
             masked = h_nbr_off[p + 1] > h_nbr_off[p];
@@ -4134,6 +4192,7 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         XH_HIP(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope per iteration
         RowMap M;
         M.poff = d_poff; M.rowSlot = d_rowSlot; M.refIds = d_ids; M.nt = nt; M.nq = !lists ? pm->nrefs : 0; M.noMirror = pm->no_mirror;
+        M.thr = pm->ref_threads;
         pm->stat_rows += masked ? listedRows : nrows;
         const size_t smem64 = sizeof(xh_cd) * (2 * (size_t)L.nk + L.N) + (n_orient > 1 ? sizeof(double) * 2 * L.N : 0);
         if (n_orient > 1) {
@@ -4154,8 +4213,15 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
                                    L.ncoef, L.N, L.nk, (CandRes *)pm->d_candRes.p, (double *)nullptr, n_orient, pm->tie_rel);
                 XH_LAUNCH_CHECK();
             }
+            double *wcorr = nullptr;
+            int *wref = nullptr, *wpsi = nullptr;
+            if (M.thr > 1) {       // the workers' lists of --thr: [particle][worker][rank]
+                const size_t e = (size_t)m * M.thr * n_orient;
+                XH_TRY(xh_buf_reserve(ctx, pm->d_thrLists, e * (sizeof(double) + 2 * sizeof(int))));
+                wcorr = (double *)pm->d_thrLists.p; wref = (int *)(wcorr + e); wpsi = wref + e;
+            }
             hipLaunchKernelGGL(k_pm_pick_multi, dim3((m + 63) / 64), dim3(64), 0, ctx->stream, (const CandRes *)pm->d_candRes.p, M, m,
-                               p0, parity, L.N, n_orient, pm->tie_rel, d_refno, d_psi, d_flip);
+                               p0, parity, L.N, n_orient, pm->tie_rel, d_refno, d_psi, d_flip, wcorr, wref, wpsi);
             XH_LAUNCH_CHECK();
             XH_HIP(hipEventRecord(pm->ev[5], ctx->stream));
             XH_HIP(hipEventSynchronize(pm->ev[5]));

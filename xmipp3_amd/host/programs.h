@@ -193,9 +193,10 @@ public:
         addParamsLine("                     : CTF parameter file or a 2D image with the CTF amplitudes");
         addParamsLine("  [--pad <pad=1>]             : Padding factor (for CTF correction only)");
         addParamsLine("  [--phase_flipped]            : Use this if the experimental images have been phase flipped");
-        addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads (accepted; the search runs on the device in the order of");
-        addParamsLine("                               : --thr 1. With --thr n the reference merges n per-thread lists (APM:1063-1108), which");
-        addParamsLine("                               : differs only in which of two EXACTLY equal correlation values is kept)");
+        addParamsLine("  [--thr <threads=1>]           : Number of concurrent threads of the reference. The search runs on the device whatever");
+        addParamsLine("                               : the value; it only decides which of two EXACTLY equal correlation values is kept, as the");
+        addParamsLine("                               : reference's split of a neighbour list over its threads and the merge of their results do");
+        addParamsLine("                               : (up to 16)");
         addParamsLine("  [--number_orientations <numOrientations=1>]  : Number of possible orientations for each experimental image");
         addParamsLine("  [--append]                : Append (versus overwrite) data to the output file");
         addParamsLine("  [--device <id=0>]         : first HIP device");
@@ -371,6 +372,8 @@ public:
             d_refs.reserve(s.ctx, refs.size() * sizeof(float));
             xhCheck(xh_memcpy_h2d(s.ctx, d_refs.p, refs.data(), refs.size() * sizeof(float)));
             xhCheck(xh_pm_create(s.ctx, (int)dim, Ri, Ro, (int)total_nr_refs, d_refs.as<float>(), Mctf.empty() ? nullptr : Mctf.data(), paddim, &s.pm));
+            // which of two exactly equal correlation values wins follows the reference's worker threads (APM:631,1063-1108)
+            if (threads > 1) xhCheck(xh_pm_set_option(s.pm, "threads", (double)std::min(threads, 16)));
             feederReady.get();
         });
         int32_t nn;
