@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds docs/experiments.md: ONE table of every variant that was built or costed, with the file that holds the numbers, what it did and
 whether it was adopted.  Rounds 1-4 are read out of profiles/README.md (tables headed `idea | result` = not adopted, `change | before ->
-after` = adopted); round 5 is listed below by hand.    python3 tools/make_experiments_index.py"""
+after` = adopted); rounds 5 and 6 are listed below by hand.    python3 tools/make_experiments_index.py"""
 import os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R5 = [
@@ -44,6 +44,17 @@ R5 = [
     ("FlexAlign", "three and four movies in flight", "gpurun A/B", "25.7 / 27.6 movies/s against 27.8 with two", "no"),
 ]
 
+R6 = [
+    ("host side of the programs", "reader threads that enqueue their own H2D copies on their own streams (16 / 32 / 64 readers)", "profiles/experiments/r06_cli_sweeps.txt", "image loop of `xmipp_angular_projection_matching` 75 / 52 / 30 k particles/s: the runtime serialises the threads and the compute thread's launches with them", "no"),
+    ("host side of the programs", "persistent reader pool (pread into page-locked 4 MB pieces) + copier threads that alone talk to the runtime; one / two copiers, pieces of 4 / 8 / 16 MB", "profiles/experiments/r06_cli_sweeps.txt", "one copier 152-158 k, two copiers 176 / 168 / 150 k particles/s at 256 px", "yes (two copiers, 4 MB)"),
+    ("host side of the programs", "loader threads and their page-locked memory bound to the device's NUMA node (`xh_device_numa_node`)", "profiles/r06_b_ubench_hostfeed.txt", "H2D beside 16 readers on a two-socket host: 21 GB/s unbound, 56 GB/s bound to either node; readers alone 73 -> 97 GB/s on the device's node", "yes"),
+    ("host side of the programs", "whole batches page-locked (2 x 1.07 GB) instead of pieces", "profiles/experiments/r06_cli_sweeps.txt", "page-locking costs 0.25 s per GB: 0.52 s of a 1.4 s run", "no (256 MB of pieces)"),
+    ("FlexAlign global", "sums of the pruned transforms and the pair windows in blocks of 16 / 32 terms (block sums apart from the total)", "profiles/experiments/r06_flexalign_precision.txt", "K3 parity sample 7.9e-4 -> 3.5e-5 px, but `k_fa_pairwin_a2` 2.16 -> 4.47 ms (twice the accumulators: 3 instead of 5 waves per SIMD); with half the rows per thread 8.3 -> 9.4 ms per movie for the stage", "no"),
+    ("FlexAlign global", "the mean of the correlation map (its (0, 0) coefficient) left out of the window sums and of the full inverse transform: bestShift subtracts it again", "profiles/r06_b_flexalign_precision_k3.txt", "K3 parity sample 7.9e-4 -> 2.6e-6 px at round 5's speed (8e-8 through the full inverse transform): the digits were lost to adding small terms to a sum dominated by the mean, not to the length of the sums", "yes"),
+    ("gridding kernel", "kernels of the matcher BESIDE the gridding kernel on the same CUs: `grid_waves` 8 leaves 42 KB of LDS and 176 registers per lane, S6's kernels (<= 100 registers, <= 37 KB) fit", "profiles/r06_b_exp_corun.txt, profiles/r06_b_ubench_coresidency.txt", "they do co-reside (microbenchmark and kernel trace) and the work is purely additive: 4 x S6 (16 ms alone) beside a 33.6 ms insert = 50.0 ms; 29.5 + 16 = 45.1 at twelve waves.  Both sides are bound by vector issue; the fp64 repeat kernels and `k_pm_ringdft_mfma` / `k_pm_idft_max3` (225 / 233 registers) do not fit and block their stream until the launch ends", "no"),
+    ("gridding kernel", "tap rejection without compare + select: (a) clamp of the table index, (b) index pushed beyond the table by max(d - r^2, 0) 2^44 with packed min / max, (c) execution mask per tap (`v_cmpx`)", "DESIGN.md 9 (round 6), costed from the ISA of the dense block (155 vector instructions: 29 v_pk_add, 15 v_pk_mul, 16 v_pk_fma, 16 v_fmac, 18 v_cvt, 17 v_lshl, 16 v_cmp, 16 v_cndmask)", "(a) keeps table entry 9999 for d in (r^2, r^2 + 0.5 / k]: voxel sets differ (round 2 found the same); (b) exact, but four packed instructions per pair of taps = the two it replaces; (c) saves the select (16 of 155) only with the sixteen distances or masks kept live across the LDS latency: 16 more registers at 167 of 168, or 32 scalar registers in a kernel that already spills 80 -- not built", "no"),
+]
+
 
 def main():
     src = open(os.path.join(ROOT, "profiles", "README.md")).read().split("\n")
@@ -64,7 +75,10 @@ def main():
     out = ["# Experiments index", "",
            "Every variant that was built or costed, one line each.  Rounds 1-4 are lifted from the tables of `profiles/README.md` (which keeps the",
            "commands and the longer readings); `profiles/experiments/*` hold the raw A/B records.  Generated by `tools/make_experiments_index.py`.", "",
-           "## Round 5", "", "| area | variant | numbers in | result | adopted |", "|---|---|---|---|---|"]
+           "## Round 6", "", "| area | variant | numbers in | result | adopted |", "|---|---|---|---|---|"]
+    for a, v, f, r, ad in R6:
+        out.append(f"| {a} | {v} | {f} | {r} | {ad} |")
+    out += ["", "## Round 5", "", "| area | variant | numbers in | result | adopted |", "|---|---|---|---|---|"]
     for a, v, f, r, ad in R5:
         out.append(f"| {a} | {v} | {f} | {r} | {ad} |")
     out += ["", "## Rounds 1-4 (from profiles/README.md)", "", "| section of profiles/README.md | variant | result | adopted |", "|---|---|---|---|"]
@@ -72,7 +86,7 @@ def main():
         out.append(f"| {s[:60]} | {v} | {r} | {ad} |")
     os.makedirs(os.path.join(ROOT, "docs"), exist_ok=True)
     open(os.path.join(ROOT, "docs", "experiments.md"), "w").write("\n".join(out) + "\n")
-    print(len(R5), "+", len(rows), "rows")
+    print(len(R6), "+", len(R5), "+", len(rows), "rows")
 
 
 if __name__ == "__main__":
