@@ -269,6 +269,7 @@ struct xh_rf {
     int fuse_ctf = 1;     // xh_rf_insert_images: evaluate the CTF inside the pack kernel (0: through planes, for A/B)
     XhBuf d_finSpec, d_finVol, d_finFbt;   // the finaliser's expanded spectrum, output volume and Fourier blob table
     int shift_bands = 1;  // 256-px images shifted band by band out of LDS (k_rf_shift_band; 0: k_rf_shift, for A/B)
+    int skip_far_cells = 1;   // the pack kernels skip the record cells no tap can reach (0: every cell written, for A/B)
     int order_spaces = 1; // the traverse spaces of a launch ordered by plane, so that k_rf_grid reuses voxel queues (0: input order, for A/B)
     XhBuf d_spacePos;
     int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
@@ -1535,6 +1536,7 @@ int xh_rf_set_option(xh_rf *rf, const char *name, double value)
     else if (!strcmp(name, "fuse_ctf")) rf->fuse_ctf = (int)value;
     else if (!strcmp(name, "ctf_fast")) rf->ctf_fast = (int)value;
     else if (!strcmp(name, "order_spaces")) rf->order_spaces = (int)value;
+    else if (!strcmp(name, "skip_far_cells")) rf->skip_far_cells = (int)value;
     else if (!strcmp(name, "shift_bands")) rf->shift_bands = (int)value;
     else if (!strcmp(name, "records_from_images")) rf->records_from_images = (int)value;
     else if (!strcmp(name, "tile_max_spaces")) rf->tile_max_spaces = (int)value;
@@ -1883,7 +1885,15 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
     XH_CHECK(cells < ((size_t)1 << 31), XH_ERR_ARG, "xh_rf_insert: more than 2^31 record cells in one call; insert in smaller batches");
     const size_t d = rf->mv + 1;
     float *tempV = rf->d_temp, *tempW = rf->d_temp + 2 * d * d * d;
-    XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(XgCell) + 16));          // (the patch copy reads 16 bytes from the last record too)
+    {
+        // the record buffer is zeroed when it is (re)allocated: the pack kernels leave the cells no tap can reach alone, and what lies there
+        // must be finite (it only ever meets the table's zero entry)
+        const void *before = rf->d_pack.p;
+        XH_TRY(xh_buf_reserve(ctx, rf->d_pack, cells * sizeof(XgCell) + 16));          // (the patch copy reads 16 bytes from the last record too)
+        if (rf->d_pack.p != before) XH_HIP(hipMemsetAsync(rf->d_pack.p, 0, rf->d_pack.bytes, ctx->stream));
+    }
+    // pixels further than sizeX + 2 r (+ 2) from the origin of the half spectrum are beyond every tap (xh_rf_grid.h)
+    const int skipR = rf->sizeX + (int)std::ceil(2.0 * br) + 2, skipR2 = rf->skip_far_cells ? skipR * skipR : 0x7fffffff;
     if (rf->packImgs) XH_TRY(fft_cols_rows(rf, rf->packImgs, n, nullptr, (XgCell *)rf->d_pack.p, d_weights));
     else
     for (int i0 = 0; i0 < n; i0 += 65535) {          // blockIdx.y: image
@@ -1894,11 +1904,11 @@ static int grid_run(xh_rf *rf, int ns, const float *d_fft, const float *d_ctf, c
             hipLaunchKernelGGL(k_rf_pack_grid_ctf, dim3((unsigned)((K * SXp + 255) / 256), m), dim3(256), 0, ctx->stream, (const xh_cf *)d_fft + o,
                                (const XhCtfDev *)rf->d_ctfp.p + i0, d_weights ? d_weights + i0 : nullptr,
                                (XgCell *)rf->d_pack.p + (size_t)i0 * SXp * SYp, rf->sizeX, rf->sizeY, rf->P, 1.0 / rf->p.sampling,
-                               rf->p.min_ctf, rf->p.phase_flipped);
+                               rf->p.min_ctf, rf->p.phase_flipped, skipR2);
         } else
         hipLaunchKernelGGL(k_rf_pack_grid, dim3((unsigned)((SXp * SYp + XG_PACK_CELLS - 1) / XG_PACK_CELLS), m), dim3(256), 0, ctx->stream,
                            (const xh_cf *)d_fft + o, d_ctf ? d_ctf + o : nullptr, d_mod ? d_mod + o : nullptr, d_weights ? d_weights + i0 : nullptr,
-                           (XgCell *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY);
+                           (XgCell *)rf->d_pack.p + (size_t)i0 * SXp * SYp, m, rf->sizeX, rf->sizeY, skipR2);
         XH_LAUNCH_CHECK();
     }
     // float thresholds equivalent to the double reach tests of the sparse pass (a voxel with no pixel within reach adds

@@ -99,7 +99,7 @@ typedef float xg_v4f __attribute__((ext_vector_type(4)));
 #define XG_PACK_CELLS 1024
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, const float *__restrict__ mods,
-               const float *__restrict__ weights, XgCell *__restrict__ pk, int n, int sizeX, int sizeY)
+               const float *__restrict__ weights, XgCell *__restrict__ pk, int n, int sizeX, int sizeY, int skipR2)
 {
     const unsigned SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD, cells = SX * SY;
     const unsigned img = blockIdx.y;
@@ -110,13 +110,14 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
     constexpr int NC = XG_PACK_CELLS / 256;
     xh_cf f[NC];
     float cm[NC], cc[NC];
-    bool in[NC];
+    bool in[NC], far[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const unsigned c = blockIdx.x * XG_PACK_CELLS + k * 256 + threadIdx.x;
         const unsigned row = c / SX;
         const int x = (int)(c - row * SX) - XG_PAD, y = (int)row - XG_PAD;
         in[k] = x >= 0 && x < sizeX && y >= 0 && y < sizeY;     // false beyond the last cell too (y >= sizeY)
+        far[k] = x * x + (y - sizeY / 2) * (y - sizeY / 2) > skipR2;      // beyond every tap's reach (k_rf_pack_grid_ctf): left alone
         const size_t o = src + (size_t)(in[k] ? y * sizeX + x : 0);
         f[k] = xh_cf{0.f, 0.f}; cm[k] = 1.f; cc[k] = 1.f;
         if (in[k]) {
@@ -128,6 +129,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
     for (int k = 0; k < NC; ++k) {
         const unsigned c = blockIdx.x * XG_PACK_CELLS + k * 256 + threadIdx.x;
         if (c >= cells) break;
+        if (far[k]) continue;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in[k]) {
             if (ctfs) { const float mw = cm[k] * w; v = make_float4(f[k].x * mw * cc[k], f[k].y * mw * cc[k], mw, 0.f); }
@@ -143,7 +145,7 @@ k_rf_pack_grid(const xh_cf *__restrict__ ffts, const float *__restrict__ ctfs, c
 // and its mirror row (x, dc - k): a non-astigmatic CTF is the same on both, evaluated once (see k_rf_ctf).
 __global__ void __launch_bounds__(256)
 k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ cp, const float *__restrict__ weights,
-                   XgCell *__restrict__ pk, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped)
+                   XgCell *__restrict__ pk, int sizeX, int sizeY, int P, double iTs, double minCTF, int phaseFlipped, int skipR2)
 {
     const int SX = sizeX + 2 * XG_PAD, SY = sizeY + 2 * XG_PAD;
     const int dc = P / 2;
@@ -151,15 +153,23 @@ k_rf_pack_grid_ctf(const xh_cf *__restrict__ ffts, const XhCtfDev *__restrict__ 
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (unsigned)K * SX) return;
     const int k = c / (unsigned)SX, x = (int)(c - k * SX) - XG_PAD;
+    // Cells no tap can reach stay as they are (zero since the buffer was allocated, or an earlier batch's finite values): the
+    // traversal keeps voxels within sizeX + r of the origin (RFA:640), their image coordinates lie within that radius too and a tap
+    // within r of them, so a pixel further than sizeX + 2 r from the origin only ever meets the table's zero entry.  A quarter of the
+    // record, of its CTF evaluations and of its bytes (round 6).  (The origin of the record's rows is sizeY / 2 -- where the gridding
+    // kernel puts it --, which is the CTF's centre row dc = P / 2 only when nothing was cropped.)
+    const int g1 = dc + k - sizeY / 2, g2 = dc - k - sizeY / 2;
+    const bool far1 = x * x + g1 * g1 > skipR2, far2 = x * x + g2 * g2 > skipR2;
+    if (far1 && far2) return;
     const unsigned img = blockIdx.y;
     const XhCtfDev par = cp[img];
     const float w = weights ? weights[img] : 1.f;
     const xh_cf *src = ffts + (size_t)img * sizeX * sizeY;
     XgCell *dst = pk + (size_t)img * SX * SY;
     const int y1 = dc + k, y2 = dc - k;
-    const bool row1 = y1 < sizeY + XG_PAD, row2 = k > 0 && y2 >= -XG_PAD && y2 < sizeY + XG_PAD;
+    const bool row1 = y1 < sizeY + XG_PAD && !far1, row2 = k > 0 && y2 >= -XG_PAD && y2 < sizeY + XG_PAD && !far2;
     const bool inx = x >= 0 && x < sizeX;
-    const bool in1 = inx && y1 < sizeY, in2 = inx && k > 0 && y2 >= 0 && y2 < sizeY;
+    const bool in1 = inx && y1 < sizeY && !far1, in2 = inx && k > 0 && y2 >= 0 && y2 < sizeY && !far2;
     xh_cf f1 = xh_cf{0.f, 0.f}, f2 = f1;
     if (in1) f1 = src[(size_t)y1 * sizeX + x];
     if (in2) f2 = src[(size_t)y2 * sizeX + x];
