@@ -270,6 +270,7 @@ struct xh_rf {
     XhBuf d_finSpec, d_finVol, d_finFbt;   // the finaliser's expanded spectrum, output volume and Fourier blob table
     int shift_bands = 1;  // 256-px images shifted band by band out of LDS (k_rf_shift_band; 0: k_rf_shift, for A/B)
     int skip_far_cells = 1;   // the pack kernels skip the record cells no tap can reach (0: every cell written, for A/B)
+    int fftSkipR2 = 0x7fffffff;   // set by xh_rf_insert_images* around its own projection FFT: spectra cells beyond that radius are not stored
     int order_spaces = 1; // the traverse spaces of a launch ordered by plane, so that k_rf_grid reuses voxel queues (0: input order, for A/B)
     XhBuf d_spacePos;
     int ctf_fast = 1;     // envelope-free CTFs through d_ctf_pixel_fast (0: the general double-precision formula everywhere, for A/B)
@@ -903,7 +904,7 @@ template <int R1, int R2, bool PACK>
 __global__ void __launch_bounds__(256)
 k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, XgCell *__restrict__ pk, const XhCtfDev *__restrict__ cp,
            const float *__restrict__ weights, const xh_cf *__restrict__ W, int D, int TD, int sizeX, double maxResSqr, int nlines,
-           double iTs, double minCTF, int phaseFlipped)
+           double iTs, double minCTF, int phaseFlipped, int skipR2)
 {
     typedef TrGeom<R1, R2, float> G;
     constexpr int P = G::D, ZS = P + 1;
@@ -978,6 +979,8 @@ k_rf_rowsB(const xh_cf *__restrict__ T, xh_cf *__restrict__ out, XgCell *__restr
                 }
             }
             if constexpr (!PACK) {
+                // (skipR2: the caller is the gridding path, which never looks at a pixel beyond every tap's reach, k_rf_pack_grid_ctf)
+                if (j * j + k * k > skipR2) continue;
                 if (in1) out[((size_t)img * sizeY + r1) * sizeX + j] = o1;
                 if (in2) out[((size_t)img * sizeY + r2) * sizeX + j] = o2;
             } else {
@@ -1642,12 +1645,12 @@ static int fft_cols_rows(xh_rf *rf, const float *d_imgs, int n, xh_cf *d_fft, Xg
                                (const xh_cf *)rf->d_rows.p, (xh_cf *)nullptr, d_pk + (size_t)i0 * recCells,                          \
                                (const XhCtfDev *)rf->d_ctfp.p + i0, d_weights ? d_weights + i0 : nullptr,                           \
                                (const xh_cf *)rf->d_twP32.p, D, TD, sizeX, maxResSqr, nlines, 1.0 / rf->p.sampling, rf->p.min_ctf,    \
-                               rf->p.phase_flipped);                                                                                \
+                               rf->p.phase_flipped, 0x7fffffff);                                                                    \
         else                                                                                                                        \
             hipLaunchKernelGGL((k_rf_rowsB<A_, B_, false>), dim3(m * ((nlines + G::LN - 1) / G::LN)), dim3(256), G::smem, ctx->stream, \
                                (const xh_cf *)rf->d_rows.p, d_fft + (size_t)i0 * rf->sizeY * sizeX, (XgCell *)nullptr,               \
                                (const XhCtfDev *)nullptr, (const float *)nullptr, (const xh_cf *)rf->d_twP32.p, D, TD, sizeX, maxResSqr, \
-                               nlines, 0.0, 0.0, 0);                                                                                \
+                               nlines, 0.0, 0.0, 0, rf->fftSkipR2);                                                                 \
     }
         if (P == 512) XH_RFB(16, 32)
         else if (P == 256) XH_RFB(16, 16)
@@ -2067,7 +2070,12 @@ int xh_rf_insert_images(xh_rf *rf, const float *d_imgs, const xh_ctf_params *h_c
     const bool fromImages = fuse && rf->records_from_images && fft_cols_rows_ok(rf);   // records straight from the images (A/B)
     if (!fromImages) {
         XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
-        XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+        // (the spectra go to the pack kernels only, which skip what no tap can reach: the row pass need not store it)
+        const int skipR = rf->sizeX + (int)std::ceil(2.0 * rf->p.blob_radius) + 2;
+        rf->fftSkipR2 = rf->skip_far_cells ? skipR * skipR : 0x7fffffff;
+        const int rcp = xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p);
+        rf->fftSkipR2 = 0x7fffffff;
+        if (rcp != XH_OK) return rcp;
     }
     rf->packCtf = fuse;
     rf->packImgs = fromImages ? d_imgs : nullptr;
@@ -2103,7 +2111,11 @@ int xh_rf_insert_images_dev(xh_rf *rf, const float *d_imgs, const xh_ctf_params 
     const bool fromImages = fuse && rf->records_from_images && fft_cols_rows_ok(rf);   // records straight from the images (A/B)
     if (!fromImages) {
         XH_TRY(xh_buf_reserve(ctx, rf->d_spectra, plane * sizeof(xh_cf)));
-        XH_TRY(xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p));
+        const int skipR = rf->sizeX + (int)std::ceil(2.0 * rf->p.blob_radius) + 2;      // (as in xh_rf_insert_images)
+        rf->fftSkipR2 = rf->skip_far_cells ? skipR * skipR : 0x7fffffff;
+        const int rcp = xh_rf_prepare_images(rf, d_imgs, n, (float *)rf->d_spectra.p);
+        rf->fftSkipR2 = 0x7fffffff;
+        if (rcp != XH_OK) return rcp;
     }
     const int ns = n * nsym;
     const double *d_sym = nullptr;
