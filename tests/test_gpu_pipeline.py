@@ -84,3 +84,43 @@ def test_two_streams_give_the_one_stream_results():
             # flagged particles in the order an atomic counter hands them out)
             assert all(np.abs(x - y).max() <= 1e-12 for x, y in zip(a[3:], b[3:]))
         assert np.array_equal(v1, v2) and np.array_equal(w1, w2)                             # temp spaces: the same bits
+
+
+def test_host_feed_entry_points():
+    """The ABI's pieces for a host that feeds the device while it computes (xmipp3_amd/host/fastio.h uses them from C++): page-locked
+    memory, copies that only enqueue, one context's stream waiting for another's on the device, the device's NUMA node."""
+    import ctypes as C
+    import torch
+    from xmipp3_amd import _lib
+    L = _lib.lib()
+    a, b = C.c_void_p(), C.c_void_p()
+    assert L.xh_ctx_create_private(0, C.byref(a)) == 0 and L.xh_ctx_create_private(0, C.byref(b)) == 0
+    n = 1 << 22
+    hp, hq, d1, d2 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.xh_host_alloc(a, n * 4, C.byref(hp)) == 0 and L.xh_host_alloc(a, n * 4, C.byref(hq)) == 0
+    assert L.xh_malloc(a, n * 4, C.byref(d1)) == 0 and L.xh_malloc(a, n * 4, C.byref(d2)) == 0
+    src = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), (n,))
+    dst = np.ctypeslib.as_array(C.cast(hq, C.POINTER(C.c_float)), (n,))
+    src[:] = np.arange(n, dtype=np.float32)
+    dst[:] = -1
+    # a: host -> d1 (enqueued only); b waits for a on the device, copies d1 -> host through its own stream
+    assert L.xh_memcpy_h2d_async(a, d1, hp, n * 4) == 0
+    assert L.xh_ctx_wait_for(b, a) == 0
+    assert L.xh_memcpy_d2h_async(b, hq, d1, n * 4) == 0
+    assert L.xh_ctx_sync(b) == 0
+    assert np.array_equal(dst, src)
+    node = C.c_int(-5)
+    assert L.xh_device_numa_node(0, C.byref(node)) == 0 and node.value >= -1
+    # contexts on different devices cannot wait for each other; null arguments are refused
+    assert L.xh_ctx_wait_for(b, None) != 0 and L.xh_host_alloc(a, 16, None) != 0
+    assert L.xh_host_free(a, hp) == 0 and L.xh_host_free(a, hq) == 0 and L.xh_host_free(a, None) == 0
+    assert L.xh_free(a, d1) == 0 and L.xh_free(a, d2) == 0
+    # the crop used by the size-search stand-in of the movie program
+    fr = torch.arange(2 * 6 * 8, dtype=torch.float32, device="cuda").reshape(2, 6, 8)
+    out = torch.empty((2, 4, 5), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    assert L.xh_movie_crop_frames(a, C.c_void_p(fr.data_ptr()), 2, 6, 8, 4, 5, C.c_void_p(out.data_ptr())) == 0
+    assert L.xh_ctx_sync(a) == 0
+    assert torch.equal(out, fr[:, :4, :5])
+    assert L.xh_movie_crop_frames(a, C.c_void_p(fr.data_ptr()), 2, 6, 8, 7, 5, C.c_void_p(out.data_ptr())) != 0
+    assert L.xh_ctx_destroy(a) == 0 and L.xh_ctx_destroy(b) == 0
