@@ -27,6 +27,9 @@
 #ifndef XH_RF_GRID_H
 #define XH_RF_GRID_H
 
+#ifndef XG_TAPMASK
+#define XG_TAPMASK 0            // 1: taps beyond the blob switched off with an execution mask instead of a select (A/B: tools/build_variant.sh)
+#endif
 #ifndef XG_PAD
 #define XG_PAD 6                // zero cells around a packed record: a 6 x 6 footprint (blob radius < 3) starts at ceil(-2 r) >= -5
 #endif
@@ -56,7 +59,19 @@ template <int W, int ZD, int NW> struct XgCfg {
     static constexpr int NDMA = (PN * PW + 63) / 64;
     static constexpr int PATCH_BYTES = TIGHT ? PN * PW * 16 : NDMA * 1024;
     static constexpr int KCAP = TIGHT ? 32 : 64;
-    static constexpr int HALVES = TIGHT ? 2 : 1;           // the 4 x 4 footprint in one go or two rows at a time (registers)
+    // The 4 x 4 footprint in one go, two rows at a time (registers: fourteen waves and more) or -- the product's twelve waves -- row by
+    // row with the records and table entries of the next row requested before this row's multiply-adds (PIPE: two register sets; 133
+    // registers instead of 167 and 1.4 % off the launch, round 6: profiles/experiments/r06_ab_grid_pipeline.txt)
+#ifdef XG_HALVES
+    static constexpr int HALVES = XG_HALVES;               // A/B builds (tools/build_variant.sh)
+#else
+    static constexpr int HALVES = (W == 4 && NW == 12) ? 4 : (TIGHT ? 2 : 1);
+#endif
+#ifdef XG_PIPE
+    static constexpr bool PIPE = XG_PIPE != 0 && HALVES >= 2;
+#else
+    static constexpr bool PIPE = HALVES == 4;
+#endif
     static constexpr int NVOX = 64 * ZD;
     static constexpr int LDS_PATCH = 0;                                  // [NW][PATCH_BYTES]; first, so that LDS-DMA bases stay below 64 KB
     static constexpr int LDS_BLOB = NW * PATCH_BYTES;                    // float[XH_BLOB_TABLE + 4]; entry XH_BLOB_TABLE is 0
@@ -662,6 +677,93 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
                             const xg_v2f yz01 = ya * ya + z2, yz23 = yb * yb + z2;
                             const float yz[4] = {yz01.x, yz01.y, yz23.x, yz23.y};
                             constexpr int NT = 16 / C::HALVES, NR = 4 / C::HALVES;     // taps and footprint rows per go
+                            if constexpr (C::PIPE) {
+                            // NR footprint rows at a time, the records and table entries of the next go requested before this go's
+                            // multiply-adds (two register sets)
+                            xg_v4f qq[2][NT];
+#if XG_TAPMASK
+                            typedef xg_v2f xg_wt;           // a table entry in the low half of a register pair: the packed multiply-add's operand as it is
+#else
+                            typedef float xg_wt;
+#endif
+                            xg_wt ww[2][NT];
+#if XG_TAPMASK
+                            // A tap beyond the blob (d > r^2, RFA:679) is switched off instead of being sent to the table's zero entry: its
+                            // distance stays in a register until the multiply-adds, where v_cmpx takes its lane out of EXEC for the two of
+                            // them (compare + select + 2 multiply-adds -> compare + 2 multiply-adds; what a dead lane read from the table
+                            // -- its index is not clamped any more, the LDS returns zero or whatever lies there -- is never used)
+                            float dd[2][NT];
+                            const unsigned long long lanesOn = __builtin_amdgcn_read_exec();
+#endif
+                            auto loadq = [&](int h, xg_v4f (&q_)[NT]) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) q_[t] = tap[(h * NR + t / 4) * PW + (t & 3)];
+                            };
+                            auto loadw = [&](int h, xg_wt (&w_)[NT], float *d_) {
+                                int aux[NT];
+#pragma unroll
+                                for (int a = 0; a < NR; ++a) {
+                                    const xg_v2f ya2 = {yz[h * NR + a], yz[h * NR + a]};
+                                    const xg_v2f d01 = xs01 + ya2, d23 = xs23 + ya2;
+                                    const xg_v2f t01 = d01 * idel2 + half2, t23 = d23 * idel2 + half2;
+#if XG_TAPMASK
+                                    d_[a * 4 + 0] = d01.x; d_[a * 4 + 1] = d01.y; d_[a * 4 + 2] = d23.x; d_[a * 4 + 3] = d23.y;
+                                    aux[a * 4 + 0] = (int)t01.x; aux[a * 4 + 1] = (int)t01.y; aux[a * 4 + 2] = (int)t23.x; aux[a * 4 + 3] = (int)t23.y;
+#else
+                                    aux[a * 4 + 0] = (int)(d01.x > radiusSqr ? limf : t01.x);
+                                    aux[a * 4 + 1] = (int)(d01.y > radiusSqr ? limf : t01.y);
+                                    aux[a * 4 + 2] = (int)(d23.x > radiusSqr ? limf : t23.x);
+                                    aux[a * 4 + 3] = (int)(d23.y > radiusSqr ? limf : t23.y);
+#endif
+                                }
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+#if XG_TAPMASK
+                                    w_[t].x = sBlob[aux[t]];                    // (.y stays undefined on purpose: never read, op_sel_hi 0)
+#else
+                                    w_[t] = sBlob[aux[t]];
+#endif
+                                }
+                            };
+                            auto fmas = [&](xg_v4f (&q_)[NT], xg_wt (&w_)[NT], const float *d_) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+#if XG_TAPMASK
+                                    const xg_v2f w2 = w_[t];                    // (the packed instruction reads the low half for both products: op_sel_hi 0)
+                                    const xg_v2f qxy = {q_[t].x, q_[t].y};
+                                    // !(d > r^2), the reference's test with the reference's operands: v_cmpx_nlt r^2, d
+                                    asm volatile("v_cmpx_nlt_f32_e32 vcc, %[r2], %[d]\n\t"
+                                                 "v_pk_fma_f32 %[ri], %[w2], %[qxy], %[ri] op_sel_hi:[0,1,1]\n\t"
+                                                 "v_fmac_f32_e32 %[aw], %[w], %[qz]\n\t"
+                                                 "s_mov_b64 exec, %[on]"
+                                                 : [ri] "+v"(accRI), [aw] "+v"(accW)
+                                                 : [r2] "s"(radiusSqr), [d] "v"(d_[t]), [w2] "v"(w2), [qxy] "v"(qxy), [w] "v"(w2.x), [qz] "v"(q_[t].z), [on] "s"(lanesOn)
+                                                 : "vcc");
+#else
+                                    const xg_v2f w2 = {w_[t], w_[t]};
+                                    accRI = __builtin_elementwise_fma(w2, (xg_v2f){q_[t].x, q_[t].y}, accRI);
+                                    accW = __builtin_fmaf(w_[t], q_[t].z, accW);
+#endif
+                                    asm volatile("" :: "v"(q_[t].w));
+                                }
+                            };
+#if XG_TAPMASK
+#define XG_DD(i) dd[i]
+#else
+#define XG_DD(i) nullptr
+#endif
+                            loadq(0, qq[0]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            loadw(0, ww[0], XG_DD(0));
+#pragma unroll
+                            for (int h = 0; h < C::HALVES; ++h) {
+                                if (h + 1 < C::HALVES) { loadq(h + 1, qq[(h + 1) & 1]); loadw(h + 1, ww[(h + 1) & 1], XG_DD((h + 1) & 1)); }
+                                __builtin_amdgcn_sched_barrier(0);
+                                fmas(qq[h & 1], ww[h & 1], XG_DD(h & 1));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#undef XG_DD
+                            } else
 #pragma unroll
                             for (int h = 0; h < C::HALVES; ++h) {
                                 // the records are requested before the index arithmetic of the weights, which they do not depend
