@@ -680,19 +680,23 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
                             if constexpr (C::PIPE) {
                             // NR footprint rows at a time, the records and table entries of the next go requested before this go's
                             // multiply-adds (two register sets)
-                            xg_v4f qq[2][NT];
+#ifndef XG_PIPE_DEPTH
+#define XG_PIPE_DEPTH 1                                     // goes requested ahead of the multiply-adds (A/B: 2 = three register sets)
+#endif
+                            constexpr int PD = XG_PIPE_DEPTH, NS = PD + 1;
+                            xg_v4f qq[NS][NT];
 #if XG_TAPMASK
                             typedef xg_v2f xg_wt;           // a table entry in the low half of a register pair: the packed multiply-add's operand as it is
 #else
                             typedef float xg_wt;
 #endif
-                            xg_wt ww[2][NT];
+                            xg_wt ww[NS][NT];
 #if XG_TAPMASK
                             // A tap beyond the blob (d > r^2, RFA:679) is switched off instead of being sent to the table's zero entry: its
                             // distance stays in a register until the multiply-adds, where v_cmpx takes its lane out of EXEC for the two of
                             // them (compare + select + 2 multiply-adds -> compare + 2 multiply-adds; what a dead lane read from the table
                             // -- its index is not clamped any more, the LDS returns zero or whatever lies there -- is never used)
-                            float dd[2][NT];
+                            float dd[NS][NT];
                             const unsigned long long lanesOn = __builtin_amdgcn_read_exec();
 #endif
                             auto loadq = [&](int h, xg_v4f (&q_)[NT]) {
@@ -752,14 +756,17 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
 #else
 #define XG_DD(i) nullptr
 #endif
-                            loadq(0, qq[0]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            loadw(0, ww[0], XG_DD(0));
+#pragma unroll
+                            for (int h = 0; h < PD && h < C::HALVES; ++h) {
+                                loadq(h, qq[h % NS]);
+                                if (h == 0) __builtin_amdgcn_sched_barrier(0);
+                                loadw(h, ww[h % NS], XG_DD(h % NS));
+                            }
 #pragma unroll
                             for (int h = 0; h < C::HALVES; ++h) {
-                                if (h + 1 < C::HALVES) { loadq(h + 1, qq[(h + 1) & 1]); loadw(h + 1, ww[(h + 1) & 1], XG_DD((h + 1) & 1)); }
+                                if (h + PD < C::HALVES) { loadq(h + PD, qq[(h + PD) % NS]); loadw(h + PD, ww[(h + PD) % NS], XG_DD((h + PD) % NS)); }
                                 __builtin_amdgcn_sched_barrier(0);
-                                fmas(qq[h & 1], ww[h & 1], XG_DD(h & 1));
+                                fmas(qq[h % NS], ww[h % NS], XG_DD(h % NS));
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #undef XG_DD
