@@ -47,11 +47,11 @@ R5 = [
 R6 = [
     ("host side of the programs", "reader threads that enqueue their own H2D copies on their own streams (16 / 32 / 64 readers)", "profiles/experiments/r06_cli_sweeps.txt", "image loop of `xmipp_angular_projection_matching` 75 / 52 / 30 k particles/s: the runtime serialises the threads and the compute thread's launches with them", "no"),
     ("host side of the programs", "persistent reader pool (pread into page-locked 4 MB pieces) + copier threads that alone talk to the runtime; one / two copiers, pieces of 4 / 8 / 16 MB", "profiles/experiments/r06_cli_sweeps.txt", "one copier 152-158 k, two copiers 176 / 168 / 150 k particles/s at 256 px", "yes (two copiers, 4 MB)"),
-    ("host side of the programs", "loader threads and their page-locked memory bound to the device's NUMA node (`xh_device_numa_node`)", "profiles/r06_b_ubench_hostfeed.txt", "H2D beside 16 readers on a two-socket host: 21 GB/s unbound, 56 GB/s bound to either node; readers alone 73 -> 97 GB/s on the device's node", "yes"),
+    ("host side of the programs", "loader threads and their page-locked memory bound to the device's NUMA node (`xh_device_numa_node`)", "profiles/r06_c_ubench_hostfeed.txt", "H2D beside 16 readers on a two-socket host: 21 GB/s unbound, 56 GB/s bound to either node; readers alone 73 -> 97 GB/s on the device's node", "yes"),
     ("host side of the programs", "whole batches page-locked (2 x 1.07 GB) instead of pieces", "profiles/experiments/r06_cli_sweeps.txt", "page-locking costs 0.25 s per GB: 0.52 s of a 1.4 s run", "no (256 MB of pieces)"),
     ("FlexAlign global", "sums of the pruned transforms and the pair windows in blocks of 16 / 32 terms (block sums apart from the total)", "profiles/experiments/r06_flexalign_precision.txt", "K3 parity sample 7.9e-4 -> 3.5e-5 px, but `k_fa_pairwin_a2` 2.16 -> 4.47 ms (twice the accumulators: 3 instead of 5 waves per SIMD); with half the rows per thread 8.3 -> 9.4 ms per movie for the stage", "no"),
-    ("FlexAlign global", "the mean of the correlation map (its (0, 0) coefficient) left out of the window sums and of the full inverse transform: bestShift subtracts it again", "profiles/r06_b_flexalign_precision_k3.txt", "K3 parity sample 7.9e-4 -> 2.6e-6 px at round 5's speed (8e-8 through the full inverse transform): the digits were lost to adding small terms to a sum dominated by the mean, not to the length of the sums", "yes"),
-    ("gridding kernel", "kernels of the matcher BESIDE the gridding kernel on the same CUs: `grid_waves` 8 leaves 42 KB of LDS and 176 registers per lane, S6's kernels (<= 100 registers, <= 37 KB) fit", "profiles/r06_b_exp_corun.txt, profiles/r06_b_ubench_coresidency.txt", "they do co-reside (microbenchmark and kernel trace) and the work is purely additive: 4 x S6 (16 ms alone) beside a 33.6 ms insert = 50.0 ms; 29.5 + 16 = 45.1 at twelve waves.  Both sides are bound by vector issue; the fp64 repeat kernels and `k_pm_ringdft_mfma` / `k_pm_idft_max3` (225 / 233 registers) do not fit and block their stream until the launch ends", "no"),
+    ("FlexAlign global", "the mean of the correlation map (its (0, 0) coefficient) left out of the window sums and of the full inverse transform: bestShift subtracts it again", "profiles/r06_c_flexalign_precision_k3.txt", "K3 parity sample 7.9e-4 -> 2.6e-6 px at round 5's speed (8e-8 through the full inverse transform): the digits were lost to adding small terms to a sum dominated by the mean, not to the length of the sums", "yes"),
+    ("gridding kernel", "kernels of the matcher BESIDE the gridding kernel on the same CUs: `grid_waves` 8 leaves 42 KB of LDS and 176 registers per lane, S6's kernels (<= 100 registers, <= 37 KB) fit", "profiles/r06_c_exp_corun.txt, profiles/r06_c_ubench_coresidency.txt", "they do co-reside (microbenchmark and kernel trace) and the work is purely additive: 4 x S6 (16 ms alone) beside a 33.6 ms insert = 50.0 ms; 29.5 + 16 = 45.1 at twelve waves.  Both sides are bound by vector issue; the fp64 repeat kernels and `k_pm_ringdft_mfma` / `k_pm_idft_max3` (225 / 233 registers) do not fit and block their stream until the launch ends", "no"),
     ("gridding kernel", "the 4 x 4 footprint row by row, the records and table entries of the next row requested before this row's multiply-adds (`XgCfg::HALVES` 4, `XgCfg::PIPE`); also two rows at a time, with and without the prefetch, at 12 and 16 waves", "profiles/experiments/r06_ab_grid_pipeline.txt", "23.49 -> 23.15 ms per launch alone (167 -> 133 registers, bit-identical); two rows: 23.3; sixteen waves no better (23.3-24.7)", "yes (row by row + prefetch at twelve waves)"),
     ("gridding kernel", "taps beyond the blob switched off with `v_cmpx` for their two multiply-adds instead of compare + select to the table's zero entry (`-DXG_TAPMASK=1`; possible once the footprint runs row by row: four distances live instead of sixteen)", "profiles/experiments/r06_ab_grid_pipeline.txt", "dense block 155 -> 140 vector instructions, bit-identical, and 4 % SLOWER (22.9 -> 23.9 ms): the select had been sending 53 % of the table reads to one address (a broadcast); unclamped the dead lanes read all over the LDS, and every `v_cmpx` is an EXEC write the next instruction waits for", "no"),
     ("gridding records", "the pack kernels and the projection FFT's row pass leave the record / spectrum cells no tap can reach alone (pixels further than sizeX + 2 r from the origin only ever meet the table's zero entry; record buffer zeroed when allocated)", "gpurun A/B (`--rf-opt skip_far_cells=0`)", "a quarter of the records, their CTF evaluations and bytes: step 38.76 -> 38.39 ms", "yes"),
