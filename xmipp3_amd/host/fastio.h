@@ -450,14 +450,17 @@ struct HostTiming {
     }
 };
 
-// Two device buffers of `capacity` images and the threads that fill them.  `readers` reader threads take 4 MB pieces of a batch
-// (runs of consecutive images) off a counter and pread() them into page-locked memory, two pieces per reader; two copier threads, a copy
-// stream each, are the only ones to talk to the runtime: each enqueues pieces that are ready, waits for its stream and hands them
-// back.  (Measured on the 256-core host: readers that enqueue their own copies on their own streams get slower with every reader added --
-// 75 k particles/s with 16, 30 k with 64 -- the runtime serialises them and the compute thread's launches with them.  Page-locking
-// costs ~0.25 s per GB, so the batch itself is never page-locked.)
-// request(k) starts batch k into device buffer k & 1; take(k) waits until it is in HBM.  The copy stream first waits (on the device)
-// for everything the compute context had been given when request() was called: the buffer it overwrites was last read by batch k - 2.
+// Two device buffers of `capacity` images and the threads that fill them.  A batch is cut into pieces of 4 MB (runs of consecutive
+// images); piece number g of the run (counted across batches) owns slot g % R of ONE page-locked ring of R pieces.  `readers` threads take
+// pieces off a counter and pread() them into their slots; ONE copier thread -- the only one to talk to the runtime -- waits for the
+// next piece in order, takes every consecutive piece that is ready with it and sends the whole run as one copy (neighbours in the ring
+// are neighbours on the device), alternating between two copy streams so that a copy is queued while the previous one flies; a slot is
+// handed back when its copy has completed.  Large copies are what the link wants: 43 GB/s in 4 MB copies, 55 in 16 MB ones
+// (tools/ubench_hostfeed.hip).  (Measured on the 256-core host: readers that enqueue their own copies on their own streams get slower
+// with every reader added -- 75 k particles/s with 16, 30 k with 64: the runtime serialises them and the compute thread's launches
+// with them.  Page-locking costs ~0.25 s per GB, so the batch itself is never page-locked.)
+// request(k) starts batch k into device buffer k & 1; take(k) waits until it is in HBM.  The copy streams first wait (on the device)
+// for everything the compute context had been given when request() was called: the buffer they overwrite was last read by batch k - 2.
 class BatchFeeder {
 public:
     StackSource source;
@@ -470,157 +473,186 @@ public:
         {
             std::unique_lock<std::mutex> lk(m);
             if (!started) return;
-            cvDone.wait(lk, [&] { return !active || done + failed == npieces; });
+            cvDone.wait(lk, [&] { return !active || copied + failed >= npieces; });
             stop = true;
             started = false;
         }
         cvWork.notify_all();
         cvCopy.notify_all();
+        cvSlot.notify_all();
         for (auto &t : threads) t.join();
         threads.clear();
-        for (Reader &r : rd) for (int s = 0; s < 2; ++s) if (r.pin[s]) xh_host_free(copyCtx, r.pin[s]);
-        rd.clear();
-        for (int s = 0; s < 2; ++s) { if (d[s]) xh_free(copyCtx, d[s]); d[s] = nullptr; }
-        for (xh_ctx *c : copiers) if (c) xh_ctx_destroy(c);
-        copiers.clear();
-        copyCtx = nullptr;
+        if (ring) xh_host_free(copyCtx[0], ring);
+        ring = nullptr;
+        for (int s = 0; s < 2; ++s) { if (d[s]) xh_free(copyCtx[0], d[s]); d[s] = nullptr; }
+        for (int c = 0; c < 2; ++c) { if (copyCtx[c]) xh_ctx_destroy(copyCtx[c]); copyCtx[c] = nullptr; }
     }
     void create(int device, size_t dim_, size_t capacity_, int readers, HostTiming *tm)
     {
         dim = dim_; capacity = capacity_; timing = tm;
         const size_t per = dim * dim;
-        const char *ePiece = getenv("XMIPP_HIP_PIECE_MB"), *eCop = getenv("XMIPP_HIP_COPIERS");      // (A/B knobs of tools/cli_sweep.sh)
-        const size_t pieceBytes = (size_t)std::max(1, ePiece ? atoi(ePiece) : 8) << 20;
-        const size_t ncop = (size_t)std::max(1, std::min(4, eCop ? atoi(eCop) : 2));
+        const char *ePiece = getenv("XMIPP_HIP_PIECE_MB"), *eRing = getenv("XMIPP_HIP_RING_MB");      // (A/B knobs of tools/cli_sweep.sh)
+        const size_t pieceBytes = (size_t)std::max(1, ePiece ? atoi(ePiece) : 4) << 20;
         pieceImages = std::max<size_t>(1, pieceBytes / (per * sizeof(float)));
-        const size_t nr = std::max<size_t>(1, std::min<size_t>((size_t)hostThreads(readers), (capacity + pieceImages - 1) / pieceImages));
-        xhCheck(xh_ctx_create_private(device, &copyCtx));
-        copiers.assign(ncop, nullptr);
-        copiers[0] = copyCtx;
-        for (size_t c = 1; c < ncop; ++c) xhCheck(xh_ctx_create_private(device, &copiers[c]));
-        for (int s = 0; s < 2; ++s) xhCheck(xh_malloc(copyCtx, capacity * per * sizeof(float), (void **)&d[s]));
-        rd.resize(nr);
-        runOnSlots(std::min<size_t>(nr, 8), [&](size_t t) {                 // (page-locking is per call: a few threads lock the pieces side by side)
-            for (size_t r = t; r < nr; r += std::min<size_t>(nr, 8))
-                for (int s = 0; s < 2; ++s) xhCheck(xh_host_alloc(copyCtx, pieceImages * per * sizeof(float), (void **)&rd[r].pin[s]));
-        });
+        const size_t batchPieces = (capacity + pieceImages - 1) / pieceImages;
+        const size_t nr = std::max<size_t>(1, std::min<size_t>((size_t)hostThreads(readers), batchPieces));
+        // the ring: room for every reader's piece in progress plus the copies in flight (256 MB unless the batch is smaller)
+        const size_t ringBytes = (size_t)std::max(16, eRing ? atoi(eRing) : 256) << 20;
+        R = std::max<size_t>(2 * nr, std::min<size_t>(std::max<size_t>(2 * nr, batchPieces), ringBytes / (pieceImages * per * sizeof(float))));
+        for (int c = 0; c < 2; ++c) xhCheck(xh_ctx_create_private(device, &copyCtx[c]));
+        for (int s = 0; s < 2; ++s) xhCheck(xh_malloc(copyCtx[0], capacity * per * sizeof(float), (void **)&d[s]));
+        xhCheck(xh_host_alloc(copyCtx[0], R * pieceImages * per * sizeof(float), (void **)&ring));
+        ready.assign(R, 0);
         stop = false; started = true; active = false;
-        for (size_t r = 0; r < nr; ++r) threads.emplace_back([this, r] { readerLoop(r); });
-        for (size_t c = 0; c < ncop; ++c) threads.emplace_back([this, c] { copierLoop(copiers[c]); });
+        for (size_t r = 0; r < nr; ++r) threads.emplace_back([this] { readerLoop(); });
+        threads.emplace_back([this] { copierLoop(); });
     }
     // where the images of batch k lie -> device buffer k & 1; `compute`: the context whose queued work must finish before the buffer is overwritten
     void request(size_t k, std::vector<StackSource::Loc> locs_, xh_ctx *compute)
     {
         if (locs_.size() > capacity) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: batch larger than the buffers");
-        if (compute) for (xh_ctx *c : copiers) xhCheck(xh_ctx_wait_for(c, compute));
+        if (compute) for (int c = 0; c < 2; ++c) xhCheck(xh_ctx_wait_for(copyCtx[c], compute));
         {
             std::lock_guard<std::mutex> lk(m);
             if (active) REPORT_ERROR(ERR_LOGIC_ERROR, "BatchFeeder: request() before take()");
             locs = std::move(locs_);
             slot = (int)(k & 1);
+            base += npieces;                       // the pieces of this batch continue the ring where the last batch stopped
             npieces = (locs.size() + pieceImages - 1) / pieceImages;
-            next = 0; done = 0; failed = 0; err = nullptr;
+            next = 0; copied = 0; failed = 0; err = nullptr;
             active = true;
-            ++generation;
             t0 = nowSeconds();
         }
         cvWork.notify_all();
+        cvCopy.notify_all();
     }
     float *take(size_t k)
     {
         const double w0 = nowSeconds();
         std::unique_lock<std::mutex> lk(m);
-        cvDone.wait(lk, [&] { return done + failed == npieces; });
+        cvDone.wait(lk, [&] { return copied + failed >= npieces; });
         active = false;
-        if (timing) { timing->stall += nowSeconds() - w0; timing->load += tEnd - t0; }
+        if (timing) { timing->stall += nowSeconds() - w0; timing->load += tEnd - t0; timing->h2d += std::max(0.0, tEnd - tRead); }
         if (err) std::rethrow_exception(err);
         return d[k & 1];
     }
 
 private:
-    struct Reader { float *pin[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; };
-    struct CopyJob { size_t reader; int buf; size_t first, count; };
-    std::vector<Reader> rd;
     std::vector<std::thread> threads;
-    std::vector<CopyJob> queue;
     std::mutex m;
-    std::condition_variable cvWork, cvCopy, cvDone, cvBuf;
-    xh_ctx *copyCtx = nullptr;              // = copiers[0]; owns the buffers
-    std::vector<xh_ctx *> copiers;          // one stream per copier thread: the copies of one are queued while the other waits for its own
-    float *d[2] = {nullptr, nullptr};
+    std::condition_variable cvWork, cvCopy, cvDone, cvSlot;
+    xh_ctx *copyCtx[2] = {nullptr, nullptr};
+    float *d[2] = {nullptr, nullptr}, *ring = nullptr;
     std::vector<StackSource::Loc> locs;
-    size_t pieceImages = 1, npieces = 0, next = 0, done = 0, failed = 0;
-    uint64_t generation = 0;
+    std::vector<char> ready;             // per ring slot: the piece in it has been read and waits for its copy
+    size_t pieceImages = 1, R = 2;
+    size_t base = 0;                     // ring sequence number of the current batch's piece 0
+    size_t npieces = 0, next = 0;        // pieces of the current batch; the next one a reader takes
+    size_t copied = 0, failed = 0;       // pieces of the current batch whose copy has completed (in order) / that could not be read or copied
+    size_t retired = 0;                  // ring sequence number below which every slot is free again
     int slot = 0;
     bool stop = false, started = false, active = false;
-    double t0 = 0, tEnd = 0;
+    double t0 = 0, tEnd = 0, tRead = 0;
     std::exception_ptr err;
 
-    void readerLoop(size_t r)
+    void readerLoop()
     {
         std::vector<unsigned char> scratch;
-        uint64_t seen = 0;
-        int b = 0;
         const size_t per = dim * dim;
         for (;;) {
-            size_t piece;
+            size_t piece, seq;
             {
                 std::unique_lock<std::mutex> lk(m);
-                cvWork.wait(lk, [&] { return stop || generation != seen; });
+                cvWork.wait(lk, [&] { return stop || (active && next < npieces); });
                 if (stop) return;
-                if (next >= npieces) { seen = generation; continue; }
                 piece = next++;
-                cvBuf.wait(lk, [&] { return stop || !rd[r].busy[b]; });
+                seq = base + piece;
+                cvSlot.wait(lk, [&] { return stop || seq < retired + R; });       // the slot's previous piece has left
                 if (stop) return;
             }
             const size_t first = piece * pieceImages, count = std::min(pieceImages, locs.size() - first);
+            float *dst = ring + (seq % R) * pieceImages * per;
+            bool ok = true;
             try {
-                for (size_t i = 0; i < count; ++i) StackSource::readFloats(locs[first + i], rd[r].pin[b] + i * per, dim, scratch);
+                for (size_t i = 0; i < count; ++i) StackSource::readFloats(locs[first + i], dst + i * per, dim, scratch);
             } catch (...) {
+                ok = false;
                 std::lock_guard<std::mutex> lk(m);
                 if (!err) err = std::current_exception();
-                ++failed;
-                tEnd = nowSeconds();
-                cvDone.notify_all();
-                continue;
             }
             {
                 std::lock_guard<std::mutex> lk(m);
-                rd[r].busy[b] = true;
-                queue.push_back(CopyJob{r, b, first, count});
+                ready[seq % R] = ok ? 1 : 2;                 // 2: nothing to copy, the slot is passed on as it is
+                tRead = nowSeconds();                        // (the last reader to finish leaves the batch's read-end time)
             }
             cvCopy.notify_one();
-            b ^= 1;
         }
     }
-    void copierLoop(xh_ctx *ctx)
+    // one copy in flight per stream: (stream, ring sequence numbers [from, to) it carries)
+    struct Flight { bool busy = false; size_t from = 0, to = 0, bad = 0; };
+    void retire(Flight &f, int c, bool &broken)
+    {
+        if (!f.busy) return;
+        if (xh_ctx_sync(copyCtx[c]) != XH_OK) broken = true;
+        std::lock_guard<std::mutex> lk(m);
+        if (broken && !err) err = std::make_exception_ptr(XmippError(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error()));
+        const size_t n = f.to - f.from;
+        failed += broken ? n : f.bad;
+        copied += broken ? 0 : n - f.bad;
+        retired = f.to;
+        tEnd = nowSeconds();
+        f.busy = false;
+        cvSlot.notify_all();
+        cvDone.notify_all();
+    }
+    void copierLoop()
     {
         const size_t per = dim * dim;
-        std::vector<CopyJob> jobs;
+        Flight fl[2];
+        size_t nextSeq = 0;               // the next ring sequence number to send
+        int c = 0;
+        bool broken = false;
         for (;;) {
+            size_t from, to, firstImage, bad = 0;
+            int dstSlot;
             {
                 std::unique_lock<std::mutex> lk(m);
-                cvCopy.wait(lk, [&] { return stop || !queue.empty(); });
-                if (stop && queue.empty()) return;
-                // (with another copier at work, take half of what is ready: both streams stay busy)
-                const size_t take = copiers.size() > 1 ? (queue.size() + 1) / 2 : queue.size();
-                jobs.assign(queue.begin(), queue.begin() + take);
-                queue.erase(queue.begin(), queue.begin() + take);
+                // the next piece in order is ready -- or there is a copy in flight to look after meanwhile
+                cvCopy.wait(lk, [&] { return stop || (active && nextSeq < base + npieces && ready[nextSeq % R]) || fl[0].busy || fl[1].busy; });
+                if (stop && !fl[0].busy && !fl[1].busy) return;
+                const bool have = active && nextSeq >= base && nextSeq < base + npieces && ready[nextSeq % R];
+                if (!have) {
+                    lk.unlock();
+                    retire(fl[c], c, broken);              // nothing to send: finish what flies, oldest first (stream c carries the older copy)
+                    retire(fl[c ^ 1], c ^ 1, broken);
+                    continue;
+                }
+                // every consecutive ready piece up to the end of the batch or the wrap of the ring goes in one copy
+                from = nextSeq;
+                to = from;
+                while (to < base + npieces && ready[to % R] && (to == from || to % R != 0)) {
+                    if (ready[to % R] == 2) ++bad;
+                    ready[to % R] = 0;
+                    ++to;
+                }
+                firstImage = (from - base) * pieceImages;
+                dstSlot = slot;
             }
-            bool bad = false;
-            for (const CopyJob &j : jobs)
-                bad = bad || xh_memcpy_h2d_async(ctx, d[slot] + j.first * per, rd[j.reader].pin[j.buf], j.count * per * sizeof(float)) != XH_OK;
-            bad = (xh_ctx_sync(ctx) != XH_OK) || bad;
+            retire(fl[c], c, broken);                       // this stream's previous copy (the other stream's is still flying)
+            const size_t images = std::min((to - base) * pieceImages, locs.size()) - firstImage;
+            if (!broken && bad == 0 &&
+                xh_memcpy_h2d_async(copyCtx[c], d[dstSlot] + firstImage * per, ring + (from % R) * pieceImages * per, images * per * sizeof(float)) != XH_OK)
+                broken = true;
+            fl[c].busy = true; fl[c].from = from; fl[c].to = to; fl[c].bad = bad ? to - from : 0;
+            nextSeq = to;
+            c ^= 1;
             {
-                std::lock_guard<std::mutex> lk(m);
-                for (const CopyJob &j : jobs) rd[j.reader].busy[j.buf] = false;
-                if (bad) { if (!err) err = std::make_exception_ptr(XmippError(ERR_GPU, std::string("xmipp_hip: ") + xh_last_error())); failed += jobs.size(); }
-                else done += jobs.size();
-                tEnd = nowSeconds();
+                // the batch's last run: nothing more will come for a while, finish both flights so that take() returns
+                std::unique_lock<std::mutex> lk(m);
+                const bool last = nextSeq >= base + npieces;
+                lk.unlock();
+                if (last) { retire(fl[c], c, broken); retire(fl[c ^ 1], c ^ 1, broken); }
             }
-            jobs.clear();
-            cvBuf.notify_all();
-            cvDone.notify_all();
         }
     }
 };
