@@ -27,6 +27,9 @@
 #ifndef XH_RF_GRID_H
 #define XH_RF_GRID_H
 
+#ifndef XG_ACC_ATOMIC
+#define XG_ACC_ATOMIC 0         // 1: the unit's sums updated by LDS additions without a return (A/B: tools/build_variant.sh)
+#endif
 #ifndef XG_TAPMASK
 #define XG_TAPMASK 0            // 1: taps beyond the blob switched off with an execution mask instead of a select (A/B: tools/build_variant.sh)
 #endif
@@ -666,7 +669,9 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
                         xg_v2f accRI = {0.f, 0.f};
                         float accW = 0.f;
                         // the voxel's sums so far: requested now, needed at the very end
+#if !XG_ACC_ATOMIC
                         const float oW = sAcc[ai], oR = sAcc[NVOX + ai], oI = sAcc[2 * NVOX + ai];
+#endif
                         if constexpr (W == 4) {
                             // distances to the footprint's columns and rows as the reference forms them, i - (float)j (RFA:663,673)
                             const xg_v2f ix2 = {ixy.x, ixy.x}, iy2 = {ixy.y, ixy.y}, fbx2 = {fbx, fbx}, fby2 = {fby, fby};
@@ -840,9 +845,16 @@ k_rf_grid(const XgRec *__restrict__ recs, const XgCell *__restrict__ pk, const f
                                 }
                             }
                         }
+#if XG_ACC_ATOMIC
+                        // A/B build: three LDS additions without a return instead of three reads, three adds and three writes
+                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(sAcc + ai), accW, 0, 0, false);
+                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(sAcc + NVOX + ai), accRI.x, 0, 0, false);
+                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(sAcc + 2 * NVOX + ai), accRI.y, 0, 0, false);
+#else
                         sAcc[ai] = oW + accW;
                         sAcc[NVOX + ai] = oR + accRI.x;
                         sAcc[2 * NVOX + ai] = oI + accRI.y;
+#endif
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
