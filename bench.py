@@ -70,7 +70,7 @@ def parse(argv=None):
     ap.add_argument("--fa-shared-copy", type=int, default=1, help="flexalign mode: 1 one copy stream for all lanes, 0 one per lane")
     ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
-    ap.add_argument("--refs", default="phantom", choices=["phantom", "noise"],
+    ap.add_argument("--refs", default="phantom", choices=["phantom", "noise", "compact"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
     ap.add_argument("--tr-chunk-mb", type=int, default=0, help="S6 scratch per pass in MB (0: library default)")
     ap.add_argument("--chunk-rows", type=float, default=0, help="correlation rows per chunk of the matcher (0: library default)")
@@ -571,10 +571,11 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region
     dirs = synth.fibonacci_directions(nrefs)
     dirs_dev = torch.from_numpy(np.ascontiguousarray(dirs[:, :2], np.float64)).to(dev)
-    if args.refs == "phantom":
+    if args.refs in ("phantom", "compact"):
         # BASELINE config 2/4: the gallery = projections of the phantom at Fibonacci-sphere directions, made with the
         # library's own central-slice projector (xh_fp_*, the xmipp_angular_project_library path)
-        fpj = xa.FourierProjector(ctx, phantom_volume(torch, D, genr, dev), 2.0, 0.5, 3)
+        # (--refs compact: every blob within 0.3 of the box radius, the nearly rotation-invariant map of the compact_phantom leg)
+        fpj = xa.FourierProjector(ctx, phantom_volume(torch, D, genr, dev, **({"rmax": 9.6} if args.refs == "compact" else {})), 2.0, 0.5, 3)
         refs = fpj.project(np.concatenate([dirs, np.zeros((nrefs, 1))], 1))
         fpj.close()
         refs = ((refs - refs.mean()) / refs.std()).contiguous()
@@ -874,6 +875,7 @@ def main():
             step(False)            # warm-up of the other code path
             finish()
             barrier()
+            pm.stage_ms(reset=True)
             tw0 = time.perf_counter()
             nw = 2
             for _ in range(nw):
@@ -886,6 +888,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = t.item()
             extra["worst_case"] = {"value": nw * B * world / el, "unit": "particles/s", "steps": nw,
+                                   "matcher_stage_ms_per_step": {k_: v_ / nw for k_, v_ in pm.stage_ms(reset=True).items()},
                                    "what": "branch and bound of the row transforms off, contraction over all frequencies: "
                                            "what a gallery and particles with flat correlation peaks would cost"}
             pm.set_option("prune", 1)
@@ -928,6 +931,7 @@ def main():
             step(False, parts_c, pm=pm_c)
             finish()
             barrier()
+            pm_c.stage_ms(reset=True)
             tc0 = time.perf_counter()
             for _ in range(2):
                 step(False, parts_c, pm=pm_c)
@@ -940,6 +944,8 @@ def main():
                 el = t.item()
             extra["compact_phantom"] = {"value": 2 * B * world / el, "unit": "particles/s", "steps": 2,
                                         "rescored_fraction_compact_phantom": pm_c.last_stats()["rescored_particles"] / float(B),
+                                        "matcher_stage_ms_per_step": {k_: v_ / 2 for k_, v_ in pm_c.stage_ms(reset=True).items()},
+                                        "matcher_stats": {k_: v_ for k_, v_ in pm_c.last_stats().items() if not hasattr(v_, "__len__")},
                                         "what": "the same step (resident batch) with the gallery of a compact, nearly rotation-invariant phantom "
                                                 "(blobs within 0.3 of the box radius): flat correlation peaks in the in-plane angle, most particles re-scored in fp64"}
             pm_c.close()

@@ -382,6 +382,60 @@ def test_branch_and_bound_at_full_size(gpu, kind):
     print(kind, "pruned", st["pruned_rows"] / st["rows"], "K0", K0, "of", nk, "rescored particles", st["rescored_particles"])
 
 
+def test_many_surviving_rows_switch_the_next_chunk_to_the_full_contraction(gpu, oracle):
+    """A gallery whose rows mostly survive the bounds (here: a large constant added to every reference) is cheaper contracted at
+    every frequency with the coefficients kept than finished row by row (xh_pm.hip, adaptive_finish): the survivors of one chunk
+    decide the form of the next.  Same indices in either form, equal to the oracle's; a friendly batch switches back."""
+    xa, ctx, torch = gpu
+    D, nrefs, n = 64, 96, 40
+    rng = np.random.default_rng(15)
+    refs, _ = synth.make_refs(synth.phantom(D, seed=2, nblobs=14), nrefs)
+    flat = (refs + 10.0).astype(np.float32)
+    parts, _ = synth.make_particles(flat, n, rng, snr=0.1, max_shift=2)
+    er, ep, ef, _ = oracle.PM(flat).match(parts)
+    pm = xa.ProjectionMatcher(ctx, torch.from_numpy(flat).cuda())
+    dp = torch.from_numpy(parts).cuda()
+    pm.set_option("adaptive_finish", 0)
+    base = [t.cpu().numpy() for t in pm.match(dp)]
+    st = pm.last_stats()
+    assert st["pruned_rows"] < 0.8 * st["rows"], st           # the premise: more than a fifth of the rows survive
+    assert pm.get_option("dense_chunks") == 0
+    pm.set_option("adaptive_finish", 1)
+    pm.set_option("chunk_rows", 10 * nrefs)                    # four chunks of ten particles
+    first = [t.cpu().numpy() for t in pm.match(dp)]
+    assert pm.get_option("dense_chunks") == 3                  # the first chunk found out
+    second = [t.cpu().numpy() for t in pm.match(dp)]
+    assert pm.get_option("dense_chunks") == 4
+    K0, nk = pm.two_level_cut()
+    assert K0 < nk                                             # (the configured cut is what the handle reports, whatever the chunks ran with)
+    for got in (first, second):
+        for a, b, e in zip(got, base, (er[:, 0], ep[:, 0], ef[:, 0])):
+            assert np.array_equal(a, b) and np.array_equal(a, e)
+    # neighbour lists that run over the bank with a mask take the same switch
+    k = 24
+    ids = np.stack([np.sort(rng.choice(nrefs, k, replace=False)) for _ in range(n)]).astype(np.int32)
+    off = (np.arange(n + 1) * k).astype(np.int32)
+    lr, lp, lf, _ = oracle.PM(flat).match(parts, off, ids.ravel())
+    got = [t.cpu().numpy() for t in pm.match(dp, off, ids.ravel())]
+    for a, e in zip(got, (lr[:, 0], lp[:, 0], lf[:, 0])):
+        assert np.array_equal(a, e)
+    # ... and an ordinary gallery switches back after its first chunk
+    pm2 = xa.ProjectionMatcher(ctx, torch.from_numpy(refs).cuda())
+    parts2, _ = synth.make_particles(refs, n, rng, snr=0.1, max_shift=2)
+    dp2 = torch.from_numpy(parts2).cuda()
+    pm2.set_option("adaptive_finish", 2)                       # start in the dense form
+    pm2.set_option("chunk_rows", 10 * nrefs)
+    g2 = [t.cpu().numpy() for t in pm2.match(dp2)]
+    dense2 = pm2.get_option("dense_chunks")
+    st2 = pm2.last_stats()
+    r2, p2, f2, _ = oracle.PM(refs).match(parts2)
+    for a, e in zip(g2, (r2[:, 0], p2[:, 0], f2[:, 0])):
+        assert np.array_equal(a, e)
+    if st2["pruned_rows"] > 0.95 * st2["rows"]:
+        assert dense2 == 1, dense2
+    print("flat gallery pruned", st["pruned_rows"], "of", st["rows"], "; ordinary gallery dense chunks", dense2, "pruned", st2["pruned_rows"], "of", st2["rows"])
+
+
 @pytest.mark.parametrize("D", [512, 24])
 def test_match_extreme_box_sizes(gpu, oracle, D):
     """512 px: N=1602, Bluestein M=4096 (radix-2 LDS S3 kernel), 255 rings, nk=802; 24 px: M=256 (radix-2 too)."""

@@ -146,6 +146,13 @@ struct xh_pm {
     int use_early_exit;          // surviving rows are dropped while their high frequencies are computed, once the bound allows it
     int64_t stat_pruned;
     int lastPruneRows;           // rows of the last chunk that went through k_pm_survivors (0: none)
+    // A map with flat correlation peaks lets a third of the rows through the bounds, and a surviving row that contracts its own
+    // frequencies (d_row_high, 410 KB of operands out of the L2s) costs 60 ns where the matrix cores contract a row for 4.3 ns and the
+    // transform of a stored row takes 13.5: above ~9 % survivors the whole chunk is cheaper contracted at every frequency with its
+    // coefficients kept (the form of rounds 1-4).  The survivors of the chunk before (the host reads that count anyway, S5) decide.
+    int adaptive_finish;         // option: 1 (default) switch as described, 0 never
+    int finish_dense;            // state: the next chunk is contracted in full
+    int stat_dense_chunks;       // chunks of the last call that were
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
     XhBuf d_bT, d_aT, d_kboundsLow;
@@ -3496,6 +3503,9 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->tr_chunk_mb = 0;
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
+    pm->adaptive_finish = 1;
+    pm->finish_dense = 0;
+    pm->stat_dense_chunks = 0;
     pm->use_fir = 1;
     pm->contract_shape = 14;
     pm->store_cut = 0;
@@ -3837,6 +3847,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "early_exit")) pm->use_early_exit = value != 0;
     else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
+    else if (!strcmp(name, "adaptive_finish")) { pm->adaptive_finish = (int)value; pm->finish_dense = value >= 2; }      // (2: start in the dense form)
     else if (!strcmp(name, "threads")) {
         // the program's --thr: which of two EXACTLY equal correlation values is kept follows the reference's split of a neighbour list over
         // its worker threads and the merge of their results (APM:631,1063-1108); nothing else depends on it
@@ -4133,17 +4144,27 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
     // the S2->S3 intermediate is sized for parallelism (thousands of tiles in flight), not thrift: 4 GiB of 288
     // (with the two-level contraction a row only holds the frequencies below K0: far more rows per chunk)
     const bool willPrune = !lists && pm->use_mfma && pm->use_prune && pm->R1 && pm->use_idft3 && n_orient == 1;
-    // (a bank without a band limit stores store_cut coefficients per row, none by default: the whole batch is one chunk)
-    const bool willBoundsOnly = willPrune && pm->K0 >= L.nk && pm->store_cut >= 0 && pm->store_cut < L.nk;
-    const size_t rawStride = willBoundsOnly ? (size_t)std::max(1, pm->store_cut) : willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
-    size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (rawStride * sizeof(float4)));
-    // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
-    if (n_orient > 1) maxRows = std::min<size_t>(maxRows, std::max<size_t>(1024, ((size_t)1 << 30) / (sizeof(CandRes) * n_orient)));
     const size_t maxSlots = n_orient > 1 ? 2048 : 32768;      // grid.y limit of the ring DFT / fp64 footprint
     const float tauAbs = (float)(pm->tau_rel * pm->scale);
     const double tieAbs = pm->tie_rel * pm->scale;
+    // the cut and what is kept, as configured; a chunk in the dense form (pm->finish_dense) replaces them for its own duration
+    struct CutGuard {
+        xh_pm *pm; int K0, store;
+        ~CutGuard() { pm->K0 = K0; pm->store_cut = store; }
+    } cut{pm, pm->K0, pm->store_cut};
+    pm->stat_dense_chunks = 0;
     int p0 = 0;
     while (p0 < n) {
+        const bool denseFinish = willPrune && pm->adaptive_finish && pm->finish_dense && cut.K0 < L.nk;
+        pm->K0 = denseFinish ? L.nk : cut.K0;
+        pm->store_cut = denseFinish ? -1 : cut.store;
+        pm->stat_dense_chunks += denseFinish ? 1 : 0;
+        // (a bank without a band limit stores store_cut coefficients per row, none by default: the whole batch is one chunk)
+        const bool willBoundsOnly = willPrune && pm->K0 >= L.nk && pm->store_cut >= 0 && pm->store_cut < L.nk;
+        const size_t rawStride = willBoundsOnly ? (size_t)std::max(1, pm->store_cut) : willPrune ? (size_t)std::min(pm->K0, L.nk) : (size_t)L.nk;
+        size_t maxRows = pm->chunk_rows ? pm->chunk_rows : std::max<size_t>(1024, ((size_t)4 << 30) / (rawStride * sizeof(float4)));
+        // the exact top-N path keeps an fp64 polar transform per slot and K results per row instead
+        if (n_orient > 1) maxRows = std::min<size_t>(maxRows, std::max<size_t>(1024, ((size_t)1 << 30) / (sizeof(CandRes) * n_orient)));
         // particles of this chunk
         int m = 0;
         size_t rows = 0;
@@ -4268,6 +4289,13 @@ int xh_pm_match_ex(xh_pm *pm, const float *d_particles, int32_t n, const int32_t
         pm->stat_resc_p += counters[0];
         pm->stat_resc_r += counters[1];
         if (pm->lastPruneRows > 0) pm->stat_pruned += pm->lastPruneRows - counters[3];
+        if (pm->lastPruneRows > 0 && nrows > 0) {
+            // the next chunk's form (see adaptive_finish): break-even at 0.09 of the chunk's rows surviving; the full contraction's own
+            // bounds are tighter than the two-level ones, hence two thresholds
+            const double surv = (double)counters[3] / (double)nrows;
+            if (surv > 0.10) pm->finish_dense = 1;
+            else if (surv < 0.06) pm->finish_dense = 0;
+        }
         if (counters[0] > 0) {
             const int na = counters[0], nc = counters[1];
             XH_TRY(run_prep<double>(pm, d_particles + (size_t)p0 * D * D, true, (const int *)pm->d_ambList.p, na, nullptr,
@@ -4552,6 +4580,8 @@ int xh_pm_get_option(const xh_pm *pm, const char *name, double *value)
     XH_CHECK(pm && name && value, XH_ERR_ARG, "xh_pm_get_option: null argument");
     if (!strcmp(name, "tau_rel")) *value = pm->tau_rel;
     else if (!strcmp(name, "s6_eps")) *value = pm->s6_eps;
+    else if (!strcmp(name, "adaptive_finish")) *value = pm->adaptive_finish;
+    else if (!strcmp(name, "dense_chunks")) *value = pm->stat_dense_chunks;      // chunks of the last match call contracted at every frequency
     else { xh_set_error("xh_pm_get_option: unknown option %s", name); return XH_ERR_ARG; }
     return XH_OK;
 }
