@@ -324,6 +324,9 @@ def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kin
     assert 8 <= K0 <= nk
     # the two-level contraction at other cuts (and switched off): same indices
     others = []
+    pm.set_option("group_high", 0)          # the surviving rows finished one by one instead of particle by particle (k_pm_rows_high)
+    others.append([t.cpu().numpy() for t in pm.match(dp)])
+    pm.set_option("group_high", 1)
     for k0 in (8, 20, nk):
         pm.set_option("k0", k0)
         others.append([t.cpu().numpy() for t in pm.match(dp)])

@@ -141,7 +141,8 @@ struct xh_pm {
     int tr_chunk_mb;             // S6: MB of the z buffer per pass (0: default)
     int use_prune;               // S3 branch and bound (k_pm_prune_plan); identical results either way
     int use_mask_lists;          // neighbour-list searches over the whole bank with the off-list references masked (0: gather path)
-    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList, d_rowLow;
+    XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList, d_rowLow, d_survSpan, d_highStore;
+    int group_high;              // the surviving rows' frequencies >= K0 particle by particle (k_pm_rows_high; 0: each transforming wave its own, for A/B)
     int no_mirror;               // option "mirror" 0: the mirrored particle is not searched (rotation estimator)
     int use_early_exit;          // surviving rows are dropped while their high frequencies are computed, once the bound allows it
     int64_t stat_pruned;
@@ -1200,6 +1201,10 @@ struct XhHigh {          // what S3 needs to finish a row the contraction left a
     const float *aT, *bT;        // the per-frequency norms behind that tail: [slot][nk], [nk][nrefs]
     int nk, nrefs;
     int noMirror;                // 1: only the straight particle is a candidate (option "mirror" 0: the rotation estimator)
+    // the frequencies >= K0 of the listed rows where k_pm_rows_high left them: [list position][nk - K0], positions < highCap (null: the
+    // transforming wave contracts them itself, d_row_high)
+    const float4 *highStore;
+    int highCap;
 };
 #ifndef XH_HIGH_RINGS
 #define XH_HIGH_RINGS 8
@@ -1234,6 +1239,129 @@ __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref,
     }
     return acc;
 }
+
+// The frequencies >= K0 of the rows that survived the bounds, a particle at a time.  A wave that finishes its own row (d_row_high)
+// reads the particle's coefficients and the reference's, 2 x 190 KB out of the L2s per row, and a particle's ~6 surviving rows read its
+// coefficients six times; here a workgroup owns a particle, a lane a frequency, and the particle's coefficient of a ring is loaded once for
+// XH_HIGH_ROWS of its rows -- the same multiply-adds in the same (ascending ring) order per row and frequency, so the same bits.  The
+// rows' low frequencies stay where the matrix-core contraction put them; k_pm_idft_max3 picks both up (XhHigh::highStore).
+#ifndef XH_HIGH_ROWS
+#define XH_HIGH_ROWS 8
+#endif
+#ifndef XH_HIGH_WAVES
+#define XH_HIGH_WAVES 3
+#endif
+// one ring's worth of a batch: x = the particle's coefficient, y[u] = the rows' references'
+#define XH_HIGH_STEP(x_, y_)                                    \
+    _Pragma("unroll") for (int u = 0; u < XH_HIGH_ROWS; ++u) {  \
+        acc[u].x = fmaf((x_).x, (y_)[u].x, acc[u].x);           \
+        acc[u].y = fmaf((x_).x, (y_)[u].y, acc[u].y);           \
+        acc[u].z = fmaf((x_).y, (y_)[u].x, acc[u].z);           \
+        acc[u].w = fmaf((x_).y, (y_)[u].y, acc[u].w);           \
+    }
+#ifndef XH_HIGH_UNROLL
+#define XH_HIGH_UNROLL 4
+#endif
+// items[i] = (first list position, rows <= XH_HIGH_ROWS) of one particle (k_pm_survivors), *nitems of them: a workgroup takes one at a
+// time, so that a particle with a hundred surviving rows is spread over thirteen workgroups
+__global__ void __launch_bounds__(64 * XH_HIGH_WAVES)
+k_pm_rows_high(XhHigh H, const int *__restrict__ rowList, const int2 *__restrict__ items, const int *__restrict__ nitems,
+               float4 *__restrict__ out)
+{
+    __shared__ int scoff[1024];
+    for (int i = threadIdx.x; i < H.nrings && i < 1024; i += blockDim.x) scoff[i] = H.coff[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nkHigh = H.nk - H.K0, nchunks = (nkHigh + 63) / 64;
+    const int ni = *nitems;
+    for (int item = blockIdx.x; item < ni; item += gridDim.x) {
+        const int2 it = items[item];
+        const int pos0 = it.x;
+        if (pos0 >= H.highCap) continue;
+        const int ns = min(it.y, H.highCap - pos0);
+        // the rows of the batch: wave-uniform (scalar registers), the lane's frequency comes in through the index alone
+        const xh_cf *a[XH_HIGH_ROWS], *b[XH_HIGH_ROWS];
+        bool same = true;
+#pragma unroll
+        for (int u = 0; u < XH_HIGH_ROWS; ++u) {
+            const int row = __builtin_amdgcn_readfirstlane(rowList[pos0 + (u < ns ? u : 0)]);
+            const int slot = row / H.nq, ref = row - slot * H.nq;
+            a[u] = H.A + (size_t)slot * H.ncoef;
+            b[u] = H.B + (size_t)ref * H.ncoef;
+            same = same && slot == __builtin_amdgcn_readfirstlane(rowList[pos0]) / H.nq;
+        }
+        // 64 frequencies at a time; a wave takes a long chunk (low frequencies: every ring) and then a short one
+        for (int j = 0;; ++j) {
+            const int c = (j & 1) ? (j + 1) * XH_HIGH_WAVES - 1 - wv : j * XH_HIGH_WAVES + wv;
+            if (c >= nchunks) break;
+            const int k = H.K0 + 64 * c + lane;
+            const bool live = k < H.nk;
+            const int rs = live ? H.rstart[k] : H.nrings;
+            // the rings every live frequency of the chunk reaches (r >= rhi), and the few before them that only the lower ones do
+            int rlo = rs, rhi = live ? rs : 0;
+            for (int o = 32; o > 0; o >>= 1) { rlo = min(rlo, __shfl_xor(rlo, o, 64)); rhi = max(rhi, __shfl_xor(rhi, o, 64)); }
+            rlo = __builtin_amdgcn_readfirstlane(rlo); rhi = __builtin_amdgcn_readfirstlane(rhi);
+            float4 acc[XH_HIGH_ROWS];
+#pragma unroll
+            for (int u = 0; u < XH_HIGH_ROWS; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (same && H.nrings <= 1024) {              // (the rows of a particle share its slot unless the search has 5-D translations)
+                for (int r = rlo; r < rhi; ++r) {
+                    const int o = scoff[r] + k;
+                    if (r >= rs) {
+                        const xh_cf x = a[0][o];
+                        xh_cf y[XH_HIGH_ROWS];
+#pragma unroll
+                        for (int u = 0; u < XH_HIGH_ROWS; ++u) y[u] = b[u][o];
+                        XH_HIGH_STEP(x, y)
+                    }
+                }
+                if (live) {
+                    int r = rhi;
+                    for (; r + XH_HIGH_UNROLL <= H.nrings; r += XH_HIGH_UNROLL) {
+                        xh_cf x[XH_HIGH_UNROLL], y[XH_HIGH_UNROLL][XH_HIGH_ROWS];
+#pragma unroll
+                        for (int q = 0; q < XH_HIGH_UNROLL; ++q) {
+                            const int o = scoff[r + q] + k;
+                            x[q] = a[0][o];
+#pragma unroll
+                            for (int u = 0; u < XH_HIGH_ROWS; ++u) y[q][u] = b[u][o];
+                        }
+#pragma unroll
+                        for (int q = 0; q < XH_HIGH_UNROLL; ++q) XH_HIGH_STEP(x[q], y[q])
+                    }
+                    for (; r < H.nrings; ++r) {
+                        const int o = scoff[r] + k;
+                        const xh_cf x = a[0][o];
+                        xh_cf y[XH_HIGH_ROWS];
+#pragma unroll
+                        for (int u = 0; u < XH_HIGH_ROWS; ++u) y[u] = b[u][o];
+                        XH_HIGH_STEP(x, y)
+                    }
+                }
+            } else {
+                for (int r = rlo; r < H.nrings; ++r) {
+                    const int o = H.coff[r] + k;
+                    if (r >= rs) {
+#pragma unroll
+                        for (int u = 0; u < XH_HIGH_ROWS; ++u) {
+                            const xh_cf x = a[u][o], y = b[u][o];
+                            acc[u].x = fmaf(x.x, y.x, acc[u].x);
+                            acc[u].y = fmaf(x.x, y.y, acc[u].y);
+                            acc[u].z = fmaf(x.y, y.x, acc[u].z);
+                            acc[u].w = fmaf(x.y, y.y, acc[u].w);
+                        }
+                    }
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < XH_HIGH_ROWS; ++u)
+                    if (u < ns) out[(size_t)(pos0 + u) * nkHigh + (k - H.K0)] = acc[u];
+            }
+        }
+    }
+}
+#undef XH_HIGH_STEP
 
 template <int R1, int R2, int R3>
 __global__ void __launch_bounds__(256, 2)
@@ -1318,6 +1446,9 @@ k_pm_idft_max3(const float4 *__restrict__ raw, RowRes *__restrict__ res, const x
                     __builtin_amdgcn_wave_barrier();
                     continue;
                 }
+            } else if (H.highStore && it < H.highCap) {
+                const float4 *hs = H.highStore + (size_t)it * (nk - H.K0);
+                for (int k = lane; k < nk; k += 64) sraw[k] = k < H.K0 ? rr[k] : hs[k - H.K0];
             } else
             for (int k = lane; k < nk; k += 64)
                 sraw[k] = k < H.K0 ? rr[k] : (H.zeroHigh ? make_float4(0.f, 0.f, 0.f, 0.f) : d_row_high(H, slot, ref, k));
@@ -1594,7 +1725,8 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
 // for those). Pruned rows get the "no value" result here.
 __global__ void __launch_bounds__(256)
 k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr, int rowsPerParticle, int nrows,
-               RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count)
+               RowRes *__restrict__ res, int *__restrict__ list, int *__restrict__ count, int2 *__restrict__ items, int *__restrict__ nitems,
+               int perItem)
 {
     // block per particle: its survivors are listed next to each other, so the four waves of a transforming workgroup
     // (which take four consecutive list entries) mostly work on one particle and share its coefficient rows in the caches
@@ -1620,7 +1752,14 @@ k_pm_survivors(const float *__restrict__ rowBound, const float *__restrict__ thr
         sc[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 255) sBase = sc[255] ? atomicAdd(count, sc[255]) : 0;
+    if (threadIdx.x == 255) {
+        const int cnt = sc[255];
+        sBase = cnt ? atomicAdd(count, cnt) : 0;
+        if (items && cnt) {                                   // the particle's stretch of the list in pieces of perItem rows (k_pm_rows_high)
+            const int nb = (cnt + perItem - 1) / perItem, ib = atomicAdd(nitems, nb);
+            for (int i = 0; i < nb; ++i) items[ib + i] = make_int2(sBase + i * perItem, min(perItem, cnt - i * perItem));
+        }
+    }
     __syncthreads();
     int o = sBase + sc[threadIdx.x] - c;
     for (int r = r0 + threadIdx.x; r < r0 + rowsPerParticle; r += 256)
@@ -3399,7 +3538,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData, &pm->d_thrLists};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_survSpan, &pm->d_highStore, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData, &pm->d_thrLists};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -3504,6 +3643,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->stat_pruned = 0;
     pm->lastPruneRows = 0;
     pm->adaptive_finish = 1;
+    pm->group_high = 1;
     pm->finish_dense = 0;
     pm->stat_dense_chunks = 0;
     pm->use_fir = 1;
@@ -3847,6 +3987,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "early_exit")) pm->use_early_exit = value != 0;
     else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
+    else if (!strcmp(name, "group_high")) pm->group_high = (int)value;
     else if (!strcmp(name, "adaptive_finish")) { pm->adaptive_finish = (int)value; pm->finish_dense = value >= 2; }      // (2: start in the dense form)
     else if (!strcmp(name, "threads")) {
         // the program's --thr: which of two EXACTLY equal correlation values is kept follows the reference's split of a neighbour list over
@@ -3964,6 +4105,7 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
     H.A = (const xh_cf *)pm->d_A32.p; H.B = (const xh_cf *)pm->d_refsB.p; H.coff = (const int *)pm->d_coff.p;
     H.rstart = (const int *)pm->d_rstart.p; H.nrings = L.nrings; H.ncoef = L.ncoef; H.K0 = boundsOnly ? rawStride : K0; H.nq = nq; H.zeroHigh = 0; H.rawStride = rawStride;
     H.rowLow = nullptr; H.aT = H.bT = nullptr; H.nk = L.nk; H.nrefs = pm->nrefs; H.noMirror = pm->no_mirror;
+    H.highStore = nullptr; H.highCap = 0;
     if (mfma) {
         const int ptiles = (m + 15) / 16, qtiles = (nq + 15) / 16;
         const size_t nvec = (size_t)ptiles * pm->totalQuads * 64;
@@ -4055,12 +4197,35 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             XH_LAUNCH_CHECK();
             // survivors, compacted on the device; d_pruned[1] counts them (the host derives the pruned rows)
             XH_TRY(xh_buf_reserve(ctx, pm->d_survList, sizeof(int) * (size_t)nrows));
+            // the survivors' frequencies >= K0 particle by particle (k_pm_rows_high) unless the early exit wants them one at a time; the
+            // store holds what an ordinary gallery leaves (rows beyond it are finished by the transforming wave, and a gallery that
+            // leaves that many switches its next chunk to the full contraction anyway)
+            const int nkHigh = L.nk - H.K0;
+            const bool grouped = pm->group_high && !earlyExit && nkHigh > 0 && H.nq > 0;
+            const int highCap = grouped ? (int)std::min<size_t>((size_t)nrows, std::max<size_t>(65536, (size_t)nrows / 16)) : 0;
+            int2 *d_items = nullptr;
+            int *d_nitems = nullptr;
+            if (grouped) {
+                // (the items: at most one partly filled piece per particle; their count behind them)
+                const size_t maxItems = (size_t)nrows / XH_HIGH_ROWS + (size_t)nparticles;
+                XH_TRY(xh_buf_reserve(ctx, pm->d_survSpan, sizeof(int2) * (maxItems + 1)));
+                XH_TRY(xh_buf_reserve(ctx, pm->d_highStore, sizeof(float4) * (size_t)highCap * nkHigh));
+                d_items = (int2 *)pm->d_survSpan.p;
+                d_nitems = (int *)(d_items + maxItems);
+                XH_HIP(hipMemsetAsync(d_nitems, 0, sizeof(int), ctx->stream));
+            }
             hipLaunchKernelGGL(k_pm_survivors, dim3(nparticles), dim3(256), 0, ctx->stream, (const float *)pm->d_rowBound.p,
                                (const float *)pm->d_thr.p, nrows / nparticles, nrows, (RowRes *)pm->d_rowres.p, (int *)pm->d_survList.p,
-                               d_pruned + 1);
+                               d_pruned + 1, d_items, d_nitems, XH_HIGH_ROWS);
             XH_LAUNCH_CHECK();
             pm->lastPruneRows = d_mask ? listedRows : nrows;
             nr = nrows; rowList = (const int *)pm->d_survList.p; nrDev = d_pruned + 1;
+            if (grouped) {
+                H.highStore = (const float4 *)pm->d_highStore.p; H.highCap = highCap;
+                hipLaunchKernelGGL(k_pm_rows_high, dim3(std::min(nparticles, ctx->num_cus * 8)), dim3(64 * XH_HIGH_WAVES), 0, ctx->stream, H, rowList,
+                                   (const int2 *)d_items, (const int *)d_nitems, (float4 *)pm->d_highStore.p);
+                XH_LAUNCH_CHECK();
+            }
             if (earlyExit) { thr = (const float *)pm->d_thr.p; rowsPer = nrows / nparticles; H.rowLow = (const float4 *)pm->d_rowLow.p; H.aT = (const float *)pm->d_aT.p; H.bT = (const float *)pm->d_bT.p; H.nk = L.nk; H.nrefs = pm->nrefs; }
         }
         grid = std::max(8, std::min((nr + 3) / 4, ctx->num_cus * 8) / 8 * 8);
