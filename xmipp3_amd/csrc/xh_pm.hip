@@ -156,7 +156,8 @@ struct xh_pm {
     int stat_dense_chunks;       // chunks of the last call that were
     // two-level S2: the MFMA contraction stops at frequency K0 (multiple of 4; K0 == nk: off), see k_pm_tail_norms
     int K0, K0auto, quadsLow;
-    XhBuf d_bT, d_aT, d_kboundsLow;
+    XhBuf d_bT, d_aT, d_kboundsLow, d_bTband;
+    int tail_band;               // k_pm_prune_plan bounds the frequencies >= K0 in bands of XH_TAIL_BAND (1: one by one, for A/B)
     XhBuf d_firTmp, d_polarPart, d_trPart, d_listMask, d_s6Flag, d_s6List, d_s6Parts, d_s6Meta, d_s6Out;
     XhBuf d_qoff, d_Bpack, d_Apack, d_kbounds;
     int totalQuads;
@@ -1618,11 +1619,14 @@ __device__ __forceinline__ int d_row_ref(const RowMap &M, int row, int slot) { r
 #ifndef XH_PRUNE_T
 #define XH_PRUNE_T 4
 #endif
+#ifndef XH_TAIL_BAND
+#define XH_TAIL_BAND 8
+#endif
 __global__ void __launch_bounds__(256)
 k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal, RowMap M, const double *__restrict__ refSigma,
                 const double *__restrict__ stat32, float *__restrict__ rowBound, int *__restrict__ topRows,
                 const float *__restrict__ aT, const float *__restrict__ bT, int K0, int nk, int nrefs, float *__restrict__ rowTail,
-                const unsigned *__restrict__ mask, int maskW, float4 *__restrict__ rowLow)
+                const unsigned *__restrict__ mask, int maskW, float4 *__restrict__ rowLow, const float *__restrict__ bTband, int band)
 {
     __shared__ float sv[256];
     __shared__ int sr[256];
@@ -1632,12 +1636,22 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
     // frequencies the contraction did not compute: Cauchy-Schwarz per frequency (see k_pm_tail_norms); slot by slot,
     // the slot's norms staged in LDS, four rows per thread so that one LDS read feeds four independent FMA chains
     __shared__ float sA[1024];
-    const int nhigh = nk - K0;
+    __shared__ float sAm[1024 / 4];
+    // band > 1: the frequencies from the first multiple of band on are bounded band by band, (largest norm of the particle in the band) x
+    // (sum of the reference's norms over it, bTband [band index][nrefs]) >= the band's sum of products: an eighth of the multiply-adds
+    // for a tail bound a few per cent larger, where the tail is 1e-5 of the bound
+    const int kAl = band > 1 ? min(nk, (K0 + band - 1) / band * band) : nk;
+    const int nhigh = kAl - K0, nbands = band > 1 ? (nk - kAl + band - 1) / band : 0, b0 = band > 1 ? kAl / band : 0;
     for (int it = 0; it < M.nt; ++it) {
         const int slot = p * M.nt + it;
         const int s0 = M.poff[slot], s1 = M.poff[slot + 1];
         __syncthreads();
         for (int k = threadIdx.x; k < nhigh; k += blockDim.x) sA[k] = aT[(size_t)slot * nk + K0 + k];
+        for (int b = threadIdx.x; b < nbands; b += blockDim.x) {
+            float m = 0.f;
+            for (int u = 0; u < band && kAl + b * band + u < nk; ++u) m = fmaxf(m, aT[(size_t)slot * nk + kAl + b * band + u]);
+            sAm[b] = m;
+        }
         __syncthreads();
         for (int base = s0; base < s1; base += 4 * (int)blockDim.x) {
             int rr[4], ref[4];
@@ -1668,6 +1682,28 @@ k_pm_prune_plan(const float2 *__restrict__ bpart, int nslices, size_t nrowsTotal
             for (; k < nhigh; ++k) {
                 const float av = sA[k];
                 const float *bk = bT + (size_t)(K0 + k) * nrefs;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tail[j] = fmaf(av, bk[ref[j]], tail[j]);
+            }
+            int b = 0;
+            for (; b + 4 <= nbands; b += 4) {
+                float bv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *bk = bTband + (size_t)(b0 + b + u) * nrefs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[u][j] = bk[ref[j]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float av = sAm[b + u];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tail[j] = fmaf(av, bv[u][j], tail[j]);
+                }
+            }
+            for (; b < nbands; ++b) {
+                const float av = sAm[b];
+                const float *bk = bTband + (size_t)(b0 + b) * nrefs;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tail[j] = fmaf(av, bk[ref[j]], tail[j]);
             }
@@ -3538,7 +3574,7 @@ static void free_all(xh_pm *pm)
                      &pm->d_chirp, &pm->d_vhat, &pm->d_csN, &pm->d_WD64, &pm->d_coef32, &pm->d_polar32, &pm->d_A32,
                      &pm->d_stat32, &pm->d_coef64, &pm->d_polar64, &pm->d_A64, &pm->d_stat64, &pm->d_raw, &pm->d_rowres,
                      &pm->d_desc, &pm->d_nbr, &pm->d_poff, &pm->d_ambList, &pm->d_ambSlot, &pm->d_candRow, &pm->d_candRes,
-                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_survSpan, &pm->d_highStore, &pm->d_thr, &pm->d_bT, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData, &pm->d_thrLists};
+                     &pm->d_counters, &pm->d_offs5d, &pm->d_bpart, &pm->d_rowBound, &pm->d_rowLow, &pm->d_rowTail, &pm->d_topRows, &pm->d_survList, &pm->d_survSpan, &pm->d_highStore, &pm->d_thr, &pm->d_bT, &pm->d_bTband, &pm->d_aT, &pm->d_kboundsLow, &pm->d_firTmp, &pm->d_firTmp64, &pm->d_polarPart, &pm->d_t1, &pm->d_t2, &pm->d_t3, &pm->d_trAngles, &pm->d_trPart, &pm->d_listMask, &pm->d_s6Flag, &pm->d_s6List, &pm->d_s6Parts, &pm->d_s6Meta, &pm->d_s6Out, &pm->d_cellStart, &pm->d_cellSamples, &pm->d_cellOrg, &pm->d_cellData, &pm->d_thrLists};
     for (XhBuf *b : bufs) xh_buf_free(*b);
     xh_plan_free(pm->planD);
 }
@@ -3644,6 +3680,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->lastPruneRows = 0;
     pm->adaptive_finish = 1;
     pm->group_high = 1;
+    pm->tail_band = XH_TAIL_BAND;
     pm->finish_dense = 0;
     pm->stat_dense_chunks = 0;
     pm->use_fir = 1;
@@ -3937,6 +3974,13 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
                     if (K0 > (int)(0.6 * L.nk)) K0 = L.nk;
                     pm->K0auto = K0;
                     rc = set_k0(pm, K0);
+                    // the norms summed over bands of XH_TAIL_BAND frequencies (k_pm_prune_plan), rounded up
+                    const int nb = (L.nk + XH_TAIL_BAND - 1) / XH_TAIL_BAND;
+                    std::vector<float> bb((size_t)nb * nrefs, 0.f);
+                    for (int k = 0; k < L.nk; ++k)
+                        for (int r = 0; r < nrefs; ++r) bb[(size_t)(k / XH_TAIL_BAND) * nrefs + r] += bT[(size_t)k * nrefs + r];
+                    for (float &v : bb) v *= 1.000002f;
+                    if (rc == XH_OK) rc = upload(ctx, pm->d_bTband, bb);
                 }
             }
         }
@@ -3988,6 +4032,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "group_high")) pm->group_high = (int)value;
+    else if (!strcmp(name, "tail_band")) pm->tail_band = value > 1 ? XH_TAIL_BAND : 1;
     else if (!strcmp(name, "adaptive_finish")) { pm->adaptive_finish = (int)value; pm->finish_dense = value >= 2; }      // (2: start in the dense form)
     else if (!strcmp(name, "threads")) {
         // the program's --thr: which of two EXACTLY equal correlation values is kept follows the reference's split of a neighbour list over
@@ -4182,7 +4227,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             hipLaunchKernelGGL(k_pm_prune_plan, dim3(nparticles), dim3(256), 0, ctx->stream, (const float2 *)pm->d_bpart.p, XH_KSPLIT,
                                (size_t)nrows, *prune, (const double *)pm->d_refSigma.p, (const double *)pm->d_stat32.p,
                                (float *)pm->d_rowBound.p, (int *)pm->d_topRows.p, (const float *)pm->d_aT.p, (const float *)pm->d_bT.p,
-                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p, d_mask, maskW, earlyExit ? (float4 *)pm->d_rowLow.p : (float4 *)nullptr);
+                               K0, L.nk, pm->nrefs, (float *)pm->d_rowTail.p, d_mask, maskW, earlyExit ? (float4 *)pm->d_rowLow.p : (float4 *)nullptr,
+                               (const float *)pm->d_bTband.p, earlyExit ? 1 : pm->tail_band);
             XH_LAUNCH_CHECK();
             nr = nparticles * XH_PRUNE_T;
             rowList = (const int *)pm->d_topRows.p;
