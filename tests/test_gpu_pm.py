@@ -439,6 +439,50 @@ def test_many_surviving_rows_switch_the_next_chunk_to_the_full_contraction(gpu, 
     print("flat gallery pruned", st["pruned_rows"], "of", st["rows"], "; ordinary gallery dense chunks", dense2, "pruned", st2["pruned_rows"], "of", st2["rows"])
 
 
+def test_full_contraction_of_a_flat_peaked_map_at_full_size(gpu, oracle):
+    """BASELINE config 4 shape with the compact phantom (every blob within 0.3 of the box radius: nearly rotation invariant) and particles
+    that are rotated, mirrored and shifted: a large part of the rows survives the bounds.  The chunks contracted at every frequency with
+    their coefficients kept (adaptive_finish 2: from the first chunk on) give the indices of the two-level form, and a sample of them the oracle's."""
+    import math
+    xa, ctx, torch = gpu
+    D, nrefs, n = 256, 1000, 1536
+    g = torch.Generator(device="cuda").manual_seed(21)
+    vol = torch.from_numpy(synth.phantom(D, seed=9, nblobs=20).astype(np.float32)).cuda()
+    fp = xa.FourierProjector(ctx, vol, 2.0, 0.5, 3)
+    dirs = synth.fibonacci_directions(nrefs)
+    refs = fp.project(np.concatenate([dirs, np.zeros((nrefs, 1))], 1))
+    fp.close()
+    refs = ((refs - refs.mean()) / refs.std()).contiguous()
+    idx = torch.randint(0, nrefs, (n,), generator=g, device="cuda")
+    th = torch.rand((n,), generator=g, device="cuda") * (2 * math.pi)
+    mir = (torch.rand((n,), generator=g, device="cuda") < 0.5).float() * 2 - 1
+    rot = torch.zeros((n, 2, 3), device="cuda")
+    rot[:, 0, 0] = torch.cos(th) * mir; rot[:, 0, 1] = -torch.sin(th); rot[:, 1, 0] = torch.sin(th) * mir; rot[:, 1, 1] = torch.cos(th)
+    rot[:, :, 2] = torch.randint(-3, 4, (n, 2), generator=g, device="cuda").float() * (2.0 / D)
+    parts = torch.empty((n, D, D), device="cuda")
+    for b0 in range(0, n, 512):
+        sl = slice(b0, b0 + 512)
+        grid = torch.nn.functional.affine_grid(rot[sl], (rot[sl].shape[0], 1, D, D), align_corners=False)
+        parts[sl] = torch.nn.functional.grid_sample(refs[idx[sl]][:, None], grid, mode="bilinear", padding_mode="zeros", align_corners=False)[:, 0]
+    parts = (parts + math.sqrt(10.0) * torch.randn((n, D, D), generator=g, device="cuda")).contiguous()
+    pm = xa.ProjectionMatcher(ctx, refs)
+    pm.set_option("adaptive_finish", 0)
+    two_level = [t.cpu().numpy() for t in pm.match(parts)]
+    st = pm.last_stats()
+    assert pm.get_option("dense_chunks") == 0
+    pm.set_option("adaptive_finish", 2)
+    full = [t.cpu().numpy() for t in pm.match(parts)]
+    assert pm.get_option("dense_chunks") >= 1
+    for a, b in zip(two_level, full):
+        assert np.array_equal(a, b)
+    m = 24
+    er, ep, ef, _ = oracle.PM(refs.cpu().numpy()).match(parts[:m].cpu().numpy())
+    for a, e in zip(full, (er[:, 0], ep[:, 0], ef[:, 0])):
+        assert np.array_equal(a[:m], e)
+    print("survived the bounds:", 1 - st["pruned_rows"] / st["rows"], "re-scored particles", st["rescored_particles"], "of", n,
+          "; chunks contracted in full:", pm.get_option("dense_chunks"))
+
+
 @pytest.mark.parametrize("D", [512, 24])
 def test_match_extreme_box_sizes(gpu, oracle, D):
     """512 px: N=1602, Bluestein M=4096 (radix-2 LDS S3 kernel), 255 rings, nk=802; 24 px: M=256 (radix-2 too)."""
