@@ -23,6 +23,7 @@ One JSON line on rank 0 (see the driver contract in the task statement), with
   roofline      -- the kernel that dominates the timed region, algorithmic work / HIP-event time
   worst_case    -- the same step with the data-dependent shortcuts of the matcher switched off
   value_streamed -- the same steps + finish with every batch H2D inside the clock
+  match_only_leg -- the matching half alone (xh_pm_match + xh_pm_translate), the rate north_star's 2 M / 8 GPUs is stated for
   noise_gallery / compact_phantom / flexalign -- the data dependence of the headline, and BASELINE config 5
   cpu_baseline  -- the CPU oracle ("port" of the reference algorithm; Xmipp itself cannot be
                    built here: xmippCore/FFTW absent) timed on a bounded sample on rank 0.
@@ -867,6 +868,31 @@ def main():
                                        "matcher_stage_ms_per_step": {k_: v_ / nres for k_, v_ in st1.items()},
                                        "what": "resident batch, reconstruction half behind the matching on the same timeline: what the second stream buys, "
                                                "and the gridding kernel's duration without the other stream's kernels beside it"}
+        # (1c) the matching half alone (rotational search + translational alignment, results copied back): north_star's target is stated
+        # for it -- >= 2 M particles/s projection-matched at 8 GPUs = 250 k per GPU -- while `value` is the whole refine iteration
+        if pm is not None and args.mode == "full":
+            barrier()
+            pm.stage_ms(reset=True)
+            nm = 6
+            outs = None
+            tm0 = time.perf_counter()
+            for _ in range(nm):
+                refno_, psi_, flip_ = pm.match(particles)
+                outs = (refno_, psi_, flip_) + tuple(pm.translate(particles, refno_, psi_, flip_))
+                host_ = [t_.cpu() for t_ in outs]            # every step's results back on the host
+            torch.cuda.synchronize()
+            barrier()
+            el = time.perf_counter() - tm0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            extra["match_only_leg"] = {"value": nm * B * world / el, "unit": "particles/s projection-matched", "steps": nm, "ms_per_step": 1e3 * el / nm,
+                                       "matcher_stage_ms_per_step": {k_: v_ / nm for k_, v_ in pm.stage_ms(reset=True).items()},
+                                       "north_star_target_per_gpu": 250000.0,
+                                       "what": "the same resident batch through xh_pm_match + xh_pm_translate only (no shift, CTF, FFT, gridding): the rate the "
+                                               "north_star's 2 M particles/s at 8 GPUs is stated for; `--mode match` times the same thing as the headline"}
+            del host_, outs
         # (2) the matcher without its data-dependent shortcuts: every correlation row contracted over all frequencies and
         # transformed (S3 branch and bound off, two-level cut off)
         if pm is not None and not args.no_prune:
