@@ -295,9 +295,13 @@ int xh_pm_stage_ms(xh_pm *pm, double *h_ms, int32_t reset);
 int xh_pm_rows_pruned(const xh_pm *pm, int64_t *rows_pruned);
 /* Two-level contraction: the angular frequency K0 at which the MFMA contraction of the dense search stops
  * (the reference bank holds < 1e-5 of its summed coefficient norms above it); rows that survive the branch and
- * bound get their frequencies K0..nk-1 from the wave that transforms them, all others are covered by a
- * Cauchy-Schwarz term in their bound. K0 == nk: the bank is not band limited, everything is contracted.
- * set_option("k0", v) overrides (0 = automatic). Identical results for every K0. */
+ * bound get their frequencies K0..nk-1 afterwards, a particle's rows together (set_option "group_high" 0: each by the wave
+ * that transforms it), all others are covered by a Cauchy-Schwarz term in their bound. K0 == nk: the bank is not band
+ * limited, everything is contracted. set_option("k0", v) overrides (0 = automatic). Identical results for every K0.
+ * A gallery with flat correlation peaks leaves a large part of the rows standing: when more than 10 % of a chunk's rows
+ * survive, the next chunk (of this or of the next call) is contracted at every frequency with its coefficients kept, which
+ * is cheaper from 9 % on; below 6 % it goes back (set_option "adaptive_finish" 0: never; get_option "dense_chunks": how
+ * many chunks of the last call took that form). Identical results either way. */
 int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk);
 /* tuning knobs: fp32 ambiguity margin relative to sum_r 2*pi*r; rows per launch chunk.
  * "threads" n (1..16): the reference program's --thr (angular_projection_matching.cpp:64,631,1018-1108).  Its n worker threads take
@@ -307,7 +311,8 @@ int xh_pm_two_level_cut(const xh_pm *pm, int32_t *K0, int32_t *nk);
  * running top-N (n_orient > 1) as well. */
 int xh_pm_set_option(xh_pm *pm, const char *name, double value);
 /* current value of "tau_rel" (ambiguity margin of the fp32 coarse search, relative to sum_r 2 pi r) or "s6_eps" (margin of the
- * fp32 pass of xh_pm_translate, relative to the maximum of the correlation map): the tests hold the measured fp32 errors against them */
+ * fp32 pass of xh_pm_translate, relative to the maximum of the correlation map): the tests hold the measured fp32 errors against them;
+ * "adaptive_finish", "dense_chunks": see xh_pm_two_level_cut */
 int xh_pm_get_option(const xh_pm *pm, const char *name, double *value);
 
 /* ---- FourierProjector: central-slice projections of a volume ------------------
