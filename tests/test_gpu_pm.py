@@ -327,6 +327,9 @@ def test_branch_and_bound_of_the_row_transforms_changes_nothing(gpu, oracle, kin
     pm.set_option("group_high", 0)          # the surviving rows finished one by one instead of particle by particle (k_pm_rows_high)
     others.append([t.cpu().numpy() for t in pm.match(dp)])
     pm.set_option("group_high", 1)
+    pm.set_option("high_cap", 13)           # ... and with room for thirteen rows in the store: the rest take the other form in the same launch
+    others.append([t.cpu().numpy() for t in pm.match(dp)])
+    pm.set_option("high_cap", 0)
     for k0 in (8, 20, nk):
         pm.set_option("k0", k0)
         others.append([t.cpu().numpy() for t in pm.match(dp)])

@@ -143,6 +143,7 @@ struct xh_pm {
     int use_mask_lists;          // neighbour-list searches over the whole bank with the off-list references masked (0: gather path)
     XhBuf d_bpart, d_rowBound, d_rowTail, d_topRows, d_thr, d_survList, d_rowLow, d_survSpan, d_highStore;
     int group_high;              // the surviving rows' frequencies >= K0 particle by particle (k_pm_rows_high; 0: each transforming wave its own, for A/B)
+    int high_cap;                // rows of the store behind k_pm_rows_high (0: max(65536, rows / 16); the tests set a few to reach the rows beyond it)
     int no_mirror;               // option "mirror" 0: the mirrored particle is not searched (rotation estimator)
     int use_early_exit;          // surviving rows are dropped while their high frequencies are computed, once the bound allows it
     int64_t stat_pruned;
@@ -3680,6 +3681,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->lastPruneRows = 0;
     pm->adaptive_finish = 1;
     pm->group_high = 1;
+    pm->high_cap = 0;
     pm->tail_band = XH_TAIL_BAND;
     pm->finish_dense = 0;
     pm->stat_dense_chunks = 0;
@@ -4032,6 +4034,7 @@ int xh_pm_set_option(xh_pm *pm, const char *name, double value)
     else if (!strcmp(name, "mirror")) pm->no_mirror = value == 0;
     else if (!strcmp(name, "mask_lists")) pm->use_mask_lists = (int)value;
     else if (!strcmp(name, "group_high")) pm->group_high = (int)value;
+    else if (!strcmp(name, "high_cap")) pm->high_cap = (int)value;
     else if (!strcmp(name, "tail_band")) pm->tail_band = value > 1 ? XH_TAIL_BAND : 1;
     else if (!strcmp(name, "adaptive_finish")) { pm->adaptive_finish = (int)value; pm->finish_dense = value >= 2; }      // (2: start in the dense form)
     else if (!strcmp(name, "threads")) {
@@ -4248,7 +4251,8 @@ static int run_rows(xh_pm *pm, int m, const std::vector<int> &poff, const int *d
             // leaves that many switches its next chunk to the full contraction anyway)
             const int nkHigh = L.nk - H.K0;
             const bool grouped = pm->group_high && !earlyExit && nkHigh > 0 && H.nq > 0;
-            const int highCap = grouped ? (int)std::min<size_t>((size_t)nrows, std::max<size_t>(65536, (size_t)nrows / 16)) : 0;
+            const int highCap = !grouped ? 0 : pm->high_cap > 0 ? std::min(nrows, pm->high_cap)
+                                         : (int)std::min<size_t>((size_t)nrows, std::max<size_t>(65536, (size_t)nrows / 16));
             int2 *d_items = nullptr;
             int *d_nitems = nullptr;
             if (grouped) {
