@@ -1074,6 +1074,28 @@ __device__ __forceinline__ float d_fa_b3(float x)
     return 0.f;
 }
 
+#ifndef XH_FA_B3_TAPS
+#define XH_FA_B3_TAPS 1             // d_fa_b3_taps without d_fa_b3's branches (0: d_fa_b3 per weight, A/B)
+#endif
+// The four weights d_fa_b3(t0 - i), i = 0 .. 3, of a position whose taps start one control point / pixel before it: t0 lies in [1, 2],
+// so the arguments fall into (1, 2], (0, 1], (-1, 0], (-2, -1] and each weight's polynomial is known beforehand -- the outer two take
+// the cubic tail, the inner two the central piece (at |x| = 1 the two pieces meet: 1/6 from either, to a rounding).  Same expressions
+// as d_fa_b3, without its two compares and selects per weight (12 -> 4-5 vector instructions; twenty weights per pixel of the warp).
+__device__ __forceinline__ void d_fa_b3_taps(float t0, float (&w)[4])
+{
+#if XH_FA_B3_TAPS
+    float a0 = fabsf(t0) - 2.f, a3 = fabsf(t0 - 3.f) - 2.f;
+    const float a1 = fabsf(t0 - 1.f), a2 = fabsf(t0 - 2.f);
+    w[0] = a0 * a0 * a0 * (-1.f / 6.f);
+    w[1] = a1 * a1 * (a1 - 2.f) * 0.5f + (2.f / 3.f);
+    w[2] = a2 * a2 * (a2 - 2.f) * 0.5f + (2.f / 3.f);
+    w[3] = a3 * a3 * a3 * (-1.f / 6.f);
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = d_fa_b3(t0 - i);
+#endif
+}
+
 // applyLocalShiftGeometryKernelMorePixels<T, 3> (cuda_gpu_geo_transformer.cu:193-254): the shift of every pixel from the control
 // points (getShiftMorePixels: terms of weight <= 1e-4 are dropped), the frame sampled at (x - shiftX, y - shiftY) with mirrored
 // borders (interpolatedElementBSpline2D_Degree3MorePixelsEdge, cuda_gpu_multidim_array.cu:277-334)
@@ -1151,6 +1173,12 @@ __global__ void __launch_bounds__(256) k_fa_warp(const float *__restrict__ coef,
 // wave share the cell almost always: a broadcast) instead of eight ds_read_b32, and the 1e-4 cut multiplies a dropped term by zero
 // instead of branching around it (sx + C * 0 = sx).  Same terms, same order (layer, column, row), same products bY (bX bT).
 #define XH_FA_WARP_RG 8
+#ifndef XH_FA_WARP_INSIDE
+#define XH_FA_WARP_INSIDE 1         // the mirrored-border index loops only in the waves that touch a border (0: in every wave, A/B)
+#endif
+#ifndef XH_FA_WARP_WAVE
+#define XH_FA_WARP_WAVE 1           // the 64 terms of the shift once per wave where its pixels share a control cell (0: per lane always, A/B)
+#endif
 __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__ coef, const float *__restrict__ cX, const float *__restrict__ cY, int lX, int lY, int lT,
                                                        float hX, float hY, float tPos, int Y, int X, float *__restrict__ out, float *__restrict__ sum)
 {
@@ -1177,13 +1205,68 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
     const float xPos = x / hX, yPos = y / hY;
     const int xi = (int)xPos, yi = (int)yPos;                 // first control column / row of the pixel: xB + 1, yB + 1
     float bT[4], bX[4], bY[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { bT[i] = d_fa_b3(tPos - (tB + i)); bX[i] = d_fa_b3(xPos - (xi - 1 + i)); bY[i] = d_fa_b3(yPos - (yi - 1 + i)); }
+    d_fa_b3_taps(tPos - tB, bT);
+    d_fa_b3_taps(xPos - (xi - 1), bX);
+    d_fa_b3_taps(yPos - (yi - 1), bY);
     fa_v2 sxy = fa_v2{0.f, 0.f};
+    const unsigned long long lanesOn = __builtin_amdgcn_read_exec();
+#if XH_FA_WARP_WAVE
+    // A wave is 64 neighbouring pixels of one row: they share the frame's layers, the control row and -- unless a control column ends
+    // inside them -- the control column, i.e. all 64 control points and the products bY bT; only bX differs from lane to lane, and
+    // within a control cell each bX[b] runs monotonically from the first lane to the last.  So the 64 terms are formed ONCE per wave,
+    // a lane a term: a term whose weight passes the 1e-4 cut at both ends of the wave passes it on every lane and goes into the sum
+    // G[b] of its column (sixteen lanes each, added by shuffles); a term that fails at both ends is dropped; the few that change sides
+    // inside the wave are handled lane by lane as before.  A pixel is then sx = sum_b bX[b] G[b] + its share of the mixed terms:
+    // 4 packed multiply-adds instead of 64 compares and 64 multiply-adds.  (Same terms and the same cut on every lane; the sums are
+    // taken in another order and the weight is bX (bY bT) instead of bY (bX bT): rounding, where the parity bound is 2e-4 of the peak.)
+    const int xi0 = __builtin_amdgcn_readfirstlane(xi);
+    const bool waveForm = lanesOn == ~0ull && __builtin_amdgcn_ballot_w64(xi != xi0) == 0ull;
+    if (waveForm) {
+        const int lane = threadIdx.x & 63, tb = lane >> 4, ta = (lane >> 2) & 3, tc = lane & 3;
+        float bmin[4], bmax[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bX[b]), 0));
+            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bX[b]), 63));
+            bmin[b] = fminf(f0, f1); bmax[b] = fmaxf(f0, f1);
+        }
+        const float bTa = ta == 0 ? bT[0] : ta == 1 ? bT[1] : ta == 2 ? bT[2] : bT[3];
+        const float bYc = tc == 0 ? bY[0] : tc == 1 ? bY[1] : tc == 2 ? bY[2] : bY[3];
+        const float lob = tb == 0 ? bmin[0] : tb == 1 ? bmin[1] : tb == 2 ? bmin[2] : bmin[3];
+        const float hib = tb == 0 ? bmax[0] : tb == 1 ? bmax[1] : tb == 2 ? bmax[2] : bmax[3];
+        const float wyt = bYc * bTa;
+        const bool valid = ta < nT;
+        const bool kept = valid && wyt * lob > delta, mixed = valid && !kept && wyt * hib > delta;
+        fa_v2 C = fa_v2{0.f, 0.f};
+        if (valid) {
+            const float *rec = reinterpret_cast<const float *>(sq + 2 * (ta * nq + (yi + tc) * qx + xi0));
+            C = fa_v2{rec[2 * tb], rec[2 * tb + 1]};
+        }
+        float px = kept ? wyt * C.x : 0.f, py = kept ? wyt * C.y : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), 16 * b));
+            const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), 16 * b));
+            sxy.x = __builtin_fmaf(bX[b], gx, sxy.x);
+            sxy.y = __builtin_fmaf(bX[b], gy, sxy.y);
+        }
+        unsigned long long mm = __builtin_amdgcn_ballot_w64(mixed);
+        while (mm) {
+            const int t = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyt), t));
+            const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.x), t));
+            const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.y), t));
+            const int bt = t >> 4;
+            const float tmp = (bt == 0 ? bX[0] : bt == 1 ? bX[1] : bt == 2 ? bX[2] : bX[3]) * w;
+            if (tmp > delta) { sxy.x = __builtin_fmaf(cx, tmp, sxy.x); sxy.y = __builtin_fmaf(cy, tmp, sxy.y); }
+        }
+    } else
+#endif
     // The 1e-4 cut as an execution mask: v_cmpx switches the lanes whose term is dropped off for the one packed multiply-add that follows
     // (compare + select + multiply-add were three vector instructions per term, 192 of a pixel's 540; this is two and a scalar move).
-    const unsigned long long lanesOn = __builtin_amdgcn_read_exec();
-    (void)delta;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (a >= nT) break;
@@ -1213,25 +1296,31 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
     const int xc = (int)ceilf(-sx), yc = (int)ceilf(-sy);
     const float xd = 2.f - (sx + xc), yd = 2.f - (sy + yc);
     const int l1 = x + xc - 2, m1 = y + yc - 2;
-    float wx[4];
+    float wx[4], wy[4];
     int lx[4];
+    d_fa_b3_taps(xd, wx);
+    d_fa_b3_taps(yd, wy);
+    // the mirrored borders concern the waves at the frame's edges: where the sixteen taps of every lane lie inside the frame (one ballot)
+    // the indices are l1 + i, m1 + i as they stand
+    const bool inside = XH_FA_WARP_INSIDE && __builtin_amdgcn_ballot_w64(l1 < 0 || l1 + 3 >= X || m1 < 0 || m1 + 3 >= Y) == 0ull;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int l = l1 + i;
-        wx[i] = d_fa_b3(xd - i);
-        while (l < 0 || l >= X) l = l < 0 ? -l - 1 : 2 * X - l - 1;
+        if (!inside)
+            while (l < 0 || l >= X) l = l < 0 ? -l - 1 : 2 * X - l - 1;
         lx[i] = l;
     }
     float columns = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m1 + i;
-        while (m < 0 || m >= Y) m = m < 0 ? -m - 1 : 2 * Y - m - 1;
+        if (!inside)
+            while (m < 0 || m >= Y) m = m < 0 ? -m - 1 : 2 * Y - m - 1;
         const float *ref = coef + (size_t)m * X;
         float rows = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) rows += ref[lx[j]] * wx[j];
-        columns += rows * d_fa_b3(yd - i);
+        columns += rows * wy[i];
     }
     const size_t o = (size_t)y * X + x;
     if (out) out[o] = columns;
