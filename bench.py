@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument("--fa-opt", action="append", default=[], metavar="NAME=VALUE", help="flexalign mode: xh_fa_set_option on every lane (A/B runs), "
                     "e.g. --fa-opt pruned_columns=0 --fa-opt pairwin_form=0")
     ap.add_argument("--fa-shared-copy", type=int, default=1, help="flexalign mode: 1 one copy stream for all lanes, 0 one per lane")
-    ap.add_argument("--fa-lanes", type=int, default=2, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
+    ap.add_argument("--fa-lanes", type=int, default=4, help="flexalign mode: movies in flight per GPU (each lane: a host thread with its own stream, library "
                     "handle and pair of device buffers; the kernels of one lane fill the device while another lane's host solves its shifts / fits its spline)")
     ap.add_argument("--refs", default="phantom", choices=["phantom", "noise", "compact"],
                     help="reference gallery: projections of a Gaussian-blob phantom (BASELINE config 2/4) or unrelated band-limited noise images")
@@ -1228,11 +1228,11 @@ def cli_leg(D, nrefs, B):
 
 
 def flexalign_leg():
-    """BASELINE config 5 in the default line: `bench.py --mode flexalign` (two K3 movies of int8 counts streamed from page-locked memory, two
+    """BASELINE config 5 in the default line: `bench.py --mode flexalign` (two K3 movies of int8 counts streamed from page-locked memory, four
     in flight) as a CHILD process -- its own runtime, its own contexts; nothing is exec'ed over this process's GPU state -- reduced to the
     figures a reader needs: movies/s and the three stages' times and roofline fractions."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "flexalign", "--steps", "8", "--warmup", "2", "--no-extra-legs"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "flexalign", "--steps", "12", "--warmup", "4", "--no-extra-legs"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -1247,7 +1247,7 @@ def flexalign_leg():
                 "stage_roofline_frac": fr,
                 "global_shift_error_px": d.get("global_shift_error_px"), "global_shift_error_bound_px": d.get("global_shift_error_bound_px"),
                 "parity_sample": d.get("parity_sample"), "cpu_baseline": d.get("cpu_baseline"),
-                "what": "`python bench.py --mode flexalign --steps 8 --warmup 2` run as a child process after the timed region of the refine iteration"}
+                "what": "`python bench.py --mode flexalign --steps 12 --warmup 4` (four movies in flight) run as a child process after the timed region of the refine iteration"}
     except Exception as e:      # the headline must not depend on this leg
         return {"error": repr(e)}
 

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds a variant of the library for A/B measurements on one box (one source file recompiled with extra flags):
 #   bash tools/build_variant.sh <tag> [-DXG_...=...]            ->  xmipp3_amd/libxmipp_hip_<tag>.so   (XMIPP_HIP_LIB selects it)
-#   SRC=xh_pm bash tools/build_variant.sh <tag> [-DXH_...=...]   the matcher instead of the reconstruction
+#   SRC=xh_pm bash tools/build_variant.sh <tag> [-DXH_...=...]   the matcher instead of the reconstruction (SRC=xh_flexalign, ...): ONLY the named
+#   file sees the flags -- a variant of another file built without SRC is the product library under another name
 set -e
 tag=$1; shift
 SRC=${SRC:-xh_rf}

@@ -1262,7 +1262,7 @@ __device__ __forceinline__ float4 d_row_high(const XhHigh &H, int slot, int ref,
         acc[u].w = fmaf((x_).y, (y_)[u].y, acc[u].w);           \
     }
 #ifndef XH_HIGH_UNROLL
-#define XH_HIGH_UNROLL 4
+#define XH_HIGH_UNROLL 2            // rings in flight per lane (1 / 2 / 4: S3 1.90 / 1.91 / 1.95 ms per 4096 x 1000 rows)
 #endif
 // items[i] = (first list position, rows <= XH_HIGH_ROWS) of one particle (k_pm_survivors), *nitems of them: a workgroup takes one at a
 // time, so that a particle with a hundred surviving rows is spread over thirteen workgroups
