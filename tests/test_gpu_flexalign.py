@@ -575,6 +575,31 @@ def test_two_movies_in_flight_on_one_device(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Y,X,cp", [(96, 512, (6, 6, 5)), (130, 448, (5, 4, 4)), (64, 300, (6, 6, 5))])
+def test_warp_with_the_usual_control_grid_against_the_oracle(gpu, oracle, Y, X, cp):
+    """The kernel a 6 x 6 x 5 control grid takes (k_fa_warp_quads) against the oracle's applyBSplineTransform, every frame of a short
+    movie (first and last frames have fewer than four layers).  Rows of 512 and 448 pixels are whole waves, some of which share a
+    control cell -- the 64 terms of the shift are then formed once per wave, the 1e-4 cut decided at the wave's two ends and per
+    lane only for the terms that change sides in between -- and some of which a control column ends in (every lane its own terms);
+    300 pixels leave a partial wave at the end of every row."""
+    xa, ctx, torch = gpu
+    N = 7
+    rng = np.random.default_rng(Y + X)
+    nc = cp[0] * cp[1] * cp[2]
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 8.0)
+    for amp in (6.0, 0.05):                 # shifts of pixels, and shifts small enough that many terms sit near the cut
+        cx, cy = rng.uniform(-amp, amp, nc), rng.uniform(-amp, amp, nc)
+        for n in range(N):
+            frame = rng.standard_normal((Y, X)).astype(np.float32)
+            out = torch.empty((Y, X), device="cuda")
+            total = torch.ones((Y, X), device="cuda")
+            fa.apply_bspline(torch.from_numpy(frame).cuda(), cx, cy, cp, N, n, out=out, total=total)
+            exp = oracle.fa_apply_bspline(frame.astype(np.float64), cx.astype(np.float32), cy.astype(np.float32), cp, N, n)
+            err = np.abs(out.cpu().numpy() - exp).max()
+            assert err <= 2e-4 * (frame.max() - frame.min()), (amp, n, err)
+            assert np.abs(total.cpu().numpy() - 1.0 - exp).max() <= 2e-4 * (frame.max() - frame.min())
+
+
 def test_warp_with_a_large_control_grid_takes_the_plain_kernel(gpu, oracle):
     """the quad form of the warp kernel stages 32 (lX - 3) lY bytes per layer pair in LDS; a control grid whose quads
     exceed 64 KB (here 30 x 30 x 5, as `--controlPoints 30 30 5` would ask for) must fall back to the plain kernel, not fail the

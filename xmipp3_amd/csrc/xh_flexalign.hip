@@ -1236,7 +1236,11 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
         const float hib = tb == 0 ? bmax[0] : tb == 1 ? bmax[1] : tb == 2 ? bmax[2] : bmax[3];
         const float wyt = bYc * bTa;
         const bool valid = ta < nT;
+#ifdef XH_FA_WARP_DEBUG
+        const bool kept = false, mixed = valid && wyt * hib > delta;
+#else
         const bool kept = valid && wyt * lob > delta, mixed = valid && !kept && wyt * hib > delta;
+#endif
         fa_v2 C = fa_v2{0.f, 0.f};
         if (valid) {
             const float *rec = reinterpret_cast<const float *>(sq + 2 * (ta * nq + (yi + tc) * qx + xi0));
@@ -1257,8 +1261,11 @@ __global__ void __launch_bounds__(256) k_fa_warp_quads(const float *__restrict__
             const int t = __builtin_ctzll(mm);
             mm &= mm - 1;
             const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyt), t));
-            const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.x), t));
-            const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.y), t));
+            // (the term's control point comes out of LDS again, a broadcast: two v_readlane of C.x and C.y here were merged by ROCm 7.2's
+            // clang into ONE read of C.x feeding both halves of the packed multiply-add below -- seen in the ISA, and in
+            // tests/test_gpu_flexalign.py::test_warp_with_the_usual_control_grid_against_the_oracle as wrong shifts in y)
+            const float *rt = reinterpret_cast<const float *>(sq + 2 * (((t >> 2) & 3) * nq + (yi + (t & 3)) * qx + xi0)) + 2 * (t >> 4);
+            const float cx = rt[0], cy = rt[1];
             const int bt = t >> 4;
             const float tmp = (bt == 0 ? bX[0] : bt == 1 ? bX[1] : bt == 2 ? bX[2] : bX[3]) * w;
             if (tmp > delta) { sxy.x = __builtin_fmaf(cx, tmp, sxy.x); sxy.y = __builtin_fmaf(cy, tmp, sxy.y); }
