@@ -600,6 +600,26 @@ def test_warp_with_the_usual_control_grid_against_the_oracle(gpu, oracle, Y, X, 
             assert np.abs(total.cpu().numpy() - 1.0 - exp).max() <= 2e-4 * (frame.max() - frame.min())
 
 
+def test_warp_of_a_k3_frame_against_the_oracle(gpu, oracle):
+    """BASELINE config 5's own shape: one 4092 x 5760 frame of a 40-frame movie under a 6 x 6 x 5 control grid with shifts of a few
+    pixels, against the oracle's applyBSplineTransform (every wave of the kernel shares a control cell here: 5760 / 3 = 1920 = 30 x 64)."""
+    xa, ctx, torch = gpu
+    Y, X, N, cp = 4092, 5760, 40, (6, 6, 5)
+    rng = np.random.default_rng(40)
+    nc = cp[0] * cp[1] * cp[2]
+    cx, cy = rng.uniform(-5, 5, nc), rng.uniform(-5, 5, nc)
+    fa = xa.FlexAlign(ctx, Y, X, 1.0, 30.0)
+    frame = rng.standard_normal((Y, X)).astype(np.float32)
+    d = torch.from_numpy(frame).cuda()
+    for n in (0, 17):
+        out = torch.empty((Y, X), device="cuda")
+        fa.apply_bspline(d, cx, cy, cp, N, n, out=out)
+        exp = oracle.fa_apply_bspline(frame.astype(np.float64), cx.astype(np.float32), cy.astype(np.float32), cp, N, n)
+        err = np.abs(out.cpu().numpy() - exp).max()
+        print("frame", n, "max difference", err)
+        assert err <= 2e-4 * (frame.max() - frame.min()), (n, err)
+
+
 def test_warp_with_a_large_control_grid_takes_the_plain_kernel(gpu, oracle):
     """the quad form of the warp kernel stages 32 (lX - 3) lY bytes per layer pair in LDS; a control grid whose quads
     exceed 64 KB (here 30 x 30 x 5, as `--controlPoints 30 30 5` would ask for) must fall back to the plain kernel, not fail the
