@@ -3670,7 +3670,7 @@ int xh_pm_create(xh_ctx *ctx, int32_t D, int32_t Ri, int32_t Ro, int32_t nrefs, 
     pm->s6_captured = 0;
     pm->s6_capturedN = 0;
     pm->s6_fp32 = 1;
-    pm->s6_eps = 2e-5;
+    pm->s6_eps = 6.4e-6;      // twenty times the measured error of the fp32 map (3.2e-7 of its maximum at 256 px: tests/test_gpu_pm.py)
     pm->s6_flagged = 0;
     pm->use_prune = 1;
     pm->no_mirror = 0;
@@ -4546,7 +4546,8 @@ int xh_pm_match(xh_pm *pm, const float *d_particles, int32_t n, const int32_t *h
 // grows (the first ring with an element below max / 1.414). The coarse pass runs the whole chain in fp32 (half the bytes,
 // half the LDS per line) and measures how close either decision comes to flipping; a particle whose runner-up lies within
 // eps |max| of the maximum, or which has a window element within eps |max| of the threshold, is repeated in double
-// precision (s6_eps, default 2e-5: twenty times the rounding of the fp32 map; 5 % of the bench's particles). Everyone else
+// precision (s6_eps, default 6.4e-6: twenty times the measured error of the fp32 map, 3.2e-7 of its maximum -- rounds 3-5 ran with 2e-5
+// on an assumed 1e-6 --; 1.7 % of the bench's particles, 5.7 % before). Everyone else
 // keeps shifts that differ from the double-precision ones by the rounding of an fp32 sum (1e-5 px against the tolerance of
 // 1e-3 px the tests hold the fp64 path to).
 __global__ void k_pm_s6_list(const unsigned char *__restrict__ flag, int m, int *__restrict__ list, int *__restrict__ count)
